@@ -1,0 +1,360 @@
+"""ORACLE - TEST INFRASTRUCTURE ONLY.  Never imported by the product path (`ladiff_amd/`).
+
+CPU restatement, in plain PyTorch (fp32 by default, fp64 on request), of the LADiff sampling
+hot path: DDIM/DDPM reverse loop with classifier-free guidance over the length-aware
+denoiser, then the LA-VAE decoder.  Only `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` may import this module, and only as the checker / the
+timed CPU baseline.
+
+Parity status
+-------------
+* Denoiser forward (rows A5-A14 of SURVEY.md §8a) and VAE decode (A15-A18) are PINNED:
+  `tests/golden/make_golden.py` imports the reference modules from /root/reference in the
+  build container, runs them on seeded inputs, and commits the input/output vectors under
+  `tests/golden/*.npz`; `tests/test_oracle_golden.py` checks this file against them (<=2e-5).
+* The sampling loop (A2, A4) is pinned the same way with the *reference* denoiser / VAE
+  modules driven by the loop below.
+* The schedulers (A3) are PARITY UNPINNED: `diffusers` is not vendored in the reference, is not
+  version-pinned (`src/requirements.txt:23`) and is not installed here.  The formulas below restate
+  diffusers' published DDIM/DDPM `step()` semantics for the options the reference sets in
+  `src/configs/modules/scheduler.yaml:5-14` and `modules_novae/scheduler.yaml:16-29`; only
+  known-answer properties (timestep lists, alpha endpoints) are checked.
+
+Everything is written batch-first ([B, T, D]); the reference is sequence-first, which only
+changes strides, not arithmetic.  Each function cites the reference lines it follows.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+EPS_LN = 1e-5
+NUM_HEADS = 4
+
+
+# --------------------------------------------------------------------------- helpers
+def block_names(num_layers=9):
+    nb = (num_layers - 1) // 2
+    return ([f"input_blocks.{i}" for i in range(nb)] + ["middle_block"] +
+            [f"output_blocks.{i}" for i in range(nb)])
+
+
+def sub(sd, prefix):
+    """View of a state dict under `prefix.`"""
+    p = prefix + "."
+    return {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+
+
+def cast(sd, dtype):
+    return {k: v.to(dtype) for k, v in sd.items()}
+
+
+def linear(x, w, b=None):
+    return F.linear(x, w, b)
+
+
+def layer_norm(x, w, b):
+    return F.layer_norm(x, (x.shape[-1],), w, b, EPS_LN)
+
+
+def max_iter_elements(lengths, frame_per_latent=48):
+    """ladiff.py:379 / ladiff_vae.py:292: ceil(len / FRAME_PER_LATENT)."""
+    return [int(math.ceil(l / frame_per_latent)) for l in lengths]
+
+
+def lengths_to_mask(lengths, max_len=None):
+    """utils/temos_utils.py:10-17.  True = frame is real."""
+    lengths = torch.as_tensor(lengths)
+    max_len = int(max_len if max_len else lengths.max())
+    return torch.arange(max_len)[None, :] < lengths[:, None]
+
+
+def count_mask(counts, n):
+    """ladiff_denoiser.py:164-171 / ladiff_vae.py:152-159.  True = latent row is real."""
+    counts = torch.as_tensor(counts)
+    return torch.arange(n)[None, :] < counts[:, None]
+
+
+def mha(q_in, k_in, v_in, p, key_padding_mask=None, num_heads=NUM_HEADS):
+    """torch.nn.MultiheadAttention forward (eval), batch-first.
+
+    q_in [B,Lq,D], k_in/v_in [B,Lk,D]; key_padding_mask [B,Lk] True = ignore.
+    Packed in_proj = [Wq;Wk;Wv], scale 1/sqrt(dh) on q, -inf masking,
+    softmax over keys, out_proj.
+    """
+    d = q_in.shape[-1]
+    dh = d // num_heads
+    w, b = p["in_proj_weight"], p["in_proj_bias"]
+    q = linear(q_in, w[:d], b[:d])
+    k = linear(k_in, w[d:2 * d], b[d:2 * d])
+    v = linear(v_in, w[2 * d:], b[2 * d:])
+    B, Lq, _ = q.shape
+    Lk = k.shape[1]
+    q = q.view(B, Lq, num_heads, dh).transpose(1, 2) * (1.0 / math.sqrt(dh))
+    k = k.view(B, Lk, num_heads, dh).transpose(1, 2)
+    v = v.view(B, Lk, num_heads, dh).transpose(1, 2)
+    s = q @ k.transpose(-1, -2)                                  # [B,H,Lq,Lk]
+    if key_padding_mask is not None:
+        s = s.masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
+    a = torch.softmax(s, dim=-1)
+    o = (a @ v).transpose(1, 2).reshape(B, Lq, d)
+    return linear(o, p["out_proj.weight"], p["out_proj.bias"])
+
+
+# --------------------------------------------------------------------------- denoiser
+def timestep_sinusoid(t, dim=768, max_period=10000.0):
+    """tools/embeddings.py:245-285 with flip_sin_to_cos=True, freq_shift=0 -> [cos | sin]."""
+    half = dim // 2
+    expo = -math.log(max_period) * torch.arange(half, dtype=torch.float32) / (half - 0)
+    arg = t.reshape(-1, 1).to(torch.float32) * torch.exp(expo)[None, :]
+    return torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1)
+
+
+def time_embedding(sd, t, dtype=torch.float32):
+    """Timesteps + TimestepEmbedding (tools/embeddings.py:288-322): Linear, SiLU, Linear."""
+    e = timestep_sinusoid(t).to(dtype)
+    h = F.silu(linear(e, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"]))
+    return linear(h, sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
+
+
+def stylization(h, emb, p):
+    """StylizationBlock.forward (mdiff_transformer.py:152-163). h [B,T,D], emb [B,D]."""
+    e = linear(F.silu(emb), p["emb_layers.1.weight"], p["emb_layers.1.bias"])[:, None, :]
+    scale, shift = torch.chunk(e, 2, dim=2)
+    h = layer_norm(h, p["norm.weight"], p["norm.bias"]) * (1 + scale) + shift
+    return linear(F.silu(h), p["out_layers.2.weight"], p["out_layers.2.bias"])
+
+
+def sa_block(seq, p, key_padding_mask):
+    """mdiff_transformer.TransformerEncoderLayer.forward_post (:54-67), relu feed-forward."""
+    a = mha(seq, seq, seq, sub(p, "self_attn"), key_padding_mask)
+    seq = layer_norm(seq + a, p["norm1.weight"], p["norm1.bias"])
+    f = linear(F.relu(linear(seq, p["linear1.weight"], p["linear1.bias"])),
+               p["linear2.weight"], p["linear2.bias"])
+    return layer_norm(seq + f, p["norm2.weight"], p["norm2.bias"])
+
+
+def linear_cross_attention(x, xf, emb, p, pad_mask, num_heads=NUM_HEADS):
+    """LinearTemporalCrossAttention.forward (mdiff_transformer.py:219-247).
+
+    x [B,T,D] latents, xf [B,N,D] text tokens, emb [B,D] time, pad_mask [B,T] True = padded row.
+    """
+    B, T, D = x.shape
+    N = xf.shape[1]
+    H = num_heads
+    q = linear(layer_norm(x, p["norm.weight"], p["norm.bias"]), p["query.weight"], p["query.bias"])
+    xn = layer_norm(xf, p["text_norm.weight"], p["text_norm.bias"])
+    k = linear(xn, p["key.weight"], p["key.bias"])
+    v = linear(xn, p["value.weight"], p["value.bias"]).view(B, N, H, -1)
+    q = torch.softmax(q.view(B, T, H, -1), dim=-1)
+    k = torch.softmax(k.view(B, N, H, -1), dim=1)
+    att = torch.einsum("bnhd,bnhl->bhdl", k, v)
+    if pad_mask is not None:
+        q = q * (~pad_mask).to(q.dtype)[:, :, None, None]       # :224-225, :242-243
+    y = torch.einsum("bnhd,bhdl->bnhl", q, att).reshape(B, T, D)
+    return x + stylization(y, emb, sub(p, "proj_out"))
+
+
+def ffn_block(x, emb, p):
+    """FFN.forward (mdiff_transformer.py:259-262): GELU(erf) MLP then StylizationBlock, residual."""
+    y = linear(F.gelu(linear(x, p["linear1.weight"], p["linear1.bias"])),
+               p["linear2.weight"], p["linear2.bias"])
+    return x + stylization(y, emb, sub(p, "proj_out"))
+
+
+def denoiser_layer(x, xf, emb, p, pad_mask):
+    """LinearTemporalDiffusionTransformerDecoderLayer.forward (mdiff_transformer.py:294-321)."""
+    B, T, _ = x.shape
+    seq = torch.cat([x, xf, emb[:, None, :]], dim=1)            # [B,T+N+1,D]  :308-311
+    kpm = None
+    if pad_mask is not None:
+        kpm = torch.cat([pad_mask, torch.zeros(B, seq.shape[1] - T, dtype=torch.bool)], dim=1)
+    x = sa_block(seq, sub(p, "sa_block"), kpm)[:, :T]           # :312-313
+    x = linear_cross_attention(x, xf, emb, sub(p, "ca_block"), pad_mask)
+    return ffn_block(x, emb, sub(p, "ffn"))
+
+
+def skip_encoder(x, xf, emb, p, pad_mask, num_layers=9):
+    """SkipTransformerEncoder.forward, MD_trans branch (cross_attention.py:69-85)."""
+    nb = (num_layers - 1) // 2
+    xs = []
+    for i in range(nb):
+        x = denoiser_layer(x, xf, emb, sub(p, f"input_blocks.{i}"), pad_mask)
+        xs.append(x)
+    x = denoiser_layer(x, xf, emb, sub(p, "middle_block"), pad_mask)
+    for i in range(nb):
+        x = torch.cat([x, xs.pop()], dim=-1)
+        x = linear(x, p[f"linear_blocks.{i}.weight"], p[f"linear_blocks.{i}.bias"])
+        x = denoiser_layer(x, xf, emb, sub(p, f"output_blocks.{i}"), pad_mask)
+    return layer_norm(x, p["norm.weight"], p["norm.bias"])
+
+
+def denoiser_forward(sd, sample, timestep, encoder_hidden_states, max_iter_elems=None,
+                     num_layers=9):
+    """LADiffDenoiser.forward, text / trans_enc / MD_TRANS branch (ladiff_denoiser.py:153-295).
+
+    sample [B2,T,D]; timestep scalar; encoder_hidden_states [B2,N,E]; max_iter_elems [B2] or None.
+    Returns [B2,T,D] (the reference returns it wrapped in a 1-tuple).
+    """
+    dtype = sample.dtype
+    B, T, D = sample.shape
+    pad_mask = None
+    if max_iter_elems is not None:
+        pad_mask = ~count_mask(max_iter_elems, T)                # :164-171, :254
+    t = torch.as_tensor(timestep).reshape(1).expand(B)           # :184
+    emb = time_embedding(sd, t, dtype)                           # [B,D]  :185-188
+    xf = linear(F.relu(encoder_hidden_states), sd["emb_proj.1.weight"], sd["emb_proj.1.bias"])  # :198
+    x = sample + sd["query_pos.pe"][:T, 0][None]                 # :251, position_encoding.py:158
+    return skip_encoder(x, xf, emb, sub(sd, "encoder"), pad_mask, num_layers)
+
+
+# --------------------------------------------------------------------------- LA-VAE decoder
+def decoder_layer(tgt, memory, p, tgt_pad, mem_pad):
+    """cross_attention.TransformerDecoderLayer.forward_post (:358-413), gelu feed-forward."""
+    a = mha(tgt, tgt, tgt, sub(p, "self_attn"), tgt_pad)
+    tgt = layer_norm(tgt + a, p["norm1.weight"], p["norm1.bias"])
+    c = mha(tgt, memory, memory, sub(p, "multihead_attn"), mem_pad)
+    tgt = layer_norm(tgt + c, p["norm2.weight"], p["norm2.bias"])
+    f = linear(F.gelu(linear(tgt, p["linear1.weight"], p["linear1.bias"])),
+               p["linear2.weight"], p["linear2.bias"])
+    return layer_norm(tgt + f, p["norm3.weight"], p["norm3.bias"])
+
+
+def skip_decoder(x, memory, p, tgt_pad, mem_pad, num_layers=9):
+    """SkipTransformerDecoder.forward (cross_attention.py:113-153)."""
+    nb = (num_layers - 1) // 2
+    xs = []
+    for i in range(nb):
+        x = decoder_layer(x, memory, sub(p, f"input_blocks.{i}"), tgt_pad, mem_pad)
+        xs.append(x)
+    x = decoder_layer(x, memory, sub(p, "middle_block"), tgt_pad, mem_pad)
+    for i in range(nb):
+        x = torch.cat([x, xs.pop()], dim=-1)
+        x = linear(x, p[f"linear_blocks.{i}.weight"], p[f"linear_blocks.{i}.bias"])
+        x = decoder_layer(x, memory, sub(p, f"output_blocks.{i}"), tgt_pad, mem_pad)
+    return layer_norm(x, p["norm.weight"], p["norm.bias"])
+
+
+def vae_decode(sd, z, lengths, frame_per_latent=48, num_layers=9, latent_counts=None):
+    """LADiffVae.decode, encoder_decoder / mld-PE branch (ladiff_vae.py:288-362).
+
+    z [max_it,B,D] (sequence-first, as the reference passes it), lengths list -> [B,max(len),C].
+    `latent_counts` overrides ceil(len/48) (used for latentwise_gen="fw", :295).
+    """
+    dtype = z.dtype
+    mask = lengths_to_mask(lengths)                              # [B,F]
+    counts = max_iter_elements(lengths, frame_per_latent) if latent_counts is None else latent_counts
+    B, Fr = mask.shape
+    mem = z.permute(1, 0, 2)                                     # [B,max_it,D]
+    mem_pad = ~count_mask(counts, mem.shape[1])
+    q = torch.zeros(B, Fr, z.shape[-1], dtype=dtype) + sd["query_pos_decoder.pe"][:Fr, 0][None]  # :299,:334
+    out = skip_decoder(q, mem, sub(sd, "decoder"), ~mask, mem_pad, num_layers)
+    out = linear(out, sd["final_layer.weight"], sd["final_layer.bias"])   # :356
+    out = out * mask[:, :, None].to(dtype)                       # :358
+    return out
+
+
+# --------------------------------------------------------------------------- schedulers (A3, restated; parity unpinned)
+class _SchedulerBase:
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012):
+        self.num_train_timesteps = num_train_timesteps
+        self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps,
+                                    dtype=torch.float32) ** 2    # 'scaled_linear'
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.init_noise_sigma = 1.0
+        self.timesteps = None
+
+
+class DDIM(_SchedulerBase):
+    """diffusers.DDIMScheduler with clip_sample=False, set_alpha_to_one=False, steps_offset=1."""
+
+    def __init__(self, steps_offset=1, **kw):
+        super().__init__(**kw)
+        self.steps_offset = steps_offset
+        self.final_alpha_cumprod = self.alphas_cumprod[0]        # set_alpha_to_one: false
+
+    def set_timesteps(self, n):
+        self.num_inference_steps = n
+        ratio = self.num_train_timesteps // n
+        self.timesteps = torch.arange(n - 1, -1, -1, dtype=torch.int64) * ratio + self.steps_offset
+
+    def step(self, eps, t, x, eta=0.0, noise=None):
+        t = int(t)
+        prev = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t].to(x.dtype)
+        a_p = (self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod).to(x.dtype)
+        x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
+        var = (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
+        sigma = eta * var ** 0.5
+        direction = (1 - a_p - sigma ** 2) ** 0.5 * eps
+        out = a_p ** 0.5 * x0 + direction
+        if eta > 0:
+            out = out + sigma * noise
+        return out
+
+
+class DDPM(_SchedulerBase):
+    """diffusers.DDPMScheduler, variance_type fixed_small, clip_sample False."""
+
+    def set_timesteps(self, n):
+        n = min(self.num_train_timesteps, n)
+        self.num_inference_steps = n
+        self.timesteps = torch.arange(0, self.num_train_timesteps, self.num_train_timesteps // n,
+                                      dtype=torch.int64).flip(0)
+
+    def step(self, eps, t, x, noise=None):
+        t = int(t)
+        a_t = self.alphas_cumprod[t].to(x.dtype)
+        a_p = (self.alphas_cumprod[t - 1] if t > 0 else torch.tensor(1.0)).to(x.dtype)
+        b_t = self.betas[t].to(x.dtype)
+        x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
+        out = (a_p ** 0.5 * b_t / (1 - a_t)) * x0 + ((1 - b_t) ** 0.5 * (1 - a_p) / (1 - a_t)) * x
+        if t > 0:
+            var = torch.clamp((1 - a_p) / (1 - a_t) * b_t, min=1e-20)
+            out = out + var ** 0.5 * noise
+        return out
+
+
+# --------------------------------------------------------------------------- sampling loop (A2, A4)
+def diffusion_reverse(denoise_fn, scheduler, text_emb, lengths, init_noise, n_steps,
+                      guidance_scale=7.5, eta=0.0, step_noise=None, frame_per_latent=48):
+    """LADIFF._diffusion_reverse, live branch (ladiff.py:379-390, 407-417, 470-500, 562-566).
+
+    denoise_fn(sample[2B,T,D], t, text[2B,N,E], counts[2B]) -> eps[2B,T,D]
+    text_emb [2B,N,E] with the unconditional half FIRST (ladiff.py:258-264);
+    init_noise [B,T,D] stands in for torch.randn (:380-385); padded rows are zeroed here (:389-390).
+    step_noise [n_steps,B,T,D] feeds DDPM / eta>0 variance noise.  Returns [T,B,D].
+    """
+    counts = max_iter_elements(lengths, frame_per_latent)
+    B, T, _ = init_noise.shape
+    valid = count_mask(counts, T)
+    latents = init_noise * valid[:, :, None].to(init_noise.dtype)
+    latents = latents * scheduler.init_noise_sigma
+    scheduler.set_timesteps(n_steps)
+    counts2 = torch.tensor(counts + counts)
+    for i, t in enumerate(scheduler.timesteps):
+        model_in = torch.cat([latents, latents], dim=0)
+        eps = denoise_fn(model_in, t, text_emb, counts2)
+        eps_u, eps_c = eps.chunk(2)
+        eps = eps_u + guidance_scale * (eps_c - eps_u)
+        nz = None if step_noise is None else step_noise[i]
+        if isinstance(scheduler, DDIM):
+            latents = scheduler.step(eps, t, latents, eta=eta, noise=nz)
+        else:
+            latents = scheduler.step(eps, t, latents, noise=nz)
+    latents = latents.permute(1, 0, 2).clone()                   # :500
+    latents = latents * valid.t()[:, :, None].to(latents.dtype)  # :562-566
+    return latents
+
+
+def sample_motions(den_sd, vae_sd, text_emb, lengths, init_noise, n_steps=50, scheduler="ddim",
+                   guidance_scale=7.5, eta=0.0, step_noise=None, dtype=torch.float32):
+    """Whole hot path: _diffusion_reverse + vae.decode (ladiff.py:266, :283). -> (z[T,B,D], feats[B,F,C])."""
+    den_sd, vae_sd = cast(den_sd, dtype), cast(vae_sd, dtype)
+    sch = DDIM() if scheduler == "ddim" else DDPM()
+    fn = lambda x, t, txt, counts: denoiser_forward(den_sd, x, t, txt, counts)
+    z = diffusion_reverse(fn, sch, text_emb.to(dtype), lengths, init_noise.to(dtype), n_steps,
+                          guidance_scale, eta, None if step_noise is None else step_noise.to(dtype))
+    feats = vae_decode(vae_sd, z, lengths)
+    return z, feats

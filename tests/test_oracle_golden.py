@@ -1,0 +1,88 @@
+"""Pins oracle/ladiff_oracle.py against vectors captured from the reference (tests/golden/make_golden.py)."""
+import json
+import os
+
+import pytest
+import torch
+
+from ladiff_amd import synthetic as syn
+from oracle import ladiff_oracle as orc
+
+from conftest import GOLDEN, load_golden
+
+TOL = 2e-5   # fp32 CPU restatement vs fp32 CPU reference: same math, different op order
+
+
+def maxdiff(a, b):
+    return (a.double() - b.double()).abs().max().item()
+
+
+@pytest.fixture(scope="module")
+def den_sd():
+    return syn.denoiser_weights()
+
+
+def test_weight_generator_is_stable():
+    want = json.load(open(os.path.join(GOLDEN, "weights.sha256.json")))
+    assert syn.state_dict_sha256(syn.denoiser_weights()) == want["denoiser_seed1234"]
+    assert syn.state_dict_sha256(syn.vae_weights(263)) == want["vae263_seed1235"]
+    assert syn.state_dict_sha256(syn.vae_weights(251)) == want["vae251_seed1235"]
+
+
+def test_timestep_sinusoid():
+    g = load_golden("timestep_embedding")
+    assert maxdiff(orc.timestep_sinusoid(g["t"]), g["out"]) < 1e-6
+
+
+def test_cross_attention_general_n(den_sd):
+    g = load_golden("cross_attention_n4")
+    p = orc.sub(den_sd, "encoder.input_blocks.0.ca_block")
+    out = orc.linear_cross_attention(g["x"], g["xf"], g["emb"], p, g["pad"])
+    assert maxdiff(out, g["out"]) < TOL
+
+
+@pytest.mark.parametrize("t", [981, 1])
+def test_denoiser_forward(den_sd, t):
+    g = load_golden(f"denoiser_forward_t{t}")
+    eps = orc.denoiser_forward(den_sd, g["sample"], g["t"], g["text"], g["counts"])
+    assert maxdiff(eps, g["eps"]) < TOL
+
+
+@pytest.mark.parametrize("name,nfeats", [("vae_decode_c1", 263), ("vae_decode_mixed_kit", 251),
+                                         ("vae_decode_ragged", 263)])
+def test_vae_decode(name, nfeats):
+    g = load_golden(name)
+    feats = orc.vae_decode(syn.vae_weights(nfeats), g["z"], g["lengths"].tolist())
+    assert feats.shape == g["feats"].shape
+    assert maxdiff(feats, g["feats"]) < TOL
+
+
+@pytest.mark.parametrize("tag,sched", [("ddim5", "ddim"), ("ddim50", "ddim"), ("ddpm10", "ddpm")])
+def test_sampling_loop(den_sd, tag, sched):
+    g = load_golden(f"loop_{tag}")
+    z, feats = orc.sample_motions(den_sd, syn.vae_weights(263), g["text"], g["lengths"].tolist(),
+                                  g["init_noise"], int(g["n_steps"]), sched,
+                                  step_noise=g.get("step_noise"))
+    # 50 guided steps on random-init weights amplify rounding (latents reach |x|~300): scale the bound
+    scale = max(1.0, g["latents"].abs().max().item())
+    assert maxdiff(z, g["latents"]) < 5e-6 * scale
+    assert maxdiff(feats, g["feats"]) < 1e-4
+
+
+def test_scheduler_known_answers():
+    """A3 is unpinned (no diffusers here): check the published closed-form properties only."""
+    d = orc.DDIM()
+    d.set_timesteps(50)
+    assert d.timesteps[0].item() == 981 and d.timesteps[-1].item() == 1 and len(d.timesteps) == 50
+    d.set_timesteps(20)
+    assert d.timesteps[0].item() == 951 and d.timesteps[-1].item() == 1
+    assert abs(d.alphas_cumprod[0].item() - (1 - 0.00085)) < 1e-7
+    assert abs(d.betas[-1].item() - 0.012) < 1e-7
+    p = orc.DDPM()
+    p.set_timesteps(1000)
+    assert p.timesteps[0].item() == 999 and p.timesteps[-1].item() == 0
+    # DDIM with eta=0 and eps=0 only rescales x by sqrt(a_prev/a_t)
+    x = torch.ones(1, 1, 4)
+    d.set_timesteps(50)
+    y = d.step(torch.zeros_like(x), 981, x)
+    assert torch.allclose(y, x * (d.alphas_cumprod[961] / d.alphas_cumprod[981]) ** 0.5, atol=1e-6)
