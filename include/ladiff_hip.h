@@ -1,0 +1,158 @@
+/*
+ * ladiff_hip.h - C ABI of libladiff_hip.so, the MI355X (gfx950) implementation of the LADiff
+ * latent-diffusion sampling hot path.
+ *
+ * The reference (AlessioSam/LADiff) is pure Python/PyTorch and has no FFI of its own; the
+ * "interface each entry point replaces" is therefore a Python call site of the reference, cited
+ * per function as `src/...py:line`.  The binding a maintainer adds is a ctypes stub - see
+ * INTEGRATION.md and ladiff_amd/_lib.py.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no torch / C++ types.
+ *   - every pointer is a DEVICE pointer (fp32 unless typed otherwise) except those named h_*.
+ *   - return 0 = ok, < 0 = argument / shape / workspace error (LADIFF_ERR_*), > 0 = hipError_t.
+ *   - nothing allocates, frees or synchronises: work is enqueued on the given stream, scratch comes
+ *     from the caller's workspace (size from the *_workspace_bytes query), so every call is
+ *     hipGraph-capturable.  Calls are re-entrant across distinct (workspace, stream) pairs.
+ *   - tensors are dense row-major; the arithmetic type is fp32 (fp32-input MFMA, fp32 accumulate).
+ *   - weights are passed as an array of device pointers, one per state-dict tensor, in the order
+ *     given by ladiff_{denoiser,decoder}_param_name(i) (names = the reference's state-dict keys,
+ *     SURVEY.md Appendix A).
+ */
+#ifndef LADIFF_HIP_H
+#define LADIFF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ladiff_stream_t; /* hipStream_t */
+
+enum {
+    LADIFF_OK = 0,
+    LADIFF_ERR_ARG = -1,         /* null pointer / negative size */
+    LADIFF_ERR_SHAPE = -2,       /* shape outside what the kernels are built for */
+    LADIFF_ERR_WORKSPACE = -3,   /* workspace too small */
+    LADIFF_ERR_UNSUPPORTED = -4  /* configuration branch of the reference that is not built */
+};
+
+/* activation codes for ladiff_gemm */
+enum { LADIFF_ACT_NONE = 0, LADIFF_ACT_RELU = 1, LADIFF_ACT_GELU = 2, LADIFF_ACT_SILU = 3 };
+
+#define LADIFF_ABI_VERSION 1
+#define LADIFF_LATENT_DIM 256     /* model.latent_dim[-1], config_ladiff_humanml3d.yaml:132 */
+#define LADIFF_NUM_HEADS 4        /* configs/modules/denoiser.yaml:7 */
+#define LADIFF_NUM_LAYERS 9       /* configs/modules/denoiser.yaml:6, motion_vae.yaml:5 */
+#define LADIFF_FF_SIZE 1024       /* configs/modules/denoiser.yaml:5 */
+#define LADIFF_TEXT_DIM 768       /* configs/modules/denoiser.yaml:4 */
+#define LADIFF_MAX_LATENTS 8      /* MAX_IT <= 8 (shipped: 5, config_ladiff_humanml3d.yaml:58) */
+#define LADIFF_MAX_FRAMES 224     /* frames per motion <= 224 (reference MAX_LEN 196, base.yaml:78) */
+#define LADIFF_COEF_STRIDE 8      /* floats per scheduler-coefficient row */
+
+int ladiff_version(void);
+const char* ladiff_error_string(int code);
+
+/* ------------------------------------------------------------------ weight tables */
+int ladiff_denoiser_num_params(void);
+const char* ladiff_denoiser_param_name(int i); /* state-dict key of LADiffDenoiser, ladiff_denoiser.py:62-123 */
+int ladiff_decoder_num_params(void);
+const char* ladiff_decoder_param_name(int i);  /* keys LADiffVae.decode reads, ladiff_vae.py:334-356 */
+
+/* ------------------------------------------------------------------ unit kernels (parity tests)
+ * Y[M,N] = LN?( act(A[M,K] . W[N,K]^T + bias) + res ), A optionally the concat [A | A2] along K.
+ * Replaces nn.Linear (+ F.relu / F.gelu / residual / nn.LayerNorm) call sites such as
+ * mdiff_transformer.py:62-66, cross_attention.py:79-82 and :408-412.  ln_gamma != NULL needs N == 256. */
+int ladiff_gemm(const float* A, int lda, const float* A2, int lda2, int K1, const float* W, int ldw,
+                const float* bias, const float* res, int ldres, const float* ln_gamma,
+                const float* ln_beta, float* Y, int ldy, int M, int N, int K, int act,
+                ladiff_stream_t stream);
+
+/* y = LayerNorm(x) over rows of 256 (nn.LayerNorm, eps 1e-5), cross_attention.py:84-85, :150-151 */
+int ladiff_layernorm(const float* x, const float* gamma, const float* beta, float* y, int M,
+                     ladiff_stream_t stream);
+
+/* Decoder self-attention core (softmax(QK^T/8 + key mask) V per sample and head) on packed
+ * qkv[B*F,768]; keys >= lengths[b] are masked.  The nn.MultiheadAttention inside
+ * TransformerDecoderLayer.forward_post, cross_attention.py:367-369 (without in/out projections). */
+int ladiff_decoder_self_attention(const float* qkv, const int32_t* lengths, float* out, int B, int F,
+                                  ladiff_stream_t stream);
+
+/* Decoder cross-attention core: q[B*F,256] against the T memory tokens kv[T*B,512] (row = t*B+b,
+ * K | V), tokens >= counts[b] masked.  cross_attention.py:373-376. */
+int ladiff_decoder_cross_attention(const float* q, const float* kv, const int32_t* counts, float* out,
+                                   int B, int F, int T, ladiff_stream_t stream);
+
+/* ------------------------------------------------------------------ denoiser (LADiffDenoiser.forward)
+ * Step-invariant and t-only work is hoisted:
+ *   time tables  [n_steps][9 layers][1536] = AdaLN (scale|shift) of ca_block and ffn, K|V of the time token
+ *                (tools/embeddings.py:245-305, mdiff_transformer.py:158-160, :308-311)
+ *   text cache   emb_proj output, per-layer K|V of the text token and the normalised cross-attention value
+ *                (ladiff_denoiser.py:193-198, mdiff_transformer.py:233-245 with one text token)            */
+size_t ladiff_denoiser_tables_floats(int n_steps);
+size_t ladiff_denoiser_text_cache_floats(int B2);
+size_t ladiff_denoiser_workspace_bytes(int B2, int T, int n_steps);
+
+/* sinusoid[n_steps,768] = Timesteps(768, flip_sin_to_cos, freq_shift 0)(t) for every step of the schedule
+ * (tools/embeddings.py:245-285).  It is a t-only table like the scheduler coefficients; the host may fill it
+ * itself (bit-identical to the reference's fp32 ops) or with ladiff_timestep_sinusoid. */
+int ladiff_timestep_sinusoid(const int64_t* timesteps, int n_steps, float* sinusoid, ladiff_stream_t stream);
+int ladiff_denoiser_time_tables(const float* const* w, const float* sinusoid, int n_steps,
+                                float* tables, void* ws, size_t ws_bytes, ladiff_stream_t stream);
+int ladiff_denoiser_text_cache(const float* const* w, const float* text_emb /*[B2,1,768]*/, int B2,
+                               float* cache, void* ws, size_t ws_bytes, ladiff_stream_t stream);
+
+/* eps[Bs*dup,T,256] = denoiser(cat([sample]*dup), t = step *d_step of the time tables, text, counts).
+ * ladiff_denoiser.py:153-295 (call site ladiff.py:472-485).  counts[Bs] (int32, valid latent rows per
+ * prompt, ceil(len/48)) may be NULL = no masking (TEST_EFFICIENCY / max_iter_elements=None). */
+int ladiff_denoiser_forward(const float* const* w, const float* tables, const int32_t* d_step,
+                            const float* text_cache, const float* sample /*[Bs,T,256]*/, int Bs, int dup,
+                            int T, const int32_t* counts, float* eps, void* ws, size_t ws_bytes,
+                            ladiff_stream_t stream);
+
+/* ------------------------------------------------------------------ guidance + scheduler step
+ * latents <- step(eps_u + g (eps_c - eps_u)) with one row of coef per step:
+ *   {sqrt(a_t), sqrt(1-a_t), k_x0, k_x, k_eps, k_noise, 0, 0}
+ *   x0 = (x - sqrt(1-a_t) e) / sqrt(a_t);  x' = k_x0 x0 + k_x x + k_eps e + k_noise z
+ * (DDIM: k_x0 = sqrt(a_prev), k_eps = sqrt(1-a_prev-sigma^2), k_noise = sigma; DDPM: posterior mean
+ * coefficients and sqrt(variance)).  Replaces ladiff.py:487-492 + diffusers *Scheduler.step. */
+int ladiff_cfg_scheduler_step(const float* eps, float* latents /*[B,T,256] in/out*/, const float* coef,
+                              const int32_t* d_step, const float* step_noise /*[n,B,T,256] or NULL*/,
+                              float guidance_scale, int cfg, int B, int T, ladiff_stream_t stream);
+int ladiff_advance_step(int32_t* d_step, ladiff_stream_t stream);
+
+/* latents[B,T,256] = noise * valid * sigma  (ladiff.py:380-390, :407) */
+int ladiff_init_latents(const float* noise, const int32_t* counts, float init_noise_sigma, float* latents,
+                        int B, int T, ladiff_stream_t stream);
+/* z[T,B,256] = permute(latents) with rows >= counts[b] zeroed  (ladiff.py:500, :562-566) */
+int ladiff_finalize_latents(const float* latents, const int32_t* counts, float* z, int B, int T,
+                            ladiff_stream_t stream);
+
+/* ------------------------------------------------------------------ whole reverse loop
+ * LADIFF._diffusion_reverse (ladiff.py:333-571, live branch).  `sampler` (from ladiff_sampler_create, or
+ * NULL) owns a hipGraph of ONE step (denoiser + guidance + scheduler + step counter) that is captured on
+ * first use and replayed n_steps times; it is re-captured when any argument changes. */
+int ladiff_sampler_create(void** sampler);
+int ladiff_sampler_destroy(void* sampler);
+size_t ladiff_reverse_workspace_bytes(int B, int T, int n_steps);
+int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* text_emb /*[2B,1,768]*/,
+                             const float* init_noise /*[B,T,256]*/, const int32_t* counts /*[B] or NULL*/,
+                             const float* sinusoid /*[n,768]*/, const float* coef /*[n,8]*/,
+                             const float* step_noise /*[n,B,T,256] or NULL*/, float guidance_scale,
+                             float init_noise_sigma, int B, int T, int n_steps, float* z /*[T,B,256]*/,
+                             void* ws, size_t ws_bytes, ladiff_stream_t stream);
+
+/* ------------------------------------------------------------------ LA-VAE decoder (LADiffVae.decode)
+ * feats[B,F,C] from z[T,B,256]; frames >= lengths[b] come out zero.  ladiff_vae.py:288-362
+ * (call site ladiff.py:283).  lengths/counts are int32 device arrays of B entries. */
+size_t ladiff_decoder_workspace_bytes(int B, int F, int T, int C);
+int ladiff_vae_decode(const float* const* w, const float* z, const int32_t* lengths, const int32_t* counts,
+                      int B, int F, int T, int C, float* feats, void* ws, size_t ws_bytes,
+                      ladiff_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LADIFF_HIP_H */

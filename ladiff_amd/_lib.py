@@ -1,0 +1,132 @@
+"""ctypes binding of libladiff_hip.so (C ABI in include/ladiff_hip.h).
+
+This is the stub a maintainer of the reference would add: the reference is pure
+Python, so its "FFI" for the hot path is a `ctypes.CDLL` with `tensor.data_ptr()` arguments and the
+current HIP stream.  There is NO CPU fallback: if the library is missing, or a call gets a non-GPU
+tensor, it raises.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libladiff_hip.so")
+
+MAX_LATENTS = 8
+MAX_FRAMES = 224
+COEF_STRIDE = 8
+ACT = {"none": 0, "relu": 1, "gelu": 2, "silu": 3}
+
+
+class LadiffHipError(RuntimeError):
+    pass
+
+
+_SIGNATURES = {
+    "ladiff_version": (c_int, []),
+    "ladiff_error_string": (c_char_p, [c_int]),
+    "ladiff_denoiser_num_params": (c_int, []),
+    "ladiff_denoiser_param_name": (c_char_p, [c_int]),
+    "ladiff_decoder_num_params": (c_int, []),
+    "ladiff_decoder_param_name": (c_char_p, [c_int]),
+    "ladiff_gemm": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                            c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ladiff_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ladiff_timestep_sinusoid": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "ladiff_decoder_self_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ladiff_decoder_cross_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ladiff_denoiser_tables_floats": (c_size_t, [c_int]),
+    "ladiff_denoiser_text_cache_floats": (c_size_t, [c_int]),
+    "ladiff_denoiser_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ladiff_denoiser_time_tables": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ladiff_denoiser_text_cache": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ladiff_denoiser_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                        c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ladiff_cfg_scheduler_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int,
+                                          c_int, c_void_p]),
+    "ladiff_advance_step": (c_int, [c_void_p, c_void_p]),
+    "ladiff_init_latents": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p]),
+    "ladiff_finalize_latents": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ladiff_sampler_create": (c_int, [ctypes.POINTER(c_void_p)]),
+    "ladiff_sampler_destroy": (c_int, [c_void_p]),
+    "ladiff_reverse_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ladiff_diffusion_reverse": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p,
+                                         c_size_t, c_void_p]),
+    "ladiff_decoder_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "ladiff_vae_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                  c_void_p, c_size_t, c_void_p]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+_lib = None
+
+
+def lib():
+    """The loaded library; raises LadiffHipError when it has not been built (python -m ladiff_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LadiffHipError(f"{LIB_PATH} not found: build it with `python -m ladiff_amd.build` "
+                                 "(the HIP library is the only implementation of this path; there is no CPU fallback)")
+        cdll = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(cdll, name)   # AttributeError if a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = cdll
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise LadiffHipError(f"libladiff_hip: {lib().ladiff_error_string(rc).decode()} (code {rc})")
+
+
+def ptr(t, dtype=torch.float32):
+    """Device pointer of a contiguous GPU tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise LadiffHipError("libladiff_hip works on GPU tensors only; got a CPU tensor (no CPU fallback exists)")
+    if t.dtype != dtype:
+        raise LadiffHipError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise LadiffHipError("expected a contiguous tensor")
+    return t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def param_names(kind):
+    l = lib()
+    n = getattr(l, f"ladiff_{kind}_num_params")()
+    return [getattr(l, f"ladiff_{kind}_param_name")(i).decode() for i in range(n)]
+
+
+class WeightTable:
+    """Array of device pointers in the order the library expects, built from a state dict."""
+
+    def __init__(self, kind, tensors):
+        names = param_names(kind)
+        self.tensors = []   # keep the fp32 contiguous GPU tensors alive
+        for n in names:
+            if n not in tensors:
+                raise LadiffHipError(f"missing weight {n}")
+            t = tensors[n].detach()
+            if not t.is_cuda:
+                raise LadiffHipError(f"weight {n} is on {t.device}; move the module to the GPU first")
+            self.tensors.append(t.to(torch.float32).contiguous())
+        self.array = (c_void_p * len(names))(*[t.data_ptr() for t in self.tensors])
+        self.key = tuple((tensors[n].data_ptr(), tensors[n]._version) for n in names)
+
+    @staticmethod
+    def key_of(kind_names, tensors):
+        return tuple((tensors[n].data_ptr(), tensors[n]._version) for n in kind_names)
+
+
+def workspace(nbytes, device):
+    return torch.empty((int(nbytes) + 3) // 4, dtype=torch.float32, device=device)

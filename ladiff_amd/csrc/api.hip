@@ -1,0 +1,257 @@
+// extern "C" surface of libladiff_hip.so (declared in include/ladiff_hip.h).
+#include <cstring>
+
+#include "model.h"
+
+using namespace ladiff;
+
+namespace {
+
+inline hipStream_t S(ladiff_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+template <class W>
+bool load_weights(W& dst, const float* const* ptrs) {
+    constexpr int n = sizeof(W) / sizeof(const float*);
+    if (ptrs == nullptr) return false;
+    for (int i = 0; i < n; ++i)
+        if (ptrs[i] == nullptr) return false;
+    std::memcpy(&dst, ptrs, sizeof(W));
+    return true;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- reverse-loop workspace carve-up (floats)
+struct ReverseWs {
+    float *tables, *cache, *latents, *eps, *fwd;
+    int32_t* d_step;
+    size_t fwd_floats, total_bytes;
+};
+ReverseWs carve_reverse(void* ws, int B, int T, int n) {
+    ReverseWs r;
+    const int B2 = 2 * B;
+    size_t off = 0;
+    auto take = [&](size_t floats) { float* p = ws ? reinterpret_cast<float*>(ws) + off : nullptr; off += align_up(floats, 64); return p; };
+    r.d_step = reinterpret_cast<int32_t*>(take(64));
+    r.tables = take(den_tables_floats(n));
+    r.cache = take(den_text_cache_floats(B2));
+    r.latents = take((size_t)B * T * D);
+    r.eps = take((size_t)B2 * T * D);
+    size_t pre = (size_t)n * D * 3;                                    // time-table scratch
+    const size_t txt = (size_t)B2 * TEXT_DIM + (size_t)B2 * D;         // text-cache scratch
+    if (txt > pre) pre = txt;
+    r.fwd_floats = den_forward_ws_floats(B2, T);
+    if (pre > r.fwd_floats) r.fwd_floats = pre;
+    r.fwd = take(r.fwd_floats);
+    r.total_bytes = off * sizeof(float);
+    return r;
+}
+
+struct Sampler {
+    hipGraphExec_t exec = nullptr;
+    // capture key: a graph bakes pointers and shapes into its kernel nodes
+    const void* key_ptrs[8] = {nullptr};
+    int key_ints[4] = {0};
+    float key_g = 0.f;
+};
+
+}  // namespace
+
+extern "C" {
+
+int ladiff_version(void) { return LADIFF_ABI_VERSION; }
+
+const char* ladiff_error_string(int code) {
+    switch (code) {
+        case LADIFF_OK: return "ok";
+        case LADIFF_ERR_ARG: return "invalid argument (null pointer or negative size)";
+        case LADIFF_ERR_SHAPE: return "shape not supported by the gfx950 kernels";
+        case LADIFF_ERR_WORKSPACE: return "workspace too small";
+        case LADIFF_ERR_UNSUPPORTED: return "configuration branch not built";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown ladiff error";
+    }
+}
+
+int ladiff_denoiser_num_params(void) { return DEN_NPARAMS; }
+const char* ladiff_denoiser_param_name(int i) {
+    const auto& n = denoiser_param_names();
+    return (i >= 0 && i < (int)n.size()) ? n[i].c_str() : nullptr;
+}
+int ladiff_decoder_num_params(void) { return DEC_NPARAMS; }
+const char* ladiff_decoder_param_name(int i) {
+    const auto& n = decoder_param_names();
+    return (i >= 0 && i < (int)n.size()) ? n[i].c_str() : nullptr;
+}
+
+// ------------------------------------------------------------------ unit kernels
+int ladiff_gemm(const float* A, int lda, const float* A2, int lda2, int K1, const float* W, int ldw, const float* bias,
+                const float* res, int ldres, const float* ln_gamma, const float* ln_beta, float* Y, int ldy, int M,
+                int N, int K, int act, ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(A && W && Y && M >= 0 && N > 0 && K > 0);
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.A2 = A2; g.lda2 = lda2; g.K1 = A2 ? K1 : K; g.W = W; g.ldw = ldw; g.bias = bias;
+    g.res = res; g.ldres = ldres; g.ln_g = ln_gamma; g.ln_b = ln_beta; g.Y = Y; g.ldy = ldy; g.M = M; g.N = N; g.K = K;
+    g.act = act;
+    return launch_gemm(g, S(stream));
+}
+
+int ladiff_layernorm(const float* x, const float* gamma, const float* beta, float* y, int M, ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(x && gamma && beta && y && M >= 0);
+    return launch_layernorm(x, gamma, beta, y, M, S(stream));
+}
+
+int ladiff_timestep_sinusoid(const int64_t* timesteps, int n, float* out, ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(timesteps && out && n >= 0);
+    if (n == 0) return 0;
+    return launch_sinusoid(timesteps, n, out, S(stream));
+}
+
+int ladiff_decoder_self_attention(const float* qkv, const int32_t* lengths, float* out, int B, int F,
+                                  ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(qkv && lengths && out && B >= 0);
+    return launch_decoder_self_attention(qkv, lengths, out, B, F, S(stream));
+}
+
+int ladiff_decoder_cross_attention(const float* q, const float* kv, const int32_t* counts, float* out, int B, int F,
+                                   int T, ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(q && kv && out && B >= 0 && F >= 0);
+    return launch_decoder_cross_attention(q, kv, counts, out, B, F, T, S(stream));
+}
+
+// ------------------------------------------------------------------ denoiser
+size_t ladiff_denoiser_tables_floats(int n_steps) { return den_tables_floats(n_steps); }
+size_t ladiff_denoiser_text_cache_floats(int B2) { return den_text_cache_floats(B2); }
+size_t ladiff_denoiser_workspace_bytes(int B2, int T, int n_steps) {
+    size_t f = den_forward_ws_floats(B2, T);
+    const size_t a = (size_t)n_steps * D * 3, b = (size_t)B2 * TEXT_DIM + (size_t)B2 * D;
+    if (a > f) f = a;
+    if (b > f) f = b;
+    return f * sizeof(float);
+}
+
+int ladiff_denoiser_time_tables(const float* const* w, const float* sinusoid, int n_steps, float* tables, void* ws,
+                                size_t ws_bytes, ladiff_stream_t stream) {
+    DenoiserW W;
+    LADIFF_CHECK_ARG(load_weights(W, w) && sinusoid && tables && ws && n_steps > 0);
+    return denoiser_time_tables(W, sinusoid, n_steps, tables, (float*)ws, ws_bytes / sizeof(float), S(stream));
+}
+
+int ladiff_denoiser_text_cache(const float* const* w, const float* text_emb, int B2, float* cache, void* ws,
+                               size_t ws_bytes, ladiff_stream_t stream) {
+    DenoiserW W;
+    LADIFF_CHECK_ARG(load_weights(W, w) && text_emb && cache && ws && B2 > 0);
+    return denoiser_text_cache(W, text_emb, B2, cache, (float*)ws, ws_bytes / sizeof(float), S(stream));
+}
+
+int ladiff_denoiser_forward(const float* const* w, const float* tables, const int32_t* d_step, const float* text_cache,
+                            const float* sample, int Bs, int dup, int T, const int32_t* counts, float* eps, void* ws,
+                            size_t ws_bytes, ladiff_stream_t stream) {
+    DenoiserW W;
+    LADIFF_CHECK_ARG(load_weights(W, w) && tables && d_step && text_cache && sample && eps && ws && Bs > 0 && dup > 0);
+    return denoiser_forward(W, tables, d_step, text_cache, sample, Bs, dup, T, counts, eps, (float*)ws,
+                            ws_bytes / sizeof(float), S(stream));
+}
+
+// ------------------------------------------------------------------ guidance + scheduler
+int ladiff_cfg_scheduler_step(const float* eps, float* latents, const float* coef, const int32_t* d_step,
+                              const float* step_noise, float guidance_scale, int cfg, int B, int T,
+                              ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(eps && latents && coef && d_step && B > 0 && T > 0);
+    return launch_cfg_step(eps, latents, coef, d_step, step_noise, guidance_scale, cfg, B, T, S(stream));
+}
+int ladiff_advance_step(int32_t* d_step, ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(d_step);
+    return launch_advance(d_step, S(stream));
+}
+int ladiff_init_latents(const float* noise, const int32_t* counts, float sigma, float* latents, int B, int T,
+                        ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(noise && latents && B > 0 && T > 0);
+    return launch_init_latents(noise, counts, sigma, latents, B, T, S(stream));
+}
+int ladiff_finalize_latents(const float* latents, const int32_t* counts, float* z, int B, int T, ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(latents && z && B > 0 && T > 0);
+    return launch_finalize_latents(latents, counts, z, B, T, S(stream));
+}
+
+// ------------------------------------------------------------------ whole reverse loop
+int ladiff_sampler_create(void** sampler) {
+    LADIFF_CHECK_ARG(sampler);
+    *sampler = new Sampler();
+    return 0;
+}
+int ladiff_sampler_destroy(void* sampler) {
+    Sampler* sp = reinterpret_cast<Sampler*>(sampler);
+    if (sp == nullptr) return 0;
+    if (sp->exec) (void)hipGraphExecDestroy(sp->exec);
+    delete sp;
+    return 0;
+}
+
+size_t ladiff_reverse_workspace_bytes(int B, int T, int n_steps) { return carve_reverse(nullptr, B, T, n_steps).total_bytes; }
+
+int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* text_emb, const float* init_noise,
+                             const int32_t* counts, const float* sinusoid, const float* coef, const float* step_noise,
+                             float guidance_scale, float init_noise_sigma, int B, int T, int n_steps, float* z,
+                             void* ws, size_t ws_bytes, ladiff_stream_t stream) {
+    DenoiserW W;
+    LADIFF_CHECK_ARG(load_weights(W, w) && text_emb && init_noise && sinusoid && coef && z && ws && B > 0 && n_steps > 0);
+    if (T < 1 || T > LADIFF_MAX_LATENTS) return LADIFF_ERR_SHAPE;
+    ReverseWs r = carve_reverse(ws, B, T, n_steps);
+    if (ws_bytes < r.total_bytes) return LADIFF_ERR_WORKSPACE;
+    hipStream_t s = S(stream);
+    const int B2 = 2 * B;
+
+    // hoisted, once per call: time tables for every step, text cache, initial latents, step counter
+    LADIFF_TRY(denoiser_time_tables(W, sinusoid, n_steps, r.tables, r.fwd, r.fwd_floats, s));
+    LADIFF_TRY(denoiser_text_cache(W, text_emb, B2, r.cache, r.fwd, r.fwd_floats, s));
+    LADIFF_TRY(launch_init_latents(init_noise, counts, init_noise_sigma, r.latents, B, T, s));
+    LADIFF_HIP(hipMemsetAsync(r.d_step, 0, sizeof(int32_t), s));
+
+    auto one_step = [&](hipStream_t st) -> int {
+        LADIFF_TRY(denoiser_forward(W, r.tables, r.d_step, r.cache, r.latents, B, 2, T, counts, r.eps, r.fwd, r.fwd_floats, st));
+        LADIFF_TRY(launch_cfg_step(r.eps, r.latents, coef, r.d_step, step_noise, guidance_scale, 1, B, T, st));
+        return launch_advance(r.d_step, st);
+    };
+
+    Sampler* sp = reinterpret_cast<Sampler*>(sampler);
+    if (sp == nullptr) {
+        for (int i = 0; i < n_steps; ++i) LADIFF_TRY(one_step(s));
+    } else {
+        const void* kp[8] = {w, w[0], ws, counts, coef, step_noise, stream, nullptr};
+        const int ki[4] = {B, T, n_steps, 0};
+        const bool same = sp->exec && std::memcmp(kp, sp->key_ptrs, sizeof(kp)) == 0 &&
+                          std::memcmp(ki, sp->key_ints, sizeof(ki)) == 0 && sp->key_g == guidance_scale;
+        if (!same) {
+            if (sp->exec) { (void)hipGraphExecDestroy(sp->exec); sp->exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            LADIFF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            const int rc = one_step(s);
+            const hipError_t ec = hipStreamEndCapture(s, &graph);
+            if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            LADIFF_HIP(ec);
+            const hipError_t ei = hipGraphInstantiate(&sp->exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            LADIFF_HIP(ei);
+            std::memcpy(sp->key_ptrs, kp, sizeof(kp));
+            std::memcpy(sp->key_ints, ki, sizeof(ki));
+            sp->key_g = guidance_scale;
+        }
+        for (int i = 0; i < n_steps; ++i) LADIFF_HIP(hipGraphLaunch(sp->exec, s));
+    }
+    return launch_finalize_latents(r.latents, counts, z, B, T, s);
+}
+
+// ------------------------------------------------------------------ LA-VAE decoder
+size_t ladiff_decoder_workspace_bytes(int B, int F, int T, int C) {
+    (void)C;
+    return dec_ws_floats(B, F, T) * sizeof(float);
+}
+
+int ladiff_vae_decode(const float* const* w, const float* z, const int32_t* lengths, const int32_t* counts, int B,
+                      int F, int T, int C, float* feats, void* ws, size_t ws_bytes, ladiff_stream_t stream) {
+    DecoderW W;
+    LADIFF_CHECK_ARG(load_weights(W, w) && z && lengths && feats && ws && B >= 0);
+    return vae_decode(W, z, lengths, counts, B, F, T, C, feats, (float*)ws, ws_bytes / sizeof(float), S(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,265 @@
+// Attention cores of the hot path.
+//   * decoder self-attention over F <= 224 frames (fp32 MFMA, K/V of one (sample, head) resident in LDS)
+//   * decoder cross-attention to the <= 8 latent tokens (VALU, one wave per frame row)
+//   * denoiser self-attention over the T + 2 <= 10 tokens [latents | text | time] (VALU, one wave per head)
+#include "kernels.h"
+
+namespace ladiff {
+
+// ===================================================================== decoder self-attention
+// nn.MultiheadAttention core of TransformerDecoderLayer.forward_post (cross_attention.py:367-369):
+//   P = softmax(Q K^T / 8 + mask(key >= len_b)),  O = P V,  per sample b and head h, dh = 64.
+// One workgroup = (b, h, group of 4 query tiles); wave w owns query tile qt = 4*blockIdx.x + w (32 queries).
+//   S^T tile [32 keys x 32 queries] = K_tile [32 x 64] . Q_tile^T   (mfma 32x32x2 f32, A = K from LDS, B = Q in regs)
+// so a query's scores sit in ONE lane pair (lane, lane^32): the row softmax needs a single cross-lane op, and
+// the exponentiated tile is directly the B operand of  O^T [64 d x 32 queries] += V_tile^T . P_tile^T.
+constexpr int SA_FMAX = LADIFF_MAX_FRAMES;   // 224 = 7 key tiles
+constexpr int SA_NKT = SA_FMAX / 32;
+
+__global__ __launch_bounds__(256) void dec_self_attn_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ lengths,
+                                                            float* __restrict__ out, int B, int F) {
+    __shared__ __attribute__((aligned(16))) float Ks[SA_FMAX * DH];   // chunk c of row r at slot c ^ (r & 15)
+    __shared__ __attribute__((aligned(16))) float Vs[SA_FMAX * DH];   // plain [key][d]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    int len = lengths[b];
+    len = len < 1 ? 1 : (len > F ? F : len);
+    const int nkt = (len + 31) >> 5;
+    const size_t base = (size_t)b * F * 768 + h * DH;
+
+    for (int id = tid; id < nkt * 32 * 16; id += 256) {
+        const int r = id >> 4, c = id & 15;
+        f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+        if (r < F) {
+            const float* src = qkv + base + (size_t)r * 768 + c * 4;
+            kk = ld4(src + 256);
+            vv = ld4(src + 512);
+        }
+        st4(Ks + r * DH + ((c ^ (r & 15)) << 2), kk);
+        st4(Vs + r * DH + c * 4, vv);
+    }
+    __syncthreads();
+
+    const int qt = blockIdx.x * 4 + wave;
+    if (qt * 32 >= F) return;
+    const int q = lane & 31, h2 = lane >> 5;
+    const int qrow = qt * 32 + q;
+
+    f32x4 qf[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (qrow < F) v = ld4(qkv + base + (size_t)qrow * 768 + g * 8 + h2 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= 0.125f;   // q / sqrt(64), exact
+        qf[g] = v;
+    }
+
+    f32x16 sT[SA_NKT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < SA_NKT; ++kt) {
+        if (kt < nkt) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            const int r = kt * 32 + q;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 a = ld4(Ks + r * DH + ((((g << 1) + h2) ^ (r & 15)) << 2));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], qf[g][e], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2;
+                const float s = key < len ? acc[i] : -INFINITY;
+                acc[i] = s;
+                m = fmaxf(m, s);
+            }
+            sT[kt] = acc;
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < SA_NKT; ++kt) {
+        if (kt < nkt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pv = expf(sT[kt][i] - m);
+                sT[kt][i] = pv;
+                l += pv;
+            }
+        }
+    }
+    l += __shfl_xor(l, 32, 64);
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+#pragma unroll
+    for (int kt = 0; kt < SA_NKT; ++kt) {
+        if (kt < nkt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2;
+                const float a0 = Vs[key * DH + q];
+                const float a1 = Vs[key * DH + 32 + q];
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, sT[kt][i], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, sT[kt][i], o1, 0, 0, 0);
+            }
+        }
+    }
+
+    if (qrow < F) {
+        const float inv = 1.f / l;
+        float* dst = out + ((size_t)b * F + qrow) * D + h * DH + 4 * h2;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            f32x4 v0, v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] = o0[4 * rg + e] * inv; v1[e] = o1[4 * rg + e] * inv; }
+            st4(dst + 8 * rg, v0);
+            st4(dst + 32 + 8 * rg, v1);
+        }
+    }
+}
+
+int launch_decoder_self_attention(const float* qkv, const int32_t* lengths, float* out, int B, int F, hipStream_t s) {
+    if (F > SA_FMAX || F < 1) return LADIFF_ERR_SHAPE;
+    if (B == 0) return 0;
+    const int nqt = (F + 31) / 32;
+    hipLaunchKernelGGL(dec_self_attn_kernel, dim3((nqt + 3) / 4, B * H), dim3(256), 0, s, qkv, lengths, out, B, F);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+// ===================================================================== decoder cross-attention
+// multihead_attn core (cross_attention.py:373-376): frame query against the T latent tokens of its sample,
+// tokens >= counts[b] masked.  One wave per frame row; lane owns 4 of the 256 columns (16 lanes per head).
+template <int T>
+__global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __restrict__ q, const float* __restrict__ kv,
+                                                             const int32_t* __restrict__ counts, float* __restrict__ out,
+                                                             int B, int F, int M) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int c = (threadIdx.x & 63) * 4;
+    const int b = row / F;
+    int nv = counts ? counts[b] : T;
+    nv = nv < 1 ? 1 : (nv > T ? T : nv);
+    f32x4 qv = ld4(q + (size_t)row * D + c);
+    float s[T];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const f32x4 kk = ld4(kv + ((size_t)j * B + b) * 512 + c);
+        float d = (qv[0] * 0.125f) * kk[0] + (qv[1] * 0.125f) * kk[1] + (qv[2] * 0.125f) * kk[2] + (qv[3] * 0.125f) * kk[3];
+        d = group_sum<16>(d);
+        s[j] = j < nv ? d : -INFINITY;
+        m = fmaxf(m, s[j]);
+    }
+    float l = 0.f;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const float pv = expf(s[j] - m);
+        l += pv;
+        const f32x4 vv = ld4(kv + ((size_t)j * B + b) * 512 + 256 + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += pv * vv[e];
+    }
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] *= inv;
+    st4(out + (size_t)row * D + c, o);
+}
+
+int launch_decoder_cross_attention(const float* q, const float* kv, const int32_t* counts, float* out, int B, int F,
+                                   int T, hipStream_t s) {
+    const int M = B * F;
+    if (M == 0) return 0;
+    const dim3 grid((M + 3) / 4), block(256);
+#define LADIFF_CA_CASE(TT) \
+    case TT: hipLaunchKernelGGL(dec_cross_attn_kernel<TT>, grid, block, 0, s, q, kv, counts, out, B, F, M); break;
+    switch (T) {
+        LADIFF_CA_CASE(1) LADIFF_CA_CASE(2) LADIFF_CA_CASE(3) LADIFF_CA_CASE(4)
+        LADIFF_CA_CASE(5) LADIFF_CA_CASE(6) LADIFF_CA_CASE(7) LADIFF_CA_CASE(8)
+        default: return LADIFF_ERR_SHAPE;
+    }
+#undef LADIFF_CA_CASE
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+// ===================================================================== denoiser self-attention
+// sa_block attention of LinearTemporalDiffusionTransformerDecoderLayer (mdiff_transformer.py:296-313): queries
+// are the T latent rows; keys/values are [T latent rows | text token | time token]; latent keys >= counts[b]
+// are masked, the two extra tokens never are.  The text token's K|V are step-invariant (text cache) and the
+// time token's K|V depend on (step, layer) only (time table).  One workgroup per sample, wave = head, lane = d.
+template <int T>
+__global__ __launch_bounds__(256) void den_self_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ text_kv,
+                                                            const float* __restrict__ tables, int kv_off, int step_stride,
+                                                            const int32_t* __restrict__ d_step,
+                                                            const int32_t* __restrict__ counts, int Bs,
+                                                            float* __restrict__ out) {
+    const int b2 = blockIdx.x;
+    const int col = threadIdx.x;   // = head * 64 + d
+    float qv[T], kk[T + 2], vv[T + 2];
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        const float* r = qkv + ((size_t)b2 * T + i) * 768 + col;
+        qv[i] = r[0] * 0.125f;
+        kk[i] = r[256];
+        vv[i] = r[512];
+    }
+    kk[T] = text_kv[(size_t)b2 * 512 + col];
+    vv[T] = text_kv[(size_t)b2 * 512 + 256 + col];
+    const float* tk = tables + (size_t)(*d_step) * step_stride + kv_off;
+    kk[T + 1] = tk[col];
+    vv[T + 1] = tk[256 + col];
+    int nv = counts ? counts[b2 % Bs] : T;
+    nv = nv > T ? T : nv;
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        float s[T + 2];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < T + 2; ++j) {
+            const float d = group_sum<64>(qv[i] * kk[j]);
+            s[j] = (j < T && j >= nv) ? -INFINITY : d;
+            m = fmaxf(m, s[j]);
+        }
+        float l = 0.f, o = 0.f;
+#pragma unroll
+        for (int j = 0; j < T + 2; ++j) {
+            const float pv = expf(s[j] - m);
+            l += pv;
+            o += pv * vv[j];
+        }
+        out[((size_t)b2 * T + i) * D + col] = o / l;
+    }
+}
+
+int launch_denoiser_self_attention(const float* qkv, const float* text_kv, const float* tables, int kv_off,
+                                   int step_stride, const int32_t* d_step, const int32_t* counts, int Bs, int B2,
+                                   int T, float* out, hipStream_t s) {
+    if (B2 == 0) return 0;
+    const dim3 grid(B2), block(256);
+#define LADIFF_SA_CASE(TT)                                                                                          \
+    case TT:                                                                                                        \
+        hipLaunchKernelGGL(den_self_attn_kernel<TT>, grid, block, 0, s, qkv, text_kv, tables, kv_off, step_stride, \
+                           d_step, counts, Bs, out);                                                                \
+        break;
+    switch (T) {
+        LADIFF_SA_CASE(1) LADIFF_SA_CASE(2) LADIFF_SA_CASE(3) LADIFF_SA_CASE(4)
+        LADIFF_SA_CASE(5) LADIFF_SA_CASE(6) LADIFF_SA_CASE(7) LADIFF_SA_CASE(8)
+        default: return LADIFF_ERR_SHAPE;
+    }
+#undef LADIFF_SA_CASE
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace ladiff

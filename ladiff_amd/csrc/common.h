@@ -1,0 +1,58 @@
+// Shared definitions for the LADiff gfx950 kernels (CDNA4, wave64, fp32-input MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ladiff_hip.h"
+
+namespace ladiff {
+
+constexpr int D = 256;     // latent / model width      (config_ladiff_humanml3d.yaml:132 latent_dim[-1])
+constexpr int H = 4;       // heads                     (configs/modules/denoiser.yaml:7)
+constexpr int DH = 64;     // head dim
+constexpr float LN_EPS = 1e-5f;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- error plumbing: 0 ok, <0 argument error, >0 hipError_t (include/ladiff_hip.h)
+#define LADIFF_CHECK_ARG(cond) \
+    do { if (!(cond)) return LADIFF_ERR_ARG; } while (0)
+#define LADIFF_HIP(expr) \
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
+#define LADIFF_TRY(expr) \
+    do { int r_ = (expr); if (r_ != 0) return r_; } while (0)
+#define LADIFF_LAUNCH_CHECK() LADIFF_HIP(hipGetLastError())
+
+// ---- activations
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SILU = 3 };
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return fmaxf(v, 0.f);
+        case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));  // exact erf GELU
+        case ACT_SILU: return v / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float silu(float v) { return v / (1.f + expf(-v)); }
+
+// ---- wave-level reductions (64 lanes)
+template <int WIDTH>
+__device__ __forceinline__ float group_sum(float v) {   // sum over aligned groups of WIDTH lanes
+#pragma unroll
+    for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int WIDTH>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int o = WIDTH / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+}  // namespace ladiff

@@ -1,0 +1,199 @@
+// Host-side sequencing of the length-aware denoiser (LADiffDenoiser.forward, ladiff_denoiser.py:153-295)
+// on top of the gfx950 kernels.  Everything is enqueued on the caller's stream; no allocation, no sync.
+#include "model.h"
+
+namespace ladiff {
+
+static std::vector<std::string> block_prefixes(const char* root) {
+    std::vector<std::string> v;
+    for (int i = 0; i < NSKIP; ++i) v.push_back(std::string(root) + ".input_blocks." + std::to_string(i));
+    v.push_back(std::string(root) + ".middle_block");
+    for (int i = 0; i < NSKIP; ++i) v.push_back(std::string(root) + ".output_blocks." + std::to_string(i));
+    return v;
+}
+static void wb(std::vector<std::string>& v, const std::string& p) { v.push_back(p + ".weight"); v.push_back(p + ".bias"); }
+static void mha_names(std::vector<std::string>& v, const std::string& p) {
+    v.push_back(p + ".in_proj_weight"); v.push_back(p + ".in_proj_bias"); wb(v, p + ".out_proj");
+}
+static void styl_names(std::vector<std::string>& v, const std::string& p) {
+    wb(v, p + ".emb_layers.1"); wb(v, p + ".norm"); wb(v, p + ".out_layers.2");
+}
+
+const std::vector<std::string>& denoiser_param_names() {
+    static const std::vector<std::string> names = [] {
+        std::vector<std::string> v;
+        wb(v, "time_embedding.linear_1"); wb(v, "time_embedding.linear_2"); wb(v, "emb_proj.1");
+        v.push_back("query_pos.pe"); v.push_back("mem_pos.pe");
+        wb(v, "encoder.norm");
+        for (const auto& p : block_prefixes("encoder")) {
+            wb(v, p + ".ca_block.norm"); wb(v, p + ".ca_block.text_norm");
+            wb(v, p + ".ca_block.query"); wb(v, p + ".ca_block.key"); wb(v, p + ".ca_block.value");
+            styl_names(v, p + ".ca_block.proj_out");
+            wb(v, p + ".ffn.linear1"); wb(v, p + ".ffn.linear2");
+            styl_names(v, p + ".ffn.proj_out");
+            mha_names(v, p + ".sa_block.self_attn");
+            wb(v, p + ".sa_block.linear1"); wb(v, p + ".sa_block.linear2");
+            wb(v, p + ".sa_block.norm1"); wb(v, p + ".sa_block.norm2");
+        }
+        for (int i = 0; i < NSKIP; ++i) wb(v, "encoder.linear_blocks." + std::to_string(i));
+        return v;
+    }();
+    return names;
+}
+
+const std::vector<std::string>& decoder_param_names() {
+    static const std::vector<std::string> names = [] {
+        std::vector<std::string> v;
+        v.push_back("query_pos_decoder.pe");
+        for (const auto& p : block_prefixes("decoder")) {
+            mha_names(v, p + ".self_attn"); mha_names(v, p + ".multihead_attn");
+            wb(v, p + ".linear1"); wb(v, p + ".linear2");
+            wb(v, p + ".norm1"); wb(v, p + ".norm2"); wb(v, p + ".norm3");
+        }
+        for (int i = 0; i < NSKIP; ++i) wb(v, "decoder.linear_blocks." + std::to_string(i));
+        wb(v, "decoder.norm"); wb(v, "final_layer");
+        return v;
+    }();
+    return names;
+}
+
+// ------------------------------------------------------------------ small GEMM helper
+static GemmArgs lin(const float* A, int lda, const LinearW& l, float* Y, int ldy, int M, int N, int K, int act = ACT_NONE) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = l.w; g.ldw = K; g.bias = l.b; g.Y = Y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.act = act;
+    return g;
+}
+
+// ------------------------------------------------------------------ time tables
+size_t den_tables_floats(int n_steps) { return (size_t)n_steps * DEN_STEP_STRIDE; }
+static size_t time_ws_floats(int n) { return (size_t)n * D * 3; }
+
+int denoiser_time_tables(const DenoiserW& w, const float* sinus, int n, float* tables, float* ws, size_t ws_floats,
+                         hipStream_t s) {
+    if (ws_floats < time_ws_floats(n)) return LADIFF_ERR_WORKSPACE;
+    float* h1 = ws;                 // SiLU(linear_1(sinusoid))       tools/embeddings.py:296-301
+    float* temb = h1 + (size_t)n * D;   // time_emb                     :303
+    float* semb = temb + (size_t)n * D; // SiLU(time_emb), input of every StylizationBlock.emb_layers
+    LADIFF_TRY(launch_gemm(lin(sinus, TEXT_DIM, w.time1, h1, D, n, D, TEXT_DIM, ACT_SILU), s));
+    LADIFF_TRY(launch_gemm(lin(h1, D, w.time2, temb, D, n, D, D), s));
+    LADIFF_TRY(launch_silu(temb, semb, (size_t)n * D, s));
+    for (int l = 0; l < NL; ++l) {
+        const DenLayerW& L = w.layer[l];
+        float* base = tables + (size_t)l * DEN_LAYER_STRIDE;
+        LADIFF_TRY(launch_gemm(lin(semb, D, L.ca_proj.emb, base + DEN_OFF_CA_MOD, DEN_STEP_STRIDE, n, 2 * D, D), s));
+        LADIFF_TRY(launch_gemm(lin(semb, D, L.ffn_proj.emb, base + DEN_OFF_FFN_MOD, DEN_STEP_STRIDE, n, 2 * D, D), s));
+        // K | V of the time token = rows [256, 768) of the packed in_proj applied to time_emb
+        LinearW kvw{L.sa_attn.in_w + (size_t)D * D, L.sa_attn.in_b + D};
+        LADIFF_TRY(launch_gemm(lin(temb, D, kvw, base + DEN_OFF_TIME_KV, DEN_STEP_STRIDE, n, 2 * D, D), s));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ text cache
+//   [B2,256]      emb_proj(text)                      (ladiff_denoiser.py:198)
+//   [9][B2,512]   K | V of the text token per layer   (sa_block in_proj rows 256..767)
+//   [9][B2,256]   StylizationBlock.norm(value(text_norm(xf))) per layer (mdiff_transformer.py:237, :161)
+size_t den_text_cache_floats(int B2) { return (size_t)B2 * D + (size_t)NL * B2 * 3 * D; }
+static size_t text_ws_floats(int B2) { return (size_t)B2 * TEXT_DIM + (size_t)B2 * D; }
+
+int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, float* cache, float* ws, size_t ws_floats,
+                        hipStream_t s) {
+    if (ws_floats < text_ws_floats(B2)) return LADIFF_ERR_WORKSPACE;
+    float* rl = ws;
+    float* tn = rl + (size_t)B2 * TEXT_DIM;
+    float* tproj = cache;
+    float* tkv = cache + (size_t)B2 * D;
+    float* nval = tkv + (size_t)NL * B2 * 2 * D;
+    LADIFF_TRY(launch_relu(text, rl, (size_t)B2 * TEXT_DIM, s));
+    LADIFF_TRY(launch_gemm(lin(rl, TEXT_DIM, w.emb_proj, tproj, D, B2, D, TEXT_DIM), s));
+    for (int l = 0; l < NL; ++l) {
+        const DenLayerW& L = w.layer[l];
+        LinearW kvw{L.sa_attn.in_w + (size_t)D * D, L.sa_attn.in_b + D};
+        LADIFF_TRY(launch_gemm(lin(tproj, D, kvw, tkv + (size_t)l * B2 * 2 * D, 2 * D, B2, 2 * D, D), s));
+        LADIFF_TRY(launch_layernorm(tproj, L.ca_text_norm.g, L.ca_text_norm.b, tn, B2, s));
+        GemmArgs g = lin(tn, D, L.ca_value, nval + (size_t)l * B2 * D, D, B2, D, D);
+        g.ln_g = L.ca_proj.norm.g; g.ln_b = L.ca_proj.norm.b;
+        LADIFF_TRY(launch_gemm(g, s));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ forward
+size_t den_forward_ws_floats(int B2, int T) { return (size_t)B2 * T * (8 * D + 3 * D + D + FF + D); }
+
+int denoiser_forward(const DenoiserW& w, const float* tables, const int32_t* d_step, const float* cache,
+                     const float* sample, int Bs, int dup, int T, const int32_t* counts, float* eps, float* ws,
+                     size_t ws_floats, hipStream_t s) {
+    const int B2 = Bs * dup;
+    const int M = B2 * T;
+    if (T < 1 || T > LADIFF_MAX_LATENTS) return LADIFF_ERR_SHAPE;
+    if (ws_floats < den_forward_ws_floats(B2, T)) return LADIFF_ERR_WORKSPACE;
+    const size_t MD = (size_t)M * D;
+    float* P[4]; float* SK[NSKIP];
+    float* p = ws;
+    for (int i = 0; i < 4; ++i) { P[i] = p; p += MD; }
+    for (int i = 0; i < NSKIP; ++i) { SK[i] = p; p += MD; }
+    float* qkv = p; p += 3 * MD;
+    float* att = p; p += MD;
+    float* hid = p; p += (size_t)M * FF;
+    float* u = p;
+    const float* tkv = cache + (size_t)B2 * D;
+    const float* nval = tkv + (size_t)NL * B2 * 2 * D;
+
+    // x = cat([sample]*dup) + query_pos.pe[:T]        ladiff.py:472-474, ladiff_denoiser.py:251
+    LADIFF_TRY(launch_add_pe(sample, w.query_pe, Bs, dup, T, P[0], s));
+    const float* cur = P[0];
+    for (int l = 0; l < NL; ++l) {
+        const DenLayerW& L = w.layer[l];
+        const float* tl = tables + (size_t)l * DEN_LAYER_STRIDE;
+        const bool is_in = l < NSKIP, is_out = l > NSKIP;
+        if (is_out) {   // x = linear(cat([x, xs.pop()]))   cross_attention.py:79-82 (LIFO)
+            GemmArgs g = lin(cur, D, w.skip[l - NSKIP - 1], P[3], D, M, D, 2 * D);
+            g.A2 = SK[NL - 1 - l]; g.lda2 = D; g.K1 = D;
+            LADIFF_TRY(launch_gemm(g, s));
+            cur = P[3];
+        }
+        // ---- sa_block: post-norm encoder layer over [latents | text | time]   mdiff_transformer.py:54-67
+        LADIFF_TRY(launch_gemm(lin(cur, D, LinearW{L.sa_attn.in_w, L.sa_attn.in_b}, qkv, 3 * D, M, 3 * D, D), s));
+        LADIFF_TRY(launch_denoiser_self_attention(qkv, tkv + (size_t)l * B2 * 2 * D, tl, DEN_OFF_TIME_KV, DEN_STEP_STRIDE,
+                                                  d_step, counts, Bs, B2, T, att, s));
+        {
+            GemmArgs g = lin(att, D, LinearW{L.sa_attn.out_w, L.sa_attn.out_b}, P[1], D, M, D, D);
+            g.res = cur; g.ldres = D; g.ln_g = L.sa_norm1.g; g.ln_b = L.sa_norm1.b;
+            LADIFF_TRY(launch_gemm(g, s));
+        }
+        LADIFF_TRY(launch_gemm(lin(P[1], D, L.sa_lin1, hid, FF, M, FF, D, ACT_RELU), s));
+        {
+            GemmArgs g = lin(hid, FF, L.sa_lin2, P[2], D, M, D, FF);
+            g.res = P[1]; g.ldres = D; g.ln_g = L.sa_norm2.g; g.ln_b = L.sa_norm2.b;
+            LADIFF_TRY(launch_gemm(g, s));
+        }
+        // ---- ca_block with one text token: x + out(SiLU(AdaLN(value_b | 0)))   mdiff_transformer.py:219-247
+        LADIFF_TRY(launch_ca_stylize(nval + (size_t)l * B2 * D, L.ca_proj.norm.b, tl, DEN_OFF_CA_MOD, DEN_STEP_STRIDE, d_step,
+                                     counts, Bs, T, M, u, s));
+        {
+            GemmArgs g = lin(u, D, L.ca_proj.out, P[1], D, M, D, D);
+            g.res = P[2]; g.ldres = D;
+            LADIFF_TRY(launch_gemm(g, s));
+        }
+        // ---- ffn: x + out(SiLU(AdaLN(linear2(GELU(linear1 x)))))   mdiff_transformer.py:259-262
+        LADIFF_TRY(launch_gemm(lin(P[1], D, L.ffn1, hid, FF, M, FF, D, ACT_GELU), s));
+        {
+            GemmArgs g = lin(hid, FF, L.ffn2, u, D, M, D, FF);
+            g.ln_g = L.ffn_proj.norm.g; g.ln_b = L.ffn_proj.norm.b;
+            g.mod = tl + DEN_OFF_FFN_MOD; g.d_step = d_step; g.mod_stride = DEN_STEP_STRIDE; g.post_act = ACT_SILU;
+            LADIFF_TRY(launch_gemm(g, s));
+        }
+        float* dst = is_in ? SK[l] : P[0];
+        {
+            GemmArgs g = lin(u, D, L.ffn_proj.out, dst, D, M, D, D);
+            g.res = P[1]; g.ldres = D;
+            LADIFF_TRY(launch_gemm(g, s));
+        }
+        cur = dst;
+    }
+    // encoder.norm, then [B2,T,256] out   cross_attention.py:84-85, ladiff_denoiser.py:272,292
+    return launch_layernorm(cur, w.norm.g, w.norm.b, eps, M, s);
+}
+
+}  // namespace ladiff

@@ -1,0 +1,29 @@
+// fp32-input MFMA GEMM with fused prologue / epilogue:  Y = epi( [A | A2] . W^T )
+#pragma once
+#include "common.h"
+
+namespace ladiff {
+
+struct GemmArgs {
+    // operands
+    const float* A = nullptr;  int lda = 0;      // [M, K1]
+    const float* A2 = nullptr; int lda2 = 0;     // optional second K segment [M, K-K1] (skip-connection concat)
+    int K1 = 0;                                  // columns taken from A (== K when A2 == nullptr)
+    const float* W = nullptr;  int ldw = 0;      // [N, K] row-major (nn.Linear.weight layout)
+    const float* bias = nullptr;                 // [N] or null
+    float* Y = nullptr;        int ldy = 0;      // [M, N]
+    int M = 0, N = 0, K = 0;
+    // epilogue, applied in this order
+    int act = ACT_NONE;                          // activation on (acc + bias)
+    const float* res = nullptr; int ldres = 0;   // + residual[M, N]
+    const float* ln_g = nullptr; const float* ln_b = nullptr;    // LayerNorm over the row (needs N == 256)
+    const float* ln2_g = nullptr; const float* ln2_b = nullptr;  // second LayerNorm (decoder.norm after norm3)
+    const float* mod = nullptr;                  // AdaLN: v*(1+scale)+shift, scale|shift = mod + *d_step*mod_stride
+    const int32_t* d_step = nullptr; int mod_stride = 0;
+    int post_act = ACT_NONE;                     // activation after LN / modulation
+    const int32_t* row_len = nullptr; int rows_per_item = 0;     // zero rows with (row % rows_per_item) >= row_len[row / rows_per_item]
+};
+
+int launch_gemm(const GemmArgs& a, hipStream_t stream);
+
+}  // namespace ladiff

@@ -1,0 +1,309 @@
+// fp32-input MFMA GEMM for gfx950:  Y[M,N] = epi( [A | A2][M,K] . W[N,K]^T )
+//
+// Why fp32 MFMA: the parity gate (decoded frames within 1e-3 of the fp32 reference after 50
+// guided steps on random-init weights, where latents reach |x| ~ 300) needs fp32-class products
+// (bf16 misses it by ~50x).  v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 are
+// exact fp32 fma chains at 64 FLOP/clk/SIMD (157 TF/s chip peak).
+//
+// Structure
+//   * block tile BM x BN, K-step 32, WM x WN waves, each wave RM x RN MFMA tiles (MT = 32 or 16);
+//   * both operands are K-contiguous ("NT" GEMM: activations [M,K], nn.Linear weights [N,K]), staged
+//     global -> registers -> LDS as 16-byte chunks, double-buffered in LDS, one barrier per K-step;
+//   * LDS rows are 32 floats (128 B, no padding); chunk c of row r is stored at chunk slot
+//     c ^ ((r >> 1) & 7), which makes the ds_read_b128 fragment reads of both MFMA shapes
+//     bank-conflict free (16-lane read groups touch 16 distinct 16-byte slots of the 256-byte bank row);
+//   * the MFMA k index is permuted (lane group g reads 4 consecutive k and feeds them to 4 MFMAs);
+//     A and B use the same permutation, so the sum over k is unchanged;
+//   * epilogue in registers: bias, activation, residual, LayerNorm over the 256-wide row (when the
+//     block owns whole rows), optional second LayerNorm, AdaLN modulation, activation, row zeroing.
+#include "gemm.h"
+
+namespace ladiff {
+
+constexpr int BK = 32;
+
+template <int MT> struct Mfma;
+template <> struct Mfma<32> {
+    typedef f32x16 Acc;
+    static constexpr int REGS = 16;
+    static constexpr int KGROUP = 8;    // k covered by one 16-byte fragment read (2 lane groups x 4)
+    __device__ static __forceinline__ Acc zero() { Acc a; for (int i = 0; i < 16; ++i) a[i] = 0.f; return a; }
+    __device__ static __forceinline__ Acc mma(float a, float b, Acc c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ int lane_row(int lane) { return lane & 31; }   // A/B fragment row
+    __device__ static __forceinline__ int lane_kgrp(int lane) { return lane >> 5; }  // which 4-k chunk
+    __device__ static __forceinline__ int acc_row(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+    __device__ static __forceinline__ int acc_col(int lane) { return lane & 31; }
+};
+template <> struct Mfma<16> {
+    typedef f32x4 Acc;
+    static constexpr int REGS = 4;
+    static constexpr int KGROUP = 16;   // 4 lane groups x 4
+    __device__ static __forceinline__ Acc zero() { Acc a; for (int i = 0; i < 4; ++i) a[i] = 0.f; return a; }
+    __device__ static __forceinline__ Acc mma(float a, float b, Acc c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ int lane_row(int lane) { return lane & 15; }
+    __device__ static __forceinline__ int lane_kgrp(int lane) { return lane >> 4; }
+    __device__ static __forceinline__ int acc_row(int lane, int r) { return 4 * (lane >> 4) + r; }
+    __device__ static __forceinline__ int acc_col(int lane) { return lane & 15; }
+};
+
+// float offset of 16-byte chunk c (0..7) of row r inside a [rows][32] fp32 LDS tile
+__device__ __forceinline__ int lds_off(int r, int c) { return r * BK + ((c ^ ((r >> 1) & 7)) << 2); }
+
+template <int BM, int BN, int WM, int WN, int MT, bool LN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs p) {
+    typedef Mfma<MT> MM;
+    typedef typename MM::Acc Acc;
+    constexpr int NT = WM * WN * 64;
+    constexpr int TMW = BM / WM, TNW = BN / WN;       // wave tile
+    constexpr int RM = TMW / MT, RN = TNW / MT;       // MFMA tiles per wave
+    constexpr int CHA = BM * (BK / 4), CHB = BN * (BK / 4);   // 16-byte chunks per stage
+    constexpr int LA = (CHA + NT - 1) / NT, LB = (CHB + NT - 1) / NT;
+    constexpr int STAGE = (BM + BN) * BK;
+    static_assert(TMW % MT == 0 && TNW % MT == 0, "wave tile must be a multiple of the MFMA tile");
+    static_assert(!LN || BN == 256, "LayerNorm epilogue needs the block to own whole 256-wide rows");
+
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int nbn = (p.N + BN - 1) / BN;
+    const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
+    const int row0 = bm * BM, col0 = bn * BN;
+
+    Acc acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) acc[i][j] = MM::zero();
+
+    f32x4 ra[LA], rb[LB];
+    const int nk = p.K / BK;
+
+    auto gload = [&](int kt) {
+        const int k0 = kt * BK;
+        const float* abase; int ald; int ak;
+        if (k0 < p.K1) { abase = p.A; ald = p.lda; ak = k0; } else { abase = p.A2; ald = p.lda2; ak = k0 - p.K1; }
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int id = tid + i * NT;
+            const int r = id >> 3, c = id & 7;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((CHA % NT == 0 || id < CHA) && row0 + r < p.M) v = ld4(abase + (size_t)(row0 + r) * ald + ak + c * 4);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int id = tid + i * NT;
+            const int r = id >> 3, c = id & 7;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((CHB % NT == 0 || id < CHB) && col0 + r < p.N) v = ld4(p.W + (size_t)(col0 + r) * p.ldw + k0 + c * 4);
+            rb[i] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* sa = lds + buf * STAGE;
+        float* sb = sa + BM * BK;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int id = tid + i * NT;
+            if (CHA % NT == 0 || id < CHA) st4(sa + lds_off(id >> 3, id & 7), ra[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int id = tid + i * NT;
+            if (CHB % NT == 0 || id < CHB) st4(sb + lds_off(id >> 3, id & 7), rb[i]);
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    const int frow = MM::lane_row(lane);
+    const int fk = MM::lane_kgrp(lane);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const float* sa = lds + cur * STAGE + (wm * TMW) * BK;
+        const float* sb = lds + cur * STAGE + BM * BK + (wn * TNW) * BK;
+#pragma unroll
+        for (int g = 0; g < BK / MM::KGROUP; ++g) {
+            const int c = g * (MM::KGROUP / 4) + fk;
+            f32x4 fa[RM], fb[RN];
+#pragma unroll
+            for (int i = 0; i < RM; ++i) fa[i] = ld4(sa + lds_off(i * MT + frow, c));
+#pragma unroll
+            for (int j = 0; j < RN; ++j) fb[j] = ld4(sb + lds_off(j * MT + frow, c));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+#pragma unroll
+                    for (int j = 0; j < RN; ++j) acc[i][j] = MM::mma(fa[i][e], fb[j][e], acc[i][j]);
+        }
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue (registers)
+    const int arow_base = row0 + wm * TMW;
+    const int acol_base = col0 + wn * TNW + MM::acc_col(lane);
+
+    float bcol[RN];
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        const int gc = acol_base + j * MT;
+        bcol[j] = (p.bias != nullptr && gc < p.N) ? p.bias[gc] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int r = 0; r < MM::REGS; ++r) {
+            const int gr = arow_base + i * MT + MM::acc_row(lane, r);
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {
+                const int gc = acol_base + j * MT;
+                float v = act_apply(acc[i][j][r] + bcol[j], p.act);
+                if (p.res != nullptr && gr < p.M && gc < p.N) v += p.res[(size_t)gr * p.ldres + gc];
+                acc[i][j][r] = v;
+            }
+        }
+
+    if constexpr (LN) {
+        // LayerNorm over the 256 columns of each row; the row lives in RN tiles x MT lanes x WN waves.
+        float* red = lds;   // [2][BM][WN], safe: every wave passed the last barrier of the K loop
+        const float* mod = nullptr;
+        if (p.mod != nullptr) mod = p.mod + (size_t)(p.d_step ? *p.d_step : 0) * p.mod_stride;
+        for (int pass = 0; pass < (p.ln2_g != nullptr ? 2 : 1); ++pass) {
+            const float* g = pass == 0 ? p.ln_g : p.ln2_g;
+            const float* b = pass == 0 ? p.ln_b : p.ln2_b;
+            float mean[RM][MM::REGS], rstd[RM][MM::REGS];
+            if (pass == 1) __syncthreads();
+            // mean
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int r = 0; r < MM::REGS; ++r) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < RN; ++j) s += acc[i][j][r];
+                    s = group_sum<MT>(s);
+                    if (WN > 1) {
+                        if (MM::acc_col(lane) == 0) red[(wm * TMW + i * MT + MM::acc_row(lane, r)) * WN + wn] = s;
+                    } else mean[i][r] = s * (1.f / 256.f);
+                }
+            if (WN > 1) {
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+#pragma unroll
+                    for (int r = 0; r < MM::REGS; ++r) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int w = 0; w < WN; ++w) s += red[(wm * TMW + i * MT + MM::acc_row(lane, r)) * WN + w];
+                        mean[i][r] = s * (1.f / 256.f);
+                    }
+            }
+            // variance (two-pass, like the fp32 reference kernel)
+            float* red2 = red + BM * WN;
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int r = 0; r < MM::REGS; ++r) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < RN; ++j) { const float d = acc[i][j][r] - mean[i][r]; s += d * d; }
+                    s = group_sum<MT>(s);
+                    if (WN > 1) {
+                        if (MM::acc_col(lane) == 0) red2[(wm * TMW + i * MT + MM::acc_row(lane, r)) * WN + wn] = s;
+                    } else rstd[i][r] = rsqrtf(s * (1.f / 256.f) + LN_EPS);
+                }
+            if (WN > 1) {
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+#pragma unroll
+                    for (int r = 0; r < MM::REGS; ++r) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int w = 0; w < WN; ++w) s += red2[(wm * TMW + i * MT + MM::acc_row(lane, r)) * WN + w];
+                        rstd[i][r] = rsqrtf(s * (1.f / 256.f) + LN_EPS);
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {
+                const int gc = acol_base + j * MT;
+                const float gg = g[gc], bb = b[gc];
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+#pragma unroll
+                    for (int r = 0; r < MM::REGS; ++r)
+                        acc[i][j][r] = (acc[i][j][r] - mean[i][r]) * rstd[i][r] * gg + bb;
+            }
+        }
+        if (mod != nullptr) {
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {
+                const int gc = acol_base + j * MT;
+                const float sc = 1.f + mod[gc], sh = mod[256 + gc];
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+#pragma unroll
+                    for (int r = 0; r < MM::REGS; ++r) acc[i][j][r] = acc[i][j][r] * sc + sh;
+            }
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int r = 0; r < MM::REGS; ++r) {
+            const int gr = arow_base + i * MT + MM::acc_row(lane, r);
+            if (gr >= p.M) continue;
+            bool zero = false;
+            if (p.row_len != nullptr) zero = (gr % p.rows_per_item) >= p.row_len[gr / p.rows_per_item];
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {
+                const int gc = acol_base + j * MT;
+                if (gc < p.N) {
+                    float v = act_apply(acc[i][j][r], p.post_act);
+                    p.Y[(size_t)gr * p.ldy + gc] = zero ? 0.f : v;
+                }
+            }
+        }
+}
+
+template <int BM, int BN, int WM, int WN, int MT, bool LN>
+static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
+    const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, MT, LN>), dim3(nbm * nbn), dim3(WM * WN * 64), 0, stream, a);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_gemm(const GemmArgs& a0, hipStream_t stream) {
+    GemmArgs a = a0;
+    if (a.A2 == nullptr) a.K1 = a.K;
+    LADIFF_CHECK_ARG(a.A && a.W && a.Y && a.M >= 0 && a.N > 0 && a.K > 0);
+    if (a.M == 0) return 0;
+    if (a.K % BK != 0 || a.K1 % BK != 0 || a.K1 > a.K) return LADIFF_ERR_SHAPE;
+    if ((a.lda % 4) || (a.ldw % 4) || (a.A2 && (a.lda2 % 4))) return LADIFF_ERR_SHAPE;   // 16-byte chunk loads
+    const bool ln = a.ln_g != nullptr;
+    if (!ln && (a.ln2_g || a.mod)) return LADIFF_ERR_ARG;
+    if (ln) {
+        if (a.N != 256 || a.ln_b == nullptr) return LADIFF_ERR_SHAPE;
+        if (a.M >= 4096) return launch_cfg<64, 256, 2, 1, 32, true>(a, stream);
+        return launch_cfg<16, 256, 1, 4, 16, true>(a, stream);
+    }
+    if (a.M >= 4096) return launch_cfg<128, 128, 2, 2, 32, false>(a, stream);
+    if (a.N >= 512) return launch_cfg<64, 64, 2, 2, 32, false>(a, stream);
+    return launch_cfg<32, 32, 2, 2, 16, false>(a, stream);
+}
+
+}  // namespace ladiff

@@ -1,0 +1,30 @@
+// Launchers of the non-GEMM kernels (rowops.hip, attention.hip).
+#pragma once
+#include "common.h"
+
+namespace ladiff {
+
+// rowops.hip
+int launch_layernorm(const float* x, const float* g, const float* b, float* y, int M, hipStream_t s);
+int launch_ca_stylize(const float* nval, const float* beta, const float* tables, int mod_off, int step_stride,
+                      const int32_t* d_step, const int32_t* counts, int Bs, int T, int M, float* u, hipStream_t s);
+int launch_add_pe(const float* sample, const float* pe, int Bs, int dup, int T, float* x, hipStream_t s);
+int launch_broadcast_pe(const float* pe, int B, int F, float* x, hipStream_t s);
+int launch_relu(const float* x, float* y, size_t n, hipStream_t s);
+int launch_silu(const float* x, float* y, size_t n, hipStream_t s);
+int launch_sinusoid(const int64_t* t, int n, float* out, hipStream_t s);
+int launch_cfg_step(const float* eps, float* lat, const float* coef, const int32_t* d_step, const float* noise,
+                    float g, int cfg, int B, int T, hipStream_t s);
+int launch_advance(int32_t* d_step, hipStream_t s);
+int launch_init_latents(const float* noise, const int32_t* counts, float sigma, float* lat, int B, int T, hipStream_t s);
+int launch_finalize_latents(const float* lat, const int32_t* counts, float* z, int B, int T, hipStream_t s);
+
+// attention.hip
+int launch_denoiser_self_attention(const float* qkv, const float* text_kv, const float* tables, int kv_off,
+                                   int step_stride, const int32_t* d_step, const int32_t* counts, int Bs, int B2,
+                                   int T, float* out, hipStream_t s);
+int launch_decoder_self_attention(const float* qkv, const int32_t* lengths, float* out, int B, int F, hipStream_t s);
+int launch_decoder_cross_attention(const float* q, const float* kv, const int32_t* counts, float* out, int B, int F,
+                                   int T, hipStream_t s);
+
+}  // namespace ladiff

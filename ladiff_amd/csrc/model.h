@@ -1,0 +1,29 @@
+// Host-side sequencing entry points shared by denoiser.hip / decoder.hip / api.hip.
+#pragma once
+#include "gemm.h"
+#include "kernels.h"
+#include "weights.h"
+
+namespace ladiff {
+
+// time-table layout: tables[step][layer][1536] = { ca scale|shift (512), ffn scale|shift (512), time-token K|V (512) }
+constexpr int DEN_OFF_CA_MOD = 0;
+constexpr int DEN_OFF_FFN_MOD = 2 * D;
+constexpr int DEN_OFF_TIME_KV = 4 * D;
+constexpr int DEN_LAYER_STRIDE = 6 * D;
+constexpr int DEN_STEP_STRIDE = NL * DEN_LAYER_STRIDE;
+
+size_t den_tables_floats(int n_steps);
+size_t den_text_cache_floats(int B2);
+size_t den_forward_ws_floats(int B2, int T);
+int denoiser_time_tables(const DenoiserW& w, const float* sinus, int n, float* tables, float* ws, size_t ws_floats, hipStream_t s);
+int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, float* cache, float* ws, size_t ws_floats, hipStream_t s);
+int denoiser_forward(const DenoiserW& w, const float* tables, const int32_t* d_step, const float* cache,
+                     const float* sample, int Bs, int dup, int T, const int32_t* counts, float* eps, float* ws,
+                     size_t ws_floats, hipStream_t s);
+
+size_t dec_ws_floats(int B, int F, int T);
+int vae_decode(const DecoderW& w, const float* z, const int32_t* lengths, const int32_t* counts, int B, int F, int T,
+               int C, float* feats, float* ws, size_t ws_floats, hipStream_t s);
+
+}  // namespace ladiff

@@ -1,0 +1,238 @@
+// Row-wise / elementwise kernels (HBM- or latency-bound; one wave per 256-float row, 16-byte accesses).
+#include "kernels.h"
+
+namespace ladiff {
+
+constexpr int ROWS_PER_BLOCK = 4;   // 256 threads = 4 waves = 4 rows
+
+// mean / rstd of a 256-wide row held as one f32x4 per lane
+__device__ __forceinline__ void row_stats(const f32x4 v, float& mean, float& rstd) {
+    float s = group_sum<64>(v[0] + v[1] + v[2] + v[3]);
+    mean = s * (1.f / 256.f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float d = v[i] - mean; q += d * d; }
+    q = group_sum<64>(q);
+    rstd = rsqrtf(q * (1.f / 256.f) + LN_EPS);
+}
+
+// y = LayerNorm(x)   (nn.LayerNorm(256), eps 1e-5)
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ b, float* __restrict__ y, int M) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int c = (threadIdx.x & 63) * 4;
+    if (row >= M) return;
+    f32x4 v = ld4(x + (size_t)row * D + c);
+    float mean, rstd;
+    row_stats(v, mean, rstd);
+    const f32x4 gg = ld4(g + c), bb = ld4(b + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i];
+    st4(y + (size_t)row * D + c, v);
+}
+
+int launch_layernorm(const float* x, const float* g, const float* b, float* y, int M, hipStream_t s) {
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, x, g, b, y, M);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+// Cross-attention StylizationBlock input for ONE text token (mdiff_transformer.py:234-246, :158-162):
+// with N = 1, softmax(key) over the token axis is exactly 1 and sum_d softmax(query)_d = 1, so the
+// attention output of a valid latent row is the value vector of its sample and of a padded row is 0.
+//   valid row : u = SiLU( LN(v_b) * (1 + scale_t) + shift_t )      (LN(v_b) cached in `nval`)
+//   padded row: u = SiLU( beta    * (1 + scale_t) + shift_t )      (LN(0) = beta)
+__global__ __launch_bounds__(256) void ca_stylize_kernel(const float* __restrict__ nval /*[B2,256]*/,
+                                                         const float* __restrict__ beta,
+                                                         const float* __restrict__ tables, int mod_off,
+                                                         int step_stride, const int32_t* __restrict__ d_step,
+                                                         const int32_t* __restrict__ counts, int Bs, int T, int M,
+                                                         float* __restrict__ u) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int c = (threadIdx.x & 63) * 4;
+    if (row >= M) return;
+    const int b2 = row / T, t = row % T;
+    const bool valid = counts == nullptr || t < counts[b2 % Bs];
+    const float* mod = tables + (size_t)(*d_step) * step_stride + mod_off;
+    const f32x4 sc = ld4(mod + c), sh = ld4(mod + 256 + c);
+    f32x4 v = valid ? ld4(nval + (size_t)b2 * D + c) : ld4(beta + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = silu(v[i] * (1.f + sc[i]) + sh[i]);
+    st4(u + (size_t)row * D + c, v);
+}
+
+int launch_ca_stylize(const float* nval, const float* beta, const float* tables, int mod_off, int step_stride,
+                      const int32_t* d_step, const int32_t* counts, int Bs, int T, int M, float* u, hipStream_t s) {
+    hipLaunchKernelGGL(ca_stylize_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, nval, beta,
+                       tables, mod_off, step_stride, d_step, counts, Bs, T, M, u);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+// x[b2,t,:] = sample[b2 % Bs, t, :] + pe[t, :]     (ladiff.py:472-474 duplication + position_encoding.py:158)
+__global__ __launch_bounds__(256) void add_pe_kernel(const float* __restrict__ sample, const float* __restrict__ pe,
+                                                     int Bs, int T, int M, float* __restrict__ x) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int c = (threadIdx.x & 63) * 4;
+    if (row >= M) return;
+    const int b2 = row / T, t = row % T;
+    f32x4 v = ld4(sample + ((size_t)(b2 % Bs) * T + t) * D + c);
+    const f32x4 p = ld4(pe + (size_t)t * D + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += p[i];
+    st4(x + (size_t)row * D + c, v);
+}
+
+int launch_add_pe(const float* sample, const float* pe, int Bs, int dup, int T, float* x, hipStream_t s) {
+    const int M = Bs * dup * T;
+    hipLaunchKernelGGL(add_pe_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, sample, pe, Bs, T, M, x);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+// q0[b,f,:] = pe[f,:]   (queries = zeros + learned PE, ladiff_vae.py:299,:334)
+__global__ __launch_bounds__(256) void broadcast_pe_kernel(const float* __restrict__ pe, int F, int M, float* __restrict__ x) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int c = (threadIdx.x & 63) * 4;
+    if (row >= M) return;
+    st4(x + (size_t)row * D + c, ld4(pe + (size_t)(row % F) * D + c));
+}
+
+int launch_broadcast_pe(const float* pe, int B, int F, float* x, hipStream_t s) {
+    const int M = B * F;
+    hipLaunchKernelGGL(broadcast_pe_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, pe, F, M, x);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+// y = relu(x), flat
+__global__ __launch_bounds__(256) void relu_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 v = ld4(x + i * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+    st4(y + i * 4, v);
+}
+int launch_relu(const float* x, float* y, size_t n, hipStream_t s) {
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(relu_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, y, n4);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+// y = silu(x), flat
+__global__ __launch_bounds__(256) void silu_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 v = ld4(x + i * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = silu(v[k]);
+    st4(y + i * 4, v);
+}
+int launch_silu(const float* x, float* y, size_t n, hipStream_t s) {
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(silu_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, y, n4);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+// Timesteps(768, flip_sin_to_cos=True, freq_shift=0): out[n, 0:384] = cos(t f_i), out[n, 384:768] = sin(t f_i),
+// f_i = exp(-ln(1e4) i / 384)   (tools/embeddings.py:263-280)
+__global__ __launch_bounds__(384) void sinusoid_kernel(const int64_t* __restrict__ t, float* __restrict__ out) {
+    // fp32 op order of the reference (exponent, frequency and angle are rounded to fp32 exactly where torch rounds
+    // them); exp / cos / sin are evaluated in fp64 and rounded once, i.e. correctly rounded fp32 results.
+    const int n = blockIdx.x, i = threadIdx.x;
+    const float ex = (-9.210340371976184f * (float)i) / 384.f;
+    const float f = (float)exp((double)ex);
+    const float a = (float)t[n] * f;
+    out[(size_t)n * 768 + i] = (float)cos((double)a);
+    out[(size_t)n * 768 + 384 + i] = (float)sin((double)a);
+}
+int launch_sinusoid(const int64_t* t, int n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(sinusoid_kernel, dim3(n), dim3(384), 0, s, t, out);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+// Classifier-free guidance + one scheduler step (ladiff.py:487-492), elementwise on [B,T,256].
+__global__ __launch_bounds__(256) void cfg_step_kernel(const float* __restrict__ eps, float* __restrict__ lat,
+                                                       const float* __restrict__ coef, const int32_t* __restrict__ d_step,
+                                                       const float* __restrict__ noise, float g, int cfg, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int step = *d_step;
+    const float* c = coef + (size_t)step * LADIFF_COEF_STRIDE;
+    const float sa = c[0], sb = c[1], kx0 = c[2], kx = c[3], ke = c[4], kn = c[5];
+    f32x4 e = ld4(eps + i * 4);
+    if (cfg) {
+        const f32x4 ec = ld4(eps + (n4 + i) * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e[k] = e[k] + g * (ec[k] - e[k]);
+    }
+    f32x4 x = ld4(lat + i * 4);
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (noise != nullptr && kn != 0.f) z = ld4(noise + ((size_t)step * n4 + i) * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float x0 = (x[k] - sb * e[k]) / sa;
+        x[k] = kx0 * x0 + kx * x[k] + ke * e[k] + kn * z[k];
+    }
+    st4(lat + i * 4, x);
+}
+int launch_cfg_step(const float* eps, float* lat, const float* coef, const int32_t* d_step, const float* noise,
+                    float g, int cfg, int B, int T, hipStream_t s) {
+    const size_t n4 = (size_t)B * T * D / 4;
+    hipLaunchKernelGGL(cfg_step_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, eps, lat, coef, d_step, noise, g, cfg, n4);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void advance_kernel(int32_t* d_step) { if (threadIdx.x == 0) *d_step += 1; }
+int launch_advance(int32_t* d_step, hipStream_t s) {
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, s, d_step);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+// latents = noise * valid * sigma   (ladiff.py:380-390, :407)
+__global__ __launch_bounds__(256) void init_latents_kernel(const float* __restrict__ noise, const int32_t* __restrict__ counts,
+                                                           float sigma, int T, int M, float* __restrict__ lat) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int c = (threadIdx.x & 63) * 4;
+    if (row >= M) return;
+    const int b = row / T, t = row % T;
+    f32x4 v = ld4(noise + (size_t)row * D + c);
+    const bool valid = counts == nullptr || t < counts[b];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = valid ? v[i] * sigma : 0.f;
+    st4(lat + (size_t)row * D + c, v);
+}
+int launch_init_latents(const float* noise, const int32_t* counts, float sigma, float* lat, int B, int T, hipStream_t s) {
+    const int M = B * T;
+    hipLaunchKernelGGL(init_latents_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, noise, counts, sigma, T, M, lat);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+// z[t,b,:] = latents[b,t,:] with rows t >= counts[b] zeroed   (ladiff.py:500, :562-566)
+__global__ __launch_bounds__(256) void finalize_latents_kernel(const float* __restrict__ lat, const int32_t* __restrict__ counts,
+                                                               int B, int T, int M, float* __restrict__ z) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int c = (threadIdx.x & 63) * 4;
+    if (row >= M) return;
+    const int b = row / T, t = row % T;
+    f32x4 v = ld4(lat + (size_t)row * D + c);
+    const bool valid = counts == nullptr || t < counts[b];
+    if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    st4(z + ((size_t)t * B + b) * D + c, v);
+}
+int launch_finalize_latents(const float* lat, const int32_t* counts, float* z, int B, int T, hipStream_t s) {
+    const int M = B * T;
+    hipLaunchKernelGGL(finalize_latents_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, lat, counts, B, T, M, z);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace ladiff

@@ -1,0 +1,219 @@
+"""`LADIFF`-compatible owner of the sampling loop (SURVEY.md §8b "Loop owner").
+
+The reference's loop is a *method* of its LightningModule (`LADIFF._diffusion_reverse`,
+`src/ladiff/models/modeltype/ladiff.py:333-571`), not a plugin, so the drop-in for it is a class with the same
+method names and call behaviour: `forward(batch)` (ladiff.py:250-308), `_diffusion_reverse(text_emb, lengths)`,
+`gen_from_latent(batch)` (:310-318) and the attributes callers touch (`sample_mean`, `fact`, `times`, `cfg`,
+`feats2joints`, `guidance_scale`, `do_classifier_free_guidance`).  The whole reverse loop - hoisted time/text
+tables, N x (denoiser, guidance, scheduler step) captured as one hipGraph step replayed N times, final masking -
+is ONE call into libladiff_hip.so; the decoder is a second one.  Nothing here falls back to PyTorch math.
+
+Out of scope (not built): training/eval steps, metrics, losses, the CLIP text encoder (pass any callable
+`texts -> [len(texts),1,768]`), `feats2joints` (pass the datamodule's).
+"""
+import importlib
+import math
+import time
+from ctypes import c_void_p, byref
+
+import torch
+from torch import nn
+
+from . import _lib
+from .schedulers import DDIMScheduler, DDPMScheduler, timestep_sinusoid
+
+_TARGET_ALIASES = {
+    # reference dotted paths -> this package (so an unmodified reference YAML also resolves)
+    "ladiff.models.architectures.ladiff_denoiser.LADiffDenoiser": "ladiff_amd.modules.LADiffDenoiser",
+    "ladiff.models.architectures.ladiff_vae.LADiffVae": "ladiff_amd.modules.LADiffVae",
+    "diffusers.DDIMScheduler": "ladiff_amd.schedulers.DDIMScheduler",
+    "diffusers.DDPMScheduler": "ladiff_amd.schedulers.DDPMScheduler",
+}
+
+
+def _cfg_get(node, key, default=None):
+    if node is None:
+        return default
+    if isinstance(node, dict):
+        return node.get(key, default)
+    try:
+        return node[key] if key in node else default
+    except TypeError:
+        return getattr(node, key, default)
+
+
+def instantiate_from_config(config):
+    """`{target: "pkg.mod.Class", params: {...}}` -> object (the reference's plugin API, src/ladiff/config.py:16-33)."""
+    target = _cfg_get(config, "target")
+    if target is None:
+        raise KeyError("Expected key `target` to instantiate.")
+    target = _TARGET_ALIASES.get(target, target)
+    module, cls = target.rsplit(".", 1)
+    params = _cfg_get(config, "params", {}) or {}
+    return getattr(importlib.import_module(module), cls)(**dict(params))
+
+
+def remove_padding(tensors, lengths):
+    return [t[:l] for t, l in zip(tensors, lengths)]
+
+
+class LADIFF(nn.Module):
+    def __init__(self, cfg=None, datamodule=None, *, denoiser=None, vae=None, scheduler=None, text_encoder=None,
+                 guidance_scale=None, num_inference_timesteps=None, eta=None, max_it=None, frame_per_latent=None,
+                 test_efficiency=None, use_graph=True, **kwargs):
+        super().__init__()
+        self.cfg = cfg
+        self.datamodule = datamodule
+        model = _cfg_get(cfg, "model")
+        abl = _cfg_get(_cfg_get(cfg, "TRAIN"), "ABLATION")
+        sch_cfg = _cfg_get(model, "scheduler")
+
+        def pick(explicit, node, key, default):
+            return explicit if explicit is not None else _cfg_get(node, key, default)
+
+        self.guidance_scale = float(pick(guidance_scale, model, "guidance_scale", 7.5))
+        self.num_inference_timesteps = int(pick(num_inference_timesteps, sch_cfg, "num_inference_timesteps", 20))
+        self.eta = float(pick(eta, sch_cfg, "eta", 0.0))
+        self.max_it = int(pick(max_it, abl, "MAX_IT", 5))
+        self.frame_per_latent = int(pick(frame_per_latent, abl, "FRAME_PER_LATENT", 48))
+        self.test_efficiency = bool(pick(test_efficiency, abl, "TEST_EFFICIENCY", False))
+        if _cfg_get(cfg, "ARDIFF", False) or _cfg_get(abl, "JOINT_DISTRO_FIX", False):
+            raise NotImplementedError("ARDIFF / JOINT_DISTRO_FIX branches of _diffusion_reverse are not built")
+        self.denoiser = denoiser if denoiser is not None else instantiate_from_config(_cfg_get(model, "denoiser"))
+        self.vae = vae if vae is not None else instantiate_from_config(_cfg_get(model, "motion_vae"))
+        self.scheduler = scheduler if scheduler is not None else instantiate_from_config(sch_cfg)
+        te_cfg = _cfg_get(model, "text_encoder")
+        self.text_encoder = text_encoder if text_encoder is not None else (
+            instantiate_from_config(te_cfg) if te_cfg is not None else None)
+        self.latent_dim = [self.max_it, 256]
+        self.do_classifier_free_guidance = self.guidance_scale > 1.0
+        self.feats2joints = getattr(datamodule, "feats2joints", None)
+        self.sample_mean = False
+        self.fact = None
+        self.times = []
+        self.use_graph = use_graph
+        self._sampler = None
+        self._stream = None
+        self._plan = None
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def device(self):
+        return next(self.denoiser.parameters()).device
+
+    def __del__(self):
+        try:
+            if self._sampler is not None:
+                _lib.lib().ladiff_sampler_destroy(self._sampler)
+        except Exception:
+            pass
+
+    def _get_plan(self, B, T, n_steps, eta, dev, need_noise):
+        """Persistent device buffers for one (B, T, schedule): hipGraph kernel nodes bake pointers in."""
+        sch = self.scheduler
+        key = (B, T, n_steps, float(eta), str(dev), type(sch).__name__, need_noise)
+        if self._plan is not None and self._plan["key"] == key:
+            return self._plan
+        L = _lib.lib()
+        sch.set_timesteps(n_steps)
+        wsb = L.ladiff_reverse_workspace_bytes(B, T, n_steps)
+        plan = {
+            "key": key,
+            "timesteps": sch.timesteps.clone(),
+            "coef": sch.coef_table(eta).to(dev),
+            "sinus": timestep_sinusoid(sch.timesteps, 768).to(dev),
+            "text": torch.empty(2 * B, 1, 768, dtype=torch.float32, device=dev),
+            "noise": torch.empty(B, T, 256, dtype=torch.float32, device=dev),
+            "counts": torch.empty(B, dtype=torch.int32, device=dev),
+            "step_noise": torch.empty(n_steps, B, T, 256, dtype=torch.float32, device=dev) if need_noise else None,
+            "z": torch.empty(T, B, 256, dtype=torch.float32, device=dev),
+            "ws": _lib.workspace(wsb, dev), "ws_bytes": wsb,
+        }
+        self._plan = plan
+        return plan
+
+    def _counts(self, lengths):
+        return [int(math.ceil(l / self.frame_per_latent)) for l in lengths]
+
+    # ------------------------------------------------------------------ the hot loop
+    def _diffusion_reverse(self, encoder_hidden_states, lengths=None, init_noise=None, step_noise=None):
+        """text_emb [2B,1,768] (unconditional half first), lengths list[int] -> z [max_it, B, 256]  (ladiff.py:333-571)."""
+        if not self.do_classifier_free_guidance:
+            raise NotImplementedError("guidance_scale <= 1 (no classifier-free guidance) is not built")
+        L = _lib.lib()
+        dev = encoder_hidden_states.device
+        if not encoder_hidden_states.is_cuda:
+            raise _lib.LadiffHipError("_diffusion_reverse needs GPU tensors; there is no CPU fallback")
+        B = encoder_hidden_states.shape[0] // 2
+        lengths = [int(l) for l in lengths]
+        counts = self._counts(lengths)
+        T = counts[0] if self.test_efficiency else self.max_it     # ladiff.py:381
+        n = self.num_inference_timesteps
+        sch = self.scheduler
+        sch.set_timesteps(n)
+        n = len(sch.timesteps)
+        need_noise = sch.needs_noise(self.eta)
+        plan = self._get_plan(B, T, n, self.eta, dev, need_noise)
+        if self._stream is None or self._stream.device != dev:
+            self._stream = torch.cuda.Stream(device=dev)
+        if self.use_graph and self._sampler is None:
+            h = c_void_p()
+            _lib.check(L.ladiff_sampler_create(byref(h)))
+            self._sampler = h
+        if init_noise is None:
+            init_noise = torch.randn(B, T, 256, device=dev, dtype=torch.float32)       # ladiff.py:380-385
+        if need_noise and step_noise is None:
+            step_noise = torch.randn(n, B, T, 256, device=dev, dtype=torch.float32)
+        wt = self.denoiser._weight_table()
+        cur = torch.cuda.current_stream(dev)
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            plan["text"].copy_(encoder_hidden_states.reshape(2 * B, 1, 768))
+            plan["noise"].copy_(init_noise)
+            plan["counts"].copy_(torch.tensor(counts, dtype=torch.int32), non_blocking=False)
+            if need_noise:
+                plan["step_noise"].copy_(step_noise)
+            _lib.check(L.ladiff_diffusion_reverse(
+                self._sampler if self.use_graph else None, wt.array, _lib.ptr(plan["text"]), _lib.ptr(plan["noise"]),
+                None if self.test_efficiency else plan["counts"].data_ptr(), _lib.ptr(plan["sinus"]),
+                _lib.ptr(plan["coef"]), _lib.ptr(plan["step_noise"]) if need_noise else None, self.guidance_scale,
+                float(sch.init_noise_sigma), B, T, n, _lib.ptr(plan["z"]), _lib.ptr(plan["ws"]), plan["ws_bytes"],
+                self._stream.cuda_stream))
+        cur.wait_stream(self._stream)
+        return plan["z"].clone()
+
+    # ------------------------------------------------------------------ callers' surface
+    def sample(self, text_emb, lengths, init_noise=None, step_noise=None):
+        """text embeddings -> (z [max_it,B,256], feats [B,max(len),nfeats]): ladiff.py:266 + :283."""
+        z = self._diffusion_reverse(text_emb, lengths, init_noise=init_noise, step_noise=step_noise)
+        feats = self.vae.decode(z, lengths)
+        return z, feats
+
+    def forward(self, batch, latentwise_gen=None, plot_att_map=None):
+        texts, lengths = batch["text"], batch["length"]
+        if self.text_encoder is None or self.feats2joints is None:
+            raise RuntimeError("LADIFF.forward needs a text_encoder callable and datamodule.feats2joints; "
+                               "use .sample(text_emb, lengths) for embeddings -> features")
+        start = time.time()
+        texts = [""] * len(texts) + list(texts)                     # ladiff.py:258-264
+        text_emb = self.text_encoder(texts)
+        z = self._diffusion_reverse(text_emb, lengths)
+        with torch.no_grad():
+            if latentwise_gen:                                      # ladiff.py:274-283
+                lengths = list(lengths) * self.max_it
+                z = z.repeat(1, self.max_it, 1)
+                for idx in range(self.max_it):
+                    if latentwise_gen == "fw":
+                        z[idx + 1:, idx, :] = 0
+                    elif latentwise_gen == "bw":
+                        z[:self.max_it - (idx + 1), idx, :] = 0
+            feats_rst = self.vae.decode(z, lengths, plot_att_map=plot_att_map, latentwise_gen=latentwise_gen)
+        torch.cuda.synchronize()
+        self.times.append(time.time() - start)
+        joints = self.feats2joints(feats_rst.detach().cpu())
+        return remove_padding(joints, lengths)
+
+    def gen_from_latent(self, batch):
+        feats_rst = self.vae.decode(batch["latent"], batch["length"])
+        joints = self.feats2joints(feats_rst.detach().cpu())
+        return remove_padding(joints, batch["length"])

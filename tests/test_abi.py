@@ -1,0 +1,144 @@
+"""CPU-side checks of the C-ABI boundary: the library builds/loads, exports every symbol the header declares,
+and its weight tables name exactly the reference's state-dict keys.  No compute calls (no GPU here)."""
+import os
+import re
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from ladiff_amd import _lib, schema
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from ladiff_amd import build
+    build.build()
+    return _lib.lib()
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "ladiff_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ladiff_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree(lib):
+    declared = header_functions()
+    assert declared == sorted(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/ladiff_hip.h but not exported"
+
+
+def test_version_and_errors(lib):
+    assert lib.ladiff_version() == 1
+    assert lib.ladiff_error_string(0) == b"ok"
+    assert b"workspace" in lib.ladiff_error_string(-3)
+
+
+def test_weight_tables_match_reference_schema(lib):
+    den = _lib.param_names("denoiser")
+    assert den == list(schema.denoiser_schema())            # same names, same order, all 360 tensors
+    vs = schema.vae_schema(263)
+    dec = _lib.param_names("decoder")
+    assert sorted(dec) == sorted(schema.vae_decode_keys(vs))
+    assert len(dec) == 175
+
+
+def test_workspace_queries(lib):
+    assert lib.ladiff_denoiser_tables_floats(50) == 50 * 9 * 1536
+    assert lib.ladiff_denoiser_text_cache_floats(256) == 256 * 256 + 9 * 256 * 768
+    assert lib.ladiff_reverse_workspace_bytes(128, 5, 50) > 0
+    assert lib.ladiff_decoder_workspace_bytes(128, 196, 5, 263) >= 128 * 196 * 4096 * 4
+
+
+def test_argument_errors_do_not_touch_the_gpu(lib):
+    assert lib.ladiff_layernorm(None, None, None, None, 4, None) == -1
+    assert lib.ladiff_gemm(None, 0, None, 0, 0, None, 0, None, None, 0, None, None, None, 0, 1, 1, 32, 0, None) == -1
+
+
+ABL = SimpleNamespace(SKIP_CONNECT=True, VAE_TYPE="actor", DIFF_PE_TYPE="mld", PE_TYPE="mld", IDEA="ard",
+                      MD_TRANS=True, TEST_EFFICIENCY=False, MLP_DIST=False, DVAE=False, PERCENTAGE_NOISED=0.0,
+                      MAX_IT=5, FRAME_PER_LATENT=48, JOINT_DISTRO_FIX=False, LAD=True)
+DEN_KW = dict(nfeats=263, condition="text", latent_dim=[7, 256], ff_size=1024, num_layers=9, num_heads=4,
+              dropout=0.1, normalize_before=False, activation="gelu", flip_sin_to_cos=True,
+              return_intermediate_dec=False, position_embedding="learned", arch="trans_enc", freq_shift=0,
+              guidance_scale=7.5, guidance_uncondp=0.1, text_encoded_dim=768, nclasses=10)
+VAE_KW = dict(nfeats=263, latent_dim=[7, 256], ff_size=1024, num_layers=9, num_heads=4, dropout=0.1,
+              arch="encoder_decoder", normalize_before=False, activation="gelu", position_embedding="learned")
+
+
+def test_modules_have_reference_state_dict_schema():
+    from ladiff_amd import LADiffDenoiser, LADiffVae, synthetic as syn
+    den = LADiffDenoiser(ABL, **DEN_KW)
+    sd = den.state_dict()
+    assert len(sd) == 360 and sum(v.numel() for v in sd.values()) == 18426880
+    den.load_state_dict(syn.denoiser_weights(), strict=True)
+    vae = LADiffVae(ABL, **VAE_KW)
+    sv = vae.state_dict()
+    assert len(sv) == 297 and sum(v.numel() for v in sv.values()) == 18034183
+    vae.load_state_dict(syn.vae_weights(263), strict=True)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    from ladiff_amd import LADiffDenoiser, LADiffVae
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    den = LADiffDenoiser(ABL, **DEN_KW)
+    with pytest.raises(_lib.LadiffHipError):
+        den(torch.zeros(2, 5, 256), torch.tensor(1), torch.zeros(2, 1, 768), max_iter_elements=torch.tensor([5, 5]))
+    vae = LADiffVae(ABL, **VAE_KW)
+    with pytest.raises(_lib.LadiffHipError):
+        vae.decode(torch.zeros(5, 2, 256), [60, 60])
+    with pytest.raises(NotImplementedError):
+        vae.encode(torch.zeros(2, 60, 263), [60, 60])
+
+
+def test_unbuilt_config_branches_raise():
+    from ladiff_amd import LADiffDenoiser
+    with pytest.raises(TypeError):
+        LADiffDenoiser(ABL, **{**DEN_KW, "condition": "action"})
+    with pytest.raises(ValueError):
+        LADiffDenoiser(ABL, **{**DEN_KW, "arch": "trans_dec2"})
+    with pytest.raises(NotImplementedError):
+        LADiffDenoiser(ABL, **{**DEN_KW, "num_layers": 7})
+
+
+def test_scheduler_tables():
+    from ladiff_amd import DDIMScheduler, DDPMScheduler
+    from oracle import ladiff_oracle as orc
+    kw = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+              clip_sample=False)
+    d = DDIMScheduler(set_alpha_to_one=False, steps_offset=1, **kw)
+    d.set_timesteps(50)
+    o = orc.DDIM(); o.set_timesteps(50)
+    assert torch.equal(d.timesteps, o.timesteps)
+    assert torch.equal(d.alphas_cumprod, o.alphas_cumprod)
+    tab = d.coef_table(0.0)
+    assert tab.shape == (50, 8) and not d.needs_noise(0.0) and d.needs_noise(0.5)
+    # the table reproduces the oracle's step on CPU numbers
+    x = torch.randn(3, 5, 256); e = torch.randn(3, 5, 256)
+    for i in (0, 17, 49):
+        sa, sb, kx0, kx, ke, kn = tab[i, :6]
+        got = kx0 * ((x - sb * e) / sa) + kx * x + ke * e
+        assert torch.allclose(got, o.step(e, d.timesteps[i], x), atol=1e-5, rtol=1e-5)
+    p = DDPMScheduler(variance_type="fixed_small", **kw)
+    p.set_timesteps(1000)
+    q = orc.DDPM(); q.set_timesteps(1000)
+    assert torch.equal(p.timesteps, q.timesteps) and p.needs_noise()
+    tab = p.coef_table()
+    z = torch.randn(3, 5, 256)
+    for i in (0, 500, 999):
+        sa, sb, kx0, kx, ke, kn = tab[i, :6]
+        got = kx0 * ((x - sb * e) / sa) + kx * x + ke * e + kn * z
+        assert torch.allclose(got, q.step(e, p.timesteps[i], x, noise=z), atol=1e-5, rtol=1e-5)
+    with pytest.raises(NotImplementedError):
+        DDIMScheduler(clip_sample=True)
+
+
+def test_host_sinusoid_matches_oracle():
+    from ladiff_amd.schedulers import timestep_sinusoid
+    from oracle import ladiff_oracle as orc
+    t = torch.tensor([981, 481, 1])
+    assert torch.equal(timestep_sinusoid(t), orc.timestep_sinusoid(t))

@@ -1,0 +1,173 @@
+"""GPU parity of the individual HIP kernels, called through the C ABI, against the CPU oracle."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ladiff_amd import _lib
+from oracle import ladiff_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def lib():
+    return _lib.lib()
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (scale * torch.randn(*shape, generator=g)).float()
+
+
+def gemm(A, W, bias=None, A2=None, res=None, ln=None, act="none"):
+    M, K1 = A.shape
+    N, K = W.shape
+    Y = torch.full((M, N), float("nan"), device=DEV)
+    d = lambda t: None if t is None else t.to(DEV).contiguous()
+    A_, W_, b_, A2_, r_ = d(A), d(W), d(bias), d(A2), d(res)
+    g_, be_ = (d(ln[0]), d(ln[1])) if ln else (None, None)
+    rc = lib().ladiff_gemm(_lib.ptr(A_), A_.shape[1], _lib.ptr(A2_), 0 if A2 is None else A2_.shape[1], K1, _lib.ptr(W_), K,
+                           _lib.ptr(b_), _lib.ptr(r_), N, _lib.ptr(g_), _lib.ptr(be_), _lib.ptr(Y), N, M, N, K,
+                           _lib.ACT[act], _lib.stream_ptr())
+    _lib.check(rc)
+    sync()
+    return Y.cpu()
+
+
+def ref_gemm(A, W, bias=None, A2=None, res=None, ln=None, act="none"):
+    X = A if A2 is None else torch.cat([A, A2], dim=1)
+    y = F.linear(X.double(), W.double(), None if bias is None else bias.double())
+    y = {"none": lambda v: v, "relu": F.relu, "gelu": F.gelu, "silu": F.silu}[act](y)
+    if res is not None:
+        y = y + res.double()
+    if ln is not None:
+        y = F.layer_norm(y, (y.shape[-1],), ln[0].double(), ln[1].double(), 1e-5)
+    return y
+
+
+# (M, N, K) chosen to hit every tile configuration of launch_gemm and ragged edges
+@pytest.mark.parametrize("M,N,K,act", [
+    (1280, 768, 256, "none"), (1280, 1024, 256, "relu"), (1280, 256, 1024, "none"), (256, 256, 256, "silu"),
+    (50, 512, 256, "none"), (7, 256, 768, "gelu"), (4099, 768, 256, "none"), (4100, 1024, 256, "gelu"),
+    (5000, 263, 256, "none"), (4097, 251, 256, "none"), (33, 263, 256, "none"), (1, 32, 32, "none"),
+])
+def test_gemm_bias_act(M, N, K, act):
+    A, W, b = rnd(M, K), rnd(N, K, scale=1 / math.sqrt(K)), rnd(N)
+    got, want = gemm(A, W, b, act=act), ref_gemm(A, W, b, act=act)
+    assert torch.isfinite(got).all()
+    assert (got.double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("M,K", [(1280, 256), (1280, 1024), (37, 256), (4100, 256), (5003, 1024), (16, 256)])
+def test_gemm_residual_layernorm(M, K):
+    A, W, b, res = rnd(M, K), rnd(256, K, scale=1 / math.sqrt(K)), rnd(256), rnd(M, 256, scale=3.0)
+    ln = (1 + 0.1 * rnd(256, seed=3), 0.1 * rnd(256, seed=4))
+    got, want = gemm(A, W, b, res=res, ln=ln), ref_gemm(A, W, b, res=res, ln=ln)
+    assert (got.double() - want).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("M", [1280, 4200, 19])
+def test_gemm_concat_k(M):
+    A, A2, W, b = rnd(M, 256), rnd(M, 256, seed=9), rnd(256, 512, scale=0.05), rnd(256)
+    got, want = gemm(A, W, b, A2=A2), ref_gemm(A, W, b, A2=A2)
+    assert (got.double() - want).abs().max().item() < 2e-5
+
+
+def test_gemm_k_order_is_a_pure_permutation():
+    """A = I picks out columns of W^T: catches a row/col swap or a wrong k permutation exactly (asymmetric W)."""
+    K = 256
+    A = torch.eye(K)
+    W = torch.arange(96 * K, dtype=torch.float32).reshape(96, K) % 251
+    assert torch.equal(gemm(A, W), W.t().contiguous())
+
+
+def test_gemm_shape_errors():
+    A = torch.zeros(4, 40, device=DEV); W = torch.zeros(8, 40, device=DEV); Y = torch.zeros(4, 8, device=DEV)
+    rc = lib().ladiff_gemm(_lib.ptr(A), 40, None, 0, 40, _lib.ptr(W), 40, None, None, 0, None, None, _lib.ptr(Y), 8,
+                           4, 8, 40, 0, _lib.stream_ptr())
+    assert rc == -2    # K must be a multiple of 32
+
+
+@pytest.mark.parametrize("M", [1, 5, 1280, 25088])
+def test_layernorm(M):
+    x, g, b = rnd(M, 256, scale=4.0), 1 + 0.1 * rnd(256), 0.1 * rnd(256, seed=2)
+    y = torch.empty(M, 256, device=DEV)
+    xd, gd, bd = x.to(DEV), g.to(DEV), b.to(DEV)
+    _lib.check(lib().ladiff_layernorm(_lib.ptr(xd), _lib.ptr(gd), _lib.ptr(bd), _lib.ptr(y), M, _lib.stream_ptr()))
+    sync()
+    want = F.layer_norm(x.double(), (256,), g.double(), b.double(), 1e-5)
+    assert (y.cpu().double() - want).abs().max().item() < 1e-5
+
+
+def test_timestep_sinusoid_kernel():
+    t = torch.tensor([981, 961, 481, 21, 1, 0, 999], dtype=torch.int64)
+    out = torch.empty(len(t), 768, device=DEV)
+    td = t.to(DEV)
+    _lib.check(lib().ladiff_timestep_sinusoid(td.data_ptr(), len(t), _lib.ptr(out), _lib.stream_ptr()))
+    sync()
+    # the angle t*f carries 1 ulp of f (x t <= 999): 1e-4 is the honest bound for any fp32 evaluation
+    assert (out.cpu() - orc.timestep_sinusoid(t)).abs().max().item() < 1e-4
+
+
+def ref_self_attention(qkv, lengths, B, Fr):
+    q, k, v = qkv.double().view(B, Fr, 3, 4, 64).permute(2, 0, 3, 1, 4)
+    s = (q * 0.125) @ k.transpose(-1, -2)
+    pad = ~orc.lengths_to_mask(lengths, Fr)
+    s = s.masked_fill(pad[:, None, None, :], float("-inf"))
+    return (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * Fr, 256)
+
+
+@pytest.mark.parametrize("lengths", [[196, 196, 60], [60] * 4, [1, 33, 32, 31, 101], [224, 200], [5], [128, 129, 97]])
+def test_decoder_self_attention(lengths):
+    B, Fr = len(lengths), max(lengths)
+    qkv = rnd(B * Fr, 768, scale=2.0)
+    out = torch.full((B * Fr, 256), float("nan"), device=DEV)
+    qd, ld = qkv.to(DEV), torch.tensor(lengths, dtype=torch.int32, device=DEV)
+    _lib.check(lib().ladiff_decoder_self_attention(_lib.ptr(qd), ld.data_ptr(), _lib.ptr(out), B, Fr, _lib.stream_ptr()))
+    sync()
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    assert (got.double() - ref_self_attention(qkv, lengths, B, Fr)).abs().max().item() < 2e-5
+
+
+def test_decoder_self_attention_softmax_extremes():
+    """One key dominates by a large margin (exp underflow of the rest) and all-equal scores."""
+    B, Fr = 2, 196
+    qkv = torch.zeros(B * Fr, 768)
+    qkv[:, 512:] = rnd(B * Fr, 256)
+    qkv[:Fr, :256] = 8.0          # sample 0: big q ...
+    qkv[77, 256:512] = 8.0        # ... against one big key -> softmax is one-hot on key 77
+    out = torch.empty(B * Fr, 256, device=DEV)
+    qd, ld = qkv.to(DEV), torch.tensor([196, 150], dtype=torch.int32, device=DEV)
+    _lib.check(lib().ladiff_decoder_self_attention(_lib.ptr(qd), ld.data_ptr(), _lib.ptr(out), B, Fr, _lib.stream_ptr()))
+    sync()
+    assert (out.cpu().double() - ref_self_attention(qkv, [196, 150], B, Fr)).abs().max().item() < 2e-5
+
+
+def test_decoder_self_attention_rejects_long_sequences():
+    x = torch.zeros(300, 768, device=DEV); o = torch.zeros(300, 256, device=DEV)
+    l = torch.tensor([300], dtype=torch.int32, device=DEV)
+    assert lib().ladiff_decoder_self_attention(_lib.ptr(x), l.data_ptr(), _lib.ptr(o), 1, 300, _lib.stream_ptr()) == -2
+
+
+@pytest.mark.parametrize("T,counts", [(5, [5, 2, 3, 1]), (5, [5] * 3), (3, [1, 3]), (8, [8, 4, 1])])
+def test_decoder_cross_attention(T, counts):
+    B, Fr = len(counts), 50
+    q, kv = rnd(B * Fr, 256, scale=2.0), rnd(T * B, 512, scale=2.0)
+    out = torch.empty(B * Fr, 256, device=DEV)
+    qd, kd, cd = q.to(DEV), kv.to(DEV), torch.tensor(counts, dtype=torch.int32, device=DEV)
+    _lib.check(lib().ladiff_decoder_cross_attention(_lib.ptr(qd), _lib.ptr(kd), cd.data_ptr(), _lib.ptr(out), B, Fr, T,
+                                                    _lib.stream_ptr()))
+    sync()
+    qq = q.double().view(B, Fr, 4, 64).transpose(1, 2) * 0.125
+    kk = kv.double().view(T, B, 2, 4, 64)
+    k, v = kk[:, :, 0].permute(1, 2, 0, 3), kk[:, :, 1].permute(1, 2, 0, 3)
+    s = (qq @ k.transpose(-1, -2)).masked_fill(~orc.count_mask(counts, T)[:, None, None, :], float("-inf"))
+    want = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * Fr, 256)
+    assert (out.cpu().double() - want).abs().max().item() < 2e-5

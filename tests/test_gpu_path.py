@@ -1,0 +1,187 @@
+"""GPU parity of the whole hot path (drop-in modules + loop owner) against golden vectors captured from the
+reference and against the CPU oracle; plus size-independent properties at the benchmark's full size."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from ladiff_amd import LADIFF, DDIMScheduler, DDPMScheduler, LADiffDenoiser, LADiffVae, _lib, synthetic as syn
+from oracle import ladiff_oracle as orc
+from conftest import load_golden
+from test_abi import ABL, DEN_KW, VAE_KW
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SCHED_KW = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                clip_sample=False)
+FRAME_TOL = 1e-3     # BASELINE.json north_star: decoded-frame max abs diff < 1e-3 (fp32 path)
+
+
+def maxdiff(a, b):
+    return (a.double().cpu() - b.double().cpu()).abs().max().item()
+
+
+@pytest.fixture(scope="module")
+def denoiser():
+    m = LADiffDenoiser(ABL, **DEN_KW)
+    m.load_state_dict(syn.denoiser_weights(), strict=True)
+    return m.to(DEV).eval()
+
+
+def make_vae(nfeats):
+    m = LADiffVae(ABL, **{**VAE_KW, "nfeats": nfeats})
+    m.load_state_dict(syn.vae_weights(nfeats), strict=True)
+    return m.to(DEV).eval()
+
+
+@pytest.fixture(scope="module")
+def vae():
+    return make_vae(263)
+
+
+def make_pipe(denoiser, vae, sched="ddim", steps=50, **kw):
+    s = (DDIMScheduler(set_alpha_to_one=False, steps_offset=1, **SCHED_KW) if sched == "ddim"
+         else DDPMScheduler(variance_type="fixed_small", **SCHED_KW))
+    return LADIFF(denoiser=denoiser, vae=vae, scheduler=s, guidance_scale=7.5, num_inference_timesteps=steps,
+                  eta=0.0, **kw)
+
+
+# ---------------------------------------------------------------- denoiser forward (A5-A14)
+@pytest.mark.parametrize("t", [981, 1])
+def test_denoiser_forward_golden(denoiser, t):
+    g = load_golden(f"denoiser_forward_t{t}")
+    eps = denoiser(sample=g["sample"].to(DEV), timestep=g["t"].to(DEV), encoder_hidden_states=g["text"].to(DEV),
+                   lengths=[196] * 8, max_iter_elements=g["counts"].to(DEV))
+    assert isinstance(eps, tuple) and len(eps) == 1
+    assert maxdiff(eps[0], g["eps"]) < 5e-5       # every row, padded latent rows included
+
+
+def test_denoiser_forward_no_mask_and_vector_timestep(denoiser):
+    g = load_golden("denoiser_forward_t981")
+    sd = syn.denoiser_weights()
+    want = orc.denoiser_forward(sd, g["sample"], 481, g["text"], None)
+    eps = denoiser(g["sample"].to(DEV), torch.full((8,), 481, device=DEV), g["text"].to(DEV))[0]
+    assert maxdiff(eps, want) < 5e-5
+
+
+def test_denoiser_short_latent_count(denoiser):
+    """TEST_EFFICIENCY-style call: T=2 latent rows, no masks."""
+    sd = syn.denoiser_weights()
+    x = torch.randn(6, 2, 256, generator=torch.Generator().manual_seed(5))
+    txt = torch.randn(6, 1, 768, generator=torch.Generator().manual_seed(6))
+    want = orc.denoiser_forward(sd, x, 21, txt, None)
+    got = denoiser(x.to(DEV), torch.tensor(21), txt.to(DEV))[0]
+    assert maxdiff(got, want) < 5e-5
+
+
+# ---------------------------------------------------------------- LA-VAE decode (A15-A18)
+@pytest.mark.parametrize("name,nfeats", [("vae_decode_c1", 263), ("vae_decode_mixed_kit", 251),
+                                         ("vae_decode_ragged", 263)])
+def test_vae_decode_golden(name, nfeats):
+    g = load_golden(name)
+    vae = make_vae(nfeats)
+    lengths = g["lengths"].tolist()
+    feats = vae.decode(g["z"].to(DEV), lengths)
+    assert feats.shape == g["feats"].shape
+    assert maxdiff(feats, g["feats"]) < 1e-4
+    for i, l in enumerate(lengths):
+        assert feats[i, l:].abs().max().item() == 0 if l < feats.shape[1] else True
+
+
+def test_vae_decode_single_frame_and_single_sample(vae):
+    sd = syn.vae_weights(263)
+    z = torch.randn(5, 1, 256, generator=torch.Generator().manual_seed(1))
+    z[1:] = 0
+    for lens in ([1], [48]):
+        assert maxdiff(vae.decode(z.to(DEV), lens), orc.vae_decode(sd, z, lens)) < 1e-4
+
+
+# ---------------------------------------------------------------- sampling loop (A1-A4)
+@pytest.mark.parametrize("tag,sched,use_graph", [("ddim5", "ddim", True), ("ddim50", "ddim", True),
+                                                 ("ddim50", "ddim", False), ("ddpm10", "ddpm", True)])
+def test_sampling_loop_golden(denoiser, vae, tag, sched, use_graph):
+    g = load_golden(f"loop_{tag}")
+    pipe = make_pipe(denoiser, vae, sched, int(g["n_steps"]), use_graph=use_graph)
+    sn = g.get("step_noise")
+    z, feats = pipe.sample(g["text"].to(DEV), g["lengths"].tolist(), init_noise=g["init_noise"].to(DEV),
+                           step_noise=None if sn is None else sn.to(DEV))
+    assert torch.equal(pipe.scheduler.timesteps, g["timesteps"])
+    scale = max(1.0, g["latents"].abs().max().item())
+    assert maxdiff(z, g["latents"]) < 2e-5 * scale
+    assert maxdiff(feats, g["feats"]) < FRAME_TOL
+    # second call through the cached hipGraph gives the same bits
+    z2, feats2 = pipe.sample(g["text"].to(DEV), g["lengths"].tolist(), init_noise=g["init_noise"].to(DEV),
+                             step_noise=None if sn is None else sn.to(DEV))
+    assert torch.equal(z, z2) and torch.equal(feats, feats2)
+
+
+def test_module_level_loop_matches_fused_loop(denoiser, vae):
+    """Reference-style Python loop over the drop-in modules (denoiser.forward + scheduler.step) == fused C loop."""
+    g = load_golden("loop_ddim5")
+    lens = g["lengths"].tolist()
+    pipe = make_pipe(denoiser, vae, "ddim", 5)
+    z = pipe._diffusion_reverse(g["text"].to(DEV), lens, init_noise=g["init_noise"].to(DEV))
+    sch = DDIMScheduler(set_alpha_to_one=False, steps_offset=1, **SCHED_KW)
+    sch.set_timesteps(5)
+    counts = torch.tensor(syn.max_iter_elements(lens))
+    lat = g["init_noise"].to(DEV)
+    text = g["text"].to(DEV)
+    for t in sch.timesteps:
+        eps = denoiser(torch.cat([lat] * 2), t, text, lengths=lens * 2, max_iter_elements=torch.cat([counts] * 2))[0]
+        eu, ec = eps.chunk(2)
+        lat = sch.step(eu + 7.5 * (ec - eu), t, lat, eta=0.0).prev_sample
+    lat = lat.permute(1, 0, 2).clone()
+    for i, m in enumerate(counts.tolist()):
+        lat[m:, i] = 0
+    assert maxdiff(z, lat) < 1e-4
+
+
+# ---------------------------------------------------------------- full-size properties (BASELINE configs)
+def test_full_size_batch_properties(denoiser, vae):
+    """B=128, F=196, 50-step DDIM: samples are independent of batch composition, so a sub-batch run alone
+    must reproduce its rows of the full batch; padded frames are exactly zero; the run is deterministic."""
+    B = 128
+    lens = [196] * 120 + [60, 120, 49, 1, 100, 150, 196, 48]
+    text = syn.text_embeddings(B)
+    noise = syn.init_noise(lens)
+    pipe = make_pipe(denoiser, vae, "ddim", 50)
+    z, feats = pipe.sample(text.to(DEV), lens, init_noise=noise.to(DEV))
+    assert feats.shape == (B, 196, 263) and torch.isfinite(feats).all()
+    for i, l in enumerate(lens):
+        if l < 196:
+            assert feats[i, l:].abs().max().item() == 0
+            assert z[syn.max_iter_elements([l])[0]:, i].abs().max().item() == 0
+    idx = [0, 57, 120, 121, 123, 127]
+    sub_text = torch.cat([text[:B][idx], text[B:][idx]])
+    z_s, f_s = make_pipe(denoiser, vae, "ddim", 50).sample(sub_text.to(DEV), [lens[i] for i in idx],
+                                                            init_noise=noise[idx].to(DEV))
+    scale = z.abs().max().item()
+    assert maxdiff(z_s, z[:, idx]) < 2e-5 * max(1.0, scale)
+    for j, i in enumerate(idx):
+        assert maxdiff(f_s[j, :lens[i]], feats[i, :lens[i]]) < FRAME_TOL
+    # against the CPU oracle on the sub-batch (the oracle finishes 6 motions x 50 steps in seconds)
+    z_o, f_o = orc.sample_motions(syn.denoiser_weights(), syn.vae_weights(263), sub_text, [lens[i] for i in idx],
+                                  noise[idx], 50, "ddim")
+    assert maxdiff(f_s, f_o) < FRAME_TOL
+
+
+def test_drop_in_via_yaml_style_config(denoiser):
+    """The reference's plugin API: {target, params} nodes with the reference's own dotted paths."""
+    cfg = {"model": {"guidance_scale": 7.5,
+                     "denoiser": {"target": "ladiff.models.architectures.ladiff_denoiser.LADiffDenoiser",
+                                  "params": {**DEN_KW, "ablation": ABL}},
+                     "motion_vae": {"target": "ladiff.models.architectures.ladiff_vae.LADiffVae",
+                                    "params": {**VAE_KW, "ablation": ABL}},
+                     "scheduler": {"target": "diffusers.DDIMScheduler", "num_inference_timesteps": 5, "eta": 0.0,
+                                   "params": {**SCHED_KW, "set_alpha_to_one": False, "steps_offset": 1}}},
+           "TRAIN": {"ABLATION": {"MAX_IT": 5, "FRAME_PER_LATENT": 48, "TEST_EFFICIENCY": False}}}
+    dm = SimpleNamespace(feats2joints=lambda f: f[..., :66].reshape(*f.shape[:-1], 22, 3))
+    enc = lambda texts: torch.randn(len(texts), 1, 768, generator=torch.Generator().manual_seed(3)).to(DEV)
+    model = LADIFF(cfg, dm, text_encoder=enc)
+    model.denoiser.load_state_dict(syn.denoiser_weights())
+    model.vae.load_state_dict(syn.vae_weights(263))
+    model.to(DEV).eval()
+    with torch.no_grad():
+        joints = model({"text": ["a person walks", "jumps"], "length": [60, 130]})
+    assert [tuple(j.shape) for j in joints] == [(60, 22, 3), (130, 22, 3)]
+    assert len(model.times) == 1
