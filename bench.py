@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Benchmark of the LADiff sampling hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch of synthetic prompts: 128 prompts per GPU, 196 frames,
+50-step DDIM with classifier-free guidance 7.5 (`_diffusion_reverse`), LA-VAE decode to [128,196,263] and, for
+N > 1, the final RCCL all-gather of the frames.  Inputs (random-init weights, random "CLIP" embeddings, seeded
+noise: ladiff_amd/synthetic.py) are resident in HBM before the timed region.  Metric: motions/s, whole job.
+
+Extra objects on the JSON line:
+  roofline     bound = mfma (fp32-input MFMA, 157.3 TF/s dense peak).  achieved = reference-equivalent FLOPs of one
+               pass (21.757 GFLOP per motion at F=196, C=263, 50 steps) / the pass's device time
+               measured with HIP events on the launching stream.  executed_tflops is the same with the FLOPs the
+               kernels really execute after hoisting so the two cannot be conflated.
+  cpu_baseline the CPU oracle (oracle/ladiff_oracle.py, a port of the reference's op sequence, fp32 PyTorch) timed on
+               the host cores of this box on a bounded sample of the same workload.  Baseline only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from ladiff_amd import LADIFF, DDIMScheduler, LADiffDenoiser, LADiffVae, distributed as D, synthetic as syn  # noqa: E402
+
+FRAMES, NFEATS, STEPS_DDIM, BATCH = 196, 263, 50, 128
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def ref_flops_per_motion(F=FRAMES, C=NFEATS, n_steps=STEPS_DDIM):
+    """Reference-equivalent FLOPs (flop-counted on the reference modules; CFG x2 included)."""
+    return n_steps * 358.27e6 + (17609728 + 512 * C) * F + 9216 * F * F + 11796480
+
+
+def executed_flops_per_motion(F=FRAMES, C=NFEATS, n_steps=STEPS_DDIM, T=5):
+    """MFMA FLOPs the kernels execute per motion: per latent row and layer 2*256*(768+256+2*1024+256
+    +2*1024+256) = 2.753 MFLOP (+ skip 512x256 on 4 of 9 layers), 2 branches x T rows; decoder as the reference."""
+    per_row_layer = 2 * 256 * (768 + 256 + 2048 + 256 + 2048 + 256)
+    den = n_steps * 2 * T * (9 * per_row_layer + 4 * 2 * 512 * 256)
+    dec_row_layer = 2 * 256 * (768 + 256 + 256 + 256 + 2048)
+    attn = 2 * 2 * 224 * 224 * 64 * 4 / F          # QK^T + PV on 32-padded tiles, per frame row
+    dec = F * (9 * (dec_row_layer + attn) + 4 * 2 * 512 * 256 + 2 * 256 * C)
+    return den + dec
+
+
+def build_pipe(dev, batch):
+    from test_abi import ABL, DEN_KW, VAE_KW
+    den = LADiffDenoiser(ABL, **DEN_KW)
+    den.load_state_dict(syn.denoiser_weights())
+    vae = LADiffVae(ABL, **VAE_KW)
+    vae.load_state_dict(syn.vae_weights(NFEATS))
+    sch = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                        clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    return LADIFF(denoiser=den.to(dev).eval(), vae=vae.to(dev).eval(), scheduler=sch, guidance_scale=7.5,
+                  num_inference_timesteps=STEPS_DDIM, eta=0.0)
+
+
+def cpu_baseline(sample_b):
+    """Oracle on the host cores, bounded sample: `sample_b` motions of the same shape (196 frames, 50 steps)."""
+    from oracle import ladiff_oracle as orc
+    lens = [FRAMES] * sample_b
+    text, noise = syn.text_embeddings(sample_b), syn.init_noise(lens)
+    den_sd, vae_sd = syn.denoiser_weights(), syn.vae_weights(NFEATS)
+    with torch.no_grad():
+        warm = torch.cat([text[:2], text[sample_b:sample_b + 2]])
+        orc.sample_motions(den_sd, vae_sd, warm, lens[:2], noise[:2], 2, "ddim")   # warm-up (threads, allocator)
+        t0 = time.perf_counter()
+        orc.sample_motions(den_sd, vae_sd, text, lens, noise, STEPS_DDIM, "ddim")
+        dt = time.perf_counter() - t0
+    return {"value": sample_b / dt, "unit": "motions/s", "cores": torch.get_num_threads(), "kind": "port",
+            "host_cpus": os.cpu_count(),
+            "sample": f"{sample_b} motions, 196 frames, 50-step DDIM + decode, fp32 PyTorch CPU oracle, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH, help="prompts per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=32, help="motions in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank, world, local = D.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    B = args.batch
+    total = B * world
+    lens = [FRAMES] * B
+    # global inputs, sliced per rank: results do not depend on the sharding
+    lo, hi = D.shard_range(total, rank, world)
+    gtext = syn.text_embeddings(total)
+    text = torch.cat([gtext[:total][lo:hi], gtext[total:][lo:hi]]).to(dev)
+    noise = syn.init_noise(lens, offset=lo, total=total).to(dev)
+    pipe = build_pipe(dev, B)
+    gather_buf = torch.empty(total, FRAMES, NFEATS, device=dev) if world > 1 else None
+
+    stream = torch.cuda.Stream(device=dev)        # hipGraph capture needs a non-null stream; events go on it too
+
+    def one_pass():
+        z, feats = pipe.sample(text, lens, init_noise=noise)
+        if world > 1:
+            feats = D.gather_feats(feats, total, world, out=gather_buf)
+        return feats
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.cuda.stream(stream), torch.no_grad():
+        for _ in range(args.warmup):
+            one_pass()
+        fence()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(args.steps):
+            feats = one_pass()
+        ev1.record(stream)
+        fence()
+        wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    assert torch.isfinite(feats).all()
+
+    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    wall = float(tmax.item())
+
+    if rank == 0:
+        motions_per_s = total * args.steps / wall
+        dev_s_per_pass = dev_ms / 1e3 / args.steps
+        ref_tf = B * ref_flops_per_motion() / dev_s_per_pass / 1e12
+        exe_tf = B * executed_flops_per_motion() / dev_s_per_pass / 1e12
+        line = {
+            "metric": "motions/sec (196-frame, 50-step DDIM, bs128)", "value": round(motions_per_s, 2),
+            "unit": "motions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ddim50_cfg7.5_b{B}_f{FRAMES}_c{NFEATS}_humanml3d", "prompts_per_gpu": B,
+                       "global_batch": total, "frames": FRAMES, "ddim_steps": STEPS_DDIM, "parallelism": f"dp{world}",
+                       "hipgraph": True},
+            "roofline": {"bound": "mfma", "achieved": round(ref_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ref_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "kernel": "whole pass (hipGraph step x50 + decode); dominant kernel gemm_kernel<fp32 MFMA>",
+                         "device_ms_per_pass": round(dev_ms / args.steps, 3),
+                         "flops_per_motion_reference_equivalent": ref_flops_per_motion(),
+                         "executed_tflops": round(exe_tf, 2), "executed_frac": round(exe_tf / PEAK_F32_MFMA_TFLOPS, 4)},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+            line["cpu_baseline"]["gpu_over_cpu"] = round(motions_per_s / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,70 @@
+"""Multi-GPU sharding of the sampling path: one process per GPU, prompts split contiguously, weights replicated,
+no collective inside the loop, ONE all-gather of the decoded frames at the end.
+
+The reference has no multi-device inference (test.py:100 pins one device); prompts are independent
+(attention is per sample, guidance pairs row i with row i+B of the same prompt), so sharding is exact.
+`backend="nccl"` is RCCL over xGMI on ROCm; the CPU tests use gloo.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Join the process group torchrun set up (RANK / WORLD_SIZE / MASTER_* / LOCAL_RANK). Returns (rank, world, local)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return rank, world, local
+
+
+def shard_range(total, rank, world):
+    """Contiguous [lo, hi) of `total` prompts for `rank`; the first total % world ranks take one extra."""
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_prompts(text_emb, lengths, init_noise, rank, world):
+    """Slice a GLOBAL batch for one rank.  text_emb [2B,1,E] keeps its uncond|cond halves paired per prompt."""
+    B = len(lengths)
+    lo, hi = shard_range(B, rank, world)
+    text = torch.cat([text_emb[:B][lo:hi], text_emb[B:][lo:hi]], dim=0)
+    noise = None if init_noise is None else init_noise[lo:hi]
+    return text, list(lengths[lo:hi]), noise, (lo, hi)
+
+
+def gather_feats(feats, total, world, out=None):
+    """All-gather per-rank frames [b_r, F_r, C] into [total, F_max, C] in global prompt order (one collective).
+
+    Ranks may hold different numbers of prompts and different F (mixed lengths): shards are zero-padded to the
+    global maxima - frames past a motion's length are zero anyway (ladiff_vae.py:358).
+    """
+    if world == 1:
+        return feats
+    dev = feats.device
+    meta = torch.tensor([feats.shape[0], feats.shape[1]], dtype=torch.int64, device=dev)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    bs = [int(m[0]) for m in metas]
+    fmax = max(int(m[1]) for m in metas)
+    bmax = max(bs)
+    C = feats.shape[2]
+    pad = torch.zeros(bmax, fmax, C, dtype=feats.dtype, device=dev)
+    pad[:feats.shape[0], :feats.shape[1]] = feats
+    buf = torch.empty(world * bmax, fmax, C, dtype=feats.dtype, device=dev) if out is None else out
+    dist.all_gather_into_tensor(buf, pad)
+    if all(b == bmax for b in bs):
+        return buf
+    return torch.cat([buf[r * bmax:r * bmax + bs[r]] for r in range(world)], dim=0)

@@ -108,17 +108,20 @@ class LADIFF(nn.Module):
         except Exception:
             pass
 
-    def _get_plan(self, B, T, n_steps, eta, dev, need_noise):
-        """Persistent device buffers for one (B, T, schedule): hipGraph kernel nodes bake pointers in."""
+    def _get_plan(self, B, T, n_steps, eta, dev):
+        """Persistent device buffers + scheduler tables for one (B, T, schedule): hipGraph kernel nodes bake
+        pointers in, and the per-step scalar tables are built once, not per call."""
         sch = self.scheduler
-        key = (B, T, n_steps, float(eta), str(dev), type(sch).__name__, need_noise)
+        key = (B, T, n_steps, float(eta), str(dev), id(sch))
         if self._plan is not None and self._plan["key"] == key:
             return self._plan
         L = _lib.lib()
         sch.set_timesteps(n_steps)
+        n_steps = len(sch.timesteps)
+        need_noise = sch.needs_noise(eta)
         wsb = L.ladiff_reverse_workspace_bytes(B, T, n_steps)
         plan = {
-            "key": key,
+            "key": key, "n": n_steps, "need_noise": need_noise,
             "timesteps": sch.timesteps.clone(),
             "coef": sch.coef_table(eta).to(dev),
             "sinus": timestep_sinusoid(sch.timesteps, 768).to(dev),
@@ -148,12 +151,9 @@ class LADIFF(nn.Module):
         lengths = [int(l) for l in lengths]
         counts = self._counts(lengths)
         T = counts[0] if self.test_efficiency else self.max_it     # ladiff.py:381
-        n = self.num_inference_timesteps
         sch = self.scheduler
-        sch.set_timesteps(n)
-        n = len(sch.timesteps)
-        need_noise = sch.needs_noise(self.eta)
-        plan = self._get_plan(B, T, n, self.eta, dev, need_noise)
+        plan = self._get_plan(B, T, self.num_inference_timesteps, self.eta, dev)
+        n, need_noise = plan["n"], plan["need_noise"]
         if self._stream is None or self._stream.device != dev:
             self._stream = torch.cuda.Stream(device=dev)
         if self.use_graph and self._sampler is None:
@@ -166,8 +166,12 @@ class LADIFF(nn.Module):
             step_noise = torch.randn(n, B, T, 256, device=dev, dtype=torch.float32)
         wt = self.denoiser._weight_table()
         cur = torch.cuda.current_stream(dev)
-        self._stream.wait_stream(cur)
-        with torch.cuda.stream(self._stream):
+        # hipStreamBeginCapture is illegal on the null stream: run on the caller's stream when it is a real
+        # one, otherwise on a private side stream fenced against it on both sides.
+        run = cur if cur.cuda_stream != 0 else self._stream
+        if run is not cur:
+            run.wait_stream(cur)
+        with torch.cuda.stream(run):
             plan["text"].copy_(encoder_hidden_states.reshape(2 * B, 1, 768))
             plan["noise"].copy_(init_noise)
             plan["counts"].copy_(torch.tensor(counts, dtype=torch.int32), non_blocking=False)
@@ -178,8 +182,9 @@ class LADIFF(nn.Module):
                 None if self.test_efficiency else plan["counts"].data_ptr(), _lib.ptr(plan["sinus"]),
                 _lib.ptr(plan["coef"]), _lib.ptr(plan["step_noise"]) if need_noise else None, self.guidance_scale,
                 float(sch.init_noise_sigma), B, T, n, _lib.ptr(plan["z"]), _lib.ptr(plan["ws"]), plan["ws_bytes"],
-                self._stream.cuda_stream))
-        cur.wait_stream(self._stream)
+                run.cuda_stream))
+        if run is not cur:
+            cur.wait_stream(run)
         return plan["z"].clone()
 
     # ------------------------------------------------------------------ callers' surface
