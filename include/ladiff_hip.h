@@ -70,6 +70,23 @@ int ladiff_gemm(const float* A, int lda, const float* A2, int lda2, int K1, cons
                 const float* ln_beta, float* Y, int ldy, int M, int N, int K, int act,
                 ladiff_stream_t stream);
 
+/* Small-M variant used by the denoiser loop (K-resident LDS-DMA tiles, K multiple of 256).
+ *   K == 256:        Y = act( pro(A) . W^T + bias ) + res;  ln_gamma != NULL: pro(A) = LayerNorm(A), xout (may be
+ *                    NULL) receives it (nn.LayerNorm + nn.Linear pair, mdiff_transformer.py:63-64)
+ *   K == 512 / 1024: split-K - Y receives K/256 raw partial planes [K/256][M][ldy]; bias/act/res are NOT applied,
+ *                    combine them with ladiff_combine_rows. */
+int ladiff_gemm_resident(const float* A, int lda, const float* A2, int lda2, int K1, const float* W, int ldw,
+                         const float* bias, const float* res, int ldres, float* Y, int ldy, int M, int N, int K,
+                         int act, const float* ln_gamma, const float* ln_beta, float* xout, ladiff_stream_t stream);
+
+/* Rows of 256: x = sum of n_planes partial planes [n_planes][M][256] + bias (+ res), then
+ *   mode 0: x;   mode 2: LN(x) + table[sample row | pad_row] (rows grouped T per sample, sample = row / T, padded when
+ *   row % T >= counts[sample % Bs]);   mode 3: SiLU(LN(x) * (1 + table[0:256]) + table[256:512]).
+ * Replaces the residual / LayerNorm / StylizationBlock element-wise tails at mdiff_transformer.py:65-66, :160-162. */
+int ladiff_combine_rows(const float* partials, int n_planes, int M, const float* bias, const float* res, int mode,
+                        const float* ln_gamma, const float* ln_beta, const float* table, const int32_t* counts,
+                        int Bs, int T, int pad_row, float* out, ladiff_stream_t stream);
+
 /* y = LayerNorm(x) over rows of 256 (nn.LayerNorm, eps 1e-5), cross_attention.py:84-85, :150-151 */
 int ladiff_layernorm(const float* x, const float* gamma, const float* beta, float* y, int M,
                      ladiff_stream_t stream);
@@ -89,10 +106,12 @@ int ladiff_decoder_cross_attention(const float* q, const float* kv, const int32_
  * Step-invariant and t-only work is hoisted:
  *   time tables  [n_steps][9 layers][1536] = AdaLN (scale|shift) of ca_block and ffn, K|V of the time token
  *                (tools/embeddings.py:245-305, mdiff_transformer.py:158-160, :308-311)
- *   text cache   emb_proj output, per-layer K|V of the text token and the normalised cross-attention value
- *                (ladiff_denoiser.py:193-198, mdiff_transformer.py:233-245 with one text token)            */
+ *   text cache   emb_proj output, per-layer K|V of the text token, and the c table [9][n_steps][B2+1][256]: the
+ *                whole cross-attention block (mdiff_transformer.py:219-247), which with ONE text token adds a
+ *                vector that depends on (step, layer, sample) only (ladiff_denoiser.py:193-198).  It is built
+ *                from the time tables, so call ladiff_denoiser_time_tables first.                             */
 size_t ladiff_denoiser_tables_floats(int n_steps);
-size_t ladiff_denoiser_text_cache_floats(int B2);
+size_t ladiff_denoiser_text_cache_floats(int B2, int n_steps);
 size_t ladiff_denoiser_workspace_bytes(int B2, int T, int n_steps);
 
 /* sinusoid[n_steps,768] = Timesteps(768, flip_sin_to_cos, freq_shift 0)(t) for every step of the schedule
@@ -102,14 +121,15 @@ int ladiff_timestep_sinusoid(const int64_t* timesteps, int n_steps, float* sinus
 int ladiff_denoiser_time_tables(const float* const* w, const float* sinusoid, int n_steps,
                                 float* tables, void* ws, size_t ws_bytes, ladiff_stream_t stream);
 int ladiff_denoiser_text_cache(const float* const* w, const float* text_emb /*[B2,1,768]*/, int B2,
-                               float* cache, void* ws, size_t ws_bytes, ladiff_stream_t stream);
+                               const float* tables, int n_steps, float* cache, void* ws, size_t ws_bytes,
+                               ladiff_stream_t stream);
 
 /* eps[Bs*dup,T,256] = denoiser(cat([sample]*dup), t = step *d_step of the time tables, text, counts).
  * ladiff_denoiser.py:153-295 (call site ladiff.py:472-485).  counts[Bs] (int32, valid latent rows per
  * prompt, ceil(len/48)) may be NULL = no masking (TEST_EFFICIENCY / max_iter_elements=None). */
 int ladiff_denoiser_forward(const float* const* w, const float* tables, const int32_t* d_step,
-                            const float* text_cache, const float* sample /*[Bs,T,256]*/, int Bs, int dup,
-                            int T, const int32_t* counts, float* eps, void* ws, size_t ws_bytes,
+                            const float* text_cache, int n_steps, const float* sample /*[Bs,T,256]*/, int Bs,
+                            int dup, int T, const int32_t* counts, float* eps, void* ws, size_t ws_bytes,
                             ladiff_stream_t stream);
 
 /* ------------------------------------------------------------------ guidance + scheduler step

@@ -33,16 +33,21 @@ _SIGNATURES = {
     "ladiff_decoder_param_name": (c_char_p, [c_int]),
     "ladiff_gemm": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                             c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ladiff_gemm_resident": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                     c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ladiff_combine_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ladiff_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ladiff_timestep_sinusoid": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "ladiff_decoder_self_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ladiff_decoder_cross_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ladiff_denoiser_tables_floats": (c_size_t, [c_int]),
-    "ladiff_denoiser_text_cache_floats": (c_size_t, [c_int]),
+    "ladiff_denoiser_text_cache_floats": (c_size_t, [c_int, c_int]),
     "ladiff_denoiser_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ladiff_denoiser_time_tables": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "ladiff_denoiser_text_cache": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "ladiff_denoiser_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+    "ladiff_denoiser_text_cache": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
+                                           c_void_p]),
+    "ladiff_denoiser_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                                         c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ladiff_cfg_scheduler_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int,
                                           c_int, c_void_p]),

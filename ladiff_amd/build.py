@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libladiff_hip.so")
-SOURCES = ["gemm.hip", "rowops.hip", "attention.hip", "denoiser.hip", "decoder.hip", "api.hip"]
+SOURCES = ["gemm.hip", "gemm_kr.hip", "rowops.hip", "attention.hip", "denoiser.hip", "decoder.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -26,7 +26,13 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, stamps=False):
+    """stamps=True builds the diagnostic twin libladiff_hip_stamps.so (in-kernel s_memtime stamps; never timed)."""
+    global OBJ, LIB
+    flags = list(FLAGS)
+    if stamps:
+        OBJ, LIB = OBJ + "_stamps", LIB.replace(".so", "_stamps.so")
+        flags.append("-DLADIFF_STAMPS")
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "ladiff_hip.h"))
@@ -36,7 +42,7 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            jobs.append([hipcc, *flags, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -57,4 +63,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, stamps="--stamps" in sys.argv))

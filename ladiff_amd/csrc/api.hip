@@ -34,11 +34,11 @@ ReverseWs carve_reverse(void* ws, int B, int T, int n) {
     auto take = [&](size_t floats) { float* p = ws ? reinterpret_cast<float*>(ws) + off : nullptr; off += align_up(floats, 64); return p; };
     r.d_step = reinterpret_cast<int32_t*>(take(64));
     r.tables = take(den_tables_floats(n));
-    r.cache = take(den_text_cache_floats(B2));
+    r.cache = take(den_text_cache_floats(B2, n));
     r.latents = take((size_t)B * T * D);
     r.eps = take((size_t)B2 * T * D);
     size_t pre = (size_t)n * D * 3;                                    // time-table scratch
-    const size_t txt = (size_t)B2 * TEXT_DIM + (size_t)B2 * D;         // text-cache scratch
+    const size_t txt = den_text_ws_floats(B2, n);                      // text-cache scratch
     if (txt > pre) pre = txt;
     r.fwd_floats = den_forward_ws_floats(B2, T);
     if (pre > r.fwd_floats) r.fwd_floats = pre;
@@ -56,6 +56,10 @@ struct Sampler {
 };
 
 }  // namespace
+
+#ifdef LADIFF_STAMPS
+static unsigned long long* g_stamps = nullptr;
+#endif
 
 extern "C" {
 
@@ -95,6 +99,36 @@ int ladiff_gemm(const float* A, int lda, const float* A2, int lda2, int K1, cons
     return launch_gemm(g, S(stream));
 }
 
+int ladiff_gemm_resident(const float* A, int lda, const float* A2, int lda2, int K1, const float* W, int ldw,
+                         const float* bias, const float* res, int ldres, float* Y, int ldy, int M, int N, int K, int act,
+                         const float* ln_gamma, const float* ln_beta, float* xout, ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(A && W && Y && M >= 0 && N > 0 && K > 0);
+    if (M == 0) return 0;
+    KrArgs g;
+    g.A = A; g.lda = lda; g.A2 = A2; g.lda2 = lda2; g.K1 = A2 ? K1 : K; g.W = W; g.ldw = ldw; g.bias = bias;
+    g.res = res; g.ldres = ldres; g.Y = Y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.act = act;
+    g.pro = ln_gamma ? KR_PRO_LN : KR_PRO_NONE; g.ln_g = ln_gamma; g.ln_b = ln_beta; g.Xout = xout;
+#ifdef LADIFF_STAMPS
+    g.stamps = g_stamps;
+#endif
+    return launch_gemm_kr(g, S(stream));
+}
+
+#ifdef LADIFF_STAMPS
+void ladiff_debug_set_stamps(unsigned long long* p) { g_stamps = p; }   // diagnostic builds only
+#endif
+
+int ladiff_combine_rows(const float* partials, int n_planes, int M, const float* bias, const float* res, int mode,
+                        const float* ln_gamma, const float* ln_beta, const float* table, const int32_t* counts, int Bs,
+                        int T, int pad_row, float* out, ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(partials && out && n_planes > 0 && M >= 0 && Bs > 0 && T > 0);
+    if (mode != RED_PLAIN && mode != RED_LN_ADD && mode != RED_LN_MOD) return LADIFF_ERR_ARG;
+    if (mode != RED_PLAIN && !(ln_gamma && ln_beta && table)) return LADIFF_ERR_ARG;
+    if (M == 0) return 0;
+    return launch_reduce_rows(partials, n_planes, M, bias, res, mode, ln_gamma, ln_beta, table, 0, nullptr, counts, Bs, T,
+                              pad_row, out, S(stream));
+}
+
 int ladiff_layernorm(const float* x, const float* gamma, const float* beta, float* y, int M, ladiff_stream_t stream) {
     LADIFF_CHECK_ARG(x && gamma && beta && y && M >= 0);
     return launch_layernorm(x, gamma, beta, y, M, S(stream));
@@ -120,10 +154,10 @@ int ladiff_decoder_cross_attention(const float* q, const float* kv, const int32_
 
 // ------------------------------------------------------------------ denoiser
 size_t ladiff_denoiser_tables_floats(int n_steps) { return den_tables_floats(n_steps); }
-size_t ladiff_denoiser_text_cache_floats(int B2) { return den_text_cache_floats(B2); }
+size_t ladiff_denoiser_text_cache_floats(int B2, int n_steps) { return den_text_cache_floats(B2, n_steps); }
 size_t ladiff_denoiser_workspace_bytes(int B2, int T, int n_steps) {
     size_t f = den_forward_ws_floats(B2, T);
-    const size_t a = (size_t)n_steps * D * 3, b = (size_t)B2 * TEXT_DIM + (size_t)B2 * D;
+    const size_t a = (size_t)n_steps * D * 3, b = den_text_ws_floats(B2, n_steps);
     if (a > f) f = a;
     if (b > f) f = b;
     return f * sizeof(float);
@@ -136,19 +170,19 @@ int ladiff_denoiser_time_tables(const float* const* w, const float* sinusoid, in
     return denoiser_time_tables(W, sinusoid, n_steps, tables, (float*)ws, ws_bytes / sizeof(float), S(stream));
 }
 
-int ladiff_denoiser_text_cache(const float* const* w, const float* text_emb, int B2, float* cache, void* ws,
-                               size_t ws_bytes, ladiff_stream_t stream) {
+int ladiff_denoiser_text_cache(const float* const* w, const float* text_emb, int B2, const float* tables, int n_steps,
+                               float* cache, void* ws, size_t ws_bytes, ladiff_stream_t stream) {
     DenoiserW W;
-    LADIFF_CHECK_ARG(load_weights(W, w) && text_emb && cache && ws && B2 > 0);
-    return denoiser_text_cache(W, text_emb, B2, cache, (float*)ws, ws_bytes / sizeof(float), S(stream));
+    LADIFF_CHECK_ARG(load_weights(W, w) && text_emb && tables && cache && ws && B2 > 0 && n_steps > 0);
+    return denoiser_text_cache(W, text_emb, B2, tables, n_steps, cache, (float*)ws, ws_bytes / sizeof(float), S(stream));
 }
 
 int ladiff_denoiser_forward(const float* const* w, const float* tables, const int32_t* d_step, const float* text_cache,
-                            const float* sample, int Bs, int dup, int T, const int32_t* counts, float* eps, void* ws,
-                            size_t ws_bytes, ladiff_stream_t stream) {
+                            int n_steps, const float* sample, int Bs, int dup, int T, const int32_t* counts, float* eps,
+                            void* ws, size_t ws_bytes, ladiff_stream_t stream) {
     DenoiserW W;
-    LADIFF_CHECK_ARG(load_weights(W, w) && tables && d_step && text_cache && sample && eps && ws && Bs > 0 && dup > 0);
-    return denoiser_forward(W, tables, d_step, text_cache, sample, Bs, dup, T, counts, eps, (float*)ws,
+    LADIFF_CHECK_ARG(load_weights(W, w) && tables && d_step && text_cache && sample && eps && ws && Bs > 0 && dup > 0 && n_steps > 0);
+    return denoiser_forward(W, tables, d_step, text_cache, n_steps, sample, Bs, dup, T, counts, eps, (float*)ws,
                             ws_bytes / sizeof(float), S(stream));
 }
 
@@ -203,12 +237,12 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
 
     // hoisted, once per call: time tables for every step, text cache, initial latents, step counter
     LADIFF_TRY(denoiser_time_tables(W, sinusoid, n_steps, r.tables, r.fwd, r.fwd_floats, s));
-    LADIFF_TRY(denoiser_text_cache(W, text_emb, B2, r.cache, r.fwd, r.fwd_floats, s));
+    LADIFF_TRY(denoiser_text_cache(W, text_emb, B2, r.tables, n_steps, r.cache, r.fwd, r.fwd_floats, s));
     LADIFF_TRY(launch_init_latents(init_noise, counts, init_noise_sigma, r.latents, B, T, s));
     LADIFF_HIP(hipMemsetAsync(r.d_step, 0, sizeof(int32_t), s));
 
     auto one_step = [&](hipStream_t st) -> int {
-        LADIFF_TRY(denoiser_forward(W, r.tables, r.d_step, r.cache, r.latents, B, 2, T, counts, r.eps, r.fwd, r.fwd_floats, st));
+        LADIFF_TRY(denoiser_forward(W, r.tables, r.d_step, r.cache, n_steps, r.latents, B, 2, T, counts, r.eps, r.fwd, r.fwd_floats, st));
         LADIFF_TRY(launch_cfg_step(r.eps, r.latents, coef, r.d_step, step_noise, guidance_scale, 1, B, T, st));
         return launch_advance(r.d_step, st);
     };

@@ -90,20 +90,33 @@ int denoiser_time_tables(const DenoiserW& w, const float* sinus, int n, float* t
 }
 
 // ------------------------------------------------------------------ text cache
-//   [B2,256]      emb_proj(text)                      (ladiff_denoiser.py:198)
-//   [9][B2,512]   K | V of the text token per layer   (sa_block in_proj rows 256..767)
-//   [9][B2,256]   StylizationBlock.norm(value(text_norm(xf))) per layer (mdiff_transformer.py:237, :161)
-size_t den_text_cache_floats(int B2) { return (size_t)B2 * D + (size_t)NL * B2 * 3 * D; }
-static size_t text_ws_floats(int B2) { return (size_t)B2 * TEXT_DIM + (size_t)B2 * D; }
+//   [B2,256]              emb_proj(text)                      (ladiff_denoiser.py:198)
+//   [9][B2,512]           K | V of the text token per layer   (sa_block in_proj rows 256..767)
+//   [9][n][B2+1,256]      c table: the whole ca_block delta   (mdiff_transformer.py:219-247 with ONE text token)
+// With one text token softmax(key) over the token axis is exactly 1 and sum_d softmax(query)_d = 1, so the attention
+// output of a valid latent row is the value vector v_b of its sample and of a padded row is 0; the block then adds
+//   c[step, layer, b]   = out( SiLU( LN(v_b) * (1 + scale) + shift ) )     for valid rows
+//   c[step, layer, pad] = out( SiLU( beta    * (1 + scale) + shift ) )     for padded rows (LN(0) = beta)
+// which depends on (step, layer, sample) only - never on the latents - so it is computed once per call for every
+// step instead of 9 x n_steps times inside the loop.
+size_t den_text_cache_floats(int B2, int n) {
+    return (size_t)B2 * D + (size_t)NL * B2 * 2 * D + (size_t)NL * n * (B2 + 1) * D;
+}
+size_t den_text_ws_floats(int B2, int n) {
+    return (size_t)B2 * TEXT_DIM + (size_t)B2 * D + (size_t)B2 * D + (size_t)n * (B2 + 1) * D;
+}
 
-int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, float* cache, float* ws, size_t ws_floats,
-                        hipStream_t s) {
-    if (ws_floats < text_ws_floats(B2)) return LADIFF_ERR_WORKSPACE;
+int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, const float* tables, int n, float* cache,
+                        float* ws, size_t ws_floats, hipStream_t s) {
+    if (ws_floats < den_text_ws_floats(B2, n)) return LADIFF_ERR_WORKSPACE;
     float* rl = ws;
     float* tn = rl + (size_t)B2 * TEXT_DIM;
+    float* nval = tn + (size_t)B2 * D;
+    float* u = nval + (size_t)B2 * D;
     float* tproj = cache;
     float* tkv = cache + (size_t)B2 * D;
-    float* nval = tkv + (size_t)NL * B2 * 2 * D;
+    float* ctab = tkv + (size_t)NL * B2 * 2 * D;
+    const int R = B2 + 1;
     LADIFF_TRY(launch_relu(text, rl, (size_t)B2 * TEXT_DIM, s));
     LADIFF_TRY(launch_gemm(lin(rl, TEXT_DIM, w.emb_proj, tproj, D, B2, D, TEXT_DIM), s));
     for (int l = 0; l < NL; ++l) {
@@ -111,17 +124,38 @@ int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, float* ca
         LinearW kvw{L.sa_attn.in_w + (size_t)D * D, L.sa_attn.in_b + D};
         LADIFF_TRY(launch_gemm(lin(tproj, D, kvw, tkv + (size_t)l * B2 * 2 * D, 2 * D, B2, 2 * D, D), s));
         LADIFF_TRY(launch_layernorm(tproj, L.ca_text_norm.g, L.ca_text_norm.b, tn, B2, s));
-        GemmArgs g = lin(tn, D, L.ca_value, nval + (size_t)l * B2 * D, D, B2, D, D);
+        GemmArgs g = lin(tn, D, L.ca_value, nval, D, B2, D, D);
         g.ln_g = L.ca_proj.norm.g; g.ln_b = L.ca_proj.norm.b;
         LADIFF_TRY(launch_gemm(g, s));
+        LADIFF_TRY(launch_ca_table_input(nval, L.ca_proj.norm.b, tables + (size_t)l * DEN_LAYER_STRIDE + DEN_OFF_CA_MOD,
+                                         DEN_STEP_STRIDE, n, B2, u, s));
+        LADIFF_TRY(launch_gemm(lin(u, D, L.ca_proj.out, ctab + (size_t)l * n * R * D, D, n * R, D, D), s));
     }
     return 0;
 }
 
 // ------------------------------------------------------------------ forward
-size_t den_forward_ws_floats(int B2, int T) { return (size_t)B2 * T * (8 * D + 3 * D + D + FF + D); }
+// Per layer (10 launches, 12 on the four output blocks); M = 2B*T rows, fp32 throughout:
+//   [skip]  x   = linear_blocks([x | xs.pop()])      split-K 2 + combine                       cross_attention.py:79-82
+//   qkv         = in_proj(x)                          N=768                                     mdiff_transformer.py:60-61
+//   att         = softmax over [latents | text | time] keys . V                                 :296-313
+//   R1          = x + out_proj(att)                   N=256 (the pre-norm1 sum)                 :62
+//   hid         = relu(linear1(LN1(R1)))              LN1 = GEMM prologue, X1 = LN1(R1) stored  :63-64
+//   part        = linear2(hid)                        K=1024 as split-K 4                       :64
+//   X3          = LN2(X1 + sum part + b) + c          combine kernel; c = hoisted ca_block      :65-66, :219-247
+//   hid         = gelu(ffn.linear1(X3))                                                         :260
+//   part        = ffn.linear2(hid)                    split-K 4
+//   u           = SiLU(LN(sum part + b) * (1 + scale_t) + shift_t)   combine kernel            :152-162
+//   x'          = X3 + out_layers(u)                  N=256                                     :162, :261
+size_t den_forward_ws_floats(int B2, int T) { return (size_t)B2 * T * (8 * D + 3 * D + D + FF + 4 * D); }
 
-int denoiser_forward(const DenoiserW& w, const float* tables, const int32_t* d_step, const float* cache,
+static KrArgs kr(const float* A, int lda, const float* W, const float* b, float* Y, int ldy, int M, int N, int K, int act = ACT_NONE) {
+    KrArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.bias = b; g.Y = Y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.act = act;
+    return g;
+}
+
+int denoiser_forward(const DenoiserW& w, const float* tables, const int32_t* d_step, const float* cache, int n_steps,
                      const float* sample, int Bs, int dup, int T, const int32_t* counts, float* eps, float* ws,
                      size_t ws_floats, hipStream_t s) {
     const int B2 = Bs * dup;
@@ -136,9 +170,10 @@ int denoiser_forward(const DenoiserW& w, const float* tables, const int32_t* d_s
     float* qkv = p; p += 3 * MD;
     float* att = p; p += MD;
     float* hid = p; p += (size_t)M * FF;
-    float* u = p;
+    float* part = p;                                  // split-K partial planes [4][M][256]
     const float* tkv = cache + (size_t)B2 * D;
-    const float* nval = tkv + (size_t)NL * B2 * 2 * D;
+    const float* ctab = tkv + (size_t)NL * B2 * 2 * D;
+    const int R = B2 + 1;
 
     // x = cat([sample]*dup) + query_pos.pe[:T]        ladiff.py:472-474, ladiff_denoiser.py:251
     LADIFF_TRY(launch_add_pe(sample, w.query_pe, Bs, dup, T, P[0], s));
@@ -147,48 +182,42 @@ int denoiser_forward(const DenoiserW& w, const float* tables, const int32_t* d_s
         const DenLayerW& L = w.layer[l];
         const float* tl = tables + (size_t)l * DEN_LAYER_STRIDE;
         const bool is_in = l < NSKIP, is_out = l > NSKIP;
-        if (is_out) {   // x = linear(cat([x, xs.pop()]))   cross_attention.py:79-82 (LIFO)
-            GemmArgs g = lin(cur, D, w.skip[l - NSKIP - 1], P[3], D, M, D, 2 * D);
+        if (is_out) {
+            const LinearW& sk = w.skip[l - NSKIP - 1];
+            KrArgs g = kr(cur, D, sk.w, nullptr, part, D, M, D, 2 * D);
             g.A2 = SK[NL - 1 - l]; g.lda2 = D; g.K1 = D;
-            LADIFF_TRY(launch_gemm(g, s));
+            LADIFF_TRY(launch_gemm_kr(g, s));
+            LADIFF_TRY(launch_reduce_rows(part, 2, M, sk.b, nullptr, RED_PLAIN, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                                          1, 1, 0, P[3], s));
             cur = P[3];
         }
-        // ---- sa_block: post-norm encoder layer over [latents | text | time]   mdiff_transformer.py:54-67
-        LADIFF_TRY(launch_gemm(lin(cur, D, LinearW{L.sa_attn.in_w, L.sa_attn.in_b}, qkv, 3 * D, M, 3 * D, D), s));
+        LADIFF_TRY(launch_gemm_kr(kr(cur, D, L.sa_attn.in_w, L.sa_attn.in_b, qkv, 3 * D, M, 3 * D, D), s));
         LADIFF_TRY(launch_denoiser_self_attention(qkv, tkv + (size_t)l * B2 * 2 * D, tl, DEN_OFF_TIME_KV, DEN_STEP_STRIDE,
                                                   d_step, counts, Bs, B2, T, att, s));
-        {
-            GemmArgs g = lin(att, D, LinearW{L.sa_attn.out_w, L.sa_attn.out_b}, P[1], D, M, D, D);
-            g.res = cur; g.ldres = D; g.ln_g = L.sa_norm1.g; g.ln_b = L.sa_norm1.b;
-            LADIFF_TRY(launch_gemm(g, s));
+        {   // R1 = x + out_proj(att) -> P[1]
+            KrArgs g = kr(att, D, L.sa_attn.out_w, L.sa_attn.out_b, P[1], D, M, D, D);
+            g.res = cur; g.ldres = D;
+            LADIFF_TRY(launch_gemm_kr(g, s));
         }
-        LADIFF_TRY(launch_gemm(lin(P[1], D, L.sa_lin1, hid, FF, M, FF, D, ACT_RELU), s));
-        {
-            GemmArgs g = lin(hid, FF, L.sa_lin2, P[2], D, M, D, FF);
-            g.res = P[1]; g.ldres = D; g.ln_g = L.sa_norm2.g; g.ln_b = L.sa_norm2.b;
-            LADIFF_TRY(launch_gemm(g, s));
+        {   // hid = relu(linear1(X1)), X1 = LN1(R1) -> P[2]
+            KrArgs g = kr(P[1], D, L.sa_lin1.w, L.sa_lin1.b, hid, FF, M, FF, D, ACT_RELU);
+            g.pro = KR_PRO_LN; g.ln_g = L.sa_norm1.g; g.ln_b = L.sa_norm1.b; g.Xout = P[2];
+            LADIFF_TRY(launch_gemm_kr(g, s));
         }
-        // ---- ca_block with one text token: x + out(SiLU(AdaLN(value_b | 0)))   mdiff_transformer.py:219-247
-        LADIFF_TRY(launch_ca_stylize(nval + (size_t)l * B2 * D, L.ca_proj.norm.b, tl, DEN_OFF_CA_MOD, DEN_STEP_STRIDE, d_step,
-                                     counts, Bs, T, M, u, s));
-        {
-            GemmArgs g = lin(u, D, L.ca_proj.out, P[1], D, M, D, D);
-            g.res = P[2]; g.ldres = D;
-            LADIFF_TRY(launch_gemm(g, s));
-        }
-        // ---- ffn: x + out(SiLU(AdaLN(linear2(GELU(linear1 x)))))   mdiff_transformer.py:259-262
-        LADIFF_TRY(launch_gemm(lin(P[1], D, L.ffn1, hid, FF, M, FF, D, ACT_GELU), s));
-        {
-            GemmArgs g = lin(hid, FF, L.ffn2, u, D, M, D, FF);
-            g.ln_g = L.ffn_proj.norm.g; g.ln_b = L.ffn_proj.norm.b;
-            g.mod = tl + DEN_OFF_FFN_MOD; g.d_step = d_step; g.mod_stride = DEN_STEP_STRIDE; g.post_act = ACT_SILU;
-            LADIFF_TRY(launch_gemm(g, s));
-        }
+        // X3 = LN2(X1 + linear2(hid)) + c[step, layer, sample] -> P[1]
+        LADIFF_TRY(launch_gemm_kr(kr(hid, FF, L.sa_lin2.w, nullptr, part, D, M, D, FF), s));
+        LADIFF_TRY(launch_reduce_rows(part, 4, M, L.sa_lin2.b, P[2], RED_LN_ADD, L.sa_norm2.g, L.sa_norm2.b,
+                                      ctab + (size_t)l * n_steps * R * D, R * D, d_step, counts, Bs, T, B2, P[1], s));
+        // u = SiLU(AdaLN(ffn.linear2(gelu(ffn.linear1(X3))))) -> P[2]
+        LADIFF_TRY(launch_gemm_kr(kr(P[1], D, L.ffn1.w, L.ffn1.b, hid, FF, M, FF, D, ACT_GELU), s));
+        LADIFF_TRY(launch_gemm_kr(kr(hid, FF, L.ffn2.w, nullptr, part, D, M, D, FF), s));
+        LADIFF_TRY(launch_reduce_rows(part, 4, M, L.ffn2.b, nullptr, RED_LN_MOD, L.ffn_proj.norm.g, L.ffn_proj.norm.b,
+                                      tl + DEN_OFF_FFN_MOD, DEN_STEP_STRIDE, d_step, nullptr, 1, 1, 0, P[2], s));
         float* dst = is_in ? SK[l] : P[0];
-        {
-            GemmArgs g = lin(u, D, L.ffn_proj.out, dst, D, M, D, D);
+        {   // x' = X3 + out_layers(u)
+            KrArgs g = kr(P[2], D, L.ffn_proj.out.w, L.ffn_proj.out.b, dst, D, M, D, D);
             g.res = P[1]; g.ldres = D;
-            LADIFF_TRY(launch_gemm(g, s));
+            LADIFF_TRY(launch_gemm_kr(g, s));
         }
         cur = dst;
     }

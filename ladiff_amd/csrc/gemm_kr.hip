@@ -1,0 +1,300 @@
+// K-resident fp32 MFMA GEMM for the small-M (denoiser) side of the path:  Y[M,N] = epi( pro(A)[M,K] . W[N,K]^T )
+//
+// The denoiser works on M = 2B*T = 1280 rows per step, so a GEMM is ~0.2-0.7 GFLOP: one tile per CU and a few
+// microseconds of MFMA.  Measured on MI355X (profiles/r1): after every kernel boundary the operands come from the
+// Infinity Cache at ~33 GB/s per CU, so a workgroup's life is launch (~2 us) + fill + MFMA, and the fill is as long as
+// the MFMA.  This kernel therefore (1) moves the minimum bytes per workgroup - one 256-wide K slice of a tile that
+// gives ~256 workgroups (80x64 for N=1024, 64x64 for N=768, 32x32 for N=256), with split-K over blockIdx.y for the
+// K=1024/512 GEMMs (partials are combined by reduce_rows_kernel, which also applies the LayerNorm that follows them);
+// (2) issues ALL of its loads at kernel entry as LDS-DMA (`global_load_lds_dwordx4`: no VGPRs, ~36 KiB in flight per
+// wave); (3) starts the MFMAs after the first 64-wide K sub-slice has landed (counted `s_waitcnt vmcnt(N)` + raw
+// `s_barrier`), the other three sub-slices stream in underneath.
+//
+// LDS image: [4 sub-slices][BM + BN rows][64 floats] (256-byte rows = one LDS bank row).  One LDS-DMA instruction
+// writes 1 KiB = 4 consecutive rows of one sub-slice, lane i -> row i/16, 16-byte slot i%16.  The slot is XOR-swizzled
+// with (row & 15) ON THE SOURCE ADDRESS (the LDS side of an LDS-DMA is always linear), and the fragment reads apply the
+// same XOR, which makes the ds_read_b128 of both MFMA shapes bank-conflict free.
+//
+// PRO_LN: because the A tile holds complete 256-wide rows when K == 256, LayerNorm of the *input* rows runs as a
+// prologue on the LDS image (4 lanes per row, quad DPP reductions; gamma/beta arrive by LDS-DMA with the tile); every
+// column block of a row tile repeats it (20 K elements, ~1 us) and column block 0 stores the normalised rows, which are
+// the next residual.  Used for norm1 -> sa_block.linear1 (mdiff_transformer.py:63-64).
+#include "gemm_kr.h"
+
+namespace ladiff {
+
+namespace {
+
+template <int MT> struct Mf;
+template <> struct Mf<32> {
+    typedef f32x16 Acc;
+    static constexpr int REGS = 16, KG = 8;
+    __device__ static __forceinline__ Acc mma(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int frow(int l) { return l & 31; }
+    __device__ static __forceinline__ int fk(int l) { return l >> 5; }
+    __device__ static __forceinline__ int arow(int l, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (l >> 5); }
+    __device__ static __forceinline__ int acol(int l) { return l & 31; }
+};
+template <> struct Mf<16> {
+    typedef f32x4 Acc;
+    static constexpr int REGS = 4, KG = 16;
+    __device__ static __forceinline__ Acc mma(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int frow(int l) { return l & 15; }
+    __device__ static __forceinline__ int fk(int l) { return l >> 4; }
+    __device__ static __forceinline__ int arow(int l, int r) { return 4 * (l >> 4) + r; }
+    __device__ static __forceinline__ int acol(int l) { return l & 15; }
+};
+
+// sum over the 4 lanes of a quad (DPP quad_perm, no LDS round trip)
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // [2,3,0,1]
+    return v;
+}
+
+#ifdef LADIFF_STAMPS
+#define STAMP(i)                                                                                      \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long t_;                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if (p.stamps != nullptr && tid == 0) p.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = t_; \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+}  // namespace
+
+template <int BM, int BN, int WM, int WN, int MT, bool PRO>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
+    typedef Mf<MT> MM;
+    typedef typename MM::Acc Acc;
+    constexpr int NW = WM * WN;
+    constexpr int TMW = BM / WM, TNW = BN / WN;
+    constexpr int RM = TMW / MT, RN = TNW / MT;
+    constexpr int ROWS = BM + BN;                  // LDS rows of one sub-slice (A rows then W rows)
+    constexpr int SUB = ROWS * 64;                 // floats per sub-slice
+    constexpr int PCS = ROWS / 4;                  // 1-KiB pieces per sub-slice
+    constexpr int PCS_A = BM / 4;
+    static_assert(NW == 4, "four waves per workgroup");
+    static_assert(PCS % NW == 0 && PCS_A % NW == 0, "pieces must split evenly over the waves");
+    constexpr int PW = 4 * PCS / NW;               // pieces per wave
+    constexpr int PW_SUB = PCS / NW;               // ... per sub-slice
+    constexpr int PW_A = 4 * PCS_A / NW;           // ... of the A tile (prologue ordering)
+    constexpr int PW_W = PW - PW_A;
+    static_assert(PW + 1 <= 63, "vmcnt is 6 bits");
+
+    __shared__ __attribute__((aligned(1024))) float lds[4 * SUB + (PRO ? 512 : 0)];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nbn = (p.N + BN - 1) / BN;
+    const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
+    const int ks = blockIdx.y;                     // K slice (split-K)
+    const int row0 = bm * BM, col0 = bn * BN;
+    const bool partial = gridDim.y > 1;            // split-K: raw partial sums, combined by reduce_rows_kernel
+
+    // ---- residual tile first: these loads are OLDER than every LDS-DMA piece, so the counted waits below also
+    // retire them and the epilogue never stalls on a dependent global load
+    const int arow_base = row0 + wm * TMW;
+    const int acol_base = col0 + wn * TNW + MM::acol(lane);
+    float rv[RM][RN][MM::REGS];
+    const bool has_res = !partial && p.res != nullptr;
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < MM::REGS; ++r) {
+                const int gr = arow_base + i * MT + MM::arow(lane, r), gc = acol_base + j * MT;
+                rv[i][j][r] = (has_res && gr < p.M && gc < p.N) ? p.res[(size_t)gr * p.ldres + gc] : 0.f;
+            }
+
+    // ---- LDS-DMA pieces.  A piece = 4 rows x 64 floats of one sub-slice; wave w takes rows 16 g + 4 w .. + 3 of every
+    // 16-row group g, so (sub-slice, group, A-or-W) are compile-time per issue slot and only a row clamp is left at run time.
+    constexpr int GA = BM / 16, GT = ROWS / 16;    // 16-row groups: A tile, total
+    static_assert(BM % 16 == 0 && BN % 16 == 0, "tiles are multiples of 16 rows");
+    const int rl = 4 * wave + (lane >> 4);         // row within a 16-row group = LDS row & 15
+    const int kl = (((lane & 15) ^ rl) << 2) + (ks << 8);   // this lane's k: swizzled 16-byte slot + K slice
+    // Workgroups that share operand rows (same bm: A rows, same bn: W rows) start at the same time; rotating which
+    // 64-wide k block lands in LDS sub-slice s keeps them from all missing on the same cache lines at once.
+    const int rot = (bm + bn) & 3;
+    const float* abase; int ald;
+    if ((ks << 8) < p.K1) { abase = p.A; ald = p.lda; } else { abase = p.A2 - p.K1; ald = p.lda2; }
+    float* const lbase = lds + 4 * wave * 64;
+    auto issue = [&](int s, int g) __attribute__((always_inline)) {   // s, g are compile-time at every call site
+        const float* src;
+        if (g < GA) {
+            int gr = row0 + 16 * g + rl; gr = gr < p.M ? gr : p.M - 1;
+            src = abase + (size_t)gr * ald + kl + (((s + rot) & 3) << 6);
+        } else {
+            int gc = col0 + 16 * (g - GA) + rl; gc = gc < p.N ? gc : p.N - 1;
+            src = p.W + (size_t)gc * p.ldw + kl + (((s + rot) & 3) << 6);
+        }
+        glds16(src, lbase + s * SUB + 16 * g * 64);
+    };
+
+    Acc acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < MM::REGS; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = MM::frow(lane), fk = MM::fk(lane);
+    auto compute_sub = [&](int s) __attribute__((always_inline)) {
+        const float* sa = lds + s * SUB + (wm * TMW) * 64;
+        const float* sb = lds + s * SUB + (BM + wn * TNW) * 64;
+#pragma unroll
+        for (int g = 0; g < 64 / MM::KG; ++g) {
+            const int c = g * (MM::KG / 4) + fk;
+            f32x4 fa[RM], fb[RN];
+#pragma unroll
+            for (int i = 0; i < RM; ++i) { const int r = i * MT + frow; fa[i] = ld4(sa + r * 64 + ((c ^ ((wm * TMW + r) & 15)) << 2)); }
+#pragma unroll
+            for (int j = 0; j < RN; ++j) { const int r = j * MT + frow; fb[j] = ld4(sb + r * 64 + ((c ^ ((BM + wn * TNW + r) & 15)) << 2)); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+#pragma unroll
+                    for (int j = 0; j < RN; ++j) acc[i][j] = MM::mma(fa[i][e], fb[j][e], acc[i][j]);
+        }
+    };
+
+    if constexpr (PRO) {
+        // ---- A pieces, then gamma | beta (one piece per wave: waves 0,2 gamma, waves 1,3 beta), then the W pieces
+        float* gam = lds + 4 * SUB;
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+            for (int g = 0; g < GA; ++g) issue(ss, g);
+        glds16(((wave & 1) ? p.ln_b : p.ln_g) + lane * 4, gam + (wave & 1) * 256);
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+            for (int g = GA; g < GT; ++g) issue(ss, g);
+        wait_vmcnt<PW_W>();                         // A tile + gamma/beta have landed; W still streaming
+        __builtin_amdgcn_s_barrier();
+        // LayerNorm on the LDS image: 4 lanes per row (lane&3 = sub-slice), 16 rows per wave and pass
+        const int q = lane & 3;
+#pragma unroll
+        for (int pass = 0; pass < (BM + 63) / 64; ++pass) {
+            const int r = pass * 64 + wave * 16 + (lane >> 2);
+            if (r < BM) {
+                float* rowp = lds + q * SUB + r * 64;
+                f32x4 v[16];
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    v[j] = ld4(rowp + (((j + lane) & 15) << 2));      // rotate the slot by the lane: conflict-free
+                    sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+                }
+                sum = quad_sum(sum);
+                const float mean = sum * (1.f / 256.f);
+                float sq = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mean; sq += d * d; }
+                sq = quad_sum(sq);
+                const float rstd = rsqrtf(sq * (1.f / 256.f) + LN_EPS);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int slot = (j + lane) & 15;
+                    const int k = (((q + rot) & 3) << 6) + ((slot ^ (r & 15)) << 2);
+                    const f32x4 gg = ld4(gam + k), bb = ld4(gam + 256 + k);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[j][e] = (v[j][e] - mean) * rstd * gg[e] + bb[e];
+                    st4(rowp + (slot << 2), v[j]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_vmcnt<PW_W - PW_W / 4>();
+        __builtin_amdgcn_s_barrier();
+        if (p.Xout != nullptr && bn == 0) {         // normalised rows = the next residual; one row per wave-instruction
+            for (int r = wave; r < BM; r += NW)
+                if (row0 + r < p.M)
+                    st4(p.Xout + (size_t)(row0 + r) * 256 + ((((lane >> 4) + rot) & 3) << 6) + (((lane & 15) ^ (r & 15)) << 2),
+                        ld4(lds + (lane >> 4) * SUB + r * 64 + (lane & 15) * 4));
+        }
+        compute_sub(0);
+        wait_vmcnt<PW_W - 2 * (PW_W / 4)>(); __builtin_amdgcn_s_barrier(); compute_sub(1);
+        wait_vmcnt<PW_W - 3 * (PW_W / 4)>(); __builtin_amdgcn_s_barrier(); compute_sub(2);
+        wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); compute_sub(3);
+    } else {
+        STAMP(0);
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+            for (int g = 0; g < GT; ++g) issue(ss, g);
+        STAMP(1);
+        wait_vmcnt<PW - PW_SUB>(); __builtin_amdgcn_s_barrier(); STAMP(2); compute_sub(0);
+        STAMP(3);
+        wait_vmcnt<PW - 2 * PW_SUB>(); __builtin_amdgcn_s_barrier(); compute_sub(1);
+        wait_vmcnt<PW - 3 * PW_SUB>(); __builtin_amdgcn_s_barrier(); compute_sub(2);
+        wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); STAMP(4); compute_sub(3);
+        STAMP(5);
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    float* Y = p.Y + (partial ? (size_t)ks * p.M * p.ldy : 0);
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        const int gc = acol_base + j * MT;
+        if (gc >= p.N) continue;
+        const float bj = (!partial && p.bias != nullptr) ? p.bias[gc] : 0.f;
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int r = 0; r < MM::REGS; ++r) {
+                const int gr = arow_base + i * MT + MM::arow(lane, r);
+                if (gr >= p.M) continue;
+                float v = acc[i][j][r];
+                if (!partial) v = act_apply(v + bj, p.act) + rv[i][j][r];
+                Y[(size_t)gr * p.ldy + gc] = v;
+            }
+    }
+    STAMP(6);
+}
+
+template <int BM, int BN, int WM, int WN, int MT, bool PRO>
+static int launch_kr_cfg(const KrArgs& a, int splits, hipStream_t s) {
+    const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_kr_kernel<BM, BN, WM, WN, MT, PRO>), dim3(nbm * nbn, splits), dim3(WM * WN * 64), 0, s, a);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+// K == 256: one launch with the fused epilogue.  K == 512 / 1024: split-K, Y must hold K/256 partial planes [K/256][M][ldy].
+int launch_gemm_kr(const KrArgs& a0, hipStream_t s) {
+    KrArgs a = a0;
+    if (a.A2 == nullptr) a.K1 = a.K;
+    LADIFF_CHECK_ARG(a.A && a.W && a.Y && a.M > 0 && a.N > 0 && a.K > 0);
+    if (a.K % 256 != 0 || a.K1 % 256 != 0 || (a.lda % 4) || (a.ldw % 4) || (a.A2 && (a.lda2 % 4))) return LADIFF_ERR_SHAPE;
+    const int splits = a.K / 256;
+    if (a.pro != KR_PRO_NONE) {
+        if (a.pro != KR_PRO_LN || a.K != 256 || a.A2 != nullptr || !a.ln_g || !a.ln_b) return LADIFF_ERR_SHAPE;
+        return launch_kr_cfg<80, 64, 1, 4, 16, true>(a, 1, s);
+    }
+    if (splits > 1) {
+        if (splits == 4) return launch_kr_cfg<80, 64, 1, 4, 16, false>(a, splits, s);   // 16 x 4 x 4 = 256 workgroups at M=1280, N=256
+        return launch_kr_cfg<64, 64, 2, 2, 32, false>(a, splits, s);
+    }
+    if (a.N >= 1024) return launch_kr_cfg<80, 64, 1, 4, 16, false>(a, 1, s);
+    if (a.N >= 512) return launch_kr_cfg<64, 64, 2, 2, 32, false>(a, 1, s);
+    return launch_kr_cfg<32, 32, 2, 2, 16, false>(a, 1, s);
+}
+
+}  // namespace ladiff

@@ -5,9 +5,13 @@
 namespace ladiff {
 
 // rowops.hip
+enum RedMode : int { RED_PLAIN = 0, RED_LN_ADD = 2, RED_LN_MOD = 3 };
+int launch_reduce_rows(const float* P, int S, int M, const float* bias, const float* res, int mode, const float* g,
+                       const float* b, const float* tab, int tab_step_stride, const int32_t* d_step,
+                       const int32_t* counts, int Bs, int T, int pad_row, float* out, hipStream_t s);
 int launch_layernorm(const float* x, const float* g, const float* b, float* y, int M, hipStream_t s);
-int launch_ca_stylize(const float* nval, const float* beta, const float* tables, int mod_off, int step_stride,
-                      const int32_t* d_step, const int32_t* counts, int Bs, int T, int M, float* u, hipStream_t s);
+int launch_ca_table_input(const float* nval, const float* beta, const float* mod, int step_stride, int n, int B2, float* u,
+                          hipStream_t s);
 int launch_add_pe(const float* sample, const float* pe, int Bs, int dup, int T, float* x, hipStream_t s);
 int launch_broadcast_pe(const float* pe, int B, int F, float* x, hipStream_t s);
 int launch_relu(const float* x, float* y, size_t n, hipStream_t s);

@@ -1,6 +1,7 @@
 // Host-side sequencing entry points shared by denoiser.hip / decoder.hip / api.hip.
 #pragma once
 #include "gemm.h"
+#include "gemm_kr.h"
 #include "kernels.h"
 #include "weights.h"
 
@@ -14,11 +15,13 @@ constexpr int DEN_LAYER_STRIDE = 6 * D;
 constexpr int DEN_STEP_STRIDE = NL * DEN_LAYER_STRIDE;
 
 size_t den_tables_floats(int n_steps);
-size_t den_text_cache_floats(int B2);
+size_t den_text_cache_floats(int B2, int n_steps);
+size_t den_text_ws_floats(int B2, int n_steps);
 size_t den_forward_ws_floats(int B2, int T);
 int denoiser_time_tables(const DenoiserW& w, const float* sinus, int n, float* tables, float* ws, size_t ws_floats, hipStream_t s);
-int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, float* cache, float* ws, size_t ws_floats, hipStream_t s);
-int denoiser_forward(const DenoiserW& w, const float* tables, const int32_t* d_step, const float* cache,
+int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, const float* tables, int n_steps, float* cache,
+                        float* ws, size_t ws_floats, hipStream_t s);
+int denoiser_forward(const DenoiserW& w, const float* tables, const int32_t* d_step, const float* cache, int n_steps,
                      const float* sample, int Bs, int dup, int T, const int32_t* counts, float* eps, float* ws,
                      size_t ws_floats, hipStream_t s);
 

@@ -38,34 +38,85 @@ int launch_layernorm(const float* x, const float* g, const float* b, float* y, i
     return 0;
 }
 
-// Cross-attention StylizationBlock input for ONE text token (mdiff_transformer.py:234-246, :158-162):
-// with N = 1, softmax(key) over the token axis is exactly 1 and sum_d softmax(query)_d = 1, so the
-// attention output of a valid latent row is the value vector of its sample and of a padded row is 0.
-//   valid row : u = SiLU( LN(v_b) * (1 + scale_t) + shift_t )      (LN(v_b) cached in `nval`)
-//   padded row: u = SiLU( beta    * (1 + scale_t) + shift_t )      (LN(0) = beta)
-__global__ __launch_bounds__(256) void ca_stylize_kernel(const float* __restrict__ nval /*[B2,256]*/,
-                                                         const float* __restrict__ beta,
-                                                         const float* __restrict__ tables, int mod_off,
-                                                         int step_stride, const int32_t* __restrict__ d_step,
-                                                         const int32_t* __restrict__ counts, int Bs, int T, int M,
-                                                         float* __restrict__ u) {
+// Combine split-K partial planes and apply what follows the GEMM in the reference, one wave per 256-wide row:
+//   x = sum_s P[s][row] + bias (+ res[row])
+//   RED_PLAIN   y = x                                              (linear_blocks, cross_attention.py:81)
+//   RED_LN_ADD  y = LN(x) + c[step][sample | pad]                  (norm2, then the hoisted ca_block: mdiff_transformer.py:66, :246)
+//   RED_LN_MOD  y = SiLU( LN(x) * (1 + scale_step) + shift_step )  (StylizationBlock of the FFN: mdiff_transformer.py:161-162)
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ P, int S, size_t plane,
+                                                          const float* __restrict__ bias, const float* __restrict__ res,
+                                                          int mode, const float* __restrict__ g, const float* __restrict__ b,
+                                                          const float* __restrict__ tab, int tab_step_stride,
+                                                          const int32_t* __restrict__ d_step, const int32_t* __restrict__ counts,
+                                                          int Bs, int T, int pad_row, int M, float* __restrict__ out) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     const int c = (threadIdx.x & 63) * 4;
     if (row >= M) return;
-    const int b2 = row / T, t = row % T;
-    const bool valid = counts == nullptr || t < counts[b2 % Bs];
-    const float* mod = tables + (size_t)(*d_step) * step_stride + mod_off;
-    const f32x4 sc = ld4(mod + c), sh = ld4(mod + 256 + c);
-    f32x4 v = valid ? ld4(nval + (size_t)b2 * D + c) : ld4(beta + c);
+    f32x4 v = ld4(P + (size_t)row * D + c);
+    for (int s = 1; s < S; ++s) {
+        const f32x4 t = ld4(P + s * plane + (size_t)row * D + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += t[i];
+    }
+    if (bias != nullptr) { const f32x4 t = ld4(bias + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += t[i]; }
+    if (res != nullptr) { const f32x4 t = ld4(res + (size_t)row * D + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += t[i]; }
+    if (mode != RED_PLAIN) {
+        float mean, rstd;
+        row_stats(v, mean, rstd);
+        const f32x4 gg = ld4(g + c), bb = ld4(b + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i];
+        const float* t = tab + (size_t)(d_step ? *d_step : 0) * tab_step_stride;
+        if (mode == RED_LN_ADD) {
+            const int b2 = row / T, tt = row % T;
+            const bool valid = counts == nullptr || tt < counts[b2 % Bs];
+            const f32x4 cc = ld4(t + (size_t)(valid ? b2 : pad_row) * D + c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += cc[i];
+        } else {
+            const f32x4 sc = ld4(t + c), sh = ld4(t + 256 + c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = silu(v[i] * (1.f + sc[i]) + sh[i]);
+        }
+    }
+    st4(out + (size_t)row * D + c, v);
+}
+
+int launch_reduce_rows(const float* P, int S, int M, const float* bias, const float* res, int mode, const float* g,
+                       const float* b, const float* tab, int tab_step_stride, const int32_t* d_step,
+                       const int32_t* counts, int Bs, int T, int pad_row, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, P, S,
+                       (size_t)M * D, bias, res, mode, g, b, tab, tab_step_stride, d_step, counts, Bs, T, pad_row, M, out);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+// Input rows of the hoisted cross-attention table: u[step, b] = SiLU(nval[b] * (1 + scale_step) + shift_step) for b < B2
+// and u[step, B2] = SiLU(beta * (1 + scale_step) + shift_step) (padded latent rows).  `mod` points at this layer's
+// scale|shift of step 0; consecutive steps are `step_stride` floats apart.
+__global__ __launch_bounds__(256) void ca_table_input_kernel(const float* __restrict__ nval, const float* __restrict__ beta,
+                                                             const float* __restrict__ mod, int step_stride, int B2, int M,
+                                                             float* __restrict__ u) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int c = (threadIdx.x & 63) * 4;
+    if (row >= M) return;
+    const int step = row / (B2 + 1), b = row % (B2 + 1);
+    const float* m = mod + (size_t)step * step_stride;
+    const f32x4 sc = ld4(m + c), sh = ld4(m + 256 + c);
+    f32x4 v = b < B2 ? ld4(nval + (size_t)b * D + c) : ld4(beta + c);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = silu(v[i] * (1.f + sc[i]) + sh[i]);
     st4(u + (size_t)row * D + c, v);
 }
-
-int launch_ca_stylize(const float* nval, const float* beta, const float* tables, int mod_off, int step_stride,
-                      const int32_t* d_step, const int32_t* counts, int Bs, int T, int M, float* u, hipStream_t s) {
-    hipLaunchKernelGGL(ca_stylize_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, nval, beta,
-                       tables, mod_off, step_stride, d_step, counts, Bs, T, M, u);
+int launch_ca_table_input(const float* nval, const float* beta, const float* mod, int step_stride, int n, int B2, float* u,
+                          hipStream_t s) {
+    const int M = n * (B2 + 1);
+    hipLaunchKernelGGL(ca_table_input_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, nval, beta, mod,
+                       step_stride, B2, M, u);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }

@@ -147,15 +147,16 @@ class LADiffDenoiser(_HipModule):
             counts = torch.as_tensor(max_iter_elements).to(device=dev, dtype=torch.int32).contiguous()
         sinus = timestep_sinusoid(t[:1].cpu(), self.text_encoded_dim).to(dev)
         tables = torch.empty(L.ladiff_denoiser_tables_floats(1), dtype=torch.float32, device=dev)
-        cache = torch.empty(L.ladiff_denoiser_text_cache_floats(B2), dtype=torch.float32, device=dev)
+        cache = torch.empty(L.ladiff_denoiser_text_cache_floats(B2, 1), dtype=torch.float32, device=dev)
         wsb = L.ladiff_denoiser_workspace_bytes(B2, T, 1)
         ws = _lib.workspace(wsb, dev)
         step0 = torch.zeros(1, dtype=torch.int32, device=dev)
         eps = torch.empty_like(x)
         st = _lib.stream_ptr()
         _lib.check(L.ladiff_denoiser_time_tables(wt.array, _lib.ptr(sinus), 1, _lib.ptr(tables), _lib.ptr(ws), wsb, st))
-        _lib.check(L.ladiff_denoiser_text_cache(wt.array, _lib.ptr(text), B2, _lib.ptr(cache), _lib.ptr(ws), wsb, st))
-        _lib.check(L.ladiff_denoiser_forward(wt.array, _lib.ptr(tables), step0.data_ptr(), _lib.ptr(cache), _lib.ptr(x),
+        _lib.check(L.ladiff_denoiser_text_cache(wt.array, _lib.ptr(text), B2, _lib.ptr(tables), 1, _lib.ptr(cache),
+                                                _lib.ptr(ws), wsb, st))
+        _lib.check(L.ladiff_denoiser_forward(wt.array, _lib.ptr(tables), step0.data_ptr(), _lib.ptr(cache), 1, _lib.ptr(x),
                                              B2, 1, T, None if counts is None else counts.data_ptr(), _lib.ptr(eps),
                                              _lib.ptr(ws), wsb, st))
         return (eps.to(sample.dtype),)

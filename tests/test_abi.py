@@ -48,7 +48,7 @@ def test_weight_tables_match_reference_schema(lib):
 
 def test_workspace_queries(lib):
     assert lib.ladiff_denoiser_tables_floats(50) == 50 * 9 * 1536
-    assert lib.ladiff_denoiser_text_cache_floats(256) == 256 * 256 + 9 * 256 * 768
+    assert lib.ladiff_denoiser_text_cache_floats(256, 50) == 256 * 256 + 9 * 256 * 512 + 9 * 50 * 257 * 256
     assert lib.ladiff_reverse_workspace_bytes(128, 5, 50) > 0
     assert lib.ladiff_decoder_workspace_bytes(128, 196, 5, 263) >= 128 * 196 * 4096 * 4
 
