@@ -70,17 +70,16 @@ int ladiff_gemm(const float* A, int lda, const float* A2, int lda2, int K1, cons
                 const float* ln_beta, float* Y, int ldy, int M, int N, int K, int act,
                 ladiff_stream_t stream);
 
-/* Small-M variant used by the denoiser loop (K-resident LDS-DMA tiles, K multiple of 256).
- *   K == 256:        Y = act( pro(A) . W^T + bias ) + res;  ln_gamma != NULL: pro(A) = LayerNorm(A), xout (may be
- *                    NULL) receives it (nn.LayerNorm + nn.Linear pair, mdiff_transformer.py:63-64)
+/* Small-M variant used by the denoiser loop (K-resident LDS-DMA tiles, K multiple of 256, N multiple of 4).
+ *   K == 256:        Y = act( A . W^T + bias ) + res
  *   K == 512 / 1024: split-K - Y receives K/256 raw partial planes [K/256][M][ldy]; bias/act/res are NOT applied,
  *                    combine them with ladiff_combine_rows. */
 int ladiff_gemm_resident(const float* A, int lda, const float* A2, int lda2, int K1, const float* W, int ldw,
                          const float* bias, const float* res, int ldres, float* Y, int ldy, int M, int N, int K,
-                         int act, const float* ln_gamma, const float* ln_beta, float* xout, ladiff_stream_t stream);
+                         int act, ladiff_stream_t stream);
 
 /* Rows of 256: x = sum of n_planes partial planes [n_planes][M][256] + bias (+ res), then
- *   mode 0: x;   mode 2: LN(x) + table[sample row | pad_row] (rows grouped T per sample, sample = row / T, padded when
+ *   mode 0: x;   mode 1: LN(x);   mode 2: LN(x) + table[sample row | pad_row] (rows grouped T per sample, sample = row / T, padded when
  *   row % T >= counts[sample % Bs]);   mode 3: SiLU(LN(x) * (1 + table[0:256]) + table[256:512]).
  * Replaces the residual / LayerNorm / StylizationBlock element-wise tails at mdiff_transformer.py:65-66, :160-162. */
 int ladiff_combine_rows(const float* partials, int n_planes, int M, const float* bias, const float* res, int mode,

@@ -101,13 +101,12 @@ int ladiff_gemm(const float* A, int lda, const float* A2, int lda2, int K1, cons
 
 int ladiff_gemm_resident(const float* A, int lda, const float* A2, int lda2, int K1, const float* W, int ldw,
                          const float* bias, const float* res, int ldres, float* Y, int ldy, int M, int N, int K, int act,
-                         const float* ln_gamma, const float* ln_beta, float* xout, ladiff_stream_t stream) {
+                         ladiff_stream_t stream) {
     LADIFF_CHECK_ARG(A && W && Y && M >= 0 && N > 0 && K > 0);
     if (M == 0) return 0;
     KrArgs g;
     g.A = A; g.lda = lda; g.A2 = A2; g.lda2 = lda2; g.K1 = A2 ? K1 : K; g.W = W; g.ldw = ldw; g.bias = bias;
     g.res = res; g.ldres = ldres; g.Y = Y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.act = act;
-    g.pro = ln_gamma ? KR_PRO_LN : KR_PRO_NONE; g.ln_g = ln_gamma; g.ln_b = ln_beta; g.Xout = xout;
 #ifdef LADIFF_STAMPS
     g.stamps = g_stamps;
 #endif
@@ -122,8 +121,9 @@ int ladiff_combine_rows(const float* partials, int n_planes, int M, const float*
                         const float* ln_gamma, const float* ln_beta, const float* table, const int32_t* counts, int Bs,
                         int T, int pad_row, float* out, ladiff_stream_t stream) {
     LADIFF_CHECK_ARG(partials && out && n_planes > 0 && M >= 0 && Bs > 0 && T > 0);
-    if (mode != RED_PLAIN && mode != RED_LN_ADD && mode != RED_LN_MOD) return LADIFF_ERR_ARG;
-    if (mode != RED_PLAIN && !(ln_gamma && ln_beta && table)) return LADIFF_ERR_ARG;
+    if (mode != RED_PLAIN && mode != RED_LN && mode != RED_LN_ADD && mode != RED_LN_MOD) return LADIFF_ERR_ARG;
+    if (mode != RED_PLAIN && !(ln_gamma && ln_beta)) return LADIFF_ERR_ARG;
+    if ((mode == RED_LN_ADD || mode == RED_LN_MOD) && !table) return LADIFF_ERR_ARG;
     if (M == 0) return 0;
     return launch_reduce_rows(partials, n_planes, M, bias, res, mode, ln_gamma, ln_beta, table, 0, nullptr, counts, Bs, T,
                               pad_row, out, S(stream));

@@ -135,12 +135,13 @@ int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, const flo
 }
 
 // ------------------------------------------------------------------ forward
-// Per layer (10 launches, 12 on the four output blocks); M = 2B*T rows, fp32 throughout:
+// Per layer (11 launches, 13 on the four output blocks); M = 2B*T rows, fp32 throughout:
 //   [skip]  x   = linear_blocks([x | xs.pop()])      split-K 2 + combine                       cross_attention.py:79-82
 //   qkv         = in_proj(x)                          N=768                                     mdiff_transformer.py:60-61
 //   att         = softmax over [latents | text | time] keys . V                                 :296-313
 //   R1          = x + out_proj(att)                   N=256 (the pre-norm1 sum)                 :62
-//   hid         = relu(linear1(LN1(R1)))              LN1 = GEMM prologue, X1 = LN1(R1) stored  :63-64
+//   X1          = LN1(R1)                             row kernel                                :63
+//   hid         = relu(linear1(X1))                                                             :64
 //   part        = linear2(hid)                        K=1024 as split-K 4                       :64
 //   X3          = LN2(X1 + sum part + b) + c          combine kernel; c = hoisted ca_block      :65-66, :219-247
 //   hid         = gelu(ffn.linear1(X3))                                                         :260
@@ -199,11 +200,10 @@ int denoiser_forward(const DenoiserW& w, const float* tables, const int32_t* d_s
             g.res = cur; g.ldres = D;
             LADIFF_TRY(launch_gemm_kr(g, s));
         }
-        {   // hid = relu(linear1(X1)), X1 = LN1(R1) -> P[2]
-            KrArgs g = kr(P[1], D, L.sa_lin1.w, L.sa_lin1.b, hid, FF, M, FF, D, ACT_RELU);
-            g.pro = KR_PRO_LN; g.ln_g = L.sa_norm1.g; g.ln_b = L.sa_norm1.b; g.Xout = P[2];
-            LADIFF_TRY(launch_gemm_kr(g, s));
-        }
+        // X1 = LN1(R1) -> P[2];  hid = relu(linear1(X1))
+        LADIFF_TRY(launch_reduce_rows(P[1], 1, M, nullptr, nullptr, RED_LN, L.sa_norm1.g, L.sa_norm1.b, nullptr, 0, nullptr,
+                                      nullptr, 1, 1, 0, P[2], s));
+        LADIFF_TRY(launch_gemm_kr(kr(P[2], D, L.sa_lin1.w, L.sa_lin1.b, hid, FF, M, FF, D, ACT_RELU), s));
         // X3 = LN2(X1 + linear2(hid)) + c[step, layer, sample] -> P[1]
         LADIFF_TRY(launch_gemm_kr(kr(hid, FF, L.sa_lin2.w, nullptr, part, D, M, D, FF), s));
         LADIFF_TRY(launch_reduce_rows(part, 4, M, L.sa_lin2.b, P[2], RED_LN_ADD, L.sa_norm2.g, L.sa_norm2.b,

@@ -4,8 +4,6 @@
 
 namespace ladiff {
 
-enum KrPrologue : int { KR_PRO_NONE = 0, KR_PRO_LN = 1 };
-
 struct KrArgs {
     const float* A = nullptr;  int lda = 0;       // [M, K1]
     const float* A2 = nullptr; int lda2 = 0;      // optional second K segment (skip concat), K1 multiple of 256
@@ -16,10 +14,6 @@ struct KrArgs {
     int M = 0, N = 0, K = 0;                      // K multiple of 256
     int act = ACT_NONE;
     const float* res = nullptr; int ldres = 0;    // + residual after the activation
-    // prologue on the A rows (K == 256 only): A <- LayerNorm(A); column block 0 stores the result to Xout
-    int pro = KR_PRO_NONE;
-    const float* ln_g = nullptr; const float* ln_b = nullptr;
-    float* Xout = nullptr;
     unsigned long long* stamps = nullptr;         // diagnostic builds only (-DLADIFF_STAMPS): 8 x u64 per workgroup
 };
 

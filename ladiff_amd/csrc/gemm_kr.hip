@@ -15,10 +15,6 @@
 // with (row & 15) ON THE SOURCE ADDRESS (the LDS side of an LDS-DMA is always linear), and the fragment reads apply the
 // same XOR, which makes the ds_read_b128 of both MFMA shapes bank-conflict free.
 //
-// PRO_LN: because the A tile holds complete 256-wide rows when K == 256, LayerNorm of the *input* rows runs as a
-// prologue on the LDS image (4 lanes per row, quad DPP reductions; gamma/beta arrive by LDS-DMA with the tile); every
-// column block of a row tile repeats it (20 K elements, ~1 us) and column block 0 stores the normalised rows, which are
-// the next residual.  Used for norm1 -> sa_block.linear1 (mdiff_transformer.py:63-64).
 #include "gemm_kr.h"
 
 namespace ladiff {
@@ -45,13 +41,6 @@ template <> struct Mf<16> {
     __device__ static __forceinline__ int acol(int l) { return l & 15; }
 };
 
-// sum over the 4 lanes of a quad (DPP quad_perm, no LDS round trip)
-__device__ __forceinline__ float quad_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // [2,3,0,1]
-    return v;
-}
-
 #ifdef LADIFF_STAMPS
 #define STAMP(i)                                                                                      \
     do {                                                                                              \
@@ -73,7 +62,7 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 
 }  // namespace
 
-template <int BM, int BN, int WM, int WN, int MT, bool PRO>
+template <int BM, int BN, int WM, int WN, int MT>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
     typedef Mf<MT> MM;
     typedef typename MM::Acc Acc;
@@ -83,16 +72,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
     constexpr int ROWS = BM + BN;                  // LDS rows of one sub-slice (A rows then W rows)
     constexpr int SUB = ROWS * 64;                 // floats per sub-slice
     constexpr int PCS = ROWS / 4;                  // 1-KiB pieces per sub-slice
-    constexpr int PCS_A = BM / 4;
     static_assert(NW == 4, "four waves per workgroup");
-    static_assert(PCS % NW == 0 && PCS_A % NW == 0, "pieces must split evenly over the waves");
+    static_assert(PCS % NW == 0, "pieces must split evenly over the waves");
     constexpr int PW = 4 * PCS / NW;               // pieces per wave
     constexpr int PW_SUB = PCS / NW;               // ... per sub-slice
-    constexpr int PW_A = 4 * PCS_A / NW;           // ... of the A tile (prologue ordering)
-    constexpr int PW_W = PW - PW_A;
-    static_assert(PW + 1 <= 63, "vmcnt is 6 bits");
+    static_assert(PW <= 63, "vmcnt is 6 bits");
 
-    __shared__ __attribute__((aligned(1024))) float lds[4 * SUB + (PRO ? 512 : 0)];
+    __shared__ __attribute__((aligned(1024))) float lds[4 * SUB];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -104,20 +90,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
     const bool partial = gridDim.y > 1;            // split-K: raw partial sums, combined by reduce_rows_kernel
 
     // ---- residual tile first: these loads are OLDER than every LDS-DMA piece, so the counted waits below also
-    // retire them and the epilogue never stalls on a dependent global load
-    const int arow_base = row0 + wm * TMW;
-    const int acol_base = col0 + wn * TNW + MM::acol(lane);
-    float rv[RM][RN][MM::REGS];
+    // retire them and the epilogue never stalls on a dependent global load.  The epilogue works on 16-byte units
+    // (row, 4 columns) spread over the 256 threads so that loads and stores are whole 256-byte row segments.
+    constexpr int UPR = BN / 4;                    // 16-byte units per tile row
+    constexpr int UNITS = BM * UPR / (NW * 64);    // units per thread
+    static_assert((BM * UPR) % (NW * 64) == 0 && (NW * 64) % UPR == 0, "epilogue units must split evenly");
+    constexpr int CLD = BN + 4;                    // LDS row stride of the staged C tile (floats)
+    static_assert(BM * CLD <= 4 * SUB, "C tile must fit in the operand buffers");
+    f32x4 rv[UNITS];
     const bool has_res = !partial && p.res != nullptr;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};               // all units of a thread share their 4 columns (256 % UPR == 0)
+    if (!partial && p.bias != nullptr && col0 + 4 * (tid % UPR) < p.N) bv = ld4(p.bias + col0 + 4 * (tid % UPR));
 #pragma unroll
-    for (int i = 0; i < RM; ++i)
-#pragma unroll
-        for (int j = 0; j < RN; ++j)
-#pragma unroll
-            for (int r = 0; r < MM::REGS; ++r) {
-                const int gr = arow_base + i * MT + MM::arow(lane, r), gc = acol_base + j * MT;
-                rv[i][j][r] = (has_res && gr < p.M && gc < p.N) ? p.res[(size_t)gr * p.ldres + gc] : 0.f;
-            }
+    for (int u = 0; u < UNITS; ++u) {
+        const int id = tid + u * NW * 64;
+        const int gr = row0 + id / UPR, gc = col0 + 4 * (id % UPR);
+        rv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (has_res && gr < p.M && gc < p.N) rv[u] = ld4(p.res + (size_t)gr * p.ldres + gc);
+    }
 
     // ---- LDS-DMA pieces.  A piece = 4 rows x 64 floats of one sub-slice; wave w takes rows 16 g + 4 w .. + 3 of every
     // 16-row group g, so (sub-slice, group, A-or-W) are compile-time per issue slot and only a row clamp is left at run time.
@@ -172,68 +162,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
         }
     };
 
-    if constexpr (PRO) {
-        // ---- A pieces, then gamma | beta (one piece per wave: waves 0,2 gamma, waves 1,3 beta), then the W pieces
-        float* gam = lds + 4 * SUB;
-#pragma unroll
-        for (int ss = 0; ss < 4; ++ss)
-#pragma unroll
-            for (int g = 0; g < GA; ++g) issue(ss, g);
-        glds16(((wave & 1) ? p.ln_b : p.ln_g) + lane * 4, gam + (wave & 1) * 256);
-#pragma unroll
-        for (int ss = 0; ss < 4; ++ss)
-#pragma unroll
-            for (int g = GA; g < GT; ++g) issue(ss, g);
-        wait_vmcnt<PW_W>();                         // A tile + gamma/beta have landed; W still streaming
-        __builtin_amdgcn_s_barrier();
-        // LayerNorm on the LDS image: 4 lanes per row (lane&3 = sub-slice), 16 rows per wave and pass
-        const int q = lane & 3;
-#pragma unroll
-        for (int pass = 0; pass < (BM + 63) / 64; ++pass) {
-            const int r = pass * 64 + wave * 16 + (lane >> 2);
-            if (r < BM) {
-                float* rowp = lds + q * SUB + r * 64;
-                f32x4 v[16];
-                float sum = 0.f;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    v[j] = ld4(rowp + (((j + lane) & 15) << 2));      // rotate the slot by the lane: conflict-free
-                    sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-                }
-                sum = quad_sum(sum);
-                const float mean = sum * (1.f / 256.f);
-                float sq = 0.f;
-#pragma unroll
-                for (int j = 0; j < 16; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mean; sq += d * d; }
-                sq = quad_sum(sq);
-                const float rstd = rsqrtf(sq * (1.f / 256.f) + LN_EPS);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int slot = (j + lane) & 15;
-                    const int k = (((q + rot) & 3) << 6) + ((slot ^ (r & 15)) << 2);
-                    const f32x4 gg = ld4(gam + k), bb = ld4(gam + 256 + k);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[j][e] = (v[j][e] - mean) * rstd * gg[e] + bb[e];
-                    st4(rowp + (slot << 2), v[j]);
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        wait_vmcnt<PW_W - PW_W / 4>();
-        __builtin_amdgcn_s_barrier();
-        if (p.Xout != nullptr && bn == 0) {         // normalised rows = the next residual; one row per wave-instruction
-            for (int r = wave; r < BM; r += NW)
-                if (row0 + r < p.M)
-                    st4(p.Xout + (size_t)(row0 + r) * 256 + ((((lane >> 4) + rot) & 3) << 6) + (((lane & 15) ^ (r & 15)) << 2),
-                        ld4(lds + (lane >> 4) * SUB + r * 64 + (lane & 15) * 4));
-        }
-        compute_sub(0);
-        wait_vmcnt<PW_W - 2 * (PW_W / 4)>(); __builtin_amdgcn_s_barrier(); compute_sub(1);
-        wait_vmcnt<PW_W - 3 * (PW_W / 4)>(); __builtin_amdgcn_s_barrier(); compute_sub(2);
-        wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); compute_sub(3);
-    } else {
+    {
         STAMP(0);
 #pragma unroll
         for (int ss = 0; ss < 4; ++ss)
@@ -248,31 +177,39 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
         STAMP(5);
     }
 
-    // ------------------------------------------------------------------ epilogue
+    // ------------------------------------------------------------------ epilogue, staged through LDS
+    __builtin_amdgcn_s_barrier();                  // every wave is done reading the operand tiles
+    float* ct = lds;
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < MM::REGS; ++r)
+                ct[(wm * TMW + i * MT + MM::arow(lane, r)) * CLD + wn * TNW + j * MT + MM::acol(lane)] = acc[i][j][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     float* Y = p.Y + (partial ? (size_t)ks * p.M * p.ldy : 0);
 #pragma unroll
-    for (int j = 0; j < RN; ++j) {
-        const int gc = acol_base + j * MT;
-        if (gc >= p.N) continue;
-        const float bj = (!partial && p.bias != nullptr) ? p.bias[gc] : 0.f;
+    for (int u = 0; u < UNITS; ++u) {
+        const int id = tid + u * NW * 64;
+        const int lr = id / UPR, lc = 4 * (id % UPR);
+        const int gr = row0 + lr, gc = col0 + lc;
+        if (gr >= p.M || gc >= p.N) continue;
+        f32x4 v = ld4(ct + lr * CLD + lc);
+        if (!partial) {
 #pragma unroll
-        for (int i = 0; i < RM; ++i)
-#pragma unroll
-            for (int r = 0; r < MM::REGS; ++r) {
-                const int gr = arow_base + i * MT + MM::arow(lane, r);
-                if (gr >= p.M) continue;
-                float v = acc[i][j][r];
-                if (!partial) v = act_apply(v + bj, p.act) + rv[i][j][r];
-                Y[(size_t)gr * p.ldy + gc] = v;
-            }
+            for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e] + bv[e], p.act) + rv[u][e];
+        }
+        st4(Y + (size_t)gr * p.ldy + gc, v);
     }
     STAMP(6);
 }
 
-template <int BM, int BN, int WM, int WN, int MT, bool PRO>
+template <int BM, int BN, int WM, int WN, int MT>
 static int launch_kr_cfg(const KrArgs& a, int splits, hipStream_t s) {
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_kr_kernel<BM, BN, WM, WN, MT, PRO>), dim3(nbm * nbn, splits), dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((gemm_kr_kernel<BM, BN, WM, WN, MT>), dim3(nbm * nbn, splits), dim3(WM * WN * 64), 0, s, a);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
@@ -283,18 +220,15 @@ int launch_gemm_kr(const KrArgs& a0, hipStream_t s) {
     if (a.A2 == nullptr) a.K1 = a.K;
     LADIFF_CHECK_ARG(a.A && a.W && a.Y && a.M > 0 && a.N > 0 && a.K > 0);
     if (a.K % 256 != 0 || a.K1 % 256 != 0 || (a.lda % 4) || (a.ldw % 4) || (a.A2 && (a.lda2 % 4))) return LADIFF_ERR_SHAPE;
+    if ((a.N % 4) || (a.ldy % 4) || (a.res && (a.ldres % 4))) return LADIFF_ERR_SHAPE;   // 16-byte epilogue units
     const int splits = a.K / 256;
-    if (a.pro != KR_PRO_NONE) {
-        if (a.pro != KR_PRO_LN || a.K != 256 || a.A2 != nullptr || !a.ln_g || !a.ln_b) return LADIFF_ERR_SHAPE;
-        return launch_kr_cfg<80, 64, 1, 4, 16, true>(a, 1, s);
-    }
     if (splits > 1) {
-        if (splits == 4) return launch_kr_cfg<80, 64, 1, 4, 16, false>(a, splits, s);   // 16 x 4 x 4 = 256 workgroups at M=1280, N=256
-        return launch_kr_cfg<64, 64, 2, 2, 32, false>(a, splits, s);
+        if (splits == 4) return launch_kr_cfg<80, 64, 1, 4, 16>(a, splits, s);   // 16 x 4 x 4 = 256 workgroups at M=1280, N=256
+        return launch_kr_cfg<64, 64, 2, 2, 32>(a, splits, s);
     }
-    if (a.N >= 1024) return launch_kr_cfg<80, 64, 1, 4, 16, false>(a, 1, s);
-    if (a.N >= 512) return launch_kr_cfg<64, 64, 2, 2, 32, false>(a, 1, s);
-    return launch_kr_cfg<32, 32, 2, 2, 16, false>(a, 1, s);
+    if (a.N >= 1024) return launch_kr_cfg<80, 64, 1, 4, 16>(a, 1, s);
+    if (a.N >= 512) return launch_kr_cfg<64, 64, 2, 2, 32>(a, 1, s);
+    return launch_kr_cfg<32, 32, 2, 2, 16>(a, 1, s);
 }
 
 }  // namespace ladiff

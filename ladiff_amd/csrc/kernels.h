@@ -5,7 +5,7 @@
 namespace ladiff {
 
 // rowops.hip
-enum RedMode : int { RED_PLAIN = 0, RED_LN_ADD = 2, RED_LN_MOD = 3 };
+enum RedMode : int { RED_PLAIN = 0, RED_LN = 1, RED_LN_ADD = 2, RED_LN_MOD = 3 };
 int launch_reduce_rows(const float* P, int S, int M, const float* bias, const float* res, int mode, const float* g,
                        const float* b, const float* tab, int tab_step_stride, const int32_t* d_step,
                        const int32_t* counts, int Bs, int T, int pad_row, float* out, hipStream_t s);

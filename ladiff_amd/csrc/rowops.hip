@@ -41,6 +41,7 @@ int launch_layernorm(const float* x, const float* g, const float* b, float* y, i
 // Combine split-K partial planes and apply what follows the GEMM in the reference, one wave per 256-wide row:
 //   x = sum_s P[s][row] + bias (+ res[row])
 //   RED_PLAIN   y = x                                              (linear_blocks, cross_attention.py:81)
+//   RED_LN      y = LN(x)                                          (norm1, mdiff_transformer.py:63)
 //   RED_LN_ADD  y = LN(x) + c[step][sample | pad]                  (norm2, then the hoisted ca_block: mdiff_transformer.py:66, :246)
 //   RED_LN_MOD  y = SiLU( LN(x) * (1 + scale_step) + shift_step )  (StylizationBlock of the FFN: mdiff_transformer.py:161-162)
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ P, int S, size_t plane,
@@ -71,7 +72,8 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i];
         const float* t = tab + (size_t)(d_step ? *d_step : 0) * tab_step_stride;
-        if (mode == RED_LN_ADD) {
+        if (mode == RED_LN) {
+        } else if (mode == RED_LN_ADD) {
             const int b2 = row / T, tt = row % T;
             const bool valid = counts == nullptr || tt < counts[b2 % Bs];
             const f32x4 cc = ld4(t + (size_t)(valid ? b2 : pad_row) * D + c);
