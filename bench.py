@@ -13,7 +13,9 @@ Extra objects on the JSON line:
   roofline     bound = mfma (fp32-input MFMA, 157.3 TF/s dense peak).  achieved = reference-equivalent FLOPs of one
                pass (21.757 GFLOP per motion at F=196, C=263, 50 steps) / the pass's device time
                measured with HIP events on the launching stream.  executed_tflops is the same with the FLOPs the
-               kernels really execute after hoisting (DESIGN.md §5) so the two cannot be conflated.
+               kernels really execute after hoisting (DESIGN.md §4) so the two cannot be conflated.
+               dominant_kernel = the same for the single kernel that takes the largest share of the pass, timed live
+               with HIP events over back-to-back launches; traffic = memory-side bytes from the PMC runs in profiles/.
   cpu_baseline the CPU oracle (oracle/ladiff_oracle.py, a port of the reference's op sequence, fp32 PyTorch) timed on
                the host cores of this box on a bounded sample of the same workload.  Baseline only.
 """
@@ -63,6 +65,32 @@ def build_pipe(dev, batch):
                   num_inference_timesteps=STEPS_DDIM, eta=0.0)
 
 
+def dominant_kernel_roofline(dev, stream, launches=400):
+    """Live HIP-event timing of the kernel that dominates the pass (profiles/r1/02: gemm_kr_kernel<80,64,...>, 41 % of
+    the device time): the denoiser's 256->1024 linear at M = 2*128*5 rows, launched back to back on the bench stream."""
+    from ladiff_amd import _lib
+    L = _lib.lib()
+    M, N, K = 2 * BATCH * 5, 1024, 256
+    A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) / 16; b = torch.randn(N, device=dev)
+    Y = torch.empty(M, N, device=dev)
+    args = (A.data_ptr(), K, None, 0, K, W.data_ptr(), K, b.data_ptr(), None, 0, Y.data_ptr(), N, M, N, K, 2, stream.cuda_stream)
+    with torch.cuda.stream(stream):
+        for _ in range(20):
+            _lib.check(L.ladiff_gemm_resident(*args))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(launches):
+            L.ladiff_gemm_resident(*args)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+    us = e0.elapsed_time(e1) * 1e3 / launches
+    flops = 2.0 * M * N * K
+    return {"name": "gemm_kr_kernel<80,64,1,4,16> (ffn.linear1: M=1280, N=1024, K=256, GELU)", "flops_per_launch": flops,
+            "us_per_launch": round(us, 2), "achieved": round(flops / us / 1e6, 2), "unit": "TFLOP/s",
+            "frac": round(flops / us / 1e6 / PEAK_F32_MFMA_TFLOPS, 4),
+            "traffic": 22.8e6, "traffic_source": "profiles/r1/03_pmc_summary.md: 2 x FETCH_SIZE + WRITE_SIZE per launch"}
+
+
 def cpu_baseline(sample_b):
     """Oracle on the host cores, bounded sample: `sample_b` motions of the same shape (196 frames, 50 steps)."""
     from oracle import ladiff_oracle as orc
@@ -90,6 +118,7 @@ def main():
     args = ap.parse_args()
 
     rank, world, local = D.init_from_env()
+    use_dist = torch.distributed.is_available() and torch.distributed.is_initialized()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
     if not torch.cuda.is_available():
@@ -106,19 +135,19 @@ def main():
     text = torch.cat([gtext[:total][lo:hi], gtext[total:][lo:hi]]).to(dev)
     noise = syn.init_noise(lens, offset=lo, total=total).to(dev)
     pipe = build_pipe(dev, B)
-    gather_buf = torch.empty(total, FRAMES, NFEATS, device=dev) if world > 1 else None
+    gather_buf = torch.empty(total, FRAMES, NFEATS, device=dev) if use_dist else None
 
     stream = torch.cuda.Stream(device=dev)        # hipGraph capture needs a non-null stream; events go on it too
 
     def one_pass():
         z, feats = pipe.sample(text, lens, init_noise=noise)
-        if world > 1:
+        if use_dist:      # final gather of the decoded frames (RCCL over xGMI); also exercised at world size 1 under torchrun
             feats = D.gather_feats(feats, total, world, out=gather_buf)
         return feats
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
@@ -138,7 +167,7 @@ def main():
     assert torch.isfinite(feats).all()
 
     tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     wall = float(tmax.item())
 
@@ -156,17 +185,20 @@ def main():
                        "global_batch": total, "frames": FRAMES, "ddim_steps": STEPS_DDIM, "parallelism": f"dp{world}",
                        "hipgraph": True},
             "roofline": {"bound": "mfma", "achieved": round(ref_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ref_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(ref_tf / PEAK_F32_MFMA_TFLOPS, 4),
                          "kernel": "whole pass (hipGraph step x50 + decode); dominant kernel gemm_kernel<fp32 MFMA>",
                          "device_ms_per_pass": round(dev_ms / args.steps, 3),
                          "flops_per_motion_reference_equivalent": ref_flops_per_motion(),
-                         "executed_tflops": round(exe_tf, 2), "executed_frac": round(exe_tf / PEAK_F32_MFMA_TFLOPS, 4)},
+                         "executed_tflops": round(exe_tf, 2), "executed_frac": round(exe_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                         "traffic": 84.1e9, "traffic_source": "profiles/r1/03_pmc_summary.md, bytes per pass at the L2-fabric interface"},
         }
+        if world == 1:
+            line["roofline"]["dominant_kernel"] = dominant_kernel_roofline(dev, stream)
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
             line["cpu_baseline"]["gpu_over_cpu"] = round(motions_per_s / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -1,4 +1,5 @@
 // extern "C" surface of libladiff_hip.so (declared in include/ladiff_hip.h).
+#include <cstdlib>
 #include <cstring>
 
 #include "model.h"
@@ -22,10 +23,11 @@ bool load_weights(W& dst, const float* const* ptrs) {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---- reverse-loop workspace carve-up (floats)
+constexpr int MAX_CHAINS = 4;
 struct ReverseWs {
     float *tables, *cache, *latents, *eps, *fwd;
     int32_t* d_step;
-    size_t fwd_floats, total_bytes;
+    size_t fwd_floats, chain_floats, total_bytes;
 };
 ReverseWs carve_reverse(void* ws, int B, int T, int n) {
     ReverseWs r;
@@ -40,7 +42,13 @@ ReverseWs carve_reverse(void* ws, int B, int T, int n) {
     size_t pre = (size_t)n * D * 3;                                    // time-table scratch
     const size_t txt = den_text_ws_floats(B2, n);                      // text-cache scratch
     if (txt > pre) pre = txt;
+    // the forward pass may be split into up to MAX_CHAINS independent sample ranges with their own scratch
+    r.chain_floats = 0;
     r.fwd_floats = den_forward_ws_floats(B2, T);
+    for (int c = 2; c <= MAX_CHAINS; ++c) {
+        const size_t need = (size_t)c * align_up(den_forward_ws_floats((B2 + c - 1) / c, T), 64);
+        if (need > r.fwd_floats) r.fwd_floats = need;
+    }
     if (pre > r.fwd_floats) r.fwd_floats = pre;
     r.fwd = take(r.fwd_floats);
     r.total_bytes = off * sizeof(float);
@@ -49,6 +57,9 @@ ReverseWs carve_reverse(void* ws, int B, int T, int n) {
 
 struct Sampler {
     hipGraphExec_t exec = nullptr;
+    int chains = 1;                       // sample ranges captured as parallel graph branches (measured: no gain)
+    hipStream_t side[MAX_CHAINS - 1] = {nullptr};
+    hipEvent_t fork = nullptr, join[MAX_CHAINS - 1] = {nullptr};
     // capture key: a graph bakes pointers and shapes into its kernel nodes
     const void* key_ptrs[8] = {nullptr};
     int key_ints[4] = {0};
@@ -126,7 +137,7 @@ int ladiff_combine_rows(const float* partials, int n_planes, int M, const float*
     if ((mode == RED_LN_ADD || mode == RED_LN_MOD) && !table) return LADIFF_ERR_ARG;
     if (M == 0) return 0;
     return launch_reduce_rows(partials, n_planes, M, bias, res, mode, ln_gamma, ln_beta, table, 0, nullptr, counts, Bs, T,
-                              pad_row, out, S(stream));
+                              pad_row, 0, out, S(stream));
 }
 
 int ladiff_layernorm(const float* x, const float* gamma, const float* beta, float* y, int M, ladiff_stream_t stream) {
@@ -210,13 +221,25 @@ int ladiff_finalize_latents(const float* latents, const int32_t* counts, float* 
 // ------------------------------------------------------------------ whole reverse loop
 int ladiff_sampler_create(void** sampler) {
     LADIFF_CHECK_ARG(sampler);
-    *sampler = new Sampler();
+    Sampler* sp = new Sampler();
+    if (const char* e = getenv("LADIFF_CHAINS")) { const int c = atoi(e); if (c >= 1 && c <= MAX_CHAINS) sp->chains = c; }
+    LADIFF_HIP(hipEventCreateWithFlags(&sp->fork, hipEventDisableTiming));
+    for (int i = 0; i < MAX_CHAINS - 1; ++i) {
+        LADIFF_HIP(hipStreamCreateWithFlags(&sp->side[i], hipStreamNonBlocking));
+        LADIFF_HIP(hipEventCreateWithFlags(&sp->join[i], hipEventDisableTiming));
+    }
+    *sampler = sp;
     return 0;
 }
 int ladiff_sampler_destroy(void* sampler) {
     Sampler* sp = reinterpret_cast<Sampler*>(sampler);
     if (sp == nullptr) return 0;
     if (sp->exec) (void)hipGraphExecDestroy(sp->exec);
+    if (sp->fork) (void)hipEventDestroy(sp->fork);
+    for (int i = 0; i < MAX_CHAINS - 1; ++i) {
+        if (sp->join[i]) (void)hipEventDestroy(sp->join[i]);
+        if (sp->side[i]) (void)hipStreamDestroy(sp->side[i]);
+    }
     delete sp;
     return 0;
 }
@@ -241,25 +264,38 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
     LADIFF_TRY(launch_init_latents(init_noise, counts, init_noise_sigma, r.latents, B, T, s));
     LADIFF_HIP(hipMemsetAsync(r.d_step, 0, sizeof(int32_t), s));
 
-    auto one_step = [&](hipStream_t st) -> int {
-        LADIFF_TRY(denoiser_forward(W, r.tables, r.d_step, r.cache, n_steps, r.latents, B, 2, T, counts, r.eps, r.fwd, r.fwd_floats, st));
+    Sampler* sp = reinterpret_cast<Sampler*>(sampler);
+    // One step.  The denoiser rows of different samples never interact, so the duplicated batch is cut into `chains`
+    // sample ranges that are captured as parallel branches of the step graph: their fill / MFMA / store phases drift
+    // apart and overlap instead of hitting the memory system in lock-step.
+    auto one_step = [&](hipStream_t st, int chains) -> int {
+        if (chains > 1) LADIFF_HIP(hipEventRecord(sp->fork, st));
+        const size_t per = r.fwd_floats / chains / 64 * 64;   // >= den_forward_ws_floats(ceil(B2 / chains), T) by carve_reverse
+        for (int c = chains - 1; c >= 0; --c) {
+            const int lo = (int)((long long)B2 * c / chains), hi = (int)((long long)B2 * (c + 1) / chains);
+            hipStream_t cs = c == 0 ? st : sp->side[c - 1];
+            if (c > 0) LADIFF_HIP(hipStreamWaitEvent(cs, sp->fork, 0));
+            LADIFF_TRY(denoiser_forward(W, r.tables, r.d_step, r.cache, n_steps, r.latents, B, 2, T, counts, r.eps,
+                                        r.fwd + (size_t)c * per, per, cs, lo, hi - lo));
+            if (c > 0) LADIFF_HIP(hipEventRecord(sp->join[c - 1], cs));
+        }
+        for (int c = 1; c < chains; ++c) LADIFF_HIP(hipStreamWaitEvent(st, sp->join[c - 1], 0));
         LADIFF_TRY(launch_cfg_step(r.eps, r.latents, coef, r.d_step, step_noise, guidance_scale, 1, B, T, st));
         return launch_advance(r.d_step, st);
     };
 
-    Sampler* sp = reinterpret_cast<Sampler*>(sampler);
     if (sp == nullptr) {
-        for (int i = 0; i < n_steps; ++i) LADIFF_TRY(one_step(s));
+        for (int i = 0; i < n_steps; ++i) LADIFF_TRY(one_step(s, 1));
     } else {
         const void* kp[8] = {w, w[0], ws, counts, coef, step_noise, stream, nullptr};
-        const int ki[4] = {B, T, n_steps, 0};
+        const int ki[4] = {B, T, n_steps, sp->chains};
         const bool same = sp->exec && std::memcmp(kp, sp->key_ptrs, sizeof(kp)) == 0 &&
                           std::memcmp(ki, sp->key_ints, sizeof(ki)) == 0 && sp->key_g == guidance_scale;
         if (!same) {
             if (sp->exec) { (void)hipGraphExecDestroy(sp->exec); sp->exec = nullptr; }
             hipGraph_t graph = nullptr;
             LADIFF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            const int rc = one_step(s);
+            const int rc = one_step(s, sp->chains);
             const hipError_t ec = hipStreamEndCapture(s, &graph);
             if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
             LADIFF_HIP(ec);

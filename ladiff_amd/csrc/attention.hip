@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
     for (int j = 0; j < T; ++j) {
         const f32x4 kk = ld4(kv + ((size_t)j * B + b) * 512 + c);
         float d = (qv[0] * 0.125f) * kk[0] + (qv[1] * 0.125f) * kk[1] + (qv[2] * 0.125f) * kk[2] + (qv[3] * 0.125f) * kk[3];
-        d = group_sum<16>(d);
+        d = row16_sum(d);
         s[j] = j < nv ? d : -INFINITY;
         m = fmaxf(m, s[j]);
     }
@@ -202,9 +202,10 @@ template <int T>
 __global__ __launch_bounds__(256) void den_self_attn_kernel(const float* __restrict__ qkv, const float* __restrict__ text_kv,
                                                             const float* __restrict__ tables, int kv_off, int step_stride,
                                                             const int32_t* __restrict__ d_step,
-                                                            const int32_t* __restrict__ counts, int Bs,
+                                                            const int32_t* __restrict__ counts, int Bs, int b_off,
                                                             float* __restrict__ out) {
-    const int b2 = blockIdx.x;
+    const int b2 = blockIdx.x;             // local sample: rows of qkv / out
+    const int bg = b_off + b2;             // sample of the whole (duplicated) batch: text cache row, counts
     const int col = threadIdx.x;   // = head * 64 + d
     float qv[T], kk[T + 2], vv[T + 2];
 #pragma unroll
@@ -214,12 +215,12 @@ __global__ __launch_bounds__(256) void den_self_attn_kernel(const float* __restr
         kk[i] = r[256];
         vv[i] = r[512];
     }
-    kk[T] = text_kv[(size_t)b2 * 512 + col];
-    vv[T] = text_kv[(size_t)b2 * 512 + 256 + col];
+    kk[T] = text_kv[(size_t)bg * 512 + col];
+    vv[T] = text_kv[(size_t)bg * 512 + 256 + col];
     const float* tk = tables + (size_t)(*d_step) * step_stride + kv_off;
     kk[T + 1] = tk[col];
     vv[T + 1] = tk[256 + col];
-    int nv = counts ? counts[b2 % Bs] : T;
+    int nv = counts ? counts[bg % Bs] : T;
     nv = nv > T ? T : nv;
 #pragma unroll
     for (int i = 0; i < T; ++i) {
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void den_self_attn_kernel(const float* __restr
         float m = -INFINITY;
 #pragma unroll
         for (int j = 0; j < T + 2; ++j) {
-            const float d = group_sum<64>(qv[i] * kk[j]);
+            const float d = wave_sum(qv[i] * kk[j]);
             s[j] = (j < T && j >= nv) ? -INFINITY : d;
             m = fmaxf(m, s[j]);
         }
@@ -243,14 +244,14 @@ __global__ __launch_bounds__(256) void den_self_attn_kernel(const float* __restr
 }
 
 int launch_denoiser_self_attention(const float* qkv, const float* text_kv, const float* tables, int kv_off,
-                                   int step_stride, const int32_t* d_step, const int32_t* counts, int Bs, int B2,
-                                   int T, float* out, hipStream_t s) {
-    if (B2 == 0) return 0;
-    const dim3 grid(B2), block(256);
+                                   int step_stride, const int32_t* d_step, const int32_t* counts, int Bs, int b_off,
+                                   int b_n, int T, float* out, hipStream_t s) {
+    if (b_n == 0) return 0;
+    const dim3 grid(b_n), block(256);
 #define LADIFF_SA_CASE(TT)                                                                                          \
     case TT:                                                                                                        \
         hipLaunchKernelGGL(den_self_attn_kernel<TT>, grid, block, 0, s, qkv, text_kv, tables, kv_off, step_stride, \
-                           d_step, counts, Bs, out);                                                                \
+                           d_step, counts, Bs, b_off, out);                                                                \
         break;
     switch (T) {
         LADIFF_SA_CASE(1) LADIFF_SA_CASE(2) LADIFF_SA_CASE(3) LADIFF_SA_CASE(4)

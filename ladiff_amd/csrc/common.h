@@ -52,6 +52,26 @@ __device__ __forceinline__ float group_max(float v) {
     return v;
 }
 
+// ---- DPP reductions (VALU speed: no ds_bpermute round trips).  gfx9 DPP controls: quad_perm 0x00-0xFF,
+// row_half_mirror 0x141, row_mirror 0x140, row_bcast15 0x142, row_bcast31 0x143.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_add(float v) {     // v + dpp(v); lanes without a source add 0 (bound_ctrl)
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {   // sum over each aligned group of 16 lanes, result in all 16
+    v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);     // row_half_mirror
+    v = dpp_add<0x140>(v);     // row_mirror
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {    // sum over the 64 lanes, result in all lanes
+    v = row16_sum(v);
+    v = dpp_add<0x142, 0xA>(v);    // row_bcast15: rows 1,3 += last lane of rows 0,2
+    v = dpp_add<0x143, 0xC>(v);    // row_bcast31: rows 2,3 += lane 31
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 

@@ -156,13 +156,18 @@ static KrArgs kr(const float* A, int lda, const float* W, const float* b, float*
     return g;
 }
 
+// Processes samples [b_lo, b_lo + b_n) of the duplicated batch of B2 = Bs * dup samples (tables / caches are sized for
+// B2); independent sample ranges can run concurrently on different streams with disjoint workspaces.
 int denoiser_forward(const DenoiserW& w, const float* tables, const int32_t* d_step, const float* cache, int n_steps,
                      const float* sample, int Bs, int dup, int T, const int32_t* counts, float* eps, float* ws,
-                     size_t ws_floats, hipStream_t s) {
+                     size_t ws_floats, hipStream_t s, int b_lo, int b_n) {
     const int B2 = Bs * dup;
-    const int M = B2 * T;
-    if (T < 1 || T > LADIFF_MAX_LATENTS) return LADIFF_ERR_SHAPE;
-    if (ws_floats < den_forward_ws_floats(B2, T)) return LADIFF_ERR_WORKSPACE;
+    if (b_n < 0) { b_lo = 0; b_n = B2; }
+    const int M = b_n * T;
+    if (T < 1 || T > LADIFF_MAX_LATENTS || b_lo < 0 || b_lo + b_n > B2) return LADIFF_ERR_SHAPE;
+    if (M == 0) return 0;
+    if (ws_floats < den_forward_ws_floats(b_n, T)) return LADIFF_ERR_WORKSPACE;
+    eps += (size_t)b_lo * T * D;
     const size_t MD = (size_t)M * D;
     float* P[4]; float* SK[NSKIP];
     float* p = ws;
@@ -177,7 +182,7 @@ int denoiser_forward(const DenoiserW& w, const float* tables, const int32_t* d_s
     const int R = B2 + 1;
 
     // x = cat([sample]*dup) + query_pos.pe[:T]        ladiff.py:472-474, ladiff_denoiser.py:251
-    LADIFF_TRY(launch_add_pe(sample, w.query_pe, Bs, dup, T, P[0], s));
+    LADIFF_TRY(launch_add_pe(sample, w.query_pe, Bs, b_lo, b_n, T, P[0], s));
     const float* cur = P[0];
     for (int l = 0; l < NL; ++l) {
         const DenLayerW& L = w.layer[l];
@@ -189,12 +194,12 @@ int denoiser_forward(const DenoiserW& w, const float* tables, const int32_t* d_s
             g.A2 = SK[NL - 1 - l]; g.lda2 = D; g.K1 = D;
             LADIFF_TRY(launch_gemm_kr(g, s));
             LADIFF_TRY(launch_reduce_rows(part, 2, M, sk.b, nullptr, RED_PLAIN, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
-                                          1, 1, 0, P[3], s));
+                                          1, 1, 0, 0, P[3], s));
             cur = P[3];
         }
         LADIFF_TRY(launch_gemm_kr(kr(cur, D, L.sa_attn.in_w, L.sa_attn.in_b, qkv, 3 * D, M, 3 * D, D), s));
         LADIFF_TRY(launch_denoiser_self_attention(qkv, tkv + (size_t)l * B2 * 2 * D, tl, DEN_OFF_TIME_KV, DEN_STEP_STRIDE,
-                                                  d_step, counts, Bs, B2, T, att, s));
+                                                  d_step, counts, Bs, b_lo, b_n, T, att, s));
         {   // R1 = x + out_proj(att) -> P[1]
             KrArgs g = kr(att, D, L.sa_attn.out_w, L.sa_attn.out_b, P[1], D, M, D, D);
             g.res = cur; g.ldres = D;
@@ -202,17 +207,17 @@ int denoiser_forward(const DenoiserW& w, const float* tables, const int32_t* d_s
         }
         // X1 = LN1(R1) -> P[2];  hid = relu(linear1(X1))
         LADIFF_TRY(launch_reduce_rows(P[1], 1, M, nullptr, nullptr, RED_LN, L.sa_norm1.g, L.sa_norm1.b, nullptr, 0, nullptr,
-                                      nullptr, 1, 1, 0, P[2], s));
+                                      nullptr, 1, 1, 0, 0, P[2], s));
         LADIFF_TRY(launch_gemm_kr(kr(P[2], D, L.sa_lin1.w, L.sa_lin1.b, hid, FF, M, FF, D, ACT_RELU), s));
         // X3 = LN2(X1 + linear2(hid)) + c[step, layer, sample] -> P[1]
         LADIFF_TRY(launch_gemm_kr(kr(hid, FF, L.sa_lin2.w, nullptr, part, D, M, D, FF), s));
         LADIFF_TRY(launch_reduce_rows(part, 4, M, L.sa_lin2.b, P[2], RED_LN_ADD, L.sa_norm2.g, L.sa_norm2.b,
-                                      ctab + (size_t)l * n_steps * R * D, R * D, d_step, counts, Bs, T, B2, P[1], s));
+                                      ctab + (size_t)l * n_steps * R * D, R * D, d_step, counts, Bs, T, B2, b_lo, P[1], s));
         // u = SiLU(AdaLN(ffn.linear2(gelu(ffn.linear1(X3))))) -> P[2]
         LADIFF_TRY(launch_gemm_kr(kr(P[1], D, L.ffn1.w, L.ffn1.b, hid, FF, M, FF, D, ACT_GELU), s));
         LADIFF_TRY(launch_gemm_kr(kr(hid, FF, L.ffn2.w, nullptr, part, D, M, D, FF), s));
         LADIFF_TRY(launch_reduce_rows(part, 4, M, L.ffn2.b, nullptr, RED_LN_MOD, L.ffn_proj.norm.g, L.ffn_proj.norm.b,
-                                      tl + DEN_OFF_FFN_MOD, DEN_STEP_STRIDE, d_step, nullptr, 1, 1, 0, P[2], s));
+                                      tl + DEN_OFF_FFN_MOD, DEN_STEP_STRIDE, d_step, nullptr, 1, 1, 0, 0, P[2], s));
         float* dst = is_in ? SK[l] : P[0];
         {   // x' = X3 + out_layers(u)
             KrArgs g = kr(P[2], D, L.ffn_proj.out.w, L.ffn_proj.out.b, dst, D, M, D, D);

@@ -25,5 +25,7 @@ struct GemmArgs {
 };
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
+bool gemm_big_supported(const GemmArgs& a);          // gemm_big.hip: large-M LDS-DMA kernels
+int launch_gemm_big(const GemmArgs& a, hipStream_t stream);
 
 }  // namespace ladiff

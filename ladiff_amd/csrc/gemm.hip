@@ -296,6 +296,8 @@ int launch_gemm(const GemmArgs& a0, hipStream_t stream) {
     if ((a.lda % 4) || (a.ldw % 4) || (a.A2 && (a.lda2 % 4))) return LADIFF_ERR_SHAPE;   // 16-byte chunk loads
     const bool ln = a.ln_g != nullptr;
     if (!ln && (a.ln2_g || a.mod)) return LADIFF_ERR_ARG;
+    if (ln && (a.N != 256 || a.ln_b == nullptr)) return LADIFF_ERR_SHAPE;
+    if (gemm_big_supported(a)) return launch_gemm_big(a, stream);
     if (ln) {
         if (a.N != 256 || a.ln_b == nullptr) return LADIFF_ERR_SHAPE;
         if (a.M >= 4096) return launch_cfg<64, 256, 2, 1, 32, true>(a, stream);

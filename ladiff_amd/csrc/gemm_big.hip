@@ -1,0 +1,200 @@
+// fp32-input MFMA GEMM for the large-M (decoder) side: Y[M,N] = LN?( act(A[M,K] . W[N,K]^T + b) + res ), M ~ 25 K rows.
+//
+//   * 128x128 tiles (4 waves, 64x64 each) or, when LayerNorm follows, 64x256 tiles that own whole rows (4 waves, 32x128);
+//   * K in stages of 32 floats, two stages in LDS, filled by LDS-DMA (`global_load_lds_dwordx4`, one 1-KiB piece = 8 rows
+//     x 128 B per wave-instruction, no staging VGPRs); stage kt+1 is in flight during the MFMAs of stage kt, stage kt+2 is
+//     issued as soon as every wave has left buffer kt; two workgroups per CU hide each other's barriers and epilogues;
+//   * LDS rows are 128 B; the 16-byte chunk c of row r sits in slot c ^ ((r >> 1) & 7) (applied on the DMA source
+//     address and on the fragment reads) -> conflict-free ds_read_b128 for the 32x32x2 operand layout;
+//   * blockIdx is remapped so that the N/BN workgroups that share an A row tile run on the same XCD (they hit in its L2);
+//   * epilogue: the accumulators go through LDS once so that bias / activation / residual / LayerNorm run row-wise -
+//     whole 512-byte or 1-KiB rows per wave-instruction for the residual loads and the stores, DPP wave reductions for
+//     the LayerNorm statistics - instead of 4-byte accesses in the MFMA accumulator layout.  The residual rows are
+//     fetched before the last K stage so their latency hides under its MFMAs.
+#include "gemm.h"
+
+namespace ladiff {
+
+namespace {
+constexpr int BKB = 32;
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void dma16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+}  // namespace
+
+template <int BM, int BN, int WM, int WN, bool LN>
+__global__ __launch_bounds__(256) void gemm_big_kernel(const GemmArgs p) {
+    constexpr int NW = 4;
+    static_assert(WM * WN == NW, "four waves");
+    constexpr int TMW = BM / WM, TNW = BN / WN, RM = TMW / 32, RN = TNW / 32;
+    constexpr int ROWS = BM + BN;
+    constexpr int STAGE = ROWS * BKB;              // floats
+    constexpr int GRP = 8 * NW;                    // rows covered by one piece per wave
+    constexpr int GA = BM / GRP, GT = ROWS / GRP;
+    static_assert(BM % GRP == 0 && BN % GRP == 0, "tiles are multiples of 32 rows");
+    constexpr int PPW = GT;                        // pieces per wave per stage
+    constexpr int CLD = BN + 4;                    // row stride of the staged C tile
+    constexpr int LDSF = (2 * STAGE > BM * CLD) ? 2 * STAGE : BM * CLD;
+    constexpr int LPR = BN / 4;                    // lanes per output row (16-byte units)
+    constexpr int RPI = 64 / LPR;                  // rows per wave-instruction
+    constexpr int EI = BM / NW / RPI;              // epilogue instructions per wave
+    static_assert(!LN || BN == 256, "LayerNorm needs whole rows");
+
+    __shared__ __attribute__((aligned(1024))) float lds[LDSF];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    // XCD-aware tile map: workgroups b and b+8 share an XCD; give each XCD whole row tiles
+    const int nbn = p.N / BN;
+    const int nbm = (p.M + BM - 1) / BM;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int bm = (local / nbn) * 8 + xcd, bn = local % nbn;
+    if (bm >= nbm) return;
+    const int row0 = bm * BM, col0 = bn * BN;
+    const int nk = p.K / BKB;
+
+    // ---- LDS-DMA of one K stage: wave w brings rows 32 g + 8 w .. + 7 of every 32-row group g of [A | W]
+    const int rl = 8 * wave + (lane >> 3);                         // row within a 32-row group
+    const int kl = (((lane & 7) ^ ((rl >> 1) & 7)) << 2);          // swizzled source chunk (floats)
+    float* const lbase = lds + 8 * wave * BKB;
+    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+        const int k0 = kt * BKB;
+        const float* abase; int ald;
+        if (k0 < p.K1) { abase = p.A + k0; ald = p.lda; } else { abase = p.A2 + (k0 - p.K1); ald = p.lda2; }
+#pragma unroll
+        for (int g = 0; g < GT; ++g) {
+            const float* src;
+            if (g < GA) {
+                int gr = row0 + GRP * g + rl; gr = gr < p.M ? gr : p.M - 1;
+                src = abase + (size_t)gr * ald + kl;
+            } else {
+                src = p.W + (size_t)(col0 + GRP * (g - GA) + rl) * p.ldw + k0 + kl;
+            }
+            dma16(src, lbase + buf * STAGE + GRP * g * BKB);
+        }
+    };
+
+    f32x16 acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fk = lane >> 5;
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const float* sa = lds + buf * STAGE + (wm * TMW) * BKB;
+        const float* sb = lds + buf * STAGE + (BM + wn * TNW) * BKB;
+#pragma unroll
+        for (int g = 0; g < BKB / 8; ++g) {
+            const int c = 2 * g + fk;
+            f32x4 fa[RM], fb[RN];
+#pragma unroll
+            for (int i = 0; i < RM; ++i) { const int r = i * 32 + frow; fa[i] = ld4(sa + r * BKB + ((c ^ ((r >> 1) & 7)) << 2)); }
+#pragma unroll
+            for (int j = 0; j < RN; ++j) { const int r = j * 32 + frow; fb[j] = ld4(sb + r * BKB + ((c ^ ((r >> 1) & 7)) << 2)); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+#pragma unroll
+                    for (int j = 0; j < RN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // epilogue geometry: wave w owns rows w*BM/4 .. of the tile; instruction e covers RPI rows, lane -> (row, 4 columns)
+    const int er = wave * (BM / NW) + lane / LPR;      // + e * RPI
+    const int ec = 4 * (lane % LPR);
+    f32x4 rv[EI];
+#pragma unroll
+    for (int e = 0; e < EI; ++e) rv[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) wait_vm<PPW>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt == nk - 1 && p.res != nullptr) {        // residual rows: latency hides under the last stage's MFMAs
+#pragma unroll
+            for (int e = 0; e < EI; ++e) {
+                const int gr = row0 + er + e * RPI;
+                if (gr < p.M) rv[e] = ld4(p.res + (size_t)gr * p.ldres + col0 + ec);
+            }
+        }
+        compute(buf);
+        __builtin_amdgcn_s_barrier();                  // every wave has left `buf`
+        if (kt + 2 < nk) issue(kt + 2, buf);
+    }
+
+    // ---- accumulators -> LDS (C tile, row stride BN + 4)
+    float* ct = lds;
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ct[(wm * TMW + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CLD + wn * TNW + j * 32 + (lane & 31)] = acc[i][j][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- row-wise: bias, activation, residual, LayerNorm(s), store
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr) bv = ld4(p.bias + col0 + ec);
+    f32x4 g1 = bv, b1 = bv, g2 = bv, b2 = bv;
+    if constexpr (LN) {
+        g1 = ld4(p.ln_g + ec); b1 = ld4(p.ln_b + ec);
+        if (p.ln2_g != nullptr) { g2 = ld4(p.ln2_g + ec); b2 = ld4(p.ln2_b + ec); }
+    }
+#pragma unroll
+    for (int e = 0; e < EI; ++e) {
+        const int lr = er + e * RPI;
+        const int gr = row0 + lr;
+        f32x4 v = ld4(ct + lr * CLD + ec);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = act_apply(v[q] + bv[q], p.act) + rv[e][q];
+        if constexpr (LN) {
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass == 1 && p.ln2_g == nullptr) break;
+                const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.f / 256.f);
+                float sq = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float d = v[q] - mean; sq += d * d; }
+                const float rstd = rsqrtf(wave_sum(sq) * (1.f / 256.f) + LN_EPS);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (v[q] - mean) * rstd * (pass ? g2[q] : g1[q]) + (pass ? b2[q] : b1[q]);
+            }
+        }
+        if (gr < p.M) st4(p.Y + (size_t)gr * p.ldy + col0 + ec, v);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool LN>
+static int launch_big(const GemmArgs& a, hipStream_t s) {
+    const int nbm = (a.M + BM - 1) / BM, nbn = a.N / BN;
+    const int grid = ((nbm + 7) / 8) * 8 * nbn;
+    hipLaunchKernelGGL((gemm_big_kernel<BM, BN, WM, WN, LN>), dim3(grid), dim3(256), 0, s, a);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+// true when the shape is served by this kernel family (otherwise the caller uses the staged kernel of gemm.hip)
+bool gemm_big_supported(const GemmArgs& a) {
+    if (a.M < 4096 || a.K % BKB || a.K1 % BKB || (a.lda % 4) || (a.ldw % 4) || (a.A2 && (a.lda2 % 4))) return false;
+    if ((a.ldy % 4) || (a.res && (a.ldres % 4)) || a.mod || a.row_len || a.post_act != ACT_NONE) return false;
+    if (a.ln_g != nullptr) return a.N == 256;
+    return a.N % 128 == 0;
+}
+
+int launch_gemm_big(const GemmArgs& a, hipStream_t s) {
+    if (a.ln_g != nullptr) return launch_big<64, 256, 2, 2, true>(a, s);
+    return launch_big<128, 128, 2, 2, false>(a, s);
+}
+
+}  // namespace ladiff

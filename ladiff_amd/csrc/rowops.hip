@@ -7,12 +7,12 @@ constexpr int ROWS_PER_BLOCK = 4;   // 256 threads = 4 waves = 4 rows
 
 // mean / rstd of a 256-wide row held as one f32x4 per lane
 __device__ __forceinline__ void row_stats(const f32x4 v, float& mean, float& rstd) {
-    float s = group_sum<64>(v[0] + v[1] + v[2] + v[3]);
+    float s = wave_sum(v[0] + v[1] + v[2] + v[3]);
     mean = s * (1.f / 256.f);
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const float d = v[i] - mean; q += d * d; }
-    q = group_sum<64>(q);
+    q = wave_sum(q);
     rstd = rsqrtf(q * (1.f / 256.f) + LN_EPS);
 }
 
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
                                                           int mode, const float* __restrict__ g, const float* __restrict__ b,
                                                           const float* __restrict__ tab, int tab_step_stride,
                                                           const int32_t* __restrict__ d_step, const int32_t* __restrict__ counts,
-                                                          int Bs, int T, int pad_row, int M, float* __restrict__ out) {
+                                                          int Bs, int T, int pad_row, int b_off, int M, float* __restrict__ out) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     const int c = (threadIdx.x & 63) * 4;
     if (row >= M) return;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
         const float* t = tab + (size_t)(d_step ? *d_step : 0) * tab_step_stride;
         if (mode == RED_LN) {
         } else if (mode == RED_LN_ADD) {
-            const int b2 = row / T, tt = row % T;
+            const int b2 = b_off + row / T, tt = row % T;
             const bool valid = counts == nullptr || tt < counts[b2 % Bs];
             const f32x4 cc = ld4(t + (size_t)(valid ? b2 : pad_row) * D + c);
 #pragma unroll
@@ -90,9 +90,9 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
 
 int launch_reduce_rows(const float* P, int S, int M, const float* bias, const float* res, int mode, const float* g,
                        const float* b, const float* tab, int tab_step_stride, const int32_t* d_step,
-                       const int32_t* counts, int Bs, int T, int pad_row, float* out, hipStream_t s) {
+                       const int32_t* counts, int Bs, int T, int pad_row, int b_off, float* out, hipStream_t s) {
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, P, S,
-                       (size_t)M * D, bias, res, mode, g, b, tab, tab_step_stride, d_step, counts, Bs, T, pad_row, M, out);
+                       (size_t)M * D, bias, res, mode, g, b, tab, tab_step_stride, d_step, counts, Bs, T, pad_row, b_off, M, out);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
@@ -125,11 +125,11 @@ int launch_ca_table_input(const float* nval, const float* beta, const float* mod
 
 // x[b2,t,:] = sample[b2 % Bs, t, :] + pe[t, :]     (ladiff.py:472-474 duplication + position_encoding.py:158)
 __global__ __launch_bounds__(256) void add_pe_kernel(const float* __restrict__ sample, const float* __restrict__ pe,
-                                                     int Bs, int T, int M, float* __restrict__ x) {
+                                                     int Bs, int T, int M, int b_off, float* __restrict__ x) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     const int c = (threadIdx.x & 63) * 4;
     if (row >= M) return;
-    const int b2 = row / T, t = row % T;
+    const int b2 = b_off + row / T, t = row % T;
     f32x4 v = ld4(sample + ((size_t)(b2 % Bs) * T + t) * D + c);
     const f32x4 p = ld4(pe + (size_t)t * D + c);
 #pragma unroll
@@ -137,9 +137,9 @@ __global__ __launch_bounds__(256) void add_pe_kernel(const float* __restrict__ s
     st4(x + (size_t)row * D + c, v);
 }
 
-int launch_add_pe(const float* sample, const float* pe, int Bs, int dup, int T, float* x, hipStream_t s) {
-    const int M = Bs * dup * T;
-    hipLaunchKernelGGL(add_pe_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, sample, pe, Bs, T, M, x);
+int launch_add_pe(const float* sample, const float* pe, int Bs, int b_off, int b_n, int T, float* x, hipStream_t s) {
+    const int M = b_n * T;   // rows of samples [b_off, b_off + b_n) of the (duplicated) batch; sample b2 reads latent row b2 % Bs
+    hipLaunchKernelGGL(add_pe_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, sample, pe, Bs, T, M, b_off, x);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }

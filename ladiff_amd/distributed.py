@@ -16,7 +16,7 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or "RANK" in os.environ) and not dist.is_initialized():   # launched by torchrun (any world size)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -51,7 +51,7 @@ def gather_feats(feats, total, world, out=None):
     Ranks may hold different numbers of prompts and different F (mixed lengths): shards are zero-padded to the
     global maxima - frames past a motion's length are zero anyway (ladiff_vae.py:358).
     """
-    if world == 1:
+    if not dist.is_initialized():
         return feats
     dev = feats.device
     meta = torch.tensor([feats.shape[0], feats.shape[1]], dtype=torch.int64, device=dev)
