@@ -185,3 +185,20 @@ def test_drop_in_via_yaml_style_config(denoiser):
         joints = model({"text": ["a person walks", "jumps"], "length": [60, 130]})
     assert [tuple(j.shape) for j in joints] == [(60, 22, 3), (130, 22, 3)]
     assert len(model.times) == 1
+
+
+def test_ddpm_1000_steps_small_batch(denoiser, vae):
+    """BASELINE config c3 shape (1000-step DDPM, hipGraph step replayed 1000x, per-step noise streamed) on 2 prompts,
+    against the CPU oracle.  1000 stochastic guided steps amplify rounding, so the bound scales with the latents."""
+    lens = [196, 100]
+    text, noise = syn.text_embeddings(2, seed=31), syn.init_noise(lens, seed=32)
+    sn = syn.ddpm_noise(1000, 2, seed=33)
+    pipe = make_pipe(denoiser, vae, "ddpm", 1000)
+    z, feats = pipe.sample(text.to(DEV), lens, init_noise=noise.to(DEV), step_noise=sn.to(DEV))
+    assert len(pipe.scheduler.timesteps) == 1000 and torch.isfinite(feats).all()
+    z_o, f_o = orc.sample_motions(syn.denoiser_weights(), syn.vae_weights(263), text, lens, noise, 1000, "ddpm",
+                                  step_noise=sn)
+    scale = max(1.0, z_o.abs().max().item())
+    assert maxdiff(z, z_o) < 1e-4 * scale
+    assert maxdiff(feats, f_o) < 5e-3
+    assert feats[1, 100:].abs().max().item() == 0
