@@ -73,7 +73,8 @@ def dominant_kernel_roofline(dev, stream, launches=400):
     M, N, K = 2 * BATCH * 5, 1024, 256
     A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) / 16; b = torch.randn(N, device=dev)
     Y = torch.empty(M, N, device=dev)
-    args = (A.data_ptr(), K, None, 0, K, W.data_ptr(), K, b.data_ptr(), None, 0, Y.data_ptr(), N, M, N, K, 2, stream.cuda_stream)
+    args = (A.data_ptr(), K, None, 0, K, W.data_ptr(), K, b.data_ptr(), None, 0, Y.data_ptr(), N, M, N, K, 2, 0, None,
+            stream.cuda_stream)
     with torch.cuda.stream(stream):
         for _ in range(20):
             _lib.check(L.ladiff_gemm_resident(*args))
@@ -115,6 +116,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="prompts per GPU")
     ap.add_argument("--cpu-sample", type=int, default=32, help="motions in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
+                    help="matrix-product arithmetic of the denoiser loop (DESIGN.md §1)")
     args = ap.parse_args()
 
     rank, world, local = D.init_from_env()
@@ -135,6 +138,7 @@ def main():
     text = torch.cat([gtext[:total][lo:hi], gtext[total:][lo:hi]]).to(dev)
     noise = syn.init_noise(lens, offset=lo, total=total).to(dev)
     pipe = build_pipe(dev, B)
+    pipe.precision = args.precision
     gather_buf = torch.empty(total, FRAMES, NFEATS, device=dev) if use_dist else None
 
     stream = torch.cuda.Stream(device=dev)        # hipGraph capture needs a non-null stream; events go on it too
@@ -180,7 +184,7 @@ def main():
             "metric": "motions/sec (196-frame, 50-step DDIM, bs128)", "value": round(motions_per_s, 2),
             "unit": "motions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16x3+f32", "data": "synthetic",
             "config": {"workload": f"ddim50_cfg7.5_b{B}_f{FRAMES}_c{NFEATS}_humanml3d", "prompts_per_gpu": B,
                        "global_batch": total, "frames": FRAMES, "ddim_steps": STEPS_DDIM, "parallelism": f"dp{world}",
                        "hipgraph": True},

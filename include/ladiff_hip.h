@@ -76,7 +76,14 @@ int ladiff_gemm(const float* A, int lda, const float* A2, int lda2, int K1, cons
  *                    combine them with ladiff_combine_rows. */
 int ladiff_gemm_resident(const float* A, int lda, const float* A2, int lda2, int K1, const float* W, int ldw,
                          const float* bias, const float* res, int ldres, float* Y, int ldy, int M, int N, int K,
-                         int act, ladiff_stream_t stream);
+                         int act, int split, float* Ys, ladiff_stream_t stream);
+
+/* bf16x3 operand format ("S-format"): a row of K fp32 values (K multiple of 64) is stored in the same K*4 bytes as
+ * K/64 blocks of [64 bf16 hi | 64 bf16 lo], x ~ hi + lo.  With split = 1 ladiff_gemm_resident reads A, A2 and W in
+ * this format and evaluates every product as hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation
+ * (~2^-16 relative error per product, fp32 exponent range); Ys (may be NULL) receives the K == 256 result in
+ * S-format, Y (may then be NULL) in fp32.  ladiff_split_rows converts fp32 [R,K] -> S-format [R,K]. */
+int ladiff_split_rows(const float* x, float* y, int R, int K, ladiff_stream_t stream);
 
 /* Rows of 256: x = sum of n_planes partial planes [n_planes][M][256] + bias (+ res), then
  *   mode 0: x;   mode 1: LN(x);   mode 2: LN(x) + table[sample row | pad_row] (rows grouped T per sample, sample = row / T, padded when
@@ -125,9 +132,12 @@ int ladiff_denoiser_text_cache(const float* const* w, const float* text_emb /*[B
 
 /* eps[Bs*dup,T,256] = denoiser(cat([sample]*dup), t = step *d_step of the time tables, text, counts).
  * ladiff_denoiser.py:153-295 (call site ladiff.py:472-485).  counts[Bs] (int32, valid latent rows per
- * prompt, ceil(len/48)) may be NULL = no masking (TEST_EFFICIENCY / max_iter_elements=None). */
-int ladiff_denoiser_forward(const float* const* w, const float* tables, const int32_t* d_step,
-                            const float* text_cache, int n_steps, const float* sample /*[Bs,T,256]*/, int Bs,
+ * prompt, ceil(len/48)) may be NULL = no masking (TEST_EFFICIENCY / max_iter_elements=None).
+ * w_split = NULL: fp32-input MFMA everywhere (bit-for-bit fp32 fma chains).  w_split != NULL: the bf16x3 matrix path;
+ * it is a second pointer table in the same order as w whose >= 2-D entries are the S-format copies of the weight
+ * matrices (ladiff_split_rows), the other entries are ignored. */
+int ladiff_denoiser_forward(const float* const* w, const float* const* w_split, const float* tables,
+                            const int32_t* d_step, const float* text_cache, int n_steps, const float* sample /*[Bs,T,256]*/, int Bs,
                             int dup, int T, const int32_t* counts, float* eps, void* ws, size_t ws_bytes,
                             ladiff_stream_t stream);
 
@@ -156,7 +166,8 @@ int ladiff_finalize_latents(const float* latents, const int32_t* counts, float* 
 int ladiff_sampler_create(void** sampler);
 int ladiff_sampler_destroy(void* sampler);
 size_t ladiff_reverse_workspace_bytes(int B, int T, int n_steps);
-int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* text_emb /*[2B,1,768]*/,
+int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* const* w_split /*or NULL*/,
+                             const float* text_emb /*[2B,1,768]*/,
                              const float* init_noise /*[B,T,256]*/, const int32_t* counts /*[B] or NULL*/,
                              const float* sinusoid /*[n,768]*/, const float* coef /*[n,8]*/,
                              const float* step_noise /*[n,B,T,256] or NULL*/, float guidance_scale,

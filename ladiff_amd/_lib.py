@@ -34,7 +34,8 @@ _SIGNATURES = {
     "ladiff_gemm": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                             c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ladiff_gemm_resident": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
-                                     c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+                                     c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ladiff_split_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ladiff_combine_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ladiff_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
@@ -47,8 +48,8 @@ _SIGNATURES = {
     "ladiff_denoiser_time_tables": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ladiff_denoiser_text_cache": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
                                            c_void_p]),
-    "ladiff_denoiser_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
-                                        c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ladiff_denoiser_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+                                        c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ladiff_cfg_scheduler_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int,
                                           c_int, c_void_p]),
     "ladiff_advance_step": (c_int, [c_void_p, c_void_p]),
@@ -57,7 +58,7 @@ _SIGNATURES = {
     "ladiff_sampler_create": (c_int, [ctypes.POINTER(c_void_p)]),
     "ladiff_sampler_destroy": (c_int, [c_void_p]),
     "ladiff_reverse_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "ladiff_diffusion_reverse": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+    "ladiff_diffusion_reverse": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p,
                                          c_size_t, c_void_p]),
     "ladiff_decoder_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -127,6 +128,22 @@ class WeightTable:
             self.tensors.append(t.to(torch.float32).contiguous())
         self.array = (c_void_p * len(names))(*[t.data_ptr() for t in self.tensors])
         self.key = tuple((tensors[n].data_ptr(), tensors[n]._version) for n in names)
+        self._split = None
+
+    def split_array(self):
+        """Second pointer table for the bf16x3 path: S-format copies of the weight matrices (built once, on the GPU)."""
+        if self._split is None:
+            L = lib()
+            self.split_tensors = []
+            for t in self.tensors:
+                if t.dim() == 2 and t.shape[1] % 64 == 0:
+                    s = torch.empty_like(t)
+                    check(L.ladiff_split_rows(t.data_ptr(), s.data_ptr(), t.shape[0], t.shape[1], stream_ptr()))
+                else:
+                    s = t
+                self.split_tensors.append(s)
+            self._split = (c_void_p * len(self.tensors))(*[t.data_ptr() for t in self.split_tensors])
+        return self._split
 
     @staticmethod
     def key_of(kind_names, tensors):

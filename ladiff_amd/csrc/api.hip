@@ -112,12 +112,13 @@ int ladiff_gemm(const float* A, int lda, const float* A2, int lda2, int K1, cons
 
 int ladiff_gemm_resident(const float* A, int lda, const float* A2, int lda2, int K1, const float* W, int ldw,
                          const float* bias, const float* res, int ldres, float* Y, int ldy, int M, int N, int K, int act,
-                         ladiff_stream_t stream) {
-    LADIFF_CHECK_ARG(A && W && Y && M >= 0 && N > 0 && K > 0);
+                         int split, float* Ys, ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(A && W && (Y || Ys) && M >= 0 && N > 0 && K > 0);
     if (M == 0) return 0;
     KrArgs g;
     g.A = A; g.lda = lda; g.A2 = A2; g.lda2 = lda2; g.K1 = A2 ? K1 : K; g.W = W; g.ldw = ldw; g.bias = bias;
     g.res = res; g.ldres = ldres; g.Y = Y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.act = act;
+    g.split = split; g.Ys = Ys;
 #ifdef LADIFF_STAMPS
     g.stamps = g_stamps;
 #endif
@@ -137,7 +138,7 @@ int ladiff_combine_rows(const float* partials, int n_planes, int M, const float*
     if ((mode == RED_LN_ADD || mode == RED_LN_MOD) && !table) return LADIFF_ERR_ARG;
     if (M == 0) return 0;
     return launch_reduce_rows(partials, n_planes, M, bias, res, mode, ln_gamma, ln_beta, table, 0, nullptr, counts, Bs, T,
-                              pad_row, 0, out, S(stream));
+                              pad_row, 0, out, nullptr, S(stream));
 }
 
 int ladiff_layernorm(const float* x, const float* gamma, const float* beta, float* y, int M, ladiff_stream_t stream) {
@@ -188,12 +189,13 @@ int ladiff_denoiser_text_cache(const float* const* w, const float* text_emb, int
     return denoiser_text_cache(W, text_emb, B2, tables, n_steps, cache, (float*)ws, ws_bytes / sizeof(float), S(stream));
 }
 
-int ladiff_denoiser_forward(const float* const* w, const float* tables, const int32_t* d_step, const float* text_cache,
-                            int n_steps, const float* sample, int Bs, int dup, int T, const int32_t* counts, float* eps,
-                            void* ws, size_t ws_bytes, ladiff_stream_t stream) {
-    DenoiserW W;
+int ladiff_denoiser_forward(const float* const* w, const float* const* w_split, const float* tables, const int32_t* d_step,
+                            const float* text_cache, int n_steps, const float* sample, int Bs, int dup, int T,
+                            const int32_t* counts, float* eps, void* ws, size_t ws_bytes, ladiff_stream_t stream) {
+    DenoiserW W, WS;
     LADIFF_CHECK_ARG(load_weights(W, w) && tables && d_step && text_cache && sample && eps && ws && Bs > 0 && dup > 0 && n_steps > 0);
-    return denoiser_forward(W, tables, d_step, text_cache, n_steps, sample, Bs, dup, T, counts, eps, (float*)ws,
+    if (w_split != nullptr) LADIFF_CHECK_ARG(load_weights(WS, w_split));
+    return denoiser_forward(W, w_split ? &WS : nullptr, tables, d_step, text_cache, n_steps, sample, Bs, dup, T, counts, eps, (float*)ws,
                             ws_bytes / sizeof(float), S(stream));
 }
 
@@ -246,12 +248,21 @@ int ladiff_sampler_destroy(void* sampler) {
 
 size_t ladiff_reverse_workspace_bytes(int B, int T, int n_steps) { return carve_reverse(nullptr, B, T, n_steps).total_bytes; }
 
-int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* text_emb, const float* init_noise,
+int ladiff_split_rows(const float* x, float* y, int R, int K, ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(x && y && R >= 0 && K > 0);
+    if (K % 64) return LADIFF_ERR_SHAPE;
+    if (R == 0) return 0;
+    return launch_split_rows(x, y, R, K, S(stream));
+}
+
+int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* const* w_split, const float* text_emb, const float* init_noise,
                              const int32_t* counts, const float* sinusoid, const float* coef, const float* step_noise,
                              float guidance_scale, float init_noise_sigma, int B, int T, int n_steps, float* z,
                              void* ws, size_t ws_bytes, ladiff_stream_t stream) {
-    DenoiserW W;
+    DenoiserW W, WS;
     LADIFF_CHECK_ARG(load_weights(W, w) && text_emb && init_noise && sinusoid && coef && z && ws && B > 0 && n_steps > 0);
+    if (w_split != nullptr) LADIFF_CHECK_ARG(load_weights(WS, w_split));
+    const DenoiserW* WSp = w_split ? &WS : nullptr;
     if (T < 1 || T > LADIFF_MAX_LATENTS) return LADIFF_ERR_SHAPE;
     ReverseWs r = carve_reverse(ws, B, T, n_steps);
     if (ws_bytes < r.total_bytes) return LADIFF_ERR_WORKSPACE;
@@ -275,7 +286,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
             const int lo = (int)((long long)B2 * c / chains), hi = (int)((long long)B2 * (c + 1) / chains);
             hipStream_t cs = c == 0 ? st : sp->side[c - 1];
             if (c > 0) LADIFF_HIP(hipStreamWaitEvent(cs, sp->fork, 0));
-            LADIFF_TRY(denoiser_forward(W, r.tables, r.d_step, r.cache, n_steps, r.latents, B, 2, T, counts, r.eps,
+            LADIFF_TRY(denoiser_forward(W, WSp, r.tables, r.d_step, r.cache, n_steps, r.latents, B, 2, T, counts, r.eps,
                                         r.fwd + (size_t)c * per, per, cs, lo, hi - lo));
             if (c > 0) LADIFF_HIP(hipEventRecord(sp->join[c - 1], cs));
         }
@@ -287,7 +298,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
     if (sp == nullptr) {
         for (int i = 0; i < n_steps; ++i) LADIFF_TRY(one_step(s, 1));
     } else {
-        const void* kp[8] = {w, w[0], ws, counts, coef, step_noise, stream, nullptr};
+        const void* kp[8] = {w, w[0], ws, counts, coef, step_noise, stream, w_split ? (const void*)w_split[0] : nullptr};
         const int ki[4] = {B, T, n_steps, sp->chains};
         const bool same = sp->exec && std::memcmp(kp, sp->key_ptrs, sizeof(kp)) == 0 &&
                           std::memcmp(ki, sp->key_ints, sizeof(ki)) == 0 && sp->key_g == guidance_scale;

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void den_self_attn_kernel(const float* __restr
                                                             const float* __restrict__ tables, int kv_off, int step_stride,
                                                             const int32_t* __restrict__ d_step,
                                                             const int32_t* __restrict__ counts, int Bs, int b_off,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, int split_out) {
     const int b2 = blockIdx.x;             // local sample: rows of qkv / out
     const int bg = b_off + b2;             // sample of the whole (duplicated) batch: text cache row, counts
     const int col = threadIdx.x;   // = head * 64 + d
@@ -239,19 +239,20 @@ __global__ __launch_bounds__(256) void den_self_attn_kernel(const float* __restr
             l += pv;
             o += pv * vv[j];
         }
-        out[((size_t)b2 * T + i) * D + col] = o / l;
+        if (split_out) store_split1(out + ((size_t)b2 * T + i) * D, col, o / l);
+        else out[((size_t)b2 * T + i) * D + col] = o / l;
     }
 }
 
 int launch_denoiser_self_attention(const float* qkv, const float* text_kv, const float* tables, int kv_off,
                                    int step_stride, const int32_t* d_step, const int32_t* counts, int Bs, int b_off,
-                                   int b_n, int T, float* out, hipStream_t s) {
+                                   int b_n, int T, float* out, int split_out, hipStream_t s) {
     if (b_n == 0) return 0;
     const dim3 grid(b_n), block(256);
 #define LADIFF_SA_CASE(TT)                                                                                          \
     case TT:                                                                                                        \
         hipLaunchKernelGGL(den_self_attn_kernel<TT>, grid, block, 0, s, qkv, text_kv, tables, kv_off, step_stride, \
-                           d_step, counts, Bs, b_off, out);                                                                \
+                           d_step, counts, Bs, b_off, out, split_out);                                                                \
         break;
     switch (T) {
         LADIFF_SA_CASE(1) LADIFF_SA_CASE(2) LADIFF_SA_CASE(3) LADIFF_SA_CASE(4)

@@ -148,7 +148,7 @@ int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, const flo
 //   part        = ffn.linear2(hid)                    split-K 4
 //   u           = SiLU(LN(sum part + b) * (1 + scale_t) + shift_t)   combine kernel            :152-162
 //   x'          = X3 + out_layers(u)                  N=256                                     :162, :261
-size_t den_forward_ws_floats(int B2, int T) { return (size_t)B2 * T * (8 * D + 3 * D + D + FF + 4 * D); }
+size_t den_forward_ws_floats(int B2, int T) { return (size_t)B2 * T * (16 * D + 3 * D + D + FF + 4 * D); }
 
 static KrArgs kr(const float* A, int lda, const float* W, const float* b, float* Y, int ldy, int M, int N, int K, int act = ACT_NONE) {
     KrArgs g;
@@ -158,8 +158,12 @@ static KrArgs kr(const float* A, int lda, const float* W, const float* b, float*
 
 // Processes samples [b_lo, b_lo + b_n) of the duplicated batch of B2 = Bs * dup samples (tables / caches are sized for
 // B2); independent sample ranges can run concurrently on different streams with disjoint workspaces.
-int denoiser_forward(const DenoiserW& w, const float* tables, const int32_t* d_step, const float* cache, int n_steps,
-                     const float* sample, int Bs, int dup, int T, const int32_t* counts, float* eps, float* ws,
+//
+// ws != nullptr selects the bf16x3 matrix path: `ws` holds the S-format copies of the weight matrices (same table order
+// as `w`), GEMM operands travel in S-format (every tensor that is both a GEMM operand and a residual is written twice:
+// fp32 for the residual / LayerNorm consumers, S-format for the MFMA), accumulation and everything else stay fp32.
+int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tables, const int32_t* d_step, const float* cache,
+                     int n_steps, const float* sample, int Bs, int dup, int T, const int32_t* counts, float* eps, float* ws,
                      size_t ws_floats, hipStream_t s, int b_lo, int b_n) {
     const int B2 = Bs * dup;
     if (b_n < 0) { b_lo = 0; b_n = B2; }
@@ -168,11 +172,14 @@ int denoiser_forward(const DenoiserW& w, const float* tables, const int32_t* d_s
     if (M == 0) return 0;
     if (ws_floats < den_forward_ws_floats(b_n, T)) return LADIFF_ERR_WORKSPACE;
     eps += (size_t)b_lo * T * D;
+    const bool sp = wsp != nullptr;
     const size_t MD = (size_t)M * D;
-    float* P[4]; float* SK[NSKIP];
+    float* P[4]; float* SK[NSKIP]; float* Ps[4]; float* SKs[NSKIP];
     float* p = ws;
     for (int i = 0; i < 4; ++i) { P[i] = p; p += MD; }
     for (int i = 0; i < NSKIP; ++i) { SK[i] = p; p += MD; }
+    for (int i = 0; i < 4; ++i) { Ps[i] = sp ? p : nullptr; p += MD; }          // S-format twins
+    for (int i = 0; i < NSKIP; ++i) { SKs[i] = sp ? p : nullptr; p += MD; }
     float* qkv = p; p += 3 * MD;
     float* att = p; p += MD;
     float* hid = p; p += (size_t)M * FF;
@@ -180,51 +187,65 @@ int denoiser_forward(const DenoiserW& w, const float* tables, const int32_t* d_s
     const float* tkv = cache + (size_t)B2 * D;
     const float* ctab = tkv + (size_t)NL * B2 * 2 * D;
     const int R = B2 + 1;
+    // operand view of a tensor: its S-format twin in the bf16x3 path, the fp32 tensor otherwise
+    auto gemm = [&](KrArgs g) { g.split = sp ? 1 : 0; return launch_gemm_kr(g, s); };
 
     // x = cat([sample]*dup) + query_pos.pe[:T]        ladiff.py:472-474, ladiff_denoiser.py:251
-    LADIFF_TRY(launch_add_pe(sample, w.query_pe, Bs, b_lo, b_n, T, P[0], s));
-    const float* cur = P[0];
+    LADIFF_TRY(launch_add_pe(sample, w.query_pe, Bs, b_lo, b_n, T, P[0], Ps[0], s));
+    const float* cur = P[0]; const float* curs = Ps[0];
     for (int l = 0; l < NL; ++l) {
         const DenLayerW& L = w.layer[l];
+        const DenLayerW& Ls = sp ? wsp->layer[l] : w.layer[l];      // matrices as the MFMA reads them
         const float* tl = tables + (size_t)l * DEN_LAYER_STRIDE;
         const bool is_in = l < NSKIP, is_out = l > NSKIP;
         if (is_out) {
             const LinearW& sk = w.skip[l - NSKIP - 1];
-            KrArgs g = kr(cur, D, sk.w, nullptr, part, D, M, D, 2 * D);
-            g.A2 = SK[NL - 1 - l]; g.lda2 = D; g.K1 = D;
-            LADIFF_TRY(launch_gemm_kr(g, s));
+            const LinearW& sks = sp ? wsp->skip[l - NSKIP - 1] : sk;
+            KrArgs g = kr(sp ? curs : cur, D, sks.w, nullptr, part, D, M, D, 2 * D);
+            g.A2 = sp ? SKs[NL - 1 - l] : SK[NL - 1 - l]; g.lda2 = D; g.K1 = D;
+            LADIFF_TRY(gemm(g));
             LADIFF_TRY(launch_reduce_rows(part, 2, M, sk.b, nullptr, RED_PLAIN, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
-                                          1, 1, 0, 0, P[3], s));
-            cur = P[3];
+                                          1, 1, 0, 0, P[3], Ps[3], s));
+            cur = P[3]; curs = Ps[3];
         }
-        LADIFF_TRY(launch_gemm_kr(kr(cur, D, L.sa_attn.in_w, L.sa_attn.in_b, qkv, 3 * D, M, 3 * D, D), s));
+        LADIFF_TRY(gemm(kr(sp ? curs : cur, D, Ls.sa_attn.in_w, L.sa_attn.in_b, qkv, 3 * D, M, 3 * D, D)));
         LADIFF_TRY(launch_denoiser_self_attention(qkv, tkv + (size_t)l * B2 * 2 * D, tl, DEN_OFF_TIME_KV, DEN_STEP_STRIDE,
-                                                  d_step, counts, Bs, b_lo, b_n, T, att, s));
+                                                  d_step, counts, Bs, b_lo, b_n, T, att, sp ? 1 : 0, s));
         {   // R1 = x + out_proj(att) -> P[1]
-            KrArgs g = kr(att, D, L.sa_attn.out_w, L.sa_attn.out_b, P[1], D, M, D, D);
+            KrArgs g = kr(att, D, Ls.sa_attn.out_w, L.sa_attn.out_b, P[1], D, M, D, D);
             g.res = cur; g.ldres = D;
-            LADIFF_TRY(launch_gemm_kr(g, s));
+            LADIFF_TRY(gemm(g));
         }
         // X1 = LN1(R1) -> P[2];  hid = relu(linear1(X1))
         LADIFF_TRY(launch_reduce_rows(P[1], 1, M, nullptr, nullptr, RED_LN, L.sa_norm1.g, L.sa_norm1.b, nullptr, 0, nullptr,
-                                      nullptr, 1, 1, 0, 0, P[2], s));
-        LADIFF_TRY(launch_gemm_kr(kr(P[2], D, L.sa_lin1.w, L.sa_lin1.b, hid, FF, M, FF, D, ACT_RELU), s));
-        // X3 = LN2(X1 + linear2(hid)) + c[step, layer, sample] -> P[1]
-        LADIFF_TRY(launch_gemm_kr(kr(hid, FF, L.sa_lin2.w, nullptr, part, D, M, D, FF), s));
-        LADIFF_TRY(launch_reduce_rows(part, 4, M, L.sa_lin2.b, P[2], RED_LN_ADD, L.sa_norm2.g, L.sa_norm2.b,
-                                      ctab + (size_t)l * n_steps * R * D, R * D, d_step, counts, Bs, T, B2, b_lo, P[1], s));
-        // u = SiLU(AdaLN(ffn.linear2(gelu(ffn.linear1(X3))))) -> P[2]
-        LADIFF_TRY(launch_gemm_kr(kr(P[1], D, L.ffn1.w, L.ffn1.b, hid, FF, M, FF, D, ACT_GELU), s));
-        LADIFF_TRY(launch_gemm_kr(kr(hid, FF, L.ffn2.w, nullptr, part, D, M, D, FF), s));
-        LADIFF_TRY(launch_reduce_rows(part, 4, M, L.ffn2.b, nullptr, RED_LN_MOD, L.ffn_proj.norm.g, L.ffn_proj.norm.b,
-                                      tl + DEN_OFF_FFN_MOD, DEN_STEP_STRIDE, d_step, nullptr, 1, 1, 0, 0, P[2], s));
-        float* dst = is_in ? SK[l] : P[0];
-        {   // x' = X3 + out_layers(u)
-            KrArgs g = kr(P[2], D, L.ffn_proj.out.w, L.ffn_proj.out.b, dst, D, M, D, D);
-            g.res = P[1]; g.ldres = D;
-            LADIFF_TRY(launch_gemm_kr(g, s));
+                                      nullptr, 1, 1, 0, 0, P[2], Ps[2], s));
+        {
+            KrArgs g = kr(sp ? Ps[2] : P[2], D, Ls.sa_lin1.w, L.sa_lin1.b, sp ? nullptr : hid, FF, M, FF, D, ACT_RELU);
+            if (sp) g.Ys = hid;
+            LADIFF_TRY(gemm(g));
         }
-        cur = dst;
+        // X3 = LN2(X1 + linear2(hid)) + c[step, layer, sample] -> P[1]
+        LADIFF_TRY(gemm(kr(hid, FF, Ls.sa_lin2.w, nullptr, part, D, M, D, FF)));
+        LADIFF_TRY(launch_reduce_rows(part, 4, M, L.sa_lin2.b, P[2], RED_LN_ADD, L.sa_norm2.g, L.sa_norm2.b,
+                                      ctab + (size_t)l * n_steps * R * D, R * D, d_step, counts, Bs, T, B2, b_lo, P[1], Ps[1], s));
+        // u = SiLU(AdaLN(ffn.linear2(gelu(ffn.linear1(X3))))) -> P[2]
+        {
+            KrArgs g = kr(sp ? Ps[1] : P[1], D, Ls.ffn1.w, L.ffn1.b, sp ? nullptr : hid, FF, M, FF, D, ACT_GELU);
+            if (sp) g.Ys = hid;
+            LADIFF_TRY(gemm(g));
+        }
+        LADIFF_TRY(gemm(kr(hid, FF, Ls.ffn2.w, nullptr, part, D, M, D, FF)));
+        LADIFF_TRY(launch_reduce_rows(part, 4, M, L.ffn2.b, nullptr, RED_LN_MOD, L.ffn_proj.norm.g, L.ffn_proj.norm.b,
+                                      tl + DEN_OFF_FFN_MOD, DEN_STEP_STRIDE, d_step, nullptr, 1, 1, 0, 0,
+                                      sp ? nullptr : P[2], sp ? P[2] : nullptr, s));
+        float* dst = is_in ? SK[l] : P[0];
+        float* dsts = is_in ? SKs[l] : Ps[0];
+        {   // x' = X3 + out_layers(u)
+            KrArgs g = kr(P[2], D, Ls.ffn_proj.out.w, L.ffn_proj.out.b, dst, D, M, D, D);
+            g.res = P[1]; g.ldres = D; g.Ys = dsts;
+            LADIFF_TRY(gemm(g));
+        }
+        cur = dst; curs = dsts;
     }
     // encoder.norm, then [B2,T,256] out   cross_attention.py:84-85, ladiff_denoiser.py:272,292
     return launch_layernorm(cur, w.norm.g, w.norm.b, eps, M, s);

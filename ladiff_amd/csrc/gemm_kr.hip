@@ -62,8 +62,10 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 
 }  // namespace
 
-template <int BM, int BN, int WM, int WN, int MT>
+// SPLIT: operands are S-format rows (common.h); every product runs as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16.
+template <int BM, int BN, int WM, int WN, int MT, bool SPLIT>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
+    static_assert(!SPLIT || MT == 16, "split products use the 16x16x32 bf16 MFMA");
     typedef Mf<MT> MM;
     typedef typename MM::Acc Acc;
     constexpr int NW = WM * WN;
@@ -145,20 +147,50 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
     auto compute_sub = [&](int s) __attribute__((always_inline)) {
         const float* sa = lds + s * SUB + (wm * TMW) * 64;
         const float* sb = lds + s * SUB + (BM + wn * TNW) * 64;
+        if constexpr (SPLIT) {
+            // sub-slice s = 64 k: 16-byte slots 0-7 hold hi (8 bf16 each), slots 8-15 hold lo.  One MFMA covers 32 k:
+            // lane (row = l & 15, kb = l >> 4) feeds k = 32 g + 8 kb .. + 7, i.e. slot 4 g + kb (hi) and 8 + 4 g + kb (lo).
 #pragma unroll
-        for (int g = 0; g < 64 / MM::KG; ++g) {
-            const int c = g * (MM::KG / 4) + fk;
-            f32x4 fa[RM], fb[RN];
+            for (int g = 0; g < 2; ++g) {
+                const int ch = 4 * g + fk, cl = 8 + 4 * g + fk;
+                bf16x8 ah[RM], al[RM], bh[RN], bl[RN];
 #pragma unroll
-            for (int i = 0; i < RM; ++i) { const int r = i * MT + frow; fa[i] = ld4(sa + r * 64 + ((c ^ ((wm * TMW + r) & 15)) << 2)); }
+                for (int i = 0; i < RM; ++i) {
+                    const int r = i * MT + frow, x = (wm * TMW + r) & 15;
+                    ah[i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((ch ^ x) << 2)));
+                    al[i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((cl ^ x) << 2)));
+                }
 #pragma unroll
-            for (int j = 0; j < RN; ++j) { const int r = j * MT + frow; fb[j] = ld4(sb + r * 64 + ((c ^ ((BM + wn * TNW + r) & 15)) << 2)); }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int j = 0; j < RN; ++j) {
+                    const int r = j * MT + frow, x = (BM + wn * TNW + r) & 15;
+                    bh[j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((ch ^ x) << 2)));
+                    bl[j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((cl ^ x) << 2)));
+                }
 #pragma unroll
                 for (int i = 0; i < RM; ++i)
 #pragma unroll
-                    for (int j = 0; j < RN; ++j) acc[i][j] = MM::mma(fa[i][e], fb[j][e], acc[i][j]);
+                    for (int j = 0; j < RN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 64 / MM::KG; ++g) {
+                const int c = g * (MM::KG / 4) + fk;
+                f32x4 fa[RM], fb[RN];
+#pragma unroll
+                for (int i = 0; i < RM; ++i) { const int r = i * MT + frow; fa[i] = ld4(sa + r * 64 + ((c ^ ((wm * TMW + r) & 15)) << 2)); }
+#pragma unroll
+                for (int j = 0; j < RN; ++j) { const int r = j * MT + frow; fb[j] = ld4(sb + r * 64 + ((c ^ ((BM + wn * TNW + r) & 15)) << 2)); }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < RM; ++i)
+#pragma unroll
+                        for (int j = 0; j < RN; ++j) acc[i][j] = MM::mma(fa[i][e], fb[j][e], acc[i][j]);
+            }
         }
     };
 
@@ -189,7 +221,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
                 ct[(wm * TMW + i * MT + MM::arow(lane, r)) * CLD + wn * TNW + j * MT + MM::acol(lane)] = acc[i][j][r];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    float* Y = p.Y + (partial ? (size_t)ks * p.M * p.ldy : 0);
+    float* Y = p.Y == nullptr ? nullptr : p.Y + (partial ? (size_t)ks * p.M * p.ldy : 0);
 #pragma unroll
     for (int u = 0; u < UNITS; ++u) {
         const int id = tid + u * NW * 64;
@@ -201,15 +233,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e] + bv[e], p.act) + rv[u][e];
         }
-        st4(Y + (size_t)gr * p.ldy + gc, v);
+        if (p.Y != nullptr) st4(Y + (size_t)gr * p.ldy + gc, v);
+        if (!partial && p.Ys != nullptr) store_split4(p.Ys + (size_t)gr * p.ldy, gc, v);
     }
     STAMP(6);
 }
 
-template <int BM, int BN, int WM, int WN, int MT>
+template <int BM, int BN, int WM, int WN, int MT, bool SPLIT>
 static int launch_kr_cfg(const KrArgs& a, int splits, hipStream_t s) {
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_kr_kernel<BM, BN, WM, WN, MT>), dim3(nbm * nbn, splits), dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((gemm_kr_kernel<BM, BN, WM, WN, MT, SPLIT>), dim3(nbm * nbn, splits), dim3(WM * WN * 64), 0, s, a);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
@@ -218,17 +251,24 @@ static int launch_kr_cfg(const KrArgs& a, int splits, hipStream_t s) {
 int launch_gemm_kr(const KrArgs& a0, hipStream_t s) {
     KrArgs a = a0;
     if (a.A2 == nullptr) a.K1 = a.K;
-    LADIFF_CHECK_ARG(a.A && a.W && a.Y && a.M > 0 && a.N > 0 && a.K > 0);
+    LADIFF_CHECK_ARG(a.A && a.W && (a.Y || a.Ys) && a.M > 0 && a.N > 0 && a.K > 0);
     if (a.K % 256 != 0 || a.K1 % 256 != 0 || (a.lda % 4) || (a.ldw % 4) || (a.A2 && (a.lda2 % 4))) return LADIFF_ERR_SHAPE;
     if ((a.N % 4) || (a.ldy % 4) || (a.res && (a.ldres % 4))) return LADIFF_ERR_SHAPE;   // 16-byte epilogue units
     const int splits = a.K / 256;
-    if (splits > 1) {
-        if (splits == 4) return launch_kr_cfg<80, 64, 1, 4, 16>(a, splits, s);   // 16 x 4 x 4 = 256 workgroups at M=1280, N=256
-        return launch_kr_cfg<64, 64, 2, 2, 32>(a, splits, s);
+    if (splits > 1 && (a.Y == nullptr || a.Ys != nullptr)) return LADIFF_ERR_ARG;
+    if (a.Ys != nullptr && (a.ldy % 64)) return LADIFF_ERR_SHAPE;                         // S-format rows are 64-column blocks
+    if (a.split) {
+        if (splits == 4 || (splits == 1 && a.N >= 1024)) return launch_kr_cfg<80, 64, 1, 4, 16, true>(a, splits, s);
+        if (splits > 1 || a.N >= 512) return launch_kr_cfg<64, 64, 2, 2, 16, true>(a, splits, s);
+        return launch_kr_cfg<32, 32, 2, 2, 16, true>(a, 1, s);
     }
-    if (a.N >= 1024) return launch_kr_cfg<80, 64, 1, 4, 16>(a, 1, s);
-    if (a.N >= 512) return launch_kr_cfg<64, 64, 2, 2, 32>(a, 1, s);
-    return launch_kr_cfg<32, 32, 2, 2, 16>(a, 1, s);
+    if (splits > 1) {
+        if (splits == 4) return launch_kr_cfg<80, 64, 1, 4, 16, false>(a, splits, s);   // 16 x 4 x 4 = 256 workgroups at M=1280, N=256
+        return launch_kr_cfg<64, 64, 2, 2, 32, false>(a, splits, s);
+    }
+    if (a.N >= 1024) return launch_kr_cfg<80, 64, 1, 4, 16, false>(a, 1, s);
+    if (a.N >= 512) return launch_kr_cfg<64, 64, 2, 2, 32, false>(a, 1, s);
+    return launch_kr_cfg<32, 32, 2, 2, 16, false>(a, 1, s);
 }
 
 }  // namespace ladiff

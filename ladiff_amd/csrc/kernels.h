@@ -8,11 +8,12 @@ namespace ladiff {
 enum RedMode : int { RED_PLAIN = 0, RED_LN = 1, RED_LN_ADD = 2, RED_LN_MOD = 3 };
 int launch_reduce_rows(const float* P, int S, int M, const float* bias, const float* res, int mode, const float* g,
                        const float* b, const float* tab, int tab_step_stride, const int32_t* d_step,
-                       const int32_t* counts, int Bs, int T, int pad_row, int b_off, float* out, hipStream_t s);
+                       const int32_t* counts, int Bs, int T, int pad_row, int b_off, float* out, float* outs, hipStream_t s);
+int launch_split_rows(const float* x, float* y, int R, int K, hipStream_t s);
 int launch_layernorm(const float* x, const float* g, const float* b, float* y, int M, hipStream_t s);
 int launch_ca_table_input(const float* nval, const float* beta, const float* mod, int step_stride, int n, int B2, float* u,
                           hipStream_t s);
-int launch_add_pe(const float* sample, const float* pe, int Bs, int b_off, int b_n, int T, float* x, hipStream_t s);
+int launch_add_pe(const float* sample, const float* pe, int Bs, int b_off, int b_n, int T, float* x, float* xs, hipStream_t s);
 int launch_broadcast_pe(const float* pe, int B, int F, float* x, hipStream_t s);
 int launch_relu(const float* x, float* y, size_t n, hipStream_t s);
 int launch_silu(const float* x, float* y, size_t n, hipStream_t s);
@@ -26,7 +27,7 @@ int launch_finalize_latents(const float* lat, const int32_t* counts, float* z, i
 // attention.hip
 int launch_denoiser_self_attention(const float* qkv, const float* text_kv, const float* tables, int kv_off,
                                    int step_stride, const int32_t* d_step, const int32_t* counts, int Bs, int b_off,
-                                   int b_n, int T, float* out, hipStream_t s);
+                                   int b_n, int T, float* out, int split_out, hipStream_t s);
 int launch_decoder_self_attention(const float* qkv, const int32_t* lengths, float* out, int B, int F, hipStream_t s);
 int launch_decoder_cross_attention(const float* q, const float* kv, const int32_t* counts, float* out, int B, int F,
                                    int T, hipStream_t s);

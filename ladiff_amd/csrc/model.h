@@ -21,8 +21,8 @@ size_t den_forward_ws_floats(int B2, int T);
 int denoiser_time_tables(const DenoiserW& w, const float* sinus, int n, float* tables, float* ws, size_t ws_floats, hipStream_t s);
 int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, const float* tables, int n_steps, float* cache,
                         float* ws, size_t ws_floats, hipStream_t s);
-int denoiser_forward(const DenoiserW& w, const float* tables, const int32_t* d_step, const float* cache, int n_steps,
-                     const float* sample, int Bs, int dup, int T, const int32_t* counts, float* eps, float* ws,
+int denoiser_forward(const DenoiserW& w, const DenoiserW* w_split, const float* tables, const int32_t* d_step,
+                     const float* cache, int n_steps, const float* sample, int Bs, int dup, int T, const int32_t* counts, float* eps, float* ws,
                      size_t ws_floats, hipStream_t s, int b_lo = 0, int b_n = -1);
 
 size_t dec_ws_floats(int B, int F, int T);

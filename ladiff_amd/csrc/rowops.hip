@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
                                                           int mode, const float* __restrict__ g, const float* __restrict__ b,
                                                           const float* __restrict__ tab, int tab_step_stride,
                                                           const int32_t* __restrict__ d_step, const int32_t* __restrict__ counts,
-                                                          int Bs, int T, int pad_row, int b_off, int M, float* __restrict__ out) {
+                                                          int Bs, int T, int pad_row, int b_off, int M, float* __restrict__ out, float* __restrict__ outs) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     const int c = (threadIdx.x & 63) * 4;
     if (row >= M) return;
@@ -85,14 +85,15 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
             for (int i = 0; i < 4; ++i) v[i] = silu(v[i] * (1.f + sc[i]) + sh[i]);
         }
     }
-    st4(out + (size_t)row * D + c, v);
+    if (out != nullptr) st4(out + (size_t)row * D + c, v);
+    if (outs != nullptr) store_split4(outs + (size_t)row * D, c, v);
 }
 
 int launch_reduce_rows(const float* P, int S, int M, const float* bias, const float* res, int mode, const float* g,
                        const float* b, const float* tab, int tab_step_stride, const int32_t* d_step,
-                       const int32_t* counts, int Bs, int T, int pad_row, int b_off, float* out, hipStream_t s) {
+                       const int32_t* counts, int Bs, int T, int pad_row, int b_off, float* out, float* outs, hipStream_t s) {
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, P, S,
-                       (size_t)M * D, bias, res, mode, g, b, tab, tab_step_stride, d_step, counts, Bs, T, pad_row, b_off, M, out);
+                       (size_t)M * D, bias, res, mode, g, b, tab, tab_step_stride, d_step, counts, Bs, T, pad_row, b_off, M, out, outs);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
@@ -125,7 +126,7 @@ int launch_ca_table_input(const float* nval, const float* beta, const float* mod
 
 // x[b2,t,:] = sample[b2 % Bs, t, :] + pe[t, :]     (ladiff.py:472-474 duplication + position_encoding.py:158)
 __global__ __launch_bounds__(256) void add_pe_kernel(const float* __restrict__ sample, const float* __restrict__ pe,
-                                                     int Bs, int T, int M, int b_off, float* __restrict__ x) {
+                                                     int Bs, int T, int M, int b_off, float* __restrict__ x, float* __restrict__ xs) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     const int c = (threadIdx.x & 63) * 4;
     if (row >= M) return;
@@ -135,11 +136,12 @@ __global__ __launch_bounds__(256) void add_pe_kernel(const float* __restrict__ s
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] += p[i];
     st4(x + (size_t)row * D + c, v);
+    if (xs != nullptr) store_split4(xs + (size_t)row * D, c, v);
 }
 
-int launch_add_pe(const float* sample, const float* pe, int Bs, int b_off, int b_n, int T, float* x, hipStream_t s) {
+int launch_add_pe(const float* sample, const float* pe, int Bs, int b_off, int b_n, int T, float* x, float* xs, hipStream_t s) {
     const int M = b_n * T;   // rows of samples [b_off, b_off + b_n) of the (duplicated) batch; sample b2 reads latent row b2 % Bs
-    hipLaunchKernelGGL(add_pe_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, sample, pe, Bs, T, M, b_off, x);
+    hipLaunchKernelGGL(add_pe_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, sample, pe, Bs, T, M, b_off, x, xs);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
@@ -155,6 +157,21 @@ __global__ __launch_bounds__(256) void broadcast_pe_kernel(const float* __restri
 int launch_broadcast_pe(const float* pe, int B, int F, float* x, hipStream_t s) {
     const int M = B * F;
     hipLaunchKernelGGL(broadcast_pe_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, pe, F, M, x);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+// fp32 [R][K] -> S-format [R][K] (weights are split once per weight table; K multiple of 64)
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int K, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const size_t row = (i * 4) / K;
+    const int k = (int)((i * 4) % K);
+    store_split4(y + row * K, k, ld4(x + i * 4));
+}
+int launch_split_rows(const float* x, float* y, int R, int K, hipStream_t s) {
+    const size_t n4 = (size_t)R * K / 4;
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, y, K, n4);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }

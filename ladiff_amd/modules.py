@@ -102,7 +102,7 @@ class LADiffDenoiser(_HipModule):
                                       + ", ".join(unsupported))
         self._build(schema.denoiser_schema(self.latent_dim, ff_size, num_layers, text_encoded_dim))
         self.reset_parameters()
-        self._buffers_cache = {}
+        self.precision = kwargs.get("precision", "fp32")     # "fp32" | "bf16x3" (matrix products only)
 
     def reset_parameters(self):
         """Init as the reference's constructors leave it."""
@@ -156,7 +156,8 @@ class LADiffDenoiser(_HipModule):
         _lib.check(L.ladiff_denoiser_time_tables(wt.array, _lib.ptr(sinus), 1, _lib.ptr(tables), _lib.ptr(ws), wsb, st))
         _lib.check(L.ladiff_denoiser_text_cache(wt.array, _lib.ptr(text), B2, _lib.ptr(tables), 1, _lib.ptr(cache),
                                                 _lib.ptr(ws), wsb, st))
-        _lib.check(L.ladiff_denoiser_forward(wt.array, _lib.ptr(tables), step0.data_ptr(), _lib.ptr(cache), 1, _lib.ptr(x),
+        _lib.check(L.ladiff_denoiser_forward(wt.array, wt.split_array() if self.precision == "bf16x3" else None,
+                                             _lib.ptr(tables), step0.data_ptr(), _lib.ptr(cache), 1, _lib.ptr(x),
                                              B2, 1, T, None if counts is None else counts.data_ptr(), _lib.ptr(eps),
                                              _lib.ptr(ws), wsb, st))
         return (eps.to(sample.dtype),)

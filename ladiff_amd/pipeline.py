@@ -60,7 +60,7 @@ def remove_padding(tensors, lengths):
 class LADIFF(nn.Module):
     def __init__(self, cfg=None, datamodule=None, *, denoiser=None, vae=None, scheduler=None, text_encoder=None,
                  guidance_scale=None, num_inference_timesteps=None, eta=None, max_it=None, frame_per_latent=None,
-                 test_efficiency=None, use_graph=True, **kwargs):
+                 test_efficiency=None, use_graph=True, precision=None, **kwargs):
         super().__init__()
         self.cfg = cfg
         self.datamodule = datamodule
@@ -92,6 +92,10 @@ class LADIFF(nn.Module):
         self.fact = None
         self.times = []
         self.use_graph = use_graph
+        # matrix-product arithmetic of the denoiser loop: "fp32" (fp32-input MFMA) or "bf16x3" (3-term bf16 split)
+        self.precision = precision if precision is not None else getattr(self.denoiser, "precision", "fp32")
+        if self.precision not in ("fp32", "bf16x3"):
+            raise ValueError(f"precision {self.precision!r} not supported")
         self._sampler = None
         self._stream = None
         self._plan = None
@@ -178,7 +182,8 @@ class LADIFF(nn.Module):
             if need_noise:
                 plan["step_noise"].copy_(step_noise)
             _lib.check(L.ladiff_diffusion_reverse(
-                self._sampler if self.use_graph else None, wt.array, _lib.ptr(plan["text"]), _lib.ptr(plan["noise"]),
+                self._sampler if self.use_graph else None, wt.array,
+                wt.split_array() if self.precision == "bf16x3" else None, _lib.ptr(plan["text"]), _lib.ptr(plan["noise"]),
                 None if self.test_efficiency else plan["counts"].data_ptr(), _lib.ptr(plan["sinus"]),
                 _lib.ptr(plan["coef"]), _lib.ptr(plan["step_noise"]) if need_noise else None, self.guidance_scale,
                 float(sch.init_noise_sigma), B, T, n, _lib.ptr(plan["z"]), _lib.ptr(plan["ws"]), plan["ws_bytes"],

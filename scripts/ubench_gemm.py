@@ -24,12 +24,14 @@ for (N, K, ln) in [(768, 256, 0), (1024, 256, 0), (256, 256, 0), (256, 1024, 0),
     Y = torch.empty(4, M, N, device=dev); res = torch.randn(M, N, device=dev)
     g_ = torch.ones(256, device=dev); be = torch.zeros(256, device=dev); xo = torch.empty(M, 256, device=dev)
     st = s.cuda_stream
-    old = lambda: L.ladiff_gemm(A.data_ptr(), K, None, 0, K, W.data_ptr(), K, b.data_ptr(), res.data_ptr(), N, None, None, Y.data_ptr(), N, M, N, K, 0, st)
-    new = lambda: L.ladiff_gemm_resident(A.data_ptr(), K, None, 0, K, W.data_ptr(), K, b.data_ptr(), res.data_ptr(), N, Y.data_ptr(), N, M, N, K, 0, st)
+    old = lambda: L.ladiff_gemm(A.data_ptr(), K, None, 0, K, W.data_ptr(), K, b.data_ptr(), res.data_ptr(), N, None, None, Y.data_ptr(), N, M, N, K, 0, 0, None, st)
+    new = lambda: L.ladiff_gemm_resident(A.data_ptr(), K, None, 0, K, W.data_ptr(), K, b.data_ptr(), res.data_ptr(), N, Y.data_ptr(), N, M, N, K, 0, 0, None, st)
     t_old = timeit(old) if not ln else float("nan")
     t_new = timeit(new)
+    spl = lambda: L.ladiff_gemm_resident(A.data_ptr(), K, None, 0, K, W.data_ptr(), K, b.data_ptr(), res.data_ptr(), N, Y.data_ptr(), N, M, N, K, 0, 1, None, st)
+    t_spl = timeit(spl)
     fl = 2.0 * M * N * K
-    print(f"N={N:5d} K={K:5d} ln={ln}: staged {t_old:7.2f} us   resident {t_new:7.2f} us   ({fl / t_new / 1e6:6.1f} TF/s; ideal {fl / 157.3e6:.2f} us)")
+    print(f"N={N:5d} K={K:5d} ln={ln}: staged {t_old:7.2f} us   resident {t_new:7.2f} us  bf16x3 {t_spl:7.2f} us  ({fl / t_new / 1e6:6.1f} TF/s; ideal {fl / 157.3e6:.2f} us)")
 P = torch.randn(4, M, 256, device=dev); out = torch.empty(M, 256, device=dev); tab = torch.randn(257, 256, device=dev)
 cnt = torch.full((128,), 5, dtype=torch.int32, device=dev)
 comb = lambda: L.ladiff_combine_rows(P.data_ptr(), 4, M, b.data_ptr(), res.data_ptr(), 2, g_.data_ptr(), be.data_ptr(), tab.data_ptr(), cnt.data_ptr(), 128, 5, 256, out.data_ptr(), s.cuda_stream)

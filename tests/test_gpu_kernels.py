@@ -174,18 +174,61 @@ def test_decoder_cross_attention(T, counts):
 
 
 # ---------------------------------------------------------------- small-M (denoiser) kernels
-def gemm_resident(A, W, bias=None, A2=None, res=None, act="none"):
+def to_split(t):
+    """fp32 [R,K] -> S-format [R,K] on the GPU (ladiff_split_rows)."""
+    x = t.to(DEV).contiguous()
+    y = torch.empty_like(x)
+    _lib.check(lib().ladiff_split_rows(_lib.ptr(x), _lib.ptr(y), x.shape[0], x.shape[1], _lib.stream_ptr()))
+    return y
+
+
+def from_split(y):
+    """S-format [R,K] (GPU) -> fp32 hi + lo on the CPU."""
+    b = y.cpu().contiguous().view(torch.bfloat16).view(y.shape[0], y.shape[1] // 64, 2, 64).float()
+    return (b[:, :, 0] + b[:, :, 1]).reshape(y.shape[0], y.shape[1])
+
+
+def gemm_resident(A, W, bias=None, A2=None, res=None, act="none", split=False, want_split_out=False):
     M, K1 = A.shape
     N, K = W.shape
     splits = K // 256
     d = lambda t: None if t is None else t.to(DEV).contiguous()
     A_, W_, b_, A2_, r_ = d(A), d(W), d(bias), d(A2), d(res)
+    if split:
+        A_, W_ = to_split(A_), to_split(W_)
+        A2_ = None if A2_ is None else to_split(A2_)
     Y = torch.full((splits, M, N) if splits > 1 else (M, N), float("nan"), device=DEV)
+    Ys = torch.zeros(M, N, device=DEV) if want_split_out else None
     _lib.check(lib().ladiff_gemm_resident(_lib.ptr(A_), A_.shape[1], _lib.ptr(A2_), 0 if A2 is None else A2_.shape[1], K1,
                                           _lib.ptr(W_), K, _lib.ptr(b_), _lib.ptr(r_), N, _lib.ptr(Y), N, M, N, K,
-                                          _lib.ACT[act], _lib.stream_ptr()))
+                                          _lib.ACT[act], 1 if split else 0, _lib.ptr(Ys), _lib.stream_ptr()))
     sync()
+    if want_split_out:
+        return Y.cpu(), from_split(Ys)
     return Y.cpu()
+
+
+def test_split_format_round_trip():
+    x = rnd(37, 256, scale=50.0)
+    back = from_split(to_split(x))
+    assert (back - x).abs().max().item() <= 2.0 ** -16 * x.abs().max().item()
+
+
+@pytest.mark.parametrize("M,N,K,act", [(1280, 1024, 256, "gelu"), (1280, 768, 256, "none"), (1280, 256, 256, "none"),
+                                       (77, 1024, 256, "relu"), (1280, 256, 1024, "none"), (90, 256, 512, "none")])
+def test_gemm_resident_bf16x3(M, N, K, act):
+    """3-term bf16 split products: ~2^-16 relative error per product (vs 2^-24 for the fp32 MFMA path)."""
+    A, W, b = rnd(M, K, scale=3.0), rnd(N, K, scale=1 / math.sqrt(K)), rnd(N)
+    if K == 256:
+        res = rnd(M, N, seed=7)
+        got, got_s = gemm_resident(A, W, b, res=res, act=act, split=True, want_split_out=True)
+        want = ref_gemm(A, W, b, res=res, act=act)
+        assert (got_s.double() - got.double()).abs().max().item() <= 2.0 ** -15 * got.abs().max().item()
+    else:
+        got = gemm_resident(A, W, split=True).double().sum(0)
+        want = ref_gemm(A, W)
+    bound = 4 * 2.0 ** -16 * (A.abs().double() @ W.abs().double().t()).max().item()
+    assert (got.double() - want).abs().max().item() < bound
 
 
 @pytest.mark.parametrize("M,N,act", [(1280, 768, "none"), (1280, 1024, "relu"), (1280, 256, "none"), (1280, 1024, "gelu"),

@@ -56,6 +56,16 @@ def test_denoiser_forward_golden(denoiser, t):
     assert maxdiff(eps[0], g["eps"]) < 5e-5       # every row, padded latent rows included
 
 
+def test_denoiser_forward_bf16x3(denoiser):
+    g = load_golden("denoiser_forward_t981")
+    denoiser.precision = "bf16x3"
+    try:
+        eps = denoiser(g["sample"].to(DEV), g["t"].to(DEV), g["text"].to(DEV), max_iter_elements=g["counts"].to(DEV))[0]
+    finally:
+        denoiser.precision = "fp32"
+    assert maxdiff(eps, g["eps"]) < 1e-3 and maxdiff(eps, g["eps"]) > 0     # one forward: ~1e-4 on O(1) outputs
+
+
 def test_denoiser_forward_no_mask_and_vector_timestep(denoiser):
     g = load_golden("denoiser_forward_t981")
     sd = syn.denoiser_weights()
@@ -97,18 +107,20 @@ def test_vae_decode_single_frame_and_single_sample(vae):
 
 
 # ---------------------------------------------------------------- sampling loop (A1-A4)
-@pytest.mark.parametrize("tag,sched,use_graph", [("ddim5", "ddim", True), ("ddim50", "ddim", True),
-                                                 ("ddim50", "ddim", False), ("ddpm10", "ddpm", True)])
-def test_sampling_loop_golden(denoiser, vae, tag, sched, use_graph):
+@pytest.mark.parametrize("tag,sched,use_graph,precision", [
+    ("ddim5", "ddim", True, "fp32"), ("ddim50", "ddim", True, "fp32"), ("ddim50", "ddim", False, "fp32"),
+    ("ddpm10", "ddpm", True, "fp32"), ("ddim50", "ddim", True, "bf16x3"), ("ddpm10", "ddpm", True, "bf16x3")])
+def test_sampling_loop_golden(denoiser, vae, tag, sched, use_graph, precision):
     g = load_golden(f"loop_{tag}")
-    pipe = make_pipe(denoiser, vae, sched, int(g["n_steps"]), use_graph=use_graph)
+    pipe = make_pipe(denoiser, vae, sched, int(g["n_steps"]), use_graph=use_graph, precision=precision)
     sn = g.get("step_noise")
     z, feats = pipe.sample(g["text"].to(DEV), g["lengths"].tolist(), init_noise=g["init_noise"].to(DEV),
                            step_noise=None if sn is None else sn.to(DEV))
     assert torch.equal(pipe.scheduler.timesteps, g["timesteps"])
     scale = max(1.0, g["latents"].abs().max().item())
-    assert maxdiff(z, g["latents"]) < 2e-5 * scale
-    assert maxdiff(feats, g["feats"]) < FRAME_TOL
+    # fp32 MFMA path: rounding only; bf16x3 path: ~2^-16 per product, still >5x inside the frame tolerance
+    assert maxdiff(z, g["latents"]) < (2e-5 if precision == "fp32" else 2e-4) * scale
+    assert maxdiff(feats, g["feats"]) < (FRAME_TOL if precision == "fp32" else FRAME_TOL / 2)
     # second call through the cached hipGraph gives the same bits
     z2, feats2 = pipe.sample(g["text"].to(DEV), g["lengths"].tolist(), init_noise=g["init_noise"].to(DEV),
                              step_noise=None if sn is None else sn.to(DEV))
