@@ -178,9 +178,9 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
  * feats[B,F,C] from z[T,B,256]; frames >= lengths[b] come out zero.  ladiff_vae.py:288-362
  * (call site ladiff.py:283).  lengths/counts are int32 device arrays of B entries. */
 size_t ladiff_decoder_workspace_bytes(int B, int F, int T, int C);
-int ladiff_vae_decode(const float* const* w, const float* z, const int32_t* lengths, const int32_t* counts,
-                      int B, int F, int T, int C, float* feats, void* ws, size_t ws_bytes,
-                      ladiff_stream_t stream);
+int ladiff_vae_decode(const float* const* w, const float* const* w_split /*or NULL: fp32 MFMA*/, const float* z,
+                      const int32_t* lengths, const int32_t* counts, int B, int F, int T, int C, float* feats,
+                      void* ws, size_t ws_bytes, ladiff_stream_t stream);
 
 #ifdef __cplusplus
 }

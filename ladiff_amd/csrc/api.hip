@@ -155,13 +155,13 @@ int ladiff_timestep_sinusoid(const int64_t* timesteps, int n, float* out, ladiff
 int ladiff_decoder_self_attention(const float* qkv, const int32_t* lengths, float* out, int B, int F,
                                   ladiff_stream_t stream) {
     LADIFF_CHECK_ARG(qkv && lengths && out && B >= 0);
-    return launch_decoder_self_attention(qkv, lengths, out, B, F, S(stream));
+    return launch_decoder_self_attention(qkv, lengths, out, B, F, 0, S(stream));
 }
 
 int ladiff_decoder_cross_attention(const float* q, const float* kv, const int32_t* counts, float* out, int B, int F,
                                    int T, ladiff_stream_t stream) {
     LADIFF_CHECK_ARG(q && kv && out && B >= 0 && F >= 0);
-    return launch_decoder_cross_attention(q, kv, counts, out, B, F, T, S(stream));
+    return launch_decoder_cross_attention(q, kv, counts, out, B, F, T, 0, S(stream));
 }
 
 // ------------------------------------------------------------------ denoiser
@@ -328,11 +328,13 @@ size_t ladiff_decoder_workspace_bytes(int B, int F, int T, int C) {
     return dec_ws_floats(B, F, T) * sizeof(float);
 }
 
-int ladiff_vae_decode(const float* const* w, const float* z, const int32_t* lengths, const int32_t* counts, int B,
-                      int F, int T, int C, float* feats, void* ws, size_t ws_bytes, ladiff_stream_t stream) {
-    DecoderW W;
+int ladiff_vae_decode(const float* const* w, const float* const* w_split, const float* z, const int32_t* lengths,
+                      const int32_t* counts, int B, int F, int T, int C, float* feats, void* ws, size_t ws_bytes,
+                      ladiff_stream_t stream) {
+    DecoderW W, WS;
     LADIFF_CHECK_ARG(load_weights(W, w) && z && lengths && feats && ws && B >= 0);
-    return vae_decode(W, z, lengths, counts, B, F, T, C, feats, (float*)ws, ws_bytes / sizeof(float), S(stream));
+    if (w_split != nullptr) LADIFF_CHECK_ARG(load_weights(WS, w_split));
+    return vae_decode(W, w_split ? &WS : nullptr, z, lengths, counts, B, F, T, C, feats, (float*)ws, ws_bytes / sizeof(float), S(stream));
 }
 
 }  // extern "C"

@@ -17,7 +17,7 @@ constexpr int SA_FMAX = LADIFF_MAX_FRAMES;   // 224 = 7 key tiles
 constexpr int SA_NKT = SA_FMAX / 32;
 
 __global__ __launch_bounds__(256) void dec_self_attn_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ lengths,
-                                                            float* __restrict__ out, int B, int F) {
+                                                            float* __restrict__ out, int B, int F, int split_out) {
     __shared__ __attribute__((aligned(16))) float Ks[SA_FMAX * DH];   // chunk c of row r at slot c ^ (r & 15)
     __shared__ __attribute__((aligned(16))) float Vs[SA_FMAX * DH];   // plain [key][d]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -115,23 +115,30 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const float* __restr
 
     if (qrow < F) {
         const float inv = 1.f / l;
-        float* dst = out + ((size_t)b * F + qrow) * D + h * DH + 4 * h2;
+        float* rowp = out + ((size_t)b * F + qrow) * D;
+        const int c0 = h * DH + 4 * h2;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             f32x4 v0, v1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v0[e] = o0[4 * rg + e] * inv; v1[e] = o1[4 * rg + e] * inv; }
-            st4(dst + 8 * rg, v0);
-            st4(dst + 32 + 8 * rg, v1);
+            if (split_out) {
+                store_split4(rowp, c0 + 8 * rg, v0);
+                store_split4(rowp, c0 + 32 + 8 * rg, v1);
+            } else {
+                st4(rowp + c0 + 8 * rg, v0);
+                st4(rowp + c0 + 32 + 8 * rg, v1);
+            }
         }
     }
 }
 
-int launch_decoder_self_attention(const float* qkv, const int32_t* lengths, float* out, int B, int F, hipStream_t s) {
+int launch_decoder_self_attention(const float* qkv, const int32_t* lengths, float* out, int B, int F, int split_out,
+                                  hipStream_t s) {
     if (F > SA_FMAX || F < 1) return LADIFF_ERR_SHAPE;
     if (B == 0) return 0;
     const int nqt = (F + 31) / 32;
-    hipLaunchKernelGGL(dec_self_attn_kernel, dim3((nqt + 3) / 4, B * H), dim3(256), 0, s, qkv, lengths, out, B, F);
+    hipLaunchKernelGGL(dec_self_attn_kernel, dim3((nqt + 3) / 4, B * H), dim3(256), 0, s, qkv, lengths, out, B, F, split_out);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
@@ -142,7 +149,7 @@ int launch_decoder_self_attention(const float* qkv, const int32_t* lengths, floa
 template <int T>
 __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __restrict__ q, const float* __restrict__ kv,
                                                              const int32_t* __restrict__ counts, float* __restrict__ out,
-                                                             int B, int F, int M) {
+                                                             int B, int F, int M, int split_out) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int c = (threadIdx.x & 63) * 4;
@@ -173,16 +180,17 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const float* __rest
     const float inv = 1.f / l;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] *= inv;
-    st4(out + (size_t)row * D + c, o);
+    if (split_out) store_split4(out + (size_t)row * D, c, o);
+    else st4(out + (size_t)row * D + c, o);
 }
 
 int launch_decoder_cross_attention(const float* q, const float* kv, const int32_t* counts, float* out, int B, int F,
-                                   int T, hipStream_t s) {
+                                   int T, int split_out, hipStream_t s) {
     const int M = B * F;
     if (M == 0) return 0;
     const dim3 grid((M + 3) / 4), block(256);
 #define LADIFF_CA_CASE(TT) \
-    case TT: hipLaunchKernelGGL(dec_cross_attn_kernel<TT>, grid, block, 0, s, q, kv, counts, out, B, F, M); break;
+    case TT: hipLaunchKernelGGL(dec_cross_attn_kernel<TT>, grid, block, 0, s, q, kv, counts, out, B, F, M, split_out); break;
     switch (T) {
         LADIFF_CA_CASE(1) LADIFF_CA_CASE(2) LADIFF_CA_CASE(3) LADIFF_CA_CASE(4)
         LADIFF_CA_CASE(5) LADIFF_CA_CASE(6) LADIFF_CA_CASE(7) LADIFF_CA_CASE(8)

@@ -14,65 +14,97 @@ static GemmArgs lin(const float* A, int lda, const float* W, const float* bias, 
 
 size_t dec_ws_floats(int B, int F, int T) {
     const size_t M = (size_t)B * F;
-    return M * (8 * D + 3 * D + D + FF) + (size_t)T * B * 2 * D;
+    return M * (16 * D + 3 * D + D + FF) + (size_t)T * B * 2 * D;
 }
 
-int vae_decode(const DecoderW& w, const float* z, const int32_t* lengths, const int32_t* counts, int B, int F, int T,
-               int C, float* feats, float* ws, size_t ws_floats, hipStream_t s) {
+// wsp != nullptr selects the bf16x3 matrix path (S-format copies of the weight matrices in `wsp`, GEMM operands in
+// S-format, LayerNorm as a row kernel after each fused GEMM); see denoiser.hip and common.h.
+int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int32_t* lengths, const int32_t* counts, int B,
+               int F, int T, int C, float* feats, float* ws, size_t ws_floats, hipStream_t s) {
     if (F < 1 || F > LADIFF_MAX_FRAMES || T < 1 || T > LADIFF_MAX_LATENTS || C < 1) return LADIFF_ERR_SHAPE;
     if (ws_floats < dec_ws_floats(B, F, T)) return LADIFF_ERR_WORKSPACE;
     const int M = B * F;
     if (M == 0) return 0;
+    const bool sp = wsp != nullptr;
     const size_t MD = (size_t)M * D;
-    float* P[4]; float* SK[NSKIP];
+    float* P[4]; float* SK[NSKIP]; float* Ps[4]; float* SKs[NSKIP];
     float* p = ws;
     for (int i = 0; i < 4; ++i) { P[i] = p; p += MD; }
     for (int i = 0; i < NSKIP; ++i) { SK[i] = p; p += MD; }
+    for (int i = 0; i < 4; ++i) { Ps[i] = sp ? p : nullptr; p += MD; }
+    for (int i = 0; i < NSKIP; ++i) { SKs[i] = sp ? p : nullptr; p += MD; }
     float* qkv = p; p += 3 * MD;
     float* att = p; p += MD;
     float* hid = p; p += (size_t)M * FF;
     float* kv = p;
     float* qb = qkv;   // cross-attention queries reuse the (dead) packed qkv buffer
 
+    // GEMM + (residual) + LayerNorm: fused epilogue in the fp32 path; GEMM(+residual) then a LayerNorm row kernel in the
+    // bf16x3 path.  `A`/`As`: operand in fp32 / S-format; result (fp32 + S-format twin) goes to dst / dsts.
+    auto gemm_ln = [&](const float* A, int K, const float* W, const float* Wsp, const float* bias, const float* res,
+                       const NormW& n1, const NormW* n2, float* dst, float* dsts) -> int {
+        GemmArgs g = lin(A, K, sp ? Wsp : W, bias, dst, D, M, D, K);
+        g.res = res; g.ldres = D;
+        if (!sp) {
+            g.ln_g = n1.g; g.ln_b = n1.b;
+            if (n2) { g.ln2_g = n2->g; g.ln2_b = n2->b; }
+            return launch_gemm(g, s);
+        }
+        g.split = 1;
+        LADIFF_TRY(launch_gemm(g, s));
+        if (n2) {
+            LADIFF_TRY(launch_reduce_rows(dst, 1, M, nullptr, nullptr, RED_LN, n1.g, n1.b, nullptr, 0, nullptr, nullptr, 1, 1, 0,
+                                          0, dst, nullptr, s));
+            return launch_reduce_rows(dst, 1, M, nullptr, nullptr, RED_LN, n2->g, n2->b, nullptr, 0, nullptr, nullptr, 1, 1, 0,
+                                      0, dst, dsts, s);
+        }
+        return launch_reduce_rows(dst, 1, M, nullptr, nullptr, RED_LN, n1.g, n1.b, nullptr, 0, nullptr, nullptr, 1, 1, 0, 0,
+                                  dst, dsts, s);
+    };
+
     // queries = zeros + query_pos_decoder.pe[:F]     ladiff_vae.py:299, :334
-    LADIFF_TRY(launch_broadcast_pe(w.query_pe, B, F, P[0], s));
-    const float* cur = P[0];
+    LADIFF_TRY(launch_broadcast_pe(w.query_pe, B, F, P[0], Ps[0], s));
+    const float* cur = P[0]; const float* curs = Ps[0];
     for (int l = 0; l < NL; ++l) {
         const DecLayerW& L = w.layer[l];
+        const DecLayerW& Ls = sp ? wsp->layer[l] : w.layer[l];
         const bool is_in = l < NSKIP, is_out = l > NSKIP, last = l == NL - 1;
         if (is_out) {   // x = linear(cat([x, xs.pop()]))   cross_attention.py:140-142
-            GemmArgs g = lin(cur, D, w.skip[l - NSKIP - 1].w, w.skip[l - NSKIP - 1].b, P[3], D, M, D, 2 * D);
-            g.A2 = SK[NL - 1 - l]; g.lda2 = D; g.K1 = D;
+            const LinearW& sk = w.skip[l - NSKIP - 1];
+            GemmArgs g = lin(sp ? curs : cur, D, sp ? wsp->skip[l - NSKIP - 1].w : sk.w, sk.b, P[3], D, M, D, 2 * D);
+            g.A2 = sp ? SKs[NL - 1 - l] : SK[NL - 1 - l]; g.lda2 = D; g.K1 = D;
+            g.split = sp ? 1 : 0; g.Ys = Ps[3];
             LADIFF_TRY(launch_gemm(g, s));
-            cur = P[3];
+            cur = P[3]; curs = Ps[3];
         }
         // ---- self-attention over frames, keys >= len masked   cross_attention.py:367-371
-        LADIFF_TRY(launch_gemm(lin(cur, D, L.self_attn.in_w, L.self_attn.in_b, qkv, 3 * D, M, 3 * D, D), s));
-        LADIFF_TRY(launch_decoder_self_attention(qkv, lengths, att, B, F, s));
         {
-            GemmArgs g = lin(att, D, L.self_attn.out_w, L.self_attn.out_b, P[1], D, M, D, D);
-            g.res = cur; g.ldres = D; g.ln_g = L.norm1.g; g.ln_b = L.norm1.b;
+            GemmArgs g = lin(sp ? curs : cur, D, Ls.self_attn.in_w, L.self_attn.in_b, qkv, 3 * D, M, 3 * D, D);
+            g.split = sp ? 1 : 0;
             LADIFF_TRY(launch_gemm(g, s));
         }
+        LADIFF_TRY(launch_decoder_self_attention(qkv, lengths, att, B, F, sp ? 1 : 0, s));
+        LADIFF_TRY(gemm_ln(att, D, L.self_attn.out_w, Ls.self_attn.out_w, L.self_attn.out_b, cur, L.norm1, nullptr, P[1], Ps[1]));
         // ---- cross-attention to the latent tokens, tokens >= ceil(len/48) masked   :373-376, :408-409
-        LADIFF_TRY(launch_gemm(lin(P[1], D, L.cross_attn.in_w, L.cross_attn.in_b, qb, D, M, D, D), s));
+        {
+            GemmArgs g = lin(sp ? Ps[1] : P[1], D, Ls.cross_attn.in_w, L.cross_attn.in_b, qb, D, M, D, D);
+            g.split = sp ? 1 : 0;
+            LADIFF_TRY(launch_gemm(g, s));
+        }
         LADIFF_TRY(launch_gemm(lin(z, D, L.cross_attn.in_w + (size_t)D * D, L.cross_attn.in_b + D, kv, 2 * D, T * B, 2 * D, D), s));
-        LADIFF_TRY(launch_decoder_cross_attention(qb, kv, counts, att, B, F, T, s));
-        {
-            GemmArgs g = lin(att, D, L.cross_attn.out_w, L.cross_attn.out_b, P[2], D, M, D, D);
-            g.res = P[1]; g.ldres = D; g.ln_g = L.norm2.g; g.ln_b = L.norm2.b;
-            LADIFF_TRY(launch_gemm(g, s));
-        }
+        LADIFF_TRY(launch_decoder_cross_attention(qb, kv, counts, att, B, F, T, sp ? 1 : 0, s));
+        LADIFF_TRY(gemm_ln(att, D, L.cross_attn.out_w, Ls.cross_attn.out_w, L.cross_attn.out_b, P[1], L.norm2, nullptr, P[2], Ps[2]));
         // ---- feed-forward, GELU(erf)   :410-412
-        LADIFF_TRY(launch_gemm(lin(P[2], D, L.lin1.w, L.lin1.b, hid, FF, M, FF, D, ACT_GELU), s));
-        float* dst = is_in ? SK[l] : P[0];
         {
-            GemmArgs g = lin(hid, FF, L.lin2.w, L.lin2.b, dst, D, M, D, FF);
-            g.res = P[2]; g.ldres = D; g.ln_g = L.norm3.g; g.ln_b = L.norm3.b;
-            if (last) { g.ln2_g = w.norm.g; g.ln2_b = w.norm.b; }   // decoder.norm, cross_attention.py:150-151
+            GemmArgs g = lin(sp ? Ps[2] : P[2], D, Ls.lin1.w, L.lin1.b, sp ? nullptr : hid, FF, M, FF, D, ACT_GELU);
+            g.split = sp ? 1 : 0; if (sp) g.Ys = hid;
             LADIFF_TRY(launch_gemm(g, s));
         }
-        cur = dst;
+        float* dst = is_in ? SK[l] : P[0];
+        float* dsts = is_in ? SKs[l] : Ps[0];
+        // norm3 (+ decoder.norm on the last layer, cross_attention.py:150-151)
+        LADIFF_TRY(gemm_ln(hid, FF, L.lin2.w, Ls.lin2.w, L.lin2.b, P[2], L.norm3, last ? &w.norm : nullptr, dst, dsts));
+        cur = dst; curs = dsts;
     }
     // final_layer + zero padded frames, written as [B, F, C]   ladiff_vae.py:356-360
     GemmArgs g = lin(cur, D, w.final_layer.w, w.final_layer.b, feats, C, M, C, D);

@@ -290,8 +290,10 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
 int launch_gemm(const GemmArgs& a0, hipStream_t stream) {
     GemmArgs a = a0;
     if (a.A2 == nullptr) a.K1 = a.K;
-    LADIFF_CHECK_ARG(a.A && a.W && a.Y && a.M >= 0 && a.N > 0 && a.K > 0);
+    LADIFF_CHECK_ARG(a.A && a.W && (a.Y || a.Ys) && a.M >= 0 && a.N > 0 && a.K > 0);
     if (a.M == 0) return 0;
+    if (a.split) return gemm_big_supported(a) ? launch_gemm_big(a, stream) : LADIFF_ERR_SHAPE;
+    if (a.Y == nullptr || a.Ys != nullptr) return LADIFF_ERR_ARG;
     if (a.K % BK != 0 || a.K1 % BK != 0 || a.K1 > a.K) return LADIFF_ERR_SHAPE;
     if ((a.lda % 4) || (a.ldw % 4) || (a.A2 && (a.lda2 % 4))) return LADIFF_ERR_SHAPE;   // 16-byte chunk loads
     const bool ln = a.ln_g != nullptr;

@@ -175,6 +175,147 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(const GemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- bf16x3 variant
+// Operands in S-format (common.h): a K stage is one 64-k block = 256 bytes per row (hi | lo), the LDS image and the
+// swizzle are those of gemm_kr.hip (16-byte slot ^ (row & 15)), every product is hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_16x16x32_bf16.  The MFMAs cost 1/5 of the fp32 ones, so the kernel is fill-bound: one 128x128 tile per
+// workgroup, two 64-KiB stages, one workgroup per CU.  Output: fp32 and/or S-format, bias/activation/residual fused;
+// LayerNorm runs as a row kernel afterwards (a 256-wide tile would move 4x the operand bytes per FLOP).
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_big_split_kernel(const GemmArgs p) {
+    constexpr int NW = 4, WM = 2, WN = 2;
+    constexpr int TMW = BM / WM, TNW = BN / WN, RM = TMW / 16, RN = TNW / 16;
+    constexpr int ROWS = BM + BN;
+    constexpr int STAGE = ROWS * 64;               // floats (256 B per row)
+    constexpr int GRP = 4 * NW;                    // rows covered by one piece per wave (a piece = 4 rows x 256 B)
+    constexpr int GA = BM / GRP, GT = ROWS / GRP;
+    constexpr int PPW = GT;
+    static_assert(PPW * 2 <= 63, "vmcnt is 6 bits");
+    constexpr int CLD = BN + 4;
+    constexpr int LPR = BN / 4, RPI = 64 / LPR, EI = BM / NW / RPI;
+    static_assert(2 * STAGE >= BM * CLD, "C tile reuses the stage buffers");
+
+    __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nbn = p.N / BN;
+    const int nbm = (p.M + BM - 1) / BM;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int bm = (local / nbn) * 8 + xcd, bn = local % nbn;
+    if (bm >= nbm) return;
+    const int row0 = bm * BM, col0 = bn * BN;
+    const int nk = p.K / 64;
+
+    const int rl = 4 * wave + (lane >> 4);                        // row within a 16-row group
+    const int kl = (((lane & 15) ^ rl) << 2);                     // swizzled source slot (floats)
+    float* const lbase = lds + 4 * wave * 64;
+    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+        const int k0 = kt * 64;
+        const float* abase; int ald;
+        if (k0 < p.K1) { abase = p.A + k0; ald = p.lda; } else { abase = p.A2 + (k0 - p.K1); ald = p.lda2; }
+#pragma unroll
+        for (int g = 0; g < GT; ++g) {
+            const float* src;
+            if (g < GA) {
+                int gr = row0 + GRP * g + rl; gr = gr < p.M ? gr : p.M - 1;
+                src = abase + (size_t)gr * ald + kl;
+            } else {
+                src = p.W + (size_t)(col0 + GRP * (g - GA) + rl) * p.ldw + k0 + kl;
+            }
+            dma16(src, lbase + buf * STAGE + GRP * g * 64);
+        }
+    };
+
+    f32x4 acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fk = lane >> 4;
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const float* sa = lds + buf * STAGE + (wm * TMW) * 64;
+        const float* sb = lds + buf * STAGE + (BM + wn * TNW) * 64;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int ch = 4 * g + fk, cl = 8 + 4 * g + fk;
+            bf16x8 ah[RM], al[RM], bh[RN], bl[RN];
+#pragma unroll
+            for (int i = 0; i < RM; ++i) {
+                const int r = i * 16 + frow;              // (wm*TMW + r) & 15 == frow: tiles start at multiples of 16
+                ah[i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((ch ^ frow) << 2)));
+                al[i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((cl ^ frow) << 2)));
+            }
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {
+                const int r = j * 16 + frow;
+                bh[j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((ch ^ frow) << 2)));
+                bl[j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((cl ^ frow) << 2)));
+            }
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    const int er = wave * (BM / NW) + lane / LPR;
+    const int ec = 4 * (lane % LPR);
+    f32x4 rv[EI];
+#pragma unroll
+    for (int e = 0; e < EI; ++e) rv[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) wait_vm<PPW>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt == nk - 1 && p.res != nullptr) {
+#pragma unroll
+            for (int e = 0; e < EI; ++e) {
+                const int gr = row0 + er + e * RPI;
+                if (gr < p.M) rv[e] = ld4(p.res + (size_t)gr * p.ldres + col0 + ec);
+            }
+        }
+        compute(buf);
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) issue(kt + 2, buf);
+    }
+
+    float* ct = lds;
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                ct[(wm * TMW + i * 16 + 4 * (lane >> 4) + r) * CLD + wn * TNW + j * 16 + (lane & 15)] = acc[i][j][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr) bv = ld4(p.bias + col0 + ec);
+#pragma unroll
+    for (int e = 0; e < EI; ++e) {
+        const int lr = er + e * RPI;
+        const int gr = row0 + lr;
+        f32x4 v = ld4(ct + lr * CLD + ec);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = act_apply(v[q] + bv[q], p.act) + rv[e][q];
+        if (gr < p.M) {
+            if (p.Y != nullptr) st4(p.Y + (size_t)gr * p.ldy + col0 + ec, v);
+            if (p.Ys != nullptr) store_split4(p.Ys + (size_t)gr * p.ldy, col0 + ec, v);
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, bool LN>
 static int launch_big(const GemmArgs& a, hipStream_t s) {
     const int nbm = (a.M + BM - 1) / BM, nbn = a.N / BN;
@@ -186,6 +327,8 @@ static int launch_big(const GemmArgs& a, hipStream_t s) {
 
 // true when the shape is served by this kernel family (otherwise the caller uses the staged kernel of gemm.hip)
 bool gemm_big_supported(const GemmArgs& a) {
+    if (a.split) return a.M > 0 && a.K % 64 == 0 && a.K1 % 64 == 0 && a.N % 128 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0 &&
+                        a.ldy % 64 == 0 && !a.ln_g && !a.mod && !a.row_len && a.post_act == ACT_NONE && (a.Y || a.Ys);
     if (a.M < 4096 || a.K % BKB || a.K1 % BKB || (a.lda % 4) || (a.ldw % 4) || (a.A2 && (a.lda2 % 4))) return false;
     if ((a.ldy % 4) || (a.res && (a.ldres % 4)) || a.mod || a.row_len || a.post_act != ACT_NONE) return false;
     if (a.ln_g != nullptr) return a.N == 256;
@@ -193,6 +336,12 @@ bool gemm_big_supported(const GemmArgs& a) {
 }
 
 int launch_gemm_big(const GemmArgs& a, hipStream_t s) {
+    if (a.split) {
+        const int nbm = (a.M + 127) / 128, nbn = a.N / 128;
+        hipLaunchKernelGGL((gemm_big_split_kernel<128, 128>), dim3(((nbm + 7) / 8) * 8 * nbn), dim3(256), 0, s, a);
+        LADIFF_LAUNCH_CHECK();
+        return 0;
+    }
     if (a.ln_g != nullptr) return launch_big<64, 256, 2, 2, true>(a, s);
     return launch_big<128, 128, 2, 2, false>(a, s);
 }

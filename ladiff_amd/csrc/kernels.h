@@ -14,7 +14,7 @@ int launch_layernorm(const float* x, const float* g, const float* b, float* y, i
 int launch_ca_table_input(const float* nval, const float* beta, const float* mod, int step_stride, int n, int B2, float* u,
                           hipStream_t s);
 int launch_add_pe(const float* sample, const float* pe, int Bs, int b_off, int b_n, int T, float* x, float* xs, hipStream_t s);
-int launch_broadcast_pe(const float* pe, int B, int F, float* x, hipStream_t s);
+int launch_broadcast_pe(const float* pe, int B, int F, float* x, float* xs, hipStream_t s);
 int launch_relu(const float* x, float* y, size_t n, hipStream_t s);
 int launch_silu(const float* x, float* y, size_t n, hipStream_t s);
 int launch_sinusoid(const int64_t* t, int n, float* out, hipStream_t s);
@@ -28,8 +28,9 @@ int launch_finalize_latents(const float* lat, const int32_t* counts, float* z, i
 int launch_denoiser_self_attention(const float* qkv, const float* text_kv, const float* tables, int kv_off,
                                    int step_stride, const int32_t* d_step, const int32_t* counts, int Bs, int b_off,
                                    int b_n, int T, float* out, int split_out, hipStream_t s);
-int launch_decoder_self_attention(const float* qkv, const int32_t* lengths, float* out, int B, int F, hipStream_t s);
+int launch_decoder_self_attention(const float* qkv, const int32_t* lengths, float* out, int B, int F, int split_out,
+                                  hipStream_t s);
 int launch_decoder_cross_attention(const float* q, const float* kv, const int32_t* counts, float* out, int B, int F,
-                                   int T, hipStream_t s);
+                                   int T, int split_out, hipStream_t s);
 
 }  // namespace ladiff

@@ -26,7 +26,7 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* w_split, const float* 
                      size_t ws_floats, hipStream_t s, int b_lo = 0, int b_n = -1);
 
 size_t dec_ws_floats(int B, int F, int T);
-int vae_decode(const DecoderW& w, const float* z, const int32_t* lengths, const int32_t* counts, int B, int F, int T,
+int vae_decode(const DecoderW& w, const DecoderW* w_split, const float* z, const int32_t* lengths, const int32_t* counts, int B, int F, int T,
                int C, float* feats, float* ws, size_t ws_floats, hipStream_t s);
 
 }  // namespace ladiff

@@ -147,16 +147,19 @@ int launch_add_pe(const float* sample, const float* pe, int Bs, int b_off, int b
 }
 
 // q0[b,f,:] = pe[f,:]   (queries = zeros + learned PE, ladiff_vae.py:299,:334)
-__global__ __launch_bounds__(256) void broadcast_pe_kernel(const float* __restrict__ pe, int F, int M, float* __restrict__ x) {
+__global__ __launch_bounds__(256) void broadcast_pe_kernel(const float* __restrict__ pe, int F, int M, float* __restrict__ x,
+                                                           float* __restrict__ xs) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     const int c = (threadIdx.x & 63) * 4;
     if (row >= M) return;
-    st4(x + (size_t)row * D + c, ld4(pe + (size_t)(row % F) * D + c));
+    const f32x4 v = ld4(pe + (size_t)(row % F) * D + c);
+    st4(x + (size_t)row * D + c, v);
+    if (xs != nullptr) store_split4(xs + (size_t)row * D, c, v);
 }
 
-int launch_broadcast_pe(const float* pe, int B, int F, float* x, hipStream_t s) {
+int launch_broadcast_pe(const float* pe, int B, int F, float* x, float* xs, hipStream_t s) {
     const int M = B * F;
-    hipLaunchKernelGGL(broadcast_pe_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, pe, F, M, x);
+    hipLaunchKernelGGL(broadcast_pe_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, pe, F, M, x, xs);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }

@@ -195,6 +195,7 @@ class LADiffVae(_HipModule):
                                       + ", ".join(unsupported))
         self._build(schema.vae_schema(nfeats, self.latent_dim, ff_size, num_layers, self.max_it))
         self.reset_parameters()
+        self.precision = kwargs.get("precision", "fp32")     # "fp32" | "bf16x3"
 
     def reset_parameters(self):
         with torch.no_grad():
@@ -248,7 +249,8 @@ class LADiffVae(_HipModule):
         feats = torch.empty(B, F, self.nfeats, dtype=torch.float32, device=dev)
         wsb = L.ladiff_decoder_workspace_bytes(B, F, T, self.nfeats)
         ws = _lib.workspace(wsb, dev)
-        _lib.check(L.ladiff_vae_decode(wt.array, _lib.ptr(zz), lens_t.data_ptr(),
+        _lib.check(L.ladiff_vae_decode(wt.array, wt.split_array() if self.precision == "bf16x3" else None, _lib.ptr(zz),
+                                       lens_t.data_ptr(),
                                        None if counts_t is None else counts_t.data_ptr(), B, F, T, self.nfeats,
                                        _lib.ptr(feats), _lib.ptr(ws), wsb, _lib.stream_ptr()))
         return feats.to(z.dtype)

@@ -94,13 +94,23 @@ class LADIFF(nn.Module):
         self.use_graph = use_graph
         # matrix-product arithmetic of the denoiser loop: "fp32" (fp32-input MFMA) or "bf16x3" (3-term bf16 split)
         self.precision = precision if precision is not None else getattr(self.denoiser, "precision", "fp32")
-        if self.precision not in ("fp32", "bf16x3"):
-            raise ValueError(f"precision {self.precision!r} not supported")
         self._sampler = None
         self._stream = None
         self._plan = None
 
     # ------------------------------------------------------------------ plumbing
+    @property
+    def precision(self):
+        return self._precision
+
+    @precision.setter
+    def precision(self, value):
+        if value not in ("fp32", "bf16x3"):
+            raise ValueError(f"precision {value!r} not supported")
+        self._precision = value
+        self.denoiser.precision = value
+        self.vae.precision = value
+
     @property
     def device(self):
         return next(self.denoiser.parameters()).device

@@ -3,6 +3,10 @@ import sys
 
 import numpy as np
 import pytest
+import torch
+
+# the CPU oracle is a chain of small ops: beyond ~16 threads it gets slower, not faster (128-core GPU hosts)
+torch.set_num_threads(min(16, os.cpu_count() or 1))
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -39,7 +39,15 @@ def vae():
     return make_vae(263)
 
 
+@pytest.fixture(autouse=True)
+def _fp32_by_default(denoiser, vae):
+    denoiser.precision = "fp32"
+    vae.precision = "fp32"
+    yield
+
+
 def make_pipe(denoiser, vae, sched="ddim", steps=50, **kw):
+    kw.setdefault("precision", "fp32")
     s = (DDIMScheduler(set_alpha_to_one=False, steps_offset=1, **SCHED_KW) if sched == "ddim"
          else DDPMScheduler(variance_type="fixed_small", **SCHED_KW))
     return LADIFF(denoiser=denoiser, vae=vae, scheduler=s, guidance_scale=7.5, num_inference_timesteps=steps,
@@ -96,6 +104,16 @@ def test_vae_decode_golden(name, nfeats):
     assert maxdiff(feats, g["feats"]) < 1e-4
     for i, l in enumerate(lengths):
         assert feats[i, l:].abs().max().item() == 0 if l < feats.shape[1] else True
+
+
+@pytest.mark.parametrize("name,nfeats", [("vae_decode_c1", 263), ("vae_decode_mixed_kit", 251)])
+def test_vae_decode_golden_bf16x3(name, nfeats):
+    g = load_golden(name)
+    vae = make_vae(nfeats)
+    vae.precision = "bf16x3"
+    feats = vae.decode(g["z"].to(DEV), g["lengths"].tolist())
+    err = maxdiff(feats, g["feats"])
+    assert 0 < err < FRAME_TOL / 2
 
 
 def test_vae_decode_single_frame_and_single_sample(vae):
