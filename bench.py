@@ -66,17 +66,24 @@ def build_pipe(dev, batch):
                   num_inference_timesteps=STEPS_DDIM, eta=0.0)
 
 
-def dominant_kernel_roofline(dev, stream, launches=400):
-    """Live HIP-event timing of the kernel that dominates the pass (profiles/r1/02: gemm_kr_kernel<80,64,...>, 41 % of
-    the device time): the denoiser's 256->1024 linear at M = 2*128*5 rows, launched back to back on the bench stream."""
+def dominant_kernel_roofline(dev, stream, precision, launches=400):
+    """Live HIP-event timing of the kernel that dominates the pass (profiles/r1: gemm_kr_kernel<80,64,...>, ~40 % of the
+    device time): the denoiser's 256->1024 linear (ffn.linear1, GELU) at M = 2*128*5 rows, launched back to back on the
+    bench stream, in the arithmetic of the timed mode."""
     from ladiff_amd import _lib
     L = _lib.lib()
     M, N, K = 2 * BATCH * 5, 1024, 256
+    split = 1 if precision == "bf16x3" else 0
     A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) / 16; b = torch.randn(N, device=dev)
     Y = torch.empty(M, N, device=dev)
-    args = (A.data_ptr(), K, None, 0, K, W.data_ptr(), K, b.data_ptr(), None, 0, Y.data_ptr(), N, M, N, K, 2, 0, None,
-            stream.cuda_stream)
     with torch.cuda.stream(stream):
+        if split:
+            As, Ws = torch.empty_like(A), torch.empty_like(W)
+            _lib.check(L.ladiff_split_rows(A.data_ptr(), As.data_ptr(), M, K, stream.cuda_stream))
+            _lib.check(L.ladiff_split_rows(W.data_ptr(), Ws.data_ptr(), N, K, stream.cuda_stream))
+            A, W = As, Ws
+        args = (A.data_ptr(), K, None, 0, K, W.data_ptr(), K, b.data_ptr(), None, 0, None if split else Y.data_ptr(), N, M, N, K,
+                2, split, Y.data_ptr() if split else None, stream.cuda_stream)
         for _ in range(20):
             _lib.check(L.ladiff_gemm_resident(*args))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -87,9 +94,12 @@ def dominant_kernel_roofline(dev, stream, launches=400):
         torch.cuda.synchronize(dev)
     us = e0.elapsed_time(e1) * 1e3 / launches
     flops = 2.0 * M * N * K
-    return {"name": "gemm_kr_kernel<80,64,1,4,16> (ffn.linear1: M=1280, N=1024, K=256, GELU)", "flops_per_launch": flops,
-            "us_per_launch": round(us, 2), "achieved": round(flops / us / 1e6, 2), "unit": "TFLOP/s",
-            "frac": round(flops / us / 1e6 / PEAK_F32_MFMA_TFLOPS, 4),
+    peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+    mfma_flops = flops * (3 if split else 1)
+    return {"name": f"gemm_kr_kernel<80,64,1,4,16,{'true' if split else 'false'}> (ffn.linear1: M=1280, N=1024, K=256, GELU)",
+            "flops_per_launch": flops, "mfma_flops_per_launch": mfma_flops, "us_per_launch": round(us, 2),
+            "achieved": round(flops / us / 1e6, 2), "unit": "TFLOP/s", "peak": peak,
+            "frac": round(flops / us / 1e6 / peak, 4), "mfma_frac": round(mfma_flops / us / 1e6 / peak, 4),
             "traffic": 22.8e6, "traffic_source": "profiles/r1/03_pmc_summary.md: 2 x FETCH_SIZE + WRITE_SIZE per launch"}
 
 
@@ -198,7 +208,7 @@ def main():
                        "hipgraph": True},
             "roofline": {"bound": "mfma", "achieved": round(ref_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ref_tf / PEAK_F32_MFMA_TFLOPS, 4),
-                         "kernel": "whole pass (hipGraph step x50 + decode); dominant kernel gemm_kernel<fp32 MFMA>",
+                         "kernel": "whole pass (hipGraph steps x50 + decode)",
                          "device_ms_per_pass": round(dev_ms / args.steps, 3),
                          "flops_per_motion_reference_equivalent": ref_flops_per_motion(),
                          "executed_tflops": round(exe_tf, 2), "executed_frac": round(exe_tf / PEAK_F32_MFMA_TFLOPS, 4),
@@ -218,7 +228,7 @@ def main():
         line["parity"] = {"max_abs_diff_frames_between_modes": mode_diff, "tolerance": 1e-3,
                           "note": "fp32 mode is within 1e-4 of the reference goldens (tests/test_gpu_path.py)"}
         if world == 1:
-            line["roofline"]["dominant_kernel"] = dominant_kernel_roofline(dev, stream)
+            line["roofline"]["dominant_kernel"] = dominant_kernel_roofline(dev, stream, args.precision)
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
             line["cpu_baseline"]["gpu_over_cpu"] = round(motions_per_s / line["cpu_baseline"]["value"], 1)

@@ -57,6 +57,7 @@ ReverseWs carve_reverse(void* ws, int B, int T, int n) {
 
 struct Sampler {
     hipGraphExec_t exec = nullptr;
+    int unroll = 1;                       // denoiser steps captured per graph launch
     int chains = 1;                       // sample ranges captured as parallel graph branches (measured: no gain)
     hipStream_t side[MAX_CHAINS - 1] = {nullptr};
     hipEvent_t fork = nullptr, join[MAX_CHAINS - 1] = {nullptr};
@@ -306,7 +307,12 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
             if (sp->exec) { (void)hipGraphExecDestroy(sp->exec); sp->exec = nullptr; }
             hipGraph_t graph = nullptr;
             LADIFF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            const int rc = one_step(s, sp->chains);
+            // several steps per graph launch (the step index lives in device memory): fewer ~9 us replay gaps
+            int unroll = 1;
+            for (int u = 2; u <= 10; ++u) if (n_steps % u == 0) unroll = u;
+            sp->unroll = unroll;
+            int rc = 0;
+            for (int u = 0; u < unroll && rc == 0; ++u) rc = one_step(s, sp->chains);
             const hipError_t ec = hipStreamEndCapture(s, &graph);
             if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
             LADIFF_HIP(ec);
@@ -317,7 +323,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
             std::memcpy(sp->key_ints, ki, sizeof(ki));
             sp->key_g = guidance_scale;
         }
-        for (int i = 0; i < n_steps; ++i) LADIFF_HIP(hipGraphLaunch(sp->exec, s));
+        for (int i = 0; i < n_steps / sp->unroll; ++i) LADIFF_HIP(hipGraphLaunch(sp->exec, s));
     }
     return launch_finalize_latents(r.latents, counts, z, B, T, s);
 }

@@ -4,7 +4,7 @@ both counters are in KiB.  Usage: python scripts/pmc_summary.py gpurun_out/pmc_r
 import csv, glob, sys
 from collections import defaultdict
 root = sys.argv[1]
-PASSES = 2   # bench.py --steps 1 --warmup 1
+PASSES = int(sys.argv[2]) if len(sys.argv) > 2 else 2   # passes in the profiled run
 def load(name):
     f = glob.glob(f"{root}/{name}/*/*_counter_collection.csv")[0]
     d = defaultdict(lambda: defaultdict(float)); n = defaultdict(int); dur = defaultdict(float)
