@@ -182,6 +182,13 @@ int ladiff_vae_decode(const float* const* w, const float* const* w_split /*or NU
                       const int32_t* lengths, const int32_t* counts, int B, int F, int T, int C, float* feats,
                       void* ws, size_t ws_bytes, ladiff_stream_t stream);
 
+/* ------------------------------------------------------------------ feats2joints (the step after the path)
+ * joints[B,F,njoints,3] = recover_from_ric(feats * std + mean): HumanML3DDataModule.feats2joints
+ * (data/HumanML3D.py:44-48, data/Kit.py:48-53; motion_process.py:362-381, :415-430).  feats [B,F,C] as produced by
+ * ladiff_vae_decode, mean/std [C] (device), C = 263 with 22 joints or 251 with 21 joints, F <= 256. */
+int ladiff_feats2joints(const float* feats, const float* mean, const float* std, int B, int F, int C, int njoints,
+                        float* joints, ladiff_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

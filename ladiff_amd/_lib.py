@@ -61,6 +61,7 @@ _SIGNATURES = {
     "ladiff_diffusion_reverse": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p,
                                          c_size_t, c_void_p]),
+    "ladiff_feats2joints": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ladiff_decoder_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ladiff_vae_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                   c_void_p, c_size_t, c_void_p]),

@@ -328,6 +328,13 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
     return launch_finalize_latents(r.latents, counts, z, B, T, s);
 }
 
+// ------------------------------------------------------------------ feats2joints (the step after the path)
+int ladiff_feats2joints(const float* feats, const float* mean, const float* std, int B, int F, int C, int njoints,
+                        float* joints, ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(feats && mean && std && joints && B >= 0);
+    return launch_feats2joints(feats, mean, std, B, F, C, njoints, joints, S(stream));
+}
+
 // ------------------------------------------------------------------ LA-VAE decoder
 size_t ladiff_decoder_workspace_bytes(int B, int F, int T, int C) {
     (void)C;

@@ -24,6 +24,10 @@ int launch_advance(int32_t* d_step, hipStream_t s);
 int launch_init_latents(const float* noise, const int32_t* counts, float sigma, float* lat, int B, int T, hipStream_t s);
 int launch_finalize_latents(const float* lat, const int32_t* counts, float* z, int B, int T, hipStream_t s);
 
+// feats2joints.hip
+int launch_feats2joints(const float* feats, const float* mean, const float* stdv, int B, int F, int C, int J, float* joints,
+                        hipStream_t s);
+
 // attention.hip
 int launch_denoiser_self_attention(const float* qkv, const float* text_kv, const float* tables, int kv_off,
                                    int step_stride, const int32_t* d_step, const int32_t* counts, int Bs, int b_off,

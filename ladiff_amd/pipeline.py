@@ -20,6 +20,7 @@ import torch
 from torch import nn
 
 from . import _lib
+from .feats2joints import Feats2Joints
 from .schedulers import DDIMScheduler, DDPMScheduler, timestep_sinusoid
 
 _TARGET_ALIASES = {
@@ -87,7 +88,9 @@ class LADIFF(nn.Module):
             instantiate_from_config(te_cfg) if te_cfg is not None else None)
         self.latent_dim = [self.max_it, 256]
         self.do_classifier_free_guidance = self.guidance_scale > 1.0
-        self.feats2joints = getattr(datamodule, "feats2joints", None)
+        self.feats2joints = getattr(datamodule, "feats2joints", None)      # the reference's CPU function (HumanML3D.py:44-48)
+        # same arithmetic on the GPU when the datamodule exposes mean / std / njoints; joints then cross PCIe, not features
+        self.feats2joints_device = Feats2Joints.from_datamodule(datamodule) if datamodule is not None else None
         self.sample_mean = False
         self.fact = None
         self.times = []
@@ -211,7 +214,7 @@ class LADIFF(nn.Module):
 
     def forward(self, batch, latentwise_gen=None, plot_att_map=None):
         texts, lengths = batch["text"], batch["length"]
-        if self.text_encoder is None or self.feats2joints is None:
+        if self.text_encoder is None or (self.feats2joints is None and self.feats2joints_device is None):
             raise RuntimeError("LADIFF.forward needs a text_encoder callable and datamodule.feats2joints; "
                                "use .sample(text_emb, lengths) for embeddings -> features")
         start = time.time()
@@ -228,6 +231,11 @@ class LADIFF(nn.Module):
                     elif latentwise_gen == "bw":
                         z[:self.max_it - (idx + 1), idx, :] = 0
             feats_rst = self.vae.decode(z, lengths, plot_att_map=plot_att_map, latentwise_gen=latentwise_gen)
+        if self.feats2joints_device is not None:
+            joints = self.feats2joints_device(feats_rst.detach())
+            torch.cuda.synchronize()
+            self.times.append(time.time() - start)
+            return remove_padding(joints.cpu(), lengths)
         torch.cuda.synchronize()
         self.times.append(time.time() - start)
         joints = self.feats2joints(feats_rst.detach().cpu())
@@ -235,5 +243,7 @@ class LADIFF(nn.Module):
 
     def gen_from_latent(self, batch):
         feats_rst = self.vae.decode(batch["latent"], batch["length"])
+        if self.feats2joints_device is not None:
+            return remove_padding(self.feats2joints_device(feats_rst.detach()).cpu(), batch["length"])
         joints = self.feats2joints(feats_rst.detach().cpu())
         return remove_padding(joints, batch["length"])

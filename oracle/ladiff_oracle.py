@@ -358,3 +358,34 @@ def sample_motions(den_sd, vae_sd, text_emb, lengths, init_noise, n_steps=50, sc
                           guidance_scale, eta, None if step_noise is None else step_noise.to(dtype))
     feats = vae_decode(vae_sd, z, lengths)
     return z, feats
+
+
+# --------------------------------------------------------------------------- feats2joints
+def feats2joints(features, mean, std, njoints):
+    """HumanML3DDataModule.feats2joints (data/HumanML3D.py:44-48): de-normalise, then recover_from_ric
+    (data/humanml/scripts/motion_process.py:362-381, :415-430; qinv/qrot quaternion.py:16-20, :54-73).
+    features [B,F,C] -> joints [B,F,njoints,3].  Pinned by tests/golden/feats2joints_*.npz."""
+    data = features * std + mean
+    rot_vel = data[..., 0]
+    ang = torch.zeros_like(rot_vel)
+    ang[..., 1:] = rot_vel[..., :-1]
+    ang = torch.cumsum(ang, dim=-1)
+    qw, qy = torch.cos(ang), -torch.sin(ang)                 # qinv(r_rot_quat) = (cos, 0, -sin, 0)
+
+    def qrot_y(vx, vy, vz):                                  # qvec = (0, qy, 0)
+        ux, uy, uz = qy * vz, torch.zeros_like(vx), -qy * vx
+        wx, wy, wz = qy * uz, torch.zeros_like(vx), -qy * ux
+        return vx + 2 * (qw * ux + wx), vy + 2 * (qw * uy + wy), vz + 2 * (qw * uz + wz)
+
+    vx = torch.zeros_like(rot_vel); vz = torch.zeros_like(rot_vel)
+    vx[..., 1:] = data[..., :-1, 1]
+    vz[..., 1:] = data[..., :-1, 2]
+    px, _, pz = qrot_y(vx, torch.zeros_like(vx), vz)
+    rx, rz = torch.cumsum(px, dim=-1), torch.cumsum(pz, dim=-1)
+    ry = data[..., 3]
+    loc = data[..., 4:4 + (njoints - 1) * 3].reshape(*data.shape[:-1], njoints - 1, 3)
+    qw, qy = qw[..., None], qy[..., None]
+    ox, oy, oz = qrot_y(loc[..., 0], loc[..., 1], loc[..., 2])
+    pos = torch.stack([ox + rx[..., None], oy, oz + rz[..., None]], dim=-1)
+    root = torch.stack([rx, ry, rz], dim=-1)[..., None, :]
+    return torch.cat([root, pos], dim=-2)

@@ -232,3 +232,37 @@ def test_ddpm_1000_steps_small_batch(denoiser, vae):
     assert maxdiff(z, z_o) < 1e-4 * scale
     assert maxdiff(feats, f_o) < 5e-3
     assert feats[1, 100:].abs().max().item() == 0
+
+
+# ---------------------------------------------------------------- feats2joints (next row)
+@pytest.mark.parametrize("name", ["feats2joints_humanml", "feats2joints_kit"])
+def test_feats2joints_golden(name):
+    from ladiff_amd import Feats2Joints
+    g = load_golden(name)
+    f2j = Feats2Joints(g["mean"], g["std"], int(g["njoints"]))
+    joints = f2j(g["feats"].to(DEV))
+    assert joints.shape == g["joints"].shape
+    # prefix sums run in frame order like torch.cumsum; the only difference is the sin/cos rounding
+    assert maxdiff(joints, g["joints"]) < 2e-5
+    with pytest.raises(_lib.LadiffHipError):
+        f2j(g["feats"])            # CPU tensor: no fallback
+
+
+def test_feats2joints_full_size_vs_oracle():
+    from ladiff_amd import Feats2Joints
+    gen = torch.Generator().manual_seed(9)
+    feats = torch.randn(128, 196, 263, generator=gen)
+    mean, std = 0.1 * torch.randn(263, generator=gen), 0.05 + 0.2 * torch.rand(263, generator=gen)
+    got = Feats2Joints(mean, std, 22)(feats.to(DEV))
+    want = orc.feats2joints(feats, mean, std, 22)
+    assert maxdiff(got, want) < 1e-4 * max(1.0, want.abs().max().item())
+
+
+def test_forward_uses_device_feats2joints(denoiser, vae):
+    mean, std = torch.zeros(263), torch.ones(263)
+    dm = SimpleNamespace(feats2joints=None, hparams=SimpleNamespace(mean=mean.numpy(), std=std.numpy()), njoints=22)
+    enc = lambda texts: torch.randn(len(texts), 1, 768, generator=torch.Generator().manual_seed(3)).to(DEV)
+    model = LADIFF(None, dm, denoiser=denoiser, vae=vae, text_encoder=enc, guidance_scale=7.5, num_inference_timesteps=5,
+                   scheduler=DDIMScheduler(set_alpha_to_one=False, steps_offset=1, **SCHED_KW))
+    joints = model({"text": ["walk", "run"], "length": [50, 196]})
+    assert [tuple(j.shape) for j in joints] == [(50, 22, 3), (196, 22, 3)] and all(torch.isfinite(j).all() for j in joints)

@@ -86,3 +86,11 @@ def test_scheduler_known_answers():
     d.set_timesteps(50)
     y = d.step(torch.zeros_like(x), 981, x)
     assert torch.allclose(y, x * (d.alphas_cumprod[961] / d.alphas_cumprod[981]) ** 0.5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["feats2joints_humanml", "feats2joints_kit"])
+def test_feats2joints(name):
+    """Next row of the scope table, pinned to the reference's recover_from_ric."""
+    g = load_golden(name)
+    j = orc.feats2joints(g["feats"], g["mean"], g["std"], int(g["njoints"]))
+    assert j.shape == g["joints"].shape and maxdiff(j, g["joints"]) < 1e-6
