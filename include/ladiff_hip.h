@@ -97,11 +97,12 @@ int ladiff_combine_rows(const float* partials, int n_planes, int M, const float*
 int ladiff_layernorm(const float* x, const float* gamma, const float* beta, float* y, int M,
                      ladiff_stream_t stream);
 
-/* Decoder self-attention core (softmax(QK^T/8 + key mask) V per sample and head) on packed
- * qkv[B*F,768]; keys >= lengths[b] are masked.  The nn.MultiheadAttention inside
- * TransformerDecoderLayer.forward_post, cross_attention.py:367-369 (without in/out projections). */
-int ladiff_decoder_self_attention(const float* qkv, const int32_t* lengths, float* out, int B, int F,
-                                  ladiff_stream_t stream);
+/* Self-attention core (softmax(QK^T/8 + key mask) V per sample and head) on packed qkv[B*F,768], F <= 224.
+ * Key validity: keys < lengths[b], or - when keybits != NULL - bit k of the 256-bit map keybits[b][8] (uint32 words,
+ * LSB first).  The nn.MultiheadAttention inside TransformerDecoderLayer.forward_post (cross_attention.py:367-369)
+ * and TransformerEncoderLayer.forward_post (:298-300), without the in/out projections. */
+int ladiff_decoder_self_attention(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out,
+                                  int B, int F, ladiff_stream_t stream);
 
 /* Decoder cross-attention core: q[B*F,256] against the T memory tokens kv[T*B,512] (row = t*B+b,
  * K | V), tokens >= counts[b] masked.  cross_attention.py:373-376. */
@@ -181,6 +182,18 @@ size_t ladiff_decoder_workspace_bytes(int B, int F, int T, int C);
 int ladiff_vae_decode(const float* const* w, const float* const* w_split /*or NULL: fp32 MFMA*/, const float* z,
                       const int32_t* lengths, const int32_t* counts, int B, int F, int T, int C, float* feats,
                       void* ws, size_t ws_bytes, ladiff_stream_t stream);
+
+/* ------------------------------------------------------------------ LA-VAE encoder
+ * LADiffVae.encode, ladiff_vae.py:162-286 (call sites ladiff.py:269, :324, :1096): features[B,F,C] ->
+ * mu, std, latent, each [T,B,256] (sequence-first like the reference); latent = mu + std * eps with rows >= counts[b]
+ * zeroed; eps[T,B,256] stands in for the draw inside Normal.rsample().  F + 2T <= 224.  Weight table as for the
+ * decoder: ladiff_encoder_param_name(i) lists the state-dict keys. */
+int ladiff_encoder_num_params(void);
+const char* ladiff_encoder_param_name(int i);
+size_t ladiff_encoder_workspace_bytes(int B, int F, int T, int C);
+int ladiff_vae_encode(const float* const* w, const float* const* w_split /*or NULL*/, const float* features,
+                      const int32_t* lengths, const int32_t* counts, const float* eps, int B, int F, int T, int C,
+                      float* mu, float* std, float* latent, void* ws, size_t ws_bytes, ladiff_stream_t stream);
 
 /* ------------------------------------------------------------------ feats2joints (the step after the path)
  * joints[B,F,njoints,3] = recover_from_ric(feats * std + mean): HumanML3DDataModule.feats2joints

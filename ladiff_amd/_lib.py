@@ -40,7 +40,7 @@ _SIGNATURES = {
                                     c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ladiff_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ladiff_timestep_sinusoid": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
-    "ladiff_decoder_self_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ladiff_decoder_self_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ladiff_decoder_cross_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ladiff_denoiser_tables_floats": (c_size_t, [c_int]),
     "ladiff_denoiser_text_cache_floats": (c_size_t, [c_int, c_int]),
@@ -61,6 +61,11 @@ _SIGNATURES = {
     "ladiff_diffusion_reverse": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p,
                                          c_size_t, c_void_p]),
+    "ladiff_encoder_num_params": (c_int, []),
+    "ladiff_encoder_param_name": (c_char_p, [c_int]),
+    "ladiff_encoder_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "ladiff_vae_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ladiff_feats2joints": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ladiff_decoder_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ladiff_vae_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,

@@ -153,10 +153,10 @@ int ladiff_timestep_sinusoid(const int64_t* timesteps, int n, float* out, ladiff
     return launch_sinusoid(timesteps, n, out, S(stream));
 }
 
-int ladiff_decoder_self_attention(const float* qkv, const int32_t* lengths, float* out, int B, int F,
-                                  ladiff_stream_t stream) {
-    LADIFF_CHECK_ARG(qkv && lengths && out && B >= 0);
-    return launch_decoder_self_attention(qkv, lengths, out, B, F, 0, S(stream));
+int ladiff_decoder_self_attention(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B,
+                                  int F, ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(qkv && (lengths || keybits) && out && B >= 0);
+    return launch_decoder_self_attention(qkv, lengths, keybits, out, B, F, 0, S(stream));
 }
 
 int ladiff_decoder_cross_attention(const float* q, const float* kv, const int32_t* counts, float* out, int B, int F,
@@ -326,6 +326,24 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
         for (int i = 0; i < n_steps / sp->unroll; ++i) LADIFF_HIP(hipGraphLaunch(sp->exec, s));
     }
     return launch_finalize_latents(r.latents, counts, z, B, T, s);
+}
+
+// ------------------------------------------------------------------ LA-VAE encoder
+int ladiff_encoder_num_params(void) { return ENC_NPARAMS; }
+const char* ladiff_encoder_param_name(int i) {
+    const auto& n = encoder_param_names();
+    return (i >= 0 && i < (int)n.size()) ? n[i].c_str() : nullptr;
+}
+size_t ladiff_encoder_workspace_bytes(int B, int F, int T, int C) { return enc_ws_floats(B, F, T, C) * sizeof(float); }
+
+int ladiff_vae_encode(const float* const* w, const float* const* w_split, const float* features, const int32_t* lengths,
+                      const int32_t* counts, const float* eps, int B, int F, int T, int C, float* mu, float* std,
+                      float* latent, void* ws, size_t ws_bytes, ladiff_stream_t stream) {
+    EncoderW W, WS;
+    LADIFF_CHECK_ARG(load_weights(W, w) && features && lengths && counts && eps && mu && std && latent && ws && B >= 0);
+    if (w_split != nullptr) LADIFF_CHECK_ARG(load_weights(WS, w_split));
+    return vae_encode(W, w_split ? &WS : nullptr, features, lengths, counts, eps, B, F, T, C, mu, std, latent, (float*)ws,
+                      ws_bytes / sizeof(float), S(stream));
 }
 
 // ------------------------------------------------------------------ feats2joints (the step after the path)

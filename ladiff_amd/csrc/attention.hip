@@ -16,14 +16,31 @@ namespace ladiff {
 constexpr int SA_FMAX = LADIFF_MAX_FRAMES;   // 224 = 7 key tiles
 constexpr int SA_NKT = SA_FMAX / 32;
 
+// Key validity is either a prefix (keys < lengths[b]) or, when `keybits` is given, an arbitrary 256-bit map per sample
+// (the LA-VAE encoder masks latent tokens in the middle of the sequence, ladiff_vae.py:193-209).
 __global__ __launch_bounds__(256) void dec_self_attn_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ lengths,
-                                                            float* __restrict__ out, int B, int F, int split_out) {
+                                                            const uint32_t* __restrict__ keybits, float* __restrict__ out,
+                                                            int B, int F, int split_out) {
     __shared__ __attribute__((aligned(16))) float Ks[SA_FMAX * DH];   // chunk c of row r at slot c ^ (r & 15)
     __shared__ __attribute__((aligned(16))) float Vs[SA_FMAX * DH];   // plain [key][d]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y / H, h = blockIdx.y % H;
-    int len = lengths[b];
-    len = len < 1 ? 1 : (len > F ? F : len);
+    int len = F;                                  // keys >= len are never valid
+    uint32_t kb[SA_NKT + 1];
+    if (keybits != nullptr) {
+        len = 1;
+#pragma unroll
+        for (int i = 0; i < SA_NKT; ++i) {
+            kb[i] = keybits[(size_t)b * 8 + i];
+            if (kb[i]) len = 32 * i + 32 - __builtin_clz(kb[i]);
+        }
+        len = len > F ? F : len;
+    } else {
+        len = lengths[b];
+        len = len < 1 ? 1 : (len > F ? F : len);
+#pragma unroll
+        for (int i = 0; i < SA_NKT; ++i) kb[i] = len >= 32 * i + 32 ? 0xFFFFFFFFu : (len > 32 * i ? (1u << (len - 32 * i)) - 1u : 0u);
+    }
     const int nkt = (len + 31) >> 5;
     const size_t base = (size_t)b * F * 768 + h * DH;
 
@@ -72,8 +89,8 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const float* __restr
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2;
-                const float s = key < len ? acc[i] : -INFINITY;
+                const int kin = (i & 3) + 8 * (i >> 2) + 4 * h2;          // key within the tile
+                const float s = ((kb[kt] >> kin) & 1u) ? acc[i] : -INFINITY;
                 acc[i] = s;
                 m = fmaxf(m, s);
             }
@@ -133,12 +150,14 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const float* __restr
     }
 }
 
-int launch_decoder_self_attention(const float* qkv, const int32_t* lengths, float* out, int B, int F, int split_out,
-                                  hipStream_t s) {
+int launch_decoder_self_attention(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
+                                  int split_out, hipStream_t s) {
     if (F > SA_FMAX || F < 1) return LADIFF_ERR_SHAPE;
+    if (lengths == nullptr && keybits == nullptr) return LADIFF_ERR_ARG;
     if (B == 0) return 0;
     const int nqt = (F + 31) / 32;
-    hipLaunchKernelGGL(dec_self_attn_kernel, dim3((nqt + 3) / 4, B * H), dim3(256), 0, s, qkv, lengths, out, B, F, split_out);
+    hipLaunchKernelGGL(dec_self_attn_kernel, dim3((nqt + 3) / 4, B * H), dim3(256), 0, s, qkv, lengths, keybits, out, B, F,
+                       split_out);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }

@@ -57,6 +57,22 @@ const std::vector<std::string>& decoder_param_names() {
     return names;
 }
 
+const std::vector<std::string>& encoder_param_names() {
+    static const std::vector<std::string> names = [] {
+        std::vector<std::string> v;
+        v.push_back("global_motion_token"); v.push_back("query_pos_encoder.pe");
+        for (const auto& p : block_prefixes("encoder")) {
+            mha_names(v, p + ".self_attn");
+            wb(v, p + ".linear1"); wb(v, p + ".linear2");
+            wb(v, p + ".norm1"); wb(v, p + ".norm2");
+        }
+        for (int i = 0; i < NSKIP; ++i) wb(v, "encoder.linear_blocks." + std::to_string(i));
+        wb(v, "encoder.norm"); wb(v, "skel_embedding");
+        return v;
+    }();
+    return names;
+}
+
 // ------------------------------------------------------------------ small GEMM helper
 static GemmArgs lin(const float* A, int lda, const LinearW& l, float* Y, int ldy, int M, int N, int K, int act = ACT_NONE) {
     GemmArgs g;

@@ -24,6 +24,12 @@ int launch_advance(int32_t* d_step, hipStream_t s);
 int launch_init_latents(const float* noise, const int32_t* counts, float sigma, float* lat, int B, int T, hipStream_t s);
 int launch_finalize_latents(const float* lat, const int32_t* counts, float* z, int B, int T, hipStream_t s);
 
+int launch_pad_cols(const float* x, float* y, int R, int C, int Cp, hipStream_t s);
+int launch_encoder_assemble(const float* token, const float* emb, const float* pe, const int32_t* lengths,
+                            const int32_t* counts, int B, int F, int T, float* x, float* xs, uint32_t* keybits, hipStream_t s);
+int launch_encoder_finalize(const float* out, const float* eps, const int32_t* counts, int B, int T, int S, float* mu, float* sd,
+                            float* latent, hipStream_t s);
+
 // feats2joints.hip
 int launch_feats2joints(const float* feats, const float* mean, const float* stdv, int B, int F, int C, int J, float* joints,
                         hipStream_t s);
@@ -32,8 +38,8 @@ int launch_feats2joints(const float* feats, const float* mean, const float* stdv
 int launch_denoiser_self_attention(const float* qkv, const float* text_kv, const float* tables, int kv_off,
                                    int step_stride, const int32_t* d_step, const int32_t* counts, int Bs, int b_off,
                                    int b_n, int T, float* out, int split_out, hipStream_t s);
-int launch_decoder_self_attention(const float* qkv, const int32_t* lengths, float* out, int B, int F, int split_out,
-                                  hipStream_t s);
+int launch_decoder_self_attention(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
+                                  int split_out, hipStream_t s);
 int launch_decoder_cross_attention(const float* q, const float* kv, const int32_t* counts, float* out, int B, int F,
                                    int T, int split_out, hipStream_t s);
 

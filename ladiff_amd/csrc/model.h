@@ -29,4 +29,9 @@ size_t dec_ws_floats(int B, int F, int T);
 int vae_decode(const DecoderW& w, const DecoderW* w_split, const float* z, const int32_t* lengths, const int32_t* counts, int B, int F, int T,
                int C, float* feats, float* ws, size_t ws_floats, hipStream_t s);
 
+size_t enc_ws_floats(int B, int F, int T, int C);
+int vae_encode(const EncoderW& w, const EncoderW* w_split, const float* features, const int32_t* lengths,
+               const int32_t* counts, const float* eps, int B, int F, int T, int C, float* mu, float* sd, float* latent, float* ws,
+               size_t ws_floats, hipStream_t s);
+
 }  // namespace ladiff

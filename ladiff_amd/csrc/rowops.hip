@@ -179,6 +179,86 @@ int launch_split_rows(const float* x, float* y, int R, int K, hipStream_t s) {
     return 0;
 }
 
+// ---------------------------------------------------------------- LA-VAE encoder plumbing (ladiff_vae.py:162-286)
+// out[r, 0:Cp] = [in[r, 0:C], 0 ...]: pads rows to a multiple of 32 columns so that K = nfeats GEMMs can use 16-byte chunks
+__global__ __launch_bounds__(256) void pad_cols_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int Cp, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t r = i / Cp; const int c = (int)(i % Cp);
+    y[i] = c < C ? x[r * C + c] : 0.f;
+}
+int launch_pad_cols(const float* x, float* y, int R, int C, int Cp, hipStream_t s) {
+    const size_t n = (size_t)R * Cp;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(pad_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, C, Cp, n);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+// xseq[b, s] = (s < 2T ? motion_token[s] : emb[b, s - 2T]) + pe[s]            ladiff_vae.py:189, :212, :219
+// keybits[b] = validity map of the S = 2T + F keys: mu tokens < count, logvar tokens < count, frames < len   :193-209
+__global__ __launch_bounds__(256) void encoder_assemble_kernel(const float* __restrict__ token, const float* __restrict__ emb,
+                                                               const float* __restrict__ pe, const int32_t* __restrict__ lengths,
+                                                               const int32_t* __restrict__ counts, int F, int T2, int S, int M,
+                                                               float* __restrict__ x, float* __restrict__ xs,
+                                                               uint32_t* __restrict__ keybits) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int c = (threadIdx.x & 63) * 4;
+    if (row >= M) return;
+    const int b = row / S, sq = row % S;
+    f32x4 v = sq < T2 ? ld4(token + (size_t)sq * D + c) : ld4(emb + ((size_t)b * F + (sq - T2)) * D + c);
+    const f32x4 p = ld4(pe + (size_t)sq * D + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += p[i];
+    st4(x + (size_t)row * D + c, v);
+    if (xs != nullptr) store_split4(xs + (size_t)row * D, c, v);
+    if (sq < 8 && (threadIdx.x & 63) == 0) {     // 8 words of the key map, written by the first 8 rows of the sample
+        const int T = T2 / 2, cnt = counts[b], len = lengths[b];
+        uint32_t w = 0;
+        for (int k = 32 * sq; k < 32 * sq + 32 && k < S; ++k) {
+            const bool ok = k < T ? k < cnt : (k < T2 ? (k - T) < cnt : (k - T2) < len);
+            if (ok) w |= 1u << (k & 31);
+        }
+        keybits[(size_t)b * 8 + sq] = w;
+    }
+}
+int launch_encoder_assemble(const float* token, const float* emb, const float* pe, const int32_t* lengths,
+                            const int32_t* counts, int B, int F, int T, float* x, float* xs, uint32_t* keybits, hipStream_t s) {
+    const int S = 2 * T + F, M = B * S;
+    if (S < 8) return LADIFF_ERR_SHAPE;
+    hipLaunchKernelGGL(encoder_assemble_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, token, emb, pe,
+                       lengths, counts, F, 2 * T, S, M, x, xs, keybits);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+// mu = dist[0:T], logvar = dist[T:2T]; std = exp(logvar)^0.5; latent = mu + std * eps, rows >= count zeroed
+// (ladiff_vae.py:258-268); outputs are sequence-first [T, B, 256] like the reference's.
+__global__ __launch_bounds__(256) void encoder_finalize_kernel(const float* __restrict__ out, const float* __restrict__ eps,
+                                                               const int32_t* __restrict__ counts, int B, int T, int S,
+                                                               float* __restrict__ mu, float* __restrict__ sd,
+                                                               float* __restrict__ latent) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);      // row = b * T + t
+    const int c = (threadIdx.x & 63) * 4;
+    if (row >= B * T) return;
+    const int b = row / T, t = row % T;
+    const f32x4 m = ld4(out + ((size_t)b * S + t) * D + c), lv = ld4(out + ((size_t)b * S + T + t) * D + c);
+    const size_t o = ((size_t)t * B + b) * D + c;
+    const f32x4 e = ld4(eps + o);
+    f32x4 sdv, z;
+    const bool valid = t < counts[b];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sdv[i] = sqrtf(expf(lv[i])); z[i] = valid ? m[i] + sdv[i] * e[i] : 0.f; }
+    st4(mu + o, m); st4(sd + o, sdv); st4(latent + o, z);
+}
+int launch_encoder_finalize(const float* out, const float* eps, const int32_t* counts, int B, int T, int S, float* mu, float* sd,
+                            float* latent, hipStream_t s) {
+    hipLaunchKernelGGL(encoder_finalize_kernel, dim3((B * T + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, out, eps,
+                       counts, B, T, S, mu, sd, latent);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
 // y = relu(x), flat
 __global__ __launch_bounds__(256) void relu_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n4) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -52,10 +52,27 @@ struct DecoderW {                                                    // ladiff_v
     LinearW final_layer;
 };
 
+struct EncLayerW {                                                   // cross_attention.py:264-286 (DETR encoder layer)
+    MhaW self_attn;
+    LinearW lin1, lin2;
+    NormW norm1, norm2;
+};
+
+struct EncoderW {                                                    // ladiff_vae.py:72-73, 79-89, 116-122 (encode side)
+    const float* motion_token;                                       // global_motion_token [2*MAX_IT, 256]
+    const float* query_pe;                                           // query_pos_encoder.pe
+    EncLayerW layer[NL];
+    LinearW skip[NSKIP];
+    NormW norm;
+    LinearW skel;                                                    // skel_embedding [256, nfeats]
+};
+
 constexpr int DEN_NPARAMS = sizeof(DenoiserW) / sizeof(const float*);
 constexpr int DEC_NPARAMS = sizeof(DecoderW) / sizeof(const float*);
+constexpr int ENC_NPARAMS = sizeof(EncoderW) / sizeof(const float*);
 
 const std::vector<std::string>& denoiser_param_names();
 const std::vector<std::string>& decoder_param_names();
+const std::vector<std::string>& encoder_param_names();
 
 }  // namespace ladiff

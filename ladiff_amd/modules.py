@@ -54,14 +54,16 @@ def _get(ablation, name, default=None):
 class _HipModule(_ParamTree):
     _KIND = None
 
-    def _weight_table(self):
+    def _weight_table(self, kind=None):
+        kind = kind or self._KIND
         sd = dict(self.named_parameters())
-        names = _lib.param_names(self._KIND)
+        names = _lib.param_names(kind)
         key = _lib.WeightTable.key_of(names, sd)
-        tab = getattr(self, "_wt", None)
+        cache = self.__dict__.setdefault("_wt", {})
+        tab = cache.get(kind)
         if tab is None or tab.key != key:
-            tab = _lib.WeightTable(self._KIND, sd)
-            self._wt = tab
+            tab = _lib.WeightTable(kind, sd)
+            cache[kind] = tab
         return tab
 
 
@@ -164,7 +166,7 @@ class LADiffDenoiser(_HipModule):
 
 
 class LADiffVae(_HipModule):
-    """Length-aware VAE; `decode` replaces `ladiff_vae.py:288-362`.  `encode` is the next row of the scope table."""
+    """Length-aware VAE; `decode` replaces `ladiff_vae.py:288-362`, `encode` replaces `:162-286`."""
     _KIND = "decoder"
 
     def __init__(self, ablation, nfeats: int, latent_dim: list = [1, 256], ff_size: int = 1024, num_layers: int = 9,
@@ -217,9 +219,38 @@ class LADiffVae(_HipModule):
             for lin in ("skel_embedding", "final_layer"):
                 _linear_default_(self.get_parameter(lin + ".weight"), self.get_parameter(lin + ".bias"))
 
-    def encode(self, features, lengths=None):
-        raise NotImplementedError("LADiffVae.encode (ladiff_vae.py:162-286) is not on the sampling path; "
-                                  "it is the next row of SURVEY.md §8(f) and is not built yet")
+    def encode(self, features, lengths=None, eps=None):
+        """features [B,F,nfeats], lengths list[int] -> (latent [max_it,B,256], Normal(mu, std), max_iter_elements).
+
+        `LADiffVae.encode` of the reference (ladiff_vae.py:162-286; LAD branch).  `eps` ([max_it,B,256], optional)
+        replaces the standard-normal draw of `dist.rsample()` so that results can be reproduced."""
+        L = _lib.lib()
+        dev = features.device
+        B, F, C = features.shape
+        if lengths is None:
+            lengths = [F] * B
+        lengths = [int(l) for l in lengths]
+        T = self.max_it
+        if len(lengths) != B or C != self.nfeats:
+            raise ValueError(f"features {tuple(features.shape)} do not match {len(lengths)} lengths / nfeats {self.nfeats}")
+        if F + 2 * T > _lib.MAX_FRAMES:
+            raise NotImplementedError(f"encode handles up to {_lib.MAX_FRAMES - 2 * T} frames")
+        counts = [int(math.ceil(l / self.frame_per_latent)) for l in lengths]
+        lens_t = torch.tensor(lengths, dtype=torch.int32, device=dev)
+        counts_t = torch.tensor(counts, dtype=torch.int32, device=dev)
+        if eps is None:
+            eps = torch.randn(T, B, self.latent_dim, dtype=torch.float32, device=dev)     # Normal.rsample's draw
+        eps = eps.detach().to(device=dev, dtype=torch.float32).contiguous()
+        x = features.detach().to(torch.float32).contiguous()
+        wt = self._weight_table("encoder")
+        mu, std, latent = (torch.empty(T, B, self.latent_dim, dtype=torch.float32, device=dev) for _ in range(3))
+        wsb = L.ladiff_encoder_workspace_bytes(B, F, T, C)
+        ws = _lib.workspace(wsb, dev)
+        _lib.check(L.ladiff_vae_encode(wt.array, wt.split_array() if self.precision == "bf16x3" else None, _lib.ptr(x),
+                                       lens_t.data_ptr(), counts_t.data_ptr(), _lib.ptr(eps), B, F, T, C, _lib.ptr(mu),
+                                       _lib.ptr(std), _lib.ptr(latent), _lib.ptr(ws), wsb, _lib.stream_ptr()))
+        dist = torch.distributions.Normal(mu, std)
+        return latent.to(features.dtype), dist, torch.tensor(counts, dtype=torch.long)
 
     def decode(self, z, lengths, plot_att_map=None, latentwise_gen=None):
         """z [max_it,B,256], lengths list[int] -> feats [B, max(lengths), nfeats]; frames >= len are zero."""

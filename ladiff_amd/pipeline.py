@@ -241,6 +241,14 @@ class LADIFF(nn.Module):
         joints = self.feats2joints(feats_rst.detach().cpu())
         return remove_padding(joints, lengths)
 
+    def recon_from_motion(self, batch):
+        """encode -> decode -> joints of the reconstruction and of the input (ladiff.py:320-331)."""
+        feats_ref, length = batch["motion"], batch["length"]
+        z, dist, _ = self.vae.encode(feats_ref, length)
+        feats_rst = self.vae.decode(z, length)
+        f2j = self.feats2joints_device or (lambda f: self.feats2joints(f.detach().cpu()))
+        return remove_padding(f2j(feats_rst.detach()).cpu(), length), remove_padding(f2j(feats_ref.detach()).cpu(), length)
+
     def gen_from_latent(self, batch):
         feats_rst = self.vae.decode(batch["latent"], batch["length"])
         if self.feats2joints_device is not None:

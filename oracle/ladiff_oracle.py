@@ -389,3 +389,42 @@ def feats2joints(features, mean, std, njoints):
     pos = torch.stack([ox + rx[..., None], oy, oz + rz[..., None]], dim=-1)
     root = torch.stack([rx, ry, rz], dim=-1)[..., None, :]
     return torch.cat([root, pos], dim=-2)
+
+
+# --------------------------------------------------------------------------- LA-VAE encoder
+def detr_encoder_layer(x, p, key_pad):
+    """cross_attention.TransformerEncoderLayer.forward_post (:293-307), gelu feed-forward."""
+    a = mha(x, x, x, sub(p, "self_attn"), key_pad)
+    x = layer_norm(x + a, p["norm1.weight"], p["norm1.bias"])
+    f = linear(F.gelu(linear(x, p["linear1.weight"], p["linear1.bias"])), p["linear2.weight"], p["linear2.bias"])
+    return layer_norm(x + f, p["norm2.weight"], p["norm2.bias"])
+
+
+def vae_encode(sd, features, lengths, eps, max_it=5, frame_per_latent=48, num_layers=9):
+    """LADiffVae.encode, LAD / mld-PE branch (ladiff_vae.py:162-286).  features [B,F,C] -> (mu, std, latent), each
+    [max_it,B,D]; `eps` [max_it,B,D] stands in for Normal.rsample's draw.  Pinned by tests/golden/vae_encode_*.npz."""
+    B, Fr, _ = features.shape
+    mask = lengths_to_mask(lengths, Fr)                                                  # :178
+    x = linear(features, sd["skel_embedding.weight"], sd["skel_embedding.bias"])         # :182
+    tok = sd["global_motion_token"][None].expand(B, -1, -1)                              # :189
+    counts = max_iter_elements(lengths, frame_per_latent)                                # :198
+    dm = count_mask(counts, max_it)
+    aug = torch.cat([dm, dm, mask], dim=1)                                               # :203-209
+    xseq = torch.cat([tok, x], dim=1)
+    xseq = xseq + sd["query_pos_encoder.pe"][:xseq.shape[1], 0][None]                    # :219
+    p = sub(sd, "encoder")
+    nb = (num_layers - 1) // 2
+    xs, h = [], xseq
+    for i in range(nb):                                                                  # cross_attention.py:48-67
+        h = detr_encoder_layer(h, sub(p, f"input_blocks.{i}"), ~aug)
+        xs.append(h)
+    h = detr_encoder_layer(h, sub(p, "middle_block"), ~aug)
+    for i in range(nb):
+        h = linear(torch.cat([h, xs.pop()], dim=-1), p[f"linear_blocks.{i}.weight"], p[f"linear_blocks.{i}.bias"])
+        h = detr_encoder_layer(h, sub(p, f"output_blocks.{i}"), ~aug)
+    h = layer_norm(h, p["norm.weight"], p["norm.bias"])
+    dist = h[:, :2 * max_it].permute(1, 0, 2)                                            # :221
+    mu, logvar = dist[:max_it], dist[max_it:]                                            # :258-259
+    std = logvar.exp().pow(0.5)                                                          # :262
+    latent = (mu + std * eps) * dm.t()[:, :, None].to(mu.dtype)                          # :264-268
+    return mu, std, latent

@@ -44,6 +44,9 @@ def test_weight_tables_match_reference_schema(lib):
     dec = _lib.param_names("decoder")
     assert sorted(dec) == sorted(schema.vae_decode_keys(vs))
     assert len(dec) == 175
+    enc = _lib.param_names("encoder")
+    assert len(enc) == 122 and set(enc) <= set(vs) and "skel_embedding.weight" in enc
+    assert sorted(set(dec) | set(enc)) == sorted(vs)        # decode + encode tables cover all 297 tensors of the VAE
 
 
 def test_workspace_queries(lib):
@@ -91,7 +94,7 @@ def test_product_path_fails_loudly_without_gpu():
     vae = LADiffVae(ABL, **VAE_KW)
     with pytest.raises(_lib.LadiffHipError):
         vae.decode(torch.zeros(5, 2, 256), [60, 60])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(_lib.LadiffHipError):
         vae.encode(torch.zeros(2, 60, 263), [60, 60])
 
 

@@ -129,7 +129,7 @@ def test_decoder_self_attention(lengths):
     qkv = rnd(B * Fr, 768, scale=2.0)
     out = torch.full((B * Fr, 256), float("nan"), device=DEV)
     qd, ld = qkv.to(DEV), torch.tensor(lengths, dtype=torch.int32, device=DEV)
-    _lib.check(lib().ladiff_decoder_self_attention(_lib.ptr(qd), ld.data_ptr(), _lib.ptr(out), B, Fr, _lib.stream_ptr()))
+    _lib.check(lib().ladiff_decoder_self_attention(_lib.ptr(qd), ld.data_ptr(), None, _lib.ptr(out), B, Fr, _lib.stream_ptr()))
     sync()
     got = out.cpu()
     assert torch.isfinite(got).all()
@@ -145,15 +145,46 @@ def test_decoder_self_attention_softmax_extremes():
     qkv[77, 256:512] = 8.0        # ... against one big key -> softmax is one-hot on key 77
     out = torch.empty(B * Fr, 256, device=DEV)
     qd, ld = qkv.to(DEV), torch.tensor([196, 150], dtype=torch.int32, device=DEV)
-    _lib.check(lib().ladiff_decoder_self_attention(_lib.ptr(qd), ld.data_ptr(), _lib.ptr(out), B, Fr, _lib.stream_ptr()))
+    _lib.check(lib().ladiff_decoder_self_attention(_lib.ptr(qd), ld.data_ptr(), None, _lib.ptr(out), B, Fr, _lib.stream_ptr()))
     sync()
     assert (out.cpu().double() - ref_self_attention(qkv, [196, 150], B, Fr)).abs().max().item() < 2e-5
+
+
+def key_bitmap(valid):
+    """bool [B,F] -> int32 tensor [B,8] holding the 256-bit key map (uint32 words, LSB first)."""
+    import numpy as np
+    B, Fr = valid.shape
+    bits = np.zeros((B, 8), dtype=np.uint32)
+    for b in range(B):
+        for k in range(Fr):
+            if valid[b, k]:
+                bits[b, k // 32] |= np.uint32(1 << (k % 32))
+    return torch.from_numpy(bits.view(np.int32).copy())
+
+
+def test_self_attention_arbitrary_key_mask():
+    """Bitmap key masks (LA-VAE encoder: masked latent tokens in the middle of the sequence)."""
+    B, Fr = 3, 206
+    g = torch.Generator().manual_seed(4)
+    valid = torch.rand(B, Fr, generator=g) < 0.6
+    valid[:, 0] = True
+    valid[2, 150:] = False
+    qkv = rnd(B * Fr, 768, scale=2.0)
+    bd = key_bitmap(valid).to(DEV)
+    out = torch.full((B * Fr, 256), float("nan"), device=DEV)
+    qd = qkv.to(DEV)
+    _lib.check(lib().ladiff_decoder_self_attention(_lib.ptr(qd), None, bd.data_ptr(), _lib.ptr(out), B, Fr, _lib.stream_ptr()))
+    sync()
+    q, k, v = qkv.double().view(B, Fr, 3, 4, 64).permute(2, 0, 3, 1, 4)
+    s = ((q * 0.125) @ k.transpose(-1, -2)).masked_fill(~valid[:, None, None, :], float("-inf"))
+    want = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * Fr, 256)
+    assert (out.cpu().double() - want).abs().max().item() < 2e-5
 
 
 def test_decoder_self_attention_rejects_long_sequences():
     x = torch.zeros(300, 768, device=DEV); o = torch.zeros(300, 256, device=DEV)
     l = torch.tensor([300], dtype=torch.int32, device=DEV)
-    assert lib().ladiff_decoder_self_attention(_lib.ptr(x), l.data_ptr(), _lib.ptr(o), 1, 300, _lib.stream_ptr()) == -2
+    assert lib().ladiff_decoder_self_attention(_lib.ptr(x), l.data_ptr(), None, _lib.ptr(o), 1, 300, _lib.stream_ptr()) == -2
 
 
 @pytest.mark.parametrize("T,counts", [(5, [5, 2, 3, 1]), (5, [5] * 3), (3, [1, 3]), (8, [8, 4, 1])])

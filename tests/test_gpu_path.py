@@ -266,3 +266,38 @@ def test_forward_uses_device_feats2joints(denoiser, vae):
                    scheduler=DDIMScheduler(set_alpha_to_one=False, steps_offset=1, **SCHED_KW))
     joints = model({"text": ["walk", "run"], "length": [50, 196]})
     assert [tuple(j.shape) for j in joints] == [(50, 22, 3), (196, 22, 3)] and all(torch.isfinite(j).all() for j in joints)
+
+
+# ---------------------------------------------------------------- LA-VAE encode (next row)
+@pytest.mark.parametrize("name,nfeats,precision", [("vae_encode_humanml", 263, "fp32"), ("vae_encode_kit", 251, "fp32"),
+                                                   ("vae_encode_humanml", 263, "bf16x3")])
+def test_vae_encode_golden(name, nfeats, precision):
+    g = load_golden(name)
+    v = make_vae(nfeats)
+    v.precision = precision
+    lens = g["lengths"].tolist()
+    latent, dist, counts = v.encode(g["features"].to(DEV), lens, eps=g["eps"].to(DEV))
+    assert counts.tolist() == g["counts"].tolist() and latent.shape == g["latent"].shape
+    tol = 1e-4 if precision == "fp32" else 2e-3     # std = exp(logvar / 2) amplifies the bf16x3 product error
+    assert maxdiff(dist.loc, g["mu"]) < tol and maxdiff(dist.scale, g["std"]) < tol * max(1.0, g["std"].max().item())
+    assert maxdiff(latent, g["latent"]) < tol * max(1.0, g["latent"].abs().max().item())
+    for i, c in enumerate(g["counts"].tolist()):
+        assert latent[c:, i].abs().max().item() == 0 if c < latent.shape[0] else True
+
+
+def test_vae_encode_decode_round_trip_full_size():
+    """recon_from_motion shape check at B=128: encode -> decode runs end to end and is deterministic given eps."""
+    v = make_vae(263)
+    gen = torch.Generator().manual_seed(3)
+    lens = syn.mixed_lengths(128)
+    feats = torch.randn(128, 196, 263, generator=gen).to(DEV)
+    eps = torch.randn(5, 128, 256, generator=gen).to(DEV)
+    z1, d1, c1 = v.encode(feats, lens, eps=eps)
+    z2, _, _ = v.encode(feats, lens, eps=eps)
+    assert torch.equal(z1, z2) and torch.isfinite(z1).all() and c1.tolist() == syn.max_iter_elements(lens)
+    rec = v.decode(z1, lens)
+    assert rec.shape == (128, 196, 263) and torch.isfinite(rec).all()
+    # sample independence: a sub-batch alone reproduces its rows
+    idx = [0, 1, 2, 127]
+    zs, _, _ = v.encode(feats[idx][:, :max(lens[i] for i in idx)], [lens[i] for i in idx], eps=eps[:, idx])
+    assert maxdiff(zs, z1[:, idx]) < 1e-4 * max(1.0, z1.abs().max().item())

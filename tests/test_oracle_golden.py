@@ -94,3 +94,11 @@ def test_feats2joints(name):
     g = load_golden(name)
     j = orc.feats2joints(g["feats"], g["mean"], g["std"], int(g["njoints"]))
     assert j.shape == g["joints"].shape and maxdiff(j, g["joints"]) < 1e-6
+
+
+@pytest.mark.parametrize("name,nfeats", [("vae_encode_humanml", 263), ("vae_encode_kit", 251)])
+def test_vae_encode(name, nfeats):
+    """Next row of the scope table, pinned to the reference's LADiffVae.encode."""
+    g = load_golden(name)
+    mu, std, latent = orc.vae_encode(syn.vae_weights(nfeats), g["features"], g["lengths"].tolist(), g["eps"])
+    assert maxdiff(mu, g["mu"]) < TOL and maxdiff(std, g["std"]) < TOL and maxdiff(latent, g["latent"]) < TOL
