@@ -163,7 +163,8 @@ int ladiff_finalize_latents(const float* latents, const int32_t* counts, float* 
 /* ------------------------------------------------------------------ whole reverse loop
  * LADIFF._diffusion_reverse (ladiff.py:333-571, live branch).  `sampler` (from ladiff_sampler_create, or
  * NULL) owns a hipGraph of ONE step (denoiser + guidance + scheduler + step counter) that is captured on
- * first use and replayed n_steps times; it is re-captured when any argument changes. */
+ * first use and replayed n_steps times; it is re-captured when any argument changes.  reuse_time_tables = 1 tells
+ * the call that `ws` still holds the time tables of a previous call with the same weights and schedule. */
 int ladiff_sampler_create(void** sampler);
 int ladiff_sampler_destroy(void* sampler);
 size_t ladiff_reverse_workspace_bytes(int B, int T, int n_steps);
@@ -173,7 +174,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
                              const float* sinusoid /*[n,768]*/, const float* coef /*[n,8]*/,
                              const float* step_noise /*[n,B,T,256] or NULL*/, float guidance_scale,
                              float init_noise_sigma, int B, int T, int n_steps, float* z /*[T,B,256]*/,
-                             void* ws, size_t ws_bytes, ladiff_stream_t stream);
+                             void* ws, size_t ws_bytes, int reuse_time_tables, ladiff_stream_t stream);
 
 /* ------------------------------------------------------------------ LA-VAE decoder (LADiffVae.decode)
  * feats[B,F,C] from z[T,B,256]; frames >= lengths[b] come out zero.  ladiff_vae.py:288-362

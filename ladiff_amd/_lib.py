@@ -60,7 +60,7 @@ _SIGNATURES = {
     "ladiff_reverse_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ladiff_diffusion_reverse": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p,
-                                         c_size_t, c_void_p]),
+                                         c_size_t, c_int, c_void_p]),
     "ladiff_encoder_num_params": (c_int, []),
     "ladiff_encoder_param_name": (c_char_p, [c_int]),
     "ladiff_encoder_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

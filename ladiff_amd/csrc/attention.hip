@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256) void den_self_attn_kernel(const float* __restr
     vv[T + 1] = tk[256 + col];
     int nv = counts ? counts[bg % Bs] : T;
     nv = nv > T ? T : nv;
+    __shared__ __attribute__((aligned(16))) float so[T * D];      // staged outputs for the S-format store
 #pragma unroll
     for (int i = 0; i < T; ++i) {
         float s[T + 2];
@@ -266,8 +267,15 @@ __global__ __launch_bounds__(256) void den_self_attn_kernel(const float* __restr
             l += pv;
             o += pv * vv[j];
         }
-        if (split_out) store_split1(out + ((size_t)b2 * T + i) * D, col, o / l);
+        if (split_out) so[i * D + col] = o / l;
         else out[((size_t)b2 * T + i) * D + col] = o / l;
+    }
+    if (split_out) {      // 16-byte units: 4 consecutive columns -> 8 B of hi + 8 B of lo
+        __syncthreads();
+        for (int u = threadIdx.x; u < T * (D / 4); u += 256) {
+            const int r = u / (D / 4), c4 = (u % (D / 4)) * 4;
+            store_split4(out + ((size_t)b2 * T + r) * D, c4, ld4(so + r * D + c4));
+        }
     }
 }
 

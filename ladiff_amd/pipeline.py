@@ -148,6 +148,7 @@ class LADIFF(nn.Module):
             "step_noise": torch.empty(n_steps, B, T, 256, dtype=torch.float32, device=dev) if need_noise else None,
             "z": torch.empty(T, B, 256, dtype=torch.float32, device=dev),
             "ws": _lib.workspace(wsb, dev), "ws_bytes": wsb,
+            "tables_key": None,      # weights the time tables inside `ws` were built from
         }
         self._plan = plan
         return plan
@@ -200,7 +201,8 @@ class LADIFF(nn.Module):
                 None if self.test_efficiency else plan["counts"].data_ptr(), _lib.ptr(plan["sinus"]),
                 _lib.ptr(plan["coef"]), _lib.ptr(plan["step_noise"]) if need_noise else None, self.guidance_scale,
                 float(sch.init_noise_sigma), B, T, n, _lib.ptr(plan["z"]), _lib.ptr(plan["ws"]), plan["ws_bytes"],
-                run.cuda_stream))
+                1 if plan["tables_key"] == wt.key else 0, run.cuda_stream))
+            plan["tables_key"] = wt.key
         if run is not cur:
             cur.wait_stream(run)
         return plan["z"].clone()
