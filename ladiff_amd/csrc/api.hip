@@ -276,14 +276,25 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
     if (!reuse_time_tables) LADIFF_TRY(denoiser_time_tables(W, sinusoid, n_steps, r.tables, r.fwd, r.fwd_floats, s));
     LADIFF_TRY(denoiser_text_cache(W, text_emb, B2, r.tables, n_steps, r.cache, r.fwd, r.fwd_floats, s));
     LADIFF_TRY(launch_init_latents(init_noise, counts, init_noise_sigma, r.latents, B, T, s));
-    LADIFF_HIP(hipMemsetAsync(r.d_step, 0, sizeof(int32_t), s));
+    LADIFF_HIP(hipMemsetAsync(r.d_step, 0, 2 * sizeof(int32_t), s));      // [0] step index, [1] tail-kernel ticket
 
     Sampler* sp = reinterpret_cast<Sampler*>(sampler);
-    // One step.  The denoiser rows of different samples never interact, so the duplicated batch is cut into `chains`
-    // sample ranges that are captured as parallel branches of the step graph: their fill / MFMA / store phases drift
-    // apart and overlap instead of hitting the memory system in lock-step.
+    // One step = the nine denoiser layers + ONE tail launch (final LayerNorm of both branches, guidance, scheduler step,
+    // next step's network input, step counter).  The network input / last-layer output buffer of the forward workspace
+    // is primed once before the loop.  `chains` > 1 (LADIFF_CHAINS, diagnostic) splits the batch into parallel graph
+    // branches with the un-fused tail; measured: no gain.
+    float *xio = nullptr, *xios = nullptr;
+    den_loop_io(r.fwd, B2 * T, &xio, &xios);
+    if (WSp == nullptr) xios = nullptr;
+    LADIFF_TRY(launch_add_pe(r.latents, W.query_pe, B, 0, B2, T, xio, xios, s));
     auto one_step = [&](hipStream_t st, int chains) -> int {
-        if (chains > 1) LADIFF_HIP(hipEventRecord(sp->fork, st));
+        if (chains <= 1) {
+            LADIFF_TRY(denoiser_forward(W, WSp, r.tables, r.d_step, r.cache, n_steps, r.latents, B, 2, T, counts, r.eps, r.fwd,
+                                        r.fwd_floats, st, 0, B2, 1));
+            return launch_step_tail(xio, xios, W.norm.g, W.norm.b, r.latents, coef, r.d_step, step_noise, W.query_pe,
+                                    guidance_scale, B, T, st);
+        }
+        LADIFF_HIP(hipEventRecord(sp->fork, st));
         const size_t per = r.fwd_floats / chains / 64 * 64;   // >= den_forward_ws_floats(ceil(B2 / chains), T) by carve_reverse
         for (int c = chains - 1; c >= 0; --c) {
             const int lo = (int)((long long)B2 * c / chains), hi = (int)((long long)B2 * (c + 1) / chains);
@@ -297,7 +308,6 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
         LADIFF_TRY(launch_cfg_step(r.eps, r.latents, coef, r.d_step, step_noise, guidance_scale, 1, B, T, st));
         return launch_advance(r.d_step, st);
     };
-
     if (sp == nullptr) {
         for (int i = 0; i < n_steps; ++i) LADIFF_TRY(one_step(s, 1));
     } else {

@@ -166,6 +166,11 @@ int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, const flo
 //   x'          = X3 + out_layers(u)                  N=256                                     :162, :261
 size_t den_forward_ws_floats(int B2, int T) { return (size_t)B2 * T * (16 * D + 3 * D + D + FF + 4 * D); }
 
+void den_loop_io(float* ws, int rows, float** x, float** xs) {
+    *x = ws;                                   // P[0]
+    *xs = ws + (size_t)8 * rows * D;           // Ps[0]: after P[0..3] and SK[0..3]
+}
+
 static KrArgs kr(const float* A, int lda, const float* W, const float* b, float* Y, int ldy, int M, int N, int K, int act = ACT_NONE) {
     KrArgs g;
     g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.bias = b; g.Y = Y; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.act = act;
@@ -174,13 +179,14 @@ static KrArgs kr(const float* A, int lda, const float* W, const float* b, float*
 
 // Processes samples [b_lo, b_lo + b_n) of the duplicated batch of B2 = Bs * dup samples (tables / caches are sized for
 // B2); independent sample ranges can run concurrently on different streams with disjoint workspaces.
+// den_loop_io() exposes the buffer that holds both the network input and the last layer's output (loop_mode).
 //
 // ws != nullptr selects the bf16x3 matrix path: `ws` holds the S-format copies of the weight matrices (same table order
 // as `w`), GEMM operands travel in S-format (every tensor that is both a GEMM operand and a residual is written twice:
 // fp32 for the residual / LayerNorm consumers, S-format for the MFMA), accumulation and everything else stay fp32.
 int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tables, const int32_t* d_step, const float* cache,
                      int n_steps, const float* sample, int Bs, int dup, int T, const int32_t* counts, float* eps, float* ws,
-                     size_t ws_floats, hipStream_t s, int b_lo, int b_n) {
+                     size_t ws_floats, hipStream_t s, int b_lo, int b_n, int loop_mode) {
     const int B2 = Bs * dup;
     if (b_n < 0) { b_lo = 0; b_n = B2; }
     const int M = b_n * T;
@@ -207,7 +213,8 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tabl
     auto gemm = [&](KrArgs g) { g.split = sp ? 1 : 0; return launch_gemm_kr(g, s); };
 
     // x = cat([sample]*dup) + query_pos.pe[:T]        ladiff.py:472-474, ladiff_denoiser.py:251
-    LADIFF_TRY(launch_add_pe(sample, w.query_pe, Bs, b_lo, b_n, T, P[0], Ps[0], s));
+    // loop_mode: the caller's step-tail kernel has already written x into P[0] / Ps[0] and will apply encoder.norm itself
+    if (!loop_mode) LADIFF_TRY(launch_add_pe(sample, w.query_pe, Bs, b_lo, b_n, T, P[0], Ps[0], s));
     const float* cur = P[0]; const float* curs = Ps[0];
     for (int l = 0; l < NL; ++l) {
         const DenLayerW& L = w.layer[l];
@@ -264,6 +271,7 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tabl
         cur = dst; curs = dsts;
     }
     // encoder.norm, then [B2,T,256] out   cross_attention.py:84-85, ladiff_denoiser.py:272,292
+    if (loop_mode) return 0;          // left in P[0] for launch_step_tail
     return launch_layernorm(cur, w.norm.g, w.norm.b, eps, M, s);
 }
 

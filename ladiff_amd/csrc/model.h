@@ -23,7 +23,8 @@ int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, const flo
                         float* ws, size_t ws_floats, hipStream_t s);
 int denoiser_forward(const DenoiserW& w, const DenoiserW* w_split, const float* tables, const int32_t* d_step,
                      const float* cache, int n_steps, const float* sample, int Bs, int dup, int T, const int32_t* counts, float* eps, float* ws,
-                     size_t ws_floats, hipStream_t s, int b_lo = 0, int b_n = -1);
+                     size_t ws_floats, hipStream_t s, int b_lo = 0, int b_n = -1, int loop_mode = 0);
+void den_loop_io(float* ws, int rows, float** x, float** xs);
 
 size_t dec_ws_floats(int B, int F, int T);
 int vae_decode(const DecoderW& w, const DecoderW* w_split, const float* z, const int32_t* lengths, const int32_t* counts, int B, int F, int T,

@@ -342,6 +342,68 @@ int launch_cfg_step(const float* eps, float* lat, const float* coef, const int32
     return 0;
 }
 
+// ---------------------------------------------------------------- fused end of a denoiser step
+// One wave per latent row (b, t): final LayerNorm of both guidance branches (encoder.norm, cross_attention.py:84-85),
+// eps = eps_u + g (eps_c - eps_u) (ladiff.py:487-490), the scheduler step (coefficient row of this step), and the NEXT
+// step's network input x = cat([latents]*2) + query_pos.pe (ladiff.py:472-474, ladiff_denoiser.py:251) written in place
+// over the last layer's output (fp32 + optional S-format twin).  The last workgroup to finish bumps the step counter
+// (every workgroup has read it before taking its ticket), so the whole tail of a step is one launch instead of five.
+__global__ __launch_bounds__(256) void step_tail_kernel(float* __restrict__ x, float* __restrict__ xs, const float* __restrict__ ng,
+                                                        const float* __restrict__ nb, float* __restrict__ lat,
+                                                        const float* __restrict__ coef, int32_t* __restrict__ d_step,
+                                                        const float* __restrict__ noise, const float* __restrict__ pe, float g,
+                                                        int B, int T) {
+    const int step = d_step[0];
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);      // row = b * T + t of the B prompts
+    const int c = (threadIdx.x & 63) * 4;
+    const int M = B * T;
+    if (row < M) {
+        const float* cf = coef + (size_t)step * LADIFF_COEF_STRIDE;
+        const float sa = cf[0], sb = cf[1], kx0 = cf[2], kx = cf[3], ke = cf[4], kn = cf[5];
+        const f32x4 gg = ld4(ng + c), bb = ld4(nb + c);
+        f32x4 eu = ld4(x + (size_t)row * D + c), ec = ld4(x + (size_t)(M + row) * D + c);
+        float mean, rstd;
+        row_stats(eu, mean, rstd);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) eu[i] = (eu[i] - mean) * rstd * gg[i] + bb[i];
+        row_stats(ec, mean, rstd);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ec[i] = (ec[i] - mean) * rstd * gg[i] + bb[i];
+        f32x4 l = ld4(lat + (size_t)row * D + c);
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (noise != nullptr && kn != 0.f) z = ld4(noise + ((size_t)step * M + row) * D + c);
+        const f32x4 p = ld4(pe + (size_t)(row % T) * D + c);
+        f32x4 xn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float e = eu[i] + g * (ec[i] - eu[i]);
+            const float x0 = (l[i] - sb * e) / sa;
+            l[i] = kx0 * x0 + kx * l[i] + ke * e + kn * z[i];
+            xn[i] = l[i] + p[i];
+        }
+        st4(lat + (size_t)row * D + c, l);
+        st4(x + (size_t)row * D + c, xn);
+        st4(x + (size_t)(M + row) * D + c, xn);
+        if (xs != nullptr) {
+            store_split4(xs + (size_t)row * D, c, xn);
+            store_split4(xs + (size_t)(M + row) * D, c, xn);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int ticket = atomicAdd(&d_step[1], 1);
+        if (ticket == (int)gridDim.x - 1) { d_step[1] = 0; d_step[0] = step + 1; }
+    }
+}
+int launch_step_tail(float* x, float* xs, const float* ng, const float* nb, float* lat, const float* coef, int32_t* d_step,
+                     const float* noise, const float* pe, float g, int B, int T, hipStream_t s) {
+    const int M = B * T;
+    hipLaunchKernelGGL(step_tail_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, x, xs, ng, nb, lat, coef,
+                       d_step, noise, pe, g, B, T);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
 __global__ void advance_kernel(int32_t* d_step) { if (threadIdx.x == 0) *d_step += 1; }
 int launch_advance(int32_t* d_step, hipStream_t s) {
     hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, s, d_step);
