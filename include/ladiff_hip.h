@@ -40,7 +40,7 @@ enum {
 };
 
 /* activation codes for ladiff_gemm */
-enum { LADIFF_ACT_NONE = 0, LADIFF_ACT_RELU = 1, LADIFF_ACT_GELU = 2, LADIFF_ACT_SILU = 3 };
+enum { LADIFF_ACT_NONE = 0, LADIFF_ACT_RELU = 1, LADIFF_ACT_GELU = 2, LADIFF_ACT_SILU = 3, LADIFF_ACT_QGELU = 4 /* x*sigmoid(1.702x) */ };
 
 #define LADIFF_ABI_VERSION 1
 #define LADIFF_LATENT_DIM 256     /* model.latent_dim[-1], config_ladiff_humanml3d.yaml:132 */
@@ -51,6 +51,8 @@ enum { LADIFF_ACT_NONE = 0, LADIFF_ACT_RELU = 1, LADIFF_ACT_GELU = 2, LADIFF_ACT
 #define LADIFF_MAX_LATENTS 8      /* MAX_IT <= 8 (shipped: 5, config_ladiff_humanml3d.yaml:58) */
 #define LADIFF_MAX_FRAMES 224     /* frames per motion <= 224 (reference MAX_LEN 196, base.yaml:78) */
 #define LADIFF_COEF_STRIDE 8      /* floats per scheduler-coefficient row */
+#define LADIFF_CLIP_MAX_LAYERS 12  /* CLIP ViT-L/14 text tower: 12 layers, width 768 (= LADIFF_TEXT_DIM), 12 heads, MLP 3072 */
+#define LADIFF_CLIP_MAX_POSITIONS 77
 
 int ladiff_version(void);
 const char* ladiff_error_string(int code);
@@ -195,6 +197,21 @@ size_t ladiff_encoder_workspace_bytes(int B, int F, int T, int C);
 int ladiff_vae_encode(const float* const* w, const float* const* w_split /*or NULL*/, const float* features,
                       const int32_t* lengths, const int32_t* counts, const float* eps, int B, int F, int T, int C,
                       float* mu, float* std, float* latent, void* ws, size_t ws_bytes, ladiff_stream_t stream);
+
+/* ------------------------------------------------------------------ CLIP text encoder (the caller side)
+ * MldTextEncoder.forward, mld_clip.py:51-86, "clip" branch (call sites ladiff.py:258-263, :1119-1141):
+ * text_model.get_text_features(input_ids) of transformers' CLIPModel -> out[B,768] (the reference then unsqueezes to
+ * [B,1,768]).  ids[B,S] int64 token ids as the CLIP tokenizer emits them (padding="max_length", S <= 77; tokenising is
+ * host string work and stays with the caller).  Only the first L <= S positions are evaluated: under the causal mask
+ * the pooled EOS row (argmax of the ids) does not depend on later positions, so any L > max_b argmax(ids[b]) gives the
+ * same result as L = S.  The pointer table lists LADIFF_CLIP_MAX_LAYERS layers; a model with n_layers < 12 fills the
+ * first 5 + 16 * n_layers entries (rest may be NULL).  vocab = rows of the token-embedding table. */
+int ladiff_clip_num_params(void);
+const char* ladiff_clip_param_name(int i);     /* keys of transformers.CLIPModel.state_dict() (text side) */
+size_t ladiff_clip_workspace_bytes(int B, int L);
+int ladiff_clip_text_encode(const float* const* w, const float* const* w_split /*or NULL*/, int n_layers, int vocab,
+                            const int64_t* ids, int B, int S, int L, float* out, void* ws, size_t ws_bytes,
+                            ladiff_stream_t stream);
 
 /* ------------------------------------------------------------------ feats2joints (the step after the path)
  * joints[B,F,njoints,3] = recover_from_ric(feats * std + mean): HumanML3DDataModule.feats2joints

@@ -66,6 +66,11 @@ _SIGNATURES = {
     "ladiff_encoder_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ladiff_vae_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ladiff_clip_num_params": (c_int, []),
+    "ladiff_clip_param_name": (c_char_p, [c_int]),
+    "ladiff_clip_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "ladiff_clip_text_encode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                        c_size_t, c_void_p]),
     "ladiff_feats2joints": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ladiff_decoder_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ladiff_vae_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
@@ -122,8 +127,12 @@ def param_names(kind):
 class WeightTable:
     """Array of device pointers in the order the library expects, built from a state dict."""
 
-    def __init__(self, kind, tensors):
+    def __init__(self, kind, tensors, n_names=None, no_split=()):
         names = param_names(kind)
+        if n_names is not None:      # a prefix of the table (CLIP with fewer than 12 layers); the tail stays NULL
+            names = names[:n_names]
+        self.no_split = set(no_split)
+        self.names = names
         self.tensors = []   # keep the fp32 contiguous GPU tensors alive
         for n in names:
             if n not in tensors:
@@ -132,7 +141,8 @@ class WeightTable:
             if not t.is_cuda:
                 raise LadiffHipError(f"weight {n} is on {t.device}; move the module to the GPU first")
             self.tensors.append(t.to(torch.float32).contiguous())
-        self.array = (c_void_p * len(names))(*[t.data_ptr() for t in self.tensors])
+        self.n_total = len(param_names(kind))
+        self.array = (c_void_p * self.n_total)(*[t.data_ptr() for t in self.tensors])
         self.key = tuple((tensors[n].data_ptr(), tensors[n]._version) for n in names)
         self._split = None
 
@@ -141,14 +151,14 @@ class WeightTable:
         if self._split is None:
             L = lib()
             self.split_tensors = []
-            for t in self.tensors:
-                if t.dim() == 2 and t.shape[1] % 64 == 0:
+            for n, t in zip(self.names, self.tensors):
+                if t.dim() == 2 and t.shape[1] % 64 == 0 and n not in self.no_split:
                     s = torch.empty_like(t)
                     check(L.ladiff_split_rows(t.data_ptr(), s.data_ptr(), t.shape[0], t.shape[1], stream_ptr()))
                 else:
                     s = t
                 self.split_tensors.append(s)
-            self._split = (c_void_p * len(self.tensors))(*[t.data_ptr() for t in self.split_tensors])
+            self._split = (c_void_p * self.n_total)(*[t.data_ptr() for t in self.split_tensors])
         return self._split
 
     @staticmethod

@@ -358,6 +358,33 @@ int ladiff_vae_encode(const float* const* w, const float* const* w_split, const 
                       ws_bytes / sizeof(float), S(stream));
 }
 
+// ------------------------------------------------------------------ CLIP text encoder
+int ladiff_clip_num_params(void) { return CLIP_NPARAMS; }
+const char* ladiff_clip_param_name(int i) {
+    const auto& n = clip_param_names();
+    return (i >= 0 && i < (int)n.size()) ? n[i].c_str() : nullptr;
+}
+size_t ladiff_clip_workspace_bytes(int B, int L) { return clip_ws_floats(B, L) * sizeof(float); }
+
+static bool load_clip(ClipW& dst, const float* const* ptrs, int n_layers) {     // only the first n_layers must be present
+    if (ptrs == nullptr || n_layers < 1 || n_layers > CLIP_MAX_LAYERS) return false;
+    const int n = CLIP_HEAD_NPARAMS + CLIP_LAYER_NPARAMS * n_layers;
+    for (int i = 0; i < n; ++i)
+        if (ptrs[i] == nullptr) return false;
+    std::memset(&dst, 0, sizeof(dst));
+    std::memcpy(&dst, ptrs, n * sizeof(const float*));
+    return true;
+}
+
+int ladiff_clip_text_encode(const float* const* w, const float* const* w_split, int n_layers, int vocab, const int64_t* ids,
+                            int B, int seq, int L, float* out, void* ws, size_t ws_bytes, ladiff_stream_t stream) {
+    ClipW W, WS;
+    LADIFF_CHECK_ARG(load_clip(W, w, n_layers) && ids && out && ws && B >= 0);
+    if (w_split != nullptr) LADIFF_CHECK_ARG(load_clip(WS, w_split, n_layers));
+    return clip_text_encode(W, w_split ? &WS : nullptr, n_layers, vocab, ids, B, seq, L, out, (float*)ws,
+                            ws_bytes / sizeof(float), S(stream));
+}
+
 // ------------------------------------------------------------------ feats2joints (the step after the path)
 int ladiff_feats2joints(const float* feats, const float* mean, const float* std, int B, int F, int C, int njoints,
                         float* joints, ladiff_stream_t stream) {

@@ -18,13 +18,17 @@ constexpr int SA_NKT = SA_FMAX / 32;
 
 // Key validity is either a prefix (keys < lengths[b]) or, when `keybits` is given, an arbitrary 256-bit map per sample
 // (the LA-VAE encoder masks latent tokens in the middle of the sequence, ladiff_vae.py:193-209).
+// `g` describes where the heads live: row stride of the packed qkv, column offsets of the K and V blocks, number of
+// heads, row stride of the output; g.causal adds key <= query (CLIP's text transformer).
+struct AttnGeom { int nheads, ld, koff, voff, out_ld, causal; };
+
 __global__ __launch_bounds__(256) void dec_self_attn_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ lengths,
                                                             const uint32_t* __restrict__ keybits, float* __restrict__ out,
-                                                            int B, int F, int split_out) {
+                                                            int B, int F, int split_out, const AttnGeom g) {
     __shared__ __attribute__((aligned(16))) float Ks[SA_FMAX * DH];   // chunk c of row r at slot c ^ (r & 15)
     __shared__ __attribute__((aligned(16))) float Vs[SA_FMAX * DH];   // plain [key][d]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    const int b = blockIdx.y / g.nheads, h = blockIdx.y % g.nheads;
     int len = F;                                  // keys >= len are never valid
     uint32_t kb[SA_NKT + 1];
     if (keybits != nullptr) {
@@ -36,21 +40,21 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const float* __restr
         }
         len = len > F ? F : len;
     } else {
-        len = lengths[b];
+        len = lengths != nullptr ? lengths[b] : F;
         len = len < 1 ? 1 : (len > F ? F : len);
 #pragma unroll
         for (int i = 0; i < SA_NKT; ++i) kb[i] = len >= 32 * i + 32 ? 0xFFFFFFFFu : (len > 32 * i ? (1u << (len - 32 * i)) - 1u : 0u);
     }
     const int nkt = (len + 31) >> 5;
-    const size_t base = (size_t)b * F * 768 + h * DH;
+    const size_t base = (size_t)b * F * g.ld + h * DH;
 
     for (int id = tid; id < nkt * 32 * 16; id += 256) {
         const int r = id >> 4, c = id & 15;
         f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
         if (r < F) {
-            const float* src = qkv + base + (size_t)r * 768 + c * 4;
-            kk = ld4(src + 256);
-            vv = ld4(src + 512);
+            const float* src = qkv + base + (size_t)r * g.ld + c * 4;
+            kk = ld4(src + g.koff);
+            vv = ld4(src + g.voff);
         }
         st4(Ks + r * DH + ((c ^ (r & 15)) << 2), kk);
         st4(Vs + r * DH + c * 4, vv);
@@ -64,12 +68,12 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const float* __restr
 
     f32x4 qf[8];
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int g8 = 0; g8 < 8; ++g8) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (qrow < F) v = ld4(qkv + base + (size_t)qrow * 768 + g * 8 + h2 * 4);
+        if (qrow < F) v = ld4(qkv + base + (size_t)qrow * g.ld + g8 * 8 + h2 * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= 0.125f;   // q / sqrt(64), exact
-        qf[g] = v;
+        qf[g8] = v;
     }
 
     f32x16 sT[SA_NKT];
@@ -82,15 +86,16 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const float* __restr
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
             const int r = kt * 32 + q;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const f32x4 a = ld4(Ks + r * DH + ((((g << 1) + h2) ^ (r & 15)) << 2));
+            for (int g8 = 0; g8 < 8; ++g8) {
+                const f32x4 a = ld4(Ks + r * DH + ((((g8 << 1) + h2) ^ (r & 15)) << 2));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], qf[g][e], acc, 0, 0, 0);
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], qf[g8][e], acc, 0, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int kin = (i & 3) + 8 * (i >> 2) + 4 * h2;          // key within the tile
-                const float s = ((kb[kt] >> kin) & 1u) ? acc[i] : -INFINITY;
+                const bool ok = ((kb[kt] >> kin) & 1u) && (!g.causal || kt * 32 + kin <= qrow);
+                const float s = ok ? acc[i] : -INFINITY;
                 acc[i] = s;
                 m = fmaxf(m, s);
             }
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const float* __restr
 
     if (qrow < F) {
         const float inv = 1.f / l;
-        float* rowp = out + ((size_t)b * F + qrow) * D;
+        float* rowp = out + ((size_t)b * F + qrow) * g.out_ld;
         const int c0 = h * DH + 4 * h2;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
@@ -150,14 +155,29 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const float* __restr
     }
 }
 
+// generic entry: `nheads` heads of 64, packed rows [q | k | v] of width 3 * 64 * nheads, optional causal mask
+int launch_self_attention(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F, int nheads,
+                          int causal, int split_out, hipStream_t s) {
+    if (F > SA_FMAX || F < 1 || nheads < 1) return LADIFF_ERR_SHAPE;
+    if (B == 0) return 0;
+    const int W = nheads * DH;
+    const AttnGeom g{nheads, 3 * W, W, 2 * W, W, causal};
+    const int nqt = (F + 31) / 32;
+    hipLaunchKernelGGL(dec_self_attn_kernel, dim3((nqt + 3) / 4, B * nheads), dim3(256), 0, s, qkv, lengths, keybits, out, B, F,
+                       split_out, g);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_decoder_self_attention(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
                                   int split_out, hipStream_t s) {
     if (F > SA_FMAX || F < 1) return LADIFF_ERR_SHAPE;
     if (lengths == nullptr && keybits == nullptr) return LADIFF_ERR_ARG;
     if (B == 0) return 0;
+    const AttnGeom g{H, 3 * D, D, 2 * D, D, 0};
     const int nqt = (F + 31) / 32;
     hipLaunchKernelGGL(dec_self_attn_kernel, dim3((nqt + 3) / 4, B * H), dim3(256), 0, s, qkv, lengths, keybits, out, B, F,
-                       split_out);
+                       split_out, g);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }

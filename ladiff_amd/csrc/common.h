@@ -11,6 +11,8 @@ constexpr int D = 256;     // latent / model width      (config_ladiff_humanml3d
 constexpr int H = 4;       // heads                     (configs/modules/denoiser.yaml:7)
 constexpr int DH = 64;     // head dim
 constexpr float LN_EPS = 1e-5f;
+constexpr int CLIP_MAX_LAYERS = LADIFF_CLIP_MAX_LAYERS;
+constexpr int CLIP_MAX_POSITIONS = LADIFF_CLIP_MAX_POSITIONS;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -25,13 +27,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LADIFF_LAUNCH_CHECK() LADIFF_HIP(hipGetLastError())
 
 // ---- activations
-enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SILU = 3 };
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_QGELU = 4 };
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
         case ACT_RELU: return fmaxf(v, 0.f);
         case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));  // exact erf GELU
         case ACT_SILU: return v / (1.f + expf(-v));
+        case ACT_QGELU: return v / (1.f + expf(-1.702f * v));                         // CLIP's quick_gelu: x * sigmoid(1.702 x)
         default: return v;
     }
 }

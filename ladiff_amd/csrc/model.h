@@ -35,4 +35,8 @@ int vae_encode(const EncoderW& w, const EncoderW* w_split, const float* features
                const int32_t* counts, const float* eps, int B, int F, int T, int C, float* mu, float* sd, float* latent, float* ws,
                size_t ws_floats, hipStream_t s);
 
+size_t clip_ws_floats(int B, int L);
+int clip_text_encode(const ClipW& w, const ClipW* w_split, int n_layers, int vocab, const int64_t* ids, int B, int S, int L,
+                     float* out, float* ws, size_t ws_floats, hipStream_t s);
+
 }  // namespace ladiff

@@ -67,12 +67,30 @@ struct EncoderW {                                                    // ladiff_v
     LinearW skel;                                                    // skel_embedding [256, nfeats]
 };
 
+struct ClipLayerW {                                                  // transformers CLIPEncoderLayer (mld_clip.py:29, :76)
+    NormW ln1;
+    LinearW q, k, v, o;
+    NormW ln2;
+    LinearW fc1, fc2;
+};
+
+struct ClipW {                                                       // text side of CLIPModel + text_projection
+    const float* tok;                                                // token_embedding [vocab, 768]
+    const float* pos;                                                // position_embedding [77, 768]
+    NormW final_ln;
+    const float* proj;                                               // text_projection.weight [768, 768], no bias
+    ClipLayerW layer[CLIP_MAX_LAYERS];                               // a shallower model fills a prefix (rest NULL)
+};
+
 constexpr int DEN_NPARAMS = sizeof(DenoiserW) / sizeof(const float*);
 constexpr int DEC_NPARAMS = sizeof(DecoderW) / sizeof(const float*);
 constexpr int ENC_NPARAMS = sizeof(EncoderW) / sizeof(const float*);
+constexpr int CLIP_NPARAMS = sizeof(ClipW) / sizeof(const float*);
+constexpr int CLIP_HEAD_NPARAMS = 5, CLIP_LAYER_NPARAMS = sizeof(ClipLayerW) / sizeof(const float*);
 
 const std::vector<std::string>& denoiser_param_names();
 const std::vector<std::string>& decoder_param_names();
 const std::vector<std::string>& encoder_param_names();
+const std::vector<std::string>& clip_param_names();
 
 }  // namespace ladiff

@@ -127,3 +127,22 @@ def vae_decode_keys(schema):
     """The subset `LADiffVae.decode` reads (ladiff_vae.py:334-356)."""
     return [k for k in schema
             if k.startswith("decoder.") or k.startswith("final_layer.") or k == "query_pos_decoder.pe"]
+
+
+def clip_text_schema(vocab_size=49408, num_layers=12, width=768, max_positions=77):
+    """Text side of transformers' CLIPModel for openai/clip-vit-large-patch14 (loaded by `mld_clip.py:29`), keys as in
+    `CLIPModel.state_dict()`: what `get_text_features` touches (`mld_clip.py:75-76`).  SURVEY.md §8f-1."""
+    s = OrderedDict()
+    s["text_model.embeddings.token_embedding.weight"] = (vocab_size, width)
+    s["text_model.embeddings.position_embedding.weight"] = (max_positions, width)
+    for i in range(num_layers):
+        p = f"text_model.encoder.layers.{i}"
+        for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            _linear(s, f"{p}.self_attn.{n}", width, width)
+        _norm(s, f"{p}.layer_norm1", width)
+        _linear(s, f"{p}.mlp.fc1", 4 * width, width)
+        _linear(s, f"{p}.mlp.fc2", width, 4 * width)
+        _norm(s, f"{p}.layer_norm2", width)
+    _norm(s, "text_model.final_layer_norm", width)
+    s["text_projection.weight"] = (width, width)
+    return s

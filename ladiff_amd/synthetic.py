@@ -32,6 +32,8 @@ def _fill(rs, name, shape):
         return rs.uniform(0.0, 1.0, size=shape)
     if name == "global_motion_token":
         return rs.standard_normal(size=shape)
+    if name.endswith(("token_embedding.weight", "position_embedding.weight")):      # CLIP token / position tables: N(0, 0.02) as transformers initialises them
+        return 0.02 * rs.standard_normal(size=shape)
     if len(shape) >= 2:
         fan_out, fan_in = shape[0], shape[1]
         a = math.sqrt(6.0 / (fan_in + fan_out))
@@ -64,6 +66,23 @@ def denoiser_weights(seed=WEIGHT_SEED, **kw):
 
 def vae_weights(nfeats=263, seed=WEIGHT_SEED + 1, **kw):
     return make_state_dict(_schema.vae_schema(nfeats=nfeats, **kw), seed)
+
+
+def clip_weights(vocab_size=49408, num_layers=12, seed=WEIGHT_SEED + 2):
+    return make_state_dict(_schema.clip_text_schema(vocab_size, num_layers), seed)
+
+
+def clip_token_ids(batch, vocab_size=49408, seq_len=77, max_words=30, seed=TEXT_SEED + 1, empty_first=0):
+    """Token ids shaped like the CLIP tokenizer's output with padding="max_length" (mld_clip.py:54-60):
+    [BOS, w_1..w_n, EOS, EOS-padding...], BOS = vocab-2, EOS = pad = vocab-1 (49406 / 49407 for the real vocabulary).
+    The first `empty_first` rows are the empty prompt "" of the classifier-free branch (ladiff.py:258-262)."""
+    rs = np.random.RandomState(seed)
+    ids = np.full((batch, seq_len), vocab_size - 1, dtype=np.int64)
+    ids[:, 0] = vocab_size - 2
+    for b in range(batch):
+        n = 0 if b < empty_first else int(rs.randint(1, min(max_words, seq_len - 2) + 1))
+        ids[b, 1:1 + n] = rs.randint(0, vocab_size - 2, size=n)
+    return torch.from_numpy(ids)
 
 
 def max_iter_elements(lengths, frame_per_latent=FRAME_PER_LATENT):

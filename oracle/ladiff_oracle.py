@@ -20,6 +20,10 @@ Parity status
   `src/configs/modules/scheduler.yaml:5-14` and `modules_novae/scheduler.yaml:16-29`; only
   known-answer properties (timestep lists, alpha endpoints) are checked.
 
+* The CLIP text tower (`clip_text_features`) lives in the third-party `transformers` package
+  (unpinned, `src/requirements.txt:9`); it is PINNED against transformers 5.15's `CLIPModel.get_text_features`
+  as installed in the build container, loaded with the synthetic weights (`tests/golden/make_golden_clip.py`).
+
 Everything is written batch-first ([B, T, D]); the reference is sequence-first, which only
 changes strides, not arithmetic.  Each function cites the reference lines it follows.
 """
@@ -428,3 +432,34 @@ def vae_encode(sd, features, lengths, eps, max_it=5, frame_per_latent=48, num_la
     std = logvar.exp().pow(0.5)                                                          # :262
     latent = (mu + std * eps) * dm.t()[:, :, None].to(mu.dtype)                          # :264-268
     return mu, std, latent
+
+
+# --------------------------------------------------------------------------- CLIP text tower
+def clip_text_features(sd, input_ids, num_layers=12, num_heads=12):
+    """`MldTextEncoder.forward`, "clip" branch (`mld_clip.py:51-78`): `text_model.get_text_features(input_ids)` with no
+    attention mask -> [B, 768]  (the reference unsqueezes to [B, 1, 768] at `:78`).  Restates transformers'
+    CLIPTextTransformer: token + position embedding, pre-LN layers under a causal mask, quick_gelu MLP, final LayerNorm,
+    the row at argmax(input_ids) (= first EOS with the CLIP vocabulary), text_projection without bias."""
+    B, S = input_ids.shape
+    x = sd["text_model.embeddings.token_embedding.weight"][input_ids] + \
+        sd["text_model.embeddings.position_embedding.weight"][:S]
+    W = x.shape[-1]
+    dh = W // num_heads
+    causal = torch.full((S, S), float("-inf"), dtype=x.dtype).triu(1)
+    for i in range(num_layers):
+        p = f"text_model.encoder.layers.{i}."
+        h = F.layer_norm(x, (W,), sd[p + "layer_norm1.weight"], sd[p + "layer_norm1.bias"], EPS_LN)
+        q = linear(h, sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"]) * dh ** -0.5
+        k = linear(h, sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.k_proj.bias"])
+        v = linear(h, sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.v_proj.bias"])
+        q, k, v = (t.view(B, S, num_heads, dh).transpose(1, 2) for t in (q, k, v))
+        a = torch.softmax(q @ k.transpose(-1, -2) + causal, dim=-1) @ v
+        a = a.transpose(1, 2).reshape(B, S, W)
+        x = x + linear(a, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])
+        h = F.layer_norm(x, (W,), sd[p + "layer_norm2.weight"], sd[p + "layer_norm2.bias"], EPS_LN)
+        h = linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])
+        h = h * torch.sigmoid(1.702 * h)                                           # quick_gelu
+        x = x + linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    x = F.layer_norm(x, (W,), sd["text_model.final_layer_norm.weight"], sd["text_model.final_layer_norm.bias"], EPS_LN)
+    pooled = x[torch.arange(B), input_ids.argmax(dim=-1)]
+    return pooled @ sd["text_projection.weight"].t()

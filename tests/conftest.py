@@ -22,7 +22,7 @@ def pytest_configure(config):
 def load_golden(name):
     import torch
     with np.load(os.path.join(GOLDEN, name + ".npz")) as f:
-        return {k: torch.from_numpy(f[k]) for k in f.files}
+        return {k: (torch.from_numpy(f[k]) if f[k].dtype.kind in "fiub" else f[k]) for k in f.files}
 
 
 @pytest.fixture(scope="session")

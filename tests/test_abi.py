@@ -49,6 +49,15 @@ def test_weight_tables_match_reference_schema(lib):
     assert sorted(set(dec) | set(enc)) == sorted(vs)        # decode + encode tables cover all 297 tensors of the VAE
 
 
+def test_clip_table_matches_transformers_key_names():
+    clip = _lib.param_names("clip")
+    sch = schema.clip_text_schema(49408, 12)
+    assert len(clip) == 197 and sorted(clip) == sorted(sch)
+    assert clip[:5] == ["text_model.embeddings.token_embedding.weight", "text_model.embeddings.position_embedding.weight",
+                        "text_model.final_layer_norm.weight", "text_model.final_layer_norm.bias", "text_projection.weight"]
+    assert sum(int(torch.Size(v).numel()) for v in sch.values()) == 123650304     # CLIPTextModelWithProjection, ViT-L/14
+
+
 def test_workspace_queries(lib):
     assert lib.ladiff_denoiser_tables_floats(50) == 50 * 9 * 1536
     assert lib.ladiff_denoiser_text_cache_floats(256, 50) == 256 * 256 + 9 * 256 * 512 + 9 * 50 * 257 * 256

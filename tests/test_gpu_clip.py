@@ -1,0 +1,95 @@
+"""GPU parity of the CLIP text tower against goldens captured from transformers' CLIPModel
+(tests/golden/make_golden_clip.py) and against the CPU oracle; plus the two exact host-side shortcuts."""
+import pytest
+import torch
+
+from ladiff_amd import synthetic as syn
+from ladiff_amd.text_encoder import MldTextEncoder
+from oracle import ladiff_oracle as orc
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = {"fp32": 5e-5, "bf16x3": 5e-4}     # outputs are O(1..4); bf16x3 keeps 16 significant bits per operand
+
+
+def make_encoder(vocab, layers, precision="fp32", **kw):
+    m = MldTextEncoder(vocab_size=vocab, num_layers=layers, precision=precision, **kw)
+    m.text_model.load_state_dict(syn.clip_weights(vocab, layers), strict=True)
+    return m.to(DEV).eval()
+
+
+def maxdiff(a, b):
+    return (a.double().cpu() - b.double().cpu()).abs().max().item()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("name", ["clip_small", "clip_small_eos", "clip_full"])
+def test_text_features_match_transformers_golden(name, precision):
+    g = load_golden(name)
+    enc = make_encoder(int(g["vocab"]), int(g["layers"]), precision)
+    out = enc.encode_ids(g["ids"])
+    assert out.shape == (g["ids"].shape[0], 768) and out.device.type == "cuda"
+    assert maxdiff(out, g["text_features"]) < TOL[precision]
+
+
+def test_truncation_and_dedup_are_exact():
+    g = load_golden("clip_small")
+    enc = make_encoder(int(g["vocab"]), int(g["layers"]))
+    ids = g["ids"]
+    ids = torch.cat([ids, ids[:2], ids[:1]])                       # duplicates, as the guidance batch has
+    a = enc.encode_ids(ids)                                         # L = last EOS + 1, unique rows only
+    b = enc.encode_ids(ids, full_length=True, dedup=False)          # all 77 positions of every row
+    assert torch.equal(a[:6], a[:6]) and maxdiff(a, b) < 2e-6       # same arithmetic per row; tile shapes may differ
+    assert torch.equal(a[0], a[6]) and torch.equal(a[0], a[8]) and torch.equal(a[1], a[7])
+
+
+def test_guidance_batch_against_oracle():
+    """[""] * B + prompts (ladiff.py:258-262) at a batch the oracle finishes in seconds; 4-layer tower, full vocabulary."""
+    vocab, layers, B = 49408, 4, 24
+    sd = syn.clip_weights(vocab, layers)
+    ids = syn.clip_token_ids(2 * B, vocab, empty_first=B)
+    enc = make_encoder(vocab, layers)
+    out = enc.encode_ids(ids)
+    ref = orc.clip_text_features(sd, ids, layers)
+    assert maxdiff(out, ref) < TOL["fp32"]
+    enc.precision = "bf16x3"
+    assert maxdiff(enc.encode_ids(ids), ref) < TOL["bf16x3"]
+
+
+def test_forward_with_a_tokenizer_callable():
+    """`forward(texts)` follows mld_clip.py:54-78: tokenizer(padding="max_length") -> ids -> [B, 1, 768]."""
+    vocab = 512
+
+    class Tok:                                   # stands in for the CLIP BPE tokenizer (vocabulary files are not offline)
+        model_max_length = 77
+
+        def __call__(self, texts, padding, truncation, max_length, return_tensors):
+            assert padding == "max_length" and truncation and max_length == 77 and return_tensors == "pt"
+            ids = torch.full((len(texts), 77), vocab - 1, dtype=torch.int64)
+            ids[:, 0] = vocab - 2
+            for i, t in enumerate(texts):
+                w = [sum(map(ord, x)) % (vocab - 2) for x in t.split()][:75]
+                ids[i, 1:1 + len(w)] = torch.tensor(w, dtype=torch.int64)
+            return {"input_ids": ids}
+
+    enc = make_encoder(vocab, 2, tokenizer=Tok())
+    texts = ["", "a person walks forward", "a person jumps", ""]
+    out = enc(texts)
+    assert out.shape == (4, 1, 768)
+    ref = orc.clip_text_features(syn.clip_weights(vocab, 2), Tok()(texts, "max_length", True, 77, "pt")["input_ids"], 2)
+    assert maxdiff(out[:, 0], ref) < TOL["fp32"]
+
+
+def test_errors_mirror_the_reference():
+    with pytest.raises(ValueError, match="not supported"):
+        MldTextEncoder("deps/t5-base")                              # mld_clip.py:47-48
+    with pytest.raises(NotImplementedError):
+        MldTextEncoder("deps/bert-base-uncased")
+    with pytest.raises(NotImplementedError):
+        MldTextEncoder(last_hidden_state=True)
+    enc = make_encoder(512, 2)
+    with pytest.raises(IndexError):
+        enc.encode_ids(torch.full((1, 77), 600))
+    with pytest.raises(Exception, match="tokenizer"):
+        enc(["a person walks"])

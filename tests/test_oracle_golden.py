@@ -102,3 +102,16 @@ def test_vae_encode(name, nfeats):
     g = load_golden(name)
     mu, std, latent = orc.vae_encode(syn.vae_weights(nfeats), g["features"], g["lengths"].tolist(), g["eps"])
     assert maxdiff(mu, g["mu"]) < TOL and maxdiff(std, g["std"]) < TOL and maxdiff(latent, g["latent"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["clip_small", "clip_small_eos", "clip_full"])
+def test_clip_text_features_against_transformers(name):
+    """the restated CLIP text tower vs transformers' CLIPModel.get_text_features (make_golden_clip.py)."""
+    g = load_golden(name)
+    vocab, layers = int(g["vocab"]), int(g["layers"])
+    sd = syn.clip_weights(vocab, layers)
+    ids = g["ids"]
+    out = orc.clip_text_features(sd, ids, layers)
+    assert (out - g["text_features"]).abs().max().item() < 2e-5
+    L = int(ids.argmax(-1).max()) + 1                      # the causal mask makes positions behind the EOS irrelevant
+    assert torch.equal(orc.clip_text_features(sd, ids[:, :L], layers), out)
