@@ -7,5 +7,6 @@ from .feats2joints import Feats2Joints                   # noqa: F401
 from .modules import LADiffDenoiser, LADiffVae          # noqa: F401
 from .pipeline import LADIFF, instantiate_from_config   # noqa: F401
 from .schedulers import DDIMScheduler, DDPMScheduler    # noqa: F401
+from .text_encoder import MldTextEncoder                # noqa: F401
 
-__all__ = ["LADiffDenoiser", "LADiffVae", "LADIFF", "DDIMScheduler", "DDPMScheduler", "instantiate_from_config", "Feats2Joints"]
+__all__ = ["LADiffDenoiser", "LADiffVae", "LADIFF", "DDIMScheduler", "DDPMScheduler", "instantiate_from_config", "Feats2Joints", "MldTextEncoder"]

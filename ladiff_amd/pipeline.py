@@ -27,6 +27,7 @@ _TARGET_ALIASES = {
     # reference dotted paths -> this package (so an unmodified reference YAML also resolves)
     "ladiff.models.architectures.ladiff_denoiser.LADiffDenoiser": "ladiff_amd.modules.LADiffDenoiser",
     "ladiff.models.architectures.ladiff_vae.LADiffVae": "ladiff_amd.modules.LADiffVae",
+    "ladiff.models.architectures.mld_clip.MldTextEncoder": "ladiff_amd.text_encoder.MldTextEncoder",
     "diffusers.DDIMScheduler": "ladiff_amd.schedulers.DDIMScheduler",
     "diffusers.DDPMScheduler": "ladiff_amd.schedulers.DDPMScheduler",
 }
@@ -113,6 +114,8 @@ class LADIFF(nn.Module):
         self._precision = value
         self.denoiser.precision = value
         self.vae.precision = value
+        if hasattr(self.text_encoder, "precision"):
+            self.text_encoder.precision = value
 
     @property
     def device(self):

@@ -93,3 +93,39 @@ def test_errors_mirror_the_reference():
         enc.encode_ids(torch.full((1, 77), 600))
     with pytest.raises(Exception, match="tokenizer"):
         enc(["a person walks"])
+
+
+def test_prompts_to_frames_against_oracle():
+    """Token ids -> CLIP -> 5-step guided DDIM -> LA-VAE frames, everything on the HIP path, against the oracle chain;
+    the text encoder comes in through the reference's YAML target (mld_clip.MldTextEncoder)."""
+    from ladiff_amd import LADIFF
+    from test_abi import ABL, DEN_KW, VAE_KW
+    vocab, layers, lens = 512, 2, [60, 196, 120]
+    cfg = {"model": {"guidance_scale": 7.5,
+                     "text_encoder": {"target": "ladiff.models.architectures.mld_clip.MldTextEncoder",
+                                      "params": {"finetune": False, "last_hidden_state": False, "latent_dim": [1, 256],
+                                                 "vocab_size": vocab, "num_layers": layers}},
+                     "denoiser": {"target": "ladiff.models.architectures.ladiff_denoiser.LADiffDenoiser",
+                                  "params": {**DEN_KW, "ablation": ABL}},
+                     "motion_vae": {"target": "ladiff.models.architectures.ladiff_vae.LADiffVae",
+                                    "params": {**VAE_KW, "ablation": ABL}},
+                     "scheduler": {"target": "diffusers.DDIMScheduler", "num_inference_timesteps": 5, "eta": 0.0,
+                                   "params": dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012,
+                                                  beta_schedule="scaled_linear", clip_sample=False,
+                                                  set_alpha_to_one=False, steps_offset=1)}},
+           "TRAIN": {"ABLATION": {"MAX_IT": 5, "FRAME_PER_LATENT": 48, "TEST_EFFICIENCY": False}}}
+    model = LADIFF(cfg, None)
+    assert isinstance(model.text_encoder, MldTextEncoder)
+    den_sd, vae_sd, clip_sd = syn.denoiser_weights(), syn.vae_weights(263), syn.clip_weights(vocab, layers)
+    model.denoiser.load_state_dict(den_sd)
+    model.vae.load_state_dict(vae_sd)
+    model.text_encoder.text_model.load_state_dict(clip_sd)
+    model.to(DEV).eval()
+    ids = syn.clip_token_ids(2 * len(lens), vocab, empty_first=len(lens))
+    noise = syn.init_noise(lens, seed=41)
+    text = model.text_encoder.encode_ids(ids).unsqueeze(1)
+    z, feats = model.sample(text, lens, init_noise=noise.to(DEV))
+    text_o = orc.clip_text_features(clip_sd, ids, layers).unsqueeze(1)
+    z_o, feats_o = orc.sample_motions(den_sd, vae_sd, text_o, lens, noise, 5, "ddim")
+    assert maxdiff(text, text_o) < TOL["fp32"]
+    assert maxdiff(feats, feats_o) < 1e-3
