@@ -199,7 +199,7 @@ int ladiff_vae_encode(const float* const* w, const float* const* w_split /*or NU
                       float* mu, float* std, float* latent, void* ws, size_t ws_bytes, ladiff_stream_t stream);
 
 /* ------------------------------------------------------------------ CLIP text encoder (the caller side)
- * MldTextEncoder.forward, mld_clip.py:51-86, "clip" branch (call sites ladiff.py:258-263, :1119-1141):
+ * MldTextEncoder.forward, mld_clip.py:51-86, "clip" branch (call sites ladiff.py:265, :1048, :1144):
  * text_model.get_text_features(input_ids) of transformers' CLIPModel -> out[B,768] (the reference then unsqueezes to
  * [B,1,768]).  ids[B,S] int64 token ids as the CLIP tokenizer emits them (padding="max_length", S <= 77; tokenising is
  * host string work and stays with the caller).  Only the first L <= S positions are evaluated: under the causal mask
