@@ -161,19 +161,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs p) {
         const int gc = acol_base + j * MT;
         bcol[j] = (p.bias != nullptr && gc < p.N) ? p.bias[gc] : 0.f;
     }
+    act_dispatch(p.act, [&](auto ACT) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < RM; ++i)
+        for (int i = 0; i < RM; ++i)
 #pragma unroll
-        for (int r = 0; r < MM::REGS; ++r) {
-            const int gr = arow_base + i * MT + MM::acc_row(lane, r);
+            for (int r = 0; r < MM::REGS; ++r) {
+                const int gr = arow_base + i * MT + MM::acc_row(lane, r);
 #pragma unroll
-            for (int j = 0; j < RN; ++j) {
-                const int gc = acol_base + j * MT;
-                float v = act_apply(acc[i][j][r] + bcol[j], p.act);
-                if (p.res != nullptr && gr < p.M && gc < p.N) v += p.res[(size_t)gr * p.ldres + gc];
-                acc[i][j][r] = v;
+                for (int j = 0; j < RN; ++j) {
+                    const int gc = acol_base + j * MT;
+                    float v = act_c<decltype(ACT)::value>(acc[i][j][r] + bcol[j]);
+                    if (p.res != nullptr && gr < p.M && gc < p.N) v += p.res[(size_t)gr * p.ldres + gc];
+                    acc[i][j][r] = v;
+                }
             }
-        }
+    });
 
     if constexpr (LN) {
         // LayerNorm over the 256 columns of each row; the row lives in RN tiles x MT lanes x WN waves.

@@ -140,8 +140,10 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 ct[(wm * TMW + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CLD + wn * TNW + j * 32 + (lane & 31)] = acc[i][j][r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int e = 0; e < EI; ++e) reg_touch(rv[e]);  // landed: keep compiler-made vmcnt(0) out of the store loop
 
     // ---- row-wise: bias, activation, residual, LayerNorm(s), store
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
@@ -151,13 +153,14 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(const GemmArgs p) {
         g1 = ld4(p.ln_g + ec); b1 = ld4(p.ln_b + ec);
         if (p.ln2_g != nullptr) { g2 = ld4(p.ln2_g + ec); b2 = ld4(p.ln2_b + ec); }
     }
+    act_dispatch(p.act, [&](auto ACT) __attribute__((always_inline)) {
 #pragma unroll
     for (int e = 0; e < EI; ++e) {
         const int lr = er + e * RPI;
         const int gr = row0 + lr;
         f32x4 v = ld4(ct + lr * CLD + ec);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = act_apply(v[q] + bv[q], p.act) + rv[e][q];
+        for (int q = 0; q < 4; ++q) v[q] = act_c<decltype(ACT)::value>(v[q] + bv[q]) + rv[e][q];
         if constexpr (LN) {
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(const GemmArgs p) {
         }
         if (gr < p.M) st4(p.Y + (size_t)gr * p.ldy + col0 + ec, v);
     }
+    });
 }
 
 // ---------------------------------------------------------------------------------------------- bf16x3 variant
@@ -302,23 +306,27 @@ __global__ __launch_bounds__(256) void gemm_big_split_kernel(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 ct[(wm * TMW + i * 16 + 4 * (lane >> 4) + r) * CLD + wn * TNW + j * 16 + (lane & 15)] = acc[i][j][r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int e = 0; e < EI; ++e) reg_touch(rv[e]);  // landed: keep compiler-made vmcnt(0) out of the store loop
 
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (p.bias != nullptr) bv = ld4(p.bias + col0 + ec);
+    act_dispatch(p.act, [&](auto ACT) __attribute__((always_inline)) {
 #pragma unroll
-    for (int e = 0; e < EI; ++e) {
-        const int lr = er + e * RPI;
-        const int gr = row0 + lr;
-        f32x4 v = ld4(ct + lr * CLD + ec);
+        for (int e = 0; e < EI; ++e) {
+            const int lr = er + e * RPI;
+            const int gr = row0 + lr;
+            f32x4 v = ld4(ct + lr * CLD + ec);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = act_apply(v[q] + bv[q], p.act) + rv[e][q];
-        if (gr < p.M) {
-            if (p.Y != nullptr) st4(p.Y + (size_t)gr * p.ldy + col0 + ec, v);
-            if (p.Ys != nullptr) store_split4(p.Ys + (size_t)gr * p.ldy, col0 + ec, v);
+            for (int q = 0; q < 4; ++q) v[q] = act_c<decltype(ACT)::value>(v[q] + bv[q]) + rv[e][q];
+            if (gr < p.M) {
+                if (p.Y != nullptr) st4(p.Y + (size_t)gr * p.ldy + col0 + ec, v);
+                if (p.Ys != nullptr) store_split4(p.Ys + (size_t)gr * p.ldy, col0 + ec, v);
+            }
         }
-    }
+    });
 }
 
 template <int BM, int BN, int WM, int WN, bool LN>

@@ -17,6 +17,9 @@
 //
 #include "gemm_kr.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace ladiff {
 
 namespace {
@@ -210,7 +213,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
         STAMP(3);
         wait_vmcnt<PW - 2 * PW_SUB>(); __builtin_amdgcn_s_barrier(); compute_sub(1);
         wait_vmcnt<PW - 3 * PW_SUB>(); __builtin_amdgcn_s_barrier(); compute_sub(2);
-        wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); STAMP(4); compute_sub(3);
+        wait_vmcnt<0>(); __builtin_amdgcn_s_barrier();
+        reg_touch(bv);                              // everything has landed: keep compiler-made vmcnt(0) out of the store loop
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) reg_touch(rv[u]);
+        STAMP(4); compute_sub(3);
         STAMP(5);
     }
 
@@ -227,21 +234,430 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     float* Y = p.Y == nullptr ? nullptr : p.Y + (partial ? (size_t)ks * p.M * p.ldy : 0);
+    act_dispatch(partial ? (int)ACT_NONE : p.act, [&](auto ACT) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const int id = tid + u * NW * 64;
+            const int lr = id / UPR, lc = 4 * (id % UPR);
+            const int gr = row0 + lr, gc = col0 + lc;
+            if (gr >= p.M || gc >= p.N) continue;
+            f32x4 v = ld4(ct + lr * CLD + lc);
+            if (!partial) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_c<decltype(ACT)::value>(v[e] + bv[e]) + rv[u][e];
+            }
+            if (p.Y != nullptr) st4(Y + (size_t)gr * p.ldy + gc, v);
+            if (!partial && p.Ys != nullptr) store_split4(p.Ys + (size_t)gr * p.ldy, gc, v);
+        }
+    });
+    STAMP(6);
+}
+
+// ---- bf16x3 variant with the four waves arranged WN x WK: each wave owns BM x (BN / WN) outputs over 1 / WK of the K
+// slice.  Why: with 16x16x32 MFMAs a wave tile of tm x tn reads (1/tm + 1/tn) * 4 bytes of LDS per MAC, and at the old
+// 80 x 16 wave tile the MFMA phase ran at LDS-read speed (384 KiB per workgroup at 128 B/clk = 3.0 k cycles against
+// 1.9 k cycles of matrix pipe; stamps in profiles/r1/04).  80 x 32 over half the K brings that to 224 KiB.  The K parts
+// are summed in the staged epilogue.  Second change: a wave can only START its MFMAs after it has pushed its LDS-DMA
+// instructions into the texture path, which accepts 64 B/clk per CU (144 KiB = 2.3 k cycles).  The sub-slices needed
+// by phase 0 are therefore issued first and the rest is issued between the MFMA passes of phase 0.
+template <int BM, int BN, int WN, int WK>
+__global__ __launch_bounds__(256) void gemm_ks_kernel(const KrArgs p) {
+    static_assert(WN * WK == 4 && (WK == 1 || WK == 2 || WK == 4), "four waves: WN x WK");
+    constexpr int MT = 16;
+    constexpr int TNW = BN / WN;
+    constexpr int RM = BM / MT, RN = TNW / MT;
+    constexpr int ROWS = BM + BN;
+    constexpr int SUB = ROWS * 64;
+    constexpr int GA = BM / 16, GT = ROWS / 16;    // 16-row groups = DMA pieces per wave per sub-slice
+    constexpr int NPH = 4 / WK;                    // phases: in phase ph, wave (wn, wk) consumes sub-slice ph * WK + wk
+    static_assert(4 * GT <= 63, "vmcnt is 6 bits");
+    static_assert(BM % 16 == 0 && BN % (16 * WN) == 0, "tiles are multiples of 16 rows");
+
+    __shared__ __attribute__((aligned(1024))) float lds[4 * SUB];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WN, wk = wave / WN;
+    const int nbn = (p.N + BN - 1) / BN;
+    const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
+    const int ks = blockIdx.y;
+    const int row0 = bm * BM, col0 = bn * BN;
+    const bool partial = gridDim.y > 1;
+    float* const argY = pin_s(p.Y); float* const argYs = pin_s(p.Ys);      // epilogue arguments, read once (common.h)
+    const int argM = pin_s(p.M), argN = pin_s(p.N), argLdy = pin_s(p.ldy), argAct = pin_s(p.act);
+
+    constexpr int UPR = BN / 4;
+    constexpr int UNITS = BM * UPR / 256;
+    static_assert((BM * UPR) % 256 == 0 && 256 % UPR == 0, "epilogue units must split evenly");
+    constexpr int CLD = BN + 4;
+    constexpr int CPL = BM * CLD;                  // floats per staged K-part plane
+    static_assert(WK * CPL <= 4 * SUB, "C planes must fit in the operand buffers");
+    f32x4 rv[UNITS];
+    const bool has_res = !partial && p.res != nullptr;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (!partial && p.bias != nullptr && col0 + 4 * (tid % UPR) < p.N) bv = ld4(p.bias + col0 + 4 * (tid % UPR));
 #pragma unroll
     for (int u = 0; u < UNITS; ++u) {
-        const int id = tid + u * NW * 64;
-        const int lr = id / UPR, lc = 4 * (id % UPR);
-        const int gr = row0 + lr, gc = col0 + lc;
-        if (gr >= p.M || gc >= p.N) continue;
-        f32x4 v = ld4(ct + lr * CLD + lc);
-        if (!partial) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e] + bv[e], p.act) + rv[u][e];
+        const int id = tid + u * 256;
+        const int gr = row0 + id / UPR, gc = col0 + 4 * (id % UPR);
+        rv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (has_res && gr < p.M && gc < p.N) rv[u] = ld4(p.res + (size_t)gr * p.ldres + gc);
+    }
+
+    const int rl = 4 * wave + (lane >> 4);
+    const int kl = (((lane & 15) ^ rl) << 2) + (ks << 8);
+    const float* abase; int ald;
+    if ((ks << 8) < p.K1) { abase = p.A; ald = p.lda; } else { abase = p.A2 - p.K1; ald = p.lda2; }
+    float* const lbase = lds + 4 * wave * 64;
+    auto issue = [&](int s, int g) __attribute__((always_inline)) {   // s, g are compile-time at every call site
+        const float* src;
+        if (g < GA) {
+            int gr = row0 + 16 * g + rl; gr = gr < p.M ? gr : p.M - 1;
+            src = abase + (size_t)gr * ald + kl + (s << 6);
+        } else {
+            int gc = col0 + 16 * (g - GA) + rl; gc = gc < p.N ? gc : p.N - 1;
+            src = p.W + (size_t)gc * p.ldw + kl + (s << 6);
         }
-        if (p.Y != nullptr) st4(Y + (size_t)gr * p.ldy + gc, v);
-        if (!partial && p.Ys != nullptr) store_split4(p.Ys + (size_t)gr * p.ldy, gc, v);
+        glds16(src, lbase + s * SUB + 16 * g * 64);
+    };
+
+    f32x4 acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fk = lane >> 4;
+    // consume sub-slice (ph * WK + wk); LATER > 0: also issue the DMA pieces of the sub-slices of phase ph + 1,
+    // spread between the MFMA passes so that the matrix pipe and the texture path run side by side
+    auto phase = [&](auto PH) __attribute__((always_inline)) {
+        constexpr int ph = decltype(PH)::value;
+        constexpr bool more = ph + 1 < NPH;
+        constexpr int NISS = more ? WK * GT : 0;   // pieces this wave still has to issue, in 6 slots (2 g x 3 passes)
+        const int s = ph * WK + wk;
+        const float* sa = lds + s * SUB;
+        const float* sb = lds + s * SUB + (BM + wn * TNW) * 64;
+        auto slot = [&](auto Q) __attribute__((always_inline)) {
+            constexpr int q = decltype(Q)::value;
+            constexpr int lo = NISS * q / 6, hi = NISS * (q + 1) / 6;
+#pragma unroll
+            for (int x = lo; x < hi; ++x) issue((ph + 1) * WK + x / GT, x % GT);
+        };
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int ch = 4 * g + fk, cl = 8 + 4 * g + fk;
+            bf16x8 ah[RM], al[RM], bh[RN], bl[RN];
+#pragma unroll
+            for (int i = 0; i < RM; ++i) {
+                const int r = i * MT + frow, x = r & 15;
+                ah[i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((ch ^ x) << 2)));
+                al[i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((cl ^ x) << 2)));
+            }
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {
+                const int r = j * MT + frow, x = (BM + wn * TNW + r) & 15;
+                bh[j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((ch ^ x) << 2)));
+                bl[j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((cl ^ x) << 2)));
+            }
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            if constexpr (more) { __builtin_amdgcn_sched_barrier(0); if (g == 0) slot(std::integral_constant<int, 0>{}); else slot(std::integral_constant<int, 3>{}); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            if constexpr (more) { __builtin_amdgcn_sched_barrier(0); if (g == 0) slot(std::integral_constant<int, 1>{}); else slot(std::integral_constant<int, 4>{}); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            if constexpr (more) { __builtin_amdgcn_sched_barrier(0); if (g == 0) slot(std::integral_constant<int, 2>{}); else slot(std::integral_constant<int, 5>{}); __builtin_amdgcn_sched_barrier(0); }
+        }
+    };
+
+    STAMP(0);
+#pragma unroll
+    for (int x = 0; x < WK * GT; ++x) issue(x / GT, x % GT);          // phase 0's sub-slices
+    STAMP(1);
+    wait_vmcnt<0>(); __builtin_amdgcn_s_barrier();
+    reg_touch(bv);                                  // the residual / bias prefetch is older than the DMA pieces: landed
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) reg_touch(rv[u]);
+    STAMP(2);
+    phase(std::integral_constant<int, 0>{});
+    STAMP(3);
+    if constexpr (NPH > 1) { wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); phase(std::integral_constant<int, 1>{}); }
+    if constexpr (NPH > 2) {
+        wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); phase(std::integral_constant<int, 2>{});
+        wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); phase(std::integral_constant<int, 3>{});
+    }
+    STAMP(4);
+
+    // ------------------------------------------------------------------ epilogue: WK partial planes staged through LDS
+    __builtin_amdgcn_s_barrier();
+    STAMP(5);
+    float* ct = lds + wk * CPL;
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                ct[(i * MT + 4 * (lane >> 4) + r) * CLD + wn * TNW + j * MT + (lane & 15)] = acc[i][j][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    STAMP(7);
+    float* Y = argY == nullptr ? nullptr : argY + (partial ? (size_t)ks * argM * argLdy : 0);
+    // all LDS reads first (one latency), then the arithmetic, then the stores back to back
+    f32x4 cv[UNITS];
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) {
+        const int id = tid + u * 256;
+        cv[u] = ld4(lds + (id / UPR) * CLD + 4 * (id % UPR));
+#pragma unroll
+        for (int k = 1; k < WK; ++k) {
+            const f32x4 t = ld4(lds + k * CPL + (id / UPR) * CLD + 4 * (id % UPR));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cv[u][e] += t[e];
+        }
+    }
+    if (!partial) {
+        act_dispatch(argAct, [&](auto ACT) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < UNITS; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cv[u][e] = act_c<decltype(ACT)::value>(cv[u][e] + bv[e]) + rv[u][e];
+        });
+    }
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) {
+        const int id = tid + u * 256;
+        const int gr = row0 + id / UPR, gc = col0 + 4 * (id % UPR);
+        if (gr < argM && gc < argN) {
+            if (argY != nullptr) st4g(Y + (size_t)gr * argLdy + gc, cv[u]);
+            if (!partial && argYs != nullptr) store_split4g(argYs + (size_t)gr * argLdy, gc, cv[u]);
+        }
     }
     STAMP(6);
+}
+
+template <int BM, int BN, int WN, int WK>
+static int launch_ks_cfg(const KrArgs& a, int splits, hipStream_t s) {
+    const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_ks_kernel<BM, BN, WN, WK>), dim3(nbm * nbn, splits), dim3(256), 0, s, a);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- producer / consumer variant: 8 waves.  Waves 4-7 only issue LDS-DMA (the texture path takes 64 B/clk per CU, so
+// the 144 KiB of an 80x64 workgroup need ~2.3 k cycles of issue slots, and a wave that issues DMA cannot run MFMAs in the
+// meantime); waves 0-3 (one per SIMD, WN x WK as above) only compute.  The producers signal "phase landed" through the
+// workgroup barrier: counted s_waitcnt vmcnt with the next phase's first half already in flight.
+template <int BM, int BN, int WN, int WK>
+__global__ __launch_bounds__(512) void gemm_kp_kernel(const KrArgs p) {
+    static_assert(WN == 2 && WK == 2, "four consumer waves: 2 (N halves) x 2 (K halves); two phases");
+    constexpr int MT = 16;
+    constexpr int TNW = BN / WN;
+    constexpr int RM = BM / MT, RN = TNW / MT;
+    constexpr int ROWS = BM + BN;
+    constexpr int SUB = ROWS * 64;
+    constexpr int GA = BM / 16, GT = ROWS / 16;    // 16-row groups = DMA pieces per producer wave per sub-slice
+    constexpr int NPH = 4 / WK;                    // phases: in phase ph, consumer (wn, wk) reads sub-slice ph * WK + wk
+    constexpr int H1 = (WK + 1) / 2;               // sub-slices of the next phase issued before the current one is signalled
+    static_assert(WK * GT <= 63, "vmcnt is 6 bits");
+    static_assert(BM % 16 == 0 && BN % (16 * WN) == 0, "tiles are multiples of 16 rows");
+
+    __shared__ __attribute__((aligned(1024))) float lds[4 * SUB];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nbn = (p.N + BN - 1) / BN;
+    const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
+    const int ks = blockIdx.y;
+    const int row0 = bm * BM, col0 = bn * BN;
+    const bool partial = gridDim.y > 1;
+    // epilogue: 16-byte units (row, 4 columns) spread over all 512 threads (the producers have nothing else left to do)
+    constexpr int UPR = BN / 4;
+    constexpr int TU = BM * UPR;
+    constexpr int UNITS = (TU + 511) / 512;
+    static_assert(512 % UPR == 0, "all units of a thread share their columns");
+    constexpr int CLD = BN + 4;
+    constexpr int CPL = BM * CLD;
+    // the C planes go into sub-slices 0..WK-1, which nobody reads after phase 0: no barrier between the MFMAs and the staging
+    static_assert(CPL <= SUB, "a C plane must fit in one phase-0 sub-slice");
+    float* const argY = pin_s(p.Y); float* const argYs = pin_s(p.Ys);
+    const int argM = pin_s(p.M), argN = pin_s(p.N), argLdy = pin_s(p.ldy), argAct = pin_s(p.act);
+    f32x4 rv[UNITS];
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    auto prefetch_epilogue = [&]() __attribute__((always_inline)) {
+        const bool has_res = !partial && p.res != nullptr;
+        if (!partial && p.bias != nullptr && col0 + 4 * (tid % UPR) < p.N) bv = ld4(p.bias + col0 + 4 * (tid % UPR));
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const int id = tid + u * 512;
+            const int gr = row0 + id / UPR, gc = col0 + 4 * (id % UPR);
+            rv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (has_res && id < TU && gr < p.M && gc < p.N) rv[u] = ld4(p.res + (size_t)gr * p.ldres + gc);
+        }
+    };
+    auto store_tile = [&]() __attribute__((always_inline)) {          // after the barrier that follows the staging
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        reg_touch(bv);
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) reg_touch(rv[u]);
+        float* Y = argY == nullptr ? nullptr : argY + (partial ? (size_t)ks * argM * argLdy : 0);
+        f32x4 cv[UNITS];
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            int id = tid + u * 512; id = id < TU ? id : 0;
+            cv[u] = ld4(lds + (id / UPR) * CLD + 4 * (id % UPR));
+#pragma unroll
+            for (int k = 1; k < WK; ++k) {
+                const f32x4 t = ld4(lds + k * SUB + (id / UPR) * CLD + 4 * (id % UPR));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cv[u][e] += t[e];
+            }
+        }
+        if (!partial) {
+            act_dispatch(argAct, [&](auto ACT) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < UNITS; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cv[u][e] = act_c<decltype(ACT)::value>(cv[u][e] + bv[e]) + rv[u][e];
+            });
+        }
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            const int id = tid + u * 512;
+            const int gr = row0 + id / UPR, gc = col0 + 4 * (id % UPR);
+            if (id < TU && gr < argM && gc < argN) {
+                if (argY != nullptr) st4g(Y + (size_t)gr * argLdy + gc, cv[u]);
+                if (!partial && argYs != nullptr) store_split4g(argYs + (size_t)gr * argLdy, gc, cv[u]);
+            }
+        }
+    };
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int pw = wave - 4;
+        const int rl = 4 * pw + (lane >> 4);
+        const int kl = (((lane & 15) ^ rl) << 2) + (ks << 8);
+        const float* abase; int ald;
+        if ((ks << 8) < p.K1) { abase = p.A; ald = p.lda; } else { abase = p.A2 - p.K1; ald = p.lda2; }
+        float* const lbase = lds + 4 * pw * 64;
+        auto issue = [&](int s, int g) __attribute__((always_inline)) {
+            const float* src;
+            if (g < GA) {
+                int gr = row0 + 16 * g + rl; gr = gr < p.M ? gr : p.M - 1;
+                src = abase + (size_t)gr * ald + kl + (s << 6);
+            } else {
+                int gc = col0 + 16 * (g - GA) + rl; gc = gc < p.N ? gc : p.N - 1;
+                src = p.W + (size_t)gc * p.ldw + kl + (s << 6);
+            }
+            glds16(src, lbase + s * SUB + 16 * g * 64);
+        };
+        auto issue_subs = [&](int s0, int s1) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = s0; s < s1; ++s)
+#pragma unroll
+                for (int g = 0; g < GT; ++g) issue(s, g);
+        };
+        issue_subs(0, WK);
+        if constexpr (NPH == 1) {
+            wait_vmcnt<0>(); __builtin_amdgcn_s_barrier();
+        } else {
+            issue_subs(WK, WK + H1);
+            wait_vmcnt<H1 * GT>(); __builtin_amdgcn_s_barrier();       // phase 0 landed
+            issue_subs(WK + H1, 2 * WK);
+            wait_vmcnt<0>(); __builtin_amdgcn_s_barrier();             // phase 1 landed
+        }
+        prefetch_epilogue();
+        __builtin_amdgcn_s_barrier();                                  // C planes staged
+        store_tile();
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int wn = wave % WN, wk = wave / WN;
+    prefetch_epilogue();
+
+    f32x4 acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fk = lane >> 4;
+    auto phase = [&](int ph) __attribute__((always_inline)) {
+        const int s = ph * WK + wk;
+        const float* sa = lds + s * SUB;
+        const float* sb = lds + s * SUB + (BM + wn * TNW) * 64;
+        // both 32-k steps' fragments are requested up front: the second set streams in under the first set's MFMAs
+        bf16x8 ah[2][RM], al[2][RM], bh[2][RN], bl[2][RN];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int ch = 4 * g + fk, cl = 8 + 4 * g + fk;
+#pragma unroll
+            for (int i = 0; i < RM; ++i) {
+                const int r = i * MT + frow, x = r & 15;
+                ah[g][i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((ch ^ x) << 2)));
+                al[g][i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((cl ^ x) << 2)));
+            }
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {
+                const int r = j * MT + frow, x = (BM + wn * TNW + r) & 15;
+                bh[g][j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((ch ^ x) << 2)));
+                bl[g][j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((cl ^ x) << 2)));
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[g][i], bh[g][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g][i], bl[g][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g][i], bh[g][j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    STAMP(0);
+    __builtin_amdgcn_s_barrier();                  // phase 0 landed
+    STAMP(1);
+    phase(0);
+    STAMP(2);
+    if constexpr (NPH > 1) { __builtin_amdgcn_s_barrier(); STAMP(3); phase(1); }
+    STAMP(4);
+    float* ct = lds + wk * SUB;                    // phase-0 sub-slice of this K half: free since the phase-1 barrier
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                ct[(i * MT + 4 * (lane >> 4) + r) * CLD + wn * TNW + j * MT + (lane & 15)] = acc[i][j][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    STAMP(5);
+    __builtin_amdgcn_s_barrier();
+    STAMP(7);
+    store_tile();
+    STAMP(6);
+}
+
+template <int BM, int BN, int WN, int WK>
+static int launch_kp_cfg(const KrArgs& a, int splits, hipStream_t s) {
+    const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_kp_kernel<BM, BN, WN, WK>), dim3(nbm * nbn, splits), dim3(512), 0, s, a);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
 }
 
 template <int BM, int BN, int WM, int WN, int MT, bool SPLIT>
@@ -262,6 +678,17 @@ int launch_gemm_kr(const KrArgs& a0, hipStream_t s) {
     const int splits = a.K / 256;
     if (splits > 1 && (a.Y == nullptr || a.Ys != nullptr)) return LADIFF_ERR_ARG;
     if (a.Ys != nullptr && (a.ldy % 64)) return LADIFF_ERR_SHAPE;                         // S-format rows are 64-column blocks
+    static const int ks_layout = [] { const char* e = getenv("LADIFF_KS"); return e ? atoi(e) : 3; }();   // diagnostics: 0 old wave layout, 1-2 K-split waves, 3 producer/consumer
+    if (a.split && ks_layout == 3) {
+        if (splits == 4 || (splits == 1 && a.N >= 1024)) return launch_kp_cfg<80, 64, 2, 2>(a, splits, s);
+        if (splits > 1 || a.N >= 512) return launch_kp_cfg<64, 64, 2, 2>(a, splits, s);
+        return launch_kp_cfg<32, 32, 2, 2>(a, 1, s);
+    }
+    if (a.split && ks_layout) {
+        if (splits == 4 || (splits == 1 && a.N >= 1024)) return launch_ks_cfg<80, 64, 2, 2>(a, splits, s);
+        if (splits > 1 || a.N >= 512) return ks_layout == 2 ? launch_ks_cfg<64, 64, 1, 4>(a, splits, s) : launch_ks_cfg<64, 64, 2, 2>(a, splits, s);
+        return ks_layout == 2 ? launch_ks_cfg<32, 32, 1, 4>(a, 1, s) : launch_ks_cfg<32, 32, 2, 2>(a, 1, s);
+    }
     if (a.split) {
         if (splits == 4 || (splits == 1 && a.N >= 1024)) return launch_kr_cfg<80, 64, 1, 4, 16, true>(a, splits, s);
         if (splits > 1 || a.N >= 512) return launch_kr_cfg<64, 64, 2, 2, 16, true>(a, splits, s);

@@ -22,8 +22,8 @@ for (N, K, ln, SPLIT) in [(1024, 256, 0, 0), (1024, 256, 0, 1), (768, 256, 0, 0)
     t = st.cpu().double()
     nb = int((t[:, 0] > 0).sum())
     t = t[:nb]
-    d = (t[:, 1:7] - t[:, 0:1])
-    names = ["issued", "A landed", "LN done", "last sub starts", "mfma done", "stored"] if ln else ["issued", "sub0 landed", "sub0 done", "last sub starts", "mfma done", "stored"]
+    d = (t[:, 1:8] - t[:, 0:1])
+    names = ["issued", "A landed", "LN done", "last sub starts", "mfma done", "stored", "C staged"] if ln else ["issued", "sub0 landed", "sub0 done", "last sub starts", "mfma done", "stored", "C staged"]
     t0 = t[:, 0].min()
     print(f"N={N} K={K} split={SPLIT}: {nb} workgroups; start spread {((t[:,0]-t0).max()):.0f} cyc; last end {(t[:,6].max()-t0):.0f} cyc (100 MHz s_memtime? see ratio below)")
     print("   median cycles since workgroup start: " + ", ".join(f"{n} {d[:, i].median():.0f}" for i, n in enumerate(names)))
