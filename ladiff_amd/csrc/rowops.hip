@@ -44,56 +44,76 @@ int launch_layernorm(const float* x, const float* g, const float* b, float* y, i
 //   RED_LN      y = LN(x)                                          (norm1, mdiff_transformer.py:63)
 //   RED_LN_ADD  y = LN(x) + c[step][sample | pad]                  (norm2, then the hoisted ca_block: mdiff_transformer.py:66, :246)
 //   RED_LN_MOD  y = SiLU( LN(x) * (1 + scale_step) + shift_step )  (StylizationBlock of the FFN: mdiff_transformer.py:161-162)
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ P, int S, size_t plane,
-                                                          const float* __restrict__ bias, const float* __restrict__ res,
-                                                          int mode, const float* __restrict__ g, const float* __restrict__ b,
-                                                          const float* __restrict__ tab, int tab_step_stride,
-                                                          const int32_t* __restrict__ d_step, const int32_t* __restrict__ counts,
-                                                          int Bs, int T, int pad_row, int b_off, int M, float* __restrict__ out, float* __restrict__ outs) {
+struct RedArgs {
+    const float* P; const float* bias; const float* res; const float* g; const float* b; const float* tab;
+    const int32_t* d_step; const int32_t* counts; float* out; float* outs;
+    size_t plane;
+    int S, mode, tab_step_stride, Bs, T, pad_row, b_off, M;
+};
+
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const RedArgs p) {
+    // all arguments are read in one go and pinned (common.h: pin_s): the kernel is a chain of latencies and a kernarg
+    // re-read next to each use adds an s_load + wait per pointer
+    const float* const P = pin_s(p.P); const float* const bias = pin_s(p.bias); const float* const res = pin_s(p.res);
+    const float* const g = pin_s(p.g); const float* const b = pin_s(p.b); const float* const tab = pin_s(p.tab);
+    const int32_t* const d_step = pin_s(p.d_step); const int32_t* const counts = pin_s(p.counts);
+    float* const out = pin_s(p.out); float* const outs = pin_s(p.outs);
+    const size_t plane = pin_s(p.plane);
+    const int S = pin_s(p.S), mode = pin_s(p.mode), tab_step_stride = pin_s(p.tab_step_stride), Bs = pin_s(p.Bs),
+              T = pin_s(p.T), pad_row = pin_s(p.pad_row), b_off = pin_s(p.b_off), M = pin_s(p.M);
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     const int c = (threadIdx.x & 63) * 4;
     if (row >= M) return;
-    f32x4 v = ld4(P + (size_t)row * D + c);
-    for (int s = 1; s < S; ++s) {
-        const f32x4 t = ld4(P + s * plane + (size_t)row * D + c);
+    // every load that does not depend on another one is issued first (planes, bias, residual, gamma/beta, the step
+    // counter, the sample's latent count), then the table rows that depend on step / count, and only then the
+    // arithmetic: two round trips instead of six
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const float* prow = P + (size_t)row * D + c;
+    f32x4 pl[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += t[i];
-    }
-    if (bias != nullptr) { const f32x4 t = ld4(bias + c);
+    for (int s = 0; s < 4; ++s) pl[s] = s < S ? ld4g(prow + s * plane) : zero;
+    const f32x4 bi = bias != nullptr ? ld4g(bias + c) : zero;
+    const f32x4 rs = res != nullptr ? ld4g(res + (size_t)row * D + c) : zero;
+    f32x4 gg = zero, bb = zero;
+    if (mode != RED_PLAIN) { gg = ld4g(g + c); bb = ld4g(b + c); }
+    const int step = d_step != nullptr ? *(const __attribute__((address_space(1))) int32_t*)d_step : 0;
+    const int b2 = b_off + row / T, tt = row % T;
+    int cnt = 0x7fffffff;
+    if (mode == RED_LN_ADD && counts != nullptr) cnt = *(const __attribute__((address_space(1))) int32_t*)(counts + b2 % Bs);
+    const float* t = tab + (size_t)step * tab_step_stride;
+    f32x4 t0 = zero, t1 = zero;
+    if (mode == RED_LN_ADD) t0 = ld4g(t + (size_t)(tt < cnt ? b2 : pad_row) * D + c);
+    else if (mode == RED_LN_MOD) { t0 = ld4g(t + c); t1 = ld4g(t + 256 + c); }
+
+    f32x4 v;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += t[i]; }
-    if (res != nullptr) { const f32x4 t = ld4(res + (size_t)row * D + c);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += t[i]; }
+    for (int i = 0; i < 4; ++i) v[i] = ((pl[0][i] + pl[1][i]) + pl[2][i]) + pl[3][i] + bi[i] + rs[i];
     if (mode != RED_PLAIN) {
         float mean, rstd;
         row_stats(v, mean, rstd);
-        const f32x4 gg = ld4(g + c), bb = ld4(b + c);
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i];
-        const float* t = tab + (size_t)(d_step ? *d_step : 0) * tab_step_stride;
-        if (mode == RED_LN) {
-        } else if (mode == RED_LN_ADD) {
-            const int b2 = b_off + row / T, tt = row % T;
-            const bool valid = counts == nullptr || tt < counts[b2 % Bs];
-            const f32x4 cc = ld4(t + (size_t)(valid ? b2 : pad_row) * D + c);
+        if (mode == RED_LN_ADD) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] += cc[i];
-        } else {
-            const f32x4 sc = ld4(t + c), sh = ld4(t + 256 + c);
+            for (int i = 0; i < 4; ++i) v[i] += t0[i];
+        } else if (mode == RED_LN_MOD) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = silu(v[i] * (1.f + sc[i]) + sh[i]);
+            for (int i = 0; i < 4; ++i) v[i] = silu(v[i] * (1.f + t0[i]) + t1[i]);
         }
     }
-    if (out != nullptr) st4(out + (size_t)row * D + c, v);
-    if (outs != nullptr) store_split4(outs + (size_t)row * D, c, v);
+    if (out != nullptr) st4g(out + (size_t)row * D + c, v);
+    if (outs != nullptr) store_split4g(outs + (size_t)row * D, c, v);
 }
 
 int launch_reduce_rows(const float* P, int S, int M, const float* bias, const float* res, int mode, const float* g,
                        const float* b, const float* tab, int tab_step_stride, const int32_t* d_step,
                        const int32_t* counts, int Bs, int T, int pad_row, int b_off, float* out, float* outs, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, P, S,
-                       (size_t)M * D, bias, res, mode, g, b, tab, tab_step_stride, d_step, counts, Bs, T, pad_row, b_off, M, out, outs);
+    if (S < 1 || S > 4) return LADIFF_ERR_SHAPE;       // split-K planes: K / 256 <= 4
+    RedArgs a;
+    a.P = P; a.bias = bias; a.res = res; a.g = g; a.b = b; a.tab = tab; a.d_step = d_step; a.counts = counts; a.out = out;
+    a.outs = outs; a.plane = (size_t)M * D; a.S = S; a.mode = mode; a.tab_step_stride = tab_step_stride; a.Bs = Bs; a.T = T;
+    a.pad_row = pad_row; a.b_off = b_off; a.M = M;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, a);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
