@@ -67,7 +67,7 @@ def build_pipe(dev, batch):
 
 
 def dominant_kernel_roofline(dev, stream, precision, launches=400):
-    """Live HIP-event timing of the kernel that dominates the pass (profiles/r1: gemm_kr_kernel<80,64,...>, ~40 % of the
+    """Live HIP-event timing of the kernel that dominates the pass (profiles/r1: gemm_kp_kernel<80,64,2,2> / gemm_kr_kernel<80,64,...>, ~36-40 % of the
     device time): the denoiser's 256->1024 linear (ffn.linear1, GELU) at M = 2*128*5 rows, launched back to back on the
     bench stream, in the arithmetic of the timed mode."""
     from ladiff_amd import _lib
@@ -96,7 +96,7 @@ def dominant_kernel_roofline(dev, stream, precision, launches=400):
     flops = 2.0 * M * N * K
     peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
     mfma_flops = flops * (3 if split else 1)
-    return {"name": f"gemm_kr_kernel<80,64,1,4,16,{'true' if split else 'false'}> (ffn.linear1: M=1280, N=1024, K=256, GELU)",
+    return {"name": ("gemm_kp_kernel<80,64,2,2>" if split else "gemm_kr_kernel<80,64,1,4,16>") + " (ffn.linear1: M=1280, N=1024, K=256, GELU)",
             "flops_per_launch": flops, "mfma_flops_per_launch": mfma_flops, "us_per_launch": round(us, 2),
             "achieved": round(flops / us / 1e6, 2), "unit": "TFLOP/s", "peak": peak,
             "frac": round(flops / us / 1e6 / peak, 4), "mfma_frac": round(mfma_flops / us / 1e6 / peak, 4),

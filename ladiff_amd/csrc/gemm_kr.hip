@@ -17,7 +17,6 @@
 //
 #include "gemm_kr.h"
 
-#include <cstdlib>
 #include <type_traits>
 
 namespace ladiff {
@@ -65,10 +64,9 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 
 }  // namespace
 
-// SPLIT: operands are S-format rows (common.h); every product runs as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16.
-template <int BM, int BN, int WM, int WN, int MT, bool SPLIT>
+// fp32 mode (fp32-input MFMA); the bf16x3 mode has its own kernel below.
+template <int BM, int BN, int WM, int WN, int MT>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
-    static_assert(!SPLIT || MT == 16, "split products use the 16x16x32 bf16 MFMA");
     typedef Mf<MT> MM;
     typedef typename MM::Acc Acc;
     constexpr int NW = WM * WN;
@@ -150,55 +148,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
     auto compute_sub = [&](int s) __attribute__((always_inline)) {
         const float* sa = lds + s * SUB + (wm * TMW) * 64;
         const float* sb = lds + s * SUB + (BM + wn * TNW) * 64;
-        if constexpr (SPLIT) {
-            // sub-slice s = 64 k: 16-byte slots 0-7 hold hi (8 bf16 each), slots 8-15 hold lo.  One MFMA covers 32 k:
-            // lane (row = l & 15, kb = l >> 4) feeds k = 32 g + 8 kb .. + 7, i.e. slot 4 g + kb (hi) and 8 + 4 g + kb (lo).
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int ch = 4 * g + fk, cl = 8 + 4 * g + fk;
-                bf16x8 ah[RM], al[RM], bh[RN], bl[RN];
+        for (int g = 0; g < 64 / MM::KG; ++g) {
+            const int c = g * (MM::KG / 4) + fk;
+            f32x4 fa[RM], fb[RN];
 #pragma unroll
-                for (int i = 0; i < RM; ++i) {
-                    const int r = i * MT + frow, x = (wm * TMW + r) & 15;
-                    ah[i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((ch ^ x) << 2)));
-                    al[i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((cl ^ x) << 2)));
-                }
+            for (int i = 0; i < RM; ++i) { const int r = i * MT + frow; fa[i] = ld4(sa + r * 64 + ((c ^ ((wm * TMW + r) & 15)) << 2)); }
 #pragma unroll
-                for (int j = 0; j < RN; ++j) {
-                    const int r = j * MT + frow, x = (BM + wn * TNW + r) & 15;
-                    bh[j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((ch ^ x) << 2)));
-                    bl[j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((cl ^ x) << 2)));
-                }
-                // three passes over the tile grid: consecutive MFMAs hit different accumulators (no dependent stalls)
+            for (int j = 0; j < RN; ++j) { const int r = j * MT + frow; fb[j] = ld4(sb + r * 64 + ((c ^ ((BM + wn * TNW + r) & 15)) << 2)); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < RM; ++i)
 #pragma unroll
-                    for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < RM; ++i)
-#pragma unroll
-                    for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < RM; ++i)
-#pragma unroll
-                    for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int g = 0; g < 64 / MM::KG; ++g) {
-                const int c = g * (MM::KG / 4) + fk;
-                f32x4 fa[RM], fb[RN];
-#pragma unroll
-                for (int i = 0; i < RM; ++i) { const int r = i * MT + frow; fa[i] = ld4(sa + r * 64 + ((c ^ ((wm * TMW + r) & 15)) << 2)); }
-#pragma unroll
-                for (int j = 0; j < RN; ++j) { const int r = j * MT + frow; fb[j] = ld4(sb + r * 64 + ((c ^ ((BM + wn * TNW + r) & 15)) << 2)); }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int i = 0; i < RM; ++i)
-#pragma unroll
-                        for (int j = 0; j < RN; ++j) acc[i][j] = MM::mma(fa[i][e], fb[j][e], acc[i][j]);
-            }
+                    for (int j = 0; j < RN; ++j) acc[i][j] = MM::mma(fa[i][e], fb[j][e], acc[i][j]);
         }
     };
 
@@ -253,208 +216,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
     STAMP(6);
 }
 
-// ---- bf16x3 variant with the four waves arranged WN x WK: each wave owns BM x (BN / WN) outputs over 1 / WK of the K
-// slice.  Why: with 16x16x32 MFMAs a wave tile of tm x tn reads (1/tm + 1/tn) * 4 bytes of LDS per MAC, and at the old
-// 80 x 16 wave tile the MFMA phase ran at LDS-read speed (384 KiB per workgroup at 128 B/clk = 3.0 k cycles against
-// 1.9 k cycles of matrix pipe; stamps in profiles/r1/04).  80 x 32 over half the K brings that to 224 KiB.  The K parts
-// are summed in the staged epilogue.  Second change: a wave can only START its MFMAs after it has pushed its LDS-DMA
-// instructions into the texture path, which accepts 64 B/clk per CU (144 KiB = 2.3 k cycles).  The sub-slices needed
-// by phase 0 are therefore issued first and the rest is issued between the MFMA passes of phase 0.
-template <int BM, int BN, int WN, int WK>
-__global__ __launch_bounds__(256) void gemm_ks_kernel(const KrArgs p) {
-    static_assert(WN * WK == 4 && (WK == 1 || WK == 2 || WK == 4), "four waves: WN x WK");
-    constexpr int MT = 16;
-    constexpr int TNW = BN / WN;
-    constexpr int RM = BM / MT, RN = TNW / MT;
-    constexpr int ROWS = BM + BN;
-    constexpr int SUB = ROWS * 64;
-    constexpr int GA = BM / 16, GT = ROWS / 16;    // 16-row groups = DMA pieces per wave per sub-slice
-    constexpr int NPH = 4 / WK;                    // phases: in phase ph, wave (wn, wk) consumes sub-slice ph * WK + wk
-    static_assert(4 * GT <= 63, "vmcnt is 6 bits");
-    static_assert(BM % 16 == 0 && BN % (16 * WN) == 0, "tiles are multiples of 16 rows");
-
-    __shared__ __attribute__((aligned(1024))) float lds[4 * SUB];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave % WN, wk = wave / WN;
-    const int nbn = (p.N + BN - 1) / BN;
-    const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
-    const int ks = blockIdx.y;
-    const int row0 = bm * BM, col0 = bn * BN;
-    const bool partial = gridDim.y > 1;
-    float* const argY = pin_s(p.Y); float* const argYs = pin_s(p.Ys);      // epilogue arguments, read once (common.h)
-    const int argM = pin_s(p.M), argN = pin_s(p.N), argLdy = pin_s(p.ldy), argAct = pin_s(p.act);
-
-    constexpr int UPR = BN / 4;
-    constexpr int UNITS = BM * UPR / 256;
-    static_assert((BM * UPR) % 256 == 0 && 256 % UPR == 0, "epilogue units must split evenly");
-    constexpr int CLD = BN + 4;
-    constexpr int CPL = BM * CLD;                  // floats per staged K-part plane
-    static_assert(WK * CPL <= 4 * SUB, "C planes must fit in the operand buffers");
-    f32x4 rv[UNITS];
-    const bool has_res = !partial && p.res != nullptr;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (!partial && p.bias != nullptr && col0 + 4 * (tid % UPR) < p.N) bv = ld4(p.bias + col0 + 4 * (tid % UPR));
-#pragma unroll
-    for (int u = 0; u < UNITS; ++u) {
-        const int id = tid + u * 256;
-        const int gr = row0 + id / UPR, gc = col0 + 4 * (id % UPR);
-        rv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (has_res && gr < p.M && gc < p.N) rv[u] = ld4(p.res + (size_t)gr * p.ldres + gc);
-    }
-
-    const int rl = 4 * wave + (lane >> 4);
-    const int kl = (((lane & 15) ^ rl) << 2) + (ks << 8);
-    const float* abase; int ald;
-    if ((ks << 8) < p.K1) { abase = p.A; ald = p.lda; } else { abase = p.A2 - p.K1; ald = p.lda2; }
-    float* const lbase = lds + 4 * wave * 64;
-    auto issue = [&](int s, int g) __attribute__((always_inline)) {   // s, g are compile-time at every call site
-        const float* src;
-        if (g < GA) {
-            int gr = row0 + 16 * g + rl; gr = gr < p.M ? gr : p.M - 1;
-            src = abase + (size_t)gr * ald + kl + (s << 6);
-        } else {
-            int gc = col0 + 16 * (g - GA) + rl; gc = gc < p.N ? gc : p.N - 1;
-            src = p.W + (size_t)gc * p.ldw + kl + (s << 6);
-        }
-        glds16(src, lbase + s * SUB + 16 * g * 64);
-    };
-
-    f32x4 acc[RM][RN];
-#pragma unroll
-    for (int i = 0; i < RM; ++i)
-#pragma unroll
-        for (int j = 0; j < RN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int frow = lane & 15, fk = lane >> 4;
-    // consume sub-slice (ph * WK + wk); LATER > 0: also issue the DMA pieces of the sub-slices of phase ph + 1,
-    // spread between the MFMA passes so that the matrix pipe and the texture path run side by side
-    auto phase = [&](auto PH) __attribute__((always_inline)) {
-        constexpr int ph = decltype(PH)::value;
-        constexpr bool more = ph + 1 < NPH;
-        constexpr int NISS = more ? WK * GT : 0;   // pieces this wave still has to issue, in 6 slots (2 g x 3 passes)
-        const int s = ph * WK + wk;
-        const float* sa = lds + s * SUB;
-        const float* sb = lds + s * SUB + (BM + wn * TNW) * 64;
-        auto slot = [&](auto Q) __attribute__((always_inline)) {
-            constexpr int q = decltype(Q)::value;
-            constexpr int lo = NISS * q / 6, hi = NISS * (q + 1) / 6;
-#pragma unroll
-            for (int x = lo; x < hi; ++x) issue((ph + 1) * WK + x / GT, x % GT);
-        };
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int ch = 4 * g + fk, cl = 8 + 4 * g + fk;
-            bf16x8 ah[RM], al[RM], bh[RN], bl[RN];
-#pragma unroll
-            for (int i = 0; i < RM; ++i) {
-                const int r = i * MT + frow, x = r & 15;
-                ah[i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((ch ^ x) << 2)));
-                al[i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((cl ^ x) << 2)));
-            }
-#pragma unroll
-            for (int j = 0; j < RN; ++j) {
-                const int r = j * MT + frow, x = (BM + wn * TNW + r) & 15;
-                bh[j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((ch ^ x) << 2)));
-                bl[j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((cl ^ x) << 2)));
-            }
-#pragma unroll
-            for (int i = 0; i < RM; ++i)
-#pragma unroll
-                for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            if constexpr (more) { __builtin_amdgcn_sched_barrier(0); if (g == 0) slot(std::integral_constant<int, 0>{}); else slot(std::integral_constant<int, 3>{}); __builtin_amdgcn_sched_barrier(0); }
-#pragma unroll
-            for (int i = 0; i < RM; ++i)
-#pragma unroll
-                for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-            if constexpr (more) { __builtin_amdgcn_sched_barrier(0); if (g == 0) slot(std::integral_constant<int, 1>{}); else slot(std::integral_constant<int, 4>{}); __builtin_amdgcn_sched_barrier(0); }
-#pragma unroll
-            for (int i = 0; i < RM; ++i)
-#pragma unroll
-                for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-            if constexpr (more) { __builtin_amdgcn_sched_barrier(0); if (g == 0) slot(std::integral_constant<int, 2>{}); else slot(std::integral_constant<int, 5>{}); __builtin_amdgcn_sched_barrier(0); }
-        }
-    };
-
-    STAMP(0);
-#pragma unroll
-    for (int x = 0; x < WK * GT; ++x) issue(x / GT, x % GT);          // phase 0's sub-slices
-    STAMP(1);
-    wait_vmcnt<0>(); __builtin_amdgcn_s_barrier();
-    reg_touch(bv);                                  // the residual / bias prefetch is older than the DMA pieces: landed
-#pragma unroll
-    for (int u = 0; u < UNITS; ++u) reg_touch(rv[u]);
-    STAMP(2);
-    phase(std::integral_constant<int, 0>{});
-    STAMP(3);
-    if constexpr (NPH > 1) { wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); phase(std::integral_constant<int, 1>{}); }
-    if constexpr (NPH > 2) {
-        wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); phase(std::integral_constant<int, 2>{});
-        wait_vmcnt<0>(); __builtin_amdgcn_s_barrier(); phase(std::integral_constant<int, 3>{});
-    }
-    STAMP(4);
-
-    // ------------------------------------------------------------------ epilogue: WK partial planes staged through LDS
-    __builtin_amdgcn_s_barrier();
-    STAMP(5);
-    float* ct = lds + wk * CPL;
-#pragma unroll
-    for (int i = 0; i < RM; ++i)
-#pragma unroll
-        for (int j = 0; j < RN; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                ct[(i * MT + 4 * (lane >> 4) + r) * CLD + wn * TNW + j * MT + (lane & 15)] = acc[i][j][r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    STAMP(7);
-    float* Y = argY == nullptr ? nullptr : argY + (partial ? (size_t)ks * argM * argLdy : 0);
-    // all LDS reads first (one latency), then the arithmetic, then the stores back to back
-    f32x4 cv[UNITS];
-#pragma unroll
-    for (int u = 0; u < UNITS; ++u) {
-        const int id = tid + u * 256;
-        cv[u] = ld4(lds + (id / UPR) * CLD + 4 * (id % UPR));
-#pragma unroll
-        for (int k = 1; k < WK; ++k) {
-            const f32x4 t = ld4(lds + k * CPL + (id / UPR) * CLD + 4 * (id % UPR));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) cv[u][e] += t[e];
-        }
-    }
-    if (!partial) {
-        act_dispatch(argAct, [&](auto ACT) __attribute__((always_inline)) {
-#pragma unroll
-            for (int u = 0; u < UNITS; ++u)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) cv[u][e] = act_c<decltype(ACT)::value>(cv[u][e] + bv[e]) + rv[u][e];
-        });
-    }
-#pragma unroll
-    for (int u = 0; u < UNITS; ++u) {
-        const int id = tid + u * 256;
-        const int gr = row0 + id / UPR, gc = col0 + 4 * (id % UPR);
-        if (gr < argM && gc < argN) {
-            if (argY != nullptr) st4g(Y + (size_t)gr * argLdy + gc, cv[u]);
-            if (!partial && argYs != nullptr) store_split4g(argYs + (size_t)gr * argLdy, gc, cv[u]);
-        }
-    }
-    STAMP(6);
-}
-
-template <int BM, int BN, int WN, int WK>
-static int launch_ks_cfg(const KrArgs& a, int splits, hipStream_t s) {
-    const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_ks_kernel<BM, BN, WN, WK>), dim3(nbm * nbn, splits), dim3(256), 0, s, a);
-    LADIFF_LAUNCH_CHECK();
-    return 0;
-}
-
-// ---- producer / consumer variant: 8 waves.  Waves 4-7 only issue LDS-DMA (the texture path takes 64 B/clk per CU, so
-// the 144 KiB of an 80x64 workgroup need ~2.3 k cycles of issue slots, and a wave that issues DMA cannot run MFMAs in the
-// meantime); waves 0-3 (one per SIMD, WN x WK as above) only compute.  The producers signal "phase landed" through the
-// workgroup barrier: counted s_waitcnt vmcnt with the next phase's first half already in flight.
+// ---- bf16x3 kernel: producer / consumer, 8 waves.  Waves 4-7 only issue LDS-DMA: the texture path takes 64 B/clk per
+// CU, so the 144 KiB of an 80x64 workgroup need ~2.3 k cycles of issue slots, and a wave that is issuing DMA cannot run
+// MFMAs in the meantime.  Waves 0-3 (one per SIMD) only compute, arranged WN x WK: each owns BM x (BN / WN) outputs over
+// 1 / WK of the K slice - with 16x16x32 MFMAs a wave tile of tm x tn reads (1/tm + 1/tn) * 4 bytes of LDS per MAC, and an
+// 80 x 16 wave tile (four waves side by side) ran at LDS-read speed, not at matrix-pipe speed.  The K parts are summed in
+// the staged epilogue.  The producers signal "phase landed" through the workgroup barrier: counted s_waitcnt vmcnt with
+// the next phase's first half already in flight.  Stamps (profiles/r1/06): stores issued at 6.9 k cycles after
+// workgroup start, 11.7 k for the previous all-waves-do-everything kernel.
 template <int BM, int BN, int WN, int WK>
 __global__ __launch_bounds__(512) void gemm_kp_kernel(const KrArgs p) {
     static_assert(WN == 2 && WK == 2, "four consumer waves: 2 (N halves) x 2 (K halves); two phases");
@@ -660,10 +429,10 @@ static int launch_kp_cfg(const KrArgs& a, int splits, hipStream_t s) {
     return 0;
 }
 
-template <int BM, int BN, int WM, int WN, int MT, bool SPLIT>
+template <int BM, int BN, int WM, int WN, int MT>
 static int launch_kr_cfg(const KrArgs& a, int splits, hipStream_t s) {
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_kr_kernel<BM, BN, WM, WN, MT, SPLIT>), dim3(nbm * nbn, splits), dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((gemm_kr_kernel<BM, BN, WM, WN, MT>), dim3(nbm * nbn, splits), dim3(WM * WN * 64), 0, s, a);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
@@ -678,29 +447,18 @@ int launch_gemm_kr(const KrArgs& a0, hipStream_t s) {
     const int splits = a.K / 256;
     if (splits > 1 && (a.Y == nullptr || a.Ys != nullptr)) return LADIFF_ERR_ARG;
     if (a.Ys != nullptr && (a.ldy % 64)) return LADIFF_ERR_SHAPE;                         // S-format rows are 64-column blocks
-    static const int ks_layout = [] { const char* e = getenv("LADIFF_KS"); return e ? atoi(e) : 3; }();   // diagnostics: 0 old wave layout, 1-2 K-split waves, 3 producer/consumer
-    if (a.split && ks_layout == 3) {
+    if (a.split) {
         if (splits == 4 || (splits == 1 && a.N >= 1024)) return launch_kp_cfg<80, 64, 2, 2>(a, splits, s);
         if (splits > 1 || a.N >= 512) return launch_kp_cfg<64, 64, 2, 2>(a, splits, s);
         return launch_kp_cfg<32, 32, 2, 2>(a, 1, s);
     }
-    if (a.split && ks_layout) {
-        if (splits == 4 || (splits == 1 && a.N >= 1024)) return launch_ks_cfg<80, 64, 2, 2>(a, splits, s);
-        if (splits > 1 || a.N >= 512) return ks_layout == 2 ? launch_ks_cfg<64, 64, 1, 4>(a, splits, s) : launch_ks_cfg<64, 64, 2, 2>(a, splits, s);
-        return ks_layout == 2 ? launch_ks_cfg<32, 32, 1, 4>(a, 1, s) : launch_ks_cfg<32, 32, 2, 2>(a, 1, s);
-    }
-    if (a.split) {
-        if (splits == 4 || (splits == 1 && a.N >= 1024)) return launch_kr_cfg<80, 64, 1, 4, 16, true>(a, splits, s);
-        if (splits > 1 || a.N >= 512) return launch_kr_cfg<64, 64, 2, 2, 16, true>(a, splits, s);
-        return launch_kr_cfg<32, 32, 2, 2, 16, true>(a, 1, s);
-    }
     if (splits > 1) {
-        if (splits == 4) return launch_kr_cfg<80, 64, 1, 4, 16, false>(a, splits, s);   // 16 x 4 x 4 = 256 workgroups at M=1280, N=256
-        return launch_kr_cfg<64, 64, 2, 2, 32, false>(a, splits, s);
+        if (splits == 4) return launch_kr_cfg<80, 64, 1, 4, 16>(a, splits, s);   // 16 x 4 x 4 = 256 workgroups at M=1280, N=256
+        return launch_kr_cfg<64, 64, 2, 2, 32>(a, splits, s);
     }
-    if (a.N >= 1024) return launch_kr_cfg<80, 64, 1, 4, 16, false>(a, 1, s);
-    if (a.N >= 512) return launch_kr_cfg<64, 64, 2, 2, 32, false>(a, 1, s);
-    return launch_kr_cfg<32, 32, 2, 2, 16, false>(a, 1, s);
+    if (a.N >= 1024) return launch_kr_cfg<80, 64, 1, 4, 16>(a, 1, s);
+    if (a.N >= 512) return launch_kr_cfg<64, 64, 2, 2, 32>(a, 1, s);
+    return launch_kr_cfg<32, 32, 2, 2, 16>(a, 1, s);
 }
 
 }  // namespace ladiff

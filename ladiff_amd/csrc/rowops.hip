@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const RedArgs p) {
     if (mode == RED_LN_ADD && counts != nullptr) cnt = *(const __attribute__((address_space(1))) int32_t*)(counts + b2 % Bs);
     const float* t = tab + (size_t)step * tab_step_stride;
     f32x4 t0 = zero, t1 = zero;
-    if (mode == RED_LN_ADD) t0 = ld4g(t + (size_t)(tt < cnt ? b2 : pad_row) * D + c);
+    if (mode == RED_LN_ADD) { t0 = ld4g(t + (size_t)b2 * D + c); t1 = ld4g(t + (size_t)pad_row * D + c); }   // both candidates
     else if (mode == RED_LN_MOD) { t0 = ld4g(t + c); t1 = ld4g(t + 256 + c); }
 
     f32x4 v;
@@ -94,8 +94,9 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const RedArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i];
         if (mode == RED_LN_ADD) {
+            const bool valid = tt < cnt;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] += t0[i];
+            for (int i = 0; i < 4; ++i) v[i] += valid ? t0[i] : t1[i];
         } else if (mode == RED_LN_MOD) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = silu(v[i] * (1.f + t0[i]) + t1[i]);
