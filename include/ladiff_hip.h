@@ -80,6 +80,13 @@ int ladiff_gemm_resident(const float* A, int lda, const float* A2, int lda2, int
                          const float* bias, const float* res, int ldres, float* Y, int ldy, int M, int N, int K,
                          int act, int split, float* Ys, ladiff_stream_t stream);
 
+/* Large-M bf16x3 GEMM of the decoder / encoder / CLIP (128x128 tiles, persistent producer/consumer workgroups):
+ *   Y and/or Ys = act( [A | A2] . W^T + bias ) (+ res);  A, A2, W are S-format rows (ladiff_split_rows), K and K1
+ *   multiples of 64, N multiple of 128, ldy multiple of 64; Y fp32 and Ys its S-format twin, either may be NULL. */
+int ladiff_gemm_split(const float* A, int lda, const float* A2, int lda2, int K1, const float* W, int ldw,
+                      const float* bias, const float* res, int ldres, float* Y, float* Ys, int ldy, int M, int N, int K,
+                      int act, ladiff_stream_t stream);
+
 /* bf16x3 operand format ("S-format"): a row of K fp32 values (K multiple of 64) is stored in the same K*4 bytes as
  * K/64 blocks of [64 bf16 hi | 64 bf16 lo], x ~ hi + lo.  With split = 1 ladiff_gemm_resident reads A, A2 and W in
  * this format and evaluates every product as hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation

@@ -35,6 +35,8 @@ _SIGNATURES = {
                             c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ladiff_gemm_resident": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                      c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ladiff_gemm_split": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                  c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ladiff_split_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ladiff_combine_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

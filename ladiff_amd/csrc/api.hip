@@ -126,6 +126,17 @@ int ladiff_gemm_resident(const float* A, int lda, const float* A2, int lda2, int
     return launch_gemm_kr(g, S(stream));
 }
 
+int ladiff_gemm_split(const float* A, int lda, const float* A2, int lda2, int K1, const float* W, int ldw, const float* bias,
+                      const float* res, int ldres, float* Y, float* Ys, int ldy, int M, int N, int K, int act,
+                      ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(A && W && (Y || Ys) && M >= 0 && N > 0 && K > 0);
+    if (M == 0) return 0;
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.A2 = A2; g.lda2 = lda2; g.K1 = A2 ? K1 : K; g.W = W; g.ldw = ldw; g.bias = bias;
+    g.res = res; g.ldres = ldres; g.Y = Y; g.Ys = Ys; g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.act = act; g.split = 1;
+    return launch_gemm(g, S(stream));
+}
+
 #ifdef LADIFF_STAMPS
 void ladiff_debug_set_stamps(unsigned long long* p) { g_stamps = p; }   // diagnostic builds only
 #endif

@@ -27,12 +27,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LADIFF_LAUNCH_CHECK() LADIFF_HIP(hipGetLastError())
 
 // ---- activations
+// erf for the exact-GELU: Abramowitz-Stegun 7.1.26, |error| <= 6e-7 absolute evaluated in fp32 (GELU: <= 5e-7), 1 rcp + 1 exp2 +
+// 8 FMAs.  The device library's erff (~1 ulp, two branches) costs ~60 instructions per value, which at 20 values per
+// thread was 2 us of every ffn.linear1 launch of the denoiser loop (and 40 us of the decoder's linear1 GEMM).
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+    float q = fmaf(t, 1.061405429f, -1.453152027f);
+    q = fmaf(t, q, 1.421413741f);
+    q = fmaf(t, q, -0.284496736f);
+    q = fmaf(t, q, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    return copysignf(fmaf(-q * t, e, 1.f), x);
+}
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erf_as(v * 0.70710678118654752440f)); }
+
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_QGELU = 4 };
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
         case ACT_RELU: return fmaxf(v, 0.f);
-        case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));  // exact erf GELU
+        case ACT_GELU: return gelu_erf(v);                                            // erf GELU (F.gelu default)
         case ACT_SILU: return v / (1.f + expf(-v));
         case ACT_QGELU: return v / (1.f + expf(-1.702f * v));                         // CLIP's quick_gelu: x * sigmoid(1.702 x)
         default: return v;
@@ -45,7 +60,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 template <int ACT>
 __device__ __forceinline__ float act_c(float v) {
     if constexpr (ACT == ACT_RELU) return fmaxf(v, 0.f);
-    else if constexpr (ACT == ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    else if constexpr (ACT == ACT_GELU) return gelu_erf(v);
     else if constexpr (ACT == ACT_SILU) return v / (1.f + expf(-v));
     else if constexpr (ACT == ACT_QGELU) return v / (1.f + expf(-1.702f * v));
     else return v;

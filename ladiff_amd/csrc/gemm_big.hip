@@ -180,55 +180,61 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(const GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------- bf16x3 variant
-// Operands in S-format (common.h): a K stage is one 64-k block = 256 bytes per row (hi | lo), the LDS image and the
-// swizzle are those of gemm_kr.hip (16-byte slot ^ (row & 15)), every product is hi*hi + hi*lo + lo*hi on
-// v_mfma_f32_16x16x32_bf16.  The MFMAs cost 1/5 of the fp32 ones, so the kernel is fill-bound: one 128x128 tile per
-// workgroup, two 64-KiB stages, one workgroup per CU.  Output: fp32 and/or S-format, bias/activation/residual fused;
+// Operands in S-format (common.h), every product is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 (fp32 accumulate).
+// One 128x128 tile per workgroup, 4 waves of 64x64.  A K stage is HALF an S-format block (32 k: 64 B hi + 64 B lo per
+// row), so the two stages take 64 KiB and the staged C tile 66 KiB: TWO workgroups fit on a CU, and one's epilogue (stores
+// run at HBM write speed) and barrier stalls hide under the other's MFMAs.  Measured at M = 25088 against the two designs
+// it replaced - 64-k stages with one workgroup per CU, and a persistent producer/consumer workgroup with register-direct
+// stores: 51 us vs 60 / 70 us (N=768, K=256), 91 vs 129 / 105 us (N=1024, K=256, GELU), 434 vs 504 / 483 us (N=768,
+// K=3072).  LDS rows are 128 B; 16-byte slot c of row r sits at c ^ ((r >> 1) & 7) (DMA source side and fragment reads),
+// conflict-free for the 16x16x32 operand layout.  Output: fp32 and/or S-format, bias / activation / residual fused;
 // LayerNorm runs as a row kernel afterwards (a 256-wide tile would move 4x the operand bytes per FLOP).
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_big_split_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm_big_split_kernel(const GemmArgs p) {
     constexpr int NW = 4, WM = 2, WN = 2;
     constexpr int TMW = BM / WM, TNW = BN / WN, RM = TMW / 16, RN = TNW / 16;
     constexpr int ROWS = BM + BN;
-    constexpr int STAGE = ROWS * 64;               // floats (256 B per row)
-    constexpr int GRP = 4 * NW;                    // rows covered by one piece per wave (a piece = 4 rows x 256 B)
+    constexpr int STAGE = ROWS * 32;               // floats (128 B per row)
+    constexpr int GRP = 8 * NW;                    // rows covered by one piece per wave (a piece = 8 rows x 128 B)
     constexpr int GA = BM / GRP, GT = ROWS / GRP;
     constexpr int PPW = GT;
-    static_assert(PPW * 2 <= 63, "vmcnt is 6 bits");
     constexpr int CLD = BN + 4;
     constexpr int LPR = BN / 4, RPI = 64 / LPR, EI = BM / NW / RPI;
-    static_assert(2 * STAGE >= BM * CLD, "C tile reuses the stage buffers");
+    constexpr int LDSF = (2 * STAGE > BM * CLD) ? 2 * STAGE : BM * CLD;
 
-    __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+    __shared__ __attribute__((aligned(1024))) float lds[LDSF];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    const int argM = pin_s(p.M), argK1 = pin_s(p.K1), ldy = pin_s(p.ldy), act = pin_s(p.act);
+    float* const argY = pin_s(p.Y); float* const argYs = pin_s(p.Ys);
     const int nbn = p.N / BN;
-    const int nbm = (p.M + BM - 1) / BM;
+    const int nbm = (argM + BM - 1) / BM;
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
     const int bm = (local / nbn) * 8 + xcd, bn = local % nbn;
     if (bm >= nbm) return;
     const int row0 = bm * BM, col0 = bn * BN;
-    const int nk = p.K / 64;
+    const int nk = p.K / 32;
 
-    const int rl = 4 * wave + (lane >> 4);                        // row within a 16-row group
-    const int kl = (((lane & 15) ^ rl) << 2);                     // swizzled source slot (floats)
-    float* const lbase = lds + 4 * wave * 64;
+    const int rl = 8 * wave + (lane >> 3);                        // row within a 32-row group
+    const int cs = (lane & 7) ^ ((rl >> 1) & 7);                  // source slot that lands in LDS slot (lane & 7)
+    const int kl = (cs < 4 ? cs * 4 : 32 + (cs - 4) * 4);         // float offset inside the 64-float block: hi | lo halves
+    float* const lbase = lds + 8 * wave * 32;
     auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
-        const int k0 = kt * 64;
+        const int k0 = (kt >> 1) * 64, hf = (kt & 1) * 16;       // block start (fp32 columns), half offset (floats)
         const float* abase; int ald;
-        if (k0 < p.K1) { abase = p.A + k0; ald = p.lda; } else { abase = p.A2 + (k0 - p.K1); ald = p.lda2; }
+        if (k0 < argK1) { abase = p.A + k0; ald = p.lda; } else { abase = p.A2 + (k0 - argK1); ald = p.lda2; }
 #pragma unroll
         for (int g = 0; g < GT; ++g) {
             const float* src;
             if (g < GA) {
-                int gr = row0 + GRP * g + rl; gr = gr < p.M ? gr : p.M - 1;
-                src = abase + (size_t)gr * ald + kl;
+                int gr = row0 + GRP * g + rl; gr = gr < argM ? gr : argM - 1;
+                src = abase + (size_t)gr * ald + hf + kl;
             } else {
-                src = p.W + (size_t)(col0 + GRP * (g - GA) + rl) * p.ldw + k0 + kl;
+                src = p.W + (size_t)(col0 + GRP * (g - GA) + rl) * p.ldw + k0 + hf + kl;
             }
-            dma16(src, lbase + buf * STAGE + GRP * g * 64);
+            dma16(src, lbase + buf * STAGE + GRP * g * 32);
         }
     };
 
@@ -239,39 +245,35 @@ __global__ __launch_bounds__(256) void gemm_big_split_kernel(const GemmArgs p) {
         for (int j = 0; j < RN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fk = lane >> 4;
+    const int sw = (frow >> 1) & 7;                // tiles start at multiples of 16 rows: (r >> 1) & 7 == (frow >> 1) & 7
     auto compute = [&](int buf) __attribute__((always_inline)) {
-        const float* sa = lds + buf * STAGE + (wm * TMW) * 64;
-        const float* sb = lds + buf * STAGE + (BM + wn * TNW) * 64;
+        const float* sa = lds + buf * STAGE + (wm * TMW) * 32;
+        const float* sb = lds + buf * STAGE + (BM + wn * TNW) * 32;
+        bf16x8 ah[RM], al[RM], bh[RN], bl[RN];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int ch = 4 * g + fk, cl = 8 + 4 * g + fk;
-            bf16x8 ah[RM], al[RM], bh[RN], bl[RN];
-#pragma unroll
-            for (int i = 0; i < RM; ++i) {
-                const int r = i * 16 + frow;              // (wm*TMW + r) & 15 == frow: tiles start at multiples of 16
-                ah[i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((ch ^ frow) << 2)));
-                al[i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((cl ^ frow) << 2)));
-            }
-#pragma unroll
-            for (int j = 0; j < RN; ++j) {
-                const int r = j * 16 + frow;
-                bh[j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((ch ^ frow) << 2)));
-                bl[j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((cl ^ frow) << 2)));
-            }
-                // three passes over the tile grid: consecutive MFMAs hit different accumulators (no dependent stalls)
-#pragma unroll
-                for (int i = 0; i < RM; ++i)
-#pragma unroll
-                    for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < RM; ++i)
-#pragma unroll
-                    for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < RM; ++i)
-#pragma unroll
-                    for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < RM; ++i) {
+            const int r = i * 16 + frow;
+            ah[i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 32 + ((fk ^ sw) << 2)));
+            al[i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 32 + (((4 + fk) ^ sw) << 2)));
         }
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            const int r = j * 16 + frow;
+            bh[j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 32 + ((fk ^ sw) << 2)));
+            bl[j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 32 + (((4 + fk) ^ sw) << 2)));
+        }
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
     };
 
     const int er = wave * (BM / NW) + lane / LPR;
@@ -279,6 +281,7 @@ __global__ __launch_bounds__(256) void gemm_big_split_kernel(const GemmArgs p) {
     f32x4 rv[EI];
 #pragma unroll
     for (int e = 0; e < EI; ++e) rv[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
 
     issue(0, 0);
     if (nk > 1) issue(1, 1);
@@ -286,11 +289,14 @@ __global__ __launch_bounds__(256) void gemm_big_split_kernel(const GemmArgs p) {
         const int buf = kt & 1;
         if (kt + 1 < nk) wait_vm<PPW>(); else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
-        if (kt == nk - 1 && p.res != nullptr) {
+        if (kt == nk - 1) {                        // epilogue operands: their latency hides under the last stage's MFMAs
+            if (p.bias != nullptr) bv = ld4(p.bias + col0 + ec);
+            if (p.res != nullptr) {
 #pragma unroll
-            for (int e = 0; e < EI; ++e) {
-                const int gr = row0 + er + e * RPI;
-                if (gr < p.M) rv[e] = ld4(p.res + (size_t)gr * p.ldres + col0 + ec);
+                for (int e = 0; e < EI; ++e) {
+                    const int gr = row0 + er + e * RPI;
+                    if (gr < argM) rv[e] = ld4(p.res + (size_t)gr * p.ldres + col0 + ec);
+                }
             }
         }
         compute(buf);
@@ -308,12 +314,11 @@ __global__ __launch_bounds__(256) void gemm_big_split_kernel(const GemmArgs p) {
                 ct[(wm * TMW + i * 16 + 4 * (lane >> 4) + r) * CLD + wn * TNW + j * 16 + (lane & 15)] = acc[i][j][r];
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    reg_touch(bv);
 #pragma unroll
-    for (int e = 0; e < EI; ++e) reg_touch(rv[e]);  // landed: keep compiler-made vmcnt(0) out of the store loop
+    for (int e = 0; e < EI; ++e) reg_touch(rv[e]);
 
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr) bv = ld4(p.bias + col0 + ec);
-    act_dispatch(p.act, [&](auto ACT) __attribute__((always_inline)) {
+    act_dispatch(act, [&](auto ACT) __attribute__((always_inline)) {
 #pragma unroll
         for (int e = 0; e < EI; ++e) {
             const int lr = er + e * RPI;
@@ -321,9 +326,9 @@ __global__ __launch_bounds__(256) void gemm_big_split_kernel(const GemmArgs p) {
             f32x4 v = ld4(ct + lr * CLD + ec);
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = act_c<decltype(ACT)::value>(v[q] + bv[q]) + rv[e][q];
-            if (gr < p.M) {
-                if (p.Y != nullptr) st4(p.Y + (size_t)gr * p.ldy + col0 + ec, v);
-                if (p.Ys != nullptr) store_split4(p.Ys + (size_t)gr * p.ldy, col0 + ec, v);
+            if (gr < argM) {
+                if (argY != nullptr) st4g(argY + (size_t)gr * ldy + col0 + ec, v);
+                if (argYs != nullptr) store_split4g(argYs + (size_t)gr * ldy, col0 + ec, v);
             }
         }
     });
@@ -340,7 +345,7 @@ static int launch_big(const GemmArgs& a, hipStream_t s) {
 
 // true when the shape is served by this kernel family (otherwise the caller uses the staged kernel of gemm.hip)
 bool gemm_big_supported(const GemmArgs& a) {
-    if (a.split) return a.M > 0 && a.K % 64 == 0 && a.K1 % 64 == 0 && a.N % 128 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0 &&
+    if (a.split) return a.M > 0 && a.K % 64 == 0 && a.K1 % 64 == 0 && a.N % 128 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0 && (!a.A2 || a.lda2 % 4 == 0) &&
                         a.ldy % 64 == 0 && !a.ln_g && !a.mod && !a.row_len && a.post_act == ACT_NONE && (a.Y || a.Ys);
     if (a.M < 4096 || a.K % BKB || a.K1 % BKB || (a.lda % 4) || (a.ldw % 4) || (a.A2 && (a.lda2 % 4))) return false;
     if ((a.ldy % 4) || (a.res && (a.ldres % 4)) || a.mod || a.row_len || a.post_act != ACT_NONE) return false;
