@@ -234,14 +234,21 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tabl
         LADIFF_TRY(gemm(kr(sp ? curs : cur, D, Ls.sa_attn.in_w, L.sa_attn.in_b, qkv, 3 * D, M, 3 * D, D)));
         LADIFF_TRY(launch_denoiser_self_attention(qkv, tkv + (size_t)l * B2 * 2 * D, tl, DEN_OFF_TIME_KV, DEN_STEP_STRIDE,
                                                   d_step, counts, Bs, b_lo, b_n, T, att, sp ? 1 : 0, s));
-        {   // R1 = x + out_proj(att) -> P[1]
+        if (sp) {   // X1 = LN1(x + out_proj(att)) -> P[2] / Ps[2], one launch (gemm_rowln.hip)
+            RowLnArgs g;
+            g.A = att; g.lda = D; g.W = Ls.sa_attn.out_w; g.ldw = D; g.bias = L.sa_attn.out_b; g.res = cur; g.ldres = D;
+            g.ln_g = L.sa_norm1.g; g.ln_b = L.sa_norm1.b; g.Y = P[2]; g.Ys = Ps[2]; g.ldy = D; g.M = M; g.K = D;
+            LADIFF_TRY(launch_gemm_rowln(g, s));
+        } else {
+            // R1 = x + out_proj(att) -> P[1]
             KrArgs g = kr(att, D, Ls.sa_attn.out_w, L.sa_attn.out_b, P[1], D, M, D, D);
             g.res = cur; g.ldres = D;
             LADIFF_TRY(gemm(g));
+            // X1 = LN1(R1) -> P[2]
+            LADIFF_TRY(launch_reduce_rows(P[1], 1, M, nullptr, nullptr, RED_LN, L.sa_norm1.g, L.sa_norm1.b, nullptr, 0, nullptr,
+                                          nullptr, 1, 1, 0, 0, P[2], Ps[2], s));
         }
-        // X1 = LN1(R1) -> P[2];  hid = relu(linear1(X1))
-        LADIFF_TRY(launch_reduce_rows(P[1], 1, M, nullptr, nullptr, RED_LN, L.sa_norm1.g, L.sa_norm1.b, nullptr, 0, nullptr,
-                                      nullptr, 1, 1, 0, 0, P[2], Ps[2], s));
+        // hid = relu(linear1(X1))
         {
             KrArgs g = kr(sp ? Ps[2] : P[2], D, Ls.sa_lin1.w, L.sa_lin1.b, sp ? nullptr : hid, FF, M, FF, D, ACT_RELU);
             if (sp) g.Ys = hid;

@@ -21,4 +21,16 @@ struct KrArgs {
 
 int launch_gemm_kr(const KrArgs& a, hipStream_t s);
 
+// gemm_rowln.hip: Y / Ys = LayerNorm( A . W^T + bias + res ) over 256-wide rows, S-format A [M, K] and W [256, K]
+struct RowLnArgs {
+    const float* A = nullptr;  int lda = 0;
+    const float* W = nullptr;  int ldw = 0;
+    const float* bias = nullptr;
+    const float* res = nullptr; int ldres = 0;
+    const float* ln_g = nullptr; const float* ln_b = nullptr;
+    float* Y = nullptr; float* Ys = nullptr; int ldy = 0;     // fp32 result and / or its S-format twin
+    int M = 0, K = 0;                                          // K multiple of 64
+};
+int launch_gemm_rowln(const RowLnArgs& a, hipStream_t s);
+
 }  // namespace ladiff

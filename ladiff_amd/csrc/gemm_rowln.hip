@@ -1,0 +1,168 @@
+// Y = LayerNorm( A . W^T + bias + res ) for the 256-wide rows of the denoiser loop, bf16x3 products (S-format operands):
+// the self-attention out-projection + residual + norm1 of `TransformerEncoderLayer.forward_post`
+// (mdiff_transformer.py:57-63) in ONE launch instead of GEMM + row kernel.
+//
+// A LayerNorm needs whole rows, so a workgroup owns 16 rows x all 256 columns and streams K in 64-wide stages through a
+// two-stage LDS ring (16 A rows + 256 W rows = 68 KiB per stage).  M = 1280 gives 80 workgroups; each pulls the whole
+// weight matrix (256 KiB at K = 256) through its texture path at 64 B/clk, which is what bounds the kernel (~4.3 k
+// cycles) - still shorter than a second launch.  Producer / consumer split as in gemm_kr.hip: waves 4-7 issue the LDS-DMA
+// (counted vmcnt, stage hand-over through the workgroup barrier), waves 0-3 own 64 columns each and run the MFMAs; the
+// epilogue stages the tile through LDS once and normalises one row per wave-instruction (DPP reductions).
+#include "gemm_kr.h"
+
+namespace ladiff {
+
+namespace {
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void dma16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+}  // namespace
+
+__global__ __launch_bounds__(512) void gemm_rowln_kernel(const RowLnArgs p) {
+    constexpr int BM = 16, BN = 256;
+    constexpr int ROWS = BM + BN;                  // 272 LDS rows of 256 B per stage
+    constexpr int STAGE = ROWS * 64;
+    constexpr int PCS = ROWS / 4;                  // 68 one-KiB pieces per stage
+    constexpr int PPW = PCS / 4;                   // 17 per producer wave
+    constexpr int RN = 4;                          // 16-column tiles per consumer wave
+    constexpr int CLD = BN + 4;
+    static_assert(2 * PPW <= 63, "vmcnt is 6 bits");
+
+    __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int argM = pin_s(p.M), nk = pin_s(p.K) >> 6;
+    const int row0 = blockIdx.x * BM;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int pw = wave - 4;
+        const int rl = 4 * pw + (lane >> 4);       // LDS row & 15 of every piece this wave issues
+        const int kl = ((lane & 15) ^ rl) << 2;    // swizzled source slot (floats)
+        const float* const argA = pin_s(p.A); const float* const argW = pin_s(p.W);
+        const int lda = pin_s(p.lda), ldw = pin_s(p.ldw);
+        int gr = row0 + rl; gr = gr < argM ? gr : argM - 1;
+        const float* const arow = argA + (size_t)gr * lda + kl;           // this lane's A row (piece 0 of every stage)
+        const float* const wrow = argW + (size_t)rl * ldw + kl;           // W row rl; piece i adds 16 (i - 1) rows
+        float* const lbase = lds + 4 * pw * 64;
+        auto issue = [&](int kt) __attribute__((always_inline)) {
+            float* const dst = lbase + (kt & 1) * STAGE;
+            const int k0 = kt << 6;
+            dma16(arow + k0, dst);                                         // A rows 4 pw .. 4 pw + 3
+#pragma unroll
+            for (int i = 1; i < PPW; ++i) dma16(wrow + (size_t)(16 * (i - 1)) * ldw + k0, dst + 16 * i * 64);
+        };
+        issue(0);
+        if (nk > 1) issue(1);
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) wait_vm<PPW>(); else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();          // A(kt): stage landed
+            __builtin_amdgcn_s_barrier();          // B(kt): stage consumed
+            if (kt + 2 < nk) issue(kt + 2);
+        }
+        __builtin_amdgcn_s_barrier();              // C tile staged (the producers take no part in the epilogue)
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers: wave w owns columns 64 w .. 64 w + 63
+    float* const argY = pin_s(p.Y); float* const argYs = pin_s(p.Ys);
+    const float* const argRes = pin_s(p.res);
+    const int ldres = pin_s(p.ldres), ldy = pin_s(p.ldy);
+    const int c = lane * 4;                        // epilogue: one row per wave-instruction, 4 columns per lane
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 bi = p.bias != nullptr ? ld4(p.bias + c) : zero;
+    const f32x4 gg = ld4(p.ln_g + c), bb = ld4(p.ln_b + c);
+    f32x4 rv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int gr = row0 + 4 * wave + e;
+        rv[e] = (argRes != nullptr && gr < argM) ? ld4g(argRes + (size_t)gr * ldres + c) : zero;
+    }
+
+    f32x4 acc[RN];
+#pragma unroll
+    for (int j = 0; j < RN; ++j) acc[j] = zero;
+    const int frow = lane & 15, fk = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const float* sa = lds + (kt & 1) * STAGE;
+        const float* sb = sa + (BM + 64 * wave) * 64;
+        __builtin_amdgcn_s_barrier();              // A(kt)
+        bf16x8 ah[2], al[2], bh[2][RN], bl[2][RN];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int ch = 4 * g + fk, cl = 8 + 4 * g + fk;
+            ah[g] = __builtin_bit_cast(bf16x8, ld4(sa + frow * 64 + ((ch ^ frow) << 2)));
+            al[g] = __builtin_bit_cast(bf16x8, ld4(sa + frow * 64 + ((cl ^ frow) << 2)));
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {
+                const int r = j * 16 + frow;
+                bh[g][j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((ch ^ frow) << 2)));
+                bl[g][j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((cl ^ frow) << 2)));
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int j = 0; j < RN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[g], bh[g][j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < RN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g], bl[g][j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < RN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g], bh[g][j], acc[j], 0, 0, 0);
+            if (g == 0) {                          // both fragment sets are in registers: release the stage
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();      // B(kt)
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------------- epilogue: C tile through LDS, then row-wise
+    // stage (kt = nk - 1) & 1 may still be read by a slower consumer's second fragment set?  No: B(nk-1) was passed by every
+    // wave after its LDS reads completed.  The other stage is idle as well (nothing was issued after stage nk-1).
+    float* ct = lds;
+#pragma unroll
+    for (int j = 0; j < RN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ct[(4 * fk + r) * CLD + 64 * wave + 16 * j + frow] = acc[j][r];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    f32x4 bi_ = bi, gg_ = gg, bb_ = bb;            // landed (vmcnt(0) above): no compiler-made waits in the store loop
+    reg_touch(bi_); reg_touch(gg_); reg_touch(bb_);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) reg_touch(rv[e]);
+    f32x4 v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = ld4(ct + (4 * wave + e) * CLD + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[e][i] += bi_[i] + rv[e][i];
+        const float mean = wave_sum((v[e][0] + v[e][1]) + (v[e][2] + v[e][3])) * (1.f / 256.f);
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float d = v[e][i] - mean; sq += d * d; }
+        const float rstd = rsqrtf(wave_sum(sq) * (1.f / 256.f) + LN_EPS);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[e][i] = (v[e][i] - mean) * rstd * gg_[i] + bb_[i];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int gr = row0 + 4 * wave + e;
+        if (gr < argM) {
+            if (argY != nullptr) st4g(argY + (size_t)gr * ldy + c, v[e]);
+            if (argYs != nullptr) store_split4g(argYs + (size_t)gr * ldy, c, v[e]);
+        }
+    }
+}
+
+int launch_gemm_rowln(const RowLnArgs& a, hipStream_t s) {
+    LADIFF_CHECK_ARG(a.A && a.W && a.ln_g && a.ln_b && (a.Y || a.Ys) && a.M >= 0 && a.K > 0);
+    if (a.K % 64 != 0 || (a.lda % 4) || (a.ldw % 4) || (a.ldy % 64) || (a.res && (a.ldres % 4))) return LADIFF_ERR_SHAPE;
+    if (a.M == 0) return 0;
+    hipLaunchKernelGGL(gemm_rowln_kernel, dim3((a.M + 15) / 16), dim3(512), 0, s, a);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace ladiff
