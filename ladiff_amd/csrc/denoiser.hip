@@ -231,9 +231,14 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tabl
                                           1, 1, 0, 0, P[3], Ps[3], s));
             cur = P[3]; curs = Ps[3];
         }
-        LADIFF_TRY(gemm(kr(sp ? curs : cur, D, Ls.sa_attn.in_w, L.sa_attn.in_b, qkv, 3 * D, M, 3 * D, D)));
-        LADIFF_TRY(launch_denoiser_self_attention(qkv, tkv + (size_t)l * B2 * 2 * D, tl, DEN_OFF_TIME_KV, DEN_STEP_STRIDE,
-                                                  d_step, counts, Bs, b_lo, b_n, T, att, sp ? 1 : 0, s));
+        if (sp) {   // in_proj + attention core in one launch (qkv_attn.hip)
+            LADIFF_TRY(launch_qkv_attention(curs, Ls.sa_attn.in_w, L.sa_attn.in_b, tkv + (size_t)l * B2 * 2 * D, tl,
+                                            DEN_OFF_TIME_KV, DEN_STEP_STRIDE, d_step, counts, Bs, b_lo, b_n, T, att, s));
+        } else {
+            LADIFF_TRY(gemm(kr(cur, D, Ls.sa_attn.in_w, L.sa_attn.in_b, qkv, 3 * D, M, 3 * D, D)));
+            LADIFF_TRY(launch_denoiser_self_attention(qkv, tkv + (size_t)l * B2 * 2 * D, tl, DEN_OFF_TIME_KV, DEN_STEP_STRIDE,
+                                                      d_step, counts, Bs, b_lo, b_n, T, att, 0, s));
+        }
         if (sp) {   // X1 = LN1(x + out_proj(att)) -> P[2] / Ps[2], one launch (gemm_rowln.hip)
             RowLnArgs g;
             g.A = att; g.lda = D; g.W = Ls.sa_attn.out_w; g.ldw = D; g.bias = L.sa_attn.out_b; g.res = cur; g.ldres = D;

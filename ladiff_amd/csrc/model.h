@@ -35,6 +35,11 @@ int vae_encode(const EncoderW& w, const EncoderW* w_split, const float* features
                const int32_t* counts, const float* eps, int B, int F, int T, int C, float* mu, float* sd, float* latent, float* ws,
                size_t ws_floats, hipStream_t s);
 
+// qkv_attn.hip: in_proj GEMM + self-attention of the denoiser's sa_block in one launch (bf16x3 mode, S-format in / out)
+int launch_qkv_attention(const float* x, const float* w, const float* bias, const float* text_kv, const float* tables,
+                         int kv_off, int step_stride, const int32_t* d_step, const int32_t* counts, int Bs, int b_off,
+                         int b_n, int T, float* out, hipStream_t s);
+
 size_t clip_ws_floats(int B, int L);
 int clip_text_encode(const ClipW& w, const ClipW* w_split, int n_layers, int vocab, const int64_t* ids, int B, int S, int L,
                      float* out, float* ws, size_t ws_floats, hipStream_t s);
