@@ -270,12 +270,19 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tabl
             LADIFF_TRY(gemm(g));
         }
         LADIFF_TRY(gemm(kr(hid, FF, Ls.ffn2.w, nullptr, part, D, M, D, FF)));
-        LADIFF_TRY(launch_reduce_rows(part, 4, M, L.ffn2.b, nullptr, RED_LN_MOD, L.ffn_proj.norm.g, L.ffn_proj.norm.b,
-                                      tl + DEN_OFF_FFN_MOD, DEN_STEP_STRIDE, d_step, nullptr, 1, 1, 0, 0,
-                                      sp ? nullptr : P[2], sp ? P[2] : nullptr, s));
         float* dst = is_in ? SK[l] : P[0];
         float* dsts = is_in ? SKs[l] : Ps[0];
-        {   // x' = X3 + out_layers(u)
+        if (sp) {   // combine + StylizationBlock + out projection + residual in one launch (gemm_rowln.hip)
+            CombineGemmArgs g;
+            g.P = part; g.plane = MD; g.S = 4; g.bias2 = L.ffn2.b; g.ln_g = L.ffn_proj.norm.g; g.ln_b = L.ffn_proj.norm.b;
+            g.tab = tl + DEN_OFF_FFN_MOD; g.tab_step_stride = DEN_STEP_STRIDE; g.d_step = d_step;
+            g.W = Ls.ffn_proj.out.w; g.ldw = D; g.bias = L.ffn_proj.out.b; g.res = P[1]; g.ldres = D;
+            g.Y = dst; g.Ys = dsts; g.ldy = D; g.M = M;
+            LADIFF_TRY(launch_combine_gemm(g, s));
+        } else {
+            LADIFF_TRY(launch_reduce_rows(part, 4, M, L.ffn2.b, nullptr, RED_LN_MOD, L.ffn_proj.norm.g, L.ffn_proj.norm.b,
+                                          tl + DEN_OFF_FFN_MOD, DEN_STEP_STRIDE, d_step, nullptr, 1, 1, 0, 0, P[2], nullptr, s));
+            // x' = X3 + out_layers(u)
             KrArgs g = kr(P[2], D, Ls.ffn_proj.out.w, L.ffn_proj.out.b, dst, D, M, D, D);
             g.res = P[1]; g.ldres = D; g.Ys = dsts;
             LADIFF_TRY(gemm(g));

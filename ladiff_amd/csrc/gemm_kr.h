@@ -33,4 +33,19 @@ struct RowLnArgs {
 };
 int launch_gemm_rowln(const RowLnArgs& a, hipStream_t s);
 
+// gemm_rowln.hip: Y / Ys = res + ( SiLU( LN(sum_s P[s] + bias2) * (1 + scale) + shift ) ) . W^T + bias,  K = N = 256;
+// scale | shift = tab + step * tab_step_stride (256 + 256 floats), step = *d_step
+struct CombineGemmArgs {
+    const float* P = nullptr; size_t plane = 0; int S = 0;   // split-K partial planes [S][M][256]
+    const float* bias2 = nullptr;
+    const float* ln_g = nullptr; const float* ln_b = nullptr;
+    const float* tab = nullptr; int tab_step_stride = 0; const int32_t* d_step = nullptr;
+    const float* W = nullptr; int ldw = 0;                   // S-format [256, 256]
+    const float* bias = nullptr;
+    const float* res = nullptr; int ldres = 0;
+    float* Y = nullptr; float* Ys = nullptr; int ldy = 0;
+    int M = 0;
+};
+int launch_combine_gemm(const CombineGemmArgs& a, hipStream_t s);
+
 }  // namespace ladiff
