@@ -224,11 +224,18 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tabl
         if (is_out) {
             const LinearW& sk = w.skip[l - NSKIP - 1];
             const LinearW& sks = sp ? wsp->skip[l - NSKIP - 1] : sk;
-            KrArgs g = kr(sp ? curs : cur, D, sks.w, nullptr, part, D, M, D, 2 * D);
-            g.A2 = sp ? SKs[NL - 1 - l] : SK[NL - 1 - l]; g.lda2 = D; g.K1 = D;
-            LADIFF_TRY(gemm(g));
-            LADIFF_TRY(launch_reduce_rows(part, 2, M, sk.b, nullptr, RED_PLAIN, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
-                                          1, 1, 0, 0, P[3], Ps[3], s));
+            if (sp) {   // linear_blocks[i](cat(x, skip)): whole 256-wide rows per workgroup, K = 512 streamed (gemm_rowln.hip)
+                RowLnArgs g;
+                g.A = curs; g.lda = D; g.A2 = SKs[NL - 1 - l]; g.lda2 = D; g.K1 = D; g.W = sks.w; g.ldw = 2 * D; g.bias = sk.b;
+                g.Y = P[3]; g.Ys = Ps[3]; g.ldy = D; g.M = M; g.K = 2 * D;
+                LADIFF_TRY(launch_gemm_rowln(g, s));
+            } else {
+                KrArgs g = kr(cur, D, sks.w, nullptr, part, D, M, D, 2 * D);
+                g.A2 = SK[NL - 1 - l]; g.lda2 = D; g.K1 = D;
+                LADIFF_TRY(gemm(g));
+                LADIFF_TRY(launch_reduce_rows(part, 2, M, sk.b, nullptr, RED_PLAIN, nullptr, nullptr, nullptr, 0, nullptr,
+                                              nullptr, 1, 1, 0, 0, P[3], Ps[3], s));
+            }
             cur = P[3]; curs = Ps[3];
         }
         if (sp) {   // in_proj + attention core in one launch (qkv_attn.hip)

@@ -24,10 +24,11 @@ int launch_gemm_kr(const KrArgs& a, hipStream_t s);
 // gemm_rowln.hip: Y / Ys = LayerNorm( A . W^T + bias + res ) over 256-wide rows, S-format A [M, K] and W [256, K]
 struct RowLnArgs {
     const float* A = nullptr;  int lda = 0;
+    const float* A2 = nullptr; int lda2 = 0; int K1 = 0;      // optional second K segment (columns >= K1), skip-connection concat
     const float* W = nullptr;  int ldw = 0;
     const float* bias = nullptr;
     const float* res = nullptr; int ldres = 0;
-    const float* ln_g = nullptr; const float* ln_b = nullptr;
+    const float* ln_g = nullptr; const float* ln_b = nullptr; // both null: no LayerNorm
     float* Y = nullptr; float* Ys = nullptr; int ldy = 0;     // fp32 result and / or its S-format twin
     int M = 0, K = 0;                                          // K multiple of 64
 };

@@ -1,4 +1,4 @@
-// Y = LayerNorm( A . W^T + bias + res ) for the 256-wide rows of the denoiser loop, bf16x3 products (S-format operands):
+// Y = [LayerNorm]( [A | A2] . W^T + bias + res ) for the 256-wide rows of the denoiser loop, bf16x3 products (S-format operands):
 // the self-attention out-projection + residual + norm1 of `TransformerEncoderLayer.forward_post`
 // (mdiff_transformer.py:57-63) in ONE launch instead of GEMM + row kernel.
 //
@@ -45,12 +45,14 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const RowLnArgs p) {
         const int lda = pin_s(p.lda), ldw = pin_s(p.ldw);
         int gr = row0 + rl; gr = gr < argM ? gr : argM - 1;
         const float* const arow = argA + (size_t)gr * lda + kl;           // this lane's A row (piece 0 of every stage)
+        const int K1 = pin_s(p.K1);                                        // columns >= K1 come from A2 (skip-connection concat)
+        const float* const arow2 = p.A2 != nullptr ? p.A2 + (size_t)gr * p.lda2 + kl - K1 : arow;
         const float* const wrow = argW + (size_t)rl * ldw + kl;           // W row rl; piece i adds 16 (i - 1) rows
         float* const lbase = lds + 4 * pw * 64;
         auto issue = [&](int kt) __attribute__((always_inline)) {
             float* const dst = lbase + (kt & 1) * STAGE;
             const int k0 = kt << 6;
-            dma16(arow + k0, dst);                                         // A rows 4 pw .. 4 pw + 3
+            dma16((k0 < K1 ? arow : arow2) + k0, dst);                     // A rows 4 pw .. 4 pw + 3
 #pragma unroll
             for (int i = 1; i < PPW; ++i) dma16(wrow + (size_t)(16 * (i - 1)) * ldw + k0, dst + 16 * i * 64);
         };
@@ -73,7 +75,8 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const RowLnArgs p) {
     const int c = lane * 4;                        // epilogue: one row per wave-instruction, 4 columns per lane
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const f32x4 bi = p.bias != nullptr ? ld4(p.bias + c) : zero;
-    const f32x4 gg = ld4(p.ln_g + c), bb = ld4(p.ln_b + c);
+    const bool ln = p.ln_g != nullptr;
+    const f32x4 gg = ln ? ld4(p.ln_g + c) : zero, bb = ln ? ld4(p.ln_b + c) : zero;
     f32x4 rv[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -138,6 +141,7 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const RowLnArgs p) {
     for (int e = 0; e < 4; ++e) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[e][i] += bi_[i] + rv[e][i];
+        if (!ln) continue;
         const float mean = wave_sum((v[e][0] + v[e][1]) + (v[e][2] + v[e][3])) * (1.f / 256.f);
         float sq = 0.f;
 #pragma unroll
@@ -157,10 +161,13 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const RowLnArgs p) {
 }
 
 int launch_gemm_rowln(const RowLnArgs& a, hipStream_t s) {
-    LADIFF_CHECK_ARG(a.A && a.W && a.ln_g && a.ln_b && (a.Y || a.Ys) && a.M >= 0 && a.K > 0);
+    LADIFF_CHECK_ARG(a.A && a.W && (a.ln_g == nullptr) == (a.ln_b == nullptr) && (a.Y || a.Ys) && a.M >= 0 && a.K > 0);
+    if (a.A2 != nullptr && (a.K1 % 64 != 0 || a.K1 <= 0 || a.K1 >= a.K || (a.lda2 % 4))) return LADIFF_ERR_SHAPE;
     if (a.K % 64 != 0 || (a.lda % 4) || (a.ldw % 4) || (a.ldy % 64) || (a.res && (a.ldres % 4))) return LADIFF_ERR_SHAPE;
     if (a.M == 0) return 0;
-    hipLaunchKernelGGL(gemm_rowln_kernel, dim3((a.M + 15) / 16), dim3(512), 0, s, a);
+    RowLnArgs b = a;
+    if (b.A2 == nullptr) b.K1 = b.K;
+    hipLaunchKernelGGL(gemm_rowln_kernel, dim3((b.M + 15) / 16), dim3(512), 0, s, b);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
