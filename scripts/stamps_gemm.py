@@ -25,5 +25,5 @@ for (N, K, ln, SPLIT) in [(1024, 256, 0, 0), (1024, 256, 0, 1), (768, 256, 0, 0)
     d = (t[:, 1:8] - t[:, 0:1])
     names = ["issued", "A landed", "LN done", "last sub starts", "mfma done", "stored", "C staged"] if ln else ["issued", "sub0 landed", "sub0 done", "last sub starts", "mfma done", "stored", "C staged"]
     t0 = t[:, 0].min()
-    print(f"N={N} K={K} split={SPLIT}: {nb} workgroups; start spread {((t[:,0]-t0).max()):.0f} cyc; last end {(t[:,6].max()-t0):.0f} cyc (100 MHz s_memtime? see ratio below)")
+    print(f"N={N} K={K} split={SPLIT}: {nb} workgroups; start spread {float((t[:,0]-t0).max()):.0f} cyc; last store issued {float(t[:,6].max()-t0):.0f} cyc after the first workgroup started")
     print("   median cycles since workgroup start: " + ", ".join(f"{n} {d[:, i].median():.0f}" for i, n in enumerate(names)))

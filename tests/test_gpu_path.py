@@ -92,6 +92,27 @@ def test_denoiser_short_latent_count(denoiser):
     assert maxdiff(got, want) < 5e-5
 
 
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 2), (7, 3), (10, 4), (33, 5), (37, 5), (5, 7), (13, 8)])
+def test_denoiser_bf16x3_shapes_against_oracle(denoiser, B, T):
+    """The bf16x3 path runs on its own fused kernels (in_proj + attention per (samples, head) workgroup, row-complete
+    GEMMs with LayerNorm / combine prologues): every latent count 1..8, batches that do not fill the last workgroup, masked
+    latent rows - against the CPU oracle (and therefore against the fp32 kernels, which the goldens pin)."""
+    sd = syn.denoiser_weights()
+    gen = torch.Generator().manual_seed(100 * B + T)
+    x = torch.randn(B, T, 256, generator=gen)
+    txt = torch.randn(B, 1, 768, generator=gen)
+    counts = torch.randint(1, T + 1, (B,), generator=gen)
+    want = orc.denoiser_forward(sd, x, 301, txt, counts)
+    denoiser.precision = "bf16x3"
+    try:
+        got = denoiser(x.to(DEV), torch.tensor(301), txt.to(DEV), max_iter_elements=counts.to(DEV))[0]
+    finally:
+        denoiser.precision = "fp32"
+    ref32 = denoiser(x.to(DEV), torch.tensor(301), txt.to(DEV), max_iter_elements=counts.to(DEV))[0]
+    assert maxdiff(ref32, want) < 5e-5
+    assert maxdiff(got, want) < 1e-3
+
+
 # ---------------------------------------------------------------- LA-VAE decode (A15-A18)
 @pytest.mark.parametrize("name,nfeats", [("vae_decode_c1", 263), ("vae_decode_mixed_kit", 251),
                                          ("vae_decode_ragged", 263)])
