@@ -100,7 +100,9 @@ def dominant_kernel_roofline(dev, stream, precision, launches=400):
             "flops_per_launch": flops, "mfma_flops_per_launch": mfma_flops, "us_per_launch": round(us, 2),
             "achieved": round(flops / us / 1e6, 2), "unit": "TFLOP/s", "peak": peak,
             "frac": round(flops / us / 1e6 / peak, 4), "mfma_frac": round(mfma_flops / us / 1e6 / peak, 4),
-            "traffic": 22.8e6, "traffic_source": "profiles/r1/03_pmc_summary.md: 2 x FETCH_SIZE + WRITE_SIZE per launch"}
+            "traffic": 22.75e6 if split else 22.8e6,
+            "traffic_source": ("profiles/r1/07_pmc_summary_bf16x3_fused.md" if split else "profiles/r1/03_pmc_summary.md") +
+                              ": 2 x FETCH_SIZE + WRITE_SIZE per launch (L2-fabric interface, Infinity-Cache hits included)"}
 
 
 def cpu_baseline(sample_b):
@@ -212,7 +214,10 @@ def main():
                          "device_ms_per_pass": round(dev_ms / args.steps, 3),
                          "flops_per_motion_reference_equivalent": ref_flops_per_motion(),
                          "executed_tflops": round(exe_tf, 2), "executed_frac": round(exe_tf / PEAK_F32_MFMA_TFLOPS, 4),
-                         "traffic": 84.1e9, "traffic_source": "profiles/r1/03_pmc_summary.md, bytes per pass at the L2-fabric interface"},
+                         "traffic": 84.1e9 if args.precision == "fp32" else 72.0e9,
+                         "traffic_source": ("profiles/r1/03_pmc_summary.md" if args.precision == "fp32" else
+                                            "profiles/r1/07_pmc_summary_bf16x3_fused.md") +
+                                           ", bytes per pass at the L2-fabric interface (Infinity-Cache hits included)"},
         }
         peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
         line["roofline"].update({"peak": peak, "frac": round(ref_tf / peak, 4), "executed_frac": round(
