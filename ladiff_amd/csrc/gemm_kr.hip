@@ -91,6 +91,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
     const int ks = blockIdx.y;                     // K slice (split-K)
     const int row0 = bm * BM, col0 = bn * BN;
     const bool partial = gridDim.y > 1;            // split-K: raw partial sums, combined by reduce_rows_kernel
+    float* const argY = pin_s(p.Y); float* const argYs = pin_s(p.Ys);      // epilogue arguments, read once (common.h)
+    const int argM = pin_s(p.M), argN = pin_s(p.N), argLdy = pin_s(p.ldy), argAct = pin_s(p.act);
 
     // ---- residual tile first: these loads are OLDER than every LDS-DMA piece, so the counted waits below also
     // retire them and the epilogue never stalls on a dependent global load.  The epilogue works on 16-byte units
@@ -196,23 +198,31 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
                 ct[(wm * TMW + i * MT + MM::arow(lane, r)) * CLD + wn * TNW + j * MT + MM::acol(lane)] = acc[i][j][r];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    float* Y = p.Y == nullptr ? nullptr : p.Y + (partial ? (size_t)ks * p.M * p.ldy : 0);
-    act_dispatch(partial ? (int)ACT_NONE : p.act, [&](auto ACT) __attribute__((always_inline)) {
+    float* Y = argY == nullptr ? nullptr : argY + (partial ? (size_t)ks * argM * argLdy : 0);
+    // all LDS reads first (one latency), then the arithmetic, then the stores back to back
+    f32x4 cv[UNITS];
 #pragma unroll
-        for (int u = 0; u < UNITS; ++u) {
-            const int id = tid + u * NW * 64;
-            const int lr = id / UPR, lc = 4 * (id % UPR);
-            const int gr = row0 + lr, gc = col0 + lc;
-            if (gr >= p.M || gc >= p.N) continue;
-            f32x4 v = ld4(ct + lr * CLD + lc);
-            if (!partial) {
+    for (int u = 0; u < UNITS; ++u) {
+        const int id = tid + u * NW * 64;
+        cv[u] = ld4(ct + (id / UPR) * CLD + 4 * (id % UPR));
+    }
+    if (!partial) {
+        act_dispatch(argAct, [&](auto ACT) __attribute__((always_inline)) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_c<decltype(ACT)::value>(v[e] + bv[e]) + rv[u][e];
-            }
-            if (p.Y != nullptr) st4(Y + (size_t)gr * p.ldy + gc, v);
-            if (!partial && p.Ys != nullptr) store_split4(p.Ys + (size_t)gr * p.ldy, gc, v);
+            for (int u = 0; u < UNITS; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cv[u][e] = act_c<decltype(ACT)::value>(cv[u][e] + bv[e]) + rv[u][e];
+        });
+    }
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) {
+        const int id = tid + u * NW * 64;
+        const int gr = row0 + id / UPR, gc = col0 + 4 * (id % UPR);
+        if (gr < argM && gc < argN) {
+            if (argY != nullptr) st4g(Y + (size_t)gr * argLdy + gc, cv[u]);
+            if (!partial && argYs != nullptr) store_split4g(argYs + (size_t)gr * argLdy, gc, cv[u]);
         }
-    });
+    }
     STAMP(6);
 }
 
