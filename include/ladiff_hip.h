@@ -40,7 +40,8 @@ enum {
 };
 
 /* activation codes for ladiff_gemm */
-enum { LADIFF_ACT_NONE = 0, LADIFF_ACT_RELU = 1, LADIFF_ACT_GELU = 2, LADIFF_ACT_SILU = 3, LADIFF_ACT_QGELU = 4 /* x*sigmoid(1.702x) */ };
+enum { LADIFF_ACT_NONE = 0, LADIFF_ACT_RELU = 1, LADIFF_ACT_GELU = 2, LADIFF_ACT_SILU = 3, LADIFF_ACT_QGELU = 4 /* x*sigmoid(1.702x) */,
+       LADIFF_ACT_LRELU = 5 /* LeakyReLU(0.2) */ };
 
 #define LADIFF_ABI_VERSION 1
 #define LADIFF_LATENT_DIM 256     /* model.latent_dim[-1], config_ladiff_humanml3d.yaml:132 */
@@ -219,6 +220,33 @@ size_t ladiff_clip_workspace_bytes(int B, int L);
 int ladiff_clip_text_encode(const float* const* w, const float* const* w_split /*or NULL*/, int n_layers, int vocab,
                             const int64_t* ids, int B, int S, int L, float* out, void* ws, size_t ws_bytes,
                             ladiff_stream_t stream);
+
+/* ------------------------------------------------------------------ T2M evaluator encoders (evaluation)
+ * The three frozen networks `t2m_eval` runs to get the embeddings of the TM2T metrics (ladiff.py:1264-1271), fp32:
+ *   movement: MovementConvEncoder.forward, t2m_motionenc.py:21-25: the first Cin columns of feats[B,F,ld] (the caller
+ *             drops the 4 foot-contact columns, ladiff.py:1264: Cin = nfeats - 4, ld = nfeats) -> out[B, (F/2)/2, 512].
+ *   motion:   MotionEncoderBiGRUCo.forward, t2m_motionenc.py:51-64: movements[B,T,512], m_lens[B] (= lengths / 4,
+ *             1 <= m_lens <= T; the reference's pack_padded_sequence wants them sorted descending, this entry does not
+ *             care) -> out[B,512].
+ *   text:     TextEncoderBiGRUCo.forward, t2m_textenc.py:32-48: word_embs[B,L,300], pos_onehot[B,L,15], cap_lens[B]
+ *             -> out[B,512].
+ * Pointer tables: ladiff_t2m_*_param_name(i) are the keys of the `movement_encoder` / `motion_encoder` / `text_encoder`
+ * state dicts of the evaluator checkpoint (ladiff.py:205-212). */
+int ladiff_t2m_movement_num_params(void);
+const char* ladiff_t2m_movement_param_name(int i);
+int ladiff_t2m_motion_num_params(void);
+const char* ladiff_t2m_motion_param_name(int i);
+int ladiff_t2m_text_num_params(void);
+const char* ladiff_t2m_text_param_name(int i);
+size_t ladiff_t2m_movement_workspace_bytes(int B, int F, int Cin);
+size_t ladiff_t2m_motion_workspace_bytes(int B, int T);
+size_t ladiff_t2m_text_workspace_bytes(int B, int L);
+int ladiff_t2m_movement_encode(const float* const* w, const float* feats, int ld, int B, int F, int Cin, float* out,
+                               void* ws, size_t ws_bytes, ladiff_stream_t stream);
+int ladiff_t2m_motion_encode(const float* const* w, const float* movements, const int32_t* m_lens, int B, int T, float* out,
+                             void* ws, size_t ws_bytes, ladiff_stream_t stream);
+int ladiff_t2m_text_encode(const float* const* w, const float* word_embs, const float* pos_onehot, const int32_t* cap_lens,
+                           int B, int L, float* out, void* ws, size_t ws_bytes, ladiff_stream_t stream);
 
 /* ------------------------------------------------------------------ feats2joints (the step after the path)
  * joints[B,F,njoints,3] = recover_from_ric(feats * std + mean): HumanML3DDataModule.feats2joints

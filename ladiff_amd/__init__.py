@@ -8,5 +8,8 @@ from .modules import LADiffDenoiser, LADiffVae          # noqa: F401
 from .pipeline import LADIFF, instantiate_from_config   # noqa: F401
 from .schedulers import DDIMScheduler, DDPMScheduler    # noqa: F401
 from .text_encoder import MldTextEncoder                # noqa: F401
+from .evaluators import (MovementConvEncoder, MotionEncoderBiGRUCo, TextEncoderBiGRUCo,   # noqa: F401
+                         TM2TMetrics)
 
-__all__ = ["LADiffDenoiser", "LADiffVae", "LADIFF", "DDIMScheduler", "DDPMScheduler", "instantiate_from_config", "Feats2Joints", "MldTextEncoder"]
+__all__ = ["LADiffDenoiser", "LADiffVae", "LADIFF", "DDIMScheduler", "DDPMScheduler", "instantiate_from_config", "Feats2Joints", "MldTextEncoder", "MovementConvEncoder", "MotionEncoderBiGRUCo", "TextEncoderBiGRUCo",
+           "TM2TMetrics"]

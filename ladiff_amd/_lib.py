@@ -73,6 +73,20 @@ _SIGNATURES = {
     "ladiff_clip_workspace_bytes": (c_size_t, [c_int, c_int]),
     "ladiff_clip_text_encode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                         c_size_t, c_void_p]),
+    "ladiff_t2m_movement_num_params": (c_int, []),
+    "ladiff_t2m_movement_param_name": (c_char_p, [c_int]),
+    "ladiff_t2m_motion_num_params": (c_int, []),
+    "ladiff_t2m_motion_param_name": (c_char_p, [c_int]),
+    "ladiff_t2m_text_num_params": (c_int, []),
+    "ladiff_t2m_text_param_name": (c_char_p, [c_int]),
+    "ladiff_t2m_movement_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ladiff_t2m_motion_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "ladiff_t2m_text_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "ladiff_t2m_movement_encode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                                           c_void_p]),
+    "ladiff_t2m_motion_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ladiff_t2m_text_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                                       c_void_p]),
     "ladiff_feats2joints": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ladiff_decoder_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ladiff_vae_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,

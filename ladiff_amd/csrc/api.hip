@@ -396,6 +396,40 @@ int ladiff_clip_text_encode(const float* const* w, const float* const* w_split, 
                             ws_bytes / sizeof(float), S(stream));
 }
 
+// ------------------------------------------------------------------ T2M evaluator encoders
+static bool all_set(const float* const* w, size_t n) {
+    if (w == nullptr) return false;
+    for (size_t i = 0; i < n; ++i)
+        if (w[i] == nullptr) return false;
+    return true;
+}
+static const char* name_at(const std::vector<std::string>& n, int i) { return (i >= 0 && i < (int)n.size()) ? n[i].c_str() : nullptr; }
+int ladiff_t2m_movement_num_params(void) { return (int)t2m_move_param_names().size(); }
+const char* ladiff_t2m_movement_param_name(int i) { return name_at(t2m_move_param_names(), i); }
+int ladiff_t2m_motion_num_params(void) { return (int)t2m_motion_param_names().size(); }
+const char* ladiff_t2m_motion_param_name(int i) { return name_at(t2m_motion_param_names(), i); }
+int ladiff_t2m_text_num_params(void) { return (int)t2m_text_param_names().size(); }
+const char* ladiff_t2m_text_param_name(int i) { return name_at(t2m_text_param_names(), i); }
+size_t ladiff_t2m_movement_workspace_bytes(int B, int F, int Cin) { return t2m_move_ws_floats(B, F, Cin) * sizeof(float); }
+size_t ladiff_t2m_motion_workspace_bytes(int B, int T) { return t2m_motion_ws_floats(B, T) * sizeof(float); }
+size_t ladiff_t2m_text_workspace_bytes(int B, int L) { return t2m_text_ws_floats(B, L) * sizeof(float); }
+
+int ladiff_t2m_movement_encode(const float* const* w, const float* feats, int ld, int B, int F, int Cin, float* out, void* ws,
+                               size_t ws_bytes, ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(all_set(w, t2m_move_param_names().size()) && feats && out && ws && B >= 0);
+    return t2m_movement_encode(w, feats, ld, B, F, Cin, out, (float*)ws, ws_bytes / sizeof(float), S(stream));
+}
+int ladiff_t2m_motion_encode(const float* const* w, const float* movements, const int32_t* m_lens, int B, int T, float* out,
+                             void* ws, size_t ws_bytes, ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(all_set(w, t2m_motion_param_names().size()) && movements && m_lens && out && ws && B >= 0);
+    return t2m_motion_encode(w, movements, m_lens, B, T, out, (float*)ws, ws_bytes / sizeof(float), S(stream));
+}
+int ladiff_t2m_text_encode(const float* const* w, const float* word_embs, const float* pos_onehot, const int32_t* cap_lens,
+                           int B, int L, float* out, void* ws, size_t ws_bytes, ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(all_set(w, t2m_text_param_names().size()) && word_embs && pos_onehot && cap_lens && out && ws && B >= 0);
+    return t2m_text_encode(w, word_embs, pos_onehot, cap_lens, B, L, out, (float*)ws, ws_bytes / sizeof(float), S(stream));
+}
+
 // ------------------------------------------------------------------ feats2joints (the step after the path)
 int ladiff_feats2joints(const float* feats, const float* mean, const float* std, int B, int F, int C, int njoints,
                         float* joints, ladiff_stream_t stream) {

@@ -42,7 +42,7 @@ __device__ __forceinline__ float erf_as(float x) {
 }
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erf_as(v * 0.70710678118654752440f)); }
 
-enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_QGELU = 4 };
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_QGELU = 4, ACT_LRELU = 5 };
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
@@ -50,6 +50,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
         case ACT_GELU: return gelu_erf(v);                                            // erf GELU (F.gelu default)
         case ACT_SILU: return v / (1.f + expf(-v));
         case ACT_QGELU: return v / (1.f + expf(-1.702f * v));                         // CLIP's quick_gelu: x * sigmoid(1.702 x)
+        case ACT_LRELU: return v > 0.f ? v : 0.2f * v;                                // LeakyReLU(0.2) of the T2M evaluators
         default: return v;
     }
 }
@@ -63,6 +64,7 @@ __device__ __forceinline__ float act_c(float v) {
     else if constexpr (ACT == ACT_GELU) return gelu_erf(v);
     else if constexpr (ACT == ACT_SILU) return v / (1.f + expf(-v));
     else if constexpr (ACT == ACT_QGELU) return v / (1.f + expf(-1.702f * v));
+    else if constexpr (ACT == ACT_LRELU) return v > 0.f ? v : 0.2f * v;
     else return v;
 }
 template <int V> struct IntC { static constexpr int value = V; };
@@ -73,6 +75,7 @@ __device__ __forceinline__ void act_dispatch(int act, F&& f) {
         case ACT_GELU: f(IntC<ACT_GELU>{}); break;
         case ACT_SILU: f(IntC<ACT_SILU>{}); break;
         case ACT_QGELU: f(IntC<ACT_QGELU>{}); break;
+        case ACT_LRELU: f(IntC<ACT_LRELU>{}); break;
         default: f(IntC<ACT_NONE>{}); break;
     }
 }

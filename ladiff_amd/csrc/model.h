@@ -44,4 +44,18 @@ size_t clip_ws_floats(int B, int L);
 int clip_text_encode(const ClipW& w, const ClipW* w_split, int n_layers, int vocab, const int64_t* ids, int B, int S, int L,
                      float* out, float* ws, size_t ws_floats, hipStream_t s);
 
+// evaluator.hip: T2M evaluator encoders; tables are pointer arrays in *_param_names() order
+const std::vector<std::string>& t2m_move_param_names();
+const std::vector<std::string>& t2m_motion_param_names();
+const std::vector<std::string>& t2m_text_param_names();
+size_t t2m_move_ws_floats(int B, int F, int Cin);
+size_t t2m_motion_ws_floats(int B, int T);
+size_t t2m_text_ws_floats(int B, int L);
+int t2m_movement_encode(const float* const* w, const float* feats, int ld, int B, int F, int Cin, float* out, float* ws,
+                        size_t ws_floats, hipStream_t s);
+int t2m_motion_encode(const float* const* w, const float* mov, const int32_t* m_lens, int B, int T, float* out, float* ws,
+                      size_t ws_floats, hipStream_t s);
+int t2m_text_encode(const float* const* w, const float* word_embs, const float* pos_onehot, const int32_t* cap_lens, int B, int L,
+                    float* out, float* ws, size_t ws_floats, hipStream_t s);
+
 }  // namespace ladiff

@@ -16,6 +16,7 @@ import math
 import time
 from ctypes import c_void_p, byref
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -28,6 +29,9 @@ _TARGET_ALIASES = {
     "ladiff.models.architectures.ladiff_denoiser.LADiffDenoiser": "ladiff_amd.modules.LADiffDenoiser",
     "ladiff.models.architectures.ladiff_vae.LADiffVae": "ladiff_amd.modules.LADiffVae",
     "ladiff.models.architectures.mld_clip.MldTextEncoder": "ladiff_amd.text_encoder.MldTextEncoder",
+    "ladiff.models.architectures.t2m_textenc.TextEncoderBiGRUCo": "ladiff_amd.evaluators.TextEncoderBiGRUCo",
+    "ladiff.models.architectures.t2m_motionenc.MovementConvEncoder": "ladiff_amd.evaluators.MovementConvEncoder",
+    "ladiff.models.architectures.t2m_motionenc.MotionEncoderBiGRUCo": "ladiff_amd.evaluators.MotionEncoderBiGRUCo",
     "diffusers.DDIMScheduler": "ladiff_amd.schedulers.DDIMScheduler",
     "diffusers.DDPMScheduler": "ladiff_amd.schedulers.DDPMScheduler",
 }
@@ -245,6 +249,43 @@ class LADIFF(nn.Module):
         self.times.append(time.time() - start)
         joints = self.feats2joints(feats_rst.detach().cpu())
         return remove_padding(joints, lengths)
+
+    def set_t2m_evaluators(self, text_encoder, movement_encoder, motion_encoder, unit_len=4):
+        """The three frozen evaluator networks of `_get_t2m_evaluator` (ladiff.py:179-223); `unit_len` =
+        cfg.DATASET.HUMANML3D.UNIT_LEN (ladiff.py:1259-1261)."""
+        self.t2m_textencoder, self.t2m_moveencoder, self.t2m_motionencoder = text_encoder, movement_encoder, motion_encoder
+        self.t2m_unit_len = int(unit_len)
+
+    def t2m_eval(self, batch):
+        """Text -> motion -> evaluator embeddings for the TM2T metrics (`ladiff.py:1111-1282`, diffusion stage): returns the
+        reference's `rs_set` (m_ref, m_rst, lat_t, lat_m, lat_rm, joints_ref, joints_rst), sequences sorted by length."""
+        if getattr(self, "t2m_motionencoder", None) is None:
+            raise RuntimeError("call set_t2m_evaluators(text_encoder, movement_encoder, motion_encoder) first")
+        if self.text_encoder is None or not hasattr(self.datamodule, "renorm4t2m"):
+            raise RuntimeError("t2m_eval needs a text_encoder and datamodule.renorm4t2m / feats2joints")
+        texts, lengths = list(batch["text"]), [int(l) for l in batch["length"]]
+        dev = self.device
+        motions = batch["motion"].detach().clone().to(dev)
+        start = time.time()
+        text_emb = self.text_encoder([""] * len(texts) + texts)                       # ladiff.py:1135-1144
+        z = self._diffusion_reverse(text_emb, lengths)
+        with torch.no_grad():
+            feats_rst = self.vae.decode(z, lengths)        # [B, max(lengths), nfeats], frames >= length are zero (:1196-1207)
+        torch.cuda.synchronize()
+        self.times.append(time.time() - start)
+        f2j = self.feats2joints_device or (lambda f: self.feats2joints(f.detach().cpu()))
+        joints_rst, joints_ref = f2j(feats_rst), f2j(motions)
+        feats_rst = self.datamodule.renorm4t2m(feats_rst)                               # :1244-1246
+        motions = self.datamodule.renorm4t2m(motions)
+        align = np.argsort(lengths)[::-1].copy()                                         # :1249-1258, longest first
+        idx = torch.as_tensor(align, device=dev)
+        motions, feats_rst = motions[idx], feats_rst[idx]
+        m_lens = torch.tensor(lengths, device=dev)[idx] // self.t2m_unit_len
+        recons_emb = self.t2m_motionencoder(self.t2m_moveencoder(feats_rst[..., :-4]), m_lens)
+        motion_emb = self.t2m_motionencoder(self.t2m_moveencoder(motions[..., :-4]), m_lens)
+        text_lat = self.t2m_textencoder(batch["word_embs"].to(dev), batch["pos_ohot"].to(dev), batch["text_len"])[idx]
+        return {"m_ref": motions, "m_rst": feats_rst, "lat_t": text_lat, "lat_m": motion_emb, "lat_rm": recons_emb,
+                "joints_ref": joints_ref, "joints_rst": joints_rst}
 
     def recon_from_motion(self, batch):
         """encode -> decode -> joints of the reconstruction and of the input (ladiff.py:320-331)."""

@@ -146,3 +146,49 @@ def clip_text_schema(vocab_size=49408, num_layers=12, width=768, max_positions=7
     _norm(s, "text_model.final_layer_norm", width)
     s["text_projection.weight"] = (width, width)
     return s
+
+
+def _gru(out, prefix, d_in, d_h):
+    for sfx in ("", "_reverse"):
+        out[f"{prefix}.weight_ih_l0{sfx}"] = (3 * d_h, d_in)
+        out[f"{prefix}.weight_hh_l0{sfx}"] = (3 * d_h, d_h)
+        out[f"{prefix}.bias_ih_l0{sfx}"] = (3 * d_h,)
+        out[f"{prefix}.bias_hh_l0{sfx}"] = (3 * d_h,)
+
+
+def _coemb_head(out, d_h, d_out):
+    _linear(out, "output_net.0", d_h, 2 * d_h)
+    _norm(out, "output_net.1", d_h)
+    _linear(out, "output_net.3", d_out, d_h)
+
+
+def t2m_movement_schema(input_size=259, hidden_size=512, output_size=512):
+    """`MovementConvEncoder` (t2m_motionenc.py:6-19): the `movement_encoder` sub-dict of the evaluator checkpoint."""
+    s = OrderedDict()
+    s["main.0.weight"] = (hidden_size, input_size, 4)
+    s["main.0.bias"] = (hidden_size,)
+    s["main.3.weight"] = (output_size, hidden_size, 4)
+    s["main.3.bias"] = (output_size,)
+    _linear(s, "out_net", output_size, output_size)
+    return s
+
+
+def t2m_motion_schema(input_size=512, hidden_size=1024, output_size=512):
+    """`MotionEncoderBiGRUCo` (t2m_motionenc.py:28-49): the `motion_encoder` sub-dict."""
+    s = OrderedDict()
+    _linear(s, "input_emb", hidden_size, input_size)
+    _gru(s, "gru", hidden_size, hidden_size)
+    _coemb_head(s, hidden_size, output_size)
+    s["hidden"] = (2, 1, hidden_size)
+    return s
+
+
+def t2m_text_schema(word_size=300, pos_size=15, hidden_size=512, output_size=512):
+    """`TextEncoderBiGRUCo` (t2m_textenc.py:6-30): the `text_encoder` sub-dict."""
+    s = OrderedDict()
+    _linear(s, "pos_emb", word_size, pos_size)
+    _linear(s, "input_emb", hidden_size, word_size)
+    _gru(s, "gru", hidden_size, hidden_size)
+    _coemb_head(s, hidden_size, output_size)
+    s["hidden"] = (2, 1, hidden_size)
+    return s

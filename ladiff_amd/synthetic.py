@@ -30,7 +30,7 @@ MAX_IT = 5             # config_ladiff_humanml3d.yaml:58
 def _fill(rs, name, shape):
     if name.endswith(".pe"):
         return rs.uniform(0.0, 1.0, size=shape)
-    if name == "global_motion_token":
+    if name == "global_motion_token" or name == "hidden":
         return rs.standard_normal(size=shape)
     if name.endswith(("token_embedding.weight", "position_embedding.weight")):      # CLIP token / position tables: N(0, 0.02) as transformers initialises them
         return 0.02 * rs.standard_normal(size=shape)
@@ -83,6 +83,13 @@ def clip_token_ids(batch, vocab_size=49408, seq_len=77, max_words=30, seed=TEXT_
         n = 0 if b < empty_first else int(rs.randint(1, min(max_words, seq_len - 2) + 1))
         ids[b, 1:1 + n] = rs.randint(0, vocab_size - 2, size=n)
     return torch.from_numpy(ids)
+
+
+def t2m_weights(nfeats=263, seed=WEIGHT_SEED + 3):
+    """(movement, motion, text) evaluator state dicts; GRU / conv tensors get the Xavier-uniform fill of every >= 2-D tensor."""
+    return (make_state_dict(_schema.t2m_movement_schema(nfeats - 4), seed),
+            make_state_dict(_schema.t2m_motion_schema(), seed + 1),
+            make_state_dict(_schema.t2m_text_schema(), seed + 2))
 
 
 def max_iter_elements(lengths, frame_per_latent=FRAME_PER_LATENT):

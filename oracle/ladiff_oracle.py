@@ -24,6 +24,11 @@ Parity status
   (unpinned, `src/requirements.txt:9`); it is PINNED against transformers 5.15's `CLIPModel.get_text_features`
   as installed in the build container, loaded with the synthetic weights (`tests/golden/make_golden_clip.py`).
 
+* The T2M evaluator encoders are PINNED to the reference's own modules (t2m_motionenc.py, t2m_textenc.py,
+  importable here: torch only) on synthetic weights (`tests/golden/make_golden_t2m.py`); the TM2T metric formulas are
+  pinned to the reference's `metrics/utils.py` helpers (same script) - `TM2TMetrics` itself needs torchmetrics, which is
+  not installed, so its accumulation loop is restated from `metrics/tm2t.py:77-153`.
+
 Everything is written batch-first ([B, T, D]); the reference is sequence-first, which only
 changes strides, not arithmetic.  Each function cites the reference lines it follows.
 """
@@ -463,3 +468,89 @@ def clip_text_features(sd, input_ids, num_layers=12, num_heads=12):
     x = F.layer_norm(x, (W,), sd["text_model.final_layer_norm.weight"], sd["text_model.final_layer_norm.bias"], EPS_LN)
     pooled = x[torch.arange(B), input_ids.argmax(dim=-1)]
     return pooled @ sd["text_projection.weight"].t()
+
+
+# --------------------------------------------------------------------------- T2M evaluators + TM2T metrics
+def t2m_movement_encoder(sd, feats):
+    """`MovementConvEncoder.forward` (t2m_motionenc.py:21-25) on `feats[..., :-4]` (ladiff.py:1264): [B,F,C] -> [B,F/4,512]."""
+    x = feats[..., :-4].permute(0, 2, 1)
+    x = F.leaky_relu(F.conv1d(x, sd["main.0.weight"], sd["main.0.bias"], stride=2, padding=1), 0.2)
+    x = F.leaky_relu(F.conv1d(x, sd["main.3.weight"], sd["main.3.bias"], stride=2, padding=1), 0.2)
+    return linear(x.permute(0, 2, 1), sd["out_net.weight"], sd["out_net.bias"])
+
+
+def gru_bidir_last(sd, x, lens, h0):
+    """Final hidden states of a bidirectional one-layer nn.GRU run over `pack_padded_sequence(x, lens)`: a sample's state
+    advances over its own first `len` steps only (forward 0..len-1, backward len-1..0).  -> [B, 2H]"""
+    B, T, _ = x.shape
+    outs = []
+    for d, sfx in enumerate(("", "_reverse")):
+        wi, wh = sd[f"gru.weight_ih_l0{sfx}"], sd[f"gru.weight_hh_l0{sfx}"]
+        bi, bh = sd[f"gru.bias_ih_l0{sfx}"], sd[f"gru.bias_hh_l0{sfx}"]
+        H = wh.shape[1]
+        h = h0[d].expand(B, H).clone()
+        gi_all = linear(x, wi, bi)
+        for t in (range(T) if d == 0 else range(T - 1, -1, -1)):
+            gi, gh = gi_all[:, t], linear(h, wh, bh)
+            r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+            z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+            n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+            hn = (1 - z) * n + z * h
+            h = torch.where((t < torch.as_tensor(lens)).unsqueeze(1), hn, h)
+        outs.append(h)
+    return torch.cat(outs, dim=-1)
+
+
+def _coemb_head(sd, x):
+    x = linear(x, sd["output_net.0.weight"], sd["output_net.0.bias"])
+    x = F.leaky_relu(layer_norm(x, sd["output_net.1.weight"], sd["output_net.1.bias"]), 0.2)
+    return linear(x, sd["output_net.3.weight"], sd["output_net.3.bias"])
+
+
+def t2m_motion_encoder(sd, movements, m_lens):
+    """`MotionEncoderBiGRUCo.forward` (t2m_motionenc.py:51-64): [B,T,512], lengths -> [B,512]."""
+    emb = linear(movements, sd["input_emb.weight"], sd["input_emb.bias"])
+    return _coemb_head(sd, gru_bidir_last(sd, emb, m_lens, sd["hidden"][:, 0]))
+
+
+def t2m_text_encoder(sd, word_embs, pos_onehot, cap_lens):
+    """`TextEncoderBiGRUCo.forward` (t2m_textenc.py:32-48): [B,L,300], [B,L,15], lengths -> [B,512]."""
+    inputs = word_embs + linear(pos_onehot, sd["pos_emb.weight"], sd["pos_emb.bias"])
+    emb = linear(inputs, sd["input_emb.weight"], sd["input_emb.bias"])
+    return _coemb_head(sd, gru_bidir_last(sd, emb, cap_lens, sd["hidden"][:, 0]))
+
+
+def tm2t_metrics(text_emb, gen_emb, gt_emb, order, div_first, div_second, R_size=32, top_k=3):
+    """`TM2TMetrics.compute` (metrics/tm2t.py:77-153) with its random draws made explicit: `order` = the shuffle of the
+    sequences, `div_first` / `div_second` = the index pairs of the diversity estimate (metrics/utils.py:230-244).
+    Embeddings are [N, 512] tensors; returns a dict of python floats."""
+    import numpy as np
+    import scipy.linalg
+    text, gen, gt = (t[order].double() for t in (text_emb, gen_emb, gt_emb))
+    N = text.shape[0]
+    out = {}
+    for tag, mot in (("", gen), ("gt_", gt)):
+        match, hits = 0.0, torch.zeros(top_k)
+        for i in range(N // R_size):
+            a, b = text[i * R_size:(i + 1) * R_size], mot[i * R_size:(i + 1) * R_size]
+            d = torch.sqrt(-2 * a @ b.T + (a * a).sum(1, keepdim=True) + (b * b).sum(1)).nan_to_num()   # utils.py:26-41
+            match += d.trace().item()
+            rank = torch.argsort(d, dim=1)
+            hit = torch.zeros(R_size, dtype=torch.bool)
+            for k in range(top_k):                                                                        # utils.py:62-75
+                hit = hit | (rank[:, k] == torch.arange(R_size))
+                hits[k] += hit.sum()
+        R = N // R_size * R_size
+        out[tag + "Matching_score"] = match / R
+        for k in range(top_k):
+            out[f"{tag}R_precision_top_{k + 1}"] = (hits[k] / R).item()
+    g, t = gen.numpy(), gt.numpy()
+    mu, cov, mu_t, cov_t = g.mean(0), np.cov(g, rowvar=False), t.mean(0), np.cov(t, rowvar=False)
+    covmean = scipy.linalg.sqrtm(cov_t.dot(cov))                                                         # utils.py:161-211
+    if np.iscomplexobj(covmean):
+        covmean = covmean.real
+    diff = mu_t - mu
+    out["FID"] = float(diff.dot(diff) + np.trace(cov_t) + np.trace(cov) - 2 * np.trace(covmean))
+    out["Diversity"] = float(np.linalg.norm(g[div_first] - g[div_second], axis=1).mean())
+    out["gt_Diversity"] = float(np.linalg.norm(t[div_first] - t[div_second], axis=1).mean())
+    return out

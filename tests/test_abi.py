@@ -58,6 +58,19 @@ def test_clip_table_matches_transformers_key_names():
     assert sum(int(torch.Size(v).numel()) for v in sch.values()) == 123650304     # CLIPTextModelWithProjection, ViT-L/14
 
 
+def test_t2m_evaluator_tables_match_checkpoint_keys():
+    for kind, sch in (("t2m_movement", schema.t2m_movement_schema(259)), ("t2m_motion", schema.t2m_motion_schema()),
+                      ("t2m_text", schema.t2m_text_schema())):
+        assert sorted(_lib.param_names(kind)) == sorted(sch)
+    from ladiff_amd import MotionEncoderBiGRUCo, MovementConvEncoder, TextEncoderBiGRUCo, synthetic as syn
+    mv, mo, tx = syn.t2m_weights(263)
+    MovementConvEncoder(259, 512, 512).load_state_dict(mv, strict=True)
+    MotionEncoderBiGRUCo(512, 1024, 512).load_state_dict(mo, strict=True)
+    TextEncoderBiGRUCo(300, 15, 512, 512).load_state_dict(tx, strict=True)
+    with pytest.raises(NotImplementedError):
+        MotionEncoderBiGRUCo(512, 512, 512)
+
+
 def test_workspace_queries(lib):
     assert lib.ladiff_denoiser_tables_floats(50) == 50 * 9 * 1536
     assert lib.ladiff_denoiser_text_cache_floats(256, 50) == 256 * 256 + 9 * 256 * 512 + 9 * 50 * 257 * 256

@@ -115,3 +115,32 @@ def test_clip_text_features_against_transformers(name):
     assert (out - g["text_features"]).abs().max().item() < 2e-5
     L = int(ids.argmax(-1).max()) + 1                      # the causal mask makes positions behind the EOS irrelevant
     assert torch.equal(orc.clip_text_features(sd, ids[:, :L], layers), out)
+
+
+# ---------------------------------------------------------------- T2M evaluators + TM2T metrics
+@pytest.mark.parametrize("name,nfeats", [("t2m_humanml", 263), ("t2m_kit", 251)])
+def test_t2m_evaluator_encoders_against_reference(name, nfeats):
+    g = load_golden(name)
+    mv, mo, tx = syn.t2m_weights(nfeats)
+    assert maxdiff(orc.t2m_movement_encoder(mv, g["feats"]), g["movements"]) < 1e-5
+    assert maxdiff(orc.t2m_motion_encoder(mo, g["movements"], g["lengths"] // 4), g["motion_emb"]) < 2e-5
+    assert maxdiff(orc.t2m_text_encoder(tx, g["word_embs"], g["pos_onehot"], g["cap_lens"]), g["text_emb"]) < 2e-5
+
+
+def test_tm2t_metrics_against_reference_helpers():
+    """Oracle restatement and the shipped host-side `TM2TMetrics` vs numbers computed with the reference's metrics/utils.py."""
+    from ladiff_amd.evaluators import TM2TMetrics
+    g = load_golden("tm2t_metrics")
+    want = {k: float(g[k]) for k in TM2TMetrics().metrics}
+    got = orc.tm2t_metrics(g["text"], g["gen"], g["gt"], g["order"], g["div_first"], g["div_second"])
+    m = TM2TMetrics()
+    for lo in range(0, 352, 88):                                   # four update() calls, as test batches arrive
+        m.update(g["text"][lo:lo + 88], g["gen"][lo:lo + 88], g["gt"][lo:lo + 88], [196] * 88)
+    shipped = m.compute(order=g["order"].numpy(), div_first=g["div_first"].numpy(), div_second=g["div_second"].numpy())
+    assert m.count_seq == 352 and m.count == 352 * 196
+    for k, v in want.items():
+        tol = 1e-6 * max(1.0, abs(v)) if "R_precision" not in k else 1e-7      # hit counts are exact; the reference divides in fp32
+        assert abs(got[k] - v) <= tol, k
+        assert abs(shipped[k] - v) <= tol, k
+    assert 0 < want["R_precision_top_1"] < want["R_precision_top_3"] < 1       # a case where ranking actually matters
+    assert TM2TMetrics().compute(sanity_flag=True)["FID"] == 0.0
