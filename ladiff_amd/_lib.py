@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libladiff_hip.so")
 MAX_LATENTS = 8
 MAX_FRAMES = 224
 COEF_STRIDE = 8
-ACT = {"none": 0, "relu": 1, "gelu": 2, "silu": 3}
+ACT = {"none": 0, "relu": 1, "gelu": 2, "silu": 3, "qgelu": 4, "lrelu": 5}
 
 
 class LadiffHipError(RuntimeError):

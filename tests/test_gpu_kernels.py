@@ -305,3 +305,35 @@ def test_gemm_resident_split_k_and_combine(M, K, concat):
                                              _lib.ptr(out), _lib.stream_ptr()))
         sync()
         assert (out.cpu().double() - wants[mode]).abs().max().item() < 3e-5, mode
+
+
+# ---------------------------------------------------------------- large-M bf16x3 GEMM (decoder / encoder / CLIP)
+@pytest.mark.parametrize("M,N,K,act,concat,res", [(4100, 256, 256, "none", False, True), (5000, 768, 256, "none", False, False),
+                                                  (4224, 1024, 256, "gelu", False, False), (4099, 256, 1024, "none", False, True),
+                                                  (4160, 256, 512, "none", True, False), (300, 768, 768, "qgelu", False, True),
+                                                  (1, 128, 64, "lrelu", False, False)])
+def test_gemm_split_large_m(M, N, K, act, concat, res):
+    """`ladiff_gemm_split`: 128x128 tiles, 32-k stages, two workgroups per CU; ragged last row tile, concat K, fused residual,
+    both output formats."""
+    K1 = K // 2 if concat else K
+    A, W, b = rnd(M, K, scale=2.0), rnd(N, K, scale=1 / math.sqrt(K)), rnd(N)
+    R = rnd(M, N, seed=9) if res else None
+    As, Ws = to_split(A[:, :K1]), to_split(W)
+    A2s = to_split(A[:, K1:]) if concat else None
+    Y = torch.full((M, N), float("nan"), device=DEV); Ys = torch.zeros(M, N, device=DEV)
+    r_ = None if R is None else R.to(DEV)
+    _lib.check(lib().ladiff_gemm_split(_lib.ptr(As), K1, _lib.ptr(A2s), 0 if A2s is None else K - K1, K1, _lib.ptr(Ws), K,
+                                       _lib.ptr(b.to(DEV)), _lib.ptr(r_), N, _lib.ptr(Y), _lib.ptr(Ys), N, M, N, K,
+                                       _lib.ACT[act], _lib.stream_ptr()))
+    sync()
+    want = A.double() @ W.double().t() + b.double()
+    want = {"none": lambda v: v, "gelu": lambda v: F.gelu(v), "qgelu": lambda v: v * torch.sigmoid(1.702 * v),
+            "lrelu": lambda v: F.leaky_relu(v, 0.2)}[act](want)
+    if R is not None:
+        want = want + R.double()
+    got = Y.cpu()
+    bound = 4 * 2.0 ** -16 * (A.abs().double() @ W.abs().double().t()).max().item() + 2e-6
+    assert torch.isfinite(got).all() and (got.double() - want).abs().max().item() < bound
+    assert (from_split(Ys).double() - got.double()).abs().max().item() <= 2.0 ** -15 * got.abs().max().item()
+    assert lib().ladiff_gemm_split(_lib.ptr(As), K1, None, 0, K1, _lib.ptr(Ws), K, None, None, 0, _lib.ptr(Y), None, N, M, 100,
+                                   K, 0, _lib.stream_ptr()) == -2          # N must be a multiple of 128
