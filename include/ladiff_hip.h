@@ -114,6 +114,12 @@ int ladiff_layernorm(const float* x, const float* gamma, const float* beta, floa
 int ladiff_decoder_self_attention(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out,
                                   int B, int F, ladiff_stream_t stream);
 
+/* The same core in bf16x3 arithmetic (q, k, v and the probabilities as bf16 hi + lo pairs, three bf16 MFMAs per product,
+ * fp32 softmax and accumulation) for any number of 64-wide heads: qkv[B*F, 3*64*nheads] packed [q | k | v],
+ * out[B*F, 64*nheads] fp32.  lengths and keybits may both be NULL (all keys valid); causal != 0 adds key <= query. */
+int ladiff_self_attention_bf16x3(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
+                                 int nheads, int causal, ladiff_stream_t stream);
+
 /* Decoder cross-attention core: q[B*F,256] against the T memory tokens kv[T*B,512] (row = t*B+b,
  * K | V), tokens >= counts[b] masked.  cross_attention.py:373-376. */
 int ladiff_decoder_cross_attention(const float* q, const float* kv, const int32_t* counts, float* out,

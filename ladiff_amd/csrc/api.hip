@@ -170,6 +170,12 @@ int ladiff_decoder_self_attention(const float* qkv, const int32_t* lengths, cons
     return launch_decoder_self_attention(qkv, lengths, keybits, out, B, F, 0, S(stream));
 }
 
+int ladiff_self_attention_bf16x3(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
+                                 int nheads, int causal, ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(qkv && out && B >= 0);
+    return launch_self_attention_bf16x3(qkv, lengths, keybits, out, B, F, nheads, causal, 0, S(stream));
+}
+
 int ladiff_decoder_cross_attention(const float* q, const float* kv, const int32_t* counts, float* out, int B, int F,
                                    int T, ladiff_stream_t stream) {
     LADIFF_CHECK_ARG(q && kv && out && B >= 0 && F >= 0);

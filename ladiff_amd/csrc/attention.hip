@@ -155,6 +155,224 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const float* __restr
     }
 }
 
+// ---- bf16x3 version (precision mode "bf16x3"): the same S^T / O^T formulation on v_mfma_f32_32x32x16_bf16 with every
+// product evaluated as lo*hi + hi*lo + hi*hi of bf16 pairs (q, k, v and the probabilities are split; fp32 accumulate,
+// fp32 softmax).  The fp32 MFMA (32x32x2, 64 cycles) made the fp32 kernel matrix-pipe-bound at 28.7 k cycles per query
+// tile; here the two products take 5.4 k.  One workgroup per (sample, head), 8 waves = up to 7 query tiles, so K / V are
+// staged once.  LDS: K as [key][64 d] bf16 hi / lo planes (16-byte chunk c of row r at c ^ ((r >> 1) & 7)), V transposed
+// to [d][key] hi / lo planes (row stride 232 keys) so that the k = key operand of O^T += V^T . P^T is two 8-byte reads:
+// the accumulator tile of S^T has its query on the lane and its keys in the 16 registers, so registers 8m .. 8m+7 are,
+// unmoved, the B operand of MFMA m of a key tile (keys 16m + 4g + {0..3, 8..11}); V^T is read with the same key map.
+constexpr int SB_VLD = 232;                    // keys per row of the transposed V planes (464 B, multiple of 8)
+
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { hi[e] = (__bf16)v[e]; lo[e] = (__bf16)(v[e] - (float)hi[e]); }
+}
+
+__global__ __launch_bounds__(512) void self_attn_bf16x3_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ lengths,
+                                                               const uint32_t* __restrict__ keybits, float* __restrict__ out,
+                                                               int B, int F, int split_out, const AttnGeom g) {
+    __shared__ __attribute__((aligned(16))) __bf16 Kp[2 * SA_FMAX * DH];      // hi plane, lo plane; first the fp32 staging of V
+    __shared__ __attribute__((aligned(16))) __bf16 Vt[2 * DH * SB_VLD];       // hi plane, lo plane, [d][key]
+    __bf16* const Kh = Kp; __bf16* const Kl = Kp + SA_FMAX * DH;
+    __bf16* const Vth = Vt; __bf16* const Vtl = Vt + DH * SB_VLD;
+    float* const Vtmp = reinterpret_cast<float*>(Kp);                         // [key][64] fp32 = exactly the two K planes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / g.nheads, h = blockIdx.x % g.nheads;
+    int len = F;
+    uint32_t kb[SA_NKT + 1];
+    if (keybits != nullptr) {
+        len = 1;
+#pragma unroll
+        for (int i = 0; i < SA_NKT; ++i) {
+            kb[i] = keybits[(size_t)b * 8 + i];
+            if (kb[i]) len = 32 * i + 32 - __builtin_clz(kb[i]);
+        }
+        len = len > F ? F : len;
+    } else {
+        len = lengths != nullptr ? lengths[b] : F;
+        len = len < 1 ? 1 : (len > F ? F : len);
+#pragma unroll
+        for (int i = 0; i < SA_NKT; ++i) kb[i] = len >= 32 * i + 32 ? 0xFFFFFFFFu : (len > 32 * i ? (1u << (len - 32 * i)) - 1u : 0u);
+    }
+    const int nkt = (len + 31) >> 5;
+    const size_t base = (size_t)b * F * g.ld + h * DH;
+
+    // ---- staging.  All global loads first (7 x (k, v) float4 per thread), V through an fp32 image for the transpose.
+    f32x4 kk[7], vv[7];
+#pragma unroll
+    for (int it = 0; it < 7; ++it) {
+        const int id = tid + it * 512, r = id >> 4, c = id & 15;
+        kk[it] = f32x4{0.f, 0.f, 0.f, 0.f}; vv[it] = kk[it];
+        if (r < nkt * 32 && r < F) {
+            const float* src = qkv + base + (size_t)r * g.ld + c * 4;
+            kk[it] = ld4(src + g.koff);
+            vv[it] = ld4(src + g.voff);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 7; ++it) {
+        const int id = tid + it * 512, r = id >> 4, c = id & 15;
+        if (r < nkt * 32) st4(Vtmp + r * DH + c * 4, vv[it]);
+    }
+    __syncthreads();
+    {   // transpose + split: thread (d, key group) turns 4 keys of column d into 8 bytes of each plane
+        const int d = tid & 63, kg = tid >> 6;
+        for (int p = 0; p < 7; ++p) {
+            const int k0 = (p * 8 + kg) * 4;
+            if (k0 < nkt * 32) {
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = Vtmp[(k0 + e) * DH + d];
+                    hi[e] = (__bf16)v; lo[e] = (__bf16)(v - (float)hi[e]);
+                }
+                *reinterpret_cast<bf16x4*>(Vth + d * SB_VLD + k0) = hi;
+                *reinterpret_cast<bf16x4*>(Vtl + d * SB_VLD + k0) = lo;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 7; ++it) {
+        const int id = tid + it * 512, r = id >> 4, c = id & 15;
+        if (r < nkt * 32) {
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { hi[e] = (__bf16)kk[it][e]; lo[e] = (__bf16)(kk[it][e] - (float)hi[e]); }
+            const int off = r * DH + ((((c >> 1) ^ ((r >> 1) & 7)) << 3) | ((c & 1) << 2));   // bf16 elements
+            *reinterpret_cast<bf16x4*>(Kh + off) = hi;
+            *reinterpret_cast<bf16x4*>(Kl + off) = lo;
+        }
+    }
+    __syncthreads();
+
+    const int qt = wave;
+    if (qt * 32 >= F) return;
+    const int q = lane & 31, h2 = lane >> 5;
+    const int qrow = qt * 32 + q;
+
+    bf16x8 qh[4], ql[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (qrow < F) {
+            const f32x4 a = ld4(qkv + base + (size_t)qrow * g.ld + 16 * ks + 8 * h2);
+            const f32x4 c = ld4(qkv + base + (size_t)qrow * g.ld + 16 * ks + 8 * h2 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = a[e] * 0.125f; v[4 + e] = c[e] * 0.125f; }     // q / sqrt(64), exact
+        }
+        split8(v, qh[ks], ql[ks]);
+    }
+
+    f32x16 sT[SA_NKT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < SA_NKT; ++kt) {
+        if (kt < nkt) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            const int r = kt * 32 + q;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = r * DH + (((2 * ks + h2) ^ ((r >> 1) & 7)) << 3);
+                const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + off);
+                const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + off);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kin = (i & 3) + 8 * (i >> 2) + 4 * h2;
+                const bool ok = ((kb[kt] >> kin) & 1u) && (!g.causal || kt * 32 + kin <= qrow);
+                const float s = ok ? acc[i] : -INFINITY;
+                acc[i] = s;
+                m = fmaxf(m, s);
+            }
+            sT[kt] = acc;
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < SA_NKT; ++kt) {
+        if (kt < nkt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pv = expf(sT[kt][i] - m);
+                sT[kt][i] = pv;
+                l += pv;
+            }
+        }
+    }
+    l += __shfl_xor(l, 32, 64);
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+#pragma unroll
+    for (int kt = 0; kt < SA_NKT; ++kt) {
+        if (kt < nkt) {
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                float pv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pv[j] = sT[kt][8 * mm + j];
+                bf16x8 ph, pl;
+                split8(pv, ph, pl);
+                const int k1 = 32 * kt + 16 * mm + 4 * h2;            // keys k1 .. k1+3 and k1+8 .. k1+11
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int voff = (32 * t + q) * SB_VLD + k1;
+                    const bf16x4 h_a = *reinterpret_cast<const bf16x4*>(Vth + voff), h_b = *reinterpret_cast<const bf16x4*>(Vth + voff + 8);
+                    const bf16x4 l_a = *reinterpret_cast<const bf16x4*>(Vtl + voff), l_b = *reinterpret_cast<const bf16x4*>(Vtl + voff + 8);
+                    const bf16x8 vh = {h_a[0], h_a[1], h_a[2], h_a[3], h_b[0], h_b[1], h_b[2], h_b[3]};
+                    const bf16x8 vl = {l_a[0], l_a[1], l_a[2], l_a[3], l_b[0], l_b[1], l_b[2], l_b[3]};
+                    f32x16& o = t == 0 ? o0 : o1;
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o, 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    if (qrow < F) {
+        const float inv = 1.f / l;
+        float* rowp = out + ((size_t)b * F + qrow) * g.out_ld;
+        const int c0 = h * DH + 4 * h2;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            f32x4 v0, v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] = o0[4 * rg + e] * inv; v1[e] = o1[4 * rg + e] * inv; }
+            if (split_out) {
+                store_split4(rowp, c0 + 8 * rg, v0);
+                store_split4(rowp, c0 + 32 + 8 * rg, v1);
+            } else {
+                st4(rowp + c0 + 8 * rg, v0);
+                st4(rowp + c0 + 32 + 8 * rg, v1);
+            }
+        }
+    }
+}
+
+// bf16x3 entry (same arguments as launch_self_attention)
+int launch_self_attention_bf16x3(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
+                                 int nheads, int causal, int split_out, hipStream_t s) {
+    if (F > SA_FMAX || F < 1 || nheads < 1) return LADIFF_ERR_SHAPE;
+    if (B == 0) return 0;
+    const int W = nheads * DH;
+    const AttnGeom g{nheads, 3 * W, W, 2 * W, W, causal};
+    hipLaunchKernelGGL(self_attn_bf16x3_kernel, dim3(B * nheads), dim3(512), 0, s, qkv, lengths, keybits, out, B, F, split_out, g);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
 // generic entry: `nheads` heads of 64, packed rows [q | k | v] of width 3 * 64 * nheads, optional causal mask
 int launch_self_attention(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F, int nheads,
                           int causal, int split_out, hipStream_t s) {

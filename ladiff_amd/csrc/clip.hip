@@ -157,7 +157,8 @@ int clip_text_encode(const ClipW& w, const ClipW* wsp, int n_layers, int vocab, 
         LADIFF_TRY(gemm(h, CW, W.q, Ws.q, qkv, 3 * CW, CW, ACT_NONE, nullptr, false));
         LADIFF_TRY(gemm(h, CW, W.k, Ws.k, qkv + CW, 3 * CW, CW, ACT_NONE, nullptr, false));
         LADIFF_TRY(gemm(h, CW, W.v, Ws.v, qkv + 2 * CW, 3 * CW, CW, ACT_NONE, nullptr, false));
-        LADIFF_TRY(launch_self_attention(qkv, nullptr, nullptr, att, B, L, CH, 1, sp ? 1 : 0, s));
+        if (sp) LADIFF_TRY(launch_self_attention_bf16x3(qkv, nullptr, nullptr, att, B, L, CH, 1, 1, s));
+        else LADIFF_TRY(launch_self_attention(qkv, nullptr, nullptr, att, B, L, CH, 1, 0, s));
         LADIFF_TRY(gemm(att, CW, W.o, Ws.o, x2, CW, CW, ACT_NONE, x, false));             // x2 = x + out_proj(attn)
         LADIFF_TRY(ln_rows(x2, nullptr, 0, W.ln2, M, sp ? nullptr : h, sp ? h : nullptr, s));
         LADIFF_TRY(gemm(h, CW, W.fc1, Ws.fc1, mlp, CFF, CFF, ACT_QGELU, nullptr, true));  // quick_gelu(fc1)

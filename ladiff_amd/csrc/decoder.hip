@@ -83,7 +83,8 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
             g.split = sp ? 1 : 0;
             LADIFF_TRY(launch_gemm(g, s));
         }
-        LADIFF_TRY(launch_decoder_self_attention(qkv, lengths, nullptr, att, B, F, sp ? 1 : 0, s));
+        if (sp) LADIFF_TRY(launch_self_attention_bf16x3(qkv, lengths, nullptr, att, B, F, H, 0, 1, s));
+        else LADIFF_TRY(launch_decoder_self_attention(qkv, lengths, nullptr, att, B, F, 0, s));
         LADIFF_TRY(gemm_ln(att, D, L.self_attn.out_w, Ls.self_attn.out_w, L.self_attn.out_b, cur, L.norm1, nullptr, P[1], Ps[1]));
         // ---- cross-attention to the latent tokens, tokens >= ceil(len/48) masked   :373-376, :408-409
         {

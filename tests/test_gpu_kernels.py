@@ -337,3 +337,43 @@ def test_gemm_split_large_m(M, N, K, act, concat, res):
     assert (from_split(Ys).double() - got.double()).abs().max().item() <= 2.0 ** -15 * got.abs().max().item()
     assert lib().ladiff_gemm_split(_lib.ptr(As), K1, None, 0, K1, _lib.ptr(Ws), K, None, None, 0, _lib.ptr(Y), None, N, M, 100,
                                    K, 0, _lib.stream_ptr()) == -2          # N must be a multiple of 128
+
+
+# ---------------------------------------------------------------- self-attention core, bf16x3 arithmetic
+@pytest.mark.parametrize("lengths,nheads,causal", [([196, 196, 60], 4, 0), ([1, 33, 32, 31, 101], 4, 0), ([224, 200], 4, 0),
+                                                   ([5], 4, 0), ([77, 77, 77], 12, 1), ([20, 20], 12, 1), ([128, 129, 97], 4, 0)])
+def test_self_attention_bf16x3(lengths, nheads, causal):
+    """q, k, v and the probabilities as bf16 hi + lo pairs (3 MFMAs per product): ~2^-16 relative per product."""
+    B, Fr, W = len(lengths), max(lengths), 64 * nheads
+    qkv = rnd(B * Fr, 3 * W, scale=2.0)
+    out = torch.full((B * Fr, W), float("nan"), device=DEV)
+    qd = qkv.to(DEV)
+    ld = None if causal else torch.tensor(lengths, dtype=torch.int32, device=DEV)
+    _lib.check(lib().ladiff_self_attention_bf16x3(_lib.ptr(qd), None if ld is None else ld.data_ptr(), None, _lib.ptr(out), B, Fr,
+                                                  nheads, causal, _lib.stream_ptr()))
+    sync()
+    q, k, v = qkv.double().view(B, Fr, 3, nheads, 64).permute(2, 0, 3, 1, 4)
+    s = (q * 0.125) @ k.transpose(-1, -2)
+    if causal:
+        s = s + torch.full((Fr, Fr), float("-inf"), dtype=torch.float64).triu(1)
+    else:
+        s = s.masked_fill((~orc.lengths_to_mask(lengths, Fr))[:, None, None, :], float("-inf"))
+    want = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * Fr, W)
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    assert (got.double() - want).abs().max().item() < 2e-4                 # scores up to ~|30|: 2^-16 of that moves a softmax weight by 5e-4 relative
+
+
+def test_self_attention_bf16x3_key_bitmap_matches_fp32_kernel():
+    """Arbitrary 256-bit key maps (LA-VAE encoder): same masks as the fp32 kernel, values within the bf16x3 budget."""
+    B, Fr = 3, 206
+    valid = torch.rand(B, Fr, generator=torch.Generator().manual_seed(4)) > 0.3
+    valid[:, 0] = True
+    qkv = rnd(B * Fr, 768, scale=1.5)
+    bits = key_bitmap(valid).to(DEV)
+    qd = qkv.to(DEV)
+    a, b_ = torch.empty(B * Fr, 256, device=DEV), torch.empty(B * Fr, 256, device=DEV)
+    _lib.check(lib().ladiff_decoder_self_attention(_lib.ptr(qd), None, bits.data_ptr(), _lib.ptr(a), B, Fr, _lib.stream_ptr()))
+    _lib.check(lib().ladiff_self_attention_bf16x3(_lib.ptr(qd), None, bits.data_ptr(), _lib.ptr(b_), B, Fr, 4, 0, _lib.stream_ptr()))
+    sync()
+    assert (a - b_).abs().max().item() < 2e-4 and (a - b_).abs().max().item() > 0
