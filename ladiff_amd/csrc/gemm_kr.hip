@@ -232,23 +232,26 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
 // 1 / WK of the K slice - with 16x16x32 MFMAs a wave tile of tm x tn reads (1/tm + 1/tn) * 4 bytes of LDS per MAC, and an
 // 80 x 16 wave tile (four waves side by side) ran at LDS-read speed, not at matrix-pipe speed.  The K parts are summed in
 // the staged epilogue.  The producers signal "phase landed" through the workgroup barrier: counted s_waitcnt vmcnt with
-// the next phase's first half already in flight.  Stamps (profiles/r1/06): stores issued at 6.9 k cycles after
-// workgroup start, 11.7 k for the previous all-waves-do-everything kernel.
+// the next sub-slice already in flight; the consumers take the four 64-wide sub-slices one by one (wave wk its 32-k
+// half), so they trail the fill by one sub-slice.  Stamps: stores issued 6.5 k cycles after workgroup start (11.7 k for
+// the previous all-waves-do-everything kernel, 6.9 k with two phases of two sub-slices); an empty kernel with this
+// launch geometry costs 1.7 us per launch, the real one 5.4 us (scripts/ubench_empty.py).
 template <int BM, int BN, int WN, int WK>
 __global__ __launch_bounds__(512) void gemm_kp_kernel(const KrArgs p) {
-    static_assert(WN == 2 && WK == 2, "four consumer waves: 2 (N halves) x 2 (K halves); two phases");
+    static_assert(WN == 2 && WK == 2, "four consumer waves: 2 (N halves) x 2 (K halves of every 64-wide sub-slice)");
     constexpr int MT = 16;
     constexpr int TNW = BN / WN;
     constexpr int RM = BM / MT, RN = TNW / MT;
     constexpr int ROWS = BM + BN;
     constexpr int SUB = ROWS * 64;
     constexpr int GA = BM / 16, GT = ROWS / 16;    // 16-row groups = DMA pieces per producer wave per sub-slice
-    constexpr int NPH = 4 / WK;                    // phases: in phase ph, consumer (wn, wk) reads sub-slice ph * WK + wk
-    constexpr int H1 = (WK + 1) / 2;               // sub-slices of the next phase issued before the current one is signalled
-    static_assert(WK * GT <= 63, "vmcnt is 6 bits");
+    static_assert(2 * GT <= 63, "vmcnt is 6 bits");
     static_assert(BM % 16 == 0 && BN % (16 * WN) == 0, "tiles are multiples of 16 rows");
 
     __shared__ __attribute__((aligned(1024))) float lds[4 * SUB];
+#ifdef LADIFF_STAMPS
+    if (p.stamps == reinterpret_cast<unsigned long long*>(1)) { if (threadIdx.x == 9999) lds[0] = 0.f; return; }   // empty-launch probe
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -343,15 +346,15 @@ __global__ __launch_bounds__(512) void gemm_kp_kernel(const KrArgs p) {
 #pragma unroll
                 for (int g = 0; g < GT; ++g) issue(s, g);
         };
-        issue_subs(0, WK);
-        if constexpr (NPH == 1) {
-            wait_vmcnt<0>(); __builtin_amdgcn_s_barrier();
-        } else {
-            issue_subs(WK, WK + H1);
-            wait_vmcnt<H1 * GT>(); __builtin_amdgcn_s_barrier();       // phase 0 landed
-            issue_subs(WK + H1, 2 * WK);
-            wait_vmcnt<0>(); __builtin_amdgcn_s_barrier();             // phase 1 landed
-        }
+        // four phases = the four 64-wide sub-slices; a sub-slice is signalled when it has landed, with the next one already
+        // in flight (counted vmcnt): the consumers trail the fill by one sub-slice instead of half the K slice
+        issue_subs(0, 2);
+        wait_vmcnt<GT>(); __builtin_amdgcn_s_barrier();                // sub-slice 0 landed
+        issue_subs(2, 3);
+        wait_vmcnt<GT>(); __builtin_amdgcn_s_barrier();                // 1
+        issue_subs(3, 4);
+        wait_vmcnt<GT>(); __builtin_amdgcn_s_barrier();                // 2
+        wait_vmcnt<0>(); __builtin_amdgcn_s_barrier();                 // 3
         prefetch_epilogue();
         __builtin_amdgcn_s_barrier();                                  // C planes staged
         store_tile();
@@ -370,50 +373,46 @@ __global__ __launch_bounds__(512) void gemm_kp_kernel(const KrArgs p) {
 
     const int frow = lane & 15, fk = lane >> 4;
     auto phase = [&](int ph) __attribute__((always_inline)) {
-        const int s = ph * WK + wk;
-        const float* sa = lds + s * SUB;
-        const float* sb = lds + s * SUB + (BM + wn * TNW) * 64;
-        // both 32-k steps' fragments are requested up front: the second set streams in under the first set's MFMAs
-        bf16x8 ah[2][RM], al[2][RM], bh[2][RN], bl[2][RN];
+        // sub-slice ph, 32-k half wk: 16-byte slots 4 wk + fk (hi) and 8 + 4 wk + fk (lo)
+        const float* sa = lds + ph * SUB;
+        const float* sb = lds + ph * SUB + (BM + wn * TNW) * 64;
+        const int ch = 4 * wk + fk, cl = 8 + 4 * wk + fk;
+        bf16x8 ah[RM], al[RM], bh[RN], bl[RN];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int ch = 4 * g + fk, cl = 8 + 4 * g + fk;
-#pragma unroll
-            for (int i = 0; i < RM; ++i) {
-                const int r = i * MT + frow, x = r & 15;
-                ah[g][i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((ch ^ x) << 2)));
-                al[g][i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((cl ^ x) << 2)));
-            }
-#pragma unroll
-            for (int j = 0; j < RN; ++j) {
-                const int r = j * MT + frow, x = (BM + wn * TNW + r) & 15;
-                bh[g][j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((ch ^ x) << 2)));
-                bl[g][j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((cl ^ x) << 2)));
-            }
+        for (int i = 0; i < RM; ++i) {
+            const int r = i * MT + frow, x = r & 15;
+            ah[i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((ch ^ x) << 2)));
+            al[i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((cl ^ x) << 2)));
         }
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-#pragma unroll
-            for (int i = 0; i < RM; ++i)
-#pragma unroll
-                for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[g][i], bh[g][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < RM; ++i)
-#pragma unroll
-                for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g][i], bl[g][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < RM; ++i)
-#pragma unroll
-                for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g][i], bh[g][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < RN; ++j) {
+            const int r = j * MT + frow, x = (BM + wn * TNW + r) & 15;
+            bh[j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((ch ^ x) << 2)));
+            bl[j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((cl ^ x) << 2)));
         }
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
     };
 
     STAMP(0);
-    __builtin_amdgcn_s_barrier();                  // phase 0 landed
+    __builtin_amdgcn_s_barrier();                  // sub-slice 0 landed
     STAMP(1);
     phase(0);
     STAMP(2);
-    if constexpr (NPH > 1) { __builtin_amdgcn_s_barrier(); STAMP(3); phase(1); }
+    __builtin_amdgcn_s_barrier(); phase(1);
+    STAMP(3);
+    __builtin_amdgcn_s_barrier(); phase(2);
+    __builtin_amdgcn_s_barrier(); phase(3);
     STAMP(4);
     float* ct = lds + wk * SUB;                    // phase-0 sub-slice of this K half: free since the phase-1 barrier
 #pragma unroll
