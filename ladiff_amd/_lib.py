@@ -183,5 +183,25 @@ class WeightTable:
         return tuple((tensors[n].data_ptr(), tensors[n]._version) for n in kind_names)
 
 
+_INT_CACHE = {}
+
+
+def device_ints(values, device):
+    """int32 device tensor of a short host list (lengths, latent counts).  A pageable host-to-device copy blocks the host
+    until the stream has drained, which would serialise the host behind a whole sampling pass; the values go through a
+    pinned buffer with a non-blocking copy, and recently used lists (batches repeat their lengths) are served from a
+    small cache."""
+    key = (tuple(int(v) for v in values), str(device))
+    t = _INT_CACHE.get(key)
+    if t is None:
+        if len(_INT_CACHE) >= 64:
+            _INT_CACHE.pop(next(iter(_INT_CACHE)))
+        host = torch.tensor(key[0], dtype=torch.int32).pin_memory()
+        t = host.to(device, non_blocking=True)
+        t._ladiff_host = host                       # keep the pinned source alive until the copy has run
+        _INT_CACHE[key] = t
+    return t
+
+
 def workspace(nbytes, device):
     return torch.empty((int(nbytes) + 3) // 4, dtype=torch.float32, device=device)

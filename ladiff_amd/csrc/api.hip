@@ -57,12 +57,13 @@ ReverseWs carve_reverse(void* ws, int B, int T, int n) {
 
 struct Sampler {
     hipGraphExec_t exec = nullptr;
+    hipGraphExec_t setup = nullptr;       // per-call prologue (text cache, initial latents, counter reset, first network input)
     int unroll = 1;                       // denoiser steps captured per graph launch
     int chains = 1;                       // sample ranges captured as parallel graph branches (measured: no gain)
     hipStream_t side[MAX_CHAINS - 1] = {nullptr};
     hipEvent_t fork = nullptr, join[MAX_CHAINS - 1] = {nullptr};
     // capture key: a graph bakes pointers and shapes into its kernel nodes
-    const void* key_ptrs[8] = {nullptr};
+    const void* key_ptrs[10] = {nullptr};
     int key_ints[4] = {0};
     float key_g = 0.f;
 };
@@ -255,6 +256,7 @@ int ladiff_sampler_destroy(void* sampler) {
     Sampler* sp = reinterpret_cast<Sampler*>(sampler);
     if (sp == nullptr) return 0;
     if (sp->exec) (void)hipGraphExecDestroy(sp->exec);
+    if (sp->setup) (void)hipGraphExecDestroy(sp->setup);
     if (sp->fork) (void)hipEventDestroy(sp->fork);
     for (int i = 0; i < MAX_CHAINS - 1; ++i) {
         if (sp->join[i]) (void)hipEventDestroy(sp->join[i]);
@@ -287,23 +289,27 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
     hipStream_t s = S(stream);
     const int B2 = 2 * B;
 
-    // hoisted, once per call: time tables for every step, text cache, initial latents, step counter
-    // the time tables depend on (weights, schedule) only: a caller that re-runs with both unchanged in the same
-    // workspace may keep them (saves ~30 small GEMM launches per call)
-    if (!reuse_time_tables) LADIFF_TRY(denoiser_time_tables(W, sinusoid, n_steps, r.tables, r.fwd, r.fwd_floats, s));
-    LADIFF_TRY(denoiser_text_cache(W, text_emb, B2, r.tables, n_steps, r.cache, r.fwd, r.fwd_floats, s));
-    LADIFF_TRY(launch_init_latents(init_noise, counts, init_noise_sigma, r.latents, B, T, s));
-    LADIFF_HIP(hipMemsetAsync(r.d_step, 0, 2 * sizeof(int32_t), s));      // [0] step index, [1] tail-kernel ticket
-
     Sampler* sp = reinterpret_cast<Sampler*>(sampler);
-    // One step = the nine denoiser layers + ONE tail launch (final LayerNorm of both branches, guidance, scheduler step,
-    // next step's network input, step counter).  The network input / last-layer output buffer of the forward workspace
-    // is primed once before the loop.  `chains` > 1 (LADIFF_CHAINS, diagnostic) splits the batch into parallel graph
-    // branches with the un-fused tail; measured: no gain.
     float *xio = nullptr, *xios = nullptr;
     den_loop_io(r.fwd, B2 * T, &xio, &xios);
     if (WSp == nullptr) xios = nullptr;
-    LADIFF_TRY(launch_add_pe(r.latents, W.query_pe, B, 0, B2, T, xio, xios, s));
+
+    // hoisted, once per call: time tables for every step, text cache, initial latents, step counter, first network input.
+    // The time tables depend on (weights, schedule) only: a caller that re-runs with both unchanged in the same workspace
+    // may keep them (saves ~30 small GEMM launches per call).  The rest (~50 small launches) depends on this call's text
+    // and noise; with a sampler it is replayed as a graph so that the host does not pace the GPU through it.
+    if (!reuse_time_tables) LADIFF_TRY(denoiser_time_tables(W, sinusoid, n_steps, r.tables, r.fwd, r.fwd_floats, s));
+    auto prologue = [&](hipStream_t st) -> int {
+        LADIFF_TRY(denoiser_text_cache(W, text_emb, B2, r.tables, n_steps, r.cache, r.fwd, r.fwd_floats, st));
+        LADIFF_TRY(launch_init_latents(init_noise, counts, init_noise_sigma, r.latents, B, T, st));
+        LADIFF_HIP(hipMemsetAsync(r.d_step, 0, 2 * sizeof(int32_t), st));      // [0] step index, [1] tail-kernel ticket
+        // One step = the nine denoiser layers + ONE tail launch (final LayerNorm of both branches, guidance, scheduler step,
+        // next step's network input, step counter).  The network input / last-layer output buffer of the forward workspace
+        // is primed here.  `chains` > 1 (LADIFF_CHAINS, diagnostic) splits the batch into parallel graph branches with the
+        // un-fused tail; measured: no gain.
+        return launch_add_pe(r.latents, W.query_pe, B, 0, B2, T, xio, xios, st);
+    };
+    if (sp == nullptr) LADIFF_TRY(prologue(s));
     auto one_step = [&](hipStream_t st, int chains) -> int {
         if (chains <= 1) {
             LADIFF_TRY(denoiser_forward(W, WSp, r.tables, r.d_step, r.cache, n_steps, r.latents, B, 2, T, counts, r.eps, r.fwd,
@@ -328,13 +334,26 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
     if (sp == nullptr) {
         for (int i = 0; i < n_steps; ++i) LADIFF_TRY(one_step(s, 1));
     } else {
-        const void* kp[8] = {w, w[0], ws, counts, coef, step_noise, stream, w_split ? (const void*)w_split[0] : nullptr};
+        const void* kp[10] = {w, w[0], ws, counts, coef, step_noise, stream, w_split ? (const void*)w_split[0] : nullptr,
+                              text_emb, init_noise};
         const int ki[4] = {B, T, n_steps, sp->chains};
         const bool same = sp->exec && std::memcmp(kp, sp->key_ptrs, sizeof(kp)) == 0 &&
                           std::memcmp(ki, sp->key_ints, sizeof(ki)) == 0 && sp->key_g == guidance_scale;
         if (!same) {
             if (sp->exec) { (void)hipGraphExecDestroy(sp->exec); sp->exec = nullptr; }
+            if (sp->setup) { (void)hipGraphExecDestroy(sp->setup); sp->setup = nullptr; }
             hipGraph_t graph = nullptr;
+            {   // prologue graph
+                LADIFF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                const int rc0 = prologue(s);
+                const hipError_t e0 = hipStreamEndCapture(s, &graph);
+                if (rc0 != 0) { if (graph) (void)hipGraphDestroy(graph); return rc0; }
+                LADIFF_HIP(e0);
+                const hipError_t i0 = hipGraphInstantiate(&sp->setup, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                graph = nullptr;
+                LADIFF_HIP(i0);
+            }
             LADIFF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             // several steps per graph launch (the step index lives in device memory): fewer ~9 us replay gaps
             int unroll = 1;
@@ -352,6 +371,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
             std::memcpy(sp->key_ints, ki, sizeof(ki));
             sp->key_g = guidance_scale;
         }
+        LADIFF_HIP(hipGraphLaunch(sp->setup, s));
         for (int i = 0; i < n_steps / sp->unroll; ++i) LADIFF_HIP(hipGraphLaunch(sp->exec, s));
     }
     return launch_finalize_latents(r.latents, counts, z, B, T, s);

@@ -236,8 +236,8 @@ class LADiffVae(_HipModule):
         if F + 2 * T > _lib.MAX_FRAMES:
             raise NotImplementedError(f"encode handles up to {_lib.MAX_FRAMES - 2 * T} frames")
         counts = [int(math.ceil(l / self.frame_per_latent)) for l in lengths]
-        lens_t = torch.tensor(lengths, dtype=torch.int32, device=dev)
-        counts_t = torch.tensor(counts, dtype=torch.int32, device=dev)
+        lens_t = _lib.device_ints(lengths, dev)
+        counts_t = _lib.device_ints(counts, dev)
         if eps is None:
             eps = torch.randn(T, B, self.latent_dim, dtype=torch.float32, device=dev)     # Normal.rsample's draw
         eps = eps.detach().to(device=dev, dtype=torch.float32).contiguous()
@@ -273,8 +273,8 @@ class LADiffVae(_HipModule):
             counts = [int(math.ceil(l / self.frame_per_latent)) for l in lengths]
         counts_t = None
         if not self.test_efficiency:
-            counts_t = torch.tensor(counts, dtype=torch.int32, device=dev)
-        lens_t = torch.tensor(lengths, dtype=torch.int32, device=dev)
+            counts_t = _lib.device_ints(counts, dev)
+        lens_t = _lib.device_ints(lengths, dev)
         wt = self._weight_table()
         zz = z.detach().to(torch.float32).contiguous()
         feats = torch.empty(B, F, self.nfeats, dtype=torch.float32, device=dev)

@@ -199,7 +199,7 @@ class LADIFF(nn.Module):
         with torch.cuda.stream(run):
             plan["text"].copy_(encoder_hidden_states.reshape(2 * B, 1, 768))
             plan["noise"].copy_(init_noise)
-            plan["counts"].copy_(torch.tensor(counts, dtype=torch.int32), non_blocking=False)
+            plan["counts"].copy_(_lib.device_ints(counts, dev))       # device-to-device: the graph bakes plan["counts"] in
             if need_noise:
                 plan["step_noise"].copy_(step_noise)
             _lib.check(L.ladiff_diffusion_reverse(
