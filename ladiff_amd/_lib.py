@@ -191,6 +191,8 @@ def device_ints(values, device):
     until the stream has drained, which would serialise the host behind a whole sampling pass; the values go through a
     pinned buffer with a non-blocking copy, and recently used lists (batches repeat their lengths) are served from a
     small cache."""
+    if torch.device(device).type != "cuda":
+        raise LadiffHipError("libladiff_hip works on GPU tensors only; got a CPU tensor (no CPU fallback exists)")
     key = (tuple(int(v) for v in values), str(device))
     t = _INT_CACHE.get(key)
     if t is None:
