@@ -1,5 +1,5 @@
-"""Diagnostic (GPU box): large-M bf16x3 GEMM shapes of the decoder (M = 25088), LADIFF_PC=0 old ring kernel / 1 persistent
-producer-consumer kernel; checks against fp64 on a row sample."""
+"""Diagnostic (GPU box): large-M bf16x3 GEMM shapes of the decoder / CLIP (M = 25088 by default, env M overrides) through
+ladiff_gemm_split; checks against fp64 on a row sample."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -35,4 +35,4 @@ for (N, K, act) in [(768, 256, 0), (256, 256, 0), (1024, 256, 2), (256, 1024, 0)
     Yb = torch.empty_like(Y)
     # S-format twin decodes to the same values (16 significant bits)
     out.append(f"N={N:4d} K={K:4d}: {t:7.2f} us {2.0 * M * N * K / t / 1e6:6.1f} TF/s err {err:.1e}")
-print(f"LADIFF_PC={os.environ.get('LADIFF_PC', '1')} M={M}  " + " | ".join(out))
+print(f"M={M}  " + " | ".join(out))

@@ -1,5 +1,5 @@
-"""Diagnostic (GPU box): bf16x3 denoiser GEMM shapes, wave layout selected by LADIFF_KS (0 old, 1 WNxWK=2x2, 2 1x4 for the
-small tiles); 50 launches back to back inside a graph.  Also checks the result against fp64."""
+"""Diagnostic (GPU box): cadence of the bf16x3 denoiser GEMM shapes (gemm_kp_kernel), 50 launches back to back inside a
+graph, result checked against fp64."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -37,4 +37,4 @@ for (N, K) in [(1024, 256), (256, 1024), (768, 256), (256, 512), (256, 256)]:
     if splits == 1: ref = ref + b.double() + res.double()
     err = (got - ref).abs().max().item()
     out.append(f"N={N:5d} K={K:5d}: {t:6.2f} us  err {err:.2e}")
-print(f"LADIFF_KS={os.environ.get('LADIFF_KS', '1')}  " + " | ".join(out))
+print(" | ".join(out))
