@@ -151,7 +151,7 @@ int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, const flo
 }
 
 // ------------------------------------------------------------------ forward
-// Per layer (11 launches, 13 on the four output blocks); M = 2B*T rows, fp32 throughout:
+// Per layer, fp32 mode (11 launches, 13 on the four output blocks); M = 2B*T rows:
 //   [skip]  x   = linear_blocks([x | xs.pop()])      split-K 2 + combine                       cross_attention.py:79-82
 //   qkv         = in_proj(x)                          N=768                                     mdiff_transformer.py:60-61
 //   att         = softmax over [latents | text | time] keys . V                                 :296-313
@@ -164,6 +164,9 @@ int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, const flo
 //   part        = ffn.linear2(hid)                    split-K 4
 //   u           = SiLU(LN(sum part + b) * (1 + scale_t) + shift_t)   combine kernel            :152-162
 //   x'          = X3 + out_layers(u)                  N=256                                     :162, :261
+// bf16x3 mode (8 launches, 9 on the output blocks): the same arithmetic with the steps grouped into fused kernels -
+//   [skip] gemm_rowln (concat GEMM + bias) | qkv_attn (qkv + att) | gemm_rowln (R1, X1) | linear1 | linear2 split-K |
+//   reduce_rows (X3) | ffn.linear1 | ffn.linear2 split-K | combine_gemm (u, x').
 size_t den_forward_ws_floats(int B2, int T) { return (size_t)B2 * T * (16 * D + 3 * D + D + FF + 4 * D); }
 
 void den_loop_io(float* ws, int rows, float** x, float** xs) {
