@@ -261,7 +261,8 @@ __global__ __launch_bounds__(512) void self_attn_bf16x3_kernel(const float* __re
             const f32x4 a = ld4(qkv + base + (size_t)qrow * g.ld + 16 * ks + 8 * h2);
             const f32x4 c = ld4(qkv + base + (size_t)qrow * g.ld + 16 * ks + 8 * h2 + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = a[e] * 0.125f; v[4 + e] = c[e] * 0.125f; }     // q / sqrt(64), exact
+            // q / sqrt(64) * log2(e): the scores come out in base-2 units, so the softmax numerators are one v_exp_f32 each
+            for (int e = 0; e < 4; ++e) { v[e] = a[e] * (0.125f * 1.4426950408889634f); v[4 + e] = c[e] * (0.125f * 1.4426950408889634f); }
         }
         split8(v, qh[ks], ql[ks]);
     }
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(512) void self_attn_bf16x3_kernel(const float* __re
         if (kt < nkt) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float pv = expf(sT[kt][i] - m);
+                const float pv = __builtin_amdgcn_exp2f(sT[kt][i] - m);
                 sT[kt][i] = pv;
                 l += pv;
             }
