@@ -199,6 +199,25 @@ __global__ __launch_bounds__(512) void self_attn_bf16x3_kernel(const float* __re
     const int nkt = (len + 31) >> 5;
     const size_t base = (size_t)b * F * g.ld + h * DH;
 
+    const int qt = wave;                      // query tile of this wave; its q rows are fetched together with K / V
+    const int q = lane & 31, h2 = lane >> 5;
+    const int qrow = qt * 32 + q;
+
+    bf16x8 qh[4], ql[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (qrow < F) {
+            const f32x4 a = ld4(qkv + base + (size_t)qrow * g.ld + 16 * ks + 8 * h2);
+            const f32x4 c = ld4(qkv + base + (size_t)qrow * g.ld + 16 * ks + 8 * h2 + 4);
+#pragma unroll
+            // q / sqrt(64) * log2(e): the scores come out in base-2 units, so the softmax numerators are one v_exp_f32 each
+            for (int e = 0; e < 4; ++e) { v[e] = a[e] * (0.125f * 1.4426950408889634f); v[4 + e] = c[e] * (0.125f * 1.4426950408889634f); }
+        }
+        split8(v, qh[ks], ql[ks]);
+    }
+
+
     // ---- staging.  All global loads first (7 x (k, v) float4 per thread), V through an fp32 image for the transpose.
     f32x4 kk[7], vv[7];
 #pragma unroll
@@ -248,24 +267,7 @@ __global__ __launch_bounds__(512) void self_attn_bf16x3_kernel(const float* __re
     }
     __syncthreads();
 
-    const int qt = wave;
     if (qt * 32 >= F) return;
-    const int q = lane & 31, h2 = lane >> 5;
-    const int qrow = qt * 32 + q;
-
-    bf16x8 qh[4], ql[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (qrow < F) {
-            const f32x4 a = ld4(qkv + base + (size_t)qrow * g.ld + 16 * ks + 8 * h2);
-            const f32x4 c = ld4(qkv + base + (size_t)qrow * g.ld + 16 * ks + 8 * h2 + 4);
-#pragma unroll
-            // q / sqrt(64) * log2(e): the scores come out in base-2 units, so the softmax numerators are one v_exp_f32 each
-            for (int e = 0; e < 4; ++e) { v[e] = a[e] * (0.125f * 1.4426950408889634f); v[4 + e] = c[e] * (0.125f * 1.4426950408889634f); }
-        }
-        split8(v, qh[ks], ql[ks]);
-    }
 
     f32x16 sT[SA_NKT];
     float m = -INFINITY;
@@ -285,13 +287,18 @@ __global__ __launch_bounds__(512) void self_attn_bf16x3_kernel(const float* __re
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[ks], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], acc, 0, 0, 0);
             }
+            if (kb[kt] == 0xFFFFFFFFu && !g.causal) {             // every key of the tile is valid (wave-uniform): no masking
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int kin = (i & 3) + 8 * (i >> 2) + 4 * h2;
-                const bool ok = ((kb[kt] >> kin) & 1u) && (!g.causal || kt * 32 + kin <= qrow);
-                const float s = ok ? acc[i] : -INFINITY;
-                acc[i] = s;
-                m = fmaxf(m, s);
+                for (int i = 0; i < 16; ++i) m = fmaxf(m, acc[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int kin = (i & 3) + 8 * (i >> 2) + 4 * h2;
+                    const bool ok = ((kb[kt] >> kin) & 1u) && (!g.causal || kt * 32 + kin <= qrow);
+                    const float s = ok ? acc[i] : -INFINITY;
+                    acc[i] = s;
+                    m = fmaxf(m, s);
+                }
             }
             sT[kt] = acc;
         }
