@@ -188,14 +188,16 @@ def test_module_level_loop_matches_fused_loop(denoiser, vae):
 
 
 # ---------------------------------------------------------------- full-size properties (BASELINE configs)
-def test_full_size_batch_properties(denoiser, vae):
-    """B=128, F=196, 50-step DDIM: samples are independent of batch composition, so a sub-batch run alone
-    must reproduce its rows of the full batch; padded frames are exactly zero; the run is deterministic."""
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_full_size_batch_properties(denoiser, vae, precision):
+    """B=128, F=196, 50-step DDIM (the benchmark's workload): samples are independent of batch composition, so a
+    sub-batch run alone must reproduce its rows of the full batch; padded frames are exactly zero; and the CPU oracle
+    on the sub-batch.  Both precision modes (the bf16x3 mode runs on its own fused kernels)."""
     B = 128
     lens = [196] * 120 + [60, 120, 49, 1, 100, 150, 196, 48]
     text = syn.text_embeddings(B)
     noise = syn.init_noise(lens)
-    pipe = make_pipe(denoiser, vae, "ddim", 50)
+    pipe = make_pipe(denoiser, vae, "ddim", 50, precision=precision)
     z, feats = pipe.sample(text.to(DEV), lens, init_noise=noise.to(DEV))
     assert feats.shape == (B, 196, 263) and torch.isfinite(feats).all()
     for i, l in enumerate(lens):
@@ -204,10 +206,11 @@ def test_full_size_batch_properties(denoiser, vae):
             assert z[syn.max_iter_elements([l])[0]:, i].abs().max().item() == 0
     idx = [0, 57, 120, 121, 123, 127]
     sub_text = torch.cat([text[:B][idx], text[B:][idx]])
-    z_s, f_s = make_pipe(denoiser, vae, "ddim", 50).sample(sub_text.to(DEV), [lens[i] for i in idx],
-                                                            init_noise=noise[idx].to(DEV))
+    z_s, f_s = make_pipe(denoiser, vae, "ddim", 50, precision=precision).sample(
+        sub_text.to(DEV), [lens[i] for i in idx], init_noise=noise[idx].to(DEV))
     scale = z.abs().max().item()
-    assert maxdiff(z_s, z[:, idx]) < 2e-5 * max(1.0, scale)
+    # the sub-batch runs through different tilings (6 samples per workgroup group instead of 128): fp32 sums are reordered
+    assert maxdiff(z_s, z[:, idx]) < (2e-5 if precision == "fp32" else 5e-4) * max(1.0, scale)
     for j, i in enumerate(idx):
         assert maxdiff(f_s[j, :lens[i]], feats[i, :lens[i]]) < FRAME_TOL
     # against the CPU oracle on the sub-batch (the oracle finishes 6 motions x 50 steps in seconds)
