@@ -148,6 +148,7 @@ def main():
     B = args.batch
     total = B * world
     lens = [FRAMES] * B
+    glens = [FRAMES] * total          # every rank knows the global lengths: the gather needs no metadata exchange
     # global inputs, sliced per rank: results do not depend on the sharding
     lo, hi = D.shard_range(total, rank, world)
     gtext = syn.text_embeddings(total)
@@ -161,7 +162,7 @@ def main():
     def one_pass():
         z, feats = pipe.sample(text, lens, init_noise=noise)
         if use_dist:      # final gather of the decoded frames (RCCL over xGMI); also exercised at world size 1 under torchrun
-            feats = D.gather_feats(feats, total, world, out=gather_buf)
+            feats = D.gather_feats(feats, total, world, out=gather_buf, lengths=glens)
         return feats
 
     def fence():

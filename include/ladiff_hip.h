@@ -178,18 +178,28 @@ int ladiff_finalize_latents(const float* latents, const int32_t* counts, float* 
 
 /* ------------------------------------------------------------------ whole reverse loop
  * LADIFF._diffusion_reverse (ladiff.py:333-571, live branch).  `sampler` (from ladiff_sampler_create, or
- * NULL) owns a hipGraph of ONE step (denoiser + guidance + scheduler + step counter) that is captured on
- * first use and replayed n_steps times; it is re-captured when any argument changes.  reuse_time_tables = 1 tells
- * the call that `ws` still holds the time tables of a previous call with the same weights and schedule. */
+ * NULL) owns hipGraphs of the per-call prologue and of up to 10 steps (denoiser + guidance + scheduler + step
+ * counter) that are captured on first use and replayed; they are re-captured when any argument changes.  The
+ * weight tables are identified by a hash over all their pointers plus `weights_generation`, a number the caller
+ * bumps whenever it rebuilds a table (a rebuilt table can reuse old addresses).
+ *   cfg = 1: classifier-free guidance, text_emb is [2B,1,768] (unconditional half first, ladiff.py:258-264) and the
+ *            network runs on cat([latents]*2) (:472-474); cfg = 0: text_emb is [B,1,768], no guidance (:472-490).
+ *   counts       [B] latent rows per motion used as the denoiser's key mask and to zero the initial noise
+ *                (ladiff.py:379-390; NULL = unmasked, the TEST_EFFICIENCY branch, ladiff_denoiser.py:254)
+ *   final_counts [B] rows >= final_counts[b] of the result are zeroed (ladiff.py:559-566, applied in every branch;
+ *                NULL = no zeroing)
+ * reuse_time_tables = 1 tells the call that `ws` still holds the time tables of a previous call with the same weights
+ * and schedule. */
 int ladiff_sampler_create(void** sampler);
 int ladiff_sampler_destroy(void* sampler);
 size_t ladiff_reverse_workspace_bytes(int B, int T, int n_steps);
 int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* const* w_split /*or NULL*/,
-                             const float* text_emb /*[2B,1,768]*/,
+                             uint64_t weights_generation, const float* text_emb /*[2B or B,1,768]*/,
                              const float* init_noise /*[B,T,256]*/, const int32_t* counts /*[B] or NULL*/,
+                             const int32_t* final_counts /*[B] or NULL*/,
                              const float* sinusoid /*[n,768]*/, const float* coef /*[n,8]*/,
                              const float* step_noise /*[n,B,T,256] or NULL*/, float guidance_scale,
-                             float init_noise_sigma, int B, int T, int n_steps, float* z /*[T,B,256]*/,
+                             float init_noise_sigma, int cfg, int B, int T, int n_steps, float* z /*[T,B,256]*/,
                              void* ws, size_t ws_bytes, int reuse_time_tables, ladiff_stream_t stream);
 
 /* ------------------------------------------------------------------ LA-VAE decoder (LADiffVae.decode)

@@ -7,7 +7,7 @@ tensor, it raises.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
 
 import torch
 
@@ -61,9 +61,9 @@ _SIGNATURES = {
     "ladiff_sampler_create": (c_int, [ctypes.POINTER(c_void_p)]),
     "ladiff_sampler_destroy": (c_int, [c_void_p]),
     "ladiff_reverse_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "ladiff_diffusion_reverse": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                         c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p,
-                                         c_size_t, c_int, c_void_p]),
+    "ladiff_diffusion_reverse": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_int,
+                                         c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "ladiff_encoder_num_params": (c_int, []),
     "ladiff_encoder_param_name": (c_char_p, [c_int]),
     "ladiff_encoder_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -142,9 +142,14 @@ def param_names(kind):
 
 
 class WeightTable:
-    """Array of device pointers in the order the library expects, built from a state dict."""
+    """Array of device pointers in the order the library expects, built from a state dict.  `generation` is unique per
+    table object: the library keys its captured graphs on it, because a rebuilt table can land on the addresses (host
+    array and device copies) a freed one used."""
+    _next_generation = 1
 
     def __init__(self, kind, tensors, n_names=None, no_split=()):
+        self.generation = WeightTable._next_generation
+        WeightTable._next_generation += 1
         names = param_names(kind)
         if n_names is not None:      # a prefix of the table (CLIP with fewer than 12 layers); the tail stays NULL
             names = names[:n_names]
@@ -190,10 +195,11 @@ def device_ints(values, device):
     """int32 device tensor of a short host list (lengths, latent counts).  A pageable host-to-device copy blocks the host
     until the stream has drained, which would serialise the host behind a whole sampling pass; the values go through a
     pinned buffer with a non-blocking copy, and recently used lists (batches repeat their lengths) are served from a
-    small cache."""
+    small cache.  The cache is keyed on the current stream as well: the copy is ordered on the stream it was issued on, so
+    a hit from another stream would have no dependency on it (and the block would return to the wrong allocator pool)."""
     if torch.device(device).type != "cuda":
         raise LadiffHipError("libladiff_hip works on GPU tensors only; got a CPU tensor (no CPU fallback exists)")
-    key = (tuple(int(v) for v in values), str(device))
+    key = (tuple(int(v) for v in values), str(device), torch.cuda.current_stream(device).cuda_stream)
     t = _INT_CACHE.get(key)
     if t is None:
         if len(_INT_CACHE) >= 64:

@@ -23,11 +23,10 @@ bool load_weights(W& dst, const float* const* ptrs) {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---- reverse-loop workspace carve-up (floats)
-constexpr int MAX_CHAINS = 4;
 struct ReverseWs {
     float *tables, *cache, *latents, *eps, *fwd;
     int32_t* d_step;
-    size_t fwd_floats, chain_floats, total_bytes;
+    size_t fwd_floats, total_bytes;
 };
 ReverseWs carve_reverse(void* ws, int B, int T, int n) {
     ReverseWs r;
@@ -42,13 +41,7 @@ ReverseWs carve_reverse(void* ws, int B, int T, int n) {
     size_t pre = (size_t)n * D * 3;                                    // time-table scratch
     const size_t txt = den_text_ws_floats(B2, n);                      // text-cache scratch
     if (txt > pre) pre = txt;
-    // the forward pass may be split into up to MAX_CHAINS independent sample ranges with their own scratch
-    r.chain_floats = 0;
     r.fwd_floats = den_forward_ws_floats(B2, T);
-    for (int c = 2; c <= MAX_CHAINS; ++c) {
-        const size_t need = (size_t)c * align_up(den_forward_ws_floats((B2 + c - 1) / c, T), 64);
-        if (need > r.fwd_floats) r.fwd_floats = need;
-    }
     if (pre > r.fwd_floats) r.fwd_floats = pre;
     r.fwd = take(r.fwd_floats);
     r.total_bytes = off * sizeof(float);
@@ -59,14 +52,22 @@ struct Sampler {
     hipGraphExec_t exec = nullptr;
     hipGraphExec_t setup = nullptr;       // per-call prologue (text cache, initial latents, counter reset, first network input)
     int unroll = 1;                       // denoiser steps captured per graph launch
-    int chains = 1;                       // sample ranges captured as parallel graph branches (measured: no gain)
-    hipStream_t side[MAX_CHAINS - 1] = {nullptr};
-    hipEvent_t fork = nullptr, join[MAX_CHAINS - 1] = {nullptr};
-    // capture key: a graph bakes pointers and shapes into its kernel nodes
-    const void* key_ptrs[10] = {nullptr};
+    // capture key: a graph bakes pointers, shapes and scalars into its kernel nodes.  The weight tables are identified by
+    // a hash over EVERY pointer of both tables plus the caller's generation id (bumped whenever a table is rebuilt), not
+    // by the address of the host array (which a rebuilt table can land on again).
+    const void* key_ptrs[9] = {nullptr};
     int key_ints[4] = {0};
-    float key_g = 0.f;
+    float key_f[2] = {0.f, 0.f};
+    uint64_t key_hash = 0, key_gen = 0;
 };
+
+uint64_t hash_ptrs(const float* const* p, int n, uint64_t h) {            // FNV-1a over the pointer values
+    for (int i = 0; i < n; ++i) {
+        uint64_t v = reinterpret_cast<uint64_t>(p[i]);
+        for (int b = 0; b < 8; ++b) { h ^= (v >> (8 * b)) & 0xff; h *= 1099511628211ull; }
+    }
+    return h;
+}
 
 }  // namespace
 
@@ -242,26 +243,15 @@ int ladiff_finalize_latents(const float* latents, const int32_t* counts, float* 
 // ------------------------------------------------------------------ whole reverse loop
 int ladiff_sampler_create(void** sampler) {
     LADIFF_CHECK_ARG(sampler);
-    Sampler* sp = new Sampler();
-    if (const char* e = getenv("LADIFF_CHAINS")) { const int c = atoi(e); if (c >= 1 && c <= MAX_CHAINS) sp->chains = c; }
-    LADIFF_HIP(hipEventCreateWithFlags(&sp->fork, hipEventDisableTiming));
-    for (int i = 0; i < MAX_CHAINS - 1; ++i) {
-        LADIFF_HIP(hipStreamCreateWithFlags(&sp->side[i], hipStreamNonBlocking));
-        LADIFF_HIP(hipEventCreateWithFlags(&sp->join[i], hipEventDisableTiming));
-    }
-    *sampler = sp;
+    *sampler = new Sampler();
     return 0;
 }
 int ladiff_sampler_destroy(void* sampler) {
     Sampler* sp = reinterpret_cast<Sampler*>(sampler);
     if (sp == nullptr) return 0;
+    (void)hipDeviceSynchronize();         // a replay of these graphs may still be queued
     if (sp->exec) (void)hipGraphExecDestroy(sp->exec);
     if (sp->setup) (void)hipGraphExecDestroy(sp->setup);
-    if (sp->fork) (void)hipEventDestroy(sp->fork);
-    for (int i = 0; i < MAX_CHAINS - 1; ++i) {
-        if (sp->join[i]) (void)hipEventDestroy(sp->join[i]);
-        if (sp->side[i]) (void)hipStreamDestroy(sp->side[i]);
-    }
     delete sp;
     return 0;
 }
@@ -275,10 +265,11 @@ int ladiff_split_rows(const float* x, float* y, int R, int K, ladiff_stream_t st
     return launch_split_rows(x, y, R, K, S(stream));
 }
 
-int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* const* w_split, const float* text_emb, const float* init_noise,
-                             const int32_t* counts, const float* sinusoid, const float* coef, const float* step_noise,
-                             float guidance_scale, float init_noise_sigma, int B, int T, int n_steps, float* z,
-                             void* ws, size_t ws_bytes, int reuse_time_tables, ladiff_stream_t stream) {
+int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* const* w_split, uint64_t weights_generation,
+                             const float* text_emb, const float* init_noise, const int32_t* counts, const int32_t* final_counts,
+                             const float* sinusoid, const float* coef, const float* step_noise, float guidance_scale,
+                             float init_noise_sigma, int cfg, int B, int T, int n_steps, float* z, void* ws, size_t ws_bytes,
+                             int reuse_time_tables, ladiff_stream_t stream) {
     DenoiserW W, WS;
     LADIFF_CHECK_ARG(load_weights(W, w) && text_emb && init_noise && sinusoid && coef && z && ws && B > 0 && n_steps > 0);
     if (w_split != nullptr) LADIFF_CHECK_ARG(load_weights(WS, w_split));
@@ -287,7 +278,8 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
     ReverseWs r = carve_reverse(ws, B, T, n_steps);
     if (ws_bytes < r.total_bytes) return LADIFF_ERR_WORKSPACE;
     hipStream_t s = S(stream);
-    const int B2 = 2 * B;
+    const int dup = cfg ? 2 : 1;          // guidance: the network sees cat([latents]*2) with text [uncond | cond]  ladiff.py:472-474
+    const int B2 = dup * B;
 
     Sampler* sp = reinterpret_cast<Sampler*>(sampler);
     float *xio = nullptr, *xios = nullptr;
@@ -303,43 +295,32 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
         LADIFF_TRY(denoiser_text_cache(W, text_emb, B2, r.tables, n_steps, r.cache, r.fwd, r.fwd_floats, st));
         LADIFF_TRY(launch_init_latents(init_noise, counts, init_noise_sigma, r.latents, B, T, st));
         LADIFF_HIP(hipMemsetAsync(r.d_step, 0, 2 * sizeof(int32_t), st));      // [0] step index, [1] tail-kernel ticket
-        // One step = the nine denoiser layers + ONE tail launch (final LayerNorm of both branches, guidance, scheduler step,
-        // next step's network input, step counter).  The network input / last-layer output buffer of the forward workspace
-        // is primed here.  `chains` > 1 (LADIFF_CHAINS, diagnostic) splits the batch into parallel graph branches with the
-        // un-fused tail; measured: no gain.
+        // One step = the nine denoiser layers + ONE tail launch (final LayerNorm of the guidance branches, guidance,
+        // scheduler step, next step's network input, step counter).  The network input / last-layer output buffer of the
+        // forward workspace is primed here.
         return launch_add_pe(r.latents, W.query_pe, B, 0, B2, T, xio, xios, st);
     };
-    if (sp == nullptr) LADIFF_TRY(prologue(s));
-    auto one_step = [&](hipStream_t st, int chains) -> int {
-        if (chains <= 1) {
-            LADIFF_TRY(denoiser_forward(W, WSp, r.tables, r.d_step, r.cache, n_steps, r.latents, B, 2, T, counts, r.eps, r.fwd,
-                                        r.fwd_floats, st, 0, B2, 1));
-            return launch_step_tail(xio, xios, W.norm.g, W.norm.b, r.latents, coef, r.d_step, step_noise, W.query_pe,
-                                    guidance_scale, B, T, st);
-        }
-        LADIFF_HIP(hipEventRecord(sp->fork, st));
-        const size_t per = r.fwd_floats / chains / 64 * 64;   // >= den_forward_ws_floats(ceil(B2 / chains), T) by carve_reverse
-        for (int c = chains - 1; c >= 0; --c) {
-            const int lo = (int)((long long)B2 * c / chains), hi = (int)((long long)B2 * (c + 1) / chains);
-            hipStream_t cs = c == 0 ? st : sp->side[c - 1];
-            if (c > 0) LADIFF_HIP(hipStreamWaitEvent(cs, sp->fork, 0));
-            LADIFF_TRY(denoiser_forward(W, WSp, r.tables, r.d_step, r.cache, n_steps, r.latents, B, 2, T, counts, r.eps,
-                                        r.fwd + (size_t)c * per, per, cs, lo, hi - lo));
-            if (c > 0) LADIFF_HIP(hipEventRecord(sp->join[c - 1], cs));
-        }
-        for (int c = 1; c < chains; ++c) LADIFF_HIP(hipStreamWaitEvent(st, sp->join[c - 1], 0));
-        LADIFF_TRY(launch_cfg_step(r.eps, r.latents, coef, r.d_step, step_noise, guidance_scale, 1, B, T, st));
-        return launch_advance(r.d_step, st);
+    auto one_step = [&](hipStream_t st) -> int {
+        LADIFF_TRY(denoiser_forward(W, WSp, r.tables, r.d_step, r.cache, n_steps, r.latents, B, dup, T, counts, r.eps, r.fwd,
+                                    r.fwd_floats, st, 0, B2, 1));
+        return launch_step_tail(xio, xios, W.norm.g, W.norm.b, r.latents, coef, r.d_step, step_noise, W.query_pe,
+                                guidance_scale, cfg, B, T, st);
     };
     if (sp == nullptr) {
-        for (int i = 0; i < n_steps; ++i) LADIFF_TRY(one_step(s, 1));
+        LADIFF_TRY(prologue(s));
+        for (int i = 0; i < n_steps; ++i) LADIFF_TRY(one_step(s));
     } else {
-        const void* kp[10] = {w, w[0], ws, counts, coef, step_noise, stream, w_split ? (const void*)w_split[0] : nullptr,
-                              text_emb, init_noise};
-        const int ki[4] = {B, T, n_steps, sp->chains};
+        const void* kp[9] = {ws, counts, final_counts, coef, step_noise, stream, text_emb, init_noise, z};
+        const int ki[4] = {B, T, n_steps, cfg};
+        const float kf[2] = {guidance_scale, init_noise_sigma};
+        uint64_t h = hash_ptrs(w, DEN_NPARAMS, 1469598103934665603ull);
+        if (w_split) h = hash_ptrs(w_split, DEN_NPARAMS, h ^ 0x9e3779b97f4a7c15ull);
         const bool same = sp->exec && std::memcmp(kp, sp->key_ptrs, sizeof(kp)) == 0 &&
-                          std::memcmp(ki, sp->key_ints, sizeof(ki)) == 0 && sp->key_g == guidance_scale;
+                          std::memcmp(ki, sp->key_ints, sizeof(ki)) == 0 && std::memcmp(kf, sp->key_f, sizeof(kf)) == 0 &&
+                          h == sp->key_hash && weights_generation == sp->key_gen;
         if (!same) {
+            // replays of the old graphs may still be queued (the host never paces the GPU): drain before destroying them
+            if (sp->exec || sp->setup) LADIFF_HIP(hipStreamSynchronize(s));
             if (sp->exec) { (void)hipGraphExecDestroy(sp->exec); sp->exec = nullptr; }
             if (sp->setup) { (void)hipGraphExecDestroy(sp->setup); sp->setup = nullptr; }
             hipGraph_t graph = nullptr;
@@ -360,7 +341,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
             for (int u = 2; u <= 10; ++u) if (n_steps % u == 0) unroll = u;
             sp->unroll = unroll;
             int rc = 0;
-            for (int u = 0; u < unroll && rc == 0; ++u) rc = one_step(s, sp->chains);
+            for (int u = 0; u < unroll && rc == 0; ++u) rc = one_step(s);
             const hipError_t ec = hipStreamEndCapture(s, &graph);
             if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
             LADIFF_HIP(ec);
@@ -369,12 +350,16 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
             LADIFF_HIP(ei);
             std::memcpy(sp->key_ptrs, kp, sizeof(kp));
             std::memcpy(sp->key_ints, ki, sizeof(ki));
-            sp->key_g = guidance_scale;
+            std::memcpy(sp->key_f, kf, sizeof(kf));
+            sp->key_hash = h;
+            sp->key_gen = weights_generation;
         }
         LADIFF_HIP(hipGraphLaunch(sp->setup, s));
         for (int i = 0; i < n_steps / sp->unroll; ++i) LADIFF_HIP(hipGraphLaunch(sp->exec, s));
     }
-    return launch_finalize_latents(r.latents, counts, z, B, T, s);
+    // final zeroing of the rows past each motion's latent count: applied even when the denoiser ran unmasked
+    // (TEST_EFFICIENCY), as ladiff.py:559-566 does
+    return launch_finalize_latents(r.latents, final_counts, z, B, T, s);
 }
 
 // ------------------------------------------------------------------ LA-VAE encoder

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void step_tail_kernel(float* __restrict__ x, f
                                                         const float* __restrict__ nb, float* __restrict__ lat,
                                                         const float* __restrict__ coef, int32_t* __restrict__ d_step,
                                                         const float* __restrict__ noise, const float* __restrict__ pe, float g,
-                                                        int B, int T) {
+                                                        int cfg, int B, int T) {
     const int step = d_step[0];
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);      // row = b * T + t of the B prompts
     const int c = (threadIdx.x & 63) * 4;
@@ -382,14 +382,17 @@ __global__ __launch_bounds__(256) void step_tail_kernel(float* __restrict__ x, f
         const float* cf = coef + (size_t)step * LADIFF_COEF_STRIDE;
         const float sa = cf[0], sb = cf[1], kx0 = cf[2], kx = cf[3], ke = cf[4], kn = cf[5];
         const f32x4 gg = ld4(ng + c), bb = ld4(nb + c);
-        f32x4 eu = ld4(x + (size_t)row * D + c), ec = ld4(x + (size_t)(M + row) * D + c);
+        f32x4 eu = ld4(x + (size_t)row * D + c), ec = eu;
+        if (cfg) ec = ld4(x + (size_t)(M + row) * D + c);
         float mean, rstd;
         row_stats(eu, mean, rstd);
 #pragma unroll
         for (int i = 0; i < 4; ++i) eu[i] = (eu[i] - mean) * rstd * gg[i] + bb[i];
-        row_stats(ec, mean, rstd);
+        if (cfg) {                       // without guidance the network ran on the B latents only (ladiff.py:472-490)
+            row_stats(ec, mean, rstd);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ec[i] = (ec[i] - mean) * rstd * gg[i] + bb[i];
+            for (int i = 0; i < 4; ++i) ec[i] = (ec[i] - mean) * rstd * gg[i] + bb[i];
+        }
         f32x4 l = ld4(lat + (size_t)row * D + c);
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
         if (noise != nullptr && kn != 0.f) z = ld4(noise + ((size_t)step * M + row) * D + c);
@@ -397,17 +400,17 @@ __global__ __launch_bounds__(256) void step_tail_kernel(float* __restrict__ x, f
         f32x4 xn;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float e = eu[i] + g * (ec[i] - eu[i]);
+            const float e = cfg ? eu[i] + g * (ec[i] - eu[i]) : eu[i];
             const float x0 = (l[i] - sb * e) / sa;
             l[i] = kx0 * x0 + kx * l[i] + ke * e + kn * z[i];
             xn[i] = l[i] + p[i];
         }
         st4(lat + (size_t)row * D + c, l);
         st4(x + (size_t)row * D + c, xn);
-        st4(x + (size_t)(M + row) * D + c, xn);
+        if (cfg) st4(x + (size_t)(M + row) * D + c, xn);
         if (xs != nullptr) {
             store_split4(xs + (size_t)row * D, c, xn);
-            store_split4(xs + (size_t)(M + row) * D, c, xn);
+            if (cfg) store_split4(xs + (size_t)(M + row) * D, c, xn);
         }
     }
     __syncthreads();
@@ -417,10 +420,10 @@ __global__ __launch_bounds__(256) void step_tail_kernel(float* __restrict__ x, f
     }
 }
 int launch_step_tail(float* x, float* xs, const float* ng, const float* nb, float* lat, const float* coef, int32_t* d_step,
-                     const float* noise, const float* pe, float g, int B, int T, hipStream_t s) {
+                     const float* noise, const float* pe, float g, int cfg, int B, int T, hipStream_t s) {
     const int M = B * T;
     hipLaunchKernelGGL(step_tail_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, x, xs, ng, nb, lat, coef,
-                       d_step, noise, pe, g, B, T);
+                       d_step, noise, pe, g, cfg, B, T);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }

@@ -45,26 +45,56 @@ def shard_prompts(text_emb, lengths, init_noise, rank, world):
     return text, list(lengths[lo:hi]), noise, (lo, hi)
 
 
-def gather_feats(feats, total, world, out=None):
-    """All-gather per-rank frames [b_r, F_r, C] into [total, F_max, C] in global prompt order (one collective).
+_PAD_CACHE = {}
 
-    Ranks may hold different numbers of prompts and different F (mixed lengths): shards are zero-padded to the
-    global maxima - frames past a motion's length are zero anyway (ladiff_vae.py:358).
+
+def _pad_buffer(shape, dtype, dev):
+    """Pre-allocated, zeroed staging buffer per (shape, dtype, device): no allocation inside a timed pass."""
+    key = (tuple(shape), dtype, str(dev))
+    buf = _PAD_CACHE.get(key)
+    if buf is None:
+        if len(_PAD_CACHE) >= 8:
+            _PAD_CACHE.pop(next(iter(_PAD_CACHE)))
+        buf = torch.zeros(*shape, dtype=dtype, device=dev)
+        _PAD_CACHE[key] = buf
+    return buf
+
+
+def gather_feats(feats, total, world, out=None, lengths=None):
+    """All-gather per-rank frames [b_r, F_r, C] into [total, F_max, C] in global prompt order: ONE collective.
+
+    `lengths` = the GLOBAL list of frame counts (every rank has it: prompts are sharded from one global batch by
+    `shard_range`).  With it every rank derives all shard shapes on the host, so the pass issues exactly one
+    `all_gather_into_tensor`, no metadata exchange and no host synchronisation; a shard that already has the global
+    shape (uniform batches: the benchmark) goes into the collective directly, otherwise through a pre-allocated
+    zero-padded staging buffer (frames past a motion's length are zero anyway, ladiff_vae.py:358).
+    Without `lengths` the shard shapes are exchanged first (one extra small collective + a host sync).
     """
     if not dist.is_initialized():
         return feats
     dev = feats.device
-    meta = torch.tensor([feats.shape[0], feats.shape[1]], dtype=torch.int64, device=dev)
-    metas = [torch.empty_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta)
-    bs = [int(m[0]) for m in metas]
-    fmax = max(int(m[1]) for m in metas)
-    bmax = max(bs)
     C = feats.shape[2]
-    pad = torch.zeros(bmax, fmax, C, dtype=feats.dtype, device=dev)
-    pad[:feats.shape[0], :feats.shape[1]] = feats
+    if lengths is not None:
+        if len(lengths) != total:
+            raise ValueError(f"{len(lengths)} global lengths for {total} prompts")
+        spans = [shard_range(total, r, world) for r in range(world)]
+        bs = [hi - lo for lo, hi in spans]
+        fmax = max(lengths)
+    else:
+        meta = torch.tensor([feats.shape[0], feats.shape[1]], dtype=torch.int64, device=dev)
+        metas = [torch.empty_like(meta) for _ in range(world)]
+        dist.all_gather(metas, meta)
+        bs = [int(m[0]) for m in metas]
+        fmax = max(int(m[1]) for m in metas)
+    bmax = max(bs)
+    if feats.shape[0] == bmax and feats.shape[1] == fmax and feats.is_contiguous():
+        src = feats
+    else:
+        src = _pad_buffer((bmax, fmax, C), feats.dtype, dev)
+        src.zero_()
+        src[:feats.shape[0], :feats.shape[1]] = feats
     buf = torch.empty(world * bmax, fmax, C, dtype=feats.dtype, device=dev) if out is None else out
-    dist.all_gather_into_tensor(buf, pad)
+    dist.all_gather_into_tensor(buf, src)
     if all(b == bmax for b in bs):
         return buf
     return torch.cat([buf[r * bmax:r * bmax + bs[r]] for r in range(world)], dim=0)

@@ -166,17 +166,21 @@ class LADIFF(nn.Module):
     # ------------------------------------------------------------------ the hot loop
     def _diffusion_reverse(self, encoder_hidden_states, lengths=None, init_noise=None, step_noise=None):
         """text_emb [2B,1,768] (unconditional half first), lengths list[int] -> z [max_it, B, 256]  (ladiff.py:333-571)."""
-        if not self.do_classifier_free_guidance:
-            raise NotImplementedError("guidance_scale <= 1 (no classifier-free guidance) is not built")
         L = _lib.lib()
         dev = encoder_hidden_states.device
         if not encoder_hidden_states.is_cuda:
             raise _lib.LadiffHipError("_diffusion_reverse needs GPU tensors; there is no CPU fallback")
-        B = encoder_hidden_states.shape[0] // 2
+        if encoder_hidden_states.shape[1] != 1:
+            raise NotImplementedError("the fused loop takes one text token per prompt (CLIP pooled output, mld_clip.py:75-78)")
+        cfg = bool(self.do_classifier_free_guidance)        # ladiff.py:339-340, :472-490
+        dup = 2 if cfg else 1
+        B = encoder_hidden_states.shape[0] // dup
         lengths = [int(l) for l in lengths]
         counts = self._counts(lengths)
         T = counts[0] if self.test_efficiency else self.max_it     # ladiff.py:381
         sch = self.scheduler
+        if encoder_hidden_states.shape[0] != dup * len(lengths):
+            raise ValueError(f"{encoder_hidden_states.shape[0]} text rows for {len(lengths)} lengths (guidance: {cfg})")
         plan = self._get_plan(B, T, self.num_inference_timesteps, self.eta, dev)
         n, need_noise = plan["n"], plan["need_noise"]
         if self._stream is None or self._stream.device != dev:
@@ -197,18 +201,21 @@ class LADIFF(nn.Module):
         if run is not cur:
             run.wait_stream(cur)
         with torch.cuda.stream(run):
-            plan["text"].copy_(encoder_hidden_states.reshape(2 * B, 1, 768))
+            plan["text"][:dup * B].copy_(encoder_hidden_states.reshape(dup * B, 1, 768))
             plan["noise"].copy_(init_noise)
             plan["counts"].copy_(_lib.device_ints(counts, dev))       # device-to-device: the graph bakes plan["counts"] in
             if need_noise:
                 plan["step_noise"].copy_(step_noise)
             _lib.check(L.ladiff_diffusion_reverse(
                 self._sampler if self.use_graph else None, wt.array,
-                wt.split_array() if self.precision == "bf16x3" else None, _lib.ptr(plan["text"]), _lib.ptr(plan["noise"]),
-                None if self.test_efficiency else plan["counts"].data_ptr(), _lib.ptr(plan["sinus"]),
-                _lib.ptr(plan["coef"]), _lib.ptr(plan["step_noise"]) if need_noise else None, self.guidance_scale,
-                float(sch.init_noise_sigma), B, T, n, _lib.ptr(plan["z"]), _lib.ptr(plan["ws"]), plan["ws_bytes"],
-                1 if plan["tables_key"] == wt.key else 0, run.cuda_stream))
+                wt.split_array() if self.precision == "bf16x3" else None, wt.generation, _lib.ptr(plan["text"]),
+                _lib.ptr(plan["noise"]),
+                # TEST_EFFICIENCY: no masks inside the denoiser and no zeroing of the initial noise (ladiff.py:381-390,
+                # ladiff_denoiser.py:254) - but the final zeroing of ladiff.py:559-566 has no such switch
+                None if self.test_efficiency else plan["counts"].data_ptr(), plan["counts"].data_ptr(),
+                _lib.ptr(plan["sinus"]), _lib.ptr(plan["coef"]), _lib.ptr(plan["step_noise"]) if need_noise else None,
+                self.guidance_scale, float(sch.init_noise_sigma), 1 if cfg else 0, B, T, n, _lib.ptr(plan["z"]),
+                _lib.ptr(plan["ws"]), plan["ws_bytes"], 1 if plan["tables_key"] == wt.key else 0, run.cuda_stream))
             plan["tables_key"] = wt.key
         if run is not cur:
             cur.wait_stream(run)

@@ -26,9 +26,12 @@ class SchedulerOutput:
 
 class _Scheduler:
     def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
-                 clip_sample=False, prediction_type="epsilon", **kwargs):
+                 clip_sample=True, prediction_type="epsilon", **kwargs):
+        # the default is diffusers' (True), so that a YAML which omits the key fails loudly instead of silently
+        # sampling without the clipping diffusers would apply; the reference sets `clip_sample: false` (scheduler.yaml)
         if clip_sample:
-            raise NotImplementedError("clip_sample=True is not built (the reference sets clip_sample: false)")
+            raise NotImplementedError("clip_sample=True is not built (the reference sets clip_sample: false; "
+                                      "pass clip_sample=False explicitly)")
         if prediction_type != "epsilon":
             raise NotImplementedError("only prediction_type='epsilon' is built (base.yaml:27 PREDICT_EPSILON: True)")
         if beta_schedule == "linear":
@@ -79,6 +82,9 @@ class _Scheduler:
             variance_noise = torch.randn_like(sample)
         out = sample.detach().to(torch.float32).contiguous().clone()
         eps = model_output.detach().to(torch.float32).contiguous()
+        if out.numel() % 256 or eps.shape != out.shape:
+            raise ValueError(f"scheduler.step works on [..., 256] latents; got sample {tuple(sample.shape)}, "
+                             f"model_output {tuple(model_output.shape)}")
         n = out.numel() // 256
         noise_ptr = None
         if variance_noise is not None:
@@ -131,9 +137,18 @@ class DDIMScheduler(_Scheduler):
 
 
 class DDPMScheduler(_Scheduler):
-    def __init__(self, variance_type="fixed_small", **kwargs):
+    """`prev_timestep`: "t-1" follows diffusers <= 0.14, the reference's era (alpha_prod_t_prev = alphas_cumprod[t-1],
+    beta_t = betas[t]); "schedule" follows later releases (prev_t = t - num_train // num_inference,
+    beta_t = 1 - a_t / a_prev).  They coincide for num_inference_steps == num_train_timesteps, which is how the
+    reference runs DDPM (modules_novae/scheduler.yaml:16-29); the dependency is not version-pinned
+    (src/requirements.txt:23), hence the switch."""
+
+    def __init__(self, variance_type="fixed_small", prev_timestep="t-1", **kwargs):
         if variance_type != "fixed_small":
             raise NotImplementedError("only variance_type='fixed_small' is built (scheduler.yaml)")
+        if prev_timestep not in ("t-1", "schedule"):
+            raise ValueError(f"prev_timestep {prev_timestep!r}")
+        self.prev_timestep = prev_timestep
         super().__init__(variance_type=variance_type, **kwargs)
 
     def set_timesteps(self, num_inference_steps, device=None):
@@ -145,10 +160,15 @@ class DDPMScheduler(_Scheduler):
 
     def _row(self, t, eta):
         a_t = self.alphas_cumprod[t]
-        a_p = self.alphas_cumprod[t - 1] if t > 0 else torch.tensor(1.0)
-        b_t = self.betas[t]
+        if self.prev_timestep == "schedule":
+            prev = t - self.config.num_train_timesteps // self.num_inference_steps
+            a_p = self.alphas_cumprod[prev] if prev >= 0 else torch.tensor(1.0)
+            b_t = 1 - a_t / a_p
+        else:
+            a_p = self.alphas_cumprod[t - 1] if t > 0 else torch.tensor(1.0)
+            b_t = self.betas[t]
         k_x0 = a_p ** 0.5 * b_t / (1 - a_t)
-        k_x = self.alphas[t] ** 0.5 * (1 - a_p) / (1 - a_t)
+        k_x = (1 - b_t) ** 0.5 * (1 - a_p) / (1 - a_t)
         k_n = torch.clamp((1 - a_p) / (1 - a_t) * b_t, min=1e-20) ** 0.5 if t > 0 else 0.0
         return [a_t ** 0.5, (1 - a_t) ** 0.5, k_x0, k_x, 0.0, k_n]
 

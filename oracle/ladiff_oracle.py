@@ -304,7 +304,16 @@ class DDIM(_SchedulerBase):
 
 
 class DDPM(_SchedulerBase):
-    """diffusers.DDPMScheduler, variance_type fixed_small, clip_sample False."""
+    """diffusers.DDPMScheduler, variance_type fixed_small, clip_sample False.
+
+    `prev_timestep`: "t-1" = diffusers <= 0.14 (the reference's era: alpha_prod_t_prev = alphas_cumprod[t-1],
+    beta_t = betas[t]); "schedule" = later diffusers (prev_t = t - num_train // num_inference,
+    beta_t = 1 - a_t / a_prev).  The two coincide when num_inference_steps == num_train_timesteps, which is how the
+    reference runs DDPM (modules_novae/scheduler.yaml:16-29)."""
+
+    def __init__(self, prev_timestep="t-1", **kw):
+        super().__init__(**kw)
+        self.prev_timestep = prev_timestep
 
     def set_timesteps(self, n):
         n = min(self.num_train_timesteps, n)
@@ -315,8 +324,13 @@ class DDPM(_SchedulerBase):
     def step(self, eps, t, x, noise=None):
         t = int(t)
         a_t = self.alphas_cumprod[t].to(x.dtype)
-        a_p = (self.alphas_cumprod[t - 1] if t > 0 else torch.tensor(1.0)).to(x.dtype)
-        b_t = self.betas[t].to(x.dtype)
+        if self.prev_timestep == "schedule":
+            prev = t - self.num_train_timesteps // self.num_inference_steps
+            a_p = (self.alphas_cumprod[prev] if prev >= 0 else torch.tensor(1.0)).to(x.dtype)
+            b_t = 1 - a_t / a_p
+        else:
+            a_p = (self.alphas_cumprod[t - 1] if t > 0 else torch.tensor(1.0)).to(x.dtype)
+            b_t = self.betas[t].to(x.dtype)
         x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
         out = (a_p ** 0.5 * b_t / (1 - a_t)) * x0 + ((1 - b_t) ** 0.5 * (1 - a_p) / (1 - a_t)) * x
         if t > 0:
@@ -327,26 +341,34 @@ class DDPM(_SchedulerBase):
 
 # --------------------------------------------------------------------------- sampling loop (A2, A4)
 def diffusion_reverse(denoise_fn, scheduler, text_emb, lengths, init_noise, n_steps,
-                      guidance_scale=7.5, eta=0.0, step_noise=None, frame_per_latent=48):
+                      guidance_scale=7.5, eta=0.0, step_noise=None, frame_per_latent=48, test_efficiency=False):
     """LADIFF._diffusion_reverse, live branch (ladiff.py:379-390, 407-417, 470-500, 562-566).
 
     denoise_fn(sample[2B,T,D], t, text[2B,N,E], counts[2B]) -> eps[2B,T,D]
     text_emb [2B,N,E] with the unconditional half FIRST (ladiff.py:258-264);
     init_noise [B,T,D] stands in for torch.randn (:380-385); padded rows are zeroed here (:389-390).
     step_noise [n_steps,B,T,D] feeds DDPM / eta>0 variance noise.  Returns [T,B,D].
+    guidance_scale <= 1: no classifier-free guidance (`do_classifier_free_guidance` False, ladiff.py:472-490): text_emb is
+    [B,N,E] and the network runs on the B latents.  test_efficiency (TEST_EFFICIENCY ablation): T = counts[0] latent rows
+    (:381), no zeroing of the initial noise (:386-390), no masks in the denoiser (ladiff_denoiser.py:254) - the final
+    zeroing (:559-566) still applies.
     """
     counts = max_iter_elements(lengths, frame_per_latent)
     B, T, _ = init_noise.shape
     valid = count_mask(counts, T)
-    latents = init_noise * valid[:, :, None].to(init_noise.dtype)
+    cfg = guidance_scale > 1.0
+    latents = init_noise if test_efficiency else init_noise * valid[:, :, None].to(init_noise.dtype)
     latents = latents * scheduler.init_noise_sigma
     scheduler.set_timesteps(n_steps)
-    counts2 = torch.tensor(counts + counts)
+    counts2 = None if test_efficiency else torch.tensor(counts + counts if cfg else counts)
     for i, t in enumerate(scheduler.timesteps):
-        model_in = torch.cat([latents, latents], dim=0)
-        eps = denoise_fn(model_in, t, text_emb, counts2)
-        eps_u, eps_c = eps.chunk(2)
-        eps = eps_u + guidance_scale * (eps_c - eps_u)
+        if cfg:
+            model_in = torch.cat([latents, latents], dim=0)
+            eps = denoise_fn(model_in, t, text_emb, counts2)
+            eps_u, eps_c = eps.chunk(2)
+            eps = eps_u + guidance_scale * (eps_c - eps_u)
+        else:
+            eps = denoise_fn(latents, t, text_emb, counts2)
         nz = None if step_noise is None else step_noise[i]
         if isinstance(scheduler, DDIM):
             latents = scheduler.step(eps, t, latents, eta=eta, noise=nz)
@@ -358,14 +380,16 @@ def diffusion_reverse(denoise_fn, scheduler, text_emb, lengths, init_noise, n_st
 
 
 def sample_motions(den_sd, vae_sd, text_emb, lengths, init_noise, n_steps=50, scheduler="ddim",
-                   guidance_scale=7.5, eta=0.0, step_noise=None, dtype=torch.float32):
+                   guidance_scale=7.5, eta=0.0, step_noise=None, dtype=torch.float32, test_efficiency=False):
     """Whole hot path: _diffusion_reverse + vae.decode (ladiff.py:266, :283). -> (z[T,B,D], feats[B,F,C])."""
     den_sd, vae_sd = cast(den_sd, dtype), cast(vae_sd, dtype)
-    sch = DDIM() if scheduler == "ddim" else DDPM()
+    sch = DDIM() if scheduler == "ddim" else (DDPM() if scheduler == "ddpm" else scheduler)
     fn = lambda x, t, txt, counts: denoiser_forward(den_sd, x, t, txt, counts)
     z = diffusion_reverse(fn, sch, text_emb.to(dtype), lengths, init_noise.to(dtype), n_steps,
-                          guidance_scale, eta, None if step_noise is None else step_noise.to(dtype))
-    feats = vae_decode(vae_sd, z, lengths)
+                          guidance_scale, eta, None if step_noise is None else step_noise.to(dtype),
+                          test_efficiency=test_efficiency)
+    # TEST_EFFICIENCY: the decoder gets no memory mask either (ladiff_vae.py:292-297 builds it only when not test_efficiency)
+    feats = vae_decode(vae_sd, z, lengths, latent_counts=[z.shape[0]] * len(lengths) if test_efficiency else None)
     return z, feats
 
 

@@ -160,6 +160,22 @@ def test_scheduler_tables():
         assert torch.allclose(got, q.step(e, p.timesteps[i], x, noise=z), atol=1e-5, rtol=1e-5)
     with pytest.raises(NotImplementedError):
         DDIMScheduler(clip_sample=True)
+    with pytest.raises(NotImplementedError):      # diffusers' default is clip_sample=True: an omitted key must not sample silently
+        DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
+    # DDPM with fewer inference steps than training steps: the two diffusers generations differ, both are restated
+    for mode in ("t-1", "schedule"):
+        p10 = DDPMScheduler(variance_type="fixed_small", prev_timestep=mode, **kw); p10.set_timesteps(10)
+        q10 = orc.DDPM(prev_timestep=mode); q10.set_timesteps(10)
+        tab = p10.coef_table()
+        for i in (0, 5, 9):
+            sa, sb, kx0, kx, ke, kn = tab[i, :6]
+            got = kx0 * ((x - sb * e) / sa) + kx * x + ke * e + kn * z
+            assert torch.allclose(got, q10.step(e, p10.timesteps[i], x, noise=z), atol=1e-5, rtol=1e-5)
+    a = DDPMScheduler(variance_type="fixed_small", prev_timestep="t-1", **kw); a.set_timesteps(1000)
+    b = DDPMScheduler(variance_type="fixed_small", prev_timestep="schedule", **kw); b.set_timesteps(1000)
+    assert torch.allclose(a.coef_table(), b.coef_table(), atol=1e-4, rtol=1e-3)     # same schedule at N = 1000 (1 - a_t/a_prev vs betas[t]: rounding only)
+    a.set_timesteps(10); b.set_timesteps(10)
+    assert not torch.allclose(a.coef_table(), b.coef_table(), atol=1e-3)
 
 
 def test_host_sinusoid_matches_oracle():

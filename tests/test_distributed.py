@@ -35,7 +35,7 @@ def test_shards_keep_cfg_pairs_and_global_noise():
     assert seen == lens
 
 
-def _worker(rank, world, port, total, ret):
+def _worker(rank, world, port, total, ret, with_lengths=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     r, w, _ = D.init_from_env("gloo")
@@ -47,7 +47,18 @@ def _worker(rank, world, port, total, ret):
     feats = torch.zeros(len(my), F, 3)
     for i, l in enumerate(my):
         feats[i, :l] = (lo + i) * 1000 + torch.arange(l, dtype=torch.float32)[:, None]
-    out = D.gather_feats(feats, total, w)
+    calls = {"all_gather": 0, "into": 0}
+    real_ag, real_into = dist.all_gather, dist.all_gather_into_tensor
+    dist.all_gather = lambda *a, **k: (calls.__setitem__("all_gather", calls["all_gather"] + 1), real_ag(*a, **k))[1]
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.__setitem__("into", calls["into"] + 1), real_into(*a, **k))[1]
+    try:
+        out = D.gather_feats(feats, total, w, lengths=lens if with_lengths else None)
+    finally:
+        dist.all_gather, dist.all_gather_into_tensor = real_ag, real_into
+    # with the global lengths: exactly ONE collective per pass
+    if with_lengths and (calls["all_gather"] != 0 or calls["into"] != 1):
+        ret[rank] = False
+        return
     ok = out.shape == (total, max(lens), 3)
     for i, l in enumerate(lens):
         ok = ok and bool((out[i, :l, 0] == i * 1000 + torch.arange(l)).all()) and bool((out[i, l:] == 0).all())
@@ -56,10 +67,10 @@ def _worker(rank, world, port, total, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total", [8, 7])
-def test_gather_feats_world2_gloo(total):
+@pytest.mark.parametrize("total,with_lengths", [(8, False), (7, False), (8, True), (7, True)])
+def test_gather_feats_world2_gloo(total, with_lengths):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, port, total, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, total, ret, with_lengths), nprocs=2, join=True)
     assert ret[0] and ret[1]
