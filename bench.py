@@ -136,6 +136,12 @@ def main():
                     help="matrix-product arithmetic of the timed mode (DESIGN.md §1); the other mode is timed after it")
     args = ap.parse_args()
 
+    # the JSON line must be the ONLY thing on stdout: RCCL prints a version banner to fd 1 when the process group comes
+    # up, so everything but the final line goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank, world, local = D.init_from_env()
     use_dist = torch.distributed.is_available() and torch.distributed.is_initialized()
     if world != args.gpus:
@@ -249,7 +255,7 @@ def main():
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
             line["cpu_baseline"]["gpu_over_cpu"] = round(motions_per_s / line["cpu_baseline"]["value"], 1)
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

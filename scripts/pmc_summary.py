@@ -1,34 +1,112 @@
-"""Summarise rocprofv3 --pmc runs of bench.py (gpurun_out/pmc_r1/<counter>/...) per kernel: MFMA utilisation and
-memory-side traffic.  FETCH_SIZE is doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md §HBM);
-both counters are in KiB.  Usage: python scripts/pmc_summary.py gpurun_out/pmc_r1 > profiles/r1/03_pmc_summary.md"""
-import csv, glob, sys
+"""Per-kernel summary of rocprofv3 runs of scripts/profile_pass.py -> markdown table + profiles/rN/summary.json.
+
+    python scripts/pmc_summary.py <run_dir> <passes> <out_md> <out_json> [git_sha]
+
+<run_dir> holds one sub-directory per collection (each its own rocprofv3 run, as the guide prescribes):
+    stats/                       --kernel-trace --stats               (un-countered durations)
+    SQ_VALU_MFMA_BUSY_CYCLES/    --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace
+    FETCH_SIZE/  WRITE_SIZE/     --pmc <counter> --kernel-trace
+`passes` = sampling passes in each profiled run (profile_pass.py runs 1 warm-up + N).
+
+MFMA utilisation.  Calibrated on bare MFMA loops of known count (scripts/ubench_mfma_calib.hip, profiles/r2/02_*):
+SQ_VALU_MFMA_BUSY_CYCLES is summed over every SIMD of the chip and adds exactly 16 per v_mfma_f32_16x16x32_bf16 and 32
+per v_mfma_f32_32x32x16_bf16, i.e. 1024 bf16 FLOP per counted cycle.  So
+    util = BUSY_CYCLES / (1024 SIMDs x duration x 2.4 GHz)
+is the fraction of the 2.5 PFLOP/s dense bf16 peak the kernel's MFMAs fill, and it must equal the arithmetic figure
+(MFMA FLOPs / duration / peak) at the same duration.  The r1 summaries divided by GRBM_GUI_ACTIVE / 8 instead; on the
+calibration's 15 us dispatches that counter reads 1.26x the cycles the dispatch lasted (3.0 "GHz"), on 8 us ones more:
+that, not the MFMA counter, made the r1 PMC figure read ~2x below the arithmetic one.
+FETCH_SIZE is doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md §HBM); KiB units.
+"""
+import csv
+import glob
+import json
+import sys
 from collections import defaultdict
-root = sys.argv[1]
-PASSES = int(sys.argv[2]) if len(sys.argv) > 2 else 2   # passes in the profiled run
-def load(name):
-    f = glob.glob(f"{root}/{name}/*/*_counter_collection.csv")[0]
-    d = defaultdict(lambda: defaultdict(float)); n = defaultdict(int); dur = defaultdict(float)
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        d[k][r["Counter_Name"]] += float(r["Counter_Value"])
+
+CLOCK_GHZ = 2.4          # the clock the 2.5 PFLOP/s peak is quoted at
+N_SIMD = 1024
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").replace("ladiff::", "")
+
+
+def load_counter(root, name):
+    files = glob.glob(f"{root}/{name}/**/*_counter_collection.csv", recursive=True)
+    if not files:
+        return None
+    val = defaultdict(lambda: defaultdict(float)); n = defaultdict(int); dur = defaultdict(float)
+    for r in csv.DictReader(open(files[0])):
+        k = short(r["Kernel_Name"])
+        val[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == name:
-            n[k] += 1; dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    return d, n, dur
-mf, n, dur = load("SQ_VALU_MFMA_BUSY_CYCLES")
-fe, _, _ = load("FETCH_SIZE"); wr, _, _ = load("WRITE_SIZE")
-print("# r1 / 03 - PMC counters of one benchmark pass (rocprofv3 --pmc, separate passes per counter group)\n")
-print("`rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 1 --cpu-sample 0` (2 passes; numbers below are per pass).")
-print("MFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 4 SIMD x 256 CU) (the GRBM counter is summed over the 8 XCDs).")
-print("Traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB at the L2 <-> fabric interface (Infinity-Cache hits included, so this is an upper bound on HBM bytes).\n")
-print("| kernel | launches/pass | us/launch (profiled) | MFMA util | fetch MB/launch (x2 corrected) | write MB/launch |")
-print("|---|---|---|---|---|---|")
-tot_f = tot_w = 0.0
-for k in sorted(n, key=lambda k: -dur[k]):
-    if n[k] < 2: continue
-    g = mf[k]["GRBM_GUI_ACTIVE"] / 8.0
-    util = mf[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / (g * 4 * 256) if g else 0.0
-    f = 2 * fe[k]["FETCH_SIZE"] * 1024 / 1e6; w = wr[k]["WRITE_SIZE"] * 1024 / 1e6
-    tot_f += f; tot_w += w
-    print(f"| `{k[-60:]}` | {n[k] / PASSES:.0f} | {dur[k] / n[k]:.2f} | {100 * util:.1f} % | {f / n[k]:.2f} | {w / n[k]:.2f} |")
-print(f"\nWhole pass: fetch {tot_f / PASSES / 1e3:.2f} GB (corrected), write {tot_w / PASSES / 1e3:.2f} GB; algorithmic minimum is ~0.12 GB of weights + ~1 GB of decoder activations,"
-      " the rest is operand re-reads served by the Infinity Cache (every kernel boundary empties the L2s).")
+            n[k] += 1
+            dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    return val, n, dur
+
+
+def load_trace(root):
+    files = glob.glob(f"{root}/stats/**/*_kernel_trace.csv", recursive=True)
+    n = defaultdict(int); dur = defaultdict(float)
+    for r in csv.DictReader(open(files[0])):
+        k = short(r["Kernel_Name"])
+        n[k] += 1
+        dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    return n, dur
+
+
+def main():
+    root, passes, out_md, out_json = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    sha = sys.argv[5] if len(sys.argv) > 5 else "unknown"
+    runs = passes + 1                                   # warm-up pass included in every count
+    tn, tdur = load_trace(root)
+    mf = load_counter(root, "SQ_VALU_MFMA_BUSY_CYCLES")
+    fe = load_counter(root, "FETCH_SIZE")
+    wr = load_counter(root, "WRITE_SIZE")
+    total_us = sum(tdur.values())
+    kernels = {}
+    for k in sorted(tn, key=lambda k: -tdur[k]):
+        e = {"launches_per_pass": tn[k] / runs, "us_per_launch": tdur[k] / tn[k], "share_of_pass": tdur[k] / total_us}
+        if mf and mf[1].get(k):
+            v, n, dur = mf
+            e["us_per_launch_pmc_run"] = dur[k] / n[k]
+            e["mfma_busy_cycles_per_launch"] = v[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / n[k]
+            e["mfma_util_pmc"] = v[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / (N_SIMD * dur[k] * 1e3 * CLOCK_GHZ)
+            # the same busy cycles against the un-countered duration (counters serialise dispatches and stretch them)
+            e["mfma_util_pmc_at_trace_duration"] = e["mfma_busy_cycles_per_launch"] / (N_SIMD * e["us_per_launch"] * 1e3 * CLOCK_GHZ)
+        if fe and fe[1].get(k):
+            e["fetch_bytes_per_launch"] = 2 * fe[0][k]["FETCH_SIZE"] * 1024 / fe[1][k]
+        if wr and wr[1].get(k):
+            e["write_bytes_per_launch"] = wr[0][k]["WRITE_SIZE"] * 1024 / wr[1][k]
+        kernels[k] = e
+    whole = {"us_per_pass": total_us / runs,
+             "fetch_bytes_per_pass": sum(e.get("fetch_bytes_per_launch", 0) * e["launches_per_pass"] for e in kernels.values()),
+             "write_bytes_per_pass": sum(e.get("write_bytes_per_launch", 0) * e["launches_per_pass"] for e in kernels.values()),
+             "mfma_util_pmc": sum(e.get("mfma_busy_cycles_per_launch", 0) * e["launches_per_pass"] for e in kernels.values())
+                              / (N_SIMD * total_us / runs * 1e3 * CLOCK_GHZ)}
+    dominant = next(iter(kernels))
+    summary = {"git_sha": sha, "command": "rocprofv3 ... -- python3 scripts/profile_pass.py bf16x3 %d" % passes,
+               "normalisation": "util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x 2.4 GHz); traffic = 2 x FETCH_SIZE + WRITE_SIZE",
+               "dominant_kernel": dominant, "kernels": kernels, "whole_pass": whole}
+    json.dump(summary, open(out_json, "w"), indent=1)
+    with open(out_md, "w") as f:
+        f.write(f"# PMC + kernel-trace summary (commit {sha}; {passes} passes + 1 warm-up per run)\n\n")
+        f.write("Separate rocprofv3 runs: `--kernel-trace --stats`, `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE`, `--pmc FETCH_SIZE`, "
+                "`--pmc WRITE_SIZE`, each `-- python3 scripts/profile_pass.py bf16x3 N`.\n")
+        f.write("MFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x 2.4 GHz) - calibrated in 02_mfma_calibration.md; "
+                "traffic = 2 x FETCH_SIZE + WRITE_SIZE at the L2 <-> fabric interface (Infinity-Cache hits included).\n\n")
+        f.write("| kernel | launches/pass | us/launch (trace) | % of pass | us/launch (pmc run) | MFMA util (pmc run) | MFMA util (trace duration) | fetch MB/launch | write MB/launch |\n|---|---|---|---|---|---|---|---|---|\n")
+        for k, e in kernels.items():
+            if e["launches_per_pass"] < 1:
+                continue
+            f.write(f"| `{k[-70:]}` | {e['launches_per_pass']:.0f} | {e['us_per_launch']:.2f} | {100 * e['share_of_pass']:.1f} | "
+                    f"{e.get('us_per_launch_pmc_run', 0):.2f} | {100 * e.get('mfma_util_pmc', 0):.1f} % | "
+                    f"{100 * e.get('mfma_util_pmc_at_trace_duration', 0):.1f} % | {e.get('fetch_bytes_per_launch', 0) / 1e6:.2f} | "
+                    f"{e.get('write_bytes_per_launch', 0) / 1e6:.2f} |\n")
+        f.write(f"\nWhole pass: {whole['us_per_pass'] / 1e3:.2f} ms of kernels, fetch {whole['fetch_bytes_per_pass'] / 1e9:.2f} GB, "
+                f"write {whole['write_bytes_per_pass'] / 1e9:.2f} GB, MFMA util {100 * whole['mfma_util_pmc']:.1f} % of the bf16 peak.\n")
+
+
+if __name__ == "__main__":
+    main()

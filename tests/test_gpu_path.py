@@ -445,8 +445,8 @@ def test_ddim_eta_half_with_step_noise(denoiser, vae, precision):
     sch = DDIMScheduler(set_alpha_to_one=False, steps_offset=1, **SCHED_KW)
     pipe = LADIFF(denoiser=denoiser, vae=vae, scheduler=sch, guidance_scale=7.5, num_inference_timesteps=20, eta=0.5,
                   precision=precision)
-    assert sch.needs_noise(0.5)
     z, feats = pipe.sample(text.to(DEV), lens, init_noise=noise.to(DEV), step_noise=sn.to(DEV))
+    assert sch.needs_noise(0.5)
     z_o, f_o = orc.sample_motions(syn.denoiser_weights(), syn.vae_weights(263), text, lens, noise, 20, "ddim", eta=0.5,
                                   step_noise=sn)
     z_0, _ = orc.sample_motions(syn.denoiser_weights(), syn.vae_weights(263), text, lens, noise, 20, "ddim", eta=0.0)
