@@ -192,6 +192,13 @@ int ladiff_finalize_latents(const float* latents, const int32_t* counts, float* 
  * and schedule. */
 int ladiff_sampler_create(void** sampler);
 int ladiff_sampler_destroy(void* sampler);
+/* How a sampler runs the N steps: 1 (default) = ONE persistent pipeline kernel for the whole loop when the call qualifies
+ * (guidance on, bf16x3 weights, a CU per pipeline stage) - every CU keeps one stage's weights in registers and blocks of
+ * prompts flow through the stages (csrc/systolic.hip); 0 = one launch per stage, captured in a hipGraph of up to 10 steps. */
+int ladiff_sampler_set_loop(void* sampler, int mode);
+/* Blocking read of the pipeline kernel's status word of the last call in this workspace: code 0 = completed,
+ * 2 = a stage timed out waiting for its producer (info = workgroup).  Debug / test aid. */
+int ladiff_reverse_status(void* ws, int B, int T, int n_steps, int* code, int* info);
 size_t ladiff_reverse_workspace_bytes(int B, int T, int n_steps);
 int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* const* w_split /*or NULL*/,
                              uint64_t weights_generation, const float* text_emb /*[2B or B,1,768]*/,

@@ -1,6 +1,7 @@
 // extern "C" surface of libladiff_hip.so (declared in include/ladiff_hip.h).
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "model.h"
 
@@ -24,7 +25,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---- reverse-loop workspace carve-up (floats)
 struct ReverseWs {
-    float *tables, *cache, *latents, *eps, *fwd;
+    float *tables, *cache, *latents, *eps, *fwd, *sys;
     int32_t* d_step;
     size_t fwd_floats, total_bytes;
 };
@@ -44,6 +45,7 @@ ReverseWs carve_reverse(void* ws, int B, int T, int n) {
     r.fwd_floats = den_forward_ws_floats(B2, T);
     if (pre > r.fwd_floats) r.fwd_floats = pre;
     r.fwd = take(r.fwd_floats);
+    r.sys = take(sys_ws_floats(B, T));                                 // block buffers, flags and stage table of the pipeline loop
     r.total_bytes = off * sizeof(float);
     return r;
 }
@@ -52,6 +54,8 @@ struct Sampler {
     hipGraphExec_t exec = nullptr;
     hipGraphExec_t setup = nullptr;       // per-call prologue (text cache, initial latents, counter reset, first network input)
     int unroll = 1;                       // denoiser steps captured per graph launch
+    int loop = 1;                         // 1: persistent pipeline kernel when the call qualifies (systolic.hip), 0: launch per stage
+    std::vector<unsigned char> stages;    // host copy of the pipeline's stage table (source of the upload)
     // capture key: a graph bakes pointers, shapes and scalars into its kernel nodes.  The weight tables are identified by
     // a hash over EVERY pointer of both tables plus the caller's generation id (bumped whenever a table is rebuilt), not
     // by the address of the host array (which a rebuilt table can land on again).
@@ -256,6 +260,24 @@ int ladiff_sampler_destroy(void* sampler) {
     return 0;
 }
 
+int ladiff_sampler_set_loop(void* sampler, int mode) {
+    Sampler* sp = reinterpret_cast<Sampler*>(sampler);
+    LADIFF_CHECK_ARG(sp != nullptr && (mode == 0 || mode == 1));
+    sp->loop = mode;
+    return 0;
+}
+
+int ladiff_reverse_status(void* ws, int B, int T, int n_steps, int* code, int* info) {
+    LADIFF_CHECK_ARG(ws && code && B > 0 && n_steps > 0);
+    if (T < 1 || T > LADIFF_MAX_LATENTS) return LADIFF_ERR_SHAPE;
+    const ReverseWs r = carve_reverse(ws, B, T, n_steps);
+    unsigned st[2] = {0u, 0u};
+    LADIFF_HIP(hipMemcpy(st, r.sys + sys_status_offset_floats(B, T), sizeof(st), hipMemcpyDeviceToHost));   // synchronises
+    *code = (int)st[0];
+    if (info) *info = (int)st[1];
+    return 0;
+}
+
 size_t ladiff_reverse_workspace_bytes(int B, int T, int n_steps) { return carve_reverse(nullptr, B, T, n_steps).total_bytes; }
 
 int ladiff_split_rows(const float* x, float* y, int R, int K, ladiff_stream_t stream) {
@@ -306,16 +328,17 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
         return launch_step_tail(xio, xios, W.norm.g, W.norm.b, r.latents, coef, r.d_step, step_noise, W.query_pe,
                                 guidance_scale, cfg, B, T, st);
     };
+    const bool pipeline = sp != nullptr && sp->loop == 1 && sys_supported(B, T, cfg, WSp != nullptr);
     if (sp == nullptr) {
         LADIFF_TRY(prologue(s));
         for (int i = 0; i < n_steps; ++i) LADIFF_TRY(one_step(s));
     } else {
         const void* kp[9] = {ws, counts, final_counts, coef, step_noise, stream, text_emb, init_noise, z};
-        const int ki[4] = {B, T, n_steps, cfg};
+        const int ki[4] = {B, T, n_steps, cfg + 2 * (pipeline ? 1 : 0)};
         const float kf[2] = {guidance_scale, init_noise_sigma};
         uint64_t h = hash_ptrs(w, DEN_NPARAMS, 1469598103934665603ull);
         if (w_split) h = hash_ptrs(w_split, DEN_NPARAMS, h ^ 0x9e3779b97f4a7c15ull);
-        const bool same = sp->exec && std::memcmp(kp, sp->key_ptrs, sizeof(kp)) == 0 &&
+        const bool same = sp->setup && std::memcmp(kp, sp->key_ptrs, sizeof(kp)) == 0 &&
                           std::memcmp(ki, sp->key_ints, sizeof(ki)) == 0 && std::memcmp(kf, sp->key_f, sizeof(kf)) == 0 &&
                           h == sp->key_hash && weights_generation == sp->key_gen;
         if (!same) {
@@ -335,19 +358,27 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
                 graph = nullptr;
                 LADIFF_HIP(i0);
             }
-            LADIFF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            // several steps per graph launch (the step index lives in device memory): fewer ~9 us replay gaps
-            int unroll = 1;
-            for (int u = 2; u <= 10; ++u) if (n_steps % u == 0) unroll = u;
-            sp->unroll = unroll;
-            int rc = 0;
-            for (int u = 0; u < unroll && rc == 0; ++u) rc = one_step(s);
-            const hipError_t ec = hipStreamEndCapture(s, &graph);
-            if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-            LADIFF_HIP(ec);
-            const hipError_t ei = hipGraphInstantiate(&sp->exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            LADIFF_HIP(ei);
+            if (pipeline) {
+                // stage table of the persistent pipeline (pointers of this call's weights and workspace): built and uploaded
+                // once per key; the host copy stays alive in the sampler until the next rebuild
+                LADIFF_TRY(sys_build_stages(W, WS, r.sys, B, T, sp->stages));
+                LADIFF_HIP(hipMemcpyAsync(r.sys, sp->stages.data(), sp->stages.size(), hipMemcpyHostToDevice, s));
+                LADIFF_HIP(hipStreamSynchronize(s));
+            } else {
+                LADIFF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                // several steps per graph launch (the step index lives in device memory): fewer ~9 us replay gaps
+                int unroll = 1;
+                for (int u = 2; u <= 10; ++u) if (n_steps % u == 0) unroll = u;
+                sp->unroll = unroll;
+                int rc = 0;
+                for (int u = 0; u < unroll && rc == 0; ++u) rc = one_step(s);
+                const hipError_t ec = hipStreamEndCapture(s, &graph);
+                if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+                LADIFF_HIP(ec);
+                const hipError_t ei = hipGraphInstantiate(&sp->exec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                LADIFF_HIP(ei);
+            }
             std::memcpy(sp->key_ptrs, kp, sizeof(kp));
             std::memcpy(sp->key_ints, ki, sizeof(ki));
             std::memcpy(sp->key_f, kf, sizeof(kf));
@@ -355,7 +386,14 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
             sp->key_gen = weights_generation;
         }
         LADIFF_HIP(hipGraphLaunch(sp->setup, s));
-        for (int i = 0; i < n_steps / sp->unroll; ++i) LADIFF_HIP(hipGraphLaunch(sp->exec, s));
+        if (pipeline) {
+            const float* tkv = r.cache + (size_t)B2 * D;
+            const float* ctab = tkv + (size_t)NL * B2 * 2 * D;
+            LADIFF_TRY(launch_systolic_loop(W, r.sys, r.tables, tkv, ctab, n_steps, coef, step_noise, r.latents, counts,
+                                            guidance_scale, B, T, 0, n_steps, s));
+        } else {
+            for (int i = 0; i < n_steps / sp->unroll; ++i) LADIFF_HIP(hipGraphLaunch(sp->exec, s));
+        }
     }
     // final zeroing of the rows past each motion's latent count: applied even when the denoiser ran unmasked
     // (TEST_EFFICIENCY), as ladiff.py:559-566 does

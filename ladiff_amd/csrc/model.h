@@ -35,6 +35,16 @@ int vae_encode(const EncoderW& w, const EncoderW* w_split, const float* features
                const int32_t* counts, const float* eps, int B, int F, int T, int C, float* mu, float* sd, float* latent, float* ws,
                size_t ws_floats, hipStream_t s);
 
+// systolic.hip: the guided denoiser loop as one persistent weight-stationary pipeline (bf16x3 mode)
+size_t sys_ws_floats(int B, int T);
+bool sys_supported(int B, int T, int cfg, bool split);
+int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int B, int T, std::vector<unsigned char>& host);
+size_t sys_stage_bytes(int B, int T);
+size_t sys_status_offset_floats(int B, int T);
+int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, const float* tkv, const float* ctab, int n_ctab,
+                         const float* coef, const float* noise, float* lat, const int32_t* counts, float gscale, int B, int T,
+                         int step_lo, int n, hipStream_t s);
+
 // qkv_attn.hip: in_proj GEMM + self-attention of the denoiser's sa_block in one launch (bf16x3 mode, S-format in / out)
 int launch_qkv_attention(const float* x, const float* w, const float* bias, const float* text_kv, const float* tables,
                          int kv_off, int step_stride, const int32_t* d_step, const int32_t* counts, int Bs, int b_off,

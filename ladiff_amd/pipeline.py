@@ -66,7 +66,7 @@ def remove_padding(tensors, lengths):
 class LADIFF(nn.Module):
     def __init__(self, cfg=None, datamodule=None, *, denoiser=None, vae=None, scheduler=None, text_encoder=None,
                  guidance_scale=None, num_inference_timesteps=None, eta=None, max_it=None, frame_per_latent=None,
-                 test_efficiency=None, use_graph=True, precision=None, **kwargs):
+                 test_efficiency=None, use_graph=True, precision=None, loop="pipeline", **kwargs):
         super().__init__()
         self.cfg = cfg
         self.datamodule = datamodule
@@ -100,6 +100,11 @@ class LADIFF(nn.Module):
         self.fact = None
         self.times = []
         self.use_graph = use_graph
+        # how the N steps run (include/ladiff_hip.h, ladiff_sampler_set_loop): "pipeline" = one persistent weight-stationary
+        # kernel for the whole loop when the call qualifies (guidance on, bf16x3), "launches" = one launch per stage in hipGraphs
+        if loop not in ("pipeline", "launches"):
+            raise ValueError(f"loop {loop!r} not supported")
+        self.loop = loop
         # matrix-product arithmetic of the denoiser loop: "fp32" (fp32-input MFMA) or "bf16x3" (3-term bf16 split)
         self.precision = precision if precision is not None else getattr(self.denoiser, "precision", "fp32")
         self._sampler = None
@@ -189,6 +194,8 @@ class LADIFF(nn.Module):
             h = c_void_p()
             _lib.check(L.ladiff_sampler_create(byref(h)))
             self._sampler = h
+        if self._sampler is not None:
+            _lib.check(L.ladiff_sampler_set_loop(self._sampler, 1 if self.loop == "pipeline" else 0))
         if init_noise is None:
             init_noise = torch.randn(B, T, 256, device=dev, dtype=torch.float32)       # ladiff.py:380-385
         if need_noise and step_noise is None:
@@ -220,6 +227,18 @@ class LADIFF(nn.Module):
         if run is not cur:
             cur.wait_stream(run)
         return plan["z"].clone()
+
+    def loop_status(self):
+        """(code, info) of the persistent pipeline kernel of the last `_diffusion_reverse` call; blocks until the stream has
+        drained.  code 0 = completed; 2 = a stage timed out on its producer (results are then invalid)."""
+        from ctypes import c_int
+        if self._plan is None:
+            return 0, 0
+        p = self._plan
+        code, info = c_int(0), c_int(0)
+        B, T = p["key"][0], p["key"][1]
+        _lib.check(_lib.lib().ladiff_reverse_status(_lib.ptr(p["ws"]), B, T, p["n"], byref(code), byref(info)))
+        return code.value, info.value
 
     # ------------------------------------------------------------------ callers' surface
     def sample(self, text_emb, lengths, init_noise=None, step_noise=None):
