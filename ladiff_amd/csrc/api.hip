@@ -145,6 +145,7 @@ int ladiff_gemm_split(const float* A, int lda, const float* A2, int lda2, int K1
 
 #ifdef LADIFF_STAMPS
 void ladiff_debug_set_stamps(unsigned long long* p) { g_stamps = p; }   // diagnostic builds only
+void ladiff_debug_set_sys_stamps(unsigned long long* p) { ladiff::g_sys_stamps = p; }
 #endif
 
 int ladiff_combine_rows(const float* partials, int n_planes, int M, const float* bias, const float* res, int mode,
@@ -262,8 +263,9 @@ int ladiff_sampler_destroy(void* sampler) {
 
 int ladiff_sampler_set_loop(void* sampler, int mode) {
     Sampler* sp = reinterpret_cast<Sampler*>(sampler);
-    LADIFF_CHECK_ARG(sp != nullptr && (mode == 0 || mode == 1));
-    sp->loop = mode;
+    LADIFF_CHECK_ARG(sp != nullptr && (mode == 0 || mode == 1 || mode == 2));
+    sp->loop = mode != 0;
+    sys_set_row_tiles(mode == 2 ? 1 : 2);          // 2: one prompt per block (16-row tiles), 1: three prompts (32-row tiles)
     return 0;
 }
 
@@ -334,7 +336,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
         for (int i = 0; i < n_steps; ++i) LADIFF_TRY(one_step(s));
     } else {
         const void* kp[9] = {ws, counts, final_counts, coef, step_noise, stream, text_emb, init_noise, z};
-        const int ki[4] = {B, T, n_steps, cfg + 2 * (pipeline ? 1 : 0)};
+        const int ki[4] = {B, T, n_steps, cfg + 2 * (pipeline ? sys_row_tiles(T) : 0)};
         const float kf[2] = {guidance_scale, init_noise_sigma};
         uint64_t h = hash_ptrs(w, DEN_NPARAMS, 1469598103934665603ull);
         if (w_split) h = hash_ptrs(w_split, DEN_NPARAMS, h ^ 0x9e3779b97f4a7c15ull);

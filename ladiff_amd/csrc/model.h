@@ -36,11 +36,16 @@ int vae_encode(const EncoderW& w, const EncoderW* w_split, const float* features
                size_t ws_floats, hipStream_t s);
 
 // systolic.hip: the guided denoiser loop as one persistent weight-stationary pipeline (bf16x3 mode)
+#ifdef LADIFF_STAMPS
+extern unsigned long long* g_sys_stamps;
+#endif
 size_t sys_ws_floats(int B, int T);
 bool sys_supported(int B, int T, int cfg, bool split);
 int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int B, int T, std::vector<unsigned char>& host);
 size_t sys_stage_bytes(int B, int T);
 size_t sys_status_offset_floats(int B, int T);
+void sys_set_row_tiles(int mr);
+int sys_row_tiles(int T);
 int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, const float* tkv, const float* ctab, int n_ctab,
                          const float* coef, const float* noise, float* lat, const int32_t* counts, float gscale, int B, int T,
                          int step_lo, int n, hipStream_t s);

@@ -43,11 +43,11 @@ namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int RT = 32;                    // rows of a block tile
 constexpr int CLD = D + 4;                // row stride of the fp32 staging tile in LDS (floats)
 constexpr int NSLICE = 8;                 // hidden slices of the two MLPs (128 columns each)
 constexpr int HS = FF / NSLICE;           // 128
 constexpr int NRED = 3;                   // row parts of the two reduce stages
+constexpr int NTAIL = 4;                  // tail workgroups (block b belongs to tail b % NTAIL)
 constexpr int FLAG_SLOTS = 8;
 constexpr int SYS_LDS_BYTES = 100 * 1024;   // > 80 KiB: one workgroup per CU, so the <= 256 workgroups sit on distinct CUs
 constexpr int GROUPS_PER_LAYER = 7;
@@ -76,7 +76,37 @@ struct SysArgs {
     const int32_t* counts;
     float gscale;
     int B, T, P, NB, step_lo, n_steps, n_ctab;
+    unsigned long long* stamps;           // diagnostic twin build only (-DLADIFF_STAMPS): [workgroup][step][block][8] realtime ticks
 };
+
+// In-kernel timeline (diagnostic twin build; the shipped library executes no stamp): s_memrealtime is one 100 MHz counter
+// for the whole chip, so stamps of different workgroups order the hand-offs between CUs.
+#ifdef LADIFF_STAMPS
+#define SYS_STAMP(i)                                                                                                   \
+    do {                                                                                                               \
+        if (p.stamps != nullptr && threadIdx.x == 0 && s < 4 && b < 4)                                                 \
+            p.stamps[(((size_t)blockIdx.x * 4 + s) * 4 + b) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();             \
+    } while (0)
+// per-workgroup totals behind the timeline: ticks blocked in wait_epoch, prefetch hits, blocks processed
+#define SYS_STAT_DECL unsigned long long st_wait = 0, st_hit = 0, st_n = 0, st_t = 0
+#define SYS_STAT_T0 st_t = __builtin_amdgcn_s_memrealtime()
+#define SYS_STAT_WAIT st_wait += __builtin_amdgcn_s_memrealtime() - st_t
+#define SYS_STAT_ITER(h) do { st_hit += (h) ? 1 : 0; st_n += 1; } while (0)
+#define SYS_STAT_END                                                                                                   \
+    do {                                                                                                               \
+        if (p.stamps != nullptr && threadIdx.x == 0) {                                                                 \
+            unsigned long long* o = p.stamps + (size_t)256 * 4 * 4 * 8 + (size_t)blockIdx.x * 4;                       \
+            o[0] = st_wait; o[1] = st_hit; o[2] = st_n;                                                                \
+        }                                                                                                              \
+    } while (0)
+#else
+#define SYS_STAMP(i) do { } while (0)
+#define SYS_STAT_DECL do { } while (0)
+#define SYS_STAT_T0 do { } while (0)
+#define SYS_STAT_WAIT do { } while (0)
+#define SYS_STAT_ITER(h) do { } while (0)
+#define SYS_STAT_END do { } while (0)
+#endif
 
 // ---------------------------------------------------------------- hand-off primitives
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p) {
@@ -92,8 +122,11 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 
 constexpr unsigned long long TIMEOUT_TICKS = 150000000ull;     // s_memrealtime runs at 100 MHz: 1.5 s per wait
 
+// LDS words of the hand-off protocol (last 16 bytes of the dynamic region)
+struct Ctl { int abort, ready, pad0, pad1; };
+
 // wave 0 polls flags[0 .. n) until all are >= epoch; everybody leaves through the barrier.  Returns false on abort.
-__device__ __forceinline__ bool wait_epoch(const unsigned* flags, int n, unsigned epoch, unsigned* status, int* lds_abort) {
+__device__ __forceinline__ bool wait_epoch(const unsigned* flags, int n, unsigned epoch, unsigned* status, Ctl* ctl) {
     const int lane = threadIdx.x & 63;
     if (threadIdx.x < 64) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -114,12 +147,12 @@ __device__ __forceinline__ bool wait_epoch(const unsigned* flags, int n, unsigne
                     break;
                 }
             }
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
         }
-        if (lane == 0) *lds_abort = bad;
+        if (lane == 0) ctl->abort = bad;
     }
     __syncthreads();
-    return *lds_abort == 0;
+    return ctl->abort == 0;
 }
 
 // all rows of this workgroup are stored: drain (every wave), meet, publish
@@ -146,21 +179,25 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& hi,
         hi[4 + e] = (__bf16)b[e]; lo[4 + e] = (__bf16)(b[e] - (float)hi[4 + e]);
     }
 }
-// fill 256 columns (4 k-blocks starting at kb0) of the RT-row operand tile from a block of fp32 rows in global memory
-template <int KB>
-__device__ __forceinline__ void fill_a256(char* tile, int kb0, __amdgpu_buffer_rsrc_t r, unsigned base) {
-    f32x4 v[4][2];
+// A [16 MR][256] fp32 block of rows held in registers between its loads and its LDS image: thread t owns the 8-column
+// units id = t + 256 u (row id / 32, columns 8 (id % 32) ..)
+template <int MR> struct Rows256 { f32x4 v[2 * MR][2]; };
+template <int MR>
+__device__ __forceinline__ void issue_rows(Rows256<MR>& x, __amdgpu_buffer_rsrc_t r, unsigned base) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 2 * MR; ++u) {
         const int id = threadIdx.x + 256 * u, row = id >> 5, c8 = id & 31;
-        v[u][0] = ld_sc1(r, base + row * 1024 + c8 * 32);
-        v[u][1] = ld_sc1(r, base + row * 1024 + c8 * 32 + 16);
+        x.v[u][0] = ld_sc1(r, base + row * 1024 + c8 * 32);
+        x.v[u][1] = ld_sc1(r, base + row * 1024 + c8 * 32 + 16);
     }
+}
+template <int KB, int MR>
+__device__ __forceinline__ void commit_rows(char* tile, int kb0, const Rows256<MR>& x) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 2 * MR; ++u) {
         const int id = threadIdx.x + 256 * u, row = id >> 5, c8 = id & 31;
         bf16x8 hi, lo;
-        split8(v[u][0], v[u][1], hi, lo);
+        split8(x.v[u][0], x.v[u][1], hi, lo);
         *reinterpret_cast<bf16x8*>(a_slot<KB>(tile, row, kb0 + (c8 >> 3), c8 & 7)) = hi;
         *reinterpret_cast<bf16x8*>(a_slot<KB>(tile, row, kb0 + (c8 >> 3), 8 + (c8 & 7))) = lo;
     }
@@ -186,26 +223,34 @@ __device__ __forceinline__ void load_w(WFrag<NT, KS>& f, const float* w, int ldw
     }
 }
 
-// acc[i][j] += A(tile rows 16 i ..) . W(tile j)^T over KS k-steps; MR = row tiles used
+// acc[i][j] += A(tile rows 16 i ..) . W(tile j)^T over KS k-steps; MR = row tiles.  The operand fragments of k-step s + 1
+// are requested before the MFMAs of step s are issued, so their LDS latency hides under 3 MR NT MFMAs.
 template <int KB, int NT, int KS, int MR>
 __device__ __forceinline__ void mma(const char* tile, const WFrag<NT, KS>& f, f32x4 (&acc)[MR][NT]) {
     const int lane = threadIdx.x & 63, frow = lane & 15, fk = lane >> 4;
+    char* const t = const_cast<char*>(tile);
+    bf16x8 ah[2][MR], al[2][MR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        ah[0][i] = *reinterpret_cast<const bf16x8*>(a_slot<KB>(t, 16 * i + frow, 0, fk));
+        al[0][i] = *reinterpret_cast<const bf16x8*>(a_slot<KB>(t, 16 * i + frow, 0, 8 + fk));
+    }
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        bf16x8 ah[MR], al[MR];
+        if (s + 1 < KS) {
 #pragma unroll
-        for (int i = 0; i < MR; ++i) {
-            const int row = 16 * i + frow;
-            ah[i] = *reinterpret_cast<const bf16x8*>(a_slot<KB>(const_cast<char*>(tile), row, s >> 1, 4 * (s & 1) + fk));
-            al[i] = *reinterpret_cast<const bf16x8*>(a_slot<KB>(const_cast<char*>(tile), row, s >> 1, 8 + 4 * (s & 1) + fk));
+            for (int i = 0; i < MR; ++i) {
+                ah[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(a_slot<KB>(t, 16 * i + frow, (s + 1) >> 1, 4 * ((s + 1) & 1) + fk));
+                al[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(a_slot<KB>(t, 16 * i + frow, (s + 1) >> 1, 8 + 4 * ((s + 1) & 1) + fk));
+            }
         }
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], f.hi[j][s], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], f.lo[j][s], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], f.hi[j][s], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s & 1][i], f.hi[j][s], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1][i], f.lo[j][s], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1][i], f.hi[j][s], acc[i][j], 0, 0, 0);
             }
     }
 }
@@ -239,83 +284,153 @@ __device__ __forceinline__ void row_stats4(const f32x4 v, float& mean, float& rs
     q = wave_sum(q);
     rstd = rsqrtf(q * (1.f / 256.f) + LN_EPS);
 }
+__device__ __forceinline__ f32x4 sum8(const f32x4 (&pl)[NSLICE]) {       // fixed summation tree of the eight hidden slices
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        v[i] = ((pl[0][i] + pl[1][i]) + (pl[2][i] + pl[3][i])) + ((pl[4][i] + pl[5][i]) + (pl[6][i] + pl[7][i]));
+    return v;
+}
 
-// block geometry: row r of block b = (branch br, prompt b*P + pl, latent t), r = (br*P + pl)*T + t
-struct RowInfo { int valid, b2, prompt, t; };
-__device__ __forceinline__ RowInfo row_info(const SysArgs& p, int b, int r) {
-    RowInfo o;
-    const int sb = r / p.T;
-    o.t = r - sb * p.T;
-    const int br = sb / p.P, pl = sb - br * p.P;
-    o.prompt = b * p.P + pl;
-    o.valid = (br < 2) && (o.prompt < p.B);
-    o.b2 = br * p.B + o.prompt;
-    return o;
+// ---------------------------------------------------------------- the pipelined stage loop
+// A stage visits its blocks in the order (step, block); block order is the same everywhere, so the dependency graph is a
+// lattice and no stage can wait on something that waits on it.  While a block is being computed the NEXT block's flags are
+// polled once and, if they are up, its hand-off loads are already in flight (registers `nxt`): a stage's time per block is
+// then its compute + store time, not the whole store -> flag -> poll -> load chain.
+//   R::Pay            register image of one block's inputs
+//   r.issue(s, b, pay) every load of block (s, b)                r.commit(pay)  registers -> LDS operand images
+//   r.compute(s, b, pay) the stage's arithmetic and its sc1 stores
+template <class R>
+__device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R& r, Ctl* ctl, int b0, int bstride) {
+    typename R::Pay cur, nxt;
+    bool have = false;
+    const int lane = threadIdx.x & 63;
+    SYS_STAT_DECL;
+    for (int s = 0; s < p.n_steps; ++s)
+        for (int b = b0; b < p.NB; b += bstride) {
+            SYS_STAMP(0);
+            SYS_STAT_ITER(have);
+            if (!have) {
+                SYS_STAT_T0;
+                if (!wait_epoch(flag_of(p, st.wait_group, b, 0), st.wait_n, s + 1, p.status, ctl)) return;
+                SYS_STAT_WAIT;
+                r.issue(s, b, cur);
+            }
+            SYS_STAMP(1);
+            int s2 = s, b2 = b + bstride;
+            if (b2 >= p.NB) { s2 = s + 1; b2 = b0; }
+            const bool has_next = R::PREFETCH && s2 < p.n_steps;
+            unsigned fv = 0xffffffffu;                                   // one poll of the next block's flags, in flight under commit
+            if (has_next && threadIdx.x < 64 && lane < st.wait_n)
+                fv = __hip_atomic_load((const gu32*)flag_of(p, st.wait_group, b2, 0) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            r.commit(cur);
+            if (threadIdx.x < 64) {
+                const int ok = has_next && __all(fv >= (unsigned)(s2 + 1));
+                if (lane == 0) ctl->ready = ok;
+            }
+            __syncthreads();
+            have = R::PREFETCH && ctl->ready != 0;
+            if constexpr (R::PREFETCH) { if (have) r.issue(s2, b2, nxt); }
+            SYS_STAMP(2);
+            r.compute(s, b, cur);
+            SYS_STAMP(4);
+            publish(flag_of(p, st.out_group, b, st.out_slot), s + 1);
+            SYS_STAMP(5);
+            if constexpr (R::PREFETCH) { if (have) cur = nxt; }
+        }
+    SYS_STAT_END;
 }
 
 // ---------------------------------------------------------------- roles
 // QKV: one head.  in_proj rows {q,k,v} x 64 of head `slice` on the block, then softmax(q k^T / 8) v over the T latent
 // keys of the sample (masked by its latent count), the text token and the time token.
-__device__ __forceinline__ void run_qkv(const SysArgs& p, const Stage& st, char* lds, int* lds_abort) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frow = lane & 15;
-    const int h = st.slice, T = p.T, nkeys = p.T + 2;
-    constexpr int QLD = 196;
-    char* const atile = lds;                                              // 32 KiB operand tile
-    float* const qt = reinterpret_cast<float*>(lds + 32768);              // [RT][QLD] q | k | v (fp32)
-    float* const xt = qt + RT * QLD;                                      // [RT / 1 + 1][128] text k|v per sample-branch, time k|v last
-    float* const sc = xt + (RT + 1) * 128;                                // [RT][16] scores
+template <int MR>
+struct QkvRole {
+    static constexpr int RT = 16 * MR, QLD = 196;
+    static constexpr bool PREFETCH = true;
+    struct Pay { Rows256<MR> x; f32x4 xk[2]; int cnt; };
+    const SysArgs& p; const Stage& st;
+    char* atile; float *qt, *xt, *sc; int* cnt;
     WFrag<3, 8> wf;
-    // tile column tc = 48 wave + 16 j + frow: part tc / 64 (q, k, v), matrix row part * 256 + h * 64 + tc % 64
-    load_w(wf, st.w0, D, 0, [&](int j) { const int tc = 48 * wave + 16 * j; return (tc >> 6) * 256 + h * 64 + (tc & 63); });
     float bcol[3];
+    __amdgpu_buffer_rsrc_t rin, rout;
+    const float* tkv;
+    int h, T, P, nkeys, nsb, nrows;
+    int s_row[2], s_j[2], s_sx[2], o_sx[2], x_br[2], x_pl[2], c_pl;
+
+    __device__ __forceinline__ QkvRole(const SysArgs& p_, const Stage& st_, char* lds) : p(p_), st(st_) {
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frow = lane & 15;
+        h = st.slice; T = p.T; P = p.P; nkeys = T + 2; nsb = 2 * P; nrows = nsb * T;
+        atile = lds;                                                     // [RT] x K=256 operand tile
+        qt = reinterpret_cast<float*>(lds + RT * 1024);                  // [RT][QLD] q | k | v (fp32)
+        xt = qt + RT * QLD;                                              // [2P + 1][128]: text k|v per sample-branch, time k|v last
+        sc = xt + 16 * 128;                                              // [RT][16] scores
+        cnt = reinterpret_cast<int*>(sc + RT * 16);                      // [2P] latent counts of the block's sample-branches
+        // tile column tc = 48 wave + 16 j + frow: part tc / 64 (q, k, v), matrix row part * 256 + h * 64 + tc % 64
+        load_w(wf, st.w0, D, 0, [&](int j) { const int tc = 48 * wave + 16 * j; return (tc >> 6) * 256 + h * 64 + (tc & 63); });
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { const int tc = 48 * wave + 16 * j + frow; bcol[j] = st.b0[(tc >> 6) * 256 + h * 64 + (tc & 63)]; }
-    const __amdgpu_buffer_rsrc_t rin = rsrc_of(st.in0), rout = rsrc_of(st.out);
-    const float* tkv = p.tkv + (size_t)st.layer * 2 * p.B * 512;
-    const int nsb = 2 * p.P;                                              // sample-branches per block
-    for (int s = 0; s < p.n_steps; ++s) {
+        for (int j = 0; j < 3; ++j) { const int tc = 48 * wave + 16 * j + frow; bcol[j] = st.b0[(tc >> 6) * 256 + h * 64 + (tc & 63)]; }
+        rin = rsrc_of(st.in0); rout = rsrc_of(st.out);
+        tkv = p.tkv + (size_t)st.layer * 2 * p.B * 512;
+        // every index that does not depend on the block is computed once (integer divisions by run-time T / P are ~40
+        // instructions each): score items (row, key), output items (row, 4 columns), extra K|V slots
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int id = tid + 256 * u;
+            s_row[u] = id / nkeys; s_j[u] = id - s_row[u] * nkeys; s_sx[u] = s_row[u] / T;
+            if (id >= nrows * nkeys) s_row[u] = -1;
+            o_sx[u] = (id >> 4) / T;
+            const int sx = id >> 5;
+            x_br[u] = sx / P; x_pl[u] = sx - x_br[u] * P;
+        }
+        c_pl = tid % P;                                                  // tid < nsb: sample-branch whose count this thread fetches
+    }
+    __device__ __forceinline__ void issue(int s, int b, Pay& y) {
+        const int tid = threadIdx.x;
         const float* timekv = p.tables + (size_t)(p.step_lo + s) * DEN_STEP_STRIDE + st.layer * DEN_LAYER_STRIDE + DEN_OFF_TIME_KV;
-        for (int b = 0; b < p.NB; ++b) {
-            // text / time K|V slices of this head (read-only data of earlier kernels: plain loads), issued before the wait
-            f32x4 xk[2];
-            int xi[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int f4 = tid + 256 * u, sx = f4 >> 5, c4 = (f4 & 31) * 4;     // [nsb + 1][128]
-                xi[u] = sx <= nsb ? f4 : -1;
-                xk[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (sx < nsb) {
-                    const int br = sx / p.P, prompt = b * p.P + (sx - br * p.P);
-                    if (prompt < p.B) xk[u] = ld4(tkv + (size_t)(br * p.B + prompt) * 512 + (c4 < 64 ? c4 : 192 + c4) + h * 64);
-                } else if (sx == nsb) {
-                    xk[u] = ld4(timekv + (c4 < 64 ? c4 : 192 + c4) + h * 64);
-                }
+        for (int u = 0; u < 2; ++u) {                                    // text / time K|V slices of this head: [nsb + 1][128]
+            const int f4 = tid + 256 * u, sx = f4 >> 5, c4 = (f4 & 31) * 4;
+            y.xk[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (sx < nsb) {
+                const int prompt = b * P + x_pl[u];
+                if (prompt < p.B) y.xk[u] = ld4(tkv + (size_t)(x_br[u] * p.B + prompt) * 512 + (c4 < 64 ? c4 : 192 + c4) + h * 64);
+            } else if (sx == nsb) {
+                y.xk[u] = ld4(timekv + (c4 < 64 ? c4 : 192 + c4) + h * 64);
             }
-            if (!wait_epoch(flag_of(p, st.wait_group, b, 0), st.wait_n, s + 1, p.status, lds_abort)) return;
-            fill_a256<4>(atile, 0, rin, (unsigned)b * RT * 1024);
+        }
+        y.cnt = T;
+        if (tid < nsb && p.counts != nullptr && b * P + c_pl < p.B) { y.cnt = p.counts[b * P + c_pl]; y.cnt = y.cnt > T ? T : y.cnt; }
+        issue_rows<MR>(y.x, rin, (unsigned)b * RT * 1024);
+    }
+    __device__ __forceinline__ void commit(const Pay& y) {
+        const int tid = threadIdx.x;
+        commit_rows<4, MR>(atile, 0, y.x);
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-                if (xi[u] >= 0) st4(xt + xi[u] * 4, xk[u]);
-            __syncthreads();
-            f32x4 acc[2][3];
-            zero_acc(acc);
-            mma<4, 3, 8, 2>(atile, wf, acc);
+        for (int u = 0; u < 2; ++u)
+            if (((tid + 256 * u) >> 5) <= nsb) st4(xt + (tid + 256 * u) * 4, y.xk[u]);
+        if (tid < nsb) cnt[tid] = y.cnt;
+    }
+    __device__ __forceinline__ void compute(int s, int b, const Pay&) {
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frow = lane & 15;
+        f32x4 acc[MR][3];
+        zero_acc(acc);
+        mma<4, 3, 8, MR>(atile, wf, acc);
+        SYS_STAMP(3);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MR; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int tc = 48 * wave + 16 * j + frow;
-                    const float scl = tc < 64 ? 0.125f : 1.f;           // q / sqrt(64), exact
+            for (int j = 0; j < 3; ++j) {
+                const int tc = 48 * wave + 16 * j + frow;
+                const float scl = tc < 64 ? 0.125f : 1.f;               // q / sqrt(64), exact
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) qt[(16 * i + 4 * (lane >> 4) + r) * QLD + tc] = (acc[i][j][r] + bcol[j]) * scl;
-                }
-            __syncthreads();
-            const int nrows = nsb * T;
-            for (int u = tid; u < nrows * nkeys; u += 256) {             // one thread per (row, key)
-                const int row = u / nkeys, j = u - row * nkeys, sx = row / T;
-                const int br = sx / p.P, prompt = b * p.P + (sx - br * p.P);
-                int nv = T;
-                if (p.counts != nullptr && prompt < p.B) { nv = p.counts[prompt]; nv = nv > T ? T : nv; }
+                for (int r = 0; r < 4; ++r) qt[(16 * i + 4 * (lane >> 4) + r) * QLD + tc] = (acc[i][j][r] + bcol[j]) * scl;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < MR; ++u) {                                   // one thread per (row, key): 64-long dot product
+            const int row = s_row[u], j = s_j[u], sx = s_sx[u];
+            if (row >= 0) {
                 const float* kp = j < T ? qt + (sx * T + j) * QLD + 64 : (j == T ? xt + sx * 128 : xt + nsb * 128);
                 const float* qp = qt + row * QLD;
                 float d = 0.f;
@@ -324,393 +439,524 @@ __device__ __forceinline__ void run_qkv(const SysArgs& p, const Stage& st, char*
                     const f32x4 a = ld4(qp + c), k4 = ld4(kp + c);
                     d = fmaf(a[0], k4[0], d); d = fmaf(a[1], k4[1], d); d = fmaf(a[2], k4[2], d); d = fmaf(a[3], k4[3], d);
                 }
-                sc[row * 16 + j] = (j < T && j >= nv) ? -INFINITY : d;
+                sc[row * 16 + j] = (j < T && j >= cnt[sx]) ? -INFINITY : d;
             }
-            __syncthreads();
-            if (tid < nrows) {
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < MR; ++u) {                                   // one thread per (row, 4 columns): softmax + P.V
+            const int id = tid + 256 * u, row = id >> 4, c4 = (id & 15) * 4, sx = o_sx[u];
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            if (row < nrows) {
                 float e[LADIFF_MAX_LATENTS + 2];
                 float m = -INFINITY;
 #pragma unroll
-                for (int j = 0; j < LADIFF_MAX_LATENTS + 2; ++j) { e[j] = j < nkeys ? sc[tid * 16 + j] : -INFINITY; m = fmaxf(m, e[j]); }
+                for (int j = 0; j < LADIFF_MAX_LATENTS + 2; ++j) { e[j] = j < nkeys ? sc[row * 16 + j] : -INFINITY; m = fmaxf(m, e[j]); }
                 float l = 0.f;
 #pragma unroll
-                for (int j = 0; j < LADIFF_MAX_LATENTS + 2; ++j) { e[j] = j < nkeys ? expf(e[j] - m) : 0.f; l += e[j]; }
+                for (int j = 0; j < LADIFF_MAX_LATENTS + 2; ++j) {     // exp(x) as one v_exp_f32: 2^(x log2 e)
+                    e[j] = j < nkeys ? __builtin_amdgcn_exp2f((e[j] - m) * 1.4426950408889634f) : 0.f;
+                    l += e[j];
+                }
                 const float inv = 1.f / l;
 #pragma unroll
-                for (int j = 0; j < LADIFF_MAX_LATENTS + 2; ++j)
-                    if (j < nkeys) sc[tid * 16 + j] = e[j] * inv;
-            }
-            __syncthreads();
-            for (int u = tid; u < RT * 16; u += 256) {                   // one thread per (row, 4 columns)
-                const int row = u >> 4, c4 = (u & 15) * 4;
-                f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                if (row < nrows) {
-                    const int sx = row / T;
-                    for (int j = 0; j < nkeys; ++j) {
-                        const float pj = sc[row * 16 + j];
+                for (int j = 0; j < LADIFF_MAX_LATENTS + 2; ++j) {
+                    if (j < nkeys) {
+                        const float pj = e[j] * inv;
                         const float* vp = j < T ? qt + (sx * T + j) * QLD + 128 : (j == T ? xt + sx * 128 + 64 : xt + nsb * 128 + 64);
                         const f32x4 v = ld4(vp + c4);
                         o[0] = fmaf(pj, v[0], o[0]); o[1] = fmaf(pj, v[1], o[1]); o[2] = fmaf(pj, v[2], o[2]); o[3] = fmaf(pj, v[3], o[3]);
                     }
                 }
-                st_sc1(rout, ((unsigned)b * RT + row) * 1024 + (h * 64 + c4) * 4, o);
             }
-            publish(flag_of(p, st.out_group, b, st.out_slot), s + 1);
+            st_sc1(rout, ((unsigned)b * RT + row) * 1024 + (h * 64 + c4) * 4, o);
         }
     }
-}
+};
 
 // OUT: X1 = LN1(x + out_proj(att))
-__device__ __forceinline__ void run_out(const SysArgs& p, const Stage& st, char* lds, int* lds_abort) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    char* const atile = lds;
-    float* const ct = reinterpret_cast<float*>(lds + 32768);
+template <int MR>
+struct OutRole {
+    static constexpr int RT = 16 * MR, RPW = RT / 4;
+    static constexpr bool PREFETCH = true;
+    struct Pay { Rows256<MR> att; f32x4 res[RPW]; };
+    const SysArgs& p; const Stage& st;
+    char* atile; float* ct;
     WFrag<4, 8> wf;
-    load_w(wf, st.w0, D, 0, [&](int j) { return 64 * wave + 16 * j; });
-    const int c = 4 * lane;
-    const f32x4 bias = ld4(st.b0 + c), gg = ld4(st.g + c), bb = ld4(st.be + c);
-    const __amdgpu_buffer_rsrc_t ratt = rsrc_of(st.in0), rx = rsrc_of(st.in1), rout = rsrc_of(st.out);
-    for (int s = 0; s < p.n_steps; ++s)
-        for (int b = 0; b < p.NB; ++b) {
-            if (!wait_epoch(flag_of(p, st.wait_group, b, 0), st.wait_n, s + 1, p.status, lds_abort)) return;
-            const unsigned base = (unsigned)b * RT * 1024;
-            f32x4 res[8];
+    f32x4 bias, gg, bb;
+    __amdgpu_buffer_rsrc_t ratt, rx, rout;
+    __device__ __forceinline__ OutRole(const SysArgs& p_, const Stage& st_, char* lds) : p(p_), st(st_) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        atile = lds; ct = reinterpret_cast<float*>(lds + RT * 1024);
+        load_w(wf, st.w0, D, 0, [&](int j) { return 64 * wave + 16 * j; });
+        bias = ld4(st.b0 + 4 * lane); gg = ld4(st.g + 4 * lane); bb = ld4(st.be + 4 * lane);
+        ratt = rsrc_of(st.in0); rx = rsrc_of(st.in1); rout = rsrc_of(st.out);
+    }
+    __device__ __forceinline__ void issue(int, int b, Pay& y) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const unsigned base = (unsigned)b * RT * 1024;
+        issue_rows<MR>(y.att, ratt, base);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) res[q] = ld_sc1(rx, base + (wave + 4 * q) * 1024 + c * 4);
-            fill_a256<4>(atile, 0, ratt, base);
-            __syncthreads();
-            f32x4 acc[2][4];
-            zero_acc(acc);
-            mma<4, 4, 8, 2>(atile, wf, acc);
-            stage_c(ct, acc, [&](int j) { return 64 * wave + 16 * j; });
-            __syncthreads();
+        for (int q = 0; q < RPW; ++q) y.res[q] = ld_sc1(rx, base + (wave + 4 * q) * 1024 + lane * 16);
+    }
+    __device__ __forceinline__ void commit(const Pay& y) { commit_rows<4, MR>(atile, 0, y.att); }
+    __device__ __forceinline__ void compute(int s, int b, const Pay& y) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
+        const unsigned base = (unsigned)b * RT * 1024;
+        f32x4 acc[MR][4];
+        zero_acc(acc);
+        mma<4, 4, 8, MR>(atile, wf, acc);
+        SYS_STAMP(3);
+        stage_c(ct, acc, [&](int j) { return 64 * wave + 16 * j; });
+        __syncthreads();
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int row = wave + 4 * q;
-                f32x4 v = ld4(ct + row * CLD + c);
+        for (int q = 0; q < RPW; ++q) {
+            const int row = wave + 4 * q;
+            f32x4 v = ld4(ct + row * CLD + c);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[i] + res[q][i];
-                float mean, rstd;
-                row_stats4(v, mean, rstd);
+            for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[i] + y.res[q][i];
+            float mean, rstd;
+            row_stats4(v, mean, rstd);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i];
-                st_sc1(rout, base + row * 1024 + c * 4, v);
-            }
-            publish(flag_of(p, st.out_group, b, st.out_slot), s + 1);
+            for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i];
+            st_sc1(rout, base + row * 1024 + c * 4, v);
         }
-}
+    }
+};
 
 // LIN / FFN: hidden slice = act(x W1_slice^T + b1_slice) (128 columns), partial = hidden . W2[:, slice]^T (256 columns)
-template <int ACT>
-__device__ __forceinline__ void run_mlp(const SysArgs& p, const Stage& st, char* lds, int* lds_abort) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frow = lane & 15, fk = lane >> 4;
-    char* const atile = lds;                                            // [RT] x K=256
-    char* const htile = lds + 32768;                                    // [RT] x K=128 (hidden slice, S-format)
-    float* const ct = reinterpret_cast<float*>(lds + 32768 + 16384);
-    const int j0 = st.slice * HS;
+template <int MR, int ACT>
+struct MlpRole {
+    static constexpr int RT = 16 * MR, RPW = RT / 4;
+    static constexpr bool PREFETCH = true;
+    struct Pay { Rows256<MR> x; };
+    const SysArgs& p; const Stage& st;
+    char *atile, *htile; float* ct;
     WFrag<2, 8> w1;
     WFrag<4, 4> w2;
-    load_w(w1, st.w0, D, 0, [&](int j) { return j0 + 32 * wave + 16 * j; });
-    load_w(w2, st.w1, FF, 2 * st.slice, [&](int j) { return 64 * wave + 16 * j; });
     float b1[2];
+    __amdgpu_buffer_rsrc_t rin, rout;
+    unsigned plane;
+    __device__ __forceinline__ MlpRole(const SysArgs& p_, const Stage& st_, char* lds) : p(p_), st(st_) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, frow = lane & 15;
+        atile = lds;                                                     // [RT] x K=256
+        htile = lds + RT * 1024;                                         // [RT] x K=128 (hidden slice, S-format)
+        ct = reinterpret_cast<float*>(lds + RT * 1024 + RT * 512);
+        const int j0 = st.slice * HS;
+        load_w(w1, st.w0, D, 0, [&](int j) { return j0 + 32 * wave + 16 * j; });
+        load_w(w2, st.w1, FF, 2 * st.slice, [&](int j) { return 64 * wave + 16 * j; });
 #pragma unroll
-    for (int j = 0; j < 2; ++j) b1[j] = st.b0[j0 + 32 * wave + 16 * j + frow];
-    const __amdgpu_buffer_rsrc_t rin = rsrc_of(st.in0), rout = rsrc_of(st.out);
-    const unsigned plane = (unsigned)st.slice * p.NB * RT * 1024;
-    for (int s = 0; s < p.n_steps; ++s)
-        for (int b = 0; b < p.NB; ++b) {
-            if (!wait_epoch(flag_of(p, st.wait_group, b, 0), st.wait_n, s + 1, p.status, lds_abort)) return;
-            const unsigned base = (unsigned)b * RT * 1024;
-            fill_a256<4>(atile, 0, rin, base);
-            __syncthreads();
-            f32x4 acc1[2][2];
-            zero_acc(acc1);
-            mma<4, 2, 8, 2>(atile, w1, acc1);
-            // hidden slice -> S-format operand tile (k = hidden column within the slice)
+        for (int j = 0; j < 2; ++j) b1[j] = st.b0[j0 + 32 * wave + 16 * j + frow];
+        rin = rsrc_of(st.in0); rout = rsrc_of(st.out);
+        plane = (unsigned)st.slice * p.NB * RT * 1024;
+    }
+    __device__ __forceinline__ void issue(int, int b, Pay& y) { issue_rows<MR>(y.x, rin, (unsigned)b * RT * 1024); }
+    __device__ __forceinline__ void commit(const Pay& y) { commit_rows<4, MR>(atile, 0, y.x); }
+    __device__ __forceinline__ void compute(int s, int b, const Pay&) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, frow = lane & 15, fk = lane >> 4;
+        const unsigned base = (unsigned)b * RT * 1024;
+        f32x4 acc1[MR][2];
+        zero_acc(acc1);
+        mma<4, 2, 8, MR>(atile, w1, acc1);
+        SYS_STAMP(3);
+        // hidden slice -> S-format operand tile (k = hidden column within the slice)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MR; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int k = 32 * wave + 16 * j + frow;             // 0..127
+            for (int j = 0; j < 2; ++j) {
+                const int k = 32 * wave + 16 * j + frow;                 // 0..127
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * i + 4 * fk + r;
-                        const float v = act_c<ACT>(acc1[i][j][r] + b1[j]);
-                        const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
-                        __bf16* hp = reinterpret_cast<__bf16*>(a_slot<2>(htile, row, k >> 6, (k & 63) >> 3)) + (k & 7);
-                        __bf16* lp = reinterpret_cast<__bf16*>(a_slot<2>(htile, row, k >> 6, 8 + ((k & 63) >> 3))) + (k & 7);
-                        *hp = hi; *lp = lo;
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * i + 4 * fk + r;
+                    const float v = act_c<ACT>(acc1[i][j][r] + b1[j]);
+                    const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
+                    *(reinterpret_cast<__bf16*>(a_slot<2>(htile, row, k >> 6, (k & 63) >> 3)) + (k & 7)) = hi;
+                    *(reinterpret_cast<__bf16*>(a_slot<2>(htile, row, k >> 6, 8 + ((k & 63) >> 3))) + (k & 7)) = lo;
                 }
-            __syncthreads();
-            f32x4 acc2[2][4];
-            zero_acc(acc2);
-            mma<2, 4, 4, 2>(htile, w2, acc2);
-            stage_c(ct, acc2, [&](int j) { return 64 * wave + 16 * j; });
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int row = wave + 4 * q;
-                st_sc1(rout, plane + base + row * 1024 + lane * 16, ld4(ct + row * CLD + 4 * lane));
             }
-            publish(flag_of(p, st.out_group, b, st.out_slot), s + 1);
+        __syncthreads();
+        f32x4 acc2[MR][4];
+        zero_acc(acc2);
+        mma<2, 4, 4, MR>(htile, w2, acc2);
+        stage_c(ct, acc2, [&](int j) { return 64 * wave + 16 * j; });
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const int row = wave + 4 * q;
+            st_sc1(rout, plane + base + row * 1024 + lane * 16, ld4(ct + row * CLD + 4 * lane));
         }
-}
+    }
+};
 
-// rows of a block handled by reduce part `part`: [lo, hi)
-__device__ __forceinline__ void part_rows(int part, int& lo, int& hi) {
-    constexpr int PER = (RT + NRED - 1) / NRED;       // 11
-    lo = part * PER;
-    hi = lo + PER < RT ? lo + PER : RT;
+// rows [lo, hi) of a block handled by reduce part `part`: the 2 P T live rows split evenly
+__device__ __forceinline__ void part_rows(const SysArgs& p, int part, int& lo, int& hi) {
+    const int live = 2 * p.P * p.T, per = (live + NRED - 1) / NRED;
+    lo = part * per;
+    hi = lo + per < live ? lo + per : live;
+    if (lo > hi) lo = hi;
 }
 
 // RED2: X2 = LN2(X1 + sum_j partial_j + b2) + c[step, layer, sample | pad]
-__device__ __forceinline__ void run_red2(const SysArgs& p, const Stage& st, char* lds, int* lds_abort) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = 4 * lane;
-    const f32x4 bias = ld4(st.b0 + c), gg = ld4(st.g + c), bb = ld4(st.be + c);
-    const __amdgpu_buffer_rsrc_t rp = rsrc_of(st.in0), rx = rsrc_of(st.in1), rout = rsrc_of(st.out);
-    int lo, hi;
-    part_rows(st.slice, lo, hi);
-    const unsigned pstride = (unsigned)p.NB * RT * 1024;
-    const int R = 2 * p.B + 1;
-    for (int s = 0; s < p.n_steps; ++s) {
-        const float* ct = p.ctab + ((size_t)st.layer * p.n_ctab + s) * R * D;
-        for (int b = 0; b < p.NB; ++b) {
-            if (!wait_epoch(flag_of(p, st.wait_group, b, 0), st.wait_n, s + 1, p.status, lds_abort)) return;
-            const unsigned base = (unsigned)b * RT * 1024;
-            for (int row = lo + wave; row < hi; row += 4) {
-                f32x4 pl[NSLICE];
+template <int MR>
+struct Red2Role {
+    static constexpr int RT = 16 * MR, PQ = MR + 1;                       // rows per wave: 11 rows / 4 waves (MR 2), 6 / 4 (MR 1)
+    static constexpr bool PREFETCH = true;
+    struct Pay { f32x4 pl[PQ][NSLICE], rs[PQ], tv[PQ]; };
+    const SysArgs& p; const Stage& st;
+    f32x4 bias, gg, bb;
+    __amdgpu_buffer_rsrc_t rp, rx, rout;
+    int lo, hi, r_pl[PQ], r_br[PQ], r_t[PQ];
+    unsigned pstride;
+    __device__ __forceinline__ Red2Role(const SysArgs& p_, const Stage& st_, char*) : p(p_), st(st_) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        bias = ld4(st.b0 + 4 * lane); gg = ld4(st.g + 4 * lane); bb = ld4(st.be + 4 * lane);
+        rp = rsrc_of(st.in0); rx = rsrc_of(st.in1); rout = rsrc_of(st.out);
+        part_rows(p, st.slice, lo, hi);
+        pstride = (unsigned)p.NB * RT * 1024;
 #pragma unroll
-                for (int j = 0; j < NSLICE; ++j) pl[j] = ld_sc1(rp, j * pstride + base + row * 1024 + c * 4);
-                const f32x4 rs = ld_sc1(rx, base + row * 1024 + c * 4);
-                const RowInfo ri = row_info(p, b, row);
-                int cnt = 0x7fffffff;
-                if (p.counts != nullptr && ri.valid) cnt = p.counts[ri.prompt];
-                const int trow = (ri.valid && ri.t < cnt) ? ri.b2 : 2 * p.B;
-                const f32x4 tv = ld4(ct + (size_t)trow * D + c);
-                f32x4 v;
+        for (int q = 0; q < PQ; ++q) {                                   // this wave's rows lo + wave + 4 q
+            const int row = lo + wave + 4 * q, sb = row / p.T;
+            r_t[q] = row - sb * p.T; r_br[q] = sb / p.P; r_pl[q] = sb - r_br[q] * p.P;
+        }
+    }
+    __device__ __forceinline__ void issue(int s, int b, Pay& y) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
+        const float* ct = p.ctab + ((size_t)st.layer * p.n_ctab + s) * (2 * p.B + 1) * D;
+        const unsigned base = (unsigned)b * RT * 1024;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    v[i] = (((pl[0][i] + pl[1][i]) + (pl[2][i] + pl[3][i])) + ((pl[4][i] + pl[5][i]) + (pl[6][i] + pl[7][i]))) + bias[i] + rs[i];
+        for (int q = 0; q < PQ; ++q) {
+            const int row = lo + wave + 4 * q;
+            if (row < hi) {
+                const int prompt = b * p.P + r_pl[q];
+                int trow = 2 * p.B;                                      // padded latent row / absent prompt: the pad row
+                if (prompt < p.B) {
+                    int cnt = 0x7fffffff;
+                    if (p.counts != nullptr) cnt = p.counts[prompt];
+                    if (r_t[q] < cnt) trow = r_br[q] * p.B + prompt;
+                }
+                y.tv[q] = ld4(ct + (size_t)trow * D + c);
+#pragma unroll
+                for (int j = 0; j < NSLICE; ++j) y.pl[q][j] = ld_sc1(rp, j * pstride + base + row * 1024 + c * 4);
+                y.rs[q] = ld_sc1(rx, base + row * 1024 + c * 4);
+            }
+        }
+    }
+    __device__ __forceinline__ void commit(const Pay&) {}
+    __device__ __forceinline__ void compute(int, int b, const Pay& y) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
+        const unsigned base = (unsigned)b * RT * 1024;
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+            const int row = lo + wave + 4 * q;
+            if (row < hi) {
+                f32x4 v = sum8(y.pl[q]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[i] + y.rs[q][i];
                 float mean, rstd;
                 row_stats4(v, mean, rstd);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i] + tv[i];
+                for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i] + y.tv[q][i];
                 st_sc1(rout, base + row * 1024 + c * 4, v);
             }
-            publish(flag_of(p, st.out_group, b, st.out_slot), s + 1);
         }
     }
-}
+};
 
 // STYL: x' = X2 + out( SiLU( LN(sum_j partial_j + b2) * (1 + scale_t) + shift_t ) )
-__device__ __forceinline__ void run_styl(const SysArgs& p, const Stage& st, char* lds, int* lds_abort) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    char* const atile = lds;                                            // 16 rows used
-    float* const ct = reinterpret_cast<float*>(lds + 32768);
+template <int MR>
+struct StylRole {
+    static constexpr int RT = 16 * MR, PQ = MR + 1;
+    static constexpr bool PREFETCH = MR == 1;       // 256 weight registers + two images of 27 x 16 bytes per lane do not fit
+    struct Pay { f32x4 pl[PQ][NSLICE], rs[PQ]; };
+    const SysArgs& p; const Stage& st;
+    char* atile; float* ct;
     WFrag<4, 8> wf;
-    load_w(wf, st.w0, D, 0, [&](int j) { return 64 * wave + 16 * j; });
-    const int c = 4 * lane;
-    const f32x4 bias2 = ld4(st.b1 + c), bias = ld4(st.b0 + c), gg = ld4(st.g + c), bb = ld4(st.be + c);
-    const __amdgpu_buffer_rsrc_t rp = rsrc_of(st.in0), rx = rsrc_of(st.in1), rout = rsrc_of(st.out);
+    f32x4 bias2, bias, gg, bb;
+    __amdgpu_buffer_rsrc_t rp, rx, rout;
     int lo, hi;
-    part_rows(st.slice, lo, hi);
-    const unsigned pstride = (unsigned)p.NB * RT * 1024;
-    for (int s = 0; s < p.n_steps; ++s) {
+    unsigned pstride;
+    __device__ __forceinline__ StylRole(const SysArgs& p_, const Stage& st_, char* lds) : p(p_), st(st_) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        atile = lds; ct = reinterpret_cast<float*>(lds + 16 * 1024);
+        load_w(wf, st.w0, D, 0, [&](int j) { return 64 * wave + 16 * j; });
+        bias2 = ld4(st.b1 + 4 * lane); bias = ld4(st.b0 + 4 * lane); gg = ld4(st.g + 4 * lane); bb = ld4(st.be + 4 * lane);
+        rp = rsrc_of(st.in0); rx = rsrc_of(st.in1); rout = rsrc_of(st.out);
+        part_rows(p, st.slice, lo, hi);
+        pstride = (unsigned)p.NB * RT * 1024;
+    }
+    __device__ __forceinline__ void issue(int, int b, Pay& y) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
+        const unsigned base = (unsigned)b * RT * 1024;
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+            const int row = lo + wave + 4 * q;
+            y.rs[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < hi) {
+#pragma unroll
+                for (int j = 0; j < NSLICE; ++j) y.pl[q][j] = ld_sc1(rp, j * pstride + base + row * 1024 + c * 4);
+                y.rs[q] = ld_sc1(rx, base + row * 1024 + c * 4);
+            }
+        }
+    }
+    __device__ __forceinline__ void commit(const Pay&) {}
+    __device__ __forceinline__ void compute(int s, int b, const Pay& y) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
+        const unsigned base = (unsigned)b * RT * 1024;
         const float* mod = p.tables + (size_t)(p.step_lo + s) * DEN_STEP_STRIDE + st.layer * DEN_LAYER_STRIDE + DEN_OFF_FFN_MOD;
         const f32x4 scl = ld4(mod + c), shf = ld4(mod + D + c);
-        for (int b = 0; b < p.NB; ++b) {
-            if (!wait_epoch(flag_of(p, st.wait_group, b, 0), st.wait_n, s + 1, p.status, lds_abort)) return;
-            const unsigned base = (unsigned)b * RT * 1024;
-            f32x4 res[3];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int lr = wave + 4 * q, row = lo + lr;              // local row 0..11 of this part
-                res[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (row < hi) {
-                    f32x4 pl[NSLICE];
+        for (int q = 0; q < 4; ++q) {                                    // the 16 rows of the operand tile: local row wave + 4 q
+            const int lr = wave + 4 * q, row = lo + lr;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (q < PQ && row < hi) {
+                v = sum8(y.pl[q < PQ ? q : 0]);
 #pragma unroll
-                    for (int j = 0; j < NSLICE; ++j) pl[j] = ld_sc1(rp, j * pstride + base + row * 1024 + c * 4);
-                    res[q] = ld_sc1(rx, base + row * 1024 + c * 4);
+                for (int i = 0; i < 4; ++i) v[i] += bias2[i];
+                float mean, rstd;
+                row_stats4(v, mean, rstd);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        v[i] = (((pl[0][i] + pl[1][i]) + (pl[2][i] + pl[3][i])) + ((pl[4][i] + pl[5][i]) + (pl[6][i] + pl[7][i]))) + bias2[i];
-                    float mean, rstd;
-                    row_stats4(v, mean, rstd);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = silu(((v[i] - mean) * rstd * gg[i] + bb[i]) * (1.f + scl[i]) + shf[i]);
-                }
-                // u row -> S-format operand tile (local row lr; rows 12..15 of the tile are zero)
-                bf16x4 h4, l4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { h4[e] = (__bf16)v[e]; l4[e] = (__bf16)(v[e] - (float)h4[e]); }
-                *reinterpret_cast<bf16x4*>(a_slot<4>(atile, lr, c >> 6, (c & 63) >> 3) + (c & 7) * 2) = h4;
-                *reinterpret_cast<bf16x4*>(a_slot<4>(atile, lr, c >> 6, 8 + ((c & 63) >> 3)) + (c & 7) * 2) = l4;
+                for (int i = 0; i < 4; ++i) v[i] = silu(((v[i] - mean) * rstd * gg[i] + bb[i]) * (1.f + scl[i]) + shf[i]);
             }
-            {   // local rows 12..15: zero
-                const int lr = 12 + wave;
-                const bf16x4 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-                *reinterpret_cast<bf16x4*>(a_slot<4>(atile, lr, c >> 6, (c & 63) >> 3) + (c & 7) * 2) = z;
-                *reinterpret_cast<bf16x4*>(a_slot<4>(atile, lr, c >> 6, 8 + ((c & 63) >> 3)) + (c & 7) * 2) = z;
-            }
-            __syncthreads();
-            f32x4 acc[1][4];
-            zero_acc(acc);
-            mma<4, 4, 8, 1>(atile, wf, acc);
-            stage_c(ct, acc, [&](int j) { return 64 * wave + 16 * j; });
-            __syncthreads();
+            bf16x4 h4, l4;                                               // u row -> S-format operand tile (unused rows: zero)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int lr = wave + 4 * q, row = lo + lr;
-                if (row < hi) {
-                    f32x4 v = ld4(ct + lr * CLD + c);
+            for (int e = 0; e < 4; ++e) { h4[e] = (__bf16)v[e]; l4[e] = (__bf16)(v[e] - (float)h4[e]); }
+            *reinterpret_cast<bf16x4*>(a_slot<4>(atile, lr, c >> 6, (c & 63) >> 3) + (c & 7) * 2) = h4;
+            *reinterpret_cast<bf16x4*>(a_slot<4>(atile, lr, c >> 6, 8 + ((c & 63) >> 3)) + (c & 7) * 2) = l4;
+        }
+        __syncthreads();
+        f32x4 acc[1][4];
+        zero_acc(acc);
+        mma<4, 4, 8, 1>(atile, wf, acc);
+        stage_c(ct, acc, [&](int j) { return 64 * wave + 16 * j; });
+        __syncthreads();
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[i] + res[q][i];
-                    st_sc1(rout, base + row * 1024 + c * 4, v);
-                }
+        for (int q = 0; q < PQ; ++q) {
+            const int lr = wave + 4 * q, row = lo + lr;
+            if (row < hi) {
+                f32x4 v = ld4(ct + lr * CLD + c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[i] + y.rs[q][i];
+                st_sc1(rout, base + row * 1024 + c * 4, v);
             }
-            publish(flag_of(p, st.out_group, b, st.out_slot), s + 1);
         }
     }
-}
+};
 
 // SKIP: half of the 256 output columns of linear_blocks[i](cat(x, skip))
-__device__ __forceinline__ void run_skip(const SysArgs& p, const Stage& st, char* lds, int* lds_abort) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    char* const atile = lds;                                            // [RT] x K=512: 64 KiB
-    float* const ct = reinterpret_cast<float*>(lds + 65536);
-    const int n0 = st.slice * 128;
+template <int MR>
+struct SkipRole {
+    static constexpr int RT = 16 * MR;
+    static constexpr bool PREFETCH = true;
+    struct Pay { Rows256<MR> x, k; };
+    const SysArgs& p; const Stage& st;
+    char* atile; float* ct;
     WFrag<2, 16> wf;
-    load_w(wf, st.w0, 2 * D, 0, [&](int j) { return n0 + 32 * wave + 16 * j; });
-    const __amdgpu_buffer_rsrc_t rx = rsrc_of(st.in0), rs = rsrc_of(st.in1), rout = rsrc_of(st.out);
-    for (int s = 0; s < p.n_steps; ++s)
-        for (int b = 0; b < p.NB; ++b) {
-            if (!wait_epoch(flag_of(p, st.wait_group, b, 0), st.wait_n, s + 1, p.status, lds_abort)) return;
-            const unsigned base = (unsigned)b * RT * 1024;
-            fill_a256<8>(atile, 0, rx, base);
-            fill_a256<8>(atile, 4, rs, base);
-            __syncthreads();
-            f32x4 acc[2][2];
-            zero_acc(acc);
-            mma<8, 2, 16, 2>(atile, wf, acc);
-            stage_c(ct, acc, [&](int j) { return n0 + 32 * wave + 16 * j; });
-            __syncthreads();
-            for (int u = tid; u < RT * 32; u += 256) {                   // (row, 4 columns) of this half
-                const int row = u >> 5, cc = n0 + (u & 31) * 4;
-                f32x4 v = ld4(ct + row * CLD + cc);
-                const f32x4 bv = ld4(st.b0 + cc);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] += bv[i];
-                st_sc1(rout, base + row * 1024 + cc * 4, v);
-            }
-            publish(flag_of(p, st.out_group, b, st.out_slot), s + 1);
-        }
-}
-
-// TAIL: encoder.norm on both branches, guidance, scheduler step, latents, next step's network input (x = latents + pe)
-__device__ __forceinline__ void run_tail(const SysArgs& p, const Stage& st, char* lds, int* lds_abort) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = 4 * lane, T = p.T, P = p.P;
-    const f32x4 gg = ld4(p.ng + c), bb = ld4(p.nb + c);
-    const __amdgpu_buffer_rsrc_t rin = rsrc_of(st.in0), rout = rsrc_of(st.out);
-    const int M = p.B * T;
-    // local step 0: the first network input from the latents the prologue left (plain memory of earlier kernels)
-    for (int b = 0; b < p.NB; ++b) {
-        const unsigned base = (unsigned)b * RT * 1024;
-        for (int q = wave; q < RT; q += 4) {
-            f32x4 xn = {0.f, 0.f, 0.f, 0.f};
-            const RowInfo ri = row_info(p, b, q);
-            if (ri.valid) {
-                const f32x4 l = ld4(p.lat + ((size_t)ri.prompt * T + ri.t) * D + c), pe = ld4(p.pe + (size_t)ri.t * D + c);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) xn[i] = l[i] + pe[i];
-            }
-            st_sc1(rout, base + q * 1024 + c * 4, xn);
-        }
-        publish(flag_of(p, st.out_group, b, st.out_slot), 1);
+    __amdgpu_buffer_rsrc_t rx, rs, rout;
+    int n0;
+    __device__ __forceinline__ SkipRole(const SysArgs& p_, const Stage& st_, char* lds) : p(p_), st(st_) {
+        const int wave = threadIdx.x >> 6;
+        atile = lds; ct = reinterpret_cast<float*>(lds + RT * 2048);     // [RT] x K=512 operand tile first
+        n0 = st.slice * 128;
+        load_w(wf, st.w0, 2 * D, 0, [&](int j) { return n0 + 32 * wave + 16 * j; });
+        rx = rsrc_of(st.in0); rs = rsrc_of(st.in1); rout = rsrc_of(st.out);
     }
-    for (int s = 0; s < p.n_steps; ++s) {
-        const int step = p.step_lo + s;
-        const float* cf = p.coef + (size_t)step * LADIFF_COEF_STRIDE;
-        const float sa = cf[0], sb = cf[1], kx0 = cf[2], kx = cf[3], ke = cf[4], kn = cf[5];
-        for (int b = 0; b < p.NB; ++b) {
-            if (!wait_epoch(flag_of(p, st.wait_group, b, 0), st.wait_n, s + 1, p.status, lds_abort)) return;
+    __device__ __forceinline__ void issue(int, int b, Pay& y) {
+        issue_rows<MR>(y.x, rx, (unsigned)b * RT * 1024);
+        issue_rows<MR>(y.k, rs, (unsigned)b * RT * 1024);
+    }
+    __device__ __forceinline__ void commit(const Pay& y) { commit_rows<8, MR>(atile, 0, y.x); commit_rows<8, MR>(atile, 4, y.k); }
+    __device__ __forceinline__ void compute(int, int b, const Pay&) {
+        const int tid = threadIdx.x, wave = tid >> 6;
+        const unsigned base = (unsigned)b * RT * 1024;
+        f32x4 acc[MR][2];
+        zero_acc(acc);
+        mma<8, 2, 16, MR>(atile, wf, acc);
+        stage_c(ct, acc, [&](int j) { return n0 + 32 * wave + 16 * j; });
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2 * MR; ++u) {                               // (row, 4 columns) of this half
+            const int id = tid + 256 * u, row = id >> 5, cc = n0 + (id & 31) * 4;
+            f32x4 v = ld4(ct + row * CLD + cc);
+            const f32x4 bv = ld4(st.b0 + cc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += bv[i];
+            st_sc1(rout, base + row * 1024 + cc * 4, v);
+        }
+    }
+};
+
+// TAIL: encoder.norm on both branches, guidance, scheduler step, latents, next step's network input (x = latents + pe).
+// Tail workgroup k owns the blocks b = k (mod NTAIL).
+template <int MR>
+struct TailRole {
+    static constexpr int RT = 16 * MR, NQ = 2 * MR;                      // (prompt, latent) pairs per wave: P T <= 8 MR
+    struct Pay { f32x4 eu[NQ], ec[NQ], lt[NQ], zz[NQ]; };
+    const SysArgs& p; const Stage& st;
+    f32x4 gg, bb, pev[NQ];
+    __amdgpu_buffer_rsrc_t rin, rout;
+    int T, P, t_pl[NQ], t_t[NQ];
+    __device__ __forceinline__ TailRole(const SysArgs& p_, const Stage& st_, char*) : p(p_), st(st_) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
+        T = p.T; P = p.P;
+        gg = ld4(p.ng + c); bb = ld4(p.nb + c);
+        rin = rsrc_of(st.in0); rout = rsrc_of(st.out);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = wave + 4 * i;
+            t_pl[i] = q / T; t_t[i] = q - t_pl[i] * T;
+            pev[i] = ld4(p.pe + (size_t)t_t[i] * D + c);
+        }
+    }
+    // local step 0: the first network input from the latents the prologue left (plain memory of earlier kernels)
+    __device__ __forceinline__ void prime() {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
+        for (int b = st.slice; b < p.NB; b += NTAIL) {
             const unsigned base = (unsigned)b * RT * 1024;
-            for (int q = wave; q < P * T; q += 4) {                      // (prompt in block, latent) pairs
-                const int pl = q / T, t = q - pl * T, prompt = b * P + pl;
-                if (prompt >= p.B) continue;
-                const int ru = pl * T + t, rc = (P + pl) * T + t;
-                f32x4 eu = ld_sc1(rin, base + ru * 1024 + c * 4), ec = ld_sc1(rin, base + rc * 1024 + c * 4);
+            for (int q = wave; q < RT; q += 4) {
+                f32x4 xn = {0.f, 0.f, 0.f, 0.f};
+                const int sb = q / T, t = q - sb * T, br = sb / P, prompt = b * P + (sb - br * P);
+                if (br < 2 && prompt < p.B) {
+                    const f32x4 l = ld4(p.lat + ((size_t)prompt * T + t) * D + c), pe = ld4(p.pe + (size_t)t * D + c);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xn[i] = l[i] + pe[i];
+                }
+                st_sc1(rout, base + q * 1024 + c * 4, xn);
+            }
+            publish(flag_of(p, st.out_group, b, st.out_slot), 1);
+        }
+    }
+    __device__ __forceinline__ void issue(int s, int b, Pay& y) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
+        const unsigned base = (unsigned)b * RT * 1024;
+        const int step = p.step_lo + s;
+        const float kn = p.coef[(size_t)step * LADIFF_COEF_STRIDE + 5];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = wave + 4 * i, prompt = b * P + t_pl[i];
+            y.zz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (q < P * T && prompt < p.B) {
+                const size_t lrow = (size_t)prompt * T + t_t[i];
+                y.eu[i] = ld_sc1(rin, base + (t_pl[i] * T + t_t[i]) * 1024 + c * 4);
+                y.ec[i] = ld_sc1(rin, base + ((P + t_pl[i]) * T + t_t[i]) * 1024 + c * 4);
+                y.lt[i] = ld4(p.lat + lrow * D + c);
+                if (p.noise != nullptr && kn != 0.f) y.zz[i] = ld4(p.noise + ((size_t)step * p.B * T + lrow) * D + c);
+            }
+        }
+    }
+    __device__ __forceinline__ void commit(const Pay&) {}
+    __device__ __forceinline__ void compute(int s, int b, Pay& y) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
+        const unsigned base = (unsigned)b * RT * 1024;
+        const float* cf = p.coef + (size_t)(p.step_lo + s) * LADIFF_COEF_STRIDE;
+        const float sa = cf[0], sb = cf[1], kx0 = cf[2], kx = cf[3], ke = cf[4], kn = cf[5];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = wave + 4 * i, prompt = b * P + t_pl[i];
+            if (q < P * T && prompt < p.B) {
+                const int ru = t_pl[i] * T + t_t[i], rc = (P + t_pl[i]) * T + t_t[i];
+                f32x4 eu = y.eu[i], ec = y.ec[i], l = y.lt[i], xn;
                 float mean, rstd;
                 row_stats4(eu, mean, rstd);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) eu[i] = (eu[i] - mean) * rstd * gg[i] + bb[i];
+                for (int k = 0; k < 4; ++k) eu[k] = (eu[k] - mean) * rstd * gg[k] + bb[k];
                 row_stats4(ec, mean, rstd);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ec[i] = (ec[i] - mean) * rstd * gg[i] + bb[i];
-                const size_t lrow = (size_t)prompt * T + t;
-                f32x4 l = ld4(p.lat + lrow * D + c);
-                f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                if (p.noise != nullptr && kn != 0.f) z = ld4(p.noise + ((size_t)step * M + lrow) * D + c);
-                const f32x4 pe = ld4(p.pe + (size_t)t * D + c);
-                f32x4 xn;
+                for (int k = 0; k < 4; ++k) ec[k] = (ec[k] - mean) * rstd * gg[k] + bb[k];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float e = eu[i] + p.gscale * (ec[i] - eu[i]);
-                    const float x0 = (l[i] - sb * e) / sa;
-                    l[i] = kx0 * x0 + kx * l[i] + ke * e + kn * z[i];
-                    xn[i] = l[i] + pe[i];
+                for (int k = 0; k < 4; ++k) {
+                    const float e = eu[k] + p.gscale * (ec[k] - eu[k]);
+                    const float x0 = (l[k] - sb * e) / sa;
+                    l[k] = kx0 * x0 + kx * l[k] + ke * e + kn * y.zz[i][k];
+                    xn[k] = l[k] + pev[i][k];
                 }
-                st4(p.lat + lrow * D + c, l);
-                if (s + 1 < p.n_steps) {
-                    st_sc1(rout, base + ru * 1024 + c * 4, xn);
-                    st_sc1(rout, base + rc * 1024 + c * 4, xn);
-                }
+                st4(p.lat + ((size_t)prompt * T + t_t[i]) * D + c, l);
+                st_sc1(rout, base + ru * 1024 + c * 4, xn);            // after the last step nobody reads it
+                st_sc1(rout, base + rc * 1024 + c * 4, xn);
             }
-            if (s + 1 < p.n_steps) publish(flag_of(p, st.out_group, b, st.out_slot), s + 2);
-            else __syncthreads();
         }
     }
+};
+
+// the tail's loop differs from stage_loop in two ways: its output of step s is the input of step s + 1 (epoch s + 2), and a
+// block's latents are read in `issue` and written in `compute` of the SAME block one step earlier - with NTAIL blocks in
+// between, so a prefetch never overtakes the update it depends on as long as a tail owns more than one block; with one block
+// it simply does not prefetch.
+template <int MR>
+__device__ __forceinline__ void tail_loop(const SysArgs& p, const Stage& st, TailRole<MR>& r, Ctl* ctl) {
+    typename TailRole<MR>::Pay cur, nxt;
+    bool have = false;
+    const int lane = threadIdx.x & 63, b0 = st.slice;
+    const bool may_prefetch = b0 + NTAIL < p.NB;
+    r.prime();
+    for (int s = 0; s < p.n_steps; ++s)
+        for (int b = b0; b < p.NB; b += NTAIL) {
+            SYS_STAMP(0);
+            if (!have) {
+                if (!wait_epoch(flag_of(p, st.wait_group, b, 0), st.wait_n, s + 1, p.status, ctl)) return;
+                r.issue(s, b, cur);
+            }
+            SYS_STAMP(1);
+            int s2 = s, b2 = b + NTAIL;
+            if (b2 >= p.NB) { s2 = s + 1; b2 = b0; }
+            const bool has_next = may_prefetch && s2 < p.n_steps;
+            unsigned fv = 0xffffffffu;
+            if (has_next && threadIdx.x < 64 && lane < st.wait_n)
+                fv = __hip_atomic_load((const gu32*)flag_of(p, st.wait_group, b2, 0) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x < 64) {
+                const int ok = has_next && __all(fv >= (unsigned)(s2 + 1));
+                if (lane == 0) ctl->ready = ok;
+            }
+            __syncthreads();
+            have = ctl->ready != 0;
+            if (have) r.issue(s2, b2, nxt);
+            r.compute(s, b, cur);
+            SYS_STAMP(4);
+            publish(flag_of(p, st.out_group, b, st.out_slot), s + 2);
+            if (have) cur = nxt;
+        }
 }
 
 }  // namespace
 
+template <int MR>
 __global__ __launch_bounds__(256, 1) void systolic_loop_kernel(const SysArgs p) {
     // all LDS is dynamic (a static variable would shift the dynamic base off its 16-byte alignment, cdna_hip_programming.md G17)
     extern __shared__ __attribute__((aligned(1024))) char lds[];
-    int& lds_abort = *reinterpret_cast<int*>(lds + SYS_LDS_BYTES - 16);
+    Ctl* const ctl = reinterpret_cast<Ctl*>(lds + SYS_LDS_BYTES - 16);
     const Stage st = p.stages[blockIdx.x];
     switch (st.role) {
-        case R_QKV: run_qkv(p, st, lds, &lds_abort); break;
-        case R_OUT: run_out(p, st, lds, &lds_abort); break;
-        case R_LIN: run_mlp<ACT_RELU>(p, st, lds, &lds_abort); break;
-        case R_RED2: run_red2(p, st, lds, &lds_abort); break;
-        case R_FFN: run_mlp<ACT_GELU>(p, st, lds, &lds_abort); break;
-        case R_STYL: run_styl(p, st, lds, &lds_abort); break;
-        case R_SKIP: run_skip(p, st, lds, &lds_abort); break;
-        case R_TAIL: run_tail(p, st, lds, &lds_abort); break;
+        case R_QKV: { QkvRole<MR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
+        case R_OUT: { OutRole<MR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
+        case R_LIN: { MlpRole<MR, ACT_RELU> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
+        case R_RED2: { Red2Role<MR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
+        case R_FFN: { MlpRole<MR, ACT_GELU> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
+        case R_STYL: { StylRole<MR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
+        case R_SKIP: { SkipRole<MR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
+        case R_TAIL: { TailRole<MR> r(p, st, lds); tail_loop(p, st, r, ctl); break; }
         default: break;
     }
 }
 
-
 // ================================================================== host side
+#ifdef LADIFF_STAMPS
+unsigned long long* g_sys_stamps = nullptr;
+#endif
+static int g_sys_row_tiles = 2;
 namespace {
 struct SysLayout {
     size_t blk;                   // floats of one [NB][RT][256] buffer
     size_t off_stages, off_flags, off_status, off_xin0, off_xs, off_xo, off_att, off_x1, off_x2, off_pc, off_pe, total;
     int nwg, NB, P;
 };
-SysLayout sys_layout(int B, int T) {
+SysLayout sys_layout(int B, int T, int MR) {
     SysLayout L;
+    const int RT = 16 * MR;
     int P = RT / (2 * T);
     if (P > 7) P = 7;             // the QKV stage parks (2P + 1) x 128 floats of extra K|V through 512 thread slots
     if (P < 1) P = 1;
     L.P = P;
     L.NB = (B + P - 1) / P;
-    L.nwg = NL * (4 + 1 + NSLICE + NRED + NSLICE + NRED) + 2 * NSKIP + 1;
+    L.nwg = NL * (4 + 1 + NSLICE + NRED + NSLICE + NRED) + 2 * NSKIP + NTAIL;
     L.blk = (size_t)L.NB * RT * D;
     size_t off = 0;
     auto take = [&](size_t floats) { const size_t o = off; off += (floats + 63) / 64 * 64; return o; };
@@ -730,19 +976,24 @@ SysLayout sys_layout(int B, int T) {
 }
 }  // namespace
 
-size_t sys_ws_floats(int B, int T) { return sys_layout(B, T).total; }
+// rows per block: 32 (three prompts of five latents, both branches) while the stages' time per block leaves the loop
+// latency-bound; 16 (one prompt) is the low-latency variant
+int sys_row_tiles(int T) { return 2 * T <= 16 ? g_sys_row_tiles : 2; }
+size_t sys_ws_floats(int B, int T) { const size_t a = sys_layout(B, T, 1).total, b = sys_layout(B, T, 2).total; return a > b ? a : b; }
 
 bool sys_supported(int B, int T, int cfg, bool split) {
     if (!cfg || !split || B < 1 || T < 1 || T > LADIFF_MAX_LATENTS) return false;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    return cus >= sys_layout(B, T).nwg;          // every stage needs a CU of its own, all resident at once
+    return cus >= sys_layout(B, T, 2).nwg;       // every stage needs a CU of its own, all resident at once
 }
 
 // Builds the stage table (host) for this call's pointers.  `ws` = the systolic region of the reverse workspace.
 int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int B, int T, std::vector<unsigned char>& host) {
-    const SysLayout L = sys_layout(B, T);
+    const int MR = sys_row_tiles(T), RT = 16 * MR;
+    (void)RT;
+    const SysLayout L = sys_layout(B, T, MR);
     std::vector<Stage> st;
     float* xin0 = ws + L.off_xin0;
     float* att = ws + L.off_att; float* x1 = ws + L.off_x1; float* x2 = ws + L.off_x2;
@@ -805,9 +1056,9 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int B, 
             st.push_back(s);
         }
     }
-    {
+    for (int k = 0; k < NTAIL; ++k) {
         Stage s{};
-        s.role = R_TAIL; s.layer = NL; s.wait_group = G(NL - 1, G_XO); s.wait_n = NRED; s.out_group = G(0, G_XIN); s.out_slot = 0;
+        s.role = R_TAIL; s.layer = NL; s.slice = k; s.wait_group = G(NL - 1, G_XO); s.wait_n = NRED; s.out_group = G(0, G_XIN); s.out_slot = 0;
         s.in0 = XO(NL - 1); s.out = xin0;
         st.push_back(s);
     }
@@ -822,10 +1073,13 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int B, 
 int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, const float* tkv, const float* ctab, int n_ctab,
                          const float* coef, const float* noise, float* lat, const int32_t* counts, float gscale, int B, int T,
                          int step_lo, int n, hipStream_t s) {
-    const SysLayout L = sys_layout(B, T);
+    const int MR = sys_row_tiles(T);
+    const SysLayout L = sys_layout(B, T, MR);
     static bool attr_set = false;
     if (!attr_set) {
-        LADIFF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(systolic_loop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        LADIFF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(systolic_loop_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       SYS_LDS_BYTES));
+        LADIFF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(systolic_loop_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        SYS_LDS_BYTES));
         attr_set = true;
     }
@@ -836,14 +1090,20 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     a.tables = tables; a.tkv = tkv; a.ctab = ctab; a.coef = coef; a.noise = noise; a.pe = W.query_pe; a.ng = W.norm.g; a.nb = W.norm.b;
     a.lat = lat; a.counts = counts; a.gscale = gscale; a.B = B; a.T = T; a.P = L.P; a.NB = L.NB; a.step_lo = step_lo; a.n_steps = n;
     a.n_ctab = n_ctab;
+    a.stamps = nullptr;
+#ifdef LADIFF_STAMPS
+    a.stamps = g_sys_stamps;
+#endif
     // flags and the abort word are contiguous: one memset node, a multiple of 16 bytes
     LADIFF_HIP(hipMemsetAsync(a.flags, 0, (L.off_xin0 - L.off_flags) * sizeof(float), s));
-    hipLaunchKernelGGL(systolic_loop_kernel, dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
+    if (MR == 1) hipLaunchKernelGGL(systolic_loop_kernel<1>, dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
+    else hipLaunchKernelGGL(systolic_loop_kernel<2>, dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
 
-size_t sys_stage_bytes(int B, int T) { return (size_t)sys_layout(B, T).nwg * sizeof(Stage); }
-size_t sys_status_offset_floats(int B, int T) { return sys_layout(B, T).off_status; }
+size_t sys_stage_bytes(int B, int T) { return (size_t)sys_layout(B, T, sys_row_tiles(T)).nwg * sizeof(Stage); }
+size_t sys_status_offset_floats(int B, int T) { return sys_layout(B, T, sys_row_tiles(T)).off_status; }
+void sys_set_row_tiles(int mr) { g_sys_row_tiles = mr == 1 ? 1 : 2; }
 
 }  // namespace ladiff

@@ -1,0 +1,62 @@
+"""Diagnostic (GPU box): timeline of one block through the persistent pipeline loop (s_memrealtime stamps, twin build;
+the shipped library executes no stamp).  python scripts/stamps_pipeline.py [B] [steps]"""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+subprocess.check_call([sys.executable, "-m", "ladiff_amd.build", "--stamps"], cwd=ROOT, stdout=subprocess.DEVNULL)
+import torch
+from ladiff_amd import _lib
+_lib.LIB_PATH = os.path.join(ROOT, "ladiff_amd", "libladiff_hip_stamps.so")
+import bench
+from ladiff_amd import synthetic as syn
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+mode = sys.argv[3] if len(sys.argv) > 3 else "pipeline"
+dev = torch.device("cuda", 0)
+L = _lib.lib()
+L.ladiff_debug_set_sys_stamps.argtypes = [ctypes.c_void_p]
+pipe = bench.build_pipe(dev, B)
+pipe.precision = "bf16x3"; pipe.num_inference_timesteps = steps; pipe.loop = mode
+lens = [196] * B
+text, noise = syn.text_embeddings(B).to(dev), syn.init_noise(lens).to(dev)
+st = torch.zeros(256 * 4 * 4 * 8 + 256 * 4, dtype=torch.int64, device=dev)
+s = torch.cuda.Stream(device=dev)
+with torch.cuda.stream(s), torch.no_grad():
+    pipe._diffusion_reverse(text, lens, init_noise=noise)
+    torch.cuda.synchronize()
+    L.ladiff_debug_set_sys_stamps(st.data_ptr())
+    pipe._diffusion_reverse(text, lens, init_noise=noise)
+    torch.cuda.synchronize()
+print("status", pipe.loop_status())
+stats = st[256 * 4 * 4 * 8:].cpu().reshape(256, 4)
+t = st[:256 * 4 * 4 * 8].reshape(256, 4, 4, 8).cpu().double() * 0.01          # 100 MHz ticks -> us
+names = []
+for l in range(9):
+    if l > 4: names += [f"L{l} SKIP{c}" for c in range(2)]
+    names += [f"L{l} QKV{h}" for h in range(4)] + [f"L{l} OUT"] + [f"L{l} LIN{j}" for j in range(8)] + [f"L{l} RED2.{q}" for q in range(3)]
+    names += [f"L{l} FFN{j}" for j in range(8)] + [f"L{l} STYL.{q}" for q in range(3)]
+names += [f"TAIL{k}" for k in range(4)]
+step, blk = min(1, steps - 1), 0
+tail = len(names) - 4 + blk % 4
+t0 = t[tail, step - 1, blk, 4] if step > 0 else t[:, step, blk, 1][t[:, step, blk, 1] > 0].min()
+print(f"timeline of block {blk}, local step {step} (us after the TAIL stage finished the previous step's update of this block)")
+print(f"{'stage':12s} {'flag seen':>10s} {'operands':>10s} {'mfma done':>10s} {'stored':>10s} {'published':>10s}   wait->publish")
+for i, n in enumerate(names):
+    r = t[i, step, blk]
+    if r[1] == 0: continue
+    if any(k in n for k in ("QKV0", "OUT", "LIN0", "RED2.0", "FFN0", "STYL.0", "SKIP0", "TAIL0")):
+        f = lambda v: f"{v - t0:10.2f}" if v > 0 else f"{'-':>10s}"
+        print(f"{n:12s} {f(r[1])} {f(r[2])} {f(r[3])} {f(r[4])} {f(r[5])}   {r[5] - r[1] if r[5] > 0 else r[4] - r[1]:6.2f}")
+lap = t[tail, step, blk, 4] - t0
+print(f"one step of one block: {lap:.1f} us over {59} hops = {lap / 59:.2f} us per hop")
+
+# per-stage totals over the whole run: time blocked waiting for a producer, prefetch hit rate
+print("stage-type totals (mean over the workgroups of a type): blocked us per step, prefetch hits / blocks")
+import collections
+agg = collections.defaultdict(list)
+for i, n in enumerate(names):
+    kind = n.split()[-1].rstrip("0123456789.")
+    if stats[i, 2] > 0:
+        agg[kind].append((float(stats[i, 0]) * 0.01 / steps, float(stats[i, 1]) / float(stats[i, 2])))
+for k, v in agg.items():
+    print(f"  {k:6s} blocked {sum(a for a, _ in v) / len(v):8.1f} us/step (min {min(a for a, _ in v):8.1f})   prefetch hit rate {sum(h for _, h in v) / len(v):.2f}")
