@@ -10,10 +10,13 @@ N > 1, the final RCCL all-gather of the frames.  Inputs (random-init weights, ra
 noise: ladiff_amd/synthetic.py) are resident in HBM before the timed region.  Metric: motions/s, whole job.
 
 Extra objects on the JSON line:
-  roofline     the DOMINANT KERNEL (ffn.linear1's GEMM of the denoiser loop, ~36-40 % of the device time): bound = mfma,
-               achieved = algorithmic FLOPs of one launch (2 M N K, reference arithmetic) / its launch duration measured
-               live with HIP events over back-to-back launches on the bench stream; peak = dense MFMA peak of the timed
-               mode's dtype; traffic = memory-side bytes per launch from the PMC runs in profiles/.
+  roofline     the DOMINANT KERNEL.  bf16x3 mode: the persistent pipeline kernel that runs all 50 guided steps in one launch
+               (csrc/systolic.hip, ~85 % of the device time): achieved = algorithmic FLOPs of one launch (reference-equivalent
+               denoiser arithmetic, SURVEY.md §8d: 358.27 MFLOP per motion and step) / its duration measured live with HIP
+               events recorded around the launch on the bench stream (ladiff_sampler_loop_ms).  fp32 mode: ffn.linear1's GEMM,
+               timed live over back-to-back launches.  peak = dense MFMA peak of the timed mode's dtype.  traffic, mfma_util_pmc
+               and share_of_pass are READ from profiles/r2/summary.json (rocprofv3 runs of scripts/profile_pass.py, stamped
+               with the commit they were taken at) - null when that file has no entry for the kernel.
                roofline.whole_pass: the same for the whole pass - reference-equivalent FLOPs (21.757 GFLOP
                per motion at F=196, C=263, 50 steps) / the pass's device time; executed_tflops counts the FLOPs the
                kernels really execute after hoisting so the two cannot be conflated.
@@ -67,7 +70,7 @@ def build_pipe(dev, batch):
                   num_inference_timesteps=STEPS_DDIM, eta=0.0)
 
 
-def dominant_kernel_roofline(dev, stream, precision, launches=400):
+def dominant_kernel_roofline(dev, stream, precision, summary, launches=400):
     """Live HIP-event timing of the kernel that dominates the pass (profiles/r1: gemm_kp_kernel<80,64,2,2> / gemm_kr_kernel<80,64,...>, ~36-40 % of the
     device time): the denoiser's 256->1024 linear (ffn.linear1, GELU) at M = 2*128*5 rows, launched back to back on the
     bench stream, in the arithmetic of the timed mode."""
@@ -101,9 +104,50 @@ def dominant_kernel_roofline(dev, stream, precision, launches=400):
             "flops_per_launch": flops, "mfma_flops_per_launch": mfma_flops, "us_per_launch": round(us, 2),
             "achieved": round(flops / us / 1e6, 2), "unit": "TFLOP/s", "peak": peak,
             "frac": round(flops / us / 1e6 / peak, 4), "mfma_frac": round(mfma_flops / us / 1e6 / peak, 4),
-            "traffic": 22.75e6 if split else 22.8e6,
-            "traffic_source": ("profiles/r1/07_pmc_summary_bf16x3_fused.md" if split else "profiles/r1/03_pmc_summary.md") +
-                              ": 2 x FETCH_SIZE + WRITE_SIZE per launch (L2-fabric interface, Infinity-Cache hits included)"}
+            **dict(zip(("traffic", "mfma_util_pmc", "share_of_pass", "traffic_source"),
+                       profiled(summary, "gemm_kp_kernel<80, 64" if split else "gemm_kr_kernel<80, 64")))}
+
+
+def profile_summary():
+    """profiles/rN/summary.json of the newest round that has one (written by scripts/pmc_summary.py)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "summary.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            d["_path"] = os.path.relpath(path, ROOT)
+            return d
+        except Exception:
+            continue
+    return None
+
+
+def profiled(summary, kernel_key):
+    """(traffic bytes per launch, mfma_util_pmc, share_of_pass, source) of the kernel whose profiled name contains `kernel_key`."""
+    if summary is None:
+        return None, None, None, "no profiles/r*/summary.json in this tree"
+    for name, e in summary.get("kernels", {}).items():
+        if kernel_key in name:
+            tr = None
+            if "fetch_bytes_per_launch" in e and "write_bytes_per_launch" in e:
+                tr = e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"]
+            return tr, e.get("mfma_util_pmc"), e.get("share_of_pass"), f"{summary['_path']} (commit {summary.get('git_sha', '?')}): {name}"
+    return None, None, None, f"{summary['_path']} has no kernel matching {kernel_key!r}"
+
+
+def pipeline_kernel_roofline(pipe, loop_ms_samples, summary):
+    """The persistent pipeline kernel: one launch = 50 guided steps on the rank's 128 prompts."""
+    ms = sorted(loop_ms_samples)[len(loop_ms_samples) // 2]
+    flops = BATCH * STEPS_DDIM * 358.27e6                      # reference-equivalent (guidance x2 included), SURVEY.md §8d
+    per_row_layer = 2 * 256 * (768 + 256 + 2048 + 256 + 2048 + 256)
+    mfma_flops = 3.0 * BATCH * STEPS_DDIM * 2 * 5 * (9 * per_row_layer + 4 * 2 * 512 * 256)     # executed, 3 bf16 MFMAs per product
+    traffic, util, share, src = profiled(summary, "systolic_loop_kernel")
+    return {"bound": "mfma", "achieved": round(flops / ms / 1e9, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(flops / ms / 1e9 / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": traffic,
+            "kernel": "systolic_loop_kernel<2> (all 50 guided DDIM steps of 128 prompts in one persistent launch)",
+            "us_per_launch": round(ms * 1e3, 1), "flops_per_launch": flops, "mfma_flops_per_launch": mfma_flops,
+            "mfma_frac": round(mfma_flops / ms / 1e9 / PEAK_BF16_MFMA_TFLOPS, 4), "mfma_util_pmc": util, "share_of_pass": share,
+            "traffic_source": src}
 
 
 def cpu_baseline(sample_b):
@@ -133,7 +177,11 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="prompts per GPU")
     ap.add_argument("--cpu-sample", type=int, default=32, help="motions in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
-                    help="matrix-product arithmetic of the timed mode (DESIGN.md §1); the other mode is timed after it")
+                    help="matrix-product arithmetic of the timed mode (DESIGN.md §1); the other mode is timed after it. "
+                         "BASELINE.json's 'bf16' (config c2) and 'fp16' (c5) labels are served by bf16x3: plain bf16 / fp16 operands "
+                         "miss the 1e-3 decoded-frame gate by 50x / 7x on this network (DESIGN.md §1), three bf16 MFMAs per product do not")
+    ap.add_argument("--loop", default="pipeline", choices=["pipeline", "launches"],
+                    help="bf16x3 mode: the 50 steps as one persistent pipeline kernel (default) or as hipGraph replays of one launch per stage")
     args = ap.parse_args()
 
     # the JSON line must be the ONLY thing on stdout: RCCL prints a version banner to fd 1 when the process group comes
@@ -161,6 +209,7 @@ def main():
     text = torch.cat([gtext[:total][lo:hi], gtext[total:][lo:hi]]).to(dev)
     noise = syn.init_noise(lens, offset=lo, total=total).to(dev)
     pipe = build_pipe(dev, B)
+    pipe.loop = args.loop
     gather_buf = torch.empty(total, FRAMES, NFEATS, device=dev) if use_dist else None
 
     stream = torch.cuda.Stream(device=dev)        # hipGraph capture needs a non-null stream; events go on it too
@@ -199,15 +248,43 @@ def main():
 
     wall, dev_ms, feats = timed(args.precision, args.steps, args.warmup)
     assert torch.isfinite(feats).all()
+    # device time of the N-step loop alone (HIP events around it on the bench stream), sampled outside the timed region
+    loop_ms = []
+    with torch.cuda.stream(stream), torch.no_grad():
+        for _ in range(5):
+            one_pass()
+            loop_ms.append(pipe.loop_ms())
+    status = pipe.loop_status()
+    if status[0] != 0:
+        raise SystemExit(f"pipeline loop aborted: status {status}")
     other = "fp32" if args.precision == "bf16x3" else "bf16x3"
     o_wall, o_dev_ms, o_feats = timed(other, max(2, args.steps // 2), 1)        # second mode: shorter, reported beside
     mode_diff = (feats - o_feats).abs().max().item()
 
     if rank == 0:
+        summary = profile_summary()
         motions_per_s = total * args.steps / wall
         dev_s_per_pass = dev_ms / 1e3 / args.steps
         ref_tf = B * ref_flops_per_motion() / dev_s_per_pass / 1e12
         exe_tf = B * executed_flops_per_motion() / dev_s_per_pass / 1e12
+        peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+        pipelined = args.precision == "bf16x3" and pipe.loop != "launches"
+        whole_traffic = None
+        if summary is not None and args.precision == "bf16x3":
+            wp = summary.get("whole_pass", {})
+            if "fetch_bytes_per_pass" in wp:
+                whole_traffic = wp["fetch_bytes_per_pass"] + wp["write_bytes_per_pass"]
+        whole = {"bound": "mfma", "achieved": round(ref_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ref_tf / peak, 4),
+                 "kernel": "whole pass (" + ("pipeline loop kernel" if pipelined else "hipGraph steps x50") + " + decode)",
+                 "device_ms_per_pass": round(dev_ms / args.steps, 3),
+                 "flops_per_motion_reference_equivalent": ref_flops_per_motion(),
+                 "executed_tflops": round(exe_tf, 2),
+                 "executed_frac": round(exe_tf * (1 if args.precision == "fp32" else 3) / peak, 4),
+                 "traffic": whole_traffic,
+                 "traffic_source": (summary["_path"] + f" (commit {summary.get('git_sha', '?')})") if whole_traffic is not None else None,
+                 "mfma_util_pmc": summary.get("whole_pass", {}).get("mfma_util_pmc") if (summary and args.precision == "bf16x3") else None,
+                 "peak_note": "fp32-input MFMA 157.3 TF/s" if args.precision == "fp32" else
+                 "bf16 MFMA 2500 TF/s dense; every fp32-equivalent product costs 3 bf16 MFMAs (833 TF/s fp32-equivalent)"}
         line = {
             "metric": "motions/sec (196-frame, 50-step DDIM, bs128)", "value": round(motions_per_s, 2),
             "unit": "motions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -215,23 +292,9 @@ def main():
             "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16x3+f32", "data": "synthetic",
             "config": {"workload": f"ddim50_cfg7.5_b{B}_f{FRAMES}_c{NFEATS}_humanml3d", "prompts_per_gpu": B,
                        "global_batch": total, "frames": FRAMES, "ddim_steps": STEPS_DDIM, "parallelism": f"dp{world}",
-                       "hipgraph": True},
-            "roofline": {"bound": "mfma", "achieved": round(ref_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ref_tf / PEAK_F32_MFMA_TFLOPS, 4),
-                         "kernel": "whole pass (hipGraph steps x50 + decode)",
-                         "device_ms_per_pass": round(dev_ms / args.steps, 3),
-                         "flops_per_motion_reference_equivalent": ref_flops_per_motion(),
-                         "executed_tflops": round(exe_tf, 2), "executed_frac": round(exe_tf / PEAK_F32_MFMA_TFLOPS, 4),
-                         "traffic": 84.1e9 if args.precision == "fp32" else 72.0e9,
-                         "traffic_source": ("profiles/r1/03_pmc_summary.md" if args.precision == "fp32" else
-                                            "profiles/r1/07_pmc_summary_bf16x3_fused.md") +
-                                           ", bytes per pass at the L2-fabric interface (Infinity-Cache hits included)"},
+                       "loop": "persistent pipeline kernel (one launch for the 50 steps)" if pipelined else "hipGraph, 10 steps per replay"},
+            "roofline": whole,
         }
-        peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
-        line["roofline"].update({"peak": peak, "frac": round(ref_tf / peak, 4), "executed_frac": round(
-            exe_tf * (1 if args.precision == "fp32" else 3) / peak, 4),
-            "peak_note": "fp32-input MFMA 157.3 TF/s" if args.precision == "fp32" else
-            "bf16 MFMA 2500 TF/s dense; every fp32-equivalent product costs 3 bf16 MFMAs (833 TF/s fp32-equivalent)"})
         o_steps = max(2, args.steps // 2)
         o_tf = B * ref_flops_per_motion() / (o_dev_ms / 1e3 / o_steps) / 1e12
         o_peak = PEAK_F32_MFMA_TFLOPS if other == "fp32" else PEAK_BF16_MFMA_TFLOPS
@@ -239,19 +302,22 @@ def main():
                               "ms_per_step": round(o_wall / o_steps * 1e3, 3), "roofline_achieved_tflops": round(o_tf, 2),
                               "roofline_peak": o_peak, "roofline_frac": round(o_tf / o_peak, 4)}
         line["parity"] = {"max_abs_diff_frames_between_modes": mode_diff, "tolerance": 1e-3,
-                          "note": "fp32 mode is within 1e-4 of the reference goldens (tests/test_gpu_path.py)"}
+                          "note": "fp32 mode is within 1e-4 of the reference goldens, bf16x3 within 5e-4 (tests/test_gpu_path.py)"}
         if world == 1:
             # the contract's `roofline` describes the DOMINANT KERNEL (algorithmic FLOPs of one launch / its live HIP-event
             # duration); the whole-pass figures computed above move under roofline.whole_pass
-            whole = line["roofline"]
-            dk = dominant_kernel_roofline(dev, stream, args.precision)
-            line["roofline"] = {"bound": "mfma", "achieved": dk["achieved"], "peak": dk["peak"], "unit": "TFLOP/s",
-                                "frac": dk["frac"], "traffic": dk["traffic"], "kernel": dk["name"],
-                                "us_per_launch": dk["us_per_launch"], "flops_per_launch": dk["flops_per_launch"],
-                                "mfma_flops_per_launch": dk["mfma_flops_per_launch"], "mfma_frac": dk["mfma_frac"],
-                                "traffic_source": dk["traffic_source"], "peak_note": whole["peak_note"],
-                                "share_of_pass": "36-40 % of the device time (profiles/r1/06_bf16x3_fused_summary.md)",
-                                "whole_pass": whole}
+            if pipelined:
+                dk = pipeline_kernel_roofline(pipe, loop_ms, summary)
+            else:
+                d = dominant_kernel_roofline(dev, stream, args.precision, summary)
+                dk = {"bound": "mfma", "achieved": d["achieved"], "peak": d["peak"], "unit": "TFLOP/s", "frac": d["frac"],
+                      "traffic": d["traffic"], "kernel": d["name"], "us_per_launch": d["us_per_launch"],
+                      "flops_per_launch": d["flops_per_launch"], "mfma_flops_per_launch": d["mfma_flops_per_launch"],
+                      "mfma_frac": d["mfma_frac"], "mfma_util_pmc": d["mfma_util_pmc"], "share_of_pass": d["share_of_pass"],
+                      "traffic_source": d["traffic_source"]}
+            dk["peak_note"] = whole["peak_note"]
+            dk["whole_pass"] = whole
+            line["roofline"] = dk
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
             line["cpu_baseline"]["gpu_over_cpu"] = round(motions_per_s / line["cpu_baseline"]["value"], 1)

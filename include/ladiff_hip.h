@@ -196,6 +196,9 @@ int ladiff_sampler_destroy(void* sampler);
  * (guidance on, bf16x3 weights, a CU per pipeline stage) - every CU keeps one stage's weights in registers and blocks of
  * prompts flow through the stages (csrc/systolic.hip); 0 = one launch per stage, captured in a hipGraph of up to 10 steps. */
 int ladiff_sampler_set_loop(void* sampler, int mode);
+/* Device time of the N-step loop of the sampler's last call (HIP events recorded on the call's stream right around the
+ * pipeline kernel, or around the graph replays); blocks until it has finished.  Measurement aid (bench.py). */
+int ladiff_sampler_loop_ms(void* sampler, float* ms);
 /* Blocking read of the pipeline kernel's status word of the last call in this workspace: code 0 = completed,
  * 2 = a stage timed out waiting for its producer (info = workgroup).  Debug / test aid. */
 int ladiff_reverse_status(void* ws, int B, int T, int n_steps, int* code, int* info);

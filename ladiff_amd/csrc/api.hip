@@ -54,8 +54,10 @@ struct Sampler {
     hipGraphExec_t exec = nullptr;
     hipGraphExec_t setup = nullptr;       // per-call prologue (text cache, initial latents, counter reset, first network input)
     int unroll = 1;                       // denoiser steps captured per graph launch
+    int loop_mode = 1;
     int loop = 1;                         // 1: persistent pipeline kernel when the call qualifies (systolic.hip), 0: launch per stage
     std::vector<unsigned char> stages;    // host copy of the pipeline's stage table (source of the upload)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // bracket the N-step loop (pipeline kernel or graph replays) of the last call
     // capture key: a graph bakes pointers, shapes and scalars into its kernel nodes.  The weight tables are identified by
     // a hash over EVERY pointer of both tables plus the caller's generation id (bumped whenever a table is rebuilt), not
     // by the address of the host array (which a rebuilt table can land on again).
@@ -257,15 +259,26 @@ int ladiff_sampler_destroy(void* sampler) {
     (void)hipDeviceSynchronize();         // a replay of these graphs may still be queued
     if (sp->exec) (void)hipGraphExecDestroy(sp->exec);
     if (sp->setup) (void)hipGraphExecDestroy(sp->setup);
+    if (sp->ev0) (void)hipEventDestroy(sp->ev0);
+    if (sp->ev1) (void)hipEventDestroy(sp->ev1);
     delete sp;
     return 0;
 }
 
 int ladiff_sampler_set_loop(void* sampler, int mode) {
     Sampler* sp = reinterpret_cast<Sampler*>(sampler);
-    LADIFF_CHECK_ARG(sp != nullptr && (mode == 0 || mode == 1 || mode == 2));
+    LADIFF_CHECK_ARG(sp != nullptr && mode >= 0 && mode <= 3);
     sp->loop = mode != 0;
-    sys_set_row_tiles(mode == 2 ? 1 : 2);          // 2: one prompt per block (16-row tiles), 1: three prompts (32-row tiles)
+    sp->loop_mode = mode;
+    sys_set_row_tiles(mode == 2 ? 1 : (mode == 3 ? 3 : 2));          // 2: one prompt per block (16-row tiles), 1: three prompts (32-row tiles)
+    return 0;
+}
+
+int ladiff_sampler_loop_ms(void* sampler, float* ms) {
+    Sampler* sp = reinterpret_cast<Sampler*>(sampler);
+    LADIFF_CHECK_ARG(sp != nullptr && ms != nullptr && sp->ev1 != nullptr);
+    LADIFF_HIP(hipEventSynchronize(sp->ev1));
+    LADIFF_HIP(hipEventElapsedTime(ms, sp->ev0, sp->ev1));
     return 0;
 }
 
@@ -336,7 +349,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
         for (int i = 0; i < n_steps; ++i) LADIFF_TRY(one_step(s));
     } else {
         const void* kp[9] = {ws, counts, final_counts, coef, step_noise, stream, text_emb, init_noise, z};
-        const int ki[4] = {B, T, n_steps, cfg + 2 * (pipeline ? sys_row_tiles(T) : 0)};
+        const int ki[4] = {B, T, n_steps, cfg + 2 * (pipeline ? sp->loop_mode : 0)};
         const float kf[2] = {guidance_scale, init_noise_sigma};
         uint64_t h = hash_ptrs(w, DEN_NPARAMS, 1469598103934665603ull);
         if (w_split) h = hash_ptrs(w_split, DEN_NPARAMS, h ^ 0x9e3779b97f4a7c15ull);
@@ -388,6 +401,8 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
             sp->key_gen = weights_generation;
         }
         LADIFF_HIP(hipGraphLaunch(sp->setup, s));
+        if (sp->ev0 == nullptr) { LADIFF_HIP(hipEventCreate(&sp->ev0)); LADIFF_HIP(hipEventCreate(&sp->ev1)); }
+        LADIFF_HIP(hipEventRecord(sp->ev0, s));
         if (pipeline) {
             const float* tkv = r.cache + (size_t)B2 * D;
             const float* ctab = tkv + (size_t)NL * B2 * 2 * D;
@@ -396,6 +411,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
         } else {
             for (int i = 0; i < n_steps / sp->unroll; ++i) LADIFF_HIP(hipGraphLaunch(sp->exec, s));
         }
+        LADIFF_HIP(hipEventRecord(sp->ev1, s));
     }
     // final zeroing of the rows past each motion's latent count: applied even when the denoiser ran unmasked
     // (TEST_EFFICIENCY), as ladiff.py:559-566 does

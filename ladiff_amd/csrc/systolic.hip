@@ -942,6 +942,7 @@ __global__ __launch_bounds__(256, 1) void systolic_loop_kernel(const SysArgs p) 
 unsigned long long* g_sys_stamps = nullptr;
 #endif
 static int g_sys_row_tiles = 2;
+static int g_sys_pcap = 7;
 namespace {
 struct SysLayout {
     size_t blk;                   // floats of one [NB][RT][256] buffer
@@ -952,6 +953,7 @@ SysLayout sys_layout(int B, int T, int MR) {
     SysLayout L;
     const int RT = 16 * MR;
     int P = RT / (2 * T);
+    if (P > g_sys_pcap) P = g_sys_pcap;
     if (P > 7) P = 7;             // the QKV stage parks (2P + 1) x 128 floats of extra K|V through 512 thread slots
     if (P < 1) P = 1;
     L.P = P;
@@ -1104,6 +1106,6 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
 
 size_t sys_stage_bytes(int B, int T) { return (size_t)sys_layout(B, T, sys_row_tiles(T)).nwg * sizeof(Stage); }
 size_t sys_status_offset_floats(int B, int T) { return sys_layout(B, T, sys_row_tiles(T)).off_status; }
-void sys_set_row_tiles(int mr) { g_sys_row_tiles = mr == 1 ? 1 : 2; }
+void sys_set_row_tiles(int mr) { g_sys_row_tiles = mr == 1 ? 1 : 2; g_sys_pcap = mr == 3 ? 2 : 7; }
 
 }  // namespace ladiff

@@ -103,7 +103,7 @@ class LADIFF(nn.Module):
         # how the N steps run (include/ladiff_hip.h, ladiff_sampler_set_loop): "pipeline" = one persistent weight-stationary
         # kernel for the whole loop when the call qualifies (guidance on, bf16x3; blocks of three prompts, "pipeline16": of one
         # prompt), "launches" = one launch per stage in hipGraphs
-        if loop not in ("pipeline", "pipeline16", "launches"):
+        if loop not in ("pipeline", "pipeline16", "pipeline_p2", "launches"):
             raise ValueError(f"loop {loop!r} not supported")
         self.loop = loop
         # matrix-product arithmetic of the denoiser loop: "fp32" (fp32-input MFMA) or "bf16x3" (3-term bf16 split)
@@ -196,7 +196,7 @@ class LADIFF(nn.Module):
             _lib.check(L.ladiff_sampler_create(byref(h)))
             self._sampler = h
         if self._sampler is not None:
-            _lib.check(L.ladiff_sampler_set_loop(self._sampler, {"pipeline": 1, "pipeline16": 2, "launches": 0}[self.loop]))
+            _lib.check(L.ladiff_sampler_set_loop(self._sampler, {"pipeline": 1, "pipeline16": 2, "pipeline_p2": 3, "launches": 0}[self.loop]))
         if init_noise is None:
             init_noise = torch.randn(B, T, 256, device=dev, dtype=torch.float32)       # ladiff.py:380-385
         if need_noise and step_noise is None:
@@ -228,6 +228,13 @@ class LADIFF(nn.Module):
         if run is not cur:
             cur.wait_stream(run)
         return plan["z"].clone()
+
+    def loop_ms(self):
+        """Device milliseconds of the N-step loop of the last `_diffusion_reverse` call (HIP events on its stream)."""
+        from ctypes import c_float
+        ms = c_float(0.0)
+        _lib.check(_lib.lib().ladiff_sampler_loop_ms(self._sampler, byref(ms)))
+        return ms.value
 
     def loop_status(self):
         """(code, info) of the persistent pipeline kernel of the last `_diffusion_reverse` call; blocks until the stream has
