@@ -49,6 +49,7 @@ constexpr int HS = FF / NSLICE;           // 128
 constexpr int NRED = 3;                   // row parts of the two reduce stages
 constexpr int NTAIL = 4;                  // tail workgroups (block b belongs to tail b % NTAIL)
 constexpr int FLAG_SLOTS = 8;
+constexpr int FLAG_STRIDE = 32;             // words between the flags of two producers: every flag on a 128-byte line of its own
 constexpr int SYS_LDS_BYTES = 100 * 1024;   // > 80 KiB: one workgroup per CU, so the <= 256 workgroups sit on distinct CUs
 constexpr int GROUPS_PER_LAYER = 7;
 enum Group : int { G_XIN = 0, G_ATT = 1, G_X1 = 2, G_PC = 3, G_X2 = 4, G_PE = 5, G_XO = 6 };
@@ -76,6 +77,7 @@ struct SysArgs {
     const int32_t* counts;
     float gscale;
     int B, T, P, NB, step_lo, n_steps, n_ctab;
+    int split;                            // 1: a block holds ONE guidance branch of its P prompts (block 2g + br), 0: both
     unsigned long long* stamps;           // diagnostic twin build only (-DLADIFF_STAMPS): [workgroup][step][block][8] realtime ticks
 };
 
@@ -84,8 +86,12 @@ struct SysArgs {
 #ifdef LADIFF_STAMPS
 #define SYS_STAMP(i)                                                                                                   \
     do {                                                                                                               \
-        if (p.stamps != nullptr && threadIdx.x == 0 && s < 4 && b < 4)                                                 \
-            p.stamps[(((size_t)blockIdx.x * 4 + s) * 4 + b) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();             \
+        if (p.stamps != nullptr && threadIdx.x == 0) {                                                                 \
+            if (s < 4 && b < 4) p.stamps[(((size_t)blockIdx.x * 4 + s) * 4 + b) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+            const int sm_ = p.n_steps / 2, bm_ = p.NB / 2;       /* steady state: four consecutive blocks mid-run */         \
+            if (s == sm_ && b >= bm_ && b < bm_ + 4)                                                                   \
+                p.stamps[(size_t)256 * 4 * 4 * 8 + 256 * 4 + ((size_t)blockIdx.x * 4 + (b - bm_)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                                                              \
     } while (0)
 // per-workgroup totals behind the timeline: ticks blocked in wait_epoch, prefetch hits, blocks processed
 #define SYS_STAT_DECL unsigned long long st_wait = 0, st_hit = 0, st_n = 0, st_t = 0
@@ -133,7 +139,7 @@ __device__ __forceinline__ bool wait_epoch(const unsigned* flags, int n, unsigne
         int bad = 0;
         for (unsigned spins = 1;; ++spins) {
             unsigned v = epoch;
-            if (lane < n) v = __hip_atomic_load((const gu32*)flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane < n) v = __hip_atomic_load((const gu32*)flags + lane * FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__all(v >= epoch)) break;
             if ((spins & 31u) == 0u) {
                 const unsigned a = __hip_atomic_load((const gu32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -163,8 +169,14 @@ __device__ __forceinline__ void publish(unsigned* flag, unsigned epoch) {
 }
 
 __device__ __forceinline__ unsigned* flag_of(const SysArgs& p, int group, int b, int slot) {      // group = layer * 7 + Group
-    return p.flags + ((size_t)(group * p.NB + b) * FLAG_SLOTS + slot);
+    return p.flags + ((size_t)(group * p.NB + b) * FLAG_SLOTS + slot) * FLAG_STRIDE;
 }
+
+// block geometry.  split = 0: block b = prompts b P .. b P + P - 1, rows (br P + pl) T + t (both guidance branches);
+// split = 1: block b = branch b & 1 of prompt group b >> 1, rows pl T + t.  sx = sample-branch index within the block.
+__device__ __forceinline__ int blk_nsb(const SysArgs& p) { return p.split ? p.P : 2 * p.P; }
+__device__ __forceinline__ int blk_prompt0(const SysArgs& p, int b) { return (p.split ? (b >> 1) : b) * p.P; }
+__device__ __forceinline__ int blk_branch(const SysArgs& p, int b, int sx_br) { return p.split ? (b & 1) : sx_br; }
 
 // ---------------------------------------------------------------- LDS images
 // S-format operand tile: row = KB blocks of 256 B, block = 8 hi slots + 8 lo slots of 16 B, slot index XORed with (row & 15)
@@ -244,14 +256,20 @@ __device__ __forceinline__ void mma(const char* tile, const WFrag<NT, KS>& f, f3
                 al[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(a_slot<KB>(t, 16 * i + frow, (s + 1) >> 1, 8 + 4 * ((s + 1) & 1) + fk));
             }
         }
+        // the three products of a split operand pair go to the same accumulator: one product at a time over all MR x NT
+        // accumulators, so that consecutive MFMAs never depend on each other (a dependent 16x16x32 waits ~2x its issue time)
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s & 1][i], f.hi[j][s], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1][i], f.lo[j][s], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1][i], f.hi[j][s], acc[i][j], 0, 0, 0);
-            }
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s & 1][i], f.hi[j][s], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1][i], f.lo[j][s], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1][i], f.hi[j][s], acc[i][j], 0, 0, 0);
     }
 }
 
@@ -300,11 +318,43 @@ __device__ __forceinline__ f32x4 sum8(const f32x4 (&pl)[NSLICE]) {       // fixe
 //   R::Pay            register image of one block's inputs
 //   r.issue(s, b, pay) every load of block (s, b)                r.commit(pay)  registers -> LDS operand images
 //   r.compute(s, b, pay) the stage's arithmetic and its sc1 stores
+// What a stage does at the FIRST barrier inside its compute phase (about a microsecond after the phase started): by
+// then the previous block's write-through stores have drained for free, so its flag is published there, and only then are
+// the next block's loads and the early poll issued (a `vmcnt(0)` placed after them would wait for them as well).
+template <class R>
+struct Mid {
+    const SysArgs& p; const Stage& st; R& r; typename R::Pay& nxt;
+    unsigned* pending; unsigned pending_epoch; bool have; int s2, b2, s3, b3;
+    unsigned early; bool early_valid;
+    __device__ __forceinline__ void before_barrier() const {
+        if (pending != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __device__ __forceinline__ void after_barrier() {
+        if (pending != nullptr) {
+            if (threadIdx.x == 0) __hip_atomic_store((gu32*)pending, pending_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pending = nullptr;
+        }
+        if constexpr (R::PREFETCH) { if (have) r.issue(s2, b2, nxt); }
+        early_valid = R::PREFETCH && s3 < p.n_steps;
+        early = 0xffffffffu;
+        if (early_valid && threadIdx.x < 64 && (int)(threadIdx.x & 63) < st.wait_n)
+            early = __hip_atomic_load((const gu32*)flag_of(p, st.wait_group, b3, 0) + (threadIdx.x & 63) * FLAG_STRIDE, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+
 template <class R>
 __device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R& r, Ctl* ctl, int b0, int bstride) {
     typename R::Pay cur, nxt;
     bool have = false;
     const int lane = threadIdx.x & 63;
+    unsigned* pending = nullptr;                                         // flag of the previous block, its stores still draining
+    unsigned pending_epoch = 0;
+    // The poll that decides whether the NEXT block can be prefetched was issued one iteration earlier (a flag load is a ~1 us
+    // round trip to the memory side: waited for in place it was a quarter of a saturated stage's time per block).  A miss
+    // costs nothing: the next iteration then waits for its flags the normal way.
+    unsigned early = 0;
+    bool early_valid = false;
     SYS_STAT_DECL;
     for (int s = 0; s < p.n_steps; ++s)
         for (int b = b0; b < p.NB; b += bstride) {
@@ -319,25 +369,34 @@ __device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R&
             SYS_STAMP(1);
             int s2 = s, b2 = b + bstride;
             if (b2 >= p.NB) { s2 = s + 1; b2 = b0; }
+            int s3 = s2, b3 = b2 + bstride;
+            if (b3 >= p.NB) { s3 = s2 + 1; b3 = b0; }
             const bool has_next = R::PREFETCH && s2 < p.n_steps;
-            unsigned fv = 0xffffffffu;                                   // one poll of the next block's flags, in flight under commit
-            if (has_next && threadIdx.x < 64 && lane < st.wait_n)
-                fv = __hip_atomic_load((const gu32*)flag_of(p, st.wait_group, b2, 0) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             r.commit(cur);
             if (threadIdx.x < 64) {
-                const int ok = has_next && __all(fv >= (unsigned)(s2 + 1));
+                const int ok = has_next && early_valid && __all(early >= (unsigned)(s2 + 1));
                 if (lane == 0) ctl->ready = ok;
             }
             __syncthreads();
             have = R::PREFETCH && ctl->ready != 0;
-            if constexpr (R::PREFETCH) { if (have) r.issue(s2, b2, nxt); }
             SYS_STAMP(2);
-            r.compute(s, b, cur);
+            Mid<R> mid{p, st, r, nxt, pending, pending_epoch, have, s2, b2, s3, b3, 0u, false};
+            r.compute(s, b, cur, mid);
+            early = mid.early; early_valid = mid.early_valid;
             SYS_STAMP(4);
-            publish(flag_of(p, st.out_group, b, st.out_slot), s + 1);
+            if (have) {
+                // backlogged (the next block is already here): throughput counts, so this block's flag goes out at the next
+                // block's first compute barrier instead of stalling the stage on the write-through drain now
+                pending = flag_of(p, st.out_group, b, st.out_slot);
+                pending_epoch = s + 1;
+            } else {
+                pending = nullptr;
+                publish(flag_of(p, st.out_group, b, st.out_slot), s + 1);
+            }
             SYS_STAMP(5);
             if constexpr (R::PREFETCH) { if (have) cur = nxt; }
         }
+    if (pending != nullptr) publish(pending, pending_epoch);
     SYS_STAT_END;
 }
 
@@ -346,7 +405,7 @@ __device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R&
 // keys of the sample (masked by its latent count), the text token and the time token.
 template <int MR>
 struct QkvRole {
-    static constexpr int RT = 16 * MR, QLD = 196;
+    static constexpr int RT = 16 * MR, QLD = 196, NI = MR + 1;            // score work items per thread: 2 lanes x rows x keys
     static constexpr bool PREFETCH = true;
     struct Pay { Rows256<MR> x; f32x4 xk[2]; int cnt; };
     const SysArgs& p; const Stage& st;
@@ -356,11 +415,11 @@ struct QkvRole {
     __amdgpu_buffer_rsrc_t rin, rout;
     const float* tkv;
     int h, T, P, nkeys, nsb, nrows;
-    int s_row[2], s_j[2], s_sx[2], o_sx[2], x_br[2], x_pl[2], c_pl;
+    int s_row[NI], s_j[NI], s_sx[NI], o_sx[2], x_br[2], x_pl[2], c_pl;
 
     __device__ __forceinline__ QkvRole(const SysArgs& p_, const Stage& st_, char* lds) : p(p_), st(st_) {
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frow = lane & 15;
-        h = st.slice; T = p.T; P = p.P; nkeys = T + 2; nsb = 2 * P; nrows = nsb * T;
+        h = st.slice; T = p.T; P = p.P; nkeys = T + 2; nsb = blk_nsb(p); nrows = nsb * T;
         atile = lds;                                                     // [RT] x K=256 operand tile
         qt = reinterpret_cast<float*>(lds + RT * 1024);                  // [RT][QLD] q | k | v (fp32)
         xt = qt + RT * QLD;                                              // [2P + 1][128]: text k|v per sample-branch, time k|v last
@@ -375,10 +434,14 @@ struct QkvRole {
         // every index that does not depend on the block is computed once (integer divisions by run-time T / P are ~40
         // instructions each): score items (row, key), output items (row, 4 columns), extra K|V slots
 #pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int pair = (tid + 256 * u) >> 1;
+            s_row[u] = pair / nkeys; s_j[u] = pair - s_row[u] * nkeys; s_sx[u] = s_row[u] / T;
+            if (pair >= nrows * nkeys) s_row[u] = -1;
+        }
+#pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int id = tid + 256 * u;
-            s_row[u] = id / nkeys; s_j[u] = id - s_row[u] * nkeys; s_sx[u] = s_row[u] / T;
-            if (id >= nrows * nkeys) s_row[u] = -1;
             o_sx[u] = (id >> 4) / T;
             const int sx = id >> 5;
             x_br[u] = sx / P; x_pl[u] = sx - x_br[u] * P;
@@ -393,14 +456,14 @@ struct QkvRole {
             const int f4 = tid + 256 * u, sx = f4 >> 5, c4 = (f4 & 31) * 4;
             y.xk[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (sx < nsb) {
-                const int prompt = b * P + x_pl[u];
-                if (prompt < p.B) y.xk[u] = ld4(tkv + (size_t)(x_br[u] * p.B + prompt) * 512 + (c4 < 64 ? c4 : 192 + c4) + h * 64);
+                const int prompt = blk_prompt0(p, b) + x_pl[u];
+                if (prompt < p.B) y.xk[u] = ld4(tkv + (size_t)(blk_branch(p, b, x_br[u]) * p.B + prompt) * 512 + (c4 < 64 ? c4 : 192 + c4) + h * 64);
             } else if (sx == nsb) {
                 y.xk[u] = ld4(timekv + (c4 < 64 ? c4 : 192 + c4) + h * 64);
             }
         }
         y.cnt = T;
-        if (tid < nsb && p.counts != nullptr && b * P + c_pl < p.B) { y.cnt = p.counts[b * P + c_pl]; y.cnt = y.cnt > T ? T : y.cnt; }
+        if (tid < nsb && p.counts != nullptr && blk_prompt0(p, b) + c_pl < p.B) { y.cnt = p.counts[blk_prompt0(p, b) + c_pl]; y.cnt = y.cnt > T ? T : y.cnt; }
         issue_rows<MR>(y.x, rin, (unsigned)b * RT * 1024);
     }
     __device__ __forceinline__ void commit(const Pay& y) {
@@ -411,7 +474,8 @@ struct QkvRole {
             if (((tid + 256 * u) >> 5) <= nsb) st4(xt + (tid + 256 * u) * 4, y.xk[u]);
         if (tid < nsb) cnt[tid] = y.cnt;
     }
-    __device__ __forceinline__ void compute(int s, int b, const Pay&) {
+    template <class M>
+    __device__ __forceinline__ void compute(int s, int b, const Pay&, M& mid) {
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frow = lane & 15;
         f32x4 acc[MR][3];
         zero_acc(acc);
@@ -426,47 +490,56 @@ struct QkvRole {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) qt[(16 * i + 4 * (lane >> 4) + r) * QLD + tc] = (acc[i][j][r] + bcol[j]) * scl;
             }
+        mid.before_barrier();
         __syncthreads();
+        mid.after_barrier();
+        SYS_STAMP(6);
+        // scores: two lanes per (row, key), 32 of the 64 products each
 #pragma unroll
-        for (int u = 0; u < MR; ++u) {                                   // one thread per (row, key): 64-long dot product
-            const int row = s_row[u], j = s_j[u], sx = s_sx[u];
+        for (int u = 0; u < NI; ++u) {
+            const int row = s_row[u], j = s_j[u], sx = s_sx[u], half = (tid + 256 * u) & 1;
+            float d = 0.f;
             if (row >= 0) {
-                const float* kp = j < T ? qt + (sx * T + j) * QLD + 64 : (j == T ? xt + sx * 128 : xt + nsb * 128);
-                const float* qp = qt + row * QLD;
-                float d = 0.f;
+                const float* kp = (j < T ? qt + (sx * T + j) * QLD + 64 : (j == T ? xt + sx * 128 : xt + nsb * 128)) + 32 * half;
+                const float* qp = qt + row * QLD + 32 * half;
 #pragma unroll
-                for (int c = 0; c < 64; c += 4) {
+                for (int c = 0; c < 32; c += 4) {
                     const f32x4 a = ld4(qp + c), k4 = ld4(kp + c);
                     d = fmaf(a[0], k4[0], d); d = fmaf(a[1], k4[1], d); d = fmaf(a[2], k4[2], d); d = fmaf(a[3], k4[3], d);
                 }
-                sc[row * 16 + j] = (j < T && j >= cnt[sx]) ? -INFINITY : d;
             }
+            d += __shfl_xor(d, 1, 64);
+            if (row >= 0 && half == 0) sc[row * 16 + j] = (j < T && j >= cnt[sx]) ? -INFINITY : d;
+        }
+        __syncthreads();
+        SYS_STAMP(7);
+        if (tid < nrows) {                                               // softmax over a row's T + 2 keys, one v_exp_f32 per probability
+            float e[LADIFF_MAX_LATENTS + 2];
+            float m = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < LADIFF_MAX_LATENTS + 2; ++j) { e[j] = j < nkeys ? sc[tid * 16 + j] : -INFINITY; m = fmaxf(m, e[j]); }
+            float l = 0.f;
+#pragma unroll
+            for (int j = 0; j < LADIFF_MAX_LATENTS + 2; ++j) {
+                e[j] = j < nkeys ? __builtin_amdgcn_exp2f((e[j] - m) * 1.4426950408889634f) : 0.f;
+                l += e[j];
+            }
+            const float inv = 1.f / l;
+#pragma unroll
+            for (int j = 0; j < LADIFF_MAX_LATENTS + 2; ++j)
+                if (j < nkeys) sc[tid * 16 + j] = e[j] * inv;
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < MR; ++u) {                                   // one thread per (row, 4 columns): softmax + P.V
+        for (int u = 0; u < MR; ++u) {                                   // one thread per (row, 4 columns): o = sum_j p_j v_j
             const int id = tid + 256 * u, row = id >> 4, c4 = (id & 15) * 4, sx = o_sx[u];
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
             if (row < nrows) {
-                float e[LADIFF_MAX_LATENTS + 2];
-                float m = -INFINITY;
-#pragma unroll
-                for (int j = 0; j < LADIFF_MAX_LATENTS + 2; ++j) { e[j] = j < nkeys ? sc[row * 16 + j] : -INFINITY; m = fmaxf(m, e[j]); }
-                float l = 0.f;
-#pragma unroll
-                for (int j = 0; j < LADIFF_MAX_LATENTS + 2; ++j) {     // exp(x) as one v_exp_f32: 2^(x log2 e)
-                    e[j] = j < nkeys ? __builtin_amdgcn_exp2f((e[j] - m) * 1.4426950408889634f) : 0.f;
-                    l += e[j];
-                }
-                const float inv = 1.f / l;
-#pragma unroll
-                for (int j = 0; j < LADIFF_MAX_LATENTS + 2; ++j) {
-                    if (j < nkeys) {
-                        const float pj = e[j] * inv;
-                        const float* vp = j < T ? qt + (sx * T + j) * QLD + 128 : (j == T ? xt + sx * 128 + 64 : xt + nsb * 128 + 64);
-                        const f32x4 v = ld4(vp + c4);
-                        o[0] = fmaf(pj, v[0], o[0]); o[1] = fmaf(pj, v[1], o[1]); o[2] = fmaf(pj, v[2], o[2]); o[3] = fmaf(pj, v[3], o[3]);
-                    }
+                for (int j = 0; j < nkeys; ++j) {
+                    const float pj = sc[row * 16 + j];
+                    const float* vp = j < T ? qt + (sx * T + j) * QLD + 128 : (j == T ? xt + sx * 128 + 64 : xt + nsb * 128 + 64);
+                    const f32x4 v = ld4(vp + c4);
+                    o[0] = fmaf(pj, v[0], o[0]); o[1] = fmaf(pj, v[1], o[1]); o[2] = fmaf(pj, v[2], o[2]); o[3] = fmaf(pj, v[3], o[3]);
                 }
             }
             st_sc1(rout, ((unsigned)b * RT + row) * 1024 + (h * 64 + c4) * 4, o);
@@ -500,7 +573,8 @@ struct OutRole {
         for (int q = 0; q < RPW; ++q) y.res[q] = ld_sc1(rx, base + (wave + 4 * q) * 1024 + lane * 16);
     }
     __device__ __forceinline__ void commit(const Pay& y) { commit_rows<4, MR>(atile, 0, y.att); }
-    __device__ __forceinline__ void compute(int s, int b, const Pay& y) {
+    template <class M>
+    __device__ __forceinline__ void compute(int s, int b, const Pay& y, M& mid) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
         const unsigned base = (unsigned)b * RT * 1024;
         f32x4 acc[MR][4];
@@ -508,7 +582,9 @@ struct OutRole {
         mma<4, 4, 8, MR>(atile, wf, acc);
         SYS_STAMP(3);
         stage_c(ct, acc, [&](int j) { return 64 * wave + 16 * j; });
+        mid.before_barrier();
         __syncthreads();
+        mid.after_barrier();
 #pragma unroll
         for (int q = 0; q < RPW; ++q) {
             const int row = wave + 4 * q;
@@ -552,7 +628,8 @@ struct MlpRole {
     }
     __device__ __forceinline__ void issue(int, int b, Pay& y) { issue_rows<MR>(y.x, rin, (unsigned)b * RT * 1024); }
     __device__ __forceinline__ void commit(const Pay& y) { commit_rows<4, MR>(atile, 0, y.x); }
-    __device__ __forceinline__ void compute(int s, int b, const Pay&) {
+    template <class M>
+    __device__ __forceinline__ void compute(int s, int b, const Pay&, M& mid) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, frow = lane & 15, fk = lane >> 4;
         const unsigned base = (unsigned)b * RT * 1024;
         f32x4 acc1[MR][2];
@@ -574,7 +651,9 @@ struct MlpRole {
                     *(reinterpret_cast<__bf16*>(a_slot<2>(htile, row, k >> 6, 8 + ((k & 63) >> 3))) + (k & 7)) = lo;
                 }
             }
+        mid.before_barrier();
         __syncthreads();
+        mid.after_barrier();
         f32x4 acc2[MR][4];
         zero_acc(acc2);
         mma<2, 4, 4, MR>(htile, w2, acc2);
@@ -590,7 +669,7 @@ struct MlpRole {
 
 // rows [lo, hi) of a block handled by reduce part `part`: the 2 P T live rows split evenly
 __device__ __forceinline__ void part_rows(const SysArgs& p, int part, int& lo, int& hi) {
-    const int live = 2 * p.P * p.T, per = (live + NRED - 1) / NRED;
+    const int live = blk_nsb(p) * p.T, per = (live + NRED - 1) / NRED;
     lo = part * per;
     hi = lo + per < live ? lo + per : live;
     if (lo > hi) lo = hi;
@@ -601,7 +680,7 @@ template <int MR>
 struct Red2Role {
     static constexpr int RT = 16 * MR, PQ = MR + 1;                       // rows per wave: 11 rows / 4 waves (MR 2), 6 / 4 (MR 1)
     static constexpr bool PREFETCH = true;
-    struct Pay { f32x4 pl[PQ][NSLICE], rs[PQ], tv[PQ]; };
+    struct Pay { f32x4 pl[PQ][NSLICE], rs[PQ], tv[PQ], tp[PQ]; int cnt[PQ]; };
     const SysArgs& p; const Stage& st;
     f32x4 bias, gg, bb;
     __amdgpu_buffer_rsrc_t rp, rx, rout;
@@ -627,14 +706,17 @@ struct Red2Role {
         for (int q = 0; q < PQ; ++q) {
             const int row = lo + wave + 4 * q;
             if (row < hi) {
-                const int prompt = b * p.P + r_pl[q];
-                int trow = 2 * p.B;                                      // padded latent row / absent prompt: the pad row
+                // the row's cross-attention vector is its sample's table row while t < latent count, the pad row otherwise:
+                // both candidates and the count are fetched side by side (a dependent address would be a second round trip)
+                const int prompt = blk_prompt0(p, b) + r_pl[q];
+                y.cnt[q] = 0;
+                y.tv[q] = ld4(ct + (size_t)(2 * p.B) * D + c);
+                y.tp[q] = y.tv[q];
                 if (prompt < p.B) {
-                    int cnt = 0x7fffffff;
-                    if (p.counts != nullptr) cnt = p.counts[prompt];
-                    if (r_t[q] < cnt) trow = r_br[q] * p.B + prompt;
+                    y.cnt[q] = 0x7fffffff;
+                    if (p.counts != nullptr) y.cnt[q] = p.counts[prompt];
+                    y.tv[q] = ld4(ct + (size_t)(blk_branch(p, b, r_br[q]) * p.B + prompt) * D + c);
                 }
-                y.tv[q] = ld4(ct + (size_t)trow * D + c);
 #pragma unroll
                 for (int j = 0; j < NSLICE; ++j) y.pl[q][j] = ld_sc1(rp, j * pstride + base + row * 1024 + c * 4);
                 y.rs[q] = ld_sc1(rx, base + row * 1024 + c * 4);
@@ -642,9 +724,12 @@ struct Red2Role {
         }
     }
     __device__ __forceinline__ void commit(const Pay&) {}
-    __device__ __forceinline__ void compute(int, int b, const Pay& y) {
+    template <class M>
+    __device__ __forceinline__ void compute(int, int b, const Pay& y, M& mid) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
         const unsigned base = (unsigned)b * RT * 1024;
+        if (mid.pending != nullptr) { mid.before_barrier(); __syncthreads(); }      // no barrier of its own in this stage
+        mid.after_barrier();
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
             const int row = lo + wave + 4 * q;
@@ -655,7 +740,7 @@ struct Red2Role {
                 float mean, rstd;
                 row_stats4(v, mean, rstd);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i] + y.tv[q][i];
+                for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i] + (r_t[q] < y.cnt[q] ? y.tv[q][i] : y.tp[q][i]);
                 st_sc1(rout, base + row * 1024 + c * 4, v);
             }
         }
@@ -667,7 +752,7 @@ template <int MR>
 struct StylRole {
     static constexpr int RT = 16 * MR, PQ = MR + 1;
     static constexpr bool PREFETCH = MR == 1;       // 256 weight registers + two images of 27 x 16 bytes per lane do not fit
-    struct Pay { f32x4 pl[PQ][NSLICE], rs[PQ]; };
+    struct Pay { f32x4 pl[PQ][NSLICE], rs[PQ], scl, shf; };
     const SysArgs& p; const Stage& st;
     char* atile; float* ct;
     WFrag<4, 8> wf;
@@ -684,9 +769,11 @@ struct StylRole {
         part_rows(p, st.slice, lo, hi);
         pstride = (unsigned)p.NB * RT * 1024;
     }
-    __device__ __forceinline__ void issue(int, int b, Pay& y) {
+    __device__ __forceinline__ void issue(int s, int b, Pay& y) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
         const unsigned base = (unsigned)b * RT * 1024;
+        const float* mod = p.tables + (size_t)(p.step_lo + s) * DEN_STEP_STRIDE + st.layer * DEN_LAYER_STRIDE + DEN_OFF_FFN_MOD;
+        y.scl = ld4(mod + c); y.shf = ld4(mod + D + c);                  // AdaLN scale | shift of this step (time tables)
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
             const int row = lo + wave + 4 * q;
@@ -699,11 +786,11 @@ struct StylRole {
         }
     }
     __device__ __forceinline__ void commit(const Pay&) {}
-    __device__ __forceinline__ void compute(int s, int b, const Pay& y) {
+    template <class M>
+    __device__ __forceinline__ void compute(int s, int b, const Pay& y, M& mid) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
         const unsigned base = (unsigned)b * RT * 1024;
-        const float* mod = p.tables + (size_t)(p.step_lo + s) * DEN_STEP_STRIDE + st.layer * DEN_LAYER_STRIDE + DEN_OFF_FFN_MOD;
-        const f32x4 scl = ld4(mod + c), shf = ld4(mod + D + c);
+        const f32x4 scl = y.scl, shf = y.shf;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                                    // the 16 rows of the operand tile: local row wave + 4 q
             const int lr = wave + 4 * q, row = lo + lr;
@@ -723,7 +810,9 @@ struct StylRole {
             *reinterpret_cast<bf16x4*>(a_slot<4>(atile, lr, c >> 6, (c & 63) >> 3) + (c & 7) * 2) = h4;
             *reinterpret_cast<bf16x4*>(a_slot<4>(atile, lr, c >> 6, 8 + ((c & 63) >> 3)) + (c & 7) * 2) = l4;
         }
+        mid.before_barrier();
         __syncthreads();
+        mid.after_barrier();
         f32x4 acc[1][4];
         zero_acc(acc);
         mma<4, 4, 8, 1>(atile, wf, acc);
@@ -765,14 +854,17 @@ struct SkipRole {
         issue_rows<MR>(y.k, rs, (unsigned)b * RT * 1024);
     }
     __device__ __forceinline__ void commit(const Pay& y) { commit_rows<8, MR>(atile, 0, y.x); commit_rows<8, MR>(atile, 4, y.k); }
-    __device__ __forceinline__ void compute(int, int b, const Pay&) {
+    template <class M>
+    __device__ __forceinline__ void compute(int, int b, const Pay&, M& mid) {
         const int tid = threadIdx.x, wave = tid >> 6;
         const unsigned base = (unsigned)b * RT * 1024;
         f32x4 acc[MR][2];
         zero_acc(acc);
         mma<8, 2, 16, MR>(atile, wf, acc);
         stage_c(ct, acc, [&](int j) { return n0 + 32 * wave + 16 * j; });
+        mid.before_barrier();
         __syncthreads();
+        mid.after_barrier();
 #pragma unroll
         for (int u = 0; u < 2 * MR; ++u) {                               // (row, 4 columns) of this half
             const int id = tid + 256 * u, row = id >> 5, cc = n0 + (id & 31) * 4;
@@ -786,10 +878,11 @@ struct SkipRole {
 };
 
 // TAIL: encoder.norm on both branches, guidance, scheduler step, latents, next step's network input (x = latents + pe).
-// Tail workgroup k owns the blocks b = k (mod NTAIL).
+// A tail works on UNITS of P prompts: unit u = block u (both branches in one block) or blocks 2u (unconditional rows) and
+// 2u + 1 (conditional rows) when the blocks are split by branch.  Tail workgroup k owns the units u = k (mod NTAIL).
 template <int MR>
 struct TailRole {
-    static constexpr int RT = 16 * MR, NQ = 2 * MR;                      // (prompt, latent) pairs per wave: P T <= 8 MR
+    static constexpr int RT = 16 * MR, NQ = 4;                           // (prompt, latent) pairs per wave: P T <= 16
     struct Pay { f32x4 eu[NQ], ec[NQ], lt[NQ], zz[NQ]; };
     const SysArgs& p; const Stage& st;
     f32x4 gg, bb, pev[NQ];
@@ -807,53 +900,69 @@ struct TailRole {
             pev[i] = ld4(p.pe + (size_t)t_t[i] * D + c);
         }
     }
-    // local step 0: the first network input from the latents the prologue left (plain memory of earlier kernels)
-    __device__ __forceinline__ void prime() {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
-        for (int b = st.slice; b < p.NB; b += NTAIL) {
-            const unsigned base = (unsigned)b * RT * 1024;
-            for (int q = wave; q < RT; q += 4) {
-                f32x4 xn = {0.f, 0.f, 0.f, 0.f};
-                const int sb = q / T, t = q - sb * T, br = sb / P, prompt = b * P + (sb - br * P);
-                if (br < 2 && prompt < p.B) {
-                    const f32x4 l = ld4(p.lat + ((size_t)prompt * T + t) * D + c), pe = ld4(p.pe + (size_t)t * D + c);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) xn[i] = l[i] + pe[i];
-                }
-                st_sc1(rout, base + q * 1024 + c * 4, xn);
-            }
-            publish(flag_of(p, st.out_group, b, st.out_slot), 1);
+    __device__ __forceinline__ int blk_u(int u) const { return p.split ? 2 * u : u; }
+    __device__ __forceinline__ int blk_c(int u) const { return p.split ? 2 * u + 1 : u; }
+    __device__ __forceinline__ int row_u(int pl, int t) const { return pl * T + t; }
+    __device__ __forceinline__ int row_c(int pl, int t) const { return (p.split ? pl : P + pl) * T + t; }
+    __device__ __forceinline__ void publish_unit(int u, unsigned epoch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store((gu32*)flag_of(p, st.out_group, blk_u(u), st.out_slot), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.split)
+                __hip_atomic_store((gu32*)flag_of(p, st.out_group, blk_c(u), st.out_slot), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    __device__ __forceinline__ void issue(int s, int b, Pay& y) {
+    // local step 0: the first network input from the latents the prologue left (plain memory of earlier kernels); every row
+    // of the blocks is written (rows of absent prompts and the tile's padding rows: zero)
+    __device__ __forceinline__ void prime(int nu) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
-        const unsigned base = (unsigned)b * RT * 1024;
+        const int nsb = blk_nsb(p);
+        for (int u = st.slice; u < nu; u += NTAIL) {
+            for (int half = 0; half < (p.split ? 2 : 1); ++half) {
+                const int b = p.split ? 2 * u + half : u;
+                const unsigned base = (unsigned)b * RT * 1024;
+                for (int q = wave; q < RT; q += 4) {
+                    f32x4 xn = {0.f, 0.f, 0.f, 0.f};
+                    const int sb = q / T, t = q - sb * T, pl = p.split ? sb : sb % P, prompt = u * P + pl;
+                    if (sb < nsb && prompt < p.B) {
+                        const f32x4 l = ld4(p.lat + ((size_t)prompt * T + t) * D + c), pe = ld4(p.pe + (size_t)t * D + c);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) xn[i] = l[i] + pe[i];
+                    }
+                    st_sc1(rout, base + q * 1024 + c * 4, xn);
+                }
+            }
+            publish_unit(u, 1);
+        }
+    }
+    __device__ __forceinline__ void issue(int s, int u, Pay& y) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
+        const unsigned bu = (unsigned)blk_u(u) * RT * 1024, bc = (unsigned)blk_c(u) * RT * 1024;
         const int step = p.step_lo + s;
         const float kn = p.coef[(size_t)step * LADIFF_COEF_STRIDE + 5];
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            const int q = wave + 4 * i, prompt = b * P + t_pl[i];
+            const int q = wave + 4 * i, prompt = u * P + t_pl[i];
             y.zz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (q < P * T && prompt < p.B) {
                 const size_t lrow = (size_t)prompt * T + t_t[i];
-                y.eu[i] = ld_sc1(rin, base + (t_pl[i] * T + t_t[i]) * 1024 + c * 4);
-                y.ec[i] = ld_sc1(rin, base + ((P + t_pl[i]) * T + t_t[i]) * 1024 + c * 4);
+                y.eu[i] = ld_sc1(rin, bu + row_u(t_pl[i], t_t[i]) * 1024 + c * 4);
+                y.ec[i] = ld_sc1(rin, bc + row_c(t_pl[i], t_t[i]) * 1024 + c * 4);
                 y.lt[i] = ld4(p.lat + lrow * D + c);
                 if (p.noise != nullptr && kn != 0.f) y.zz[i] = ld4(p.noise + ((size_t)step * p.B * T + lrow) * D + c);
             }
         }
     }
-    __device__ __forceinline__ void commit(const Pay&) {}
-    __device__ __forceinline__ void compute(int s, int b, Pay& y) {
+    __device__ __forceinline__ void compute(int s, int u, Pay& y) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
-        const unsigned base = (unsigned)b * RT * 1024;
+        const unsigned bu = (unsigned)blk_u(u) * RT * 1024, bc = (unsigned)blk_c(u) * RT * 1024;
         const float* cf = p.coef + (size_t)(p.step_lo + s) * LADIFF_COEF_STRIDE;
         const float sa = cf[0], sb = cf[1], kx0 = cf[2], kx = cf[3], ke = cf[4], kn = cf[5];
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            const int q = wave + 4 * i, prompt = b * P + t_pl[i];
+            const int q = wave + 4 * i, prompt = u * P + t_pl[i];
             if (q < P * T && prompt < p.B) {
-                const int ru = t_pl[i] * T + t_t[i], rc = (P + t_pl[i]) * T + t_t[i];
                 f32x4 eu = y.eu[i], ec = y.ec[i], l = y.lt[i], xn;
                 float mean, rstd;
                 row_stats4(eu, mean, rstd);
@@ -870,48 +979,73 @@ struct TailRole {
                     xn[k] = l[k] + pev[i][k];
                 }
                 st4(p.lat + ((size_t)prompt * T + t_t[i]) * D + c, l);
-                st_sc1(rout, base + ru * 1024 + c * 4, xn);            // after the last step nobody reads it
-                st_sc1(rout, base + rc * 1024 + c * 4, xn);
+                st_sc1(rout, bu + row_u(t_pl[i], t_t[i]) * 1024 + c * 4, xn);        // after the last step nobody reads it
+                st_sc1(rout, bc + row_c(t_pl[i], t_t[i]) * 1024 + c * 4, xn);
             }
         }
     }
 };
 
-// the tail's loop differs from stage_loop in two ways: its output of step s is the input of step s + 1 (epoch s + 2), and a
-// block's latents are read in `issue` and written in `compute` of the SAME block one step earlier - with NTAIL blocks in
-// between, so a prefetch never overtakes the update it depends on as long as a tail owns more than one block; with one block
-// it simply does not prefetch.
+// The tail's loop differs from stage_loop: its output of step s is the input of step s + 1 (epoch s + 2), it may wait on two
+// blocks, and a unit's latents are read in `issue` and written in `compute` of the SAME unit one step earlier - with other
+// units in between, so a prefetch never overtakes the update it depends on as long as a tail owns more than one unit; with
+// one unit it does not prefetch.
 template <int MR>
 __device__ __forceinline__ void tail_loop(const SysArgs& p, const Stage& st, TailRole<MR>& r, Ctl* ctl) {
     typename TailRole<MR>::Pay cur, nxt;
     bool have = false;
-    const int lane = threadIdx.x & 63, b0 = st.slice;
-    const bool may_prefetch = b0 + NTAIL < p.NB;
-    r.prime();
+    const int lane = threadIdx.x & 63, u0 = st.slice;
+    const int nu = p.split ? p.NB / 2 : p.NB;
+    const bool may_prefetch = u0 + NTAIL < nu;
+    const int nflag = p.split ? 2 * st.wait_n : st.wait_n;          // lanes < wait_n: block blk_u, the next wait_n: block blk_c
+    auto flag_ptr = [&](int u) {
+        const int b = lane < st.wait_n ? r.blk_u(u) : r.blk_c(u);
+        return (const gu32*)flag_of(p, st.wait_group, b, 0) + (lane < st.wait_n ? lane : lane - st.wait_n) * FLAG_STRIDE;
+    };
+    r.prime(nu);
     for (int s = 0; s < p.n_steps; ++s)
-        for (int b = b0; b < p.NB; b += NTAIL) {
-            SYS_STAMP(0);
+        for (int u = u0; u < nu; u += NTAIL) {
             if (!have) {
-                if (!wait_epoch(flag_of(p, st.wait_group, b, 0), st.wait_n, s + 1, p.status, ctl)) return;
-                r.issue(s, b, cur);
+                if (threadIdx.x < 64) {                                  // as wait_epoch, on the flags of the unit's blocks
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    int bad = 0;
+                    for (unsigned spins = 1;; ++spins) {
+                        unsigned v = 0xffffffffu;
+                        if (lane < nflag) v = __hip_atomic_load(flag_ptr(u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (__all(v >= (unsigned)(s + 1))) break;
+                        if ((spins & 31u) == 0u) {
+                            if (__hip_atomic_load((const gu32*)p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bad = 1; break; }
+                            if (__builtin_amdgcn_s_memrealtime() - t0 > TIMEOUT_TICKS) {
+                                if (lane == 0) {
+                                    __hip_atomic_store((gu32*)p.status + 1, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    __hip_atomic_store((gu32*)p.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                                bad = 1;
+                                break;
+                            }
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (lane == 0) ctl->abort = bad;
+                }
+                __syncthreads();
+                if (ctl->abort != 0) return;
+                r.issue(s, u, cur);
             }
-            SYS_STAMP(1);
-            int s2 = s, b2 = b + NTAIL;
-            if (b2 >= p.NB) { s2 = s + 1; b2 = b0; }
+            int s2 = s, u2 = u + NTAIL;
+            if (u2 >= nu) { s2 = s + 1; u2 = u0; }
             const bool has_next = may_prefetch && s2 < p.n_steps;
             unsigned fv = 0xffffffffu;
-            if (has_next && threadIdx.x < 64 && lane < st.wait_n)
-                fv = __hip_atomic_load((const gu32*)flag_of(p, st.wait_group, b2, 0) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (has_next && threadIdx.x < 64 && lane < nflag) fv = __hip_atomic_load(flag_ptr(u2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (threadIdx.x < 64) {
                 const int ok = has_next && __all(fv >= (unsigned)(s2 + 1));
                 if (lane == 0) ctl->ready = ok;
             }
             __syncthreads();
             have = ctl->ready != 0;
-            if (have) r.issue(s2, b2, nxt);
-            r.compute(s, b, cur);
-            SYS_STAMP(4);
-            publish(flag_of(p, st.out_group, b, st.out_slot), s + 2);
+            if (have) r.issue(s2, u2, nxt);
+            r.compute(s, u, cur);
+            r.publish_unit(u, s + 2);
             if (have) cur = nxt;
         }
 }
@@ -947,23 +1081,26 @@ namespace {
 struct SysLayout {
     size_t blk;                   // floats of one [NB][RT][256] buffer
     size_t off_stages, off_flags, off_status, off_xin0, off_xs, off_xo, off_att, off_x1, off_x2, off_pc, off_pe, total;
-    int nwg, NB, P;
+    int nwg, NB, P, split;
 };
 SysLayout sys_layout(int B, int T, int MR) {
     SysLayout L;
     const int RT = 16 * MR;
-    int P = RT / (2 * T);
+    // 16-row tiles: a block is ONE guidance branch of P prompts (P T <= 16 rows; the two branches of a prompt only meet in the
+    // tail), 32-row tiles: both branches of P prompts (2 P T <= 32)
+    L.split = MR == 1 ? 1 : 0;
+    int P = L.split ? RT / T : RT / (2 * T);
     if (P > g_sys_pcap) P = g_sys_pcap;
     if (P > 7) P = 7;             // the QKV stage parks (2P + 1) x 128 floats of extra K|V through 512 thread slots
     if (P < 1) P = 1;
     L.P = P;
-    L.NB = (B + P - 1) / P;
+    L.NB = (B + P - 1) / P * (L.split ? 2 : 1);
     L.nwg = NL * (4 + 1 + NSLICE + NRED + NSLICE + NRED) + 2 * NSKIP + NTAIL;
     L.blk = (size_t)L.NB * RT * D;
     size_t off = 0;
     auto take = [&](size_t floats) { const size_t o = off; off += (floats + 63) / 64 * 64; return o; };
     L.off_stages = take((size_t)256 * sizeof(Stage) / sizeof(float));
-    L.off_flags = take((size_t)NL * GROUPS_PER_LAYER * L.NB * FLAG_SLOTS);
+    L.off_flags = take((size_t)NL * GROUPS_PER_LAYER * L.NB * FLAG_SLOTS * FLAG_STRIDE);
     L.off_status = take(64);
     L.off_xin0 = take(L.blk);
     L.off_xs = take(NSKIP * L.blk);
@@ -1092,6 +1229,7 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     a.tables = tables; a.tkv = tkv; a.ctab = ctab; a.coef = coef; a.noise = noise; a.pe = W.query_pe; a.ng = W.norm.g; a.nb = W.norm.b;
     a.lat = lat; a.counts = counts; a.gscale = gscale; a.B = B; a.T = T; a.P = L.P; a.NB = L.NB; a.step_lo = step_lo; a.n_steps = n;
     a.n_ctab = n_ctab;
+    a.split = L.split;
     a.stamps = nullptr;
 #ifdef LADIFF_STAMPS
     a.stamps = g_sys_stamps;

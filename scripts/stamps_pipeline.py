@@ -19,7 +19,7 @@ pipe = bench.build_pipe(dev, B)
 pipe.precision = "bf16x3"; pipe.num_inference_timesteps = steps; pipe.loop = mode
 lens = [196] * B
 text, noise = syn.text_embeddings(B).to(dev), syn.init_noise(lens).to(dev)
-st = torch.zeros(256 * 4 * 4 * 8 + 256 * 4, dtype=torch.int64, device=dev)
+st = torch.zeros(256 * 4 * 4 * 8 + 256 * 4 + 256 * 4 * 8, dtype=torch.int64, device=dev)
 s = torch.cuda.Stream(device=dev)
 with torch.cuda.stream(s), torch.no_grad():
     pipe._diffusion_reverse(text, lens, init_noise=noise)
@@ -28,7 +28,8 @@ with torch.cuda.stream(s), torch.no_grad():
     pipe._diffusion_reverse(text, lens, init_noise=noise)
     torch.cuda.synchronize()
 print("status", pipe.loop_status())
-stats = st[256 * 4 * 4 * 8:].cpu().reshape(256, 4)
+stats = st[256 * 4 * 4 * 8:256 * 4 * 4 * 8 + 256 * 4].cpu().reshape(256, 4)
+mid = st[256 * 4 * 4 * 8 + 256 * 4:].cpu().reshape(256, 4, 8).double() * 0.01
 t = st[:256 * 4 * 4 * 8].reshape(256, 4, 4, 8).cpu().double() * 0.01          # 100 MHz ticks -> us
 names = []
 for l in range(9):
@@ -44,7 +45,7 @@ print(f"{'stage':12s} {'flag seen':>10s} {'operands':>10s} {'mfma done':>10s} {'
 for i, n in enumerate(names):
     r = t[i, step, blk]
     if r[1] == 0: continue
-    if any(k in n for k in ("QKV0", "OUT", "LIN0", "RED2.0", "FFN0", "STYL.0", "SKIP0", "TAIL0")):
+    if any(k in n for k in ("QKV0", "OUT", "LIN0", "RED2.0", "FFN0", "STYL.0", "SKIP0", "TAIL0")) or (len(sys.argv) > 4 and n.startswith(sys.argv[4])):
         f = lambda v: f"{v - t0:10.2f}" if v > 0 else f"{'-':>10s}"
         print(f"{n:12s} {f(r[1])} {f(r[2])} {f(r[3])} {f(r[4])} {f(r[5])}   {r[5] - r[1] if r[5] > 0 else r[4] - r[1]:6.2f}")
 lap = t[tail, step, blk, 4] - t0
@@ -60,3 +61,13 @@ for i, n in enumerate(names):
         agg[kind].append((float(stats[i, 0]) * 0.01 / steps, float(stats[i, 1]) / float(stats[i, 2])))
 for k, v in agg.items():
     print(f"  {k:6s} blocked {sum(a for a, _ in v) / len(v):8.1f} us/step (min {min(a for a, _ in v):8.1f})   prefetch hit rate {sum(h for _, h in v) / len(v):.2f}")
+
+print("steady state (mid-run, four consecutive blocks): us since the first block's loop top; stamps 0 top, 1 operands issued, 2 committed, 3 mfma, 6/7 (QKV: tile in LDS / scores), 4 stored, 5 published-or-deferred")
+for i, n in enumerate(names):
+    if n in ("L4 QKV0", "L4 OUT", "L4 LIN0", "L4 RED2.0", "L4 FFN0", "L4 STYL.0"):
+        m = mid[i]
+        if m[0, 0] == 0: continue
+        t00 = m[0, 0]
+        for k in range(4):
+            order = [0, 1, 2, 3, 6, 7, 4, 5]
+            print(f"  {n:10s} block+{k}: " + " ".join(f"{j}:{m[k, j] - t00:7.2f}" if m[k, j] > 0 else f"{j}:      -" for j in order))
