@@ -43,7 +43,7 @@ enum {
 enum { LADIFF_ACT_NONE = 0, LADIFF_ACT_RELU = 1, LADIFF_ACT_GELU = 2, LADIFF_ACT_SILU = 3, LADIFF_ACT_QGELU = 4 /* x*sigmoid(1.702x) */,
        LADIFF_ACT_LRELU = 5 /* LeakyReLU(0.2) */ };
 
-#define LADIFF_ABI_VERSION 1
+#define LADIFF_ABI_VERSION 2
 #define LADIFF_LATENT_DIM 256     /* model.latent_dim[-1], config_ladiff_humanml3d.yaml:132 */
 #define LADIFF_NUM_HEADS 4        /* configs/modules/denoiser.yaml:7 */
 #define LADIFF_NUM_LAYERS 9       /* configs/modules/denoiser.yaml:6, motion_vae.yaml:5 */
@@ -134,8 +134,13 @@ int ladiff_decoder_cross_attention(const float* q, const float* kv, const int32_
  *                vector that depends on (step, layer, sample) only (ladiff_denoiser.py:193-198).  It is built
  *                from the time tables, so call ladiff_denoiser_time_tables first.                             */
 size_t ladiff_denoiser_tables_floats(int n_steps);
-size_t ladiff_denoiser_text_cache_floats(int B2, int n_steps);
-size_t ladiff_denoiser_workspace_bytes(int B2, int T, int n_steps);
+/* n_text = text tokens per prompt.  1 (the CLIP pooled token, mld_clip.py:75-78) is the hoisted form above.  n_text > 1
+ * (`clip_hidden` / `bert`, mld_clip.py:80-86) is the literal path in fp32 arithmetic (w_split must be NULL): the text
+ * cache then holds emb_proj of every token, their per-layer K|V for the self-attention over [latents | text | time], and
+ * per (layer, sample, head) the 64x64 matrix sum_n softmax_n(key) value^T of LinearTemporalCrossAttention
+ * (mdiff_transformer.py:235-239), which depends on the text only. */
+size_t ladiff_denoiser_text_cache_floats(int B2, int n_steps, int n_text);
+size_t ladiff_denoiser_workspace_bytes(int B2, int T, int n_steps, int n_text);
 
 /* sinusoid[n_steps,768] = Timesteps(768, flip_sin_to_cos, freq_shift 0)(t) for every step of the schedule
  * (tools/embeddings.py:245-285).  It is a t-only table like the scheduler coefficients; the host may fill it
@@ -143,7 +148,7 @@ size_t ladiff_denoiser_workspace_bytes(int B2, int T, int n_steps);
 int ladiff_timestep_sinusoid(const int64_t* timesteps, int n_steps, float* sinusoid, ladiff_stream_t stream);
 int ladiff_denoiser_time_tables(const float* const* w, const float* sinusoid, int n_steps,
                                 float* tables, void* ws, size_t ws_bytes, ladiff_stream_t stream);
-int ladiff_denoiser_text_cache(const float* const* w, const float* text_emb /*[B2,1,768]*/, int B2,
+int ladiff_denoiser_text_cache(const float* const* w, const float* text_emb /*[B2,n_text,768]*/, int B2, int n_text,
                                const float* tables, int n_steps, float* cache, void* ws, size_t ws_bytes,
                                ladiff_stream_t stream);
 
@@ -154,9 +159,19 @@ int ladiff_denoiser_text_cache(const float* const* w, const float* text_emb /*[B
  * it is a second pointer table in the same order as w whose >= 2-D entries are the S-format copies of the weight
  * matrices (ladiff_split_rows), the other entries are ignored. */
 int ladiff_denoiser_forward(const float* const* w, const float* const* w_split, const float* tables,
-                            const int32_t* d_step, const float* text_cache, int n_steps, const float* sample /*[Bs,T,256]*/, int Bs,
-                            int dup, int T, const int32_t* counts, float* eps, void* ws, size_t ws_bytes,
-                            ladiff_stream_t stream);
+                            const int32_t* d_step, const float* text_cache, int n_text, int n_steps,
+                            const float* sample /*[Bs,T,256]*/, int Bs, int dup, int T, const int32_t* counts, float* eps, void* ws,
+                            size_t ws_bytes, ladiff_stream_t stream);
+
+/* One LinearTemporalCrossAttention block, literal (mdiff_transformer.py:219-247), for any number of text tokens:
+ *   out[B,T,256] = x + proj_out( softmax_d(query(LN x)) . sum_n softmax_n(key(LN_t xf)) value(LN_t xf)^T , emb )
+ * x [B,T,256], xf [B,n_text,256] (text tokens already in the latent width), emb [B,256] time embedding per sample,
+ * counts [B] valid latent rows (rows >= counts[b] have their query zeroed; NULL = none), `layer` = block index 0..8 in
+ * the order input_blocks, middle_block, output_blocks.  Unit entry point of the n_text > 1 path. */
+size_t ladiff_linear_cross_attention_workspace_bytes(int B, int T, int n_text);
+int ladiff_linear_cross_attention(const float* const* w, int layer, const float* x, const float* xf, const float* emb,
+                                  const int32_t* counts, int B, int T, int n_text, float* out, void* ws, size_t ws_bytes,
+                                  ladiff_stream_t stream);
 
 /* ------------------------------------------------------------------ guidance + scheduler step
  * latents <- step(eps_u + g (eps_c - eps_u)) with one row of coef per step:
@@ -201,15 +216,15 @@ int ladiff_sampler_set_loop(void* sampler, int mode);
 int ladiff_sampler_loop_ms(void* sampler, float* ms);
 /* Blocking read of the pipeline kernel's status word of the last call in this workspace: code 0 = completed,
  * 2 = a stage timed out waiting for its producer (info = workgroup).  Debug / test aid. */
-int ladiff_reverse_status(void* ws, int B, int T, int n_steps, int* code, int* info);
-size_t ladiff_reverse_workspace_bytes(int B, int T, int n_steps);
+int ladiff_reverse_status(void* ws, int B, int T, int n_steps, int n_text, int* code, int* info);
+size_t ladiff_reverse_workspace_bytes(int B, int T, int n_steps, int n_text);
 int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* const* w_split /*or NULL*/,
-                             uint64_t weights_generation, const float* text_emb /*[2B or B,1,768]*/,
+                             uint64_t weights_generation, const float* text_emb /*[2B or B,n_text,768]*/,
                              const float* init_noise /*[B,T,256]*/, const int32_t* counts /*[B] or NULL*/,
                              const int32_t* final_counts /*[B] or NULL*/,
                              const float* sinusoid /*[n,768]*/, const float* coef /*[n,8]*/,
                              const float* step_noise /*[n,B,T,256] or NULL*/, float guidance_scale,
-                             float init_noise_sigma, int cfg, int B, int T, int n_steps, float* z /*[T,B,256]*/,
+                             float init_noise_sigma, int cfg, int B, int T, int n_text, int n_steps, float* z /*[T,B,256]*/,
                              void* ws, size_t ws_bytes, int reuse_time_tables, ladiff_stream_t stream);
 
 /* ------------------------------------------------------------------ LA-VAE decoder (LADiffVae.decode)

@@ -46,12 +46,15 @@ _SIGNATURES = {
     "ladiff_self_attention_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ladiff_decoder_cross_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ladiff_denoiser_tables_floats": (c_size_t, [c_int]),
-    "ladiff_denoiser_text_cache_floats": (c_size_t, [c_int, c_int]),
-    "ladiff_denoiser_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ladiff_denoiser_text_cache_floats": (c_size_t, [c_int, c_int, c_int]),
+    "ladiff_denoiser_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "ladiff_linear_cross_attention_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ladiff_linear_cross_attention": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                              c_void_p, c_size_t, c_void_p]),
     "ladiff_denoiser_time_tables": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "ladiff_denoiser_text_cache": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
+    "ladiff_denoiser_text_cache": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
                                            c_void_p]),
-    "ladiff_denoiser_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+    "ladiff_denoiser_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
                                         c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ladiff_cfg_scheduler_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int,
                                           c_int, c_void_p]),
@@ -62,10 +65,10 @@ _SIGNATURES = {
     "ladiff_sampler_destroy": (c_int, [c_void_p]),
     "ladiff_sampler_set_loop": (c_int, [c_void_p, c_int]),
     "ladiff_sampler_loop_ms": (c_int, [c_void_p, ctypes.POINTER(c_float)]),
-    "ladiff_reverse_status": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
-    "ladiff_reverse_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ladiff_reverse_status": (c_int, [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "ladiff_reverse_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ladiff_diffusion_reverse": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p,
-                                         c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_int, c_int,
                                          c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "ladiff_encoder_num_params": (c_int, []),
     "ladiff_encoder_param_name": (c_char_p, [c_int]),

@@ -29,18 +29,18 @@ struct ReverseWs {
     int32_t* d_step;
     size_t fwd_floats, total_bytes;
 };
-ReverseWs carve_reverse(void* ws, int B, int T, int n) {
+ReverseWs carve_reverse(void* ws, int B, int T, int n, int ntxt = 1) {
     ReverseWs r;
     const int B2 = 2 * B;
     size_t off = 0;
     auto take = [&](size_t floats) { float* p = ws ? reinterpret_cast<float*>(ws) + off : nullptr; off += align_up(floats, 64); return p; };
     r.d_step = reinterpret_cast<int32_t*>(take(64));
     r.tables = take(den_tables_floats(n));
-    r.cache = take(den_text_cache_floats(B2, n));
+    r.cache = take(den_text_cache_floats(B2, n, ntxt));
     r.latents = take((size_t)B * T * D);
     r.eps = take((size_t)B2 * T * D);
     size_t pre = (size_t)n * D * 3;                                    // time-table scratch
-    const size_t txt = den_text_ws_floats(B2, n);                      // text-cache scratch
+    const size_t txt = den_text_ws_floats(B2, n, ntxt);                // text-cache scratch
     if (txt > pre) pre = txt;
     r.fwd_floats = den_forward_ws_floats(B2, T);
     if (pre > r.fwd_floats) r.fwd_floats = pre;
@@ -193,10 +193,10 @@ int ladiff_decoder_cross_attention(const float* q, const float* kv, const int32_
 
 // ------------------------------------------------------------------ denoiser
 size_t ladiff_denoiser_tables_floats(int n_steps) { return den_tables_floats(n_steps); }
-size_t ladiff_denoiser_text_cache_floats(int B2, int n_steps) { return den_text_cache_floats(B2, n_steps); }
-size_t ladiff_denoiser_workspace_bytes(int B2, int T, int n_steps) {
+size_t ladiff_denoiser_text_cache_floats(int B2, int n_steps, int n_text) { return den_text_cache_floats(B2, n_steps, n_text); }
+size_t ladiff_denoiser_workspace_bytes(int B2, int T, int n_steps, int n_text) {
     size_t f = den_forward_ws_floats(B2, T);
-    const size_t a = (size_t)n_steps * D * 3, b = den_text_ws_floats(B2, n_steps);
+    const size_t a = (size_t)n_steps * D * 3, b = den_text_ws_floats(B2, n_steps, n_text);
     if (a > f) f = a;
     if (b > f) f = b;
     return f * sizeof(float);
@@ -209,21 +209,33 @@ int ladiff_denoiser_time_tables(const float* const* w, const float* sinusoid, in
     return denoiser_time_tables(W, sinusoid, n_steps, tables, (float*)ws, ws_bytes / sizeof(float), S(stream));
 }
 
-int ladiff_denoiser_text_cache(const float* const* w, const float* text_emb, int B2, const float* tables, int n_steps,
+int ladiff_denoiser_text_cache(const float* const* w, const float* text_emb, int B2, int n_text, const float* tables, int n_steps,
                                float* cache, void* ws, size_t ws_bytes, ladiff_stream_t stream) {
     DenoiserW W;
-    LADIFF_CHECK_ARG(load_weights(W, w) && text_emb && tables && cache && ws && B2 > 0 && n_steps > 0);
-    return denoiser_text_cache(W, text_emb, B2, tables, n_steps, cache, (float*)ws, ws_bytes / sizeof(float), S(stream));
+    LADIFF_CHECK_ARG(load_weights(W, w) && text_emb && tables && cache && ws && B2 > 0 && n_steps > 0 && n_text >= 1);
+    return denoiser_text_cache(W, text_emb, B2, tables, n_steps, cache, (float*)ws, ws_bytes / sizeof(float), S(stream), n_text);
 }
 
 int ladiff_denoiser_forward(const float* const* w, const float* const* w_split, const float* tables, const int32_t* d_step,
-                            const float* text_cache, int n_steps, const float* sample, int Bs, int dup, int T,
+                            const float* text_cache, int n_text, int n_steps, const float* sample, int Bs, int dup, int T,
                             const int32_t* counts, float* eps, void* ws, size_t ws_bytes, ladiff_stream_t stream) {
     DenoiserW W, WS;
-    LADIFF_CHECK_ARG(load_weights(W, w) && tables && d_step && text_cache && sample && eps && ws && Bs > 0 && dup > 0 && n_steps > 0);
+    LADIFF_CHECK_ARG(load_weights(W, w) && tables && d_step && text_cache && sample && eps && ws && Bs > 0 && dup > 0 && n_steps > 0 &&
+                     n_text >= 1);
     if (w_split != nullptr) LADIFF_CHECK_ARG(load_weights(WS, w_split));
     return denoiser_forward(W, w_split ? &WS : nullptr, tables, d_step, text_cache, n_steps, sample, Bs, dup, T, counts, eps, (float*)ws,
-                            ws_bytes / sizeof(float), S(stream));
+                            ws_bytes / sizeof(float), S(stream), 0, -1, 0, n_text);
+}
+
+size_t ladiff_linear_cross_attention_workspace_bytes(int B, int T, int n_text) {
+    return linear_cross_attention_ws_floats(B, T, n_text) * sizeof(float);
+}
+int ladiff_linear_cross_attention(const float* const* w, int layer, const float* x, const float* xf, const float* emb,
+                                  const int32_t* counts, int B, int T, int n_text, float* out, void* ws, size_t ws_bytes,
+                                  ladiff_stream_t stream) {
+    DenoiserW W;
+    LADIFF_CHECK_ARG(load_weights(W, w) && x && xf && emb && out && ws && B > 0);
+    return linear_cross_attention(W, layer, x, xf, emb, counts, B, T, n_text, out, (float*)ws, ws_bytes / sizeof(float), S(stream));
 }
 
 // ------------------------------------------------------------------ guidance + scheduler
@@ -282,10 +294,10 @@ int ladiff_sampler_loop_ms(void* sampler, float* ms) {
     return 0;
 }
 
-int ladiff_reverse_status(void* ws, int B, int T, int n_steps, int* code, int* info) {
+int ladiff_reverse_status(void* ws, int B, int T, int n_steps, int n_text, int* code, int* info) {
     LADIFF_CHECK_ARG(ws && code && B > 0 && n_steps > 0);
     if (T < 1 || T > LADIFF_MAX_LATENTS) return LADIFF_ERR_SHAPE;
-    const ReverseWs r = carve_reverse(ws, B, T, n_steps);
+    const ReverseWs r = carve_reverse(ws, B, T, n_steps, n_text);
     unsigned st[2] = {0u, 0u};
     LADIFF_HIP(hipMemcpy(st, r.sys + sys_status_offset_floats(B, T), sizeof(st), hipMemcpyDeviceToHost));   // synchronises
     *code = (int)st[0];
@@ -293,7 +305,7 @@ int ladiff_reverse_status(void* ws, int B, int T, int n_steps, int* code, int* i
     return 0;
 }
 
-size_t ladiff_reverse_workspace_bytes(int B, int T, int n_steps) { return carve_reverse(nullptr, B, T, n_steps).total_bytes; }
+size_t ladiff_reverse_workspace_bytes(int B, int T, int n_steps, int n_text) { return carve_reverse(nullptr, B, T, n_steps, n_text).total_bytes; }
 
 int ladiff_split_rows(const float* x, float* y, int R, int K, ladiff_stream_t stream) {
     LADIFF_CHECK_ARG(x && y && R >= 0 && K > 0);
@@ -305,14 +317,15 @@ int ladiff_split_rows(const float* x, float* y, int R, int K, ladiff_stream_t st
 int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* const* w_split, uint64_t weights_generation,
                              const float* text_emb, const float* init_noise, const int32_t* counts, const int32_t* final_counts,
                              const float* sinusoid, const float* coef, const float* step_noise, float guidance_scale,
-                             float init_noise_sigma, int cfg, int B, int T, int n_steps, float* z, void* ws, size_t ws_bytes,
+                             float init_noise_sigma, int cfg, int B, int T, int n_text, int n_steps, float* z, void* ws, size_t ws_bytes,
                              int reuse_time_tables, ladiff_stream_t stream) {
     DenoiserW W, WS;
     LADIFF_CHECK_ARG(load_weights(W, w) && text_emb && init_noise && sinusoid && coef && z && ws && B > 0 && n_steps > 0);
     if (w_split != nullptr) LADIFF_CHECK_ARG(load_weights(WS, w_split));
     const DenoiserW* WSp = w_split ? &WS : nullptr;
-    if (T < 1 || T > LADIFF_MAX_LATENTS) return LADIFF_ERR_SHAPE;
-    ReverseWs r = carve_reverse(ws, B, T, n_steps);
+    if (T < 1 || T > LADIFF_MAX_LATENTS || n_text < 1) return LADIFF_ERR_SHAPE;
+    if (n_text > 1 && WSp != nullptr) return LADIFF_ERR_UNSUPPORTED;   // more than one text token: fp32 arithmetic only
+    ReverseWs r = carve_reverse(ws, B, T, n_steps, n_text);
     if (ws_bytes < r.total_bytes) return LADIFF_ERR_WORKSPACE;
     hipStream_t s = S(stream);
     const int dup = cfg ? 2 : 1;          // guidance: the network sees cat([latents]*2) with text [uncond | cond]  ladiff.py:472-474
@@ -329,7 +342,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
     // and noise; with a sampler it is replayed as a graph so that the host does not pace the GPU through it.
     if (!reuse_time_tables) LADIFF_TRY(denoiser_time_tables(W, sinusoid, n_steps, r.tables, r.fwd, r.fwd_floats, s));
     auto prologue = [&](hipStream_t st) -> int {
-        LADIFF_TRY(denoiser_text_cache(W, text_emb, B2, r.tables, n_steps, r.cache, r.fwd, r.fwd_floats, st));
+        LADIFF_TRY(denoiser_text_cache(W, text_emb, B2, r.tables, n_steps, r.cache, r.fwd, r.fwd_floats, st, n_text));
         LADIFF_TRY(launch_init_latents(init_noise, counts, init_noise_sigma, r.latents, B, T, st));
         LADIFF_HIP(hipMemsetAsync(r.d_step, 0, 2 * sizeof(int32_t), st));      // [0] step index, [1] tail-kernel ticket
         // One step = the nine denoiser layers + ONE tail launch (final LayerNorm of the guidance branches, guidance,
@@ -339,17 +352,17 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
     };
     auto one_step = [&](hipStream_t st) -> int {
         LADIFF_TRY(denoiser_forward(W, WSp, r.tables, r.d_step, r.cache, n_steps, r.latents, B, dup, T, counts, r.eps, r.fwd,
-                                    r.fwd_floats, st, 0, B2, 1));
+                                    r.fwd_floats, st, 0, B2, 1, n_text));
         return launch_step_tail(xio, xios, W.norm.g, W.norm.b, r.latents, coef, r.d_step, step_noise, W.query_pe,
                                 guidance_scale, cfg, B, T, st);
     };
-    const bool pipeline = sp != nullptr && sp->loop == 1 && sys_supported(B, T, cfg, WSp != nullptr);
+    const bool pipeline = sp != nullptr && sp->loop == 1 && n_text == 1 && sys_supported(B, T, cfg, WSp != nullptr);
     if (sp == nullptr) {
         LADIFF_TRY(prologue(s));
         for (int i = 0; i < n_steps; ++i) LADIFF_TRY(one_step(s));
     } else {
         const void* kp[9] = {ws, counts, final_counts, coef, step_noise, stream, text_emb, init_noise, z};
-        const int ki[4] = {B, T, n_steps, cfg + 2 * (pipeline ? sp->loop_mode : 0)};
+        const int ki[4] = {B, T, n_steps, cfg + 2 * (pipeline ? sp->loop_mode : 0) + 16 * n_text};
         const float kf[2] = {guidance_scale, init_noise_sigma};
         uint64_t h = hash_ptrs(w, DEN_NPARAMS, 1469598103934665603ull);
         if (w_split) h = hash_ptrs(w_split, DEN_NPARAMS, h ^ 0x9e3779b97f4a7c15ull);

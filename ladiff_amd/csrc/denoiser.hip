@@ -115,15 +115,45 @@ int denoiser_time_tables(const DenoiserW& w, const float* sinus, int n, float* t
 //   c[step, layer, pad] = out( SiLU( beta    * (1 + scale) + shift ) )     for padded rows (LN(0) = beta)
 // which depends on (step, layer, sample) only - never on the latents - so it is computed once per call for every
 // step instead of 9 x n_steps times inside the loop.
-size_t den_text_cache_floats(int B2, int n) {
+// ntxt > 1 (general-N conditioning, linear_ca.hip): [B2 N,256] projected tokens, [9][B2 N,512] K|V of the text tokens,
+// [9][B2][4][64][64] the cross-attention's key^T value matrices (text only, so step-invariant) instead of the c table
+size_t den_text_cache_floats(int B2, int n, int ntxt) {
+    if (ntxt > 1) return (size_t)B2 * ntxt * D + (size_t)NL * B2 * ntxt * 2 * D + (size_t)NL * B2 * H * DH * DH;
     return (size_t)B2 * D + (size_t)NL * B2 * 2 * D + (size_t)NL * n * (B2 + 1) * D;
 }
-size_t den_text_ws_floats(int B2, int n) {
+size_t den_text_ws_floats(int B2, int n, int ntxt) {
+    if (ntxt > 1) return (size_t)B2 * ntxt * (TEXT_DIM + 3 * D);
     return (size_t)B2 * TEXT_DIM + (size_t)B2 * D + (size_t)B2 * D + (size_t)n * (B2 + 1) * D;
 }
 
+static int denoiser_text_cache_general(const DenoiserW& w, const float* text, int B2, int N, float* cache, float* ws, size_t ws_floats,
+                                       hipStream_t s) {
+    const int R = B2 * N;
+    if (ws_floats < den_text_ws_floats(B2, 1, N)) return LADIFF_ERR_WORKSPACE;
+    float* rl = ws;
+    float* tn = rl + (size_t)R * TEXT_DIM;
+    float* key = tn + (size_t)R * D;
+    float* val = key + (size_t)R * D;
+    float* tproj = cache;
+    float* tkv = cache + (size_t)R * D;
+    float* catt = tkv + (size_t)NL * R * 2 * D;
+    LADIFF_TRY(launch_relu(text, rl, (size_t)R * TEXT_DIM, s));
+    LADIFF_TRY(launch_gemm(lin(rl, TEXT_DIM, w.emb_proj, tproj, D, R, D, TEXT_DIM), s));          // ladiff_denoiser.py:198
+    for (int l = 0; l < NL; ++l) {
+        const DenLayerW& L = w.layer[l];
+        LinearW kvw{L.sa_attn.in_w + (size_t)D * D, L.sa_attn.in_b + D};
+        LADIFF_TRY(launch_gemm(lin(tproj, D, kvw, tkv + (size_t)l * R * 2 * D, 2 * D, R, 2 * D, D), s));
+        LADIFF_TRY(launch_layernorm(tproj, L.ca_text_norm.g, L.ca_text_norm.b, tn, R, s));            // mdiff_transformer.py:233
+        LADIFF_TRY(launch_gemm(lin(tn, D, L.ca_key, key, D, R, D, D), s));
+        LADIFF_TRY(launch_gemm(lin(tn, D, L.ca_value, val, D, R, D, D), s));                           // :237
+        LADIFF_TRY(launch_lca_kv(key, val, B2, N, catt + (size_t)l * B2 * H * DH * DH, s));            // :235, :239
+    }
+    return 0;
+}
+
 int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, const float* tables, int n, float* cache,
-                        float* ws, size_t ws_floats, hipStream_t s) {
+                        float* ws, size_t ws_floats, hipStream_t s, int ntxt) {
+    if (ntxt > 1) return denoiser_text_cache_general(w, text, B2, ntxt, cache, ws, ws_floats, s);
     if (ws_floats < den_text_ws_floats(B2, n)) return LADIFF_ERR_WORKSPACE;
     float* rl = ws;
     float* tn = rl + (size_t)B2 * TEXT_DIM;
@@ -148,6 +178,35 @@ int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, const flo
         LADIFF_TRY(launch_gemm(lin(u, D, L.ca_proj.out, ctab + (size_t)l * n * R * D, D, n * R, D, D), s));
     }
     return 0;
+}
+
+// ------------------------------------------------------------------ one ca_block, literal (unit entry for the N > 1 path)
+// out = x + StylizationBlock( softmax_d(query(LN x)) . sum_n softmax_n(key(LN_t xf)) value(LN_t xf)^T , emb )   :219-247
+size_t linear_cross_attention_ws_floats(int B, int T, int N) {
+    return (size_t)B * N * 3 * D + (size_t)B * H * DH * DH + (size_t)B * T * 2 * D + (size_t)B * 3 * D;
+}
+int linear_cross_attention(const DenoiserW& w, int layer, const float* x, const float* xf, const float* emb, const int32_t* counts,
+                           int B, int T, int N, float* out, float* ws, size_t ws_floats, hipStream_t s) {
+    if (layer < 0 || layer >= NL || T < 1 || T > LADIFF_MAX_LATENTS || N < 1) return LADIFF_ERR_SHAPE;
+    if (ws_floats < linear_cross_attention_ws_floats(B, T, N)) return LADIFF_ERR_WORKSPACE;
+    const DenLayerW& L = w.layer[layer];
+    const int R = B * N, M = B * T;
+    float* tn = ws; float* key = tn + (size_t)R * D; float* val = key + (size_t)R * D;
+    float* catt = val + (size_t)R * D;
+    float* xn = catt + (size_t)B * H * DH * DH; float* q = xn + (size_t)M * D;
+    float* semb = q + (size_t)M * D; float* mod = semb + (size_t)B * D;
+    LADIFF_TRY(launch_layernorm(xf, L.ca_text_norm.g, L.ca_text_norm.b, tn, R, s));
+    LADIFF_TRY(launch_gemm(lin(tn, D, L.ca_key, key, D, R, D, D), s));
+    LADIFF_TRY(launch_gemm(lin(tn, D, L.ca_value, val, D, R, D, D), s));
+    LADIFF_TRY(launch_lca_kv(key, val, B, N, catt, s));
+    LADIFF_TRY(launch_layernorm(x, L.ca_norm.g, L.ca_norm.b, xn, M, s));
+    LADIFF_TRY(launch_gemm(lin(xn, D, L.ca_query, q, D, M, D, D), s));
+    LADIFF_TRY(launch_silu(emb, semb, (size_t)B * D, s));                                             // emb_layers = SiLU, Linear  :141-144
+    LADIFF_TRY(launch_gemm(lin(semb, D, L.ca_proj.emb, mod, 2 * D, B, 2 * D, D), s));
+    LADIFF_TRY(launch_lca_apply(q, catt, counts, B, 0, B, T, mod, 0, 2 * D, nullptr, L.ca_proj.norm.g, L.ca_proj.norm.b, xn, s));
+    GemmArgs g = lin(xn, D, L.ca_proj.out, out, D, M, D, D);
+    g.res = x; g.ldres = D;
+    return launch_gemm(g, s);
 }
 
 // ------------------------------------------------------------------ forward
@@ -189,8 +248,9 @@ static KrArgs kr(const float* A, int lda, const float* W, const float* b, float*
 // fp32 for the residual / LayerNorm consumers, S-format for the MFMA), accumulation and everything else stay fp32.
 int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tables, const int32_t* d_step, const float* cache,
                      int n_steps, const float* sample, int Bs, int dup, int T, const int32_t* counts, float* eps, float* ws,
-                     size_t ws_floats, hipStream_t s, int b_lo, int b_n, int loop_mode) {
+                     size_t ws_floats, hipStream_t s, int b_lo, int b_n, int loop_mode, int ntxt) {
     const int B2 = Bs * dup;
+    if (ntxt > 1 && wsp != nullptr) return LADIFF_ERR_UNSUPPORTED;      // general-N conditioning is built in fp32 arithmetic only
     if (b_n < 0) { b_lo = 0; b_n = B2; }
     const int M = b_n * T;
     if (T < 1 || T > LADIFF_MAX_LATENTS || b_lo < 0 || b_lo + b_n > B2) return LADIFF_ERR_SHAPE;
@@ -209,8 +269,8 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tabl
     float* att = p; p += MD;
     float* hid = p; p += (size_t)M * FF;
     float* part = p;                                  // split-K partial planes [4][M][256]
-    const float* tkv = cache + (size_t)B2 * D;
-    const float* ctab = tkv + (size_t)NL * B2 * 2 * D;
+    const float* tkv = cache + (size_t)B2 * ntxt * D;
+    const float* ctab = tkv + (size_t)NL * B2 * ntxt * 2 * D;          // ntxt > 1: the [9][B2][4][64][64] key^T value matrices
     const int R = B2 + 1;
     // operand view of a tensor: its S-format twin in the bf16x3 path, the fp32 tensor otherwise
     auto gemm = [&](KrArgs g) { g.split = sp ? 1 : 0; return launch_gemm_kr(g, s); };
@@ -246,8 +306,12 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tabl
                                             DEN_OFF_TIME_KV, DEN_STEP_STRIDE, d_step, counts, Bs, b_lo, b_n, T, att, s));
         } else {
             LADIFF_TRY(gemm(kr(cur, D, Ls.sa_attn.in_w, L.sa_attn.in_b, qkv, 3 * D, M, 3 * D, D)));
-            LADIFF_TRY(launch_denoiser_self_attention(qkv, tkv + (size_t)l * B2 * 2 * D, tl, DEN_OFF_TIME_KV, DEN_STEP_STRIDE,
-                                                      d_step, counts, Bs, b_lo, b_n, T, att, 0, s));
+            if (ntxt > 1)
+                LADIFF_TRY(launch_denoiser_self_attention_general(qkv, tkv + (size_t)l * B2 * ntxt * 2 * D, ntxt, tl, DEN_OFF_TIME_KV,
+                                                                  DEN_STEP_STRIDE, d_step, counts, Bs, b_lo, b_n, T, att, s));
+            else
+                LADIFF_TRY(launch_denoiser_self_attention(qkv, tkv + (size_t)l * B2 * 2 * D, tl, DEN_OFF_TIME_KV, DEN_STEP_STRIDE,
+                                                          d_step, counts, Bs, b_lo, b_n, T, att, 0, s));
         }
         if (sp) {   // X1 = LN1(x + out_proj(att)) -> P[2] / Ps[2], one launch (gemm_rowln.hip)
             RowLnArgs g;
@@ -271,11 +335,27 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tabl
         }
         // X3 = LN2(X1 + linear2(hid)) + c[step, layer, sample] -> P[1]
         LADIFF_TRY(gemm(kr(hid, FF, Ls.sa_lin2.w, nullptr, part, D, M, D, FF)));
-        LADIFF_TRY(launch_reduce_rows(part, 4, M, L.sa_lin2.b, P[2], RED_LN_ADD, L.sa_norm2.g, L.sa_norm2.b,
-                                      ctab + (size_t)l * n_steps * R * D, R * D, d_step, counts, Bs, T, B2, b_lo, P[1], Ps[1], s));
+        const float* x3 = P[1];
+        if (ntxt > 1) {
+            // literal LinearTemporalCrossAttention (mdiff_transformer.py:219-247): X2 = LN2(..) -> P[1]; q = query(LN(X2));
+            // u = SiLU(AdaLN(LN(softmax_d(q) . att_b)));  X3 = X2 + out(u) -> first M x 256 of the qkv buffer
+            LADIFF_TRY(launch_reduce_rows(part, 4, M, L.sa_lin2.b, P[2], RED_LN, L.sa_norm2.g, L.sa_norm2.b, nullptr, 0, nullptr,
+                                          nullptr, 1, 1, 0, 0, P[1], nullptr, s));
+            LADIFF_TRY(launch_layernorm(P[1], L.ca_norm.g, L.ca_norm.b, P[2], M, s));
+            LADIFF_TRY(gemm(kr(P[2], D, L.ca_query.w, L.ca_query.b, att, D, M, D, D)));
+            LADIFF_TRY(launch_lca_apply(att, ctab + (size_t)l * B2 * H * DH * DH, counts, Bs, b_lo, b_n, T, tl + DEN_OFF_CA_MOD,
+                                        DEN_STEP_STRIDE, 0, d_step, L.ca_proj.norm.g, L.ca_proj.norm.b, P[2], s));
+            KrArgs g = kr(P[2], D, L.ca_proj.out.w, L.ca_proj.out.b, qkv, D, M, D, D);
+            g.res = P[1]; g.ldres = D;
+            LADIFF_TRY(gemm(g));
+            x3 = qkv;
+        } else {
+            LADIFF_TRY(launch_reduce_rows(part, 4, M, L.sa_lin2.b, P[2], RED_LN_ADD, L.sa_norm2.g, L.sa_norm2.b,
+                                          ctab + (size_t)l * n_steps * R * D, R * D, d_step, counts, Bs, T, B2, b_lo, P[1], Ps[1], s));
+        }
         // u = SiLU(AdaLN(ffn.linear2(gelu(ffn.linear1(X3))))) -> P[2]
         {
-            KrArgs g = kr(sp ? Ps[1] : P[1], D, Ls.ffn1.w, L.ffn1.b, sp ? nullptr : hid, FF, M, FF, D, ACT_GELU);
+            KrArgs g = kr(sp ? Ps[1] : x3, D, Ls.ffn1.w, L.ffn1.b, sp ? nullptr : hid, FF, M, FF, D, ACT_GELU);
             if (sp) g.Ys = hid;
             LADIFF_TRY(gemm(g));
         }
@@ -294,7 +374,7 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tabl
                                           tl + DEN_OFF_FFN_MOD, DEN_STEP_STRIDE, d_step, nullptr, 1, 1, 0, 0, P[2], nullptr, s));
             // x' = X3 + out_layers(u)
             KrArgs g = kr(P[2], D, Ls.ffn_proj.out.w, L.ffn_proj.out.b, dst, D, M, D, D);
-            g.res = P[1]; g.ldres = D; g.Ys = dsts;
+            g.res = x3; g.ldres = D; g.Ys = dsts;
             LADIFF_TRY(gemm(g));
         }
         cur = dst; curs = dsts;

@@ -32,6 +32,15 @@ int launch_encoder_assemble(const float* token, const float* emb, const float* p
 int launch_encoder_finalize(const float* out, const float* eps, const int32_t* counts, int B, int T, int S, float* mu, float* sd,
                             float* latent, hipStream_t s);
 
+// linear_ca.hip: text conditioning with more than one text token per prompt
+int launch_lca_kv(const float* key, const float* value, int B, int N, float* att, hipStream_t s);
+int launch_lca_apply(const float* q, const float* att, const int32_t* counts, int Bs, int b_off, int b_n, int T, const float* mod,
+                     int step_stride, int sample_stride, const int32_t* d_step, const float* g, const float* be, float* u,
+                     hipStream_t s);
+int launch_denoiser_self_attention_general(const float* qkv, const float* text_kv, int N, const float* tables, int kv_off,
+                                           int step_stride, const int32_t* d_step, const int32_t* counts, int Bs, int b_off,
+                                           int b_n, int T, float* out, hipStream_t s);
+
 // feats2joints.hip
 int launch_feats2joints(const float* feats, const float* mean, const float* stdv, int B, int F, int C, int J, float* joints,
                         hipStream_t s);

@@ -15,15 +15,18 @@ constexpr int DEN_LAYER_STRIDE = 6 * D;
 constexpr int DEN_STEP_STRIDE = NL * DEN_LAYER_STRIDE;
 
 size_t den_tables_floats(int n_steps);
-size_t den_text_cache_floats(int B2, int n_steps);
-size_t den_text_ws_floats(int B2, int n_steps);
+size_t den_text_cache_floats(int B2, int n_steps, int ntxt = 1);
+size_t den_text_ws_floats(int B2, int n_steps, int ntxt = 1);
 size_t den_forward_ws_floats(int B2, int T);
 int denoiser_time_tables(const DenoiserW& w, const float* sinus, int n, float* tables, float* ws, size_t ws_floats, hipStream_t s);
 int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, const float* tables, int n_steps, float* cache,
-                        float* ws, size_t ws_floats, hipStream_t s);
+                        float* ws, size_t ws_floats, hipStream_t s, int ntxt = 1);
 int denoiser_forward(const DenoiserW& w, const DenoiserW* w_split, const float* tables, const int32_t* d_step,
                      const float* cache, int n_steps, const float* sample, int Bs, int dup, int T, const int32_t* counts, float* eps, float* ws,
-                     size_t ws_floats, hipStream_t s, int b_lo = 0, int b_n = -1, int loop_mode = 0);
+                     size_t ws_floats, hipStream_t s, int b_lo = 0, int b_n = -1, int loop_mode = 0, int ntxt = 1);
+int linear_cross_attention(const DenoiserW& w, int layer, const float* x, const float* xf, const float* emb, const int32_t* counts,
+                           int B, int T, int N, float* out, float* ws, size_t ws_floats, hipStream_t s);
+size_t linear_cross_attention_ws_floats(int B, int T, int N);
 void den_loop_io(float* ws, int rows, float** x, float** xs);
 
 size_t dec_ws_floats(int B, int F, int T);

@@ -131,8 +131,10 @@ class LADiffDenoiser(_HipModule):
         """sample [B2,T,256], timestep 0-dim or [B2] (all equal), encoder_hidden_states [B2,1,768] -> (eps [B2,T,256],)"""
         if enclat is not None or enclat_future is not None:
             raise NotImplementedError("autoregressive conditioning (ARDIFF) is not built")
-        if encoder_hidden_states.shape[1] != 1:
-            raise NotImplementedError("only one text token per prompt is built (CLIP pooled output, mld_clip.py:75-78)")
+        n_text = int(encoder_hidden_states.shape[1])
+        if n_text > 1 and self.precision != "fp32":
+            raise NotImplementedError("more than one text token per prompt (clip_hidden / bert, mld_clip.py:80-86) runs in "
+                                      "fp32 arithmetic only: set precision='fp32'")
         L = _lib.lib()
         dev = sample.device
         B2, T, Dm = sample.shape
@@ -149,17 +151,17 @@ class LADiffDenoiser(_HipModule):
             counts = torch.as_tensor(max_iter_elements).to(device=dev, dtype=torch.int32).contiguous()
         sinus = timestep_sinusoid(t[:1].cpu(), self.text_encoded_dim).to(dev)
         tables = torch.empty(L.ladiff_denoiser_tables_floats(1), dtype=torch.float32, device=dev)
-        cache = torch.empty(L.ladiff_denoiser_text_cache_floats(B2, 1), dtype=torch.float32, device=dev)
-        wsb = L.ladiff_denoiser_workspace_bytes(B2, T, 1)
+        cache = torch.empty(L.ladiff_denoiser_text_cache_floats(B2, 1, n_text), dtype=torch.float32, device=dev)
+        wsb = L.ladiff_denoiser_workspace_bytes(B2, T, 1, n_text)
         ws = _lib.workspace(wsb, dev)
         step0 = torch.zeros(1, dtype=torch.int32, device=dev)
         eps = torch.empty_like(x)
         st = _lib.stream_ptr()
         _lib.check(L.ladiff_denoiser_time_tables(wt.array, _lib.ptr(sinus), 1, _lib.ptr(tables), _lib.ptr(ws), wsb, st))
-        _lib.check(L.ladiff_denoiser_text_cache(wt.array, _lib.ptr(text), B2, _lib.ptr(tables), 1, _lib.ptr(cache),
+        _lib.check(L.ladiff_denoiser_text_cache(wt.array, _lib.ptr(text), B2, n_text, _lib.ptr(tables), 1, _lib.ptr(cache),
                                                 _lib.ptr(ws), wsb, st))
         _lib.check(L.ladiff_denoiser_forward(wt.array, wt.split_array() if self.precision == "bf16x3" else None,
-                                             _lib.ptr(tables), step0.data_ptr(), _lib.ptr(cache), 1, _lib.ptr(x),
+                                             _lib.ptr(tables), step0.data_ptr(), _lib.ptr(cache), n_text, 1, _lib.ptr(x),
                                              B2, 1, T, None if counts is None else counts.data_ptr(), _lib.ptr(eps),
                                              _lib.ptr(ws), wsb, st))
         return (eps.to(sample.dtype),)

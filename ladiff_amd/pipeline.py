@@ -138,24 +138,24 @@ class LADIFF(nn.Module):
         except Exception:
             pass
 
-    def _get_plan(self, B, T, n_steps, eta, dev):
+    def _get_plan(self, B, T, n_steps, eta, dev, n_text=1):
         """Persistent device buffers + scheduler tables for one (B, T, schedule): hipGraph kernel nodes bake
         pointers in, and the per-step scalar tables are built once, not per call."""
         sch = self.scheduler
-        key = (B, T, n_steps, float(eta), str(dev), id(sch))
+        key = (B, T, n_steps, float(eta), str(dev), id(sch), n_text)
         if self._plan is not None and self._plan["key"] == key:
             return self._plan
         L = _lib.lib()
         sch.set_timesteps(n_steps)
         n_steps = len(sch.timesteps)
         need_noise = sch.needs_noise(eta)
-        wsb = L.ladiff_reverse_workspace_bytes(B, T, n_steps)
+        wsb = L.ladiff_reverse_workspace_bytes(B, T, n_steps, n_text)
         plan = {
             "key": key, "n": n_steps, "need_noise": need_noise,
             "timesteps": sch.timesteps.clone(),
             "coef": sch.coef_table(eta).to(dev),
             "sinus": timestep_sinusoid(sch.timesteps, 768).to(dev),
-            "text": torch.empty(2 * B, 1, 768, dtype=torch.float32, device=dev),
+            "text": torch.empty(2 * B, n_text, 768, dtype=torch.float32, device=dev), "n_text": n_text,
             "noise": torch.empty(B, T, 256, dtype=torch.float32, device=dev),
             "counts": torch.empty(B, dtype=torch.int32, device=dev),
             "step_noise": torch.empty(n_steps, B, T, 256, dtype=torch.float32, device=dev) if need_noise else None,
@@ -176,8 +176,9 @@ class LADIFF(nn.Module):
         dev = encoder_hidden_states.device
         if not encoder_hidden_states.is_cuda:
             raise _lib.LadiffHipError("_diffusion_reverse needs GPU tensors; there is no CPU fallback")
-        if encoder_hidden_states.shape[1] != 1:
-            raise NotImplementedError("the fused loop takes one text token per prompt (CLIP pooled output, mld_clip.py:75-78)")
+        n_text = int(encoder_hidden_states.shape[1])          # 1: CLIP pooled token; > 1: clip_hidden / bert (mld_clip.py:80-86)
+        if n_text > 1 and self.precision != "fp32":
+            raise NotImplementedError("more than one text token per prompt runs in fp32 arithmetic only: precision='fp32'")
         cfg = bool(self.do_classifier_free_guidance)        # ladiff.py:339-340, :472-490
         dup = 2 if cfg else 1
         B = encoder_hidden_states.shape[0] // dup
@@ -187,7 +188,7 @@ class LADIFF(nn.Module):
         sch = self.scheduler
         if encoder_hidden_states.shape[0] != dup * len(lengths):
             raise ValueError(f"{encoder_hidden_states.shape[0]} text rows for {len(lengths)} lengths (guidance: {cfg})")
-        plan = self._get_plan(B, T, self.num_inference_timesteps, self.eta, dev)
+        plan = self._get_plan(B, T, self.num_inference_timesteps, self.eta, dev, n_text)
         n, need_noise = plan["n"], plan["need_noise"]
         if self._stream is None or self._stream.device != dev:
             self._stream = torch.cuda.Stream(device=dev)
@@ -209,7 +210,7 @@ class LADIFF(nn.Module):
         if run is not cur:
             run.wait_stream(cur)
         with torch.cuda.stream(run):
-            plan["text"][:dup * B].copy_(encoder_hidden_states.reshape(dup * B, 1, 768))
+            plan["text"][:dup * B].copy_(encoder_hidden_states.reshape(dup * B, n_text, 768))
             plan["noise"].copy_(init_noise)
             plan["counts"].copy_(_lib.device_ints(counts, dev))       # device-to-device: the graph bakes plan["counts"] in
             if need_noise:
@@ -222,7 +223,7 @@ class LADIFF(nn.Module):
                 # ladiff_denoiser.py:254) - but the final zeroing of ladiff.py:559-566 has no such switch
                 None if self.test_efficiency else plan["counts"].data_ptr(), plan["counts"].data_ptr(),
                 _lib.ptr(plan["sinus"]), _lib.ptr(plan["coef"]), _lib.ptr(plan["step_noise"]) if need_noise else None,
-                self.guidance_scale, float(sch.init_noise_sigma), 1 if cfg else 0, B, T, n, _lib.ptr(plan["z"]),
+                self.guidance_scale, float(sch.init_noise_sigma), 1 if cfg else 0, B, T, n_text, n, _lib.ptr(plan["z"]),
                 _lib.ptr(plan["ws"]), plan["ws_bytes"], 1 if plan["tables_key"] == wt.key else 0, run.cuda_stream))
             plan["tables_key"] = wt.key
         if run is not cur:
@@ -245,7 +246,7 @@ class LADIFF(nn.Module):
         p = self._plan
         code, info = c_int(0), c_int(0)
         B, T = p["key"][0], p["key"][1]
-        _lib.check(_lib.lib().ladiff_reverse_status(_lib.ptr(p["ws"]), B, T, p["n"], byref(code), byref(info)))
+        _lib.check(_lib.lib().ladiff_reverse_status(_lib.ptr(p["ws"]), B, T, p["n"], p["n_text"], byref(code), byref(info)))
         return code.value, info.value
 
     # ------------------------------------------------------------------ callers' surface

@@ -32,7 +32,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_errors(lib):
-    assert lib.ladiff_version() == 1
+    assert lib.ladiff_version() == 2
     assert lib.ladiff_error_string(0) == b"ok"
     assert b"workspace" in lib.ladiff_error_string(-3)
 
@@ -73,8 +73,9 @@ def test_t2m_evaluator_tables_match_checkpoint_keys():
 
 def test_workspace_queries(lib):
     assert lib.ladiff_denoiser_tables_floats(50) == 50 * 9 * 1536
-    assert lib.ladiff_denoiser_text_cache_floats(256, 50) == 256 * 256 + 9 * 256 * 512 + 9 * 50 * 257 * 256
-    assert lib.ladiff_reverse_workspace_bytes(128, 5, 50) > 0
+    assert lib.ladiff_denoiser_text_cache_floats(256, 50, 1) == 256 * 256 + 9 * 256 * 512 + 9 * 50 * 257 * 256
+    assert lib.ladiff_denoiser_text_cache_floats(8, 50, 4) == 8 * 4 * 256 + 9 * 8 * 4 * 512 + 9 * 8 * 4 * 64 * 64
+    assert lib.ladiff_reverse_workspace_bytes(128, 5, 50, 1) > 0
     assert lib.ladiff_decoder_workspace_bytes(128, 196, 5, 263) >= 128 * 196 * 4096 * 4
 
 

@@ -521,3 +521,64 @@ def test_latentwise_gen_through_forward(denoiser, vae, mode):
     got = torch.stack([o.cpu() for o in out])
     assert maxdiff(got, want) < 1e-4
     assert maxdiff(got[0], got[4]) > 1e-3                   # the ablation really changes the motion
+
+
+# ---------------------------------------------------------------- more than one text token per prompt (A12, general N)
+def test_linear_cross_attention_general_n_golden(denoiser):
+    """LinearTemporalCrossAttention with N = 4 text tokens on the HIP path against the vector captured from the reference
+    (`tests/golden/cross_attention_n4.npz`: ca_block of input_blocks.0, masked latent rows)."""
+    g = load_golden("cross_attention_n4")
+    L = _lib.lib()
+    B, T, N = 3, 5, 4
+    wt = denoiser._weight_table()
+    x, xf, emb = g["x"].to(DEV).contiguous(), g["xf"].to(DEV).contiguous(), g["emb"].to(DEV).contiguous()
+    counts = (~g["pad"]).sum(1).to(torch.int32).to(DEV)               # the golden's masks are prefix masks
+    assert torch.equal(torch.arange(T)[None, :] >= counts.cpu()[:, None].long(), g["pad"])
+    out = torch.empty_like(x)
+    wsb = L.ladiff_linear_cross_attention_workspace_bytes(B, T, N)
+    ws = _lib.workspace(wsb, torch.device(DEV))
+    _lib.check(L.ladiff_linear_cross_attention(wt.array, 0, _lib.ptr(x), _lib.ptr(xf), _lib.ptr(emb), counts.data_ptr(), B, T, N,
+                                               _lib.ptr(out), _lib.ptr(ws), wsb, _lib.stream_ptr()))
+    assert maxdiff(out, g["out"]) < 2e-5
+    # N = 1 through the same literal kernels == the oracle (the shipped path uses the closed form instead)
+    sd = syn.denoiser_weights()
+    p = {k[len("encoder.middle_block.ca_block."):]: v for k, v in sd.items() if k.startswith("encoder.middle_block.ca_block.")}
+    want = orc.linear_cross_attention(g["x"], g["xf"][:, :1], g["emb"], p, g["pad"])
+    xf1 = g["xf"][:, :1].contiguous().to(DEV)
+    _lib.check(L.ladiff_linear_cross_attention(wt.array, 4, _lib.ptr(x), _lib.ptr(xf1), _lib.ptr(emb), counts.data_ptr(), B, T, 1,
+                                               _lib.ptr(out), _lib.ptr(ws), wsb, _lib.stream_ptr()))
+    assert maxdiff(out, want) < 2e-5
+
+
+@pytest.mark.parametrize("N", [4, 77])
+def test_denoiser_forward_many_text_tokens(denoiser, N):
+    """`clip_hidden` / `bert` conditioning (mld_clip.py:80-86): N text tokens per prompt enter the self-attention as N extra keys
+    and the linear cross-attention literally; fp32 arithmetic, against the CPU oracle."""
+    sd = syn.denoiser_weights()
+    gen = torch.Generator().manual_seed(700 + N)
+    B2, T = 6, 5
+    x = torch.randn(B2, T, 256, generator=gen)
+    txt = torch.randn(B2, N, 768, generator=gen)
+    counts = torch.tensor([5, 2, 3, 1, 5, 4])
+    want = orc.denoiser_forward(sd, x, 481, txt, counts)
+    got = denoiser(x.to(DEV), torch.tensor(481), txt.to(DEV), max_iter_elements=counts.to(DEV))[0]
+    assert maxdiff(got, want) < 5e-5
+    denoiser.precision = "bf16x3"
+    try:
+        with pytest.raises(NotImplementedError):
+            denoiser(x.to(DEV), torch.tensor(481), txt.to(DEV), max_iter_elements=counts.to(DEV))
+    finally:
+        denoiser.precision = "fp32"
+
+
+def test_sampling_loop_many_text_tokens(denoiser, vae):
+    """The fused loop with 4 text tokens per prompt (fp32 mode, hipGraph steps) against the CPU oracle."""
+    lens = [196, 60, 130]
+    gen = torch.Generator().manual_seed(77)
+    text = torch.randn(6, 4, 768, generator=gen)
+    noise = syn.init_noise(lens, seed=78)
+    pipe = make_pipe(denoiser, vae, "ddim", 10, precision="fp32")
+    z, feats = pipe.sample(text.to(DEV), lens, init_noise=noise.to(DEV))
+    z_o, f_o = orc.sample_motions(syn.denoiser_weights(), syn.vae_weights(263), text, lens, noise, 10, "ddim")
+    assert maxdiff(z, z_o) < 2e-5 * max(1.0, z_o.abs().max().item())
+    assert maxdiff(feats, f_o) < 1e-4
