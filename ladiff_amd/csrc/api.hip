@@ -25,10 +25,21 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---- reverse-loop workspace carve-up (floats)
 struct ReverseWs {
-    float *tables, *cache, *latents, *eps, *fwd, *sys;
+    float *tables, *cache, *latents, *eps, *fwd, *sys, *cws;
     int32_t* d_step;
-    size_t fwd_floats, total_bytes;
+    size_t fwd_floats, cws_floats, total_bytes;
+    int window;                            // steps whose c-table rows are resident at a time
 };
+// The hoisted cross-attention table is [9][steps][2B+1][256] floats: 118 MB for 50 steps at B = 128, but 2.4 GB for a
+// 1000-step DDPM schedule.  Long schedules are run window by window (the largest divisor of n_steps that is <= 64 and a
+// multiple of the graph unroll), the table rebuilt before each window from the per-layer LN(value) rows kept in the cache.
+int reverse_window(int n) {
+    if (n <= 64) return n;
+    int best = 0;
+    for (int w = 64; w >= 10; --w)
+        if (n % w == 0 && w % 10 == 0) { best = w; break; }
+    return best > 0 ? best : n;
+}
 ReverseWs carve_reverse(void* ws, int B, int T, int n, int ntxt = 1) {
     ReverseWs r;
     const int B2 = 2 * B;
@@ -36,16 +47,19 @@ ReverseWs carve_reverse(void* ws, int B, int T, int n, int ntxt = 1) {
     auto take = [&](size_t floats) { float* p = ws ? reinterpret_cast<float*>(ws) + off : nullptr; off += align_up(floats, 64); return p; };
     r.d_step = reinterpret_cast<int32_t*>(take(64));
     r.tables = take(den_tables_floats(n));
-    r.cache = take(den_text_cache_floats(B2, n, ntxt));
+    r.window = reverse_window(n);
+    r.cache = take(den_text_cache_floats(B2, r.window, ntxt));
     r.latents = take((size_t)B * T * D);
     r.eps = take((size_t)B2 * T * D);
     size_t pre = (size_t)n * D * 3;                                    // time-table scratch
-    const size_t txt = den_text_ws_floats(B2, n, ntxt);                // text-cache scratch
+    const size_t txt = den_text_ws_floats(B2, 1, ntxt);                // text-cache scratch (static part)
     if (txt > pre) pre = txt;
     r.fwd_floats = den_forward_ws_floats(B2, T);
     if (pre > r.fwd_floats) r.fwd_floats = pre;
     r.fwd = take(r.fwd_floats);
     r.sys = take(sys_ws_floats(B, T));                                 // block buffers, flags and stage table of the pipeline loop
+    r.cws_floats = (size_t)r.window * (B2 + 1) * D;                    // scratch of the c-table builder (one layer's rows)
+    r.cws = take(r.cws_floats);
     r.total_bytes = off * sizeof(float);
     return r;
 }
@@ -342,24 +356,34 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
     // and noise; with a sampler it is replayed as a graph so that the host does not pace the GPU through it.
     if (!reuse_time_tables) LADIFF_TRY(denoiser_time_tables(W, sinusoid, n_steps, r.tables, r.fwd, r.fwd_floats, s));
     auto prologue = [&](hipStream_t st) -> int {
-        LADIFF_TRY(denoiser_text_cache(W, text_emb, B2, r.tables, n_steps, r.cache, r.fwd, r.fwd_floats, st, n_text));
+        if (n_text > 1) LADIFF_TRY(denoiser_text_cache(W, text_emb, B2, r.tables, n_steps, r.cache, r.fwd, r.fwd_floats, st, n_text));
+        else LADIFF_TRY(denoiser_text_static(W, text_emb, B2, r.cache, r.fwd, r.fwd_floats, st));      // the c table: per window, below
         LADIFF_TRY(launch_init_latents(init_noise, counts, init_noise_sigma, r.latents, B, T, st));
-        LADIFF_HIP(hipMemsetAsync(r.d_step, 0, 2 * sizeof(int32_t), st));      // [0] step index, [1] tail-kernel ticket
+        LADIFF_HIP(hipMemsetAsync(r.d_step, 0, 4 * sizeof(int32_t), st));      // [0] step index, [1] tail-kernel ticket, [2] window base
         // One step = the nine denoiser layers + ONE tail launch (final LayerNorm of the guidance branches, guidance,
         // scheduler step, next step's network input, step counter).  The network input / last-layer output buffer of the
         // forward workspace is primed here.
         return launch_add_pe(r.latents, W.query_pe, B, 0, B2, T, xio, xios, st);
     };
     auto one_step = [&](hipStream_t st) -> int {
-        LADIFF_TRY(denoiser_forward(W, WSp, r.tables, r.d_step, r.cache, n_steps, r.latents, B, dup, T, counts, r.eps, r.fwd,
-                                    r.fwd_floats, st, 0, B2, 1, n_text));
+        LADIFF_TRY(denoiser_forward(W, WSp, r.tables, r.d_step, r.cache, r.window, r.latents, B, dup, T, counts, r.eps, r.fwd,
+                                    r.fwd_floats, st, 0, B2, 1, n_text, r.d_step + 2));
         return launch_step_tail(xio, xios, W.norm.g, W.norm.b, r.latents, coef, r.d_step, step_noise, W.query_pe,
                                 guidance_scale, cfg, B, T, st);
     };
     const bool pipeline = sp != nullptr && sp->loop == 1 && n_text == 1 && sys_supported(B, T, cfg, WSp != nullptr);
+    // c-table rows of the window that starts at step `lo` (plain launches, outside the graphs: `lo` changes per window)
+    auto open_window = [&](int lo) -> int {
+        if (n_text > 1) return 0;
+        LADIFF_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(r.d_step + 2), lo, 1, s));
+        return denoiser_ctab(W, r.tables + (size_t)lo * DEN_STEP_STRIDE, r.window, r.cache, B2, r.cws, r.cws_floats, s);
+    };
     if (sp == nullptr) {
         LADIFF_TRY(prologue(s));
-        for (int i = 0; i < n_steps; ++i) LADIFF_TRY(one_step(s));
+        for (int i = 0; i < n_steps; ++i) {
+            if (i % r.window == 0) LADIFF_TRY(open_window(i));
+            LADIFF_TRY(one_step(s));
+        }
     } else {
         const void* kp[9] = {ws, counts, final_counts, coef, step_noise, stream, text_emb, init_noise, z};
         const int ki[4] = {B, T, n_steps, cfg + 2 * (pipeline ? sp->loop_mode : 0) + 16 * n_text};
@@ -396,7 +420,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
                 LADIFF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
                 // several steps per graph launch (the step index lives in device memory): fewer ~9 us replay gaps
                 int unroll = 1;
-                for (int u = 2; u <= 10; ++u) if (n_steps % u == 0) unroll = u;
+                for (int u = 2; u <= 10; ++u) if (r.window % u == 0) unroll = u;
                 sp->unroll = unroll;
                 int rc = 0;
                 for (int u = 0; u < unroll && rc == 0; ++u) rc = one_step(s);
@@ -415,14 +439,15 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
         }
         LADIFF_HIP(hipGraphLaunch(sp->setup, s));
         if (sp->ev0 == nullptr) { LADIFF_HIP(hipEventCreate(&sp->ev0)); LADIFF_HIP(hipEventCreate(&sp->ev1)); }
-        LADIFF_HIP(hipEventRecord(sp->ev0, s));
-        if (pipeline) {
-            const float* tkv = r.cache + (size_t)B2 * D;
-            const float* ctab = tkv + (size_t)NL * B2 * 2 * D;
-            LADIFF_TRY(launch_systolic_loop(W, r.sys, r.tables, tkv, ctab, n_steps, coef, step_noise, r.latents, counts,
-                                            guidance_scale, B, T, 0, n_steps, s));
-        } else {
-            for (int i = 0; i < n_steps / sp->unroll; ++i) LADIFF_HIP(hipGraphLaunch(sp->exec, s));
+        for (int lo = 0; lo < n_steps; lo += r.window) {
+            LADIFF_TRY(open_window(lo));
+            if (lo == 0) LADIFF_HIP(hipEventRecord(sp->ev0, s));       // the loop itself: from the first step's first launch
+            if (pipeline) {
+                LADIFF_TRY(launch_systolic_loop(W, r.sys, r.tables, den_cache_tkv(r.cache, B2, 1), den_cache_ctab(r.cache, B2, 1), r.window,
+                                                coef, step_noise, r.latents, counts, guidance_scale, B, T, lo, r.window, s));
+            } else {
+                for (int i = 0; i < r.window / sp->unroll; ++i) LADIFF_HIP(hipGraphLaunch(sp->exec, s));
+            }
         }
         LADIFF_HIP(hipEventRecord(sp->ev1, s));
     }

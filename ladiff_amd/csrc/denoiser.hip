@@ -119,7 +119,7 @@ int denoiser_time_tables(const DenoiserW& w, const float* sinus, int n, float* t
 // [9][B2][4][64][64] the cross-attention's key^T value matrices (text only, so step-invariant) instead of the c table
 size_t den_text_cache_floats(int B2, int n, int ntxt) {
     if (ntxt > 1) return (size_t)B2 * ntxt * D + (size_t)NL * B2 * ntxt * 2 * D + (size_t)NL * B2 * H * DH * DH;
-    return (size_t)B2 * D + (size_t)NL * B2 * 2 * D + (size_t)NL * n * (B2 + 1) * D;
+    return (size_t)B2 * D + (size_t)NL * B2 * 2 * D + (size_t)NL * B2 * D + (size_t)NL * n * (B2 + 1) * D;
 }
 size_t den_text_ws_floats(int B2, int n, int ntxt) {
     if (ntxt > 1) return (size_t)B2 * ntxt * (TEXT_DIM + 3 * D);
@@ -151,18 +151,21 @@ static int denoiser_text_cache_general(const DenoiserW& w, const float* text, in
     return 0;
 }
 
-int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, const float* tables, int n, float* cache,
-                        float* ws, size_t ws_floats, hipStream_t s, int ntxt) {
-    if (ntxt > 1) return denoiser_text_cache_general(w, text, B2, ntxt, cache, ws, ws_floats, s);
-    if (ws_floats < den_text_ws_floats(B2, n)) return LADIFF_ERR_WORKSPACE;
+// cache layout, one text token: [B2,256] emb_proj | [9][B2,512] text K|V | [9][B2,256] LN(value) rows | [9][n][B2+1,256] c table
+const float* den_cache_tkv(const float* cache, int B2, int ntxt) { return cache + (size_t)B2 * ntxt * D; }
+const float* den_cache_ctab(const float* cache, int B2, int ntxt) {
+    const float* p = den_cache_tkv(cache, B2, ntxt) + (size_t)NL * B2 * ntxt * 2 * D;
+    return ntxt > 1 ? p : p + (size_t)NL * B2 * D;
+}
+
+// the part of the text cache that does not depend on the step: once per call
+int denoiser_text_static(const DenoiserW& w, const float* text, int B2, float* cache, float* ws, size_t ws_floats, hipStream_t s) {
+    if (ws_floats < (size_t)B2 * (TEXT_DIM + D)) return LADIFF_ERR_WORKSPACE;
     float* rl = ws;
     float* tn = rl + (size_t)B2 * TEXT_DIM;
-    float* nval = tn + (size_t)B2 * D;
-    float* u = nval + (size_t)B2 * D;
     float* tproj = cache;
     float* tkv = cache + (size_t)B2 * D;
-    float* ctab = tkv + (size_t)NL * B2 * 2 * D;
-    const int R = B2 + 1;
+    float* nval = tkv + (size_t)NL * B2 * 2 * D;
     LADIFF_TRY(launch_relu(text, rl, (size_t)B2 * TEXT_DIM, s));
     LADIFF_TRY(launch_gemm(lin(rl, TEXT_DIM, w.emb_proj, tproj, D, B2, D, TEXT_DIM), s));
     for (int l = 0; l < NL; ++l) {
@@ -170,14 +173,36 @@ int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, const flo
         LinearW kvw{L.sa_attn.in_w + (size_t)D * D, L.sa_attn.in_b + D};
         LADIFF_TRY(launch_gemm(lin(tproj, D, kvw, tkv + (size_t)l * B2 * 2 * D, 2 * D, B2, 2 * D, D), s));
         LADIFF_TRY(launch_layernorm(tproj, L.ca_text_norm.g, L.ca_text_norm.b, tn, B2, s));
-        GemmArgs g = lin(tn, D, L.ca_value, nval, D, B2, D, D);
+        GemmArgs g = lin(tn, D, L.ca_value, nval + (size_t)l * B2 * D, D, B2, D, D);
         g.ln_g = L.ca_proj.norm.g; g.ln_b = L.ca_proj.norm.b;
         LADIFF_TRY(launch_gemm(g, s));
-        LADIFF_TRY(launch_ca_table_input(nval, L.ca_proj.norm.b, tables + (size_t)l * DEN_LAYER_STRIDE + DEN_OFF_CA_MOD,
+    }
+    return 0;
+}
+
+// c table rows of `n` consecutive steps; `tables_lo` = the time tables at the first of them.  Sampling loops with many steps
+// build it one window at a time (ladiff_diffusion_reverse), so the table is O(window x B), not O(steps x B).
+int denoiser_ctab(const DenoiserW& w, const float* tables_lo, int n, float* cache, int B2, float* u, size_t u_floats, hipStream_t s) {
+    const int R = B2 + 1;
+    if (u_floats < (size_t)n * R * D) return LADIFF_ERR_WORKSPACE;
+    const float* nval = cache + (size_t)B2 * D + (size_t)NL * B2 * 2 * D;
+    float* ctab = const_cast<float*>(den_cache_ctab(cache, B2, 1));
+    for (int l = 0; l < NL; ++l) {
+        const DenLayerW& L = w.layer[l];
+        LADIFF_TRY(launch_ca_table_input(nval + (size_t)l * B2 * D, L.ca_proj.norm.b, tables_lo + (size_t)l * DEN_LAYER_STRIDE + DEN_OFF_CA_MOD,
                                          DEN_STEP_STRIDE, n, B2, u, s));
         LADIFF_TRY(launch_gemm(lin(u, D, L.ca_proj.out, ctab + (size_t)l * n * R * D, D, n * R, D, D), s));
     }
     return 0;
+}
+
+int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, const float* tables, int n, float* cache,
+                        float* ws, size_t ws_floats, hipStream_t s, int ntxt) {
+    if (ntxt > 1) return denoiser_text_cache_general(w, text, B2, ntxt, cache, ws, ws_floats, s);
+    if (ws_floats < den_text_ws_floats(B2, n)) return LADIFF_ERR_WORKSPACE;
+    LADIFF_TRY(denoiser_text_static(w, text, B2, cache, ws, ws_floats, s));
+    float* u = ws + (size_t)B2 * (TEXT_DIM + D);
+    return denoiser_ctab(w, tables, n, cache, B2, u, ws_floats - (size_t)B2 * (TEXT_DIM + D), s);
 }
 
 // ------------------------------------------------------------------ one ca_block, literal (unit entry for the N > 1 path)
@@ -248,7 +273,7 @@ static KrArgs kr(const float* A, int lda, const float* W, const float* b, float*
 // fp32 for the residual / LayerNorm consumers, S-format for the MFMA), accumulation and everything else stay fp32.
 int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tables, const int32_t* d_step, const float* cache,
                      int n_steps, const float* sample, int Bs, int dup, int T, const int32_t* counts, float* eps, float* ws,
-                     size_t ws_floats, hipStream_t s, int b_lo, int b_n, int loop_mode, int ntxt) {
+                     size_t ws_floats, hipStream_t s, int b_lo, int b_n, int loop_mode, int ntxt, const int32_t* d_base) {
     const int B2 = Bs * dup;
     if (ntxt > 1 && wsp != nullptr) return LADIFF_ERR_UNSUPPORTED;      // general-N conditioning is built in fp32 arithmetic only
     if (b_n < 0) { b_lo = 0; b_n = B2; }
@@ -269,8 +294,8 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tabl
     float* att = p; p += MD;
     float* hid = p; p += (size_t)M * FF;
     float* part = p;                                  // split-K partial planes [4][M][256]
-    const float* tkv = cache + (size_t)B2 * ntxt * D;
-    const float* ctab = tkv + (size_t)NL * B2 * ntxt * 2 * D;          // ntxt > 1: the [9][B2][4][64][64] key^T value matrices
+    const float* tkv = den_cache_tkv(cache, B2, ntxt);
+    const float* ctab = den_cache_ctab(cache, B2, ntxt);               // ntxt > 1: the [9][B2][4][64][64] key^T value matrices
     const int R = B2 + 1;
     // operand view of a tensor: its S-format twin in the bf16x3 path, the fp32 tensor otherwise
     auto gemm = [&](KrArgs g) { g.split = sp ? 1 : 0; return launch_gemm_kr(g, s); };
@@ -351,7 +376,7 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tabl
             x3 = qkv;
         } else {
             LADIFF_TRY(launch_reduce_rows(part, 4, M, L.sa_lin2.b, P[2], RED_LN_ADD, L.sa_norm2.g, L.sa_norm2.b,
-                                          ctab + (size_t)l * n_steps * R * D, R * D, d_step, counts, Bs, T, B2, b_lo, P[1], Ps[1], s));
+                                          ctab + (size_t)l * n_steps * R * D, R * D, d_step, counts, Bs, T, B2, b_lo, P[1], Ps[1], s, d_base));
         }
         // u = SiLU(AdaLN(ffn.linear2(gelu(ffn.linear1(X3))))) -> P[2]
         {

@@ -23,7 +23,13 @@ int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, const flo
                         float* ws, size_t ws_floats, hipStream_t s, int ntxt = 1);
 int denoiser_forward(const DenoiserW& w, const DenoiserW* w_split, const float* tables, const int32_t* d_step,
                      const float* cache, int n_steps, const float* sample, int Bs, int dup, int T, const int32_t* counts, float* eps, float* ws,
-                     size_t ws_floats, hipStream_t s, int b_lo = 0, int b_n = -1, int loop_mode = 0, int ntxt = 1);
+                     size_t ws_floats, hipStream_t s, int b_lo = 0, int b_n = -1, int loop_mode = 0, int ntxt = 1,
+                     const int32_t* d_base = nullptr);
+// n_steps = steps the c table inside `cache` covers; d_base (or NULL = 0) holds the step its first row belongs to
+const float* den_cache_tkv(const float* cache, int B2, int ntxt);
+const float* den_cache_ctab(const float* cache, int B2, int ntxt);
+int denoiser_text_static(const DenoiserW& w, const float* text, int B2, float* cache, float* ws, size_t ws_floats, hipStream_t s);
+int denoiser_ctab(const DenoiserW& w, const float* tables_lo, int n, float* cache, int B2, float* u, size_t u_floats, hipStream_t s);
 int linear_cross_attention(const DenoiserW& w, int layer, const float* x, const float* xf, const float* emb, const int32_t* counts,
                            int B, int T, int N, float* out, float* ws, size_t ws_floats, hipStream_t s);
 size_t linear_cross_attention_ws_floats(int B, int T, int N);

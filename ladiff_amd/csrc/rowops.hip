@@ -47,6 +47,7 @@ int launch_layernorm(const float* x, const float* g, const float* b, float* y, i
 struct RedArgs {
     const float* P; const float* bias; const float* res; const float* g; const float* b; const float* tab;
     const int32_t* d_step; const int32_t* counts; float* out; float* outs;
+    const int32_t* d_base;            // RED_LN_ADD: the table's first row belongs to step *d_base (windowed c table), NULL = 0
     size_t plane;
     int S, mode, tab_step_stride, Bs, T, pad_row, b_off, M;
 };
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const RedArgs p) {
     const float* const P = pin_s(p.P); const float* const bias = pin_s(p.bias); const float* const res = pin_s(p.res);
     const float* const g = pin_s(p.g); const float* const b = pin_s(p.b); const float* const tab = pin_s(p.tab);
     const int32_t* const d_step = pin_s(p.d_step); const int32_t* const counts = pin_s(p.counts);
+    const int32_t* const d_base = pin_s(p.d_base);
     float* const out = pin_s(p.out); float* const outs = pin_s(p.outs);
     const size_t plane = pin_s(p.plane);
     const int S = pin_s(p.S), mode = pin_s(p.mode), tab_step_stride = pin_s(p.tab_step_stride), Bs = pin_s(p.Bs),
@@ -76,7 +78,8 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const RedArgs p) {
     const f32x4 rs = res != nullptr ? ld4g(res + (size_t)row * D + c) : zero;
     f32x4 gg = zero, bb = zero;
     if (mode != RED_PLAIN) { gg = ld4g(g + c); bb = ld4g(b + c); }
-    const int step = d_step != nullptr ? *(const __attribute__((address_space(1))) int32_t*)d_step : 0;
+    int step = d_step != nullptr ? *(const __attribute__((address_space(1))) int32_t*)d_step : 0;
+    if (d_base != nullptr) step -= *(const __attribute__((address_space(1))) int32_t*)d_base;
     const int b2 = b_off + row / T, tt = row % T;
     int cnt = 0x7fffffff;
     if (mode == RED_LN_ADD && counts != nullptr) cnt = *(const __attribute__((address_space(1))) int32_t*)(counts + b2 % Bs);
@@ -108,12 +111,13 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const RedArgs p) {
 
 int launch_reduce_rows(const float* P, int S, int M, const float* bias, const float* res, int mode, const float* g,
                        const float* b, const float* tab, int tab_step_stride, const int32_t* d_step,
-                       const int32_t* counts, int Bs, int T, int pad_row, int b_off, float* out, float* outs, hipStream_t s) {
+                       const int32_t* counts, int Bs, int T, int pad_row, int b_off, float* out, float* outs, hipStream_t s,
+                       const int32_t* d_base) {
     if (S < 1 || S > 4) return LADIFF_ERR_SHAPE;       // split-K planes: K / 256 <= 4
     RedArgs a;
     a.P = P; a.bias = bias; a.res = res; a.g = g; a.b = b; a.tab = tab; a.d_step = d_step; a.counts = counts; a.out = out;
     a.outs = outs; a.plane = (size_t)M * D; a.S = S; a.mode = mode; a.tab_step_stride = tab_step_stride; a.Bs = Bs; a.T = T;
-    a.pad_row = pad_row; a.b_off = b_off; a.M = M;
+    a.pad_row = pad_row; a.b_off = b_off; a.M = M; a.d_base = d_base;
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, a);
     LADIFF_LAUNCH_CHECK();
     return 0;

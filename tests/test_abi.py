@@ -73,9 +73,11 @@ def test_t2m_evaluator_tables_match_checkpoint_keys():
 
 def test_workspace_queries(lib):
     assert lib.ladiff_denoiser_tables_floats(50) == 50 * 9 * 1536
-    assert lib.ladiff_denoiser_text_cache_floats(256, 50, 1) == 256 * 256 + 9 * 256 * 512 + 9 * 50 * 257 * 256
+    assert lib.ladiff_denoiser_text_cache_floats(256, 50, 1) == 256 * 256 + 9 * 256 * 512 + 9 * 256 * 256 + 9 * 50 * 257 * 256
     assert lib.ladiff_denoiser_text_cache_floats(8, 50, 4) == 8 * 4 * 256 + 9 * 8 * 4 * 512 + 9 * 8 * 4 * 64 * 64
     assert lib.ladiff_reverse_workspace_bytes(128, 5, 50, 1) > 0
+    # the c table is windowed: a 1000-step schedule needs about as much as a 50-step one, not 20x (2.4 GB at B = 128)
+    assert lib.ladiff_reverse_workspace_bytes(128, 5, 1000, 1) < 1.3 * lib.ladiff_reverse_workspace_bytes(128, 5, 50, 1)
     assert lib.ladiff_decoder_workspace_bytes(128, 196, 5, 263) >= 128 * 196 * 4096 * 4
 
 
