@@ -1,0 +1,168 @@
+// Decoder cross-attention block as a per-sample low-rank map (TransformerDecoderLayer.forward_post, cross_attention.py:373-376
+// + norm2, :409): tgt = LN2(tgt + out_proj(softmax(q k^T / 8) v)) with q = in_proj_q(tgt) and only T <= 8 memory tokens.
+//
+// With so few keys the two 256x256 projections around the attention are better folded INTO the keys and values:
+//   score[h,j] = (x Wq_h^T + bq_h) . k[b,j,h] / 8 = x . G[b,h,j] + c[b,h,j],      G[b,h,j] = Wq_h^T k[b,j,h] / 8   (256-vector)
+//   out        = sum_h sum_j p[h,j] (Wo[:, h] v[b,j,h]) + bo = sum_{h,j} p[h,j] U[b,h,j] + bo,   U[b,h,j] = Wo[:, h] v[b,j,h]
+// - exact algebra (a re-association of the reference's sums), fp32 throughout.  Per frame row that is 4 T dot products and
+// 4 T axpys of length 256 (20 kFLOP at T = 5) instead of two 256x256 projections (262 kFLOP), and the query / attention
+// output tensors ([B F, 256] each, written and re-read) never exist.  Before: q GEMM + cross-attention kernel + out GEMM +
+// LayerNorm kernel, 102 us per layer at B = 128, F = 196 (profiles/r2/03); now prep (per sample, 10 us) + apply.
+#include "kernels.h"
+
+namespace ladiff {
+
+namespace {
+constexpr int TM = LADIFF_MAX_LATENTS;
+}
+
+// one workgroup per (sample, head): G | U rows [T][2][256] of that head and the score offsets c [T] from the sample's K|V rows.
+// Wq rows h*64 .. are read coalesced over the output column; the Wo tile [256][64] goes through LDS (row stride 65: the
+// per-thread row walk is conflict-free).
+__global__ __launch_bounds__(256) void dec_cross_prep_kernel(const float* __restrict__ kv, const float* __restrict__ wq,
+                                                             const float* __restrict__ bq, const float* __restrict__ wo, int B, int T,
+                                                             float* __restrict__ gu, float* __restrict__ cc) {
+    __shared__ float wos[D * 65];
+    __shared__ float ks[TM * DH], vs[TM * DH];
+    const int b = blockIdx.x, h = blockIdx.y, n = threadIdx.x;
+    float qv[DH];                                                                  // Wq[h*64 + d][n]: all 64 loads in flight at once
+#pragma unroll
+    for (int d = 0; d < DH; ++d) qv[d] = wq[(size_t)(h * DH + d) * D + n];
+    for (int u = n; u < D * DH; u += 256) wos[(u >> 6) * 65 + (u & 63)] = wo[(size_t)(u >> 6) * D + h * DH + (u & 63)];
+    for (int u = n; u < T * DH; u += 256) {
+        const int j = u >> 6, d = u & 63;
+        ks[u] = kv[((size_t)j * B + b) * 2 * D + h * DH + d];
+        vs[u] = kv[((size_t)j * B + b) * 2 * D + D + h * DH + d];
+    }
+    __syncthreads();
+    float g[TM], u_[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) { g[j] = 0.f; u_[j] = 0.f; }
+#pragma unroll
+    for (int d = 0; d < DH; ++d) {
+        const float q = qv[d];
+        const float w = wos[n * 65 + d];                                           // Wo[n][h*64 + d]
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+            if (j < T) { g[j] = fmaf(q, ks[j * DH + d], g[j]); u_[j] = fmaf(w, vs[j * DH + d], u_[j]); }
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+        if (j < T) {
+            float* o = gu + ((((size_t)b * H + h) * T + j) * 2) * D;
+            o[n] = g[j] * 0.125f;                                                  // 1 / sqrt(64), exact
+            o[D + n] = u_[j];
+        }
+    if (n < T) {                                                                   // c[h][j] = bq_h . k[b,j,h] / 8
+        float c = 0.f;
+        for (int d = 0; d < DH; ++d) c = fmaf(bq[h * DH + d], ks[n * DH + d], c);
+        cc[((size_t)b * H + h) * T + n] = c * 0.125f;
+    }
+}
+
+// grid (B, chunks): the sample's G | U in LDS, one wave per frame row; TT = number of memory tokens (compile time, so the
+// TT score reductions of a head are independent chains the scheduler can interleave)
+template <int TT>
+__global__ __launch_bounds__(256) void dec_cross_apply_kernel(const float* __restrict__ x, const float* __restrict__ gu,
+                                                              const float* __restrict__ cc, const int32_t* __restrict__ counts,
+                                                              const float* __restrict__ bo, const float* __restrict__ g2,
+                                                              const float* __restrict__ b2, int F, int rows_per_wg,
+                                                              float* __restrict__ y, float* __restrict__ ys) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];                    // [H][TT][2][256], then c [H][TT]
+    constexpr int T = TT, HT = H * TT;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* src = gu + (size_t)b * HT * 2 * D;
+    for (int u = tid; u < HT * 2 * D / 4; u += 256) st4(sm + 4 * u, ld4(src + 4 * u));
+    float* cs = sm + (size_t)HT * 2 * D;
+    if (tid < HT) cs[tid] = cc[(size_t)b * HT + tid];
+    int nv = counts != nullptr ? counts[b] : T;
+    nv = nv > T ? T : nv;
+    __syncthreads();
+    const int c4 = 4 * lane;
+    const f32x4 bo4 = ld4(bo + c4), gg = ld4(g2 + c4), bb = ld4(b2 + c4);
+    const int f0 = blockIdx.y * rows_per_wg;
+    const int f1 = f0 + rows_per_wg < F ? f0 + rows_per_wg : F;
+    for (int f = f0 + wave; f < f1; f += 4) {
+        const size_t row = (size_t)b * F + f;
+        const f32x4 xv = ld4(x + row * D + c4);
+        f32x4 acc = {bo4[0] + xv[0], bo4[1] + xv[1], bo4[2] + xv[2], bo4[3] + xv[3]};      // out_proj bias + residual
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            float sc[T];
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const f32x4 g4 = ld4(sm + ((size_t)(h * T + j) * 2) * D + c4);
+                sc[j] = xv[0] * g4[0] + xv[1] * g4[1] + xv[2] * g4[2] + xv[3] * g4[3];
+            }
+#pragma unroll
+            for (int j = 0; j < T; ++j) sc[j] = wave_sum(sc[j]) + cs[h * T + j];
+            float m = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < T; ++j) { sc[j] = j < nv ? sc[j] : -INFINITY; m = fmaxf(m, sc[j]); }   // tokens >= count masked (:408-409)
+            float l = 0.f;
+#pragma unroll
+            for (int j = 0; j < T; ++j) { sc[j] = __builtin_amdgcn_exp2f((sc[j] - m) * 1.4426950408889634f); l += sc[j]; }
+            const float inv = 1.f / l;
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const float pj = sc[j] * inv;
+                const f32x4 u4 = ld4(sm + ((size_t)(h * T + j) * 2 + 1) * D + c4);
+                acc[0] = fmaf(pj, u4[0], acc[0]); acc[1] = fmaf(pj, u4[1], acc[1]);
+                acc[2] = fmaf(pj, u4[2], acc[2]); acc[3] = fmaf(pj, u4[3], acc[3]);
+            }
+        }
+        // norm2 over the row (two-pass, as rowops.hip)
+        const float mean = wave_sum(acc[0] + acc[1] + acc[2] + acc[3]) * (1.f / 256.f);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float dlt = acc[i] - mean; q += dlt * dlt; }
+        const float rstd = rsqrtf(wave_sum(q) * (1.f / 256.f) + LN_EPS);
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (acc[i] - mean) * rstd * gg[i] + bb[i];
+        st4(y + row * D + c4, o);
+        if (ys != nullptr) store_split4(ys + row * D, c4, o);
+    }
+}
+
+size_t dec_cross_ws_floats(int B, int T) { return (size_t)B * H * T * (2 * D + 1); }
+
+// y = LN2(x + cross_attention(x, kv)); gu_ws holds dec_cross_ws_floats(B, T) floats
+int launch_decoder_cross_block(const float* x, const float* kv, const float* wq, const float* bq, const float* wo, const float* bo,
+                               const float* g2, const float* b2, const int32_t* counts, int B, int F, int T, float* gu_ws, float* y,
+                               float* ys, hipStream_t s) {
+    if (B == 0 || F == 0) return 0;
+    if (T < 1 || T > TM) return LADIFF_ERR_SHAPE;
+    float* gu = gu_ws;
+    float* cc = gu_ws + (size_t)B * H * T * 2 * D;
+    hipLaunchKernelGGL(dec_cross_prep_kernel, dim3(B, H), dim3(256), 0, s, kv, wq, bq, wo, B, T, gu, cc);
+    LADIFF_LAUNCH_CHECK();
+    // enough workgroups to cover the chip twice; each re-loads the sample's 8 T KiB of G | U
+    int chunks = (512 + B - 1) / B;
+    if (chunks < 1) chunks = 1;
+    if (chunks > (F + 3) / 4) chunks = (F + 3) / 4;
+    const int rows_per_wg = ((F + chunks - 1) / chunks + 3) / 4 * 4;
+    chunks = (F + rows_per_wg - 1) / rows_per_wg;
+    const size_t lds = ((size_t)H * T * 2 * D + H * T) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {           // T = 8 needs 64.1 KiB of dynamic LDS
+        LADIFF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cross_apply_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(((size_t)H * TM * 2 * D + H * TM) * sizeof(float))));
+        attr_set = true;
+    }
+#define LADIFF_DC_CASE(TT)                                                                                                   \
+    case TT:                                                                                                                 \
+        hipLaunchKernelGGL(dec_cross_apply_kernel<TT>, dim3(B, chunks), dim3(256), lds, s, x, gu, cc, counts, bo, g2, b2, F, \
+                           rows_per_wg, y, ys);                                                                              \
+        break;
+    switch (T) {
+        LADIFF_DC_CASE(1) LADIFF_DC_CASE(2) LADIFF_DC_CASE(3) LADIFF_DC_CASE(4)
+        LADIFF_DC_CASE(5) LADIFF_DC_CASE(6) LADIFF_DC_CASE(7) LADIFF_DC_CASE(8)
+        default: return LADIFF_ERR_SHAPE;
+    }
+#undef LADIFF_DC_CASE
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace ladiff

@@ -14,7 +14,7 @@ static GemmArgs lin(const float* A, int lda, const float* W, const float* bias, 
 
 size_t dec_ws_floats(int B, int F, int T) {
     const size_t M = (size_t)B * F;
-    return M * (16 * D + 3 * D + D + FF) + (size_t)T * B * 2 * D;
+    return M * (16 * D + 3 * D + D + FF) + (size_t)T * B * 2 * D + dec_cross_ws_floats(B, T);
 }
 
 // wsp != nullptr selects the bf16x3 matrix path (S-format copies of the weight matrices in `wsp`, GEMM operands in
@@ -36,8 +36,8 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
     float* qkv = p; p += 3 * MD;
     float* att = p; p += MD;
     float* hid = p; p += (size_t)M * FF;
-    float* kv = p;
-    float* qb = qkv;   // cross-attention queries reuse the (dead) packed qkv buffer
+    float* kv = p; p += (size_t)T * B * 2 * D;
+    float* guws = p;   // G | U rows of the folded cross-attention (dec_cross.hip)
 
     // GEMM + (residual) + LayerNorm: fused epilogue in the fp32 path; GEMM(+residual) then a LayerNorm row kernel in the
     // bf16x3 path.  `A`/`As`: operand in fp32 / S-format; result (fp32 + S-format twin) goes to dst / dsts.
@@ -86,15 +86,11 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
         if (sp) LADIFF_TRY(launch_self_attention_bf16x3(qkv, lengths, nullptr, att, B, F, H, 0, 1, s));
         else LADIFF_TRY(launch_decoder_self_attention(qkv, lengths, nullptr, att, B, F, 0, s));
         LADIFF_TRY(gemm_ln(att, D, L.self_attn.out_w, Ls.self_attn.out_w, L.self_attn.out_b, cur, L.norm1, nullptr, P[1], Ps[1]));
-        // ---- cross-attention to the latent tokens, tokens >= ceil(len/48) masked   :373-376, :408-409
-        {
-            GemmArgs g = lin(sp ? Ps[1] : P[1], D, Ls.cross_attn.in_w, L.cross_attn.in_b, qb, D, M, D, D);
-            g.split = sp ? 1 : 0;
-            LADIFF_TRY(launch_gemm(g, s));
-        }
+        // ---- cross-attention to the latent tokens, tokens >= ceil(len/48) masked, + residual + norm2   :373-376, :408-409
+        // (the q / out projections are folded into the <= 8 keys / values per sample: dec_cross.hip; fp32 in both modes)
         LADIFF_TRY(launch_gemm(lin(z, D, L.cross_attn.in_w + (size_t)D * D, L.cross_attn.in_b + D, kv, 2 * D, T * B, 2 * D, D), s));
-        LADIFF_TRY(launch_decoder_cross_attention(qb, kv, counts, att, B, F, T, sp ? 1 : 0, s));
-        LADIFF_TRY(gemm_ln(att, D, L.cross_attn.out_w, Ls.cross_attn.out_w, L.cross_attn.out_b, P[1], L.norm2, nullptr, P[2], Ps[2]));
+        LADIFF_TRY(launch_decoder_cross_block(P[1], kv, L.cross_attn.in_w, L.cross_attn.in_b, L.cross_attn.out_w, L.cross_attn.out_b,
+                                              L.norm2.g, L.norm2.b, counts, B, F, T, guws, P[2], Ps[2], s));
         // ---- feed-forward, GELU(erf)   :410-412
         {
             GemmArgs g = lin(sp ? Ps[2] : P[2], D, Ls.lin1.w, L.lin1.b, sp ? nullptr : hid, FF, M, FF, D, ACT_GELU);

@@ -42,6 +42,13 @@ int launch_denoiser_self_attention_general(const float* qkv, const float* text_k
                                            int step_stride, const int32_t* d_step, const int32_t* counts, int Bs, int b_off,
                                            int b_n, int T, float* out, hipStream_t s);
 
+// dec_cross.hip: the decoder's cross-attention block (q projection, attention over <= 8 memory tokens, out projection,
+// residual, norm2) as a per-sample low-rank map
+size_t dec_cross_ws_floats(int B, int T);
+int launch_decoder_cross_block(const float* x, const float* kv, const float* wq, const float* bq, const float* wo, const float* bo,
+                               const float* g2, const float* b2, const int32_t* counts, int B, int F, int T, float* gu_ws, float* y,
+                               float* ys, hipStream_t s);
+
 // feats2joints.hip
 int launch_feats2joints(const float* feats, const float* mean, const float* stdv, int B, int F, int C, int J, float* joints,
                         hipStream_t s);
