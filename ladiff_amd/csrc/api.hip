@@ -386,7 +386,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
         }
     } else {
         const void* kp[9] = {ws, counts, final_counts, coef, step_noise, stream, text_emb, init_noise, z};
-        const int ki[4] = {B, T, n_steps, cfg + 2 * (pipeline ? sp->loop_mode : 0) + 16 * n_text};
+        const int ki[4] = {B, T, n_steps, cfg + 2 * (pipeline ? sp->loop_mode : 0) + 16 * n_text + 4096 * (WSp ? 1 : 0)};
         const float kf[2] = {guidance_scale, init_noise_sigma};
         uint64_t h = hash_ptrs(w, DEN_NPARAMS, 1469598103934665603ull);
         if (w_split) h = hash_ptrs(w_split, DEN_NPARAMS, h ^ 0x9e3779b97f4a7c15ull);
@@ -413,7 +413,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
             if (pipeline) {
                 // stage table of the persistent pipeline (pointers of this call's weights and workspace): built and uploaded
                 // once per key; the host copy stays alive in the sampler until the next rebuild
-                LADIFF_TRY(sys_build_stages(W, WS, r.sys, B, T, sp->stages));
+                LADIFF_TRY(sys_build_stages(W, WSp ? WS : W, r.sys, B, T, WSp ? 0 : 1, sp->stages));
                 LADIFF_HIP(hipMemcpyAsync(r.sys, sp->stages.data(), sp->stages.size(), hipMemcpyHostToDevice, s));
                 LADIFF_HIP(hipStreamSynchronize(s));
             } else {
@@ -444,7 +444,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
             if (lo == 0) LADIFF_HIP(hipEventRecord(sp->ev0, s));       // the loop itself: from the first step's first launch
             if (pipeline) {
                 LADIFF_TRY(launch_systolic_loop(W, r.sys, r.tables, den_cache_tkv(r.cache, B2, 1), den_cache_ctab(r.cache, B2, 1), r.window,
-                                                coef, step_noise, r.latents, counts, guidance_scale, B, T, lo, r.window, s));
+                                                coef, step_noise, r.latents, counts, guidance_scale, B, T, lo, r.window, WSp ? 0 : 1, s));
             } else {
                 for (int i = 0; i < r.window / sp->unroll; ++i) LADIFF_HIP(hipGraphLaunch(sp->exec, s));
             }

@@ -203,73 +203,139 @@ __device__ __forceinline__ void issue_rows(Rows256<MR>& x, __amdgpu_buffer_rsrc_
         x.v[u][1] = ld_sc1(r, base + row * 1024 + c8 * 32 + 16);
     }
 }
-template <int KB, int MR>
+// ---- arithmetic policy AR: 0 = bf16x3 (S-format operand tiles, 3 x v_mfma_f32_16x16x32_bf16 per product),
+//                           1 = fp32 (fp32 operand tiles, v_mfma_f32_16x16x4_f32: exact fp32 fma chains, the strict-parity mode)
+// fp32 tile: row stride K + 4 floats, element k of a row at (k & 3) * (K / 4) + (k >> 2): the lane (row l & 15, k-phase l >> 4) of
+// the 16x16x4 MFMA reads its A values of four consecutive k-steps with ONE conflict-free ds_read_b128.
+template <int AR, int KB> constexpr int tile_bytes(int rows) { return AR == 0 ? rows * KB * 256 : rows * (KB * 64 + 4) * 4; }
+
+template <int AR, int KB>
+__device__ __forceinline__ void tile_put4(char* tile, int row, int k0, const f32x4 v) {            // k0 % 4 == 0
+    if constexpr (AR == 0) {
+        bf16x4 h4, l4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h4[e] = (__bf16)v[e]; l4[e] = (__bf16)(v[e] - (float)h4[e]); }
+        *reinterpret_cast<bf16x4*>(a_slot<KB>(tile, row, k0 >> 6, (k0 & 63) >> 3) + (k0 & 7) * 2) = h4;
+        *reinterpret_cast<bf16x4*>(a_slot<KB>(tile, row, k0 >> 6, 8 + ((k0 & 63) >> 3)) + (k0 & 7) * 2) = l4;
+    } else {
+        float* r = reinterpret_cast<float*>(tile) + row * (KB * 64 + 4) + (k0 >> 2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e * (KB * 16)] = v[e];
+    }
+}
+template <int AR, int KB>
+__device__ __forceinline__ void tile_put1(char* tile, int row, int k, float v) {
+    if constexpr (AR == 0) {
+        const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
+        *(reinterpret_cast<__bf16*>(a_slot<KB>(tile, row, k >> 6, (k & 63) >> 3)) + (k & 7)) = hi;
+        *(reinterpret_cast<__bf16*>(a_slot<KB>(tile, row, k >> 6, 8 + ((k & 63) >> 3))) + (k & 7)) = lo;
+    } else {
+        reinterpret_cast<float*>(tile)[row * (KB * 64 + 4) + (k & 3) * (KB * 16) + (k >> 2)] = v;
+    }
+}
+
+template <int AR, int KB, int MR>
 __device__ __forceinline__ void commit_rows(char* tile, int kb0, const Rows256<MR>& x) {
 #pragma unroll
     for (int u = 0; u < 2 * MR; ++u) {
         const int id = threadIdx.x + 256 * u, row = id >> 5, c8 = id & 31;
-        bf16x8 hi, lo;
-        split8(x.v[u][0], x.v[u][1], hi, lo);
-        *reinterpret_cast<bf16x8*>(a_slot<KB>(tile, row, kb0 + (c8 >> 3), c8 & 7)) = hi;
-        *reinterpret_cast<bf16x8*>(a_slot<KB>(tile, row, kb0 + (c8 >> 3), 8 + (c8 & 7))) = lo;
+        if constexpr (AR == 0) {
+            bf16x8 hi, lo;
+            split8(x.v[u][0], x.v[u][1], hi, lo);
+            *reinterpret_cast<bf16x8*>(a_slot<KB>(tile, row, kb0 + (c8 >> 3), c8 & 7)) = hi;
+            *reinterpret_cast<bf16x8*>(a_slot<KB>(tile, row, kb0 + (c8 >> 3), 8 + (c8 & 7))) = lo;
+        } else {
+            tile_put4<1, KB>(tile, row, kb0 * 64 + c8 * 8, x.v[u][0]);
+            tile_put4<1, KB>(tile, row, kb0 * 64 + c8 * 8 + 4, x.v[u][1]);
+        }
     }
 }
 
-// weights of NT column tiles x KS k-steps for this wave, register resident
-template <int NT, int KS>
-struct WFrag { bf16x8 hi[NT][KS], lo[NT][KS]; };
+// weights of NT column tiles x KS k-steps (of 32) for this wave, register resident: 8 VGPRs per (tile, step) in both modes
+template <int AR, int NT, int KS> struct WFrag;
+template <int NT, int KS> struct WFrag<0, NT, KS> { bf16x8 hi[NT][KS], lo[NT][KS]; };
+template <int NT, int KS> struct WFrag<1, NT, KS> { float w[NT][KS * 8]; };
 
-// w: S-format matrix, row stride ldw floats; tile j covers matrix rows row_of(j) + (lane & 15); k-steps start at k block kb0
-template <int NT, int KS, class RowOf>
-__device__ __forceinline__ void load_w(WFrag<NT, KS>& f, const float* w, int ldw, int kb0, RowOf row_of) {
+// w: weight matrix (S-format for AR 0, fp32 for AR 1), row stride ldw floats; tile j covers matrix rows row_of(j) + (lane & 15);
+// the k range starts at k block kb0 (64 columns per block)
+template <int AR, int NT, int KS, class RowOf>
+__device__ __forceinline__ void load_w(WFrag<AR, NT, KS>& f, const float* w, int ldw, int kb0, RowOf row_of) {
     const int lane = threadIdx.x & 63, frow = lane & 15, fk = lane >> 4;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const char* rp = reinterpret_cast<const char*>(w + (size_t)(row_of(j) + frow) * ldw);
+        if constexpr (AR == 0) {
+            const char* rp = reinterpret_cast<const char*>(w + (size_t)(row_of(j) + frow) * ldw);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const char* bp = rp + (kb0 + (s >> 1)) * 256 + ((4 * (s & 1) + fk) << 4);
-            f.hi[j][s] = *reinterpret_cast<const bf16x8*>(bp);
-            f.lo[j][s] = *reinterpret_cast<const bf16x8*>(bp + 128);
+            for (int s = 0; s < KS; ++s) {
+                const char* bp = rp + (kb0 + (s >> 1)) * 256 + ((4 * (s & 1) + fk) << 4);
+                f.hi[j][s] = *reinterpret_cast<const bf16x8*>(bp);
+                f.lo[j][s] = *reinterpret_cast<const bf16x8*>(bp + 128);
+            }
+        } else {
+            const float* rp = w + (size_t)(row_of(j) + frow) * ldw + kb0 * 64 + fk;
+#pragma unroll
+            for (int s4 = 0; s4 < KS * 8; ++s4) f.w[j][s4] = rp[4 * s4];
         }
     }
 }
 
-// acc[i][j] += A(tile rows 16 i ..) . W(tile j)^T over KS k-steps; MR = row tiles.  The operand fragments of k-step s + 1
-// are requested before the MFMAs of step s are issued, so their LDS latency hides under 3 MR NT MFMAs.
-template <int KB, int NT, int KS, int MR>
-__device__ __forceinline__ void mma(const char* tile, const WFrag<NT, KS>& f, f32x4 (&acc)[MR][NT]) {
+// acc[i][j] += A(tile rows 16 i ..) . W(tile j)^T over KS k-steps of 32; MR = row tiles.  The operand fragments of the next
+// step are requested before the MFMAs of the current one are issued, so their LDS latency hides under the MFMAs.
+template <int AR, int KB, int NT, int KS, int MR>
+__device__ __forceinline__ void mma(const char* tile, const WFrag<AR, NT, KS>& f, f32x4 (&acc)[MR][NT]) {
     const int lane = threadIdx.x & 63, frow = lane & 15, fk = lane >> 4;
     char* const t = const_cast<char*>(tile);
-    bf16x8 ah[2][MR], al[2][MR];
+    if constexpr (AR == 0) {
+        bf16x8 ah[2][MR], al[2][MR];
 #pragma unroll
-    for (int i = 0; i < MR; ++i) {
-        ah[0][i] = *reinterpret_cast<const bf16x8*>(a_slot<KB>(t, 16 * i + frow, 0, fk));
-        al[0][i] = *reinterpret_cast<const bf16x8*>(a_slot<KB>(t, 16 * i + frow, 0, 8 + fk));
-    }
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        if (s + 1 < KS) {
-#pragma unroll
-            for (int i = 0; i < MR; ++i) {
-                ah[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(a_slot<KB>(t, 16 * i + frow, (s + 1) >> 1, 4 * ((s + 1) & 1) + fk));
-                al[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(a_slot<KB>(t, 16 * i + frow, (s + 1) >> 1, 8 + 4 * ((s + 1) & 1) + fk));
-            }
+        for (int i = 0; i < MR; ++i) {
+            ah[0][i] = *reinterpret_cast<const bf16x8*>(a_slot<KB>(t, 16 * i + frow, 0, fk));
+            al[0][i] = *reinterpret_cast<const bf16x8*>(a_slot<KB>(t, 16 * i + frow, 0, 8 + fk));
         }
-        // the three products of a split operand pair go to the same accumulator: one product at a time over all MR x NT
-        // accumulators, so that consecutive MFMAs never depend on each other (a dependent 16x16x32 waits ~2x its issue time)
 #pragma unroll
-        for (int i = 0; i < MR; ++i)
+        for (int s = 0; s < KS; ++s) {
+            if (s + 1 < KS) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s & 1][i], f.hi[j][s], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < MR; ++i) {
+                    ah[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(a_slot<KB>(t, 16 * i + frow, (s + 1) >> 1, 4 * ((s + 1) & 1) + fk));
+                    al[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(a_slot<KB>(t, 16 * i + frow, (s + 1) >> 1, 8 + 4 * ((s + 1) & 1) + fk));
+                }
+            }
+            // the three products of a split operand pair go to the same accumulator: one product at a time over all MR x NT
+            // accumulators, so that consecutive MFMAs never depend on each other
 #pragma unroll
-        for (int i = 0; i < MR; ++i)
+            for (int i = 0; i < MR; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1][i], f.lo[j][s], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s & 1][i], f.hi[j][s], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < MR; ++i)
+            for (int i = 0; i < MR; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1][i], f.hi[j][s], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1][i], f.lo[j][s], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1][i], f.hi[j][s], acc[i][j], 0, 0, 0);
+        }
+    } else {
+        constexpr int LD = KB * 64 + 4, NG = KS * 2;                     // groups of four k-steps of 4
+        const float* base = reinterpret_cast<const float*>(t) + frow * LD + fk * (KB * 16);
+        f32x4 a[2][MR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) a[0][i] = ld4(base + 16 * i * LD);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) {
+#pragma unroll
+                for (int i = 0; i < MR; ++i) a[(g + 1) & 1][i] = ld4(base + 16 * i * LD + 4 * (g + 1));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g & 1][i][e], f.w[j][4 * g + e], acc[i][j], 0, 0, 0);
+        }
     }
 }
 
@@ -403,14 +469,14 @@ __device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R&
 // ---------------------------------------------------------------- roles
 // QKV: one head.  in_proj rows {q,k,v} x 64 of head `slice` on the block, then softmax(q k^T / 8) v over the T latent
 // keys of the sample (masked by its latent count), the text token and the time token.
-template <int MR>
+template <int MR, int AR>
 struct QkvRole {
     static constexpr int RT = 16 * MR, QLD = 196, NI = MR + 1;            // score work items per thread: 2 lanes x rows x keys
     static constexpr bool PREFETCH = true;
     struct Pay { Rows256<MR> x; f32x4 xk[2]; int cnt; };
     const SysArgs& p; const Stage& st;
     char* atile; float *qt, *xt, *sc; int* cnt;
-    WFrag<3, 8> wf;
+    WFrag<AR, 3, 8> wf;
     float bcol[3];
     __amdgpu_buffer_rsrc_t rin, rout;
     const float* tkv;
@@ -421,7 +487,7 @@ struct QkvRole {
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frow = lane & 15;
         h = st.slice; T = p.T; P = p.P; nkeys = T + 2; nsb = blk_nsb(p); nrows = nsb * T;
         atile = lds;                                                     // [RT] x K=256 operand tile
-        qt = reinterpret_cast<float*>(lds + RT * 1024);                  // [RT][QLD] q | k | v (fp32)
+        qt = reinterpret_cast<float*>(lds + tile_bytes<AR, 4>(RT));      // [RT][QLD] q | k | v (fp32)
         xt = qt + RT * QLD;                                              // [2P + 1][128]: text k|v per sample-branch, time k|v last
         sc = xt + 16 * 128;                                              // [RT][16] scores
         cnt = reinterpret_cast<int*>(sc + RT * 16);                      // [2P] latent counts of the block's sample-branches
@@ -468,7 +534,7 @@ struct QkvRole {
     }
     __device__ __forceinline__ void commit(const Pay& y) {
         const int tid = threadIdx.x;
-        commit_rows<4, MR>(atile, 0, y.x);
+        commit_rows<AR, 4, MR>(atile, 0, y.x);
 #pragma unroll
         for (int u = 0; u < 2; ++u)
             if (((tid + 256 * u) >> 5) <= nsb) st4(xt + (tid + 256 * u) * 4, y.xk[u]);
@@ -479,7 +545,7 @@ struct QkvRole {
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frow = lane & 15;
         f32x4 acc[MR][3];
         zero_acc(acc);
-        mma<4, 3, 8, MR>(atile, wf, acc);
+        mma<AR, 4, 3, 8, MR>(atile, wf, acc);
         SYS_STAMP(3);
 #pragma unroll
         for (int i = 0; i < MR; ++i)
@@ -548,19 +614,19 @@ struct QkvRole {
 };
 
 // OUT: X1 = LN1(x + out_proj(att))
-template <int MR>
+template <int MR, int AR>
 struct OutRole {
     static constexpr int RT = 16 * MR, RPW = RT / 4;
     static constexpr bool PREFETCH = true;
     struct Pay { Rows256<MR> att; f32x4 res[RPW]; };
     const SysArgs& p; const Stage& st;
     char* atile; float* ct;
-    WFrag<4, 8> wf;
+    WFrag<AR, 4, 8> wf;
     f32x4 bias, gg, bb;
     __amdgpu_buffer_rsrc_t ratt, rx, rout;
     __device__ __forceinline__ OutRole(const SysArgs& p_, const Stage& st_, char* lds) : p(p_), st(st_) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        atile = lds; ct = reinterpret_cast<float*>(lds + RT * 1024);
+        atile = lds; ct = reinterpret_cast<float*>(lds + tile_bytes<AR, 4>(RT));
         load_w(wf, st.w0, D, 0, [&](int j) { return 64 * wave + 16 * j; });
         bias = ld4(st.b0 + 4 * lane); gg = ld4(st.g + 4 * lane); bb = ld4(st.be + 4 * lane);
         ratt = rsrc_of(st.in0); rx = rsrc_of(st.in1); rout = rsrc_of(st.out);
@@ -572,14 +638,14 @@ struct OutRole {
 #pragma unroll
         for (int q = 0; q < RPW; ++q) y.res[q] = ld_sc1(rx, base + (wave + 4 * q) * 1024 + lane * 16);
     }
-    __device__ __forceinline__ void commit(const Pay& y) { commit_rows<4, MR>(atile, 0, y.att); }
+    __device__ __forceinline__ void commit(const Pay& y) { commit_rows<AR, 4, MR>(atile, 0, y.att); }
     template <class M>
     __device__ __forceinline__ void compute(int s, int b, const Pay& y, M& mid) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
         const unsigned base = (unsigned)b * RT * 1024;
         f32x4 acc[MR][4];
         zero_acc(acc);
-        mma<4, 4, 8, MR>(atile, wf, acc);
+        mma<AR, 4, 4, 8, MR>(atile, wf, acc);
         SYS_STAMP(3);
         stage_c(ct, acc, [&](int j) { return 64 * wave + 16 * j; });
         mid.before_barrier();
@@ -601,23 +667,23 @@ struct OutRole {
 };
 
 // LIN / FFN: hidden slice = act(x W1_slice^T + b1_slice) (128 columns), partial = hidden . W2[:, slice]^T (256 columns)
-template <int MR, int ACT>
+template <int MR, int ACT, int AR>
 struct MlpRole {
     static constexpr int RT = 16 * MR, RPW = RT / 4;
     static constexpr bool PREFETCH = true;
     struct Pay { Rows256<MR> x; };
     const SysArgs& p; const Stage& st;
     char *atile, *htile; float* ct;
-    WFrag<2, 8> w1;
-    WFrag<4, 4> w2;
+    WFrag<AR, 2, 8> w1;
+    WFrag<AR, 4, 4> w2;
     float b1[2];
     __amdgpu_buffer_rsrc_t rin, rout;
     unsigned plane;
     __device__ __forceinline__ MlpRole(const SysArgs& p_, const Stage& st_, char* lds) : p(p_), st(st_) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, frow = lane & 15;
         atile = lds;                                                     // [RT] x K=256
-        htile = lds + RT * 1024;                                         // [RT] x K=128 (hidden slice, S-format)
-        ct = reinterpret_cast<float*>(lds + RT * 1024 + RT * 512);
+        htile = lds + tile_bytes<AR, 4>(RT);                             // [RT] x K=128 (hidden slice, operand format)
+        ct = reinterpret_cast<float*>(lds + tile_bytes<AR, 4>(RT) + tile_bytes<AR, 2>(RT));
         const int j0 = st.slice * HS;
         load_w(w1, st.w0, D, 0, [&](int j) { return j0 + 32 * wave + 16 * j; });
         load_w(w2, st.w1, FF, 2 * st.slice, [&](int j) { return 64 * wave + 16 * j; });
@@ -627,14 +693,14 @@ struct MlpRole {
         plane = (unsigned)st.slice * p.NB * RT * 1024;
     }
     __device__ __forceinline__ void issue(int, int b, Pay& y) { issue_rows<MR>(y.x, rin, (unsigned)b * RT * 1024); }
-    __device__ __forceinline__ void commit(const Pay& y) { commit_rows<4, MR>(atile, 0, y.x); }
+    __device__ __forceinline__ void commit(const Pay& y) { commit_rows<AR, 4, MR>(atile, 0, y.x); }
     template <class M>
     __device__ __forceinline__ void compute(int s, int b, const Pay&, M& mid) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, frow = lane & 15, fk = lane >> 4;
         const unsigned base = (unsigned)b * RT * 1024;
         f32x4 acc1[MR][2];
         zero_acc(acc1);
-        mma<4, 2, 8, MR>(atile, w1, acc1);
+        mma<AR, 4, 2, 8, MR>(atile, w1, acc1);
         SYS_STAMP(3);
         // hidden slice -> S-format operand tile (k = hidden column within the slice)
 #pragma unroll
@@ -645,10 +711,7 @@ struct MlpRole {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * i + 4 * fk + r;
-                    const float v = act_c<ACT>(acc1[i][j][r] + b1[j]);
-                    const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
-                    *(reinterpret_cast<__bf16*>(a_slot<2>(htile, row, k >> 6, (k & 63) >> 3)) + (k & 7)) = hi;
-                    *(reinterpret_cast<__bf16*>(a_slot<2>(htile, row, k >> 6, 8 + ((k & 63) >> 3))) + (k & 7)) = lo;
+                    tile_put1<AR, 2>(htile, row, k, act_c<ACT>(acc1[i][j][r] + b1[j]));
                 }
             }
         mid.before_barrier();
@@ -656,7 +719,7 @@ struct MlpRole {
         mid.after_barrier();
         f32x4 acc2[MR][4];
         zero_acc(acc2);
-        mma<2, 4, 4, MR>(htile, w2, acc2);
+        mma<AR, 2, 4, 4, MR>(htile, w2, acc2);
         stage_c(ct, acc2, [&](int j) { return 64 * wave + 16 * j; });
         __syncthreads();
 #pragma unroll
@@ -748,21 +811,21 @@ struct Red2Role {
 };
 
 // STYL: x' = X2 + out( SiLU( LN(sum_j partial_j + b2) * (1 + scale_t) + shift_t ) )
-template <int MR>
+template <int MR, int AR>
 struct StylRole {
     static constexpr int RT = 16 * MR, PQ = MR + 1;
     static constexpr bool PREFETCH = MR == 1;       // 256 weight registers + two images of 27 x 16 bytes per lane do not fit
     struct Pay { f32x4 pl[PQ][NSLICE], rs[PQ], scl, shf; };
     const SysArgs& p; const Stage& st;
     char* atile; float* ct;
-    WFrag<4, 8> wf;
+    WFrag<AR, 4, 8> wf;
     f32x4 bias2, bias, gg, bb;
     __amdgpu_buffer_rsrc_t rp, rx, rout;
     int lo, hi;
     unsigned pstride;
     __device__ __forceinline__ StylRole(const SysArgs& p_, const Stage& st_, char* lds) : p(p_), st(st_) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        atile = lds; ct = reinterpret_cast<float*>(lds + 16 * 1024);
+        atile = lds; ct = reinterpret_cast<float*>(lds + tile_bytes<AR, 4>(16));
         load_w(wf, st.w0, D, 0, [&](int j) { return 64 * wave + 16 * j; });
         bias2 = ld4(st.b1 + 4 * lane); bias = ld4(st.b0 + 4 * lane); gg = ld4(st.g + 4 * lane); bb = ld4(st.be + 4 * lane);
         rp = rsrc_of(st.in0); rx = rsrc_of(st.in1); rout = rsrc_of(st.out);
@@ -804,18 +867,14 @@ struct StylRole {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = silu(((v[i] - mean) * rstd * gg[i] + bb[i]) * (1.f + scl[i]) + shf[i]);
             }
-            bf16x4 h4, l4;                                               // u row -> S-format operand tile (unused rows: zero)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { h4[e] = (__bf16)v[e]; l4[e] = (__bf16)(v[e] - (float)h4[e]); }
-            *reinterpret_cast<bf16x4*>(a_slot<4>(atile, lr, c >> 6, (c & 63) >> 3) + (c & 7) * 2) = h4;
-            *reinterpret_cast<bf16x4*>(a_slot<4>(atile, lr, c >> 6, 8 + ((c & 63) >> 3)) + (c & 7) * 2) = l4;
+            tile_put4<AR, 4>(atile, lr, c, v);                           // u row -> operand tile (unused rows: zero)
         }
         mid.before_barrier();
         __syncthreads();
         mid.after_barrier();
         f32x4 acc[1][4];
         zero_acc(acc);
-        mma<4, 4, 8, 1>(atile, wf, acc);
+        mma<AR, 4, 4, 8, 1>(atile, wf, acc);
         stage_c(ct, acc, [&](int j) { return 64 * wave + 16 * j; });
         __syncthreads();
 #pragma unroll
@@ -832,19 +891,19 @@ struct StylRole {
 };
 
 // SKIP: half of the 256 output columns of linear_blocks[i](cat(x, skip))
-template <int MR>
+template <int MR, int AR>
 struct SkipRole {
     static constexpr int RT = 16 * MR;
     static constexpr bool PREFETCH = true;
     struct Pay { Rows256<MR> x, k; };
     const SysArgs& p; const Stage& st;
     char* atile; float* ct;
-    WFrag<2, 16> wf;
+    WFrag<AR, 2, 16> wf;
     __amdgpu_buffer_rsrc_t rx, rs, rout;
     int n0;
     __device__ __forceinline__ SkipRole(const SysArgs& p_, const Stage& st_, char* lds) : p(p_), st(st_) {
         const int wave = threadIdx.x >> 6;
-        atile = lds; ct = reinterpret_cast<float*>(lds + RT * 2048);     // [RT] x K=512 operand tile first
+        atile = lds; ct = reinterpret_cast<float*>(lds + tile_bytes<AR, 8>(RT));     // [RT] x K=512 operand tile first
         n0 = st.slice * 128;
         load_w(wf, st.w0, 2 * D, 0, [&](int j) { return n0 + 32 * wave + 16 * j; });
         rx = rsrc_of(st.in0); rs = rsrc_of(st.in1); rout = rsrc_of(st.out);
@@ -853,14 +912,14 @@ struct SkipRole {
         issue_rows<MR>(y.x, rx, (unsigned)b * RT * 1024);
         issue_rows<MR>(y.k, rs, (unsigned)b * RT * 1024);
     }
-    __device__ __forceinline__ void commit(const Pay& y) { commit_rows<8, MR>(atile, 0, y.x); commit_rows<8, MR>(atile, 4, y.k); }
+    __device__ __forceinline__ void commit(const Pay& y) { commit_rows<AR, 8, MR>(atile, 0, y.x); commit_rows<AR, 8, MR>(atile, 4, y.k); }
     template <class M>
     __device__ __forceinline__ void compute(int, int b, const Pay&, M& mid) {
         const int tid = threadIdx.x, wave = tid >> 6;
         const unsigned base = (unsigned)b * RT * 1024;
         f32x4 acc[MR][2];
         zero_acc(acc);
-        mma<8, 2, 16, MR>(atile, wf, acc);
+        mma<AR, 8, 2, 16, MR>(atile, wf, acc);
         stage_c(ct, acc, [&](int j) { return n0 + 32 * wave + 16 * j; });
         mid.before_barrier();
         __syncthreads();
@@ -1052,20 +1111,20 @@ __device__ __forceinline__ void tail_loop(const SysArgs& p, const Stage& st, Tai
 
 }  // namespace
 
-template <int MR>
+template <int MR, int AR>
 __global__ __launch_bounds__(256, 1) void systolic_loop_kernel(const SysArgs p) {
     // all LDS is dynamic (a static variable would shift the dynamic base off its 16-byte alignment, cdna_hip_programming.md G17)
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     Ctl* const ctl = reinterpret_cast<Ctl*>(lds + SYS_LDS_BYTES - 16);
     const Stage st = p.stages[blockIdx.x];
     switch (st.role) {
-        case R_QKV: { QkvRole<MR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
-        case R_OUT: { OutRole<MR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
-        case R_LIN: { MlpRole<MR, ACT_RELU> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
+        case R_QKV: { QkvRole<MR, AR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
+        case R_OUT: { OutRole<MR, AR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
+        case R_LIN: { MlpRole<MR, ACT_RELU, AR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
         case R_RED2: { Red2Role<MR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
-        case R_FFN: { MlpRole<MR, ACT_GELU> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
-        case R_STYL: { StylRole<MR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
-        case R_SKIP: { SkipRole<MR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
+        case R_FFN: { MlpRole<MR, ACT_GELU, AR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
+        case R_STYL: { StylRole<MR, AR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
+        case R_SKIP: { SkipRole<MR, AR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
         case R_TAIL: { TailRole<MR> r(p, st, lds); tail_loop(p, st, r, ctl); break; }
         default: break;
     }
@@ -1121,7 +1180,8 @@ int sys_row_tiles(int T) { return 2 * T <= 16 ? g_sys_row_tiles : 2; }
 size_t sys_ws_floats(int B, int T) { const size_t a = sys_layout(B, T, 1).total, b = sys_layout(B, T, 2).total; return a > b ? a : b; }
 
 bool sys_supported(int B, int T, int cfg, bool split) {
-    if (!cfg || !split || B < 1 || T < 1 || T > LADIFF_MAX_LATENTS) return false;
+    (void)split;                  // both arithmetic modes have a pipeline kernel
+    if (!cfg || B < 1 || T < 1 || T > LADIFF_MAX_LATENTS) return false;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
@@ -1129,8 +1189,9 @@ bool sys_supported(int B, int T, int cfg, bool split) {
 }
 
 // Builds the stage table (host) for this call's pointers.  `ws` = the systolic region of the reverse workspace.
-int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int B, int T, std::vector<unsigned char>& host) {
-    const int MR = sys_row_tiles(T), RT = 16 * MR;
+int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int B, int T, int fp32, std::vector<unsigned char>& host) {
+    // WS = the S-format weight table in bf16x3 mode; in fp32 mode the caller passes the fp32 table twice
+    const int MR = fp32 ? 2 : sys_row_tiles(T), RT = 16 * MR;
     (void)RT;
     const SysLayout L = sys_layout(B, T, MR);
     std::vector<Stage> st;
@@ -1211,14 +1272,16 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int B, 
 // the workspace (sys_upload_stages); `ctab` holds the hoisted cross-attention rows of n_ctab >= n steps starting at step_lo.
 int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, const float* tkv, const float* ctab, int n_ctab,
                          const float* coef, const float* noise, float* lat, const int32_t* counts, float gscale, int B, int T,
-                         int step_lo, int n, hipStream_t s) {
-    const int MR = sys_row_tiles(T);
+                         int step_lo, int n, int fp32, hipStream_t s) {
+    const int MR = fp32 ? 2 : sys_row_tiles(T);
     const SysLayout L = sys_layout(B, T, MR);
     static bool attr_set = false;
     if (!attr_set) {
-        LADIFF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(systolic_loop_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        LADIFF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(systolic_loop_kernel<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        SYS_LDS_BYTES));
-        LADIFF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(systolic_loop_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        LADIFF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(systolic_loop_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       SYS_LDS_BYTES));
+        LADIFF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(systolic_loop_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        SYS_LDS_BYTES));
         attr_set = true;
     }
@@ -1236,14 +1299,15 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
 #endif
     // flags and the abort word are contiguous: one memset node, a multiple of 16 bytes
     LADIFF_HIP(hipMemsetAsync(a.flags, 0, (L.off_xin0 - L.off_flags) * sizeof(float), s));
-    if (MR == 1) hipLaunchKernelGGL(systolic_loop_kernel<1>, dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
-    else hipLaunchKernelGGL(systolic_loop_kernel<2>, dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
+    if (fp32) hipLaunchKernelGGL((systolic_loop_kernel<2, 1>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
+    else if (MR == 1) hipLaunchKernelGGL((systolic_loop_kernel<1, 0>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((systolic_loop_kernel<2, 0>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
 
-size_t sys_stage_bytes(int B, int T) { return (size_t)sys_layout(B, T, sys_row_tiles(T)).nwg * sizeof(Stage); }
-size_t sys_status_offset_floats(int B, int T) { return sys_layout(B, T, sys_row_tiles(T)).off_status; }
+size_t sys_stage_bytes(int B, int T) { return (size_t)sys_layout(B, T, 2).nwg * sizeof(Stage); }
+size_t sys_status_offset_floats(int B, int T) { return sys_layout(B, T, 2).off_status; }    // the head of the layout does not depend on MR
 void sys_set_row_tiles(int mr) { g_sys_row_tiles = mr == 1 ? 1 : 2; g_sys_pcap = mr == 3 ? 2 : 7; }
 
 }  // namespace ladiff
