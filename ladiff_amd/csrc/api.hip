@@ -451,6 +451,8 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
         }
         LADIFF_HIP(hipEventRecord(sp->ev1, s));
     }
+    if (!pipeline)       // the pipeline kernel's status word reads "completed" for every other loop form (ladiff_reverse_status)
+        LADIFF_HIP(hipMemsetAsync(r.sys + sys_status_offset_floats(B, T), 0, 2 * sizeof(unsigned), s));
     // final zeroing of the rows past each motion's latent count: applied even when the denoiser ran unmasked
     // (TEST_EFFICIENCY), as ladiff.py:559-566 does
     return launch_finalize_latents(r.latents, final_counts, z, B, T, s);

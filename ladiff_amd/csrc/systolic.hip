@@ -1159,8 +1159,8 @@ SysLayout sys_layout(int B, int T, int MR) {
     size_t off = 0;
     auto take = [&](size_t floats) { const size_t o = off; off += (floats + 63) / 64 * 64; return o; };
     L.off_stages = take((size_t)256 * sizeof(Stage) / sizeof(float));
+    L.off_status = take(64);      // before the flags: its offset must not depend on the block geometry (ladiff_reverse_status)
     L.off_flags = take((size_t)NL * GROUPS_PER_LAYER * L.NB * FLAG_SLOTS * FLAG_STRIDE);
-    L.off_status = take(64);
     L.off_xin0 = take(L.blk);
     L.off_xs = take(NSKIP * L.blk);
     L.off_xo = take(NL * L.blk);
@@ -1297,8 +1297,8 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
 #ifdef LADIFF_STAMPS
     a.stamps = g_sys_stamps;
 #endif
-    // flags and the abort word are contiguous: one memset node, a multiple of 16 bytes
-    LADIFF_HIP(hipMemsetAsync(a.flags, 0, (L.off_xin0 - L.off_flags) * sizeof(float), s));
+    // the abort word and the flags are contiguous: one memset node, a multiple of 16 bytes
+    LADIFF_HIP(hipMemsetAsync(a.status, 0, (L.off_xin0 - L.off_status) * sizeof(float), s));
     if (fp32) hipLaunchKernelGGL((systolic_loop_kernel<2, 1>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
     else if (MR == 1) hipLaunchKernelGGL((systolic_loop_kernel<1, 0>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
     else hipLaunchKernelGGL((systolic_loop_kernel<2, 0>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
