@@ -208,8 +208,10 @@ int ladiff_finalize_latents(const float* latents, const int32_t* counts, float* 
 int ladiff_sampler_create(void** sampler);
 int ladiff_sampler_destroy(void* sampler);
 /* How a sampler runs the N steps: 1 (default) = ONE persistent pipeline kernel for the whole loop when the call qualifies
- * (guidance on, bf16x3 weights, a CU per pipeline stage) - every CU keeps one stage's weights in registers and blocks of
- * prompts flow through the stages (csrc/systolic.hip); 0 = one launch per stage, captured in a hipGraph of up to 10 steps. */
+ * (guidance on, one text token, a CU per pipeline stage; both arithmetic modes) - every CU keeps one stage's weights in
+ * registers and blocks of three prompts (32 rows) flow through the stages (csrc/systolic.hip); 2 = the same with 16-row blocks
+ * (one guidance branch of three prompts; measured slower, kept as a variant); 0 = one launch per stage, captured in a hipGraph
+ * of up to 10 steps. */
 int ladiff_sampler_set_loop(void* sampler, int mode);
 /* Device time of the N-step loop of the sampler's last call (HIP events recorded on the call's stream right around the
  * pipeline kernel, or around the graph replays); blocks until it has finished.  Measurement aid (bench.py). */

@@ -68,7 +68,7 @@ struct Sampler {
     hipGraphExec_t exec = nullptr;
     hipGraphExec_t setup = nullptr;       // per-call prologue (text cache, initial latents, counter reset, first network input)
     int unroll = 1;                       // denoiser steps captured per graph launch
-    int loop_mode = 1;
+    int loop_mode = 1;                    // 1: 32-row blocks (both guidance branches of three prompts), 2: 16-row blocks (one branch)
     int loop = 1;                         // 1: persistent pipeline kernel when the call qualifies (systolic.hip), 0: launch per stage
     std::vector<unsigned char> stages;    // host copy of the pipeline's stage table (source of the upload)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // bracket the N-step loop (pipeline kernel or graph replays) of the last call
@@ -293,10 +293,9 @@ int ladiff_sampler_destroy(void* sampler) {
 
 int ladiff_sampler_set_loop(void* sampler, int mode) {
     Sampler* sp = reinterpret_cast<Sampler*>(sampler);
-    LADIFF_CHECK_ARG(sp != nullptr && mode >= 0 && mode <= 3);
+    LADIFF_CHECK_ARG(sp != nullptr && mode >= 0 && mode <= 2);
     sp->loop = mode != 0;
     sp->loop_mode = mode;
-    sys_set_row_tiles(mode == 2 ? 1 : (mode == 3 ? 3 : 2));          // 2: one prompt per block (16-row tiles), 1: three prompts (32-row tiles)
     return 0;
 }
 
@@ -413,7 +412,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
             if (pipeline) {
                 // stage table of the persistent pipeline (pointers of this call's weights and workspace): built and uploaded
                 // once per key; the host copy stays alive in the sampler until the next rebuild
-                LADIFF_TRY(sys_build_stages(W, WSp ? WS : W, r.sys, B, T, WSp ? 0 : 1, sp->stages));
+                LADIFF_TRY(sys_build_stages(W, WSp ? WS : W, r.sys, B, T, WSp ? 0 : 1, sp->loop_mode == 2, sp->stages));
                 LADIFF_HIP(hipMemcpyAsync(r.sys, sp->stages.data(), sp->stages.size(), hipMemcpyHostToDevice, s));
                 LADIFF_HIP(hipStreamSynchronize(s));
             } else {
@@ -444,7 +443,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
             if (lo == 0) LADIFF_HIP(hipEventRecord(sp->ev0, s));       // the loop itself: from the first step's first launch
             if (pipeline) {
                 LADIFF_TRY(launch_systolic_loop(W, r.sys, r.tables, den_cache_tkv(r.cache, B2, 1), den_cache_ctab(r.cache, B2, 1), r.window,
-                                                coef, step_noise, r.latents, counts, guidance_scale, B, T, lo, r.window, WSp ? 0 : 1, s));
+                                                coef, step_noise, r.latents, counts, guidance_scale, B, T, lo, r.window, WSp ? 0 : 1, sp->loop_mode == 2, s));
             } else {
                 for (int i = 0; i < r.window / sp->unroll; ++i) LADIFF_HIP(hipGraphLaunch(sp->exec, s));
             }

@@ -50,14 +50,14 @@ extern unsigned long long* g_sys_stamps;
 #endif
 size_t sys_ws_floats(int B, int T);
 bool sys_supported(int B, int T, int cfg, bool split);
-int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int B, int T, int fp32, std::vector<unsigned char>& host);
+int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int B, int T, int fp32, int rows16,
+                     std::vector<unsigned char>& host);
 size_t sys_stage_bytes(int B, int T);
 size_t sys_status_offset_floats(int B, int T);
-void sys_set_row_tiles(int mr);
-int sys_row_tiles(int T);
+int sys_row_tiles(int T, int want16);
 int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, const float* tkv, const float* ctab, int n_ctab,
                          const float* coef, const float* noise, float* lat, const int32_t* counts, float gscale, int B, int T,
-                         int step_lo, int n, int fp32, hipStream_t s);
+                         int step_lo, int n, int fp32, int rows16, hipStream_t s);
 
 // qkv_attn.hip: in_proj GEMM + self-attention of the denoiser's sa_block in one launch (bf16x3 mode, S-format in / out)
 int launch_qkv_attention(const float* x, const float* w, const float* bias, const float* text_kv, const float* tables,

@@ -1134,8 +1134,6 @@ __global__ __launch_bounds__(256, 1) void systolic_loop_kernel(const SysArgs p) 
 #ifdef LADIFF_STAMPS
 unsigned long long* g_sys_stamps = nullptr;
 #endif
-static int g_sys_row_tiles = 2;
-static int g_sys_pcap = 7;
 namespace {
 struct SysLayout {
     size_t blk;                   // floats of one [NB][RT][256] buffer
@@ -1149,7 +1147,6 @@ SysLayout sys_layout(int B, int T, int MR) {
     // tail), 32-row tiles: both branches of P prompts (2 P T <= 32)
     L.split = MR == 1 ? 1 : 0;
     int P = L.split ? RT / T : RT / (2 * T);
-    if (P > g_sys_pcap) P = g_sys_pcap;
     if (P > 7) P = 7;             // the QKV stage parks (2P + 1) x 128 floats of extra K|V through 512 thread slots
     if (P < 1) P = 1;
     L.P = P;
@@ -1176,7 +1173,7 @@ SysLayout sys_layout(int B, int T, int MR) {
 
 // rows per block: 32 (three prompts of five latents, both branches) while the stages' time per block leaves the loop
 // latency-bound; 16 (one prompt) is the low-latency variant
-int sys_row_tiles(int T) { return 2 * T <= 16 ? g_sys_row_tiles : 2; }
+int sys_row_tiles(int T, int want16) { return (want16 && T <= 16) ? 1 : 2; }
 size_t sys_ws_floats(int B, int T) { const size_t a = sys_layout(B, T, 1).total, b = sys_layout(B, T, 2).total; return a > b ? a : b; }
 
 bool sys_supported(int B, int T, int cfg, bool split) {
@@ -1189,9 +1186,10 @@ bool sys_supported(int B, int T, int cfg, bool split) {
 }
 
 // Builds the stage table (host) for this call's pointers.  `ws` = the systolic region of the reverse workspace.
-int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int B, int T, int fp32, std::vector<unsigned char>& host) {
+int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int B, int T, int fp32, int rows16,
+                     std::vector<unsigned char>& host) {
     // WS = the S-format weight table in bf16x3 mode; in fp32 mode the caller passes the fp32 table twice
-    const int MR = fp32 ? 2 : sys_row_tiles(T), RT = 16 * MR;
+    const int MR = fp32 ? 2 : sys_row_tiles(T, rows16), RT = 16 * MR;
     (void)RT;
     const SysLayout L = sys_layout(B, T, MR);
     std::vector<Stage> st;
@@ -1272,8 +1270,8 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int B, 
 // the workspace (sys_upload_stages); `ctab` holds the hoisted cross-attention rows of n_ctab >= n steps starting at step_lo.
 int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, const float* tkv, const float* ctab, int n_ctab,
                          const float* coef, const float* noise, float* lat, const int32_t* counts, float gscale, int B, int T,
-                         int step_lo, int n, int fp32, hipStream_t s) {
-    const int MR = fp32 ? 2 : sys_row_tiles(T);
+                         int step_lo, int n, int fp32, int rows16, hipStream_t s) {
+    const int MR = fp32 ? 2 : sys_row_tiles(T, rows16);
     const SysLayout L = sys_layout(B, T, MR);
     static bool attr_set = false;
     if (!attr_set) {
@@ -1308,6 +1306,5 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
 
 size_t sys_stage_bytes(int B, int T) { return (size_t)sys_layout(B, T, 2).nwg * sizeof(Stage); }
 size_t sys_status_offset_floats(int B, int T) { return sys_layout(B, T, 2).off_status; }    // the head of the layout does not depend on MR
-void sys_set_row_tiles(int mr) { g_sys_row_tiles = mr == 1 ? 1 : 2; g_sys_pcap = mr == 3 ? 2 : 7; }
 
 }  // namespace ladiff

@@ -103,7 +103,7 @@ class LADIFF(nn.Module):
         # how the N steps run (include/ladiff_hip.h, ladiff_sampler_set_loop): "pipeline" = one persistent weight-stationary
         # kernel for the whole loop when the call qualifies (guidance on, bf16x3; blocks of three prompts, "pipeline16": of one
         # prompt), "launches" = one launch per stage in hipGraphs
-        if loop not in ("pipeline", "pipeline16", "pipeline_p2", "launches"):
+        if loop not in ("pipeline", "pipeline16", "launches"):
             raise ValueError(f"loop {loop!r} not supported")
         self.loop = loop
         # matrix-product arithmetic of the denoiser loop: "fp32" (fp32-input MFMA) or "bf16x3" (3-term bf16 split)
@@ -197,7 +197,7 @@ class LADIFF(nn.Module):
             _lib.check(L.ladiff_sampler_create(byref(h)))
             self._sampler = h
         if self._sampler is not None:
-            _lib.check(L.ladiff_sampler_set_loop(self._sampler, {"pipeline": 1, "pipeline16": 2, "pipeline_p2": 3, "launches": 0}[self.loop]))
+            _lib.check(L.ladiff_sampler_set_loop(self._sampler, {"pipeline": 1, "pipeline16": 2, "launches": 0}[self.loop]))
         if init_noise is None:
             init_noise = torch.randn(B, T, 256, device=dev, dtype=torch.float32)       # ladiff.py:380-385
         if need_noise and step_noise is None:
