@@ -203,15 +203,19 @@ int ladiff_finalize_latents(const float* latents, const int32_t* counts, float* 
  *                (ladiff.py:379-390; NULL = unmasked, the TEST_EFFICIENCY branch, ladiff_denoiser.py:254)
  *   final_counts [B] rows >= final_counts[b] of the result are zeroed (ladiff.py:559-566, applied in every branch;
  *                NULL = no zeroing)
+ *   h_counts     [B] the same numbers as `counts` in HOST memory (or NULL): lets the pipeline loop pack prompts by their
+ *                latent count so that padded latent rows are not computed at all (they never influence valid rows: masked as
+ *                keys, every other op is per row, and the final zeroing removes them)
  * reuse_time_tables = 1 tells the call that `ws` still holds the time tables of a previous call with the same weights
  * and schedule. */
 int ladiff_sampler_create(void** sampler);
 int ladiff_sampler_destroy(void* sampler);
 /* How a sampler runs the N steps: 1 (default) = ONE persistent pipeline kernel for the whole loop when the call qualifies
  * (guidance on, one text token, a CU per pipeline stage; both arithmetic modes) - every CU keeps one stage's weights in
- * registers and blocks of three prompts (32 rows) flow through the stages (csrc/systolic.hip); 2 = the same with 16-row blocks
- * (one guidance branch of three prompts; measured slower, kept as a variant); 0 = one launch per stage, captured in a hipGraph
- * of up to 10 steps. */
+ * registers and blocks of prompts flow through the stages (csrc/systolic.hip).  The block geometry is planned per call: 32-row
+ * blocks (both guidance branches of three prompts, padded to T latent rows) or LENGTH-AWARE 16-row blocks (one guidance branch of
+ * as many prompts as fit with only their valid latent rows; needs h_counts) - whichever the stage-time model predicts faster;
+ * 2 / 3 force the 16- / 32-row plan; 0 = one launch per stage, captured in a hipGraph of up to 10 steps. */
 int ladiff_sampler_set_loop(void* sampler, int mode);
 /* Device time of the N-step loop of the sampler's last call (HIP events recorded on the call's stream right around the
  * pipeline kernel, or around the graph replays); blocks until it has finished.  Measurement aid (bench.py). */
@@ -224,6 +228,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
                              uint64_t weights_generation, const float* text_emb /*[2B or B,n_text,768]*/,
                              const float* init_noise /*[B,T,256]*/, const int32_t* counts /*[B] or NULL*/,
                              const int32_t* final_counts /*[B] or NULL*/,
+                             const int32_t* h_counts /*HOST copy of counts, or NULL*/,
                              const float* sinusoid /*[n,768]*/, const float* coef /*[n,8]*/,
                              const float* step_noise /*[n,B,T,256] or NULL*/, float guidance_scale,
                              float init_noise_sigma, int cfg, int B, int T, int n_text, int n_steps, float* z /*[T,B,256]*/,
@@ -236,6 +241,13 @@ size_t ladiff_decoder_workspace_bytes(int B, int F, int T, int C);
 int ladiff_vae_decode(const float* const* w, const float* const* w_split /*or NULL: fp32 MFMA*/, const float* z,
                       const int32_t* lengths, const int32_t* counts, int B, int F, int T, int C, float* feats,
                       void* ws, size_t ws_bytes, ladiff_stream_t stream);
+/* One LENGTH BUCKET of a mixed-length batch: the B samples of the bucket (z[T,B,256], lengths, counts gathered by the
+ * caller) are decoded with the bucket's own F and written to rows out_index[i] (device int32 [B]) of feats[*,F_out,C],
+ * frames < F only; the caller zero-fills feats once.  Same arithmetic per sample as ladiff_vae_decode: the padded
+ * frames of a sample are masked keys there (cross_attention.py:367-371) and zeroed at the end (ladiff_vae.py:356-360). */
+int ladiff_vae_decode_bucket(const float* const* w, const float* const* w_split /*or NULL*/, const float* z,
+                             const int32_t* lengths, const int32_t* counts, const int32_t* out_index, int B, int F,
+                             int F_out, int T, int C, float* feats, void* ws, size_t ws_bytes, ladiff_stream_t stream);
 
 /* ------------------------------------------------------------------ LA-VAE encoder
  * LADiffVae.encode, ladiff_vae.py:162-286 (call sites ladiff.py:269, :324, :1096): features[B,F,C] ->

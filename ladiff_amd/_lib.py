@@ -67,7 +67,7 @@ _SIGNATURES = {
     "ladiff_sampler_loop_ms": (c_int, [c_void_p, ctypes.POINTER(c_float)]),
     "ladiff_reverse_status": (c_int, [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "ladiff_reverse_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "ladiff_diffusion_reverse": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p,
+    "ladiff_diffusion_reverse": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_int, c_int,
                                          c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "ladiff_encoder_num_params": (c_int, []),
@@ -98,6 +98,8 @@ _SIGNATURES = {
     "ladiff_decoder_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ladiff_vae_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                   c_void_p, c_size_t, c_void_p]),
+    "ladiff_vae_decode_bucket": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                         c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

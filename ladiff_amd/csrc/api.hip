@@ -1,4 +1,5 @@
 // extern "C" surface of libladiff_hip.so (declared in include/ladiff_hip.h).
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -68,7 +69,9 @@ struct Sampler {
     hipGraphExec_t exec = nullptr;
     hipGraphExec_t setup = nullptr;       // per-call prologue (text cache, initial latents, counter reset, first network input)
     int unroll = 1;                       // denoiser steps captured per graph launch
-    int loop_mode = 1;                    // 1: 32-row blocks (both guidance branches of three prompts), 2: 16-row blocks (one branch)
+    int loop_mode = 1;                    // 1: pick per call, 2: 16-row length-aware blocks, 3: 32-row blocks
+    std::vector<unsigned char> blocks;    // host copy of the block descriptors last uploaded (geometry of the previous call)
+    int plan_mr = 0, plan_nb = 0;
     int loop = 1;                         // 1: persistent pipeline kernel when the call qualifies (systolic.hip), 0: launch per stage
     std::vector<unsigned char> stages;    // host copy of the pipeline's stage table (source of the upload)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // bracket the N-step loop (pipeline kernel or graph replays) of the last call
@@ -293,7 +296,7 @@ int ladiff_sampler_destroy(void* sampler) {
 
 int ladiff_sampler_set_loop(void* sampler, int mode) {
     Sampler* sp = reinterpret_cast<Sampler*>(sampler);
-    LADIFF_CHECK_ARG(sp != nullptr && mode >= 0 && mode <= 2);
+    LADIFF_CHECK_ARG(sp != nullptr && mode >= 0 && mode <= 3);
     sp->loop = mode != 0;
     sp->loop_mode = mode;
     return 0;
@@ -329,7 +332,7 @@ int ladiff_split_rows(const float* x, float* y, int R, int K, ladiff_stream_t st
 
 int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* const* w_split, uint64_t weights_generation,
                              const float* text_emb, const float* init_noise, const int32_t* counts, const int32_t* final_counts,
-                             const float* sinusoid, const float* coef, const float* step_noise, float guidance_scale,
+                             const int32_t* h_counts, const float* sinusoid, const float* coef, const float* step_noise, float guidance_scale,
                              float init_noise_sigma, int cfg, int B, int T, int n_text, int n_steps, float* z, void* ws, size_t ws_bytes,
                              int reuse_time_tables, ladiff_stream_t stream) {
     DenoiserW W, WS;
@@ -371,6 +374,27 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
                                 guidance_scale, cfg, B, T, st);
     };
     const bool pipeline = sp != nullptr && sp->loop == 1 && n_text == 1 && sys_supported(B, T, cfg, WSp != nullptr);
+    // Block geometry of the pipeline for THIS call's lengths.  16-row blocks carry only the valid latent rows of each prompt
+    // (length-aware packing; needs the counts on the host), 32-row blocks the padded T rows.  A stage costs ~4.3 us per 16-row
+    // block and ~5.3 us per 32-row block (fp32: ~7 / ~13.5) and a step cannot be faster than one block's trip through the 59
+    // stages (~346 us with 32-row tiles; fp32: compute-bound, so only the block count matters): pick the cheaper plan.
+    std::vector<unsigned char> plan;
+    int plan_mr = 2, plan_nb = 0;
+    if (pipeline) {
+        const bool masked = counts != nullptr;
+        int mr16 = 1, nb16 = 0, mr32 = 2, nb32 = 0;
+        std::vector<unsigned char> p16, p32;
+        sys_pack_blocks(B, T, 2, h_counts, masked, p32, &mr32, &nb32);
+        int want = sp->loop_mode == 2 ? 1 : (sp->loop_mode == 3 ? 2 : 0);
+        if (want != 2) sys_pack_blocks(B, T, 1, h_counts, masked, p16, &mr16, &nb16);
+        if (want == 0) {
+            const double c16 = WSp ? 4.3 : 7.0, c32 = WSp ? 5.3 : 13.5, lat32 = WSp ? 346.0 : 0.0;
+            const double e16 = mr16 == 1 ? nb16 * c16 : 1e30, e32 = std::max(lat32, nb32 * c32);
+            want = e16 < e32 ? 1 : 2;
+        }
+        if (want == 1 && mr16 == 1) { plan.swap(p16); plan_mr = 1; plan_nb = nb16; }
+        else { plan.swap(p32); plan_mr = 2; plan_nb = nb32; }
+    }
     // c-table rows of the window that starts at step `lo` (plain launches, outside the graphs: `lo` changes per window)
     auto open_window = [&](int lo) -> int {
         if (n_text > 1) return 0;
@@ -385,7 +409,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
         }
     } else {
         const void* kp[9] = {ws, counts, final_counts, coef, step_noise, stream, text_emb, init_noise, z};
-        const int ki[4] = {B, T, n_steps, cfg + 2 * (pipeline ? sp->loop_mode : 0) + 16 * n_text + 4096 * (WSp ? 1 : 0)};
+        const int ki[4] = {B, T, n_steps + 65536 * plan_nb, cfg + 2 * (pipeline ? plan_mr : 0) + 16 * n_text + 4096 * (WSp ? 1 : 0)};
         const float kf[2] = {guidance_scale, init_noise_sigma};
         uint64_t h = hash_ptrs(w, DEN_NPARAMS, 1469598103934665603ull);
         if (w_split) h = hash_ptrs(w_split, DEN_NPARAMS, h ^ 0x9e3779b97f4a7c15ull);
@@ -412,7 +436,8 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
             if (pipeline) {
                 // stage table of the persistent pipeline (pointers of this call's weights and workspace): built and uploaded
                 // once per key; the host copy stays alive in the sampler until the next rebuild
-                LADIFF_TRY(sys_build_stages(W, WSp ? WS : W, r.sys, B, T, WSp ? 0 : 1, sp->loop_mode == 2, sp->stages));
+                LADIFF_TRY(sys_build_stages(W, WSp ? WS : W, r.sys, plan_mr, plan_nb, sp->stages));
+                sp->blocks.clear();            // the descriptor area moved with the layout: upload again
                 LADIFF_HIP(hipMemcpyAsync(r.sys, sp->stages.data(), sp->stages.size(), hipMemcpyHostToDevice, s));
                 LADIFF_HIP(hipStreamSynchronize(s));
             } else {
@@ -438,12 +463,19 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
         }
         LADIFF_HIP(hipGraphLaunch(sp->setup, s));
         if (sp->ev0 == nullptr) { LADIFF_HIP(hipEventCreate(&sp->ev0)); LADIFF_HIP(hipEventCreate(&sp->ev1)); }
+        if (pipeline && (plan_mr != sp->plan_mr || plan_nb != sp->plan_nb || plan != sp->blocks)) {
+            // this call's block descriptors (a few KB; the runtime stages a pageable source before it returns)
+            if (!sp->blocks.empty()) LADIFF_HIP(hipStreamSynchronize(s));      // a copy from the old buffer may still be in flight
+            sp->blocks = plan; sp->plan_mr = plan_mr; sp->plan_nb = plan_nb;
+            LADIFF_HIP(hipMemcpyAsync(r.sys + sys_blocks_offset_floats(plan_mr, plan_nb), sp->blocks.data(), sp->blocks.size(),
+                                      hipMemcpyHostToDevice, s));
+        }
         for (int lo = 0; lo < n_steps; lo += r.window) {
             LADIFF_TRY(open_window(lo));
             if (lo == 0) LADIFF_HIP(hipEventRecord(sp->ev0, s));       // the loop itself: from the first step's first launch
             if (pipeline) {
                 LADIFF_TRY(launch_systolic_loop(W, r.sys, r.tables, den_cache_tkv(r.cache, B2, 1), den_cache_ctab(r.cache, B2, 1), r.window,
-                                                coef, step_noise, r.latents, counts, guidance_scale, B, T, lo, r.window, WSp ? 0 : 1, sp->loop_mode == 2, s));
+                                                coef, step_noise, r.latents, counts, guidance_scale, B, T, lo, r.window, WSp ? 0 : 1, plan_mr, plan_nb, s));
             } else {
                 for (int i = 0; i < r.window / sp->unroll; ++i) LADIFF_HIP(hipGraphLaunch(sp->exec, s));
             }
@@ -555,7 +587,18 @@ int ladiff_vae_decode(const float* const* w, const float* const* w_split, const 
     DecoderW W, WS;
     LADIFF_CHECK_ARG(load_weights(W, w) && z && lengths && feats && ws && B >= 0);
     if (w_split != nullptr) LADIFF_CHECK_ARG(load_weights(WS, w_split));
-    return vae_decode(W, w_split ? &WS : nullptr, z, lengths, counts, B, F, T, C, feats, (float*)ws, ws_bytes / sizeof(float), S(stream));
+    return vae_decode(W, w_split ? &WS : nullptr, z, lengths, counts, nullptr, B, F, F, T, C, feats, (float*)ws, ws_bytes / sizeof(float),
+                      S(stream));
+}
+
+int ladiff_vae_decode_bucket(const float* const* w, const float* const* w_split, const float* z, const int32_t* lengths,
+                             const int32_t* counts, const int32_t* out_index, int B, int F, int F_out, int T, int C, float* feats,
+                             void* ws, size_t ws_bytes, ladiff_stream_t stream) {
+    DecoderW W, WS;
+    LADIFF_CHECK_ARG(load_weights(W, w) && z && lengths && out_index && feats && ws && B >= 0);
+    if (w_split != nullptr) LADIFF_CHECK_ARG(load_weights(WS, w_split));
+    return vae_decode(W, w_split ? &WS : nullptr, z, lengths, counts, out_index, B, F, F_out, T, C, feats, (float*)ws,
+                      ws_bytes / sizeof(float), S(stream));
 }
 
 }  // extern "C"

@@ -19,9 +19,12 @@ size_t dec_ws_floats(int B, int F, int T) {
 
 // wsp != nullptr selects the bf16x3 matrix path (S-format copies of the weight matrices in `wsp`, GEMM operands in
 // S-format, LayerNorm as a row kernel after each fused GEMM); see denoiser.hip and common.h.
-int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int32_t* lengths, const int32_t* counts, int B,
-               int F, int T, int C, float* feats, float* ws, size_t ws_floats, hipStream_t s) {
+// out_index != nullptr: sample i is written to feats row block out_index[i] of a [*, F_out, C] tensor (frames < F only) - the
+// length-bucketed decode of a mixed batch, where each bucket runs with its own F.
+int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int32_t* lengths, const int32_t* counts,
+               const int32_t* out_index, int B, int F, int F_out, int T, int C, float* feats, float* ws, size_t ws_floats, hipStream_t s) {
     if (F < 1 || F > LADIFF_MAX_FRAMES || T < 1 || T > LADIFF_MAX_LATENTS || C < 1) return LADIFF_ERR_SHAPE;
+    if (out_index != nullptr && F_out < F) return LADIFF_ERR_SHAPE;
     if (ws_floats < dec_ws_floats(B, F, T)) return LADIFF_ERR_WORKSPACE;
     const int M = B * F;
     if (M == 0) return 0;
@@ -106,6 +109,7 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
     // final_layer + zero padded frames, written as [B, F, C]   ladiff_vae.py:356-360
     GemmArgs g = lin(cur, D, w.final_layer.w, w.final_layer.b, feats, C, M, C, D);
     g.row_len = lengths; g.rows_per_item = F;
+    g.item_out = out_index; g.out_rows_per_item = F_out;
     return launch_gemm(g, s);
 }
 

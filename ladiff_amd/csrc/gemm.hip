@@ -269,13 +269,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs p) {
             const int gr = arow_base + i * MT + MM::acc_row(lane, r);
             if (gr >= p.M) continue;
             bool zero = false;
-            if (p.row_len != nullptr) zero = (gr % p.rows_per_item) >= p.row_len[gr / p.rows_per_item];
+            size_t orow = gr;
+            if (p.row_len != nullptr) {
+                const int item = gr / p.rows_per_item, f = gr - item * p.rows_per_item;
+                zero = f >= p.row_len[item];
+                if (p.item_out != nullptr) orow = (size_t)p.item_out[item] * p.out_rows_per_item + f;
+            }
 #pragma unroll
             for (int j = 0; j < RN; ++j) {
                 const int gc = acol_base + j * MT;
                 if (gc < p.N) {
                     float v = act_apply(acc[i][j][r], p.post_act);
-                    p.Y[(size_t)gr * p.ldy + gc] = zero ? 0.f : v;
+                    p.Y[orow * p.ldy + gc] = zero ? 0.f : v;
                 }
             }
         }

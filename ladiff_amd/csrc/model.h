@@ -36,28 +36,27 @@ size_t linear_cross_attention_ws_floats(int B, int T, int N);
 void den_loop_io(float* ws, int rows, float** x, float** xs);
 
 size_t dec_ws_floats(int B, int F, int T);
-int vae_decode(const DecoderW& w, const DecoderW* w_split, const float* z, const int32_t* lengths, const int32_t* counts, int B, int F, int T,
-               int C, float* feats, float* ws, size_t ws_floats, hipStream_t s);
+int vae_decode(const DecoderW& w, const DecoderW* w_split, const float* z, const int32_t* lengths, const int32_t* counts,
+               const int32_t* out_index, int B, int F, int F_out, int T, int C, float* feats, float* ws, size_t ws_floats, hipStream_t s);
 
 size_t enc_ws_floats(int B, int F, int T, int C);
 int vae_encode(const EncoderW& w, const EncoderW* w_split, const float* features, const int32_t* lengths,
                const int32_t* counts, const float* eps, int B, int F, int T, int C, float* mu, float* sd, float* latent, float* ws,
                size_t ws_floats, hipStream_t s);
 
-// systolic.hip: the guided denoiser loop as one persistent weight-stationary pipeline (bf16x3 mode)
+// systolic.hip: the guided denoiser loop as one persistent weight-stationary pipeline (both arithmetic modes)
 #ifdef LADIFF_STAMPS
 extern unsigned long long* g_sys_stamps;
 #endif
 size_t sys_ws_floats(int B, int T);
 bool sys_supported(int B, int T, int cfg, bool split);
-int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int B, int T, int fp32, int rows16,
-                     std::vector<unsigned char>& host);
-size_t sys_stage_bytes(int B, int T);
+void sys_pack_blocks(int B, int T, int want_mr, const int32_t* h_counts, bool masked, std::vector<unsigned char>& out, int* mr, int* nb);
+int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR, int NB, std::vector<unsigned char>& host);
+size_t sys_blocks_offset_floats(int MR, int NB);
 size_t sys_status_offset_floats(int B, int T);
-int sys_row_tiles(int T, int want16);
 int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, const float* tkv, const float* ctab, int n_ctab,
                          const float* coef, const float* noise, float* lat, const int32_t* counts, float gscale, int B, int T,
-                         int step_lo, int n, int fp32, int rows16, hipStream_t s);
+                         int step_lo, int n, int fp32, int MR, int NB, hipStream_t s);
 
 // qkv_attn.hip: in_proj GEMM + self-attention of the denoiser's sa_block in one launch (bf16x3 mode, S-format in / out)
 int launch_qkv_attention(const float* x, const float* w, const float* bias, const float* text_kv, const float* tables,

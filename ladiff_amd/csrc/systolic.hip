@@ -32,6 +32,7 @@
 // Numerics: the same arithmetic as the launch-per-stage bf16x3 path (S-format operands, hi*hi + hi*lo + lo*hi on
 // v_mfma_f32_16x16x32_bf16, fp32 accumulation and fp32 everything else); only the summation order of the split products
 // differs (8 hidden slices instead of 4 K-slices).
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -65,8 +66,28 @@ struct Stage {                            // one per workgroup
     float* out;
 };
 
+// Geometry of one block, built on the host (sys_pack_blocks).  32-row tiles: both guidance branches of P prompts, T rows each
+// (the latent count masks keys).  16-row tiles: ONE guidance branch of as many prompts as fit with only their count[b] valid
+// latent rows (length-aware: padded latent rows never influence valid ones - they are masked as keys, every other op is
+// per row, and ladiff.py:559-566 zeroes them at the end - so they are not computed at all).
+struct BlockDesc {
+    int nrows, nsb, pad0, pad1;
+    int b2[16];                           // per sample-branch sx: text-cache row (-1: absent)
+    // attention stage, per tile row: sx | first tile row of sx << 8 | valid latent keys << 16 (0xff: counts[] at run time); the
+    // row's cross-attention / counts row (-1: padding)
+    int row_pk[32], row_b2[32];
+    int row_lat[32], row_t[32];           // latents row (prompt * T + t, -1: padding) and latent index of a tile row
+    // reduce stages: part q of NRED handles slot k = wave + 4 i -> tile row | latent index << 8 | latent count << 16 (0xff: run
+    // time), -1: no row; and the row's cross-attention table row
+    int part_pk[3][12], part_b2[3][12];
+    // tail: (prompt, latent) pair k = wave + 4 i -> latents row (-1: none), latent index, tile row of the conditional branch
+    int pair_lat[16], pair_t[16], pair_rc[16];
+};
+static_assert(NRED == 3, "BlockDesc::part_pk");
+
 struct SysArgs {
     const Stage* stages;
+    const BlockDesc* blocks;              // [NB]
     unsigned* flags;                      // [groups][NB][FLAG_SLOTS]
     unsigned* status;                     // [0] abort code (0 = ok), [1] diagnostic
     const float* tables;                  // time tables [n_total][9][1536]
@@ -171,12 +192,6 @@ __device__ __forceinline__ void publish(unsigned* flag, unsigned epoch) {
 __device__ __forceinline__ unsigned* flag_of(const SysArgs& p, int group, int b, int slot) {      // group = layer * 7 + Group
     return p.flags + ((size_t)(group * p.NB + b) * FLAG_SLOTS + slot) * FLAG_STRIDE;
 }
-
-// block geometry.  split = 0: block b = prompts b P .. b P + P - 1, rows (br P + pl) T + t (both guidance branches);
-// split = 1: block b = branch b & 1 of prompt group b >> 1, rows pl T + t.  sx = sample-branch index within the block.
-__device__ __forceinline__ int blk_nsb(const SysArgs& p) { return p.split ? p.P : 2 * p.P; }
-__device__ __forceinline__ int blk_prompt0(const SysArgs& p, int b) { return (p.split ? (b >> 1) : b) * p.P; }
-__device__ __forceinline__ int blk_branch(const SysArgs& p, int b, int sx_br) { return p.split ? (b & 1) : sx_br; }
 
 // ---------------------------------------------------------------- LDS images
 // S-format operand tile: row = KB blocks of 256 B, block = 8 hi slots + 8 lo slots of 16 B, slot index XORed with (row & 15)
@@ -389,7 +404,7 @@ __device__ __forceinline__ f32x4 sum8(const f32x4 (&pl)[NSLICE]) {       // fixe
 // the next block's loads and the early poll issued (a `vmcnt(0)` placed after them would wait for them as well).
 template <class R>
 struct Mid {
-    const SysArgs& p; const Stage& st; R& r; typename R::Pay& nxt;
+    const SysArgs& p; const Stage& st; R& r; typename R::Pay& nxt; typename R::Geo& gnxt; typename R::Geo& gnn;
     unsigned* pending; unsigned pending_epoch; bool have; int s2, b2, s3, b3;
     unsigned early; bool early_valid;
     __device__ __forceinline__ void before_barrier() const {
@@ -400,7 +415,11 @@ struct Mid {
             if (threadIdx.x == 0) __hip_atomic_store((gu32*)pending, pending_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             pending = nullptr;
         }
-        if constexpr (R::PREFETCH) { if (have) r.issue(s2, b2, nxt); }
+        // block geometry (descriptor words) is fetched TWO blocks ahead: what the next block's loads need arrived an
+        // iteration ago, so nothing here waits on a load issued in this phase
+        r.geo_fix(gnxt);
+        if constexpr (R::PREFETCH) { if (have) r.issue(s2, b2, gnxt, nxt); }
+        if (s3 < p.n_steps) r.geo(b3, gnn);
         early_valid = R::PREFETCH && s3 < p.n_steps;
         early = 0xffffffffu;
         if (early_valid && threadIdx.x < 64 && (int)(threadIdx.x & 63) < st.wait_n)
@@ -412,8 +431,15 @@ struct Mid {
 template <class R>
 __device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R& r, Ctl* ctl, int b0, int bstride) {
     typename R::Pay cur, nxt;
+    typename R::Geo gcur, gnxt, gnn;
     bool have = false;
     const int lane = threadIdx.x & 63;
+    if (b0 < p.NB) {
+        r.geo(b0, gcur);
+        r.geo(b0 + bstride < p.NB ? b0 + bstride : b0, gnxt);
+        r.geo_fix(gcur);
+        gnn = gnxt;
+    }
     unsigned* pending = nullptr;                                         // flag of the previous block, its stores still draining
     unsigned pending_epoch = 0;
     // The poll that decides whether the NEXT block can be prefetched was issued one iteration earlier (a flag load is a ~1 us
@@ -430,7 +456,7 @@ __device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R&
                 SYS_STAT_T0;
                 if (!wait_epoch(flag_of(p, st.wait_group, b, 0), st.wait_n, s + 1, p.status, ctl)) return;
                 SYS_STAT_WAIT;
-                r.issue(s, b, cur);
+                r.issue(s, b, gcur, cur);
             }
             SYS_STAMP(1);
             int s2 = s, b2 = b + bstride;
@@ -446,8 +472,9 @@ __device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R&
             __syncthreads();
             have = R::PREFETCH && ctl->ready != 0;
             SYS_STAMP(2);
-            Mid<R> mid{p, st, r, nxt, pending, pending_epoch, have, s2, b2, s3, b3, 0u, false};
-            r.compute(s, b, cur, mid);
+            Mid<R> mid{p, st, r, nxt, gnxt, gnn, pending, pending_epoch, have, s2, b2, s3, b3, 0u, false};
+            r.compute(s, b, gcur, cur, mid);
+            gcur = gnxt; gnxt = gnn;
             early = mid.early; early_valid = mid.early_valid;
             SYS_STAMP(4);
             if (have) {
@@ -467,86 +494,80 @@ __device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R&
 }
 
 // ---------------------------------------------------------------- roles
-// QKV: one head.  in_proj rows {q,k,v} x 64 of head `slice` on the block, then softmax(q k^T / 8) v over the T latent
-// keys of the sample (masked by its latent count), the text token and the time token.
+// QKV: one head.  in_proj rows {q,k,v} x 64 of head `slice` on the block, then softmax(q k^T / 8) v over the valid latent
+// keys of the row's sample-branch, the text token and the time token.  Geometry comes from the block descriptor (LDS copy).
 template <int MR, int AR>
 struct QkvRole {
-    static constexpr int RT = 16 * MR, QLD = 196, NI = MR + 1;            // score work items per thread: 2 lanes x rows x keys
+    static constexpr int RT = 16 * MR, QLD = 196, TK = LADIFF_MAX_LATENTS + 2;   // keys of a row: <= 8 latents, text, time
     static constexpr bool PREFETCH = true;
-    struct Pay { Rows256<MR> x; f32x4 xk[2]; int cnt; };
+    struct Geo { int gw, rb2, b2[2]; };                                  // descriptor word `tid` (+ its row's sample-branch); sample-branch of this thread's text slots
+    struct Pay { Rows256<MR> x; f32x4 xk[2]; };
     const SysArgs& p; const Stage& st;
-    char* atile; float *qt, *xt, *sc; int* cnt;
+    char* atile; float *qt, *xt; int* gd;
     WFrag<AR, 3, 8> wf;
     float bcol[3];
     __amdgpu_buffer_rsrc_t rin, rout;
     const float* tkv;
-    int h, T, P, nkeys, nsb, nrows;
-    int s_row[NI], s_j[NI], s_sx[NI], o_sx[2], x_br[2], x_pl[2], c_pl;
+    int h, T, nkeys;
 
     __device__ __forceinline__ QkvRole(const SysArgs& p_, const Stage& st_, char* lds) : p(p_), st(st_) {
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frow = lane & 15;
-        h = st.slice; T = p.T; P = p.P; nkeys = T + 2; nsb = blk_nsb(p); nrows = nsb * T;
+        h = st.slice; T = p.T; nkeys = T + 2;
         atile = lds;                                                     // [RT] x K=256 operand tile
         qt = reinterpret_cast<float*>(lds + tile_bytes<AR, 4>(RT));      // [RT][QLD] q | k | v (fp32)
-        xt = qt + RT * QLD;                                              // [2P + 1][128]: text k|v per sample-branch, time k|v last
-        sc = xt + 16 * 128;                                              // [RT][16] scores
-        cnt = reinterpret_cast<int*>(sc + RT * 16);                      // [2P] latent counts of the block's sample-branches
+        xt = qt + RT * QLD;                                              // [16][128]: text k|v per sample-branch, slot 15: time k|v
+        gd = reinterpret_cast<int*>(xt + 16 * 128);                      // [0] rows of this block, [1 + r] row_pk (counts resolved)
         // tile column tc = 48 wave + 16 j + frow: part tc / 64 (q, k, v), matrix row part * 256 + h * 64 + tc % 64
         load_w(wf, st.w0, D, 0, [&](int j) { const int tc = 48 * wave + 16 * j; return (tc >> 6) * 256 + h * 64 + (tc & 63); });
 #pragma unroll
         for (int j = 0; j < 3; ++j) { const int tc = 48 * wave + 16 * j + frow; bcol[j] = st.b0[(tc >> 6) * 256 + h * 64 + (tc & 63)]; }
         rin = rsrc_of(st.in0); rout = rsrc_of(st.out);
         tkv = p.tkv + (size_t)st.layer * 2 * p.B * 512;
-        // every index that does not depend on the block is computed once (integer divisions by run-time T / P are ~40
-        // instructions each): score items (row, key), output items (row, 4 columns), extra K|V slots
-#pragma unroll
-        for (int u = 0; u < NI; ++u) {
-            const int pair = (tid + 256 * u) >> 1;
-            s_row[u] = pair / nkeys; s_j[u] = pair - s_row[u] * nkeys; s_sx[u] = s_row[u] / T;
-            if (pair >= nrows * nkeys) s_row[u] = -1;
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int id = tid + 256 * u;
-            o_sx[u] = (id >> 4) / T;
-            const int sx = id >> 5;
-            x_br[u] = sx / P; x_pl[u] = sx - x_br[u] * P;
-        }
-        c_pl = tid % P;                                                  // tid < nsb: sample-branch whose count this thread fetches
     }
-    __device__ __forceinline__ void issue(int s, int b, Pay& y) {
+    __device__ __forceinline__ void geo(int b, Geo& g) {
+        const int tid = threadIdx.x;
+        const BlockDesc* d = p.blocks + b;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int sx = (tid + 256 * u) >> 5; g.b2[u] = sx < 15 ? d->b2[sx] : -1; }
+        // one load per value (two loads into one register from different branches would make the second wait for the first -
+        // and for every load issued before it)
+        const int* src = tid == 0 ? &d->nrows : &d->row_pk[tid <= RT ? tid - 1 : 0];
+        g.gw = *src;
+        g.rb2 = d->row_b2[tid >= 1 && tid <= RT ? tid - 1 : 0];
+    }
+    __device__ __forceinline__ void geo_fix(Geo& g) {                    // a latent count that lives on the device only (0xff)
+        const int tid = threadIdx.x;
+        if (tid >= 1 && tid <= RT && ((g.gw >> 16) & 0xff) == 0xff) {
+            int c = T;
+            if (g.rb2 >= 0 && p.counts != nullptr) { c = p.counts[g.rb2 % p.B]; c = c > T ? T : c; }
+            g.gw = (g.gw & 0xffff) | (c << 16);
+        }
+    }
+    __device__ __forceinline__ void issue(int s, int b, const Geo& g, Pay& y) {
         const int tid = threadIdx.x;
         const float* timekv = p.tables + (size_t)(p.step_lo + s) * DEN_STEP_STRIDE + st.layer * DEN_LAYER_STRIDE + DEN_OFF_TIME_KV;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {                                    // text / time K|V slices of this head: [nsb + 1][128]
+        for (int u = 0; u < 2; ++u) {                                    // text K|V slices of this head per sample-branch, slot 15: time
             const int f4 = tid + 256 * u, sx = f4 >> 5, c4 = (f4 & 31) * 4;
             y.xk[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (sx < nsb) {
-                const int prompt = blk_prompt0(p, b) + x_pl[u];
-                if (prompt < p.B) y.xk[u] = ld4(tkv + (size_t)(blk_branch(p, b, x_br[u]) * p.B + prompt) * 512 + (c4 < 64 ? c4 : 192 + c4) + h * 64);
-            } else if (sx == nsb) {
-                y.xk[u] = ld4(timekv + (c4 < 64 ? c4 : 192 + c4) + h * 64);
-            }
+            if (sx == 15) y.xk[u] = ld4(timekv + (c4 < 64 ? c4 : 192 + c4) + h * 64);
+            else if (g.b2[u] >= 0) y.xk[u] = ld4(tkv + (size_t)g.b2[u] * 512 + (c4 < 64 ? c4 : 192 + c4) + h * 64);
         }
-        y.cnt = T;
-        if (tid < nsb && p.counts != nullptr && blk_prompt0(p, b) + c_pl < p.B) { y.cnt = p.counts[blk_prompt0(p, b) + c_pl]; y.cnt = y.cnt > T ? T : y.cnt; }
         issue_rows<MR>(y.x, rin, (unsigned)b * RT * 1024);
     }
-    __device__ __forceinline__ void commit(const Pay& y) {
-        const int tid = threadIdx.x;
-        commit_rows<AR, 4, MR>(atile, 0, y.x);
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            if (((tid + 256 * u) >> 5) <= nsb) st4(xt + (tid + 256 * u) * 4, y.xk[u]);
-        if (tid < nsb) cnt[tid] = y.cnt;
-    }
+    __device__ __forceinline__ void commit(const Pay& y) { commit_rows<AR, 4, MR>(atile, 0, y.x); }
     template <class M>
-    __device__ __forceinline__ void compute(int s, int b, const Pay&, M& mid) {
+    __device__ __forceinline__ void compute(int s, int b, const Geo& g, const Pay& y, M& mid) {
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frow = lane & 15;
         f32x4 acc[MR][3];
         zero_acc(acc);
         mma<AR, 4, 3, 8, MR>(atile, wf, acc);
         SYS_STAMP(3);
+        // text / time K|V and the descriptor are read by the attention phases below, up to the END of the previous block's
+        // compute: they go to LDS here, behind the stage loop's barrier, not in commit()
+#pragma unroll
+        for (int u = 0; u < 2; ++u) st4(xt + (tid + 256 * u) * 4, y.xk[u]);
+        if (tid <= RT) gd[tid] = g.gw;
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -560,54 +581,50 @@ struct QkvRole {
         __syncthreads();
         mid.after_barrier();
         SYS_STAMP(6);
-        // scores: two lanes per (row, key), 32 of the 64 products each
+        const int nrows = gd[0];
+        // attention of a row on 16 lanes (4 of the head's 64 columns each): the scores are reduced across the lanes with DPP,
+        // softmax and the weighted sum of the values stay in registers - no barrier, no score tile
 #pragma unroll
-        for (int u = 0; u < NI; ++u) {
-            const int row = s_row[u], j = s_j[u], sx = s_sx[u], half = (tid + 256 * u) & 1;
-            float d = 0.f;
-            if (row >= 0) {
-                const float* kp = (j < T ? qt + (sx * T + j) * QLD + 64 : (j == T ? xt + sx * 128 : xt + nsb * 128)) + 32 * half;
-                const float* qp = qt + row * QLD + 32 * half;
+        for (int u = 0; u < MR; ++u) {
+            const int id = tid + 256 * u, row = id >> 4, c4 = (id & 15) * 4;
+            const bool live = row < nrows;
+            const int pk = live ? gd[1 + row] : 0, sx = pk & 0xff, r0 = (pk >> 8) & 0xff, nk = pk >> 16;
+            const f32x4 q4 = ld4(qt + (live ? row : 0) * QLD + c4);
+            const float* kt = qt + r0 * QLD + 64 + c4;                   // latent keys of the row's sample-branch; values 64 further
+            const float* xs = xt + sx * 128 + c4;                        // its text token (k | v)
+            const float* xm = xt + 15 * 128 + c4;                        // the time token
+            // every load below is unconditional (a masked or absent key reads a valid dummy address): straight-line code, all the
+            // LDS reads of a row in flight at once
+            float e[TK];
+            f32x4 k4[TK], v4[TK];
 #pragma unroll
-                for (int c = 0; c < 32; c += 4) {
-                    const f32x4 a = ld4(qp + c), k4 = ld4(kp + c);
-                    d = fmaf(a[0], k4[0], d); d = fmaf(a[1], k4[1], d); d = fmaf(a[2], k4[2], d); d = fmaf(a[3], k4[3], d);
-                }
+            for (int j = 0; j < TK; ++j) {
+                const bool on = live && j < nkeys && (j >= T || j < nk);     // keys >= the latent count: masked
+                const float* kp = j < T ? kt + j * QLD : (j == T ? xs : xm);
+                k4[j] = ld4(on ? kp : qt + c4);
+                v4[j] = ld4(on ? kp + 64 : qt + c4);
             }
-            d += __shfl_xor(d, 1, 64);
-            if (row >= 0 && half == 0) sc[row * 16 + j] = (j < T && j >= cnt[sx]) ? -INFINITY : d;
-        }
-        __syncthreads();
-        SYS_STAMP(7);
-        if (tid < nrows) {                                               // softmax over a row's T + 2 keys, one v_exp_f32 per probability
-            float e[LADIFF_MAX_LATENTS + 2];
+#pragma unroll
+            for (int j = 0; j < TK; ++j)
+                e[j] = row16_sum(fmaf(q4[0], k4[j][0], fmaf(q4[1], k4[j][1], fmaf(q4[2], k4[j][2], q4[3] * k4[j][3]))));
             float m = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < LADIFF_MAX_LATENTS + 2; ++j) { e[j] = j < nkeys ? sc[tid * 16 + j] : -INFINITY; m = fmaxf(m, e[j]); }
+            for (int j = 0; j < TK; ++j) {
+                const bool on = j < nkeys && (j >= T || j < nk);
+                e[j] = on ? e[j] : -INFINITY;
+                m = fmaxf(m, e[j]);
+            }
             float l = 0.f;
 #pragma unroll
-            for (int j = 0; j < LADIFF_MAX_LATENTS + 2; ++j) {
-                e[j] = j < nkeys ? __builtin_amdgcn_exp2f((e[j] - m) * 1.4426950408889634f) : 0.f;
-                l += e[j];
-            }
+            for (int j = 0; j < TK; ++j) { e[j] = __builtin_amdgcn_exp2f((e[j] - m) * 1.4426950408889634f); l += e[j]; }   // masked: exp2(-inf) = 0
             const float inv = 1.f / l;
-#pragma unroll
-            for (int j = 0; j < LADIFF_MAX_LATENTS + 2; ++j)
-                if (j < nkeys) sc[tid * 16 + j] = e[j] * inv;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < MR; ++u) {                                   // one thread per (row, 4 columns): o = sum_j p_j v_j
-            const int id = tid + 256 * u, row = id >> 4, c4 = (id & 15) * 4, sx = o_sx[u];
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
-            if (row < nrows) {
-                for (int j = 0; j < nkeys; ++j) {
-                    const float pj = sc[row * 16 + j];
-                    const float* vp = j < T ? qt + (sx * T + j) * QLD + 128 : (j == T ? xt + sx * 128 + 64 : xt + nsb * 128 + 64);
-                    const f32x4 v = ld4(vp + c4);
-                    o[0] = fmaf(pj, v[0], o[0]); o[1] = fmaf(pj, v[1], o[1]); o[2] = fmaf(pj, v[2], o[2]); o[3] = fmaf(pj, v[3], o[3]);
-                }
+#pragma unroll
+            for (int j = 0; j < TK; ++j) {
+                const float pj = e[j] * inv;                            // exactly 0 for a masked key
+                o[0] = fmaf(pj, v4[j][0], o[0]); o[1] = fmaf(pj, v4[j][1], o[1]); o[2] = fmaf(pj, v4[j][2], o[2]); o[3] = fmaf(pj, v4[j][3], o[3]);
             }
+            if (!live) o = f32x4{0.f, 0.f, 0.f, 0.f};
             st_sc1(rout, ((unsigned)b * RT + row) * 1024 + (h * 64 + c4) * 4, o);
         }
     }
@@ -618,6 +635,7 @@ template <int MR, int AR>
 struct OutRole {
     static constexpr int RT = 16 * MR, RPW = RT / 4;
     static constexpr bool PREFETCH = true;
+    struct Geo {};
     struct Pay { Rows256<MR> att; f32x4 res[RPW]; };
     const SysArgs& p; const Stage& st;
     char* atile; float* ct;
@@ -631,7 +649,9 @@ struct OutRole {
         bias = ld4(st.b0 + 4 * lane); gg = ld4(st.g + 4 * lane); bb = ld4(st.be + 4 * lane);
         ratt = rsrc_of(st.in0); rx = rsrc_of(st.in1); rout = rsrc_of(st.out);
     }
-    __device__ __forceinline__ void issue(int, int b, Pay& y) {
+    __device__ __forceinline__ void geo(int, Geo&) {}
+    __device__ __forceinline__ void geo_fix(Geo&) {}
+    __device__ __forceinline__ void issue(int, int b, const Geo&, Pay& y) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const unsigned base = (unsigned)b * RT * 1024;
         issue_rows<MR>(y.att, ratt, base);
@@ -640,7 +660,7 @@ struct OutRole {
     }
     __device__ __forceinline__ void commit(const Pay& y) { commit_rows<AR, 4, MR>(atile, 0, y.att); }
     template <class M>
-    __device__ __forceinline__ void compute(int s, int b, const Pay& y, M& mid) {
+    __device__ __forceinline__ void compute(int s, int b, const Geo&, const Pay& y, M& mid) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
         const unsigned base = (unsigned)b * RT * 1024;
         f32x4 acc[MR][4];
@@ -671,6 +691,7 @@ template <int MR, int ACT, int AR>
 struct MlpRole {
     static constexpr int RT = 16 * MR, RPW = RT / 4;
     static constexpr bool PREFETCH = true;
+    struct Geo {};
     struct Pay { Rows256<MR> x; };
     const SysArgs& p; const Stage& st;
     char *atile, *htile; float* ct;
@@ -692,10 +713,12 @@ struct MlpRole {
         rin = rsrc_of(st.in0); rout = rsrc_of(st.out);
         plane = (unsigned)st.slice * p.NB * RT * 1024;
     }
-    __device__ __forceinline__ void issue(int, int b, Pay& y) { issue_rows<MR>(y.x, rin, (unsigned)b * RT * 1024); }
+    __device__ __forceinline__ void geo(int, Geo&) {}
+    __device__ __forceinline__ void geo_fix(Geo&) {}
+    __device__ __forceinline__ void issue(int, int b, const Geo&, Pay& y) { issue_rows<MR>(y.x, rin, (unsigned)b * RT * 1024); }
     __device__ __forceinline__ void commit(const Pay& y) { commit_rows<AR, 4, MR>(atile, 0, y.x); }
     template <class M>
-    __device__ __forceinline__ void compute(int s, int b, const Pay&, M& mid) {
+    __device__ __forceinline__ void compute(int s, int b, const Geo&, const Pay&, M& mid) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, frow = lane & 15, fk = lane >> 4;
         const unsigned base = (unsigned)b * RT * 1024;
         f32x4 acc1[MR][2];
@@ -730,56 +753,51 @@ struct MlpRole {
     }
 };
 
-// rows [lo, hi) of a block handled by reduce part `part`: the 2 P T live rows split evenly
-__device__ __forceinline__ void part_rows(const SysArgs& p, int part, int& lo, int& hi) {
-    const int live = blk_nsb(p) * p.T, per = (live + NRED - 1) / NRED;
-    lo = part * per;
-    hi = lo + per < live ? lo + per : live;
-    if (lo > hi) lo = hi;
-}
-
 // RED2: X2 = LN2(X1 + sum_j partial_j + b2) + c[step, layer, sample | pad]
 template <int MR>
 struct Red2Role {
-    static constexpr int RT = 16 * MR, PQ = MR + 1;                       // rows per wave: 11 rows / 4 waves (MR 2), 6 / 4 (MR 1)
+    static constexpr int RT = 16 * MR, PQ = MR + 1;                       // rows per wave: <= 11 rows / 4 waves (MR 2), <= 6 / 4 (MR 1)
     static constexpr bool PREFETCH = true;
-    struct Pay { f32x4 pl[PQ][NSLICE], rs[PQ], tv[PQ], tp[PQ]; int cnt[PQ]; };
+    struct Geo { int pk[PQ], b2[PQ], row[PQ], t[PQ], cnt[PQ]; };          // slot wave + 4 q of this part: raw words, then decoded
+    struct Pay { f32x4 pl[PQ][NSLICE], rs[PQ], tv[PQ], tp[PQ]; };
     const SysArgs& p; const Stage& st;
     f32x4 bias, gg, bb;
     __amdgpu_buffer_rsrc_t rp, rx, rout;
-    int lo, hi, r_pl[PQ], r_br[PQ], r_t[PQ];
     unsigned pstride;
     __device__ __forceinline__ Red2Role(const SysArgs& p_, const Stage& st_, char*) : p(p_), st(st_) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int lane = threadIdx.x & 63;
         bias = ld4(st.b0 + 4 * lane); gg = ld4(st.g + 4 * lane); bb = ld4(st.be + 4 * lane);
         rp = rsrc_of(st.in0); rx = rsrc_of(st.in1); rout = rsrc_of(st.out);
-        part_rows(p, st.slice, lo, hi);
         pstride = (unsigned)p.NB * RT * 1024;
+    }
+    __device__ __forceinline__ void geo(int b, Geo& g) {
+        const int wave = threadIdx.x >> 6;
+        const BlockDesc* d = p.blocks + b;
 #pragma unroll
-        for (int q = 0; q < PQ; ++q) {                                   // this wave's rows lo + wave + 4 q
-            const int row = lo + wave + 4 * q, sb = row / p.T;
-            r_t[q] = row - sb * p.T; r_br[q] = sb / p.P; r_pl[q] = sb - r_br[q] * p.P;
+        for (int q = 0; q < PQ; ++q) { g.pk[q] = d->part_pk[st.slice][wave + 4 * q]; g.b2[q] = d->part_b2[st.slice][wave + 4 * q]; }
+    }
+    __device__ __forceinline__ void geo_fix(Geo& g) {
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+            g.row[q] = g.pk[q] < 0 ? -1 : (g.pk[q] & 0xff);
+            g.t[q] = (g.pk[q] >> 8) & 0xff;
+            g.cnt[q] = (g.pk[q] >> 16) & 0xff;
+            if (g.pk[q] < 0 || g.b2[q] < 0) g.cnt[q] = 0;
+            else if (g.cnt[q] == 0xff) g.cnt[q] = p.counts != nullptr ? p.counts[g.b2[q] % p.B] : 0x7fffffff;   // device-only count
         }
     }
-    __device__ __forceinline__ void issue(int s, int b, Pay& y) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
+    __device__ __forceinline__ void issue(int s, int b, const Geo& g, Pay& y) {
+        const int lane = threadIdx.x & 63, c = 4 * lane;
         const float* ct = p.ctab + ((size_t)st.layer * p.n_ctab + s) * (2 * p.B + 1) * D;
         const unsigned base = (unsigned)b * RT * 1024;
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
-            const int row = lo + wave + 4 * q;
-            if (row < hi) {
-                // the row's cross-attention vector is its sample's table row while t < latent count, the pad row otherwise:
-                // both candidates and the count are fetched side by side (a dependent address would be a second round trip)
-                const int prompt = blk_prompt0(p, b) + r_pl[q];
-                y.cnt[q] = 0;
-                y.tv[q] = ld4(ct + (size_t)(2 * p.B) * D + c);
-                y.tp[q] = y.tv[q];
-                if (prompt < p.B) {
-                    y.cnt[q] = 0x7fffffff;
-                    if (p.counts != nullptr) y.cnt[q] = p.counts[prompt];
-                    y.tv[q] = ld4(ct + (size_t)(blk_branch(p, b, r_br[q]) * p.B + prompt) * D + c);
-                }
+            const int row = g.row[q];
+            if (row >= 0) {
+                // the row's cross-attention vector is its sample's table row while t < latent count, the pad row otherwise
+                y.tp[q] = ld4(ct + (size_t)(2 * p.B) * D + c);
+                y.tv[q] = y.tp[q];
+                if (g.b2[q] >= 0 && g.t[q] < g.cnt[q]) y.tv[q] = ld4(ct + (size_t)g.b2[q] * D + c);
 #pragma unroll
                 for (int j = 0; j < NSLICE; ++j) y.pl[q][j] = ld_sc1(rp, j * pstride + base + row * 1024 + c * 4);
                 y.rs[q] = ld_sc1(rx, base + row * 1024 + c * 4);
@@ -788,22 +806,22 @@ struct Red2Role {
     }
     __device__ __forceinline__ void commit(const Pay&) {}
     template <class M>
-    __device__ __forceinline__ void compute(int, int b, const Pay& y, M& mid) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
+    __device__ __forceinline__ void compute(int, int b, const Geo& g, const Pay& y, M& mid) {
+        const int lane = threadIdx.x & 63, c = 4 * lane;
         const unsigned base = (unsigned)b * RT * 1024;
         if (mid.pending != nullptr) { mid.before_barrier(); __syncthreads(); }      // no barrier of its own in this stage
         mid.after_barrier();
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
-            const int row = lo + wave + 4 * q;
-            if (row < hi) {
+            const int row = g.row[q];
+            if (row >= 0) {
                 f32x4 v = sum8(y.pl[q]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[i] + y.rs[q][i];
                 float mean, rstd;
                 row_stats4(v, mean, rstd);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i] + (r_t[q] < y.cnt[q] ? y.tv[q][i] : y.tp[q][i]);
+                for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i] + y.tv[q][i];
                 st_sc1(rout, base + row * 1024 + c * 4, v);
             }
         }
@@ -815,13 +833,13 @@ template <int MR, int AR>
 struct StylRole {
     static constexpr int RT = 16 * MR, PQ = MR + 1;
     static constexpr bool PREFETCH = MR == 1;       // 256 weight registers + two images of 27 x 16 bytes per lane do not fit
+    struct Geo { int pk[PQ], row[PQ]; };                                 // tile row of slot wave + 4 q of this part (-1: none)
     struct Pay { f32x4 pl[PQ][NSLICE], rs[PQ], scl, shf; };
     const SysArgs& p; const Stage& st;
     char* atile; float* ct;
     WFrag<AR, 4, 8> wf;
     f32x4 bias2, bias, gg, bb;
     __amdgpu_buffer_rsrc_t rp, rx, rout;
-    int lo, hi;
     unsigned pstride;
     __device__ __forceinline__ StylRole(const SysArgs& p_, const Stage& st_, char* lds) : p(p_), st(st_) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -829,19 +847,27 @@ struct StylRole {
         load_w(wf, st.w0, D, 0, [&](int j) { return 64 * wave + 16 * j; });
         bias2 = ld4(st.b1 + 4 * lane); bias = ld4(st.b0 + 4 * lane); gg = ld4(st.g + 4 * lane); bb = ld4(st.be + 4 * lane);
         rp = rsrc_of(st.in0); rx = rsrc_of(st.in1); rout = rsrc_of(st.out);
-        part_rows(p, st.slice, lo, hi);
         pstride = (unsigned)p.NB * RT * 1024;
     }
-    __device__ __forceinline__ void issue(int s, int b, Pay& y) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
+    __device__ __forceinline__ void geo(int b, Geo& g) {
+        const int wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) g.pk[q] = p.blocks[b].part_pk[st.slice][wave + 4 * q];
+    }
+    __device__ __forceinline__ void geo_fix(Geo& g) {
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) g.row[q] = g.pk[q] < 0 ? -1 : (g.pk[q] & 0xff);
+    }
+    __device__ __forceinline__ void issue(int s, int b, const Geo& g, Pay& y) {
+        const int lane = threadIdx.x & 63, c = 4 * lane;
         const unsigned base = (unsigned)b * RT * 1024;
         const float* mod = p.tables + (size_t)(p.step_lo + s) * DEN_STEP_STRIDE + st.layer * DEN_LAYER_STRIDE + DEN_OFF_FFN_MOD;
         y.scl = ld4(mod + c); y.shf = ld4(mod + D + c);                  // AdaLN scale | shift of this step (time tables)
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
-            const int row = lo + wave + 4 * q;
+            const int row = g.row[q];
             y.rs[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (row < hi) {
+            if (row >= 0) {
 #pragma unroll
                 for (int j = 0; j < NSLICE; ++j) y.pl[q][j] = ld_sc1(rp, j * pstride + base + row * 1024 + c * 4);
                 y.rs[q] = ld_sc1(rx, base + row * 1024 + c * 4);
@@ -850,15 +876,15 @@ struct StylRole {
     }
     __device__ __forceinline__ void commit(const Pay&) {}
     template <class M>
-    __device__ __forceinline__ void compute(int s, int b, const Pay& y, M& mid) {
+    __device__ __forceinline__ void compute(int s, int b, const Geo& g, const Pay& y, M& mid) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
         const unsigned base = (unsigned)b * RT * 1024;
         const f32x4 scl = y.scl, shf = y.shf;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                                    // the 16 rows of the operand tile: local row wave + 4 q
-            const int lr = wave + 4 * q, row = lo + lr;
+            const int lr = wave + 4 * q;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (q < PQ && row < hi) {
+            if (q < PQ && g.row[q < PQ ? q : 0] >= 0) {
                 v = sum8(y.pl[q < PQ ? q : 0]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] += bias2[i];
@@ -879,8 +905,8 @@ struct StylRole {
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
-            const int lr = wave + 4 * q, row = lo + lr;
-            if (row < hi) {
+            const int lr = wave + 4 * q, row = g.row[q];
+            if (row >= 0) {
                 f32x4 v = ld4(ct + lr * CLD + c);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[i] + y.rs[q][i];
@@ -895,11 +921,13 @@ template <int MR, int AR>
 struct SkipRole {
     static constexpr int RT = 16 * MR;
     static constexpr bool PREFETCH = true;
+    struct Geo {};
     struct Pay { Rows256<MR> x, k; };
     const SysArgs& p; const Stage& st;
     char* atile; float* ct;
     WFrag<AR, 2, 16> wf;
     __amdgpu_buffer_rsrc_t rx, rs, rout;
+    f32x4 bias;                                                          // columns n0 + 4 (tid & 31) ..: the same for both of a thread's rows
     int n0;
     __device__ __forceinline__ SkipRole(const SysArgs& p_, const Stage& st_, char* lds) : p(p_), st(st_) {
         const int wave = threadIdx.x >> 6;
@@ -907,14 +935,17 @@ struct SkipRole {
         n0 = st.slice * 128;
         load_w(wf, st.w0, 2 * D, 0, [&](int j) { return n0 + 32 * wave + 16 * j; });
         rx = rsrc_of(st.in0); rs = rsrc_of(st.in1); rout = rsrc_of(st.out);
+        bias = ld4(st.b0 + n0 + (threadIdx.x & 31) * 4);
     }
-    __device__ __forceinline__ void issue(int, int b, Pay& y) {
+    __device__ __forceinline__ void geo(int, Geo&) {}
+    __device__ __forceinline__ void geo_fix(Geo&) {}
+    __device__ __forceinline__ void issue(int, int b, const Geo&, Pay& y) {
         issue_rows<MR>(y.x, rx, (unsigned)b * RT * 1024);
         issue_rows<MR>(y.k, rs, (unsigned)b * RT * 1024);
     }
     __device__ __forceinline__ void commit(const Pay& y) { commit_rows<AR, 8, MR>(atile, 0, y.x); commit_rows<AR, 8, MR>(atile, 4, y.k); }
     template <class M>
-    __device__ __forceinline__ void compute(int, int b, const Pay&, M& mid) {
+    __device__ __forceinline__ void compute(int, int b, const Geo&, const Pay&, M& mid) {
         const int tid = threadIdx.x, wave = tid >> 6;
         const unsigned base = (unsigned)b * RT * 1024;
         f32x4 acc[MR][2];
@@ -928,41 +959,34 @@ struct SkipRole {
         for (int u = 0; u < 2 * MR; ++u) {                               // (row, 4 columns) of this half
             const int id = tid + 256 * u, row = id >> 5, cc = n0 + (id & 31) * 4;
             f32x4 v = ld4(ct + row * CLD + cc);
-            const f32x4 bv = ld4(st.b0 + cc);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] += bv[i];
+            for (int i = 0; i < 4; ++i) v[i] += bias[i];
             st_sc1(rout, base + row * 1024 + cc * 4, v);
         }
     }
 };
 
 // TAIL: encoder.norm on both branches, guidance, scheduler step, latents, next step's network input (x = latents + pe).
-// A tail works on UNITS of P prompts: unit u = block u (both branches in one block) or blocks 2u (unconditional rows) and
-// 2u + 1 (conditional rows) when the blocks are split by branch.  Tail workgroup k owns the units u = k (mod NTAIL).
+// A tail works on UNITS: unit u = block u when a block holds both guidance branches (32-row tiles: unconditional rows first,
+// the conditional row of (prompt, t) nrows / 2 further), or blocks 2u (unconditional) and 2u + 1 (conditional, same row) when
+// blocks hold one branch (16-row tiles).  Tail workgroup k owns the units u = k (mod NTAIL).
 template <int MR>
 struct TailRole {
-    static constexpr int RT = 16 * MR, NQ = 4;                           // (prompt, latent) pairs per wave: P T <= 16
-    struct Pay { f32x4 eu[NQ], ec[NQ], lt[NQ], zz[NQ]; };
+    static constexpr int RT = 16 * MR, NQ = 4;                           // (prompt, latent) pairs per wave: <= 16 per unit
+    struct Geo { int lat[NQ], t[NQ], rc[NQ]; };                         // latent row, position, conditional-branch row of pair q
+    struct Pay { f32x4 eu[NQ], ec[NQ], lt[NQ], zz[NQ], pe[NQ]; };
     const SysArgs& p; const Stage& st;
-    f32x4 gg, bb, pev[NQ];
+    f32x4 gg, bb;
     __amdgpu_buffer_rsrc_t rin, rout;
-    int T, P, t_pl[NQ], t_t[NQ];
+    int T;
     __device__ __forceinline__ TailRole(const SysArgs& p_, const Stage& st_, char*) : p(p_), st(st_) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
-        T = p.T; P = p.P;
+        const int lane = threadIdx.x & 63, c = 4 * lane;
+        T = p.T;
         gg = ld4(p.ng + c); bb = ld4(p.nb + c);
         rin = rsrc_of(st.in0); rout = rsrc_of(st.out);
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            const int q = wave + 4 * i;
-            t_pl[i] = q / T; t_t[i] = q - t_pl[i] * T;
-            pev[i] = ld4(p.pe + (size_t)t_t[i] * D + c);
-        }
     }
     __device__ __forceinline__ int blk_u(int u) const { return p.split ? 2 * u : u; }
     __device__ __forceinline__ int blk_c(int u) const { return p.split ? 2 * u + 1 : u; }
-    __device__ __forceinline__ int row_u(int pl, int t) const { return pl * T + t; }
-    __device__ __forceinline__ int row_c(int pl, int t) const { return (p.split ? pl : P + pl) * T + t; }
     __device__ __forceinline__ void publish_unit(int u, unsigned epoch) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -973,19 +997,19 @@ struct TailRole {
         }
     }
     // local step 0: the first network input from the latents the prologue left (plain memory of earlier kernels); every row
-    // of the blocks is written (rows of absent prompts and the tile's padding rows: zero)
+    // of the blocks is written (padding rows: zero)
     __device__ __forceinline__ void prime(int nu) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
-        const int nsb = blk_nsb(p);
         for (int u = st.slice; u < nu; u += NTAIL) {
             for (int half = 0; half < (p.split ? 2 : 1); ++half) {
                 const int b = p.split ? 2 * u + half : u;
+                const BlockDesc* d = p.blocks + b;
                 const unsigned base = (unsigned)b * RT * 1024;
                 for (int q = wave; q < RT; q += 4) {
                     f32x4 xn = {0.f, 0.f, 0.f, 0.f};
-                    const int sb = q / T, t = q - sb * T, pl = p.split ? sb : sb % P, prompt = u * P + pl;
-                    if (sb < nsb && prompt < p.B) {
-                        const f32x4 l = ld4(p.lat + ((size_t)prompt * T + t) * D + c), pe = ld4(p.pe + (size_t)t * D + c);
+                    const int lat = d->row_lat[q];
+                    if (lat >= 0) {
+                        const f32x4 l = ld4(p.lat + (size_t)lat * D + c), pe = ld4(p.pe + (size_t)d->row_t[q] * D + c);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) xn[i] = l[i] + pe[i];
                     }
@@ -995,33 +1019,39 @@ struct TailRole {
             publish_unit(u, 1);
         }
     }
-    __device__ __forceinline__ void issue(int s, int u, Pay& y) {
+    __device__ __forceinline__ void geo(int u, Geo& g) {
+        const int wave = threadIdx.x >> 6;
+        const BlockDesc* d = p.blocks + blk_u(u);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) { const int q = wave + 4 * i; g.lat[i] = d->pair_lat[q]; g.t[i] = d->pair_t[q]; g.rc[i] = d->pair_rc[q]; }
+    }
+    __device__ __forceinline__ void issue(int s, int u, const Geo& g, Pay& y) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
         const unsigned bu = (unsigned)blk_u(u) * RT * 1024, bc = (unsigned)blk_c(u) * RT * 1024;
         const int step = p.step_lo + s;
         const float kn = p.coef[(size_t)step * LADIFF_COEF_STRIDE + 5];
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            const int q = wave + 4 * i, prompt = u * P + t_pl[i];
+            const int q = wave + 4 * i;
             y.zz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (q < P * T && prompt < p.B) {
-                const size_t lrow = (size_t)prompt * T + t_t[i];
-                y.eu[i] = ld_sc1(rin, bu + row_u(t_pl[i], t_t[i]) * 1024 + c * 4);
-                y.ec[i] = ld_sc1(rin, bc + row_c(t_pl[i], t_t[i]) * 1024 + c * 4);
-                y.lt[i] = ld4(p.lat + lrow * D + c);
-                if (p.noise != nullptr && kn != 0.f) y.zz[i] = ld4(p.noise + ((size_t)step * p.B * T + lrow) * D + c);
+            if (g.lat[i] >= 0) {
+                y.eu[i] = ld_sc1(rin, bu + q * 1024 + c * 4);
+                y.ec[i] = ld_sc1(rin, bc + g.rc[i] * 1024 + c * 4);
+                y.lt[i] = ld4(p.lat + (size_t)g.lat[i] * D + c);
+                y.pe[i] = ld4(p.pe + (size_t)g.t[i] * D + c);
+                if (p.noise != nullptr && kn != 0.f) y.zz[i] = ld4(p.noise + ((size_t)step * p.B * T + g.lat[i]) * D + c);
             }
         }
     }
-    __device__ __forceinline__ void compute(int s, int u, Pay& y) {
+    __device__ __forceinline__ void compute(int s, int u, const Geo& g, Pay& y) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
         const unsigned bu = (unsigned)blk_u(u) * RT * 1024, bc = (unsigned)blk_c(u) * RT * 1024;
         const float* cf = p.coef + (size_t)(p.step_lo + s) * LADIFF_COEF_STRIDE;
         const float sa = cf[0], sb = cf[1], kx0 = cf[2], kx = cf[3], ke = cf[4], kn = cf[5];
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            const int q = wave + 4 * i, prompt = u * P + t_pl[i];
-            if (q < P * T && prompt < p.B) {
+            const int q = wave + 4 * i;
+            if (g.lat[i] >= 0) {
                 f32x4 eu = y.eu[i], ec = y.ec[i], l = y.lt[i], xn;
                 float mean, rstd;
                 row_stats4(eu, mean, rstd);
@@ -1035,11 +1065,11 @@ struct TailRole {
                     const float e = eu[k] + p.gscale * (ec[k] - eu[k]);
                     const float x0 = (l[k] - sb * e) / sa;
                     l[k] = kx0 * x0 + kx * l[k] + ke * e + kn * y.zz[i][k];
-                    xn[k] = l[k] + pev[i][k];
+                    xn[k] = l[k] + y.pe[i][k];
                 }
-                st4(p.lat + ((size_t)prompt * T + t_t[i]) * D + c, l);
-                st_sc1(rout, bu + row_u(t_pl[i], t_t[i]) * 1024 + c * 4, xn);        // after the last step nobody reads it
-                st_sc1(rout, bc + row_c(t_pl[i], t_t[i]) * 1024 + c * 4, xn);
+                st4(p.lat + (size_t)g.lat[i] * D + c, l);
+                st_sc1(rout, bu + q * 1024 + c * 4, xn);               // after the last step nobody reads it
+                st_sc1(rout, bc + g.rc[i] * 1024 + c * 4, xn);
             }
         }
     }
@@ -1052,6 +1082,7 @@ struct TailRole {
 template <int MR>
 __device__ __forceinline__ void tail_loop(const SysArgs& p, const Stage& st, TailRole<MR>& r, Ctl* ctl) {
     typename TailRole<MR>::Pay cur, nxt;
+    typename TailRole<MR>::Geo gcur, gnxt;
     bool have = false;
     const int lane = threadIdx.x & 63, u0 = st.slice;
     const int nu = p.split ? p.NB / 2 : p.NB;
@@ -1062,6 +1093,8 @@ __device__ __forceinline__ void tail_loop(const SysArgs& p, const Stage& st, Tai
         return (const gu32*)flag_of(p, st.wait_group, b, 0) + (lane < st.wait_n ? lane : lane - st.wait_n) * FLAG_STRIDE;
     };
     r.prime(nu);
+    typename TailRole<MR>::Geo gnn;
+    if (u0 < nu) { r.geo(u0, gcur); r.geo(u0 + NTAIL < nu ? u0 + NTAIL : u0, gnxt); gnn = gnxt; }
     for (int s = 0; s < p.n_steps; ++s)
         for (int u = u0; u < nu; u += NTAIL) {
             if (!have) {
@@ -1089,7 +1122,7 @@ __device__ __forceinline__ void tail_loop(const SysArgs& p, const Stage& st, Tai
                 }
                 __syncthreads();
                 if (ctl->abort != 0) return;
-                r.issue(s, u, cur);
+                r.issue(s, u, gcur, cur);
             }
             int s2 = s, u2 = u + NTAIL;
             if (u2 >= nu) { s2 = s + 1; u2 = u0; }
@@ -1102,10 +1135,14 @@ __device__ __forceinline__ void tail_loop(const SysArgs& p, const Stage& st, Tai
             }
             __syncthreads();
             have = ctl->ready != 0;
-            if (have) r.issue(s2, u2, nxt);
-            r.compute(s, u, cur);
+            if (have) r.issue(s2, u2, gnxt, nxt);
+            int s3 = s2, u3 = u2 + NTAIL;
+            if (u3 >= nu) { s3 = s2 + 1; u3 = u0; }
+            if (s3 < p.n_steps) r.geo(u3, gnn);                          // geometry two units ahead: its consumers never wait for it
+            r.compute(s, u, gcur, cur);
             r.publish_unit(u, s + 2);
             if (have) cur = nxt;
+            gcur = gnxt; gnxt = gnn;
         }
 }
 
@@ -1137,27 +1174,29 @@ unsigned long long* g_sys_stamps = nullptr;
 namespace {
 struct SysLayout {
     size_t blk;                   // floats of one [NB][RT][256] buffer
-    size_t off_stages, off_flags, off_status, off_xin0, off_xs, off_xo, off_att, off_x1, off_x2, off_pc, off_pe, total;
-    int nwg, NB, P, split;
+    size_t off_stages, off_blocks, off_flags, off_status, off_xin0, off_xs, off_xo, off_att, off_x1, off_x2, off_pc, off_pe, total;
+    int nwg, NB, split;
 };
-SysLayout sys_layout(int B, int T, int MR) {
+constexpr int NWG = NL * (4 + 1 + NSLICE + NRED + NSLICE + NRED) + 2 * NSKIP + NTAIL;
+// 32-row tiles: P prompts per block, both guidance branches, T rows each
+int prompts_per_block32(int T) { int P = 32 / (2 * T); return P > 7 ? 7 : (P < 1 ? 1 : P); }   // QKV parks <= 14 text K|V slots
+int nb32(int B, int T) { const int P = prompts_per_block32(T); return (B + P - 1) / P; }
+// 16-row tiles, worst case of the packing (every prompt with all T rows): floor(16 / T) prompts (<= 8) per branch block
+int nb16_max(int B, int T) { int P = 16 / T; P = P > 8 ? 8 : (P < 1 ? 1 : P); return 2 * ((B + P - 1) / P); }
+
+SysLayout sys_layout(int MR, int NB) {
     SysLayout L;
     const int RT = 16 * MR;
-    // 16-row tiles: a block is ONE guidance branch of P prompts (P T <= 16 rows; the two branches of a prompt only meet in the
-    // tail), 32-row tiles: both branches of P prompts (2 P T <= 32)
     L.split = MR == 1 ? 1 : 0;
-    int P = L.split ? RT / T : RT / (2 * T);
-    if (P > 7) P = 7;             // the QKV stage parks (2P + 1) x 128 floats of extra K|V through 512 thread slots
-    if (P < 1) P = 1;
-    L.P = P;
-    L.NB = (B + P - 1) / P * (L.split ? 2 : 1);
-    L.nwg = NL * (4 + 1 + NSLICE + NRED + NSLICE + NRED) + 2 * NSKIP + NTAIL;
-    L.blk = (size_t)L.NB * RT * D;
+    L.NB = NB;
+    L.nwg = NWG;
+    L.blk = (size_t)NB * RT * D;
     size_t off = 0;
     auto take = [&](size_t floats) { const size_t o = off; off += (floats + 63) / 64 * 64; return o; };
     L.off_stages = take((size_t)256 * sizeof(Stage) / sizeof(float));
-    L.off_status = take(64);      // before the flags: its offset must not depend on the block geometry (ladiff_reverse_status)
-    L.off_flags = take((size_t)NL * GROUPS_PER_LAYER * L.NB * FLAG_SLOTS * FLAG_STRIDE);
+    L.off_status = take(64);      // before everything sized by the block geometry: ladiff_reverse_status reads it at a fixed offset
+    L.off_blocks = take((size_t)NB * sizeof(BlockDesc) / sizeof(float));
+    L.off_flags = take((size_t)NL * GROUPS_PER_LAYER * NB * FLAG_SLOTS * FLAG_STRIDE);
     L.off_xin0 = take(L.blk);
     L.off_xs = take(NSKIP * L.blk);
     L.off_xo = take(NL * L.blk);
@@ -1171,10 +1210,10 @@ SysLayout sys_layout(int B, int T, int MR) {
 }
 }  // namespace
 
-// rows per block: 32 (three prompts of five latents, both branches) while the stages' time per block leaves the loop
-// latency-bound; 16 (one prompt) is the low-latency variant
-int sys_row_tiles(int T, int want16) { return (want16 && T <= 16) ? 1 : 2; }
-size_t sys_ws_floats(int B, int T) { const size_t a = sys_layout(B, T, 1).total, b = sys_layout(B, T, 2).total; return a > b ? a : b; }
+size_t sys_ws_floats(int B, int T) {
+    const size_t a = sys_layout(1, nb16_max(B, T)).total, b = sys_layout(2, nb32(B, T)).total;
+    return a > b ? a : b;
+}
 
 bool sys_supported(int B, int T, int cfg, bool split) {
     (void)split;                  // both arithmetic modes have a pipeline kernel
@@ -1182,16 +1221,99 @@ bool sys_supported(int B, int T, int cfg, bool split) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    return cus >= sys_layout(B, T, 2).nwg;       // every stage needs a CU of its own, all resident at once
+    return cus >= NWG;            // every stage needs a CU of its own, all resident at once
+}
+
+// Block geometry for this call (host).  h_counts = the latent counts on the HOST (or NULL); masked = the call has device counts.
+//   MR 2: blocks of P consecutive prompts, both branches, T rows per prompt; the count only masks keys (cnt = -1 when the host
+//         does not know it: the kernel reads counts[] itself).
+//   MR 1: LENGTH-AWARE packing - prompts sorted by latent count, a block = one guidance branch of as many prompts as fit in 16
+//         rows with ONLY their count[b] valid rows (padded latent rows are never computed); needs the counts on the host.
+// Returns the plan: `blocks`, and in `mr` the tile size actually planned (MR 1 falls back to 2 when the counts are device-only).
+void sys_pack_blocks(int B, int T, int want_mr, const int32_t* h_counts, bool masked, std::vector<unsigned char>& out, int* mr, int* nb) {
+    std::vector<BlockDesc> blocks;
+    auto count_of = [&](int b) { int c = (masked && h_counts) ? h_counts[b] : T; return c > T ? T : (c < 1 ? 1 : c); };
+    int MR = want_mr;
+    if (MR == 1 && masked && h_counts == nullptr) MR = 2;
+    auto fresh = [] { BlockDesc d; std::memset(&d, 0, sizeof(d)); for (int i = 0; i < 16; ++i) d.b2[i] = -1;
+                      for (int r = 0; r < 32; ++r) { d.row_b2[r] = -1; d.row_lat[r] = -1; } return d; };
+    // derived tables: the reduce parts' slots (the live rows split evenly over NRED parts) and the tail's (prompt, latent) pairs
+    auto finish = [&](BlockDesc& d, const int* row_cnt, int npairs, int rc_off) {
+        const int per = (d.nrows + NRED - 1) / NRED;
+        for (int part = 0; part < NRED; ++part) {
+            const int lo = part * per < d.nrows ? part * per : d.nrows, hi = lo + per < d.nrows ? lo + per : d.nrows;
+            for (int k = 0; k < 12; ++k) {
+                const int r = lo + k;
+                d.part_pk[part][k] = -1; d.part_b2[part][k] = -1;
+                if (r < hi) {
+                    d.part_pk[part][k] = r | d.row_t[r] << 8 | (row_cnt[r] < 0 ? 0xff : row_cnt[r]) << 16;
+                    d.part_b2[part][k] = d.row_b2[r];
+                }
+            }
+        }
+        for (int q = 0; q < 16; ++q) {
+            d.pair_lat[q] = -1; d.pair_t[q] = 0; d.pair_rc[q] = 0;
+            if (q < npairs) { d.pair_lat[q] = d.row_lat[q]; d.pair_t[q] = d.row_t[q]; d.pair_rc[q] = q + rc_off; }
+        }
+    };
+    if (MR == 2) {
+        const int P = prompts_per_block32(T);
+        for (int p0 = 0; p0 < B; p0 += P) {
+            const int Pb = B - p0 < P ? B - p0 : P;
+            BlockDesc d = fresh();
+            d.nsb = 2 * Pb; d.nrows = 2 * Pb * T;
+            int row_cnt[32];
+            for (int br = 0; br < 2; ++br)
+                for (int pl = 0; pl < Pb; ++pl) {
+                    const int sx = br * Pb + pl, prompt = p0 + pl;
+                    const int cnt = masked ? (h_counts ? count_of(prompt) : -1) : T;
+                    d.b2[sx] = br * B + prompt;
+                    for (int t = 0; t < T; ++t) {
+                        const int r = sx * T + t;
+                        d.row_pk[r] = sx | (sx * T) << 8 | (cnt < 0 ? 0xff : cnt) << 16;
+                        d.row_t[r] = t; d.row_b2[r] = br * B + prompt; row_cnt[r] = cnt; d.row_lat[r] = prompt * T + t;
+                    }
+                }
+            finish(d, row_cnt, d.nrows / 2, d.nrows / 2);                // conditional row of a pair: nrows / 2 further
+            blocks.push_back(d);
+        }
+    } else {
+        std::vector<int> order(B);
+        for (int b = 0; b < B; ++b) order[b] = b;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return count_of(a) > count_of(b); });
+        size_t i = 0;
+        while (i < order.size()) {
+            std::vector<int> group;
+            int rows = 0;
+            while (i < order.size() && group.size() < 8 && rows + count_of(order[i]) <= 16) { rows += count_of(order[i]); group.push_back(order[i]); ++i; }
+            for (int br = 0; br < 2; ++br) {
+                BlockDesc d = fresh();
+                d.nsb = (int)group.size(); d.nrows = rows;
+                int r0 = 0, row_cnt[32];
+                for (int sx = 0; sx < (int)group.size(); ++sx) {
+                    const int prompt = group[sx], cnt = count_of(prompt);
+                    d.b2[sx] = br * B + prompt;
+                    for (int t = 0; t < cnt; ++t) {
+                        const int r = r0 + t;
+                        d.row_pk[r] = sx | r0 << 8 | cnt << 16;
+                        d.row_t[r] = t; d.row_b2[r] = br * B + prompt; row_cnt[r] = cnt; d.row_lat[r] = prompt * T + t;
+                    }
+                    r0 += cnt;
+                }
+                finish(d, row_cnt, rows, 0);                             // the conditional branch is the next block, same row
+                blocks.push_back(d);
+            }
+        }
+    }
+    out.resize(blocks.size() * sizeof(BlockDesc));
+    std::memcpy(out.data(), blocks.data(), out.size());
+    *mr = MR; *nb = (int)blocks.size();
 }
 
 // Builds the stage table (host) for this call's pointers.  `ws` = the systolic region of the reverse workspace.
-int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int B, int T, int fp32, int rows16,
-                     std::vector<unsigned char>& host) {
+int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR, int NB, std::vector<unsigned char>& host) {
     // WS = the S-format weight table in bf16x3 mode; in fp32 mode the caller passes the fp32 table twice
-    const int MR = fp32 ? 2 : sys_row_tiles(T, rows16), RT = 16 * MR;
-    (void)RT;
-    const SysLayout L = sys_layout(B, T, MR);
+    const SysLayout L = sys_layout(MR, NB);
     std::vector<Stage> st;
     float* xin0 = ws + L.off_xin0;
     float* att = ws + L.off_att; float* x1 = ws + L.off_x1; float* x2 = ws + L.off_x2;
@@ -1270,41 +1392,43 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int B, 
 // the workspace (sys_upload_stages); `ctab` holds the hoisted cross-attention rows of n_ctab >= n steps starting at step_lo.
 int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, const float* tkv, const float* ctab, int n_ctab,
                          const float* coef, const float* noise, float* lat, const int32_t* counts, float gscale, int B, int T,
-                         int step_lo, int n, int fp32, int rows16, hipStream_t s) {
-    const int MR = fp32 ? 2 : sys_row_tiles(T, rows16);
-    const SysLayout L = sys_layout(B, T, MR);
+                         int step_lo, int n, int fp32, int MR, int NB, hipStream_t s) {
+    const SysLayout L = sys_layout(MR, NB);
     static bool attr_set = false;
     if (!attr_set) {
-        LADIFF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(systolic_loop_kernel<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       SYS_LDS_BYTES));
-        LADIFF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(systolic_loop_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       SYS_LDS_BYTES));
-        LADIFF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(systolic_loop_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       SYS_LDS_BYTES));
+        const void* k[4] = {reinterpret_cast<const void*>(systolic_loop_kernel<1, 0>), reinterpret_cast<const void*>(systolic_loop_kernel<2, 0>),
+                            reinterpret_cast<const void*>(systolic_loop_kernel<1, 1>), reinterpret_cast<const void*>(systolic_loop_kernel<2, 1>)};
+        for (int i = 0; i < 4; ++i) LADIFF_HIP(hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, SYS_LDS_BYTES));
         attr_set = true;
     }
     SysArgs a;
     a.stages = reinterpret_cast<const Stage*>(ws + L.off_stages);
+    a.blocks = reinterpret_cast<const BlockDesc*>(ws + L.off_blocks);
     a.flags = reinterpret_cast<unsigned*>(ws + L.off_flags);
     a.status = reinterpret_cast<unsigned*>(ws + L.off_status);
     a.tables = tables; a.tkv = tkv; a.ctab = ctab; a.coef = coef; a.noise = noise; a.pe = W.query_pe; a.ng = W.norm.g; a.nb = W.norm.b;
-    a.lat = lat; a.counts = counts; a.gscale = gscale; a.B = B; a.T = T; a.P = L.P; a.NB = L.NB; a.step_lo = step_lo; a.n_steps = n;
+    a.lat = lat; a.counts = counts; a.gscale = gscale; a.B = B; a.T = T; a.P = 0; a.NB = NB; a.step_lo = step_lo; a.n_steps = n;
     a.n_ctab = n_ctab;
     a.split = L.split;
     a.stamps = nullptr;
 #ifdef LADIFF_STAMPS
     a.stamps = g_sys_stamps;
 #endif
-    // the abort word and the flags are contiguous: one memset node, a multiple of 16 bytes
-    LADIFF_HIP(hipMemsetAsync(a.status, 0, (L.off_xin0 - L.off_status) * sizeof(float), s));
-    if (fp32) hipLaunchKernelGGL((systolic_loop_kernel<2, 1>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
-    else if (MR == 1) hipLaunchKernelGGL((systolic_loop_kernel<1, 0>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
-    else hipLaunchKernelGGL((systolic_loop_kernel<2, 0>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
+    // the abort word and the flags: two memset nodes (the block descriptors sit between them)
+    LADIFF_HIP(hipMemsetAsync(a.status, 0, 64 * sizeof(float), s));
+    LADIFF_HIP(hipMemsetAsync(a.flags, 0, (L.off_xin0 - L.off_flags) * sizeof(float), s));
+    if (fp32) {
+        if (MR == 1) hipLaunchKernelGGL((systolic_loop_kernel<1, 1>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
+        else hipLaunchKernelGGL((systolic_loop_kernel<2, 1>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
+    } else {
+        if (MR == 1) hipLaunchKernelGGL((systolic_loop_kernel<1, 0>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
+        else hipLaunchKernelGGL((systolic_loop_kernel<2, 0>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
+    }
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
 
-size_t sys_stage_bytes(int B, int T) { return (size_t)sys_layout(B, T, 2).nwg * sizeof(Stage); }
-size_t sys_status_offset_floats(int B, int T) { return sys_layout(B, T, 2).off_status; }    // the head of the layout does not depend on MR
+size_t sys_blocks_offset_floats(int MR, int NB) { return sys_layout(MR, NB).off_blocks; }
+size_t sys_status_offset_floats(int B, int T) { (void)B; (void)T; return sys_layout(2, 1).off_status; }
 
 }  // namespace ladiff

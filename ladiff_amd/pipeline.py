@@ -14,6 +14,7 @@ Out of scope (not built): training/eval steps, metrics, losses, the CLIP text en
 import importlib
 import math
 import time
+import ctypes
 from ctypes import c_void_p, byref
 
 import numpy as np
@@ -101,9 +102,10 @@ class LADIFF(nn.Module):
         self.times = []
         self.use_graph = use_graph
         # how the N steps run (include/ladiff_hip.h, ladiff_sampler_set_loop): "pipeline" = one persistent weight-stationary
-        # kernel for the whole loop when the call qualifies (guidance on, bf16x3; blocks of three prompts, "pipeline16": of one
-        # prompt), "launches" = one launch per stage in hipGraphs
-        if loop not in ("pipeline", "pipeline16", "launches"):
+        # kernel for the whole loop when the call qualifies (guidance on, one text token); its block geometry is planned per call
+        # ("pipeline16" / "pipeline32" force the length-aware 16-row / the padded 32-row blocks), "launches" = one launch per
+        # stage in hipGraphs
+        if loop not in ("pipeline", "pipeline16", "pipeline32", "launches"):
             raise ValueError(f"loop {loop!r} not supported")
         self.loop = loop
         # matrix-product arithmetic of the denoiser loop: "fp32" (fp32-input MFMA) or "bf16x3" (3-term bf16 split)
@@ -197,7 +199,7 @@ class LADIFF(nn.Module):
             _lib.check(L.ladiff_sampler_create(byref(h)))
             self._sampler = h
         if self._sampler is not None:
-            _lib.check(L.ladiff_sampler_set_loop(self._sampler, {"pipeline": 1, "pipeline16": 2, "launches": 0}[self.loop]))
+            _lib.check(L.ladiff_sampler_set_loop(self._sampler, {"pipeline": 1, "pipeline16": 2, "pipeline32": 3, "launches": 0}[self.loop]))
         if init_noise is None:
             init_noise = torch.randn(B, T, 256, device=dev, dtype=torch.float32)       # ladiff.py:380-385
         if need_noise and step_noise is None:
@@ -222,6 +224,7 @@ class LADIFF(nn.Module):
                 # TEST_EFFICIENCY: no masks inside the denoiser and no zeroing of the initial noise (ladiff.py:381-390,
                 # ladiff_denoiser.py:254) - but the final zeroing of ladiff.py:559-566 has no such switch
                 None if self.test_efficiency else plan["counts"].data_ptr(), plan["counts"].data_ptr(),
+                None if self.test_efficiency else (ctypes.c_int32 * B)(*counts),       # host copy: length-aware block packing
                 _lib.ptr(plan["sinus"]), _lib.ptr(plan["coef"]), _lib.ptr(plan["step_noise"]) if need_noise else None,
                 self.guidance_scale, float(sch.init_noise_sigma), 1 if cfg else 0, B, T, n_text, n, _lib.ptr(plan["z"]),
                 _lib.ptr(plan["ws"]), plan["ws_bytes"], 1 if plan["tables_key"] == wt.key else 0, run.cuda_stream))

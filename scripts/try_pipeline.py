@@ -17,7 +17,7 @@ for B, steps in cases:
     noise = syn.init_noise(lens).to(dev)
     pipe.num_inference_timesteps = steps
     out = {}
-    for loop in ("launches", "pipeline", "pipeline16"):
+    for loop in ("launches", "pipeline32", "pipeline16"):
         pipe.loop = loop
         with torch.cuda.stream(stream), torch.no_grad():
             z = pipe._diffusion_reverse(text, lens, init_noise=noise)
@@ -29,6 +29,6 @@ for B, steps in cases:
             dt = (time.perf_counter() - t0) / 3
         out[loop] = z
         print(f"B={B} steps={steps} {loop}: {dt * 1e3:.3f} ms per loop, status {pipe.loop_status()}, finite {bool(torch.isfinite(z).all())}", flush=True)
-    for k in ("pipeline", "pipeline16"):
+    for k in ("pipeline32", "pipeline16"):
         d = (out[k] - out["launches"]).abs().max().item()
         print(f"B={B} steps={steps}: max |z_{k} - z_launches| = {d:.3e} (|z| max {out['launches'].abs().max().item():.1f})", flush=True)

@@ -34,13 +34,15 @@ def run(nets, loop, precision, B, T, steps, lens, sched="ddim", step_noise=None)
     return z
 
 
+@pytest.mark.parametrize("loop", ["pipeline32", "pipeline16", "pipeline"])
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-4), ("fp32", 1e-5)])
 @pytest.mark.parametrize("B,T", [(1, 5), (2, 5), (3, 5), (4, 5), (7, 5), (43, 5), (5, 1), (9, 2), (6, 3), (5, 8)])
-def test_pipeline_matches_launches(nets, precision, tol, B, T):
-    """Blocks of P = 32 / (2 T) prompts: one block, several, a partial last block; every latent count the tiles allow."""
+def test_pipeline_matches_launches(nets, loop, precision, tol, B, T):
+    """32-row blocks of P = 32 / (2 T) prompts (one block, several, a partial last block), the length-aware 16-row packing,
+    and whichever of the two the sampler picks by itself; every latent count the tiles allow."""
     lens = [max(1, min(196, 48 * ((i % T) + 1) - 5 * (i % 3))) for i in range(B)]          # latent counts 1..T, mixed
     za = run(nets, "launches", precision, B, T, 6, lens)
-    zb = run(nets, "pipeline", precision, B, T, 6, lens)
+    zb = run(nets, loop, precision, B, T, 6, lens)
     scale = max(1.0, za.abs().max().item())
     assert torch.isfinite(zb).all()
     assert (za - zb).abs().max().item() < tol * scale
@@ -58,6 +60,48 @@ def test_pipeline16_variant_and_replay(nets):
     z16 = run(nets, "pipeline16", "bf16x3", 11, 5, 8, lens)
     assert torch.equal(z32, z16)
     assert torch.equal(z32, run(nets, "pipeline", "bf16x3", 11, 5, 8, lens))
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("name,lens", [
+    ("eight one-row prompts per block", [40] * 40),
+    ("ten-row last block", [196] * 128),
+    ("c5 per-rank mix", ([60, 120, 196] * 43)[:128]),
+    ("all counts", ([196, 60, 120, 100, 48, 150, 196] * 19)[:128]),
+])
+def test_packed_blocks_many(nets, precision, name, lens):
+    """Length-aware packing at sizes where the stages are backlogged (blocks prefetched, flags deferred) and blocks leave
+    whole waves idle in the attention stage: the packed plan is bit-identical to the 32-row plan, and both match the
+    launch-per-stage loop."""
+    B = len(lens)
+    za = run(nets, "launches", precision, B, 5, 4, lens)
+    z32 = run(nets, "pipeline32", precision, B, 5, 4, lens)
+    z16 = run(nets, "pipeline16", precision, B, 5, 4, lens)
+    assert torch.equal(z32, z16), name
+    assert (za - z16).abs().max().item() < (2e-4 if precision == "bf16x3" else 1e-5) * max(1.0, za.abs().max().item())
+
+
+def test_bucketed_decode_matches_single_pass(nets):
+    """LADiffVae.decode on a mixed-length batch: one decoder pass per length bucket (own F, forked streams, written in
+    place) against the single padded pass - same frames on the valid rows, exact zeros after each motion's length."""
+    _, vae = nets
+    lens = ([60, 120, 196, 33, 150] * 13)[:64]
+    z = torch.randn(5, 64, 256, generator=torch.Generator().manual_seed(3)).to(DEV)
+    for i, l in enumerate(lens):
+        z[-(-l // 48):, i] = 0
+    assert len(vae.length_buckets(lens)) > 1
+    old = vae.precision
+    for precision, tol in (("fp32", 1e-5), ("bf16x3", 2e-5)):
+        vae.precision = precision
+        vae.length_aware = False
+        one = vae.decode(z, lens)
+        vae.length_aware = True
+        many = vae.decode(z, lens)
+        assert one.shape == many.shape == (64, 196, 263)
+        assert (one - many).abs().max().item() < tol * max(1.0, one.abs().max().item())
+        for i, l in enumerate(lens):
+            assert many[i, l:].abs().max().item() == 0 if l < 196 else True
+    vae.precision = old
 
 
 def test_pipeline_ddpm_windows(nets):
