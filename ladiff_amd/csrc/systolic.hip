@@ -152,34 +152,31 @@ constexpr unsigned long long TIMEOUT_TICKS = 150000000ull;     // s_memrealtime 
 // LDS words of the hand-off protocol (last 16 bytes of the dynamic region)
 struct Ctl { int abort, ready, pad0, pad1; };
 
-// wave 0 polls flags[0 .. n) until all are >= epoch; everybody leaves through the barrier.  Returns false on abort.
-__device__ __forceinline__ bool wait_epoch(const unsigned* flags, int n, unsigned epoch, unsigned* status, Ctl* ctl) {
+// Every wave polls flags[0 .. n) by itself until all are >= epoch and goes on to its own loads at once (no barrier, no LDS
+// round trip after the flag is seen).  Two polls are kept in flight: a flag is then sampled every half round trip to the
+// memory side.  Returns false on abort; waves that leave end the kernel, and a barrier only counts the waves still running.
+__device__ __forceinline__ bool wait_epoch(const unsigned* flags, int n, unsigned epoch, unsigned* status, Ctl*) {
     const int lane = threadIdx.x & 63;
-    if (threadIdx.x < 64) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        int bad = 0;
-        for (unsigned spins = 1;; ++spins) {
-            unsigned v = epoch;
-            if (lane < n) v = __hip_atomic_load((const gu32*)flags + lane * FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all(v >= epoch)) break;
-            if ((spins & 31u) == 0u) {
-                const unsigned a = __hip_atomic_load((const gu32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (a != 0u) { bad = 1; break; }
-                if (__builtin_amdgcn_s_memrealtime() - t0 > TIMEOUT_TICKS) {
-                    if (lane == 0) {
-                        __hip_atomic_store((gu32*)status + 1, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store((gu32*)status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    bad = 1;
-                    break;
+    const gu32* f = (const gu32*)flags + (lane < n ? lane : 0) * FLAG_STRIDE;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned spins = 1;; ++spins) {
+        const unsigned w = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(v >= epoch)) return true;
+        v = w;
+        if ((spins & 63u) == 0u) {
+            const unsigned a = __hip_atomic_load((const gu32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a != 0u) return false;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > TIMEOUT_TICKS) {
+                if (lane == 0) {
+                    __hip_atomic_store((gu32*)status + 1, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store((gu32*)status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                return false;
             }
-            __builtin_amdgcn_s_sleep(1);
         }
-        if (lane == 0) ctl->abort = bad;
+        __builtin_amdgcn_s_sleep(1);
     }
-    __syncthreads();
-    return ctl->abort == 0;
 }
 
 // all rows of this workgroup are stored: drain (every wave), meet, publish
@@ -1098,30 +1095,29 @@ __device__ __forceinline__ void tail_loop(const SysArgs& p, const Stage& st, Tai
     for (int s = 0; s < p.n_steps; ++s)
         for (int u = u0; u < nu; u += NTAIL) {
             if (!have) {
-                if (threadIdx.x < 64) {                                  // as wait_epoch, on the flags of the unit's blocks
+                {                                                        // as wait_epoch (every wave), on the flags of the unit's blocks
                     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                    int bad = 0;
+                    const gu32* f = flag_ptr(u);
+                    unsigned v = 0xffffffffu;
+                    if (lane < nflag) v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     for (unsigned spins = 1;; ++spins) {
-                        unsigned v = 0xffffffffu;
-                        if (lane < nflag) v = __hip_atomic_load(flag_ptr(u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        unsigned w = 0xffffffffu;
+                        if (lane < nflag) w = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (__all(v >= (unsigned)(s + 1))) break;
-                        if ((spins & 31u) == 0u) {
-                            if (__hip_atomic_load((const gu32*)p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bad = 1; break; }
+                        v = w;
+                        if ((spins & 63u) == 0u) {
+                            if (__hip_atomic_load((const gu32*)p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
                             if (__builtin_amdgcn_s_memrealtime() - t0 > TIMEOUT_TICKS) {
                                 if (lane == 0) {
                                     __hip_atomic_store((gu32*)p.status + 1, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                     __hip_atomic_store((gu32*)p.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 }
-                                bad = 1;
-                                break;
+                                return;
                             }
                         }
                         __builtin_amdgcn_s_sleep(1);
                     }
-                    if (lane == 0) ctl->abort = bad;
                 }
-                __syncthreads();
-                if (ctl->abort != 0) return;
                 r.issue(s, u, gcur, cur);
             }
             int s2 = s, u2 = u + NTAIL;
