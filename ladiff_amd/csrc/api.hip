@@ -59,7 +59,7 @@ ReverseWs carve_reverse(void* ws, int B, int T, int n, int ntxt = 1) {
     if (pre > r.fwd_floats) r.fwd_floats = pre;
     r.fwd = take(r.fwd_floats);
     r.sys = take(sys_ws_floats(B, T));                                 // block buffers, flags and stage table of the pipeline loop
-    r.cws_floats = (size_t)r.window * (B2 + 1) * D;                    // scratch of the c-table builder (one layer's rows)
+    r.cws_floats = (size_t)NL * r.window * (B2 + 1) * D;               // scratch of the c-table builder (all layers' input rows)
     r.cws = take(r.cws_floats);
     r.total_bytes = off * sizeof(float);
     return r;

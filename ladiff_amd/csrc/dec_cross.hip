@@ -19,12 +19,13 @@ constexpr int TM = LADIFF_MAX_LATENTS;
 // one workgroup per (sample, head): G | U rows [T][2][256] of that head and the score offsets c [T] from the sample's K|V rows.
 // Wq rows h*64 .. are read coalesced over the output column; the Wo tile [256][64] goes through LDS (row stride 65: the
 // per-thread row walk is conflict-free).
-__global__ __launch_bounds__(256) void dec_cross_prep_kernel(const float* __restrict__ kv, const float* __restrict__ wq,
-                                                             const float* __restrict__ bq, const float* __restrict__ wo, int B, int T,
-                                                             float* __restrict__ gu, float* __restrict__ cc) {
+__global__ __launch_bounds__(256) void dec_cross_prep_kernel(const DecCrossPrepBatch pb, int B, int T) {
     __shared__ float wos[D * 65];
     __shared__ float ks[TM * DH], vs[TM * DH];
-    const int b = blockIdx.x, h = blockIdx.y, n = threadIdx.x;
+    const int b = blockIdx.x, h = blockIdx.y, n = threadIdx.x, layer = blockIdx.z;
+    const float* __restrict__ kv = pb.kv[layer]; const float* __restrict__ wq = pb.wq[layer]; const float* __restrict__ bq = pb.bq[layer];
+    const float* __restrict__ wo = pb.wo[layer]; float* __restrict__ gu = pb.gu[layer];
+    float* __restrict__ cc = gu + (size_t)B * H * T * 2 * D;
     float qv[DH];                                                                  // Wq[h*64 + d][n]: all 64 loads in flight at once
 #pragma unroll
     for (int d = 0; d < DH; ++d) qv[d] = wq[(size_t)(h * DH + d) * D + n];
@@ -127,16 +128,22 @@ __global__ __launch_bounds__(256) void dec_cross_apply_kernel(const float* __res
 
 size_t dec_cross_ws_floats(int B, int T) { return (size_t)B * H * T * (2 * D + 1); }
 
-// y = LN2(x + cross_attention(x, kv)); gu_ws holds dec_cross_ws_floats(B, T) floats
-int launch_decoder_cross_block(const float* x, const float* kv, const float* wq, const float* bq, const float* wo, const float* bo,
-                               const float* g2, const float* b2, const int32_t* counts, int B, int F, int T, float* gu_ws, float* y,
-                               float* ys, hipStream_t s) {
+// G | U | c of n layers at once (they depend on z and the weights only): pb.gu[l] holds dec_cross_ws_floats(B, T) floats
+int launch_decoder_cross_prep(const DecCrossPrepBatch& pb, int n, int B, int T, hipStream_t s) {
+    if (B == 0 || n == 0) return 0;
+    if (T < 1 || T > TM || n > DEC_PREP_MAX) return LADIFF_ERR_SHAPE;
+    hipLaunchKernelGGL(dec_cross_prep_kernel, dim3(B, H, n), dim3(256), 0, s, pb, B, T);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+// y = LN2(x + cross_attention(x, kv)) from the layer's prepared G | U | c (gu_ws, launch_decoder_cross_prep)
+int launch_decoder_cross_apply(const float* x, const float* bo, const float* g2, const float* b2, const int32_t* counts, int B, int F,
+                               int T, const float* gu_ws, float* y, float* ys, hipStream_t s) {
     if (B == 0 || F == 0) return 0;
     if (T < 1 || T > TM) return LADIFF_ERR_SHAPE;
-    float* gu = gu_ws;
-    float* cc = gu_ws + (size_t)B * H * T * 2 * D;
-    hipLaunchKernelGGL(dec_cross_prep_kernel, dim3(B, H), dim3(256), 0, s, kv, wq, bq, wo, B, T, gu, cc);
-    LADIFF_LAUNCH_CHECK();
+    const float* gu = gu_ws;
+    const float* cc = gu_ws + (size_t)B * H * T * 2 * D;
     // enough workgroups to cover the chip twice; each re-loads the sample's 8 T KiB of G | U
     int chunks = (512 + B - 1) / B;
     if (chunks < 1) chunks = 1;

@@ -14,7 +14,7 @@ static GemmArgs lin(const float* A, int lda, const float* W, const float* bias, 
 
 size_t dec_ws_floats(int B, int F, int T) {
     const size_t M = (size_t)B * F;
-    return M * (16 * D + 3 * D + D + FF) + (size_t)T * B * 2 * D + dec_cross_ws_floats(B, T);
+    return M * (16 * D + 3 * D + D + FF) + (size_t)NL * ((size_t)T * B * 2 * D + dec_cross_ws_floats(B, T));
 }
 
 // wsp != nullptr selects the bf16x3 matrix path (S-format copies of the weight matrices in `wsp`, GEMM operands in
@@ -39,8 +39,24 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
     float* qkv = p; p += 3 * MD;
     float* att = p; p += MD;
     float* hid = p; p += (size_t)M * FF;
-    float* kv = p; p += (size_t)T * B * 2 * D;
-    float* guws = p;   // G | U rows of the folded cross-attention (dec_cross.hip)
+    float* kv = p; p += (size_t)NL * T * B * 2 * D;      // memory K | V of every layer
+    float* guws = p;                                      // G | U | c of the folded cross-attention of every layer (dec_cross.hip)
+    const size_t kv_l = (size_t)T * B * 2 * D, gu_l = dec_cross_ws_floats(B, T);
+
+    // The memory side of every layer's cross-attention depends on z and the weights only: the nine K | V projections and the
+    // nine folds into G | U | c run up front, one launch each (fp32 in both modes).   cross_attention.py:373-376
+    {
+        GemmArgs g[NL];
+        DecCrossPrepBatch pb;
+        for (int l = 0; l < NL; ++l) {
+            const DecLayerW& L = w.layer[l];
+            g[l] = lin(z, D, L.cross_attn.in_w + (size_t)D * D, L.cross_attn.in_b + D, kv + l * kv_l, 2 * D, T * B, 2 * D, D);
+            pb.kv[l] = kv + l * kv_l; pb.wq[l] = L.cross_attn.in_w; pb.bq[l] = L.cross_attn.in_b; pb.wo[l] = L.cross_attn.out_w;
+            pb.gu[l] = guws + l * gu_l;
+        }
+        LADIFF_TRY(launch_gemm_batch(g, NL, s));
+        LADIFF_TRY(launch_decoder_cross_prep(pb, NL, B, T, s));
+    }
 
     // GEMM + (residual) + LayerNorm: fused epilogue in the fp32 path; GEMM(+residual) then a LayerNorm row kernel in the
     // bf16x3 path.  `A`/`As`: operand in fp32 / S-format; result (fp32 + S-format twin) goes to dst / dsts.
@@ -88,12 +104,11 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
         }
         if (sp) LADIFF_TRY(launch_self_attention_bf16x3(qkv, lengths, nullptr, att, B, F, H, 0, 1, s));
         else LADIFF_TRY(launch_decoder_self_attention(qkv, lengths, nullptr, att, B, F, 0, s));
-        LADIFF_TRY(gemm_ln(att, D, L.self_attn.out_w, Ls.self_attn.out_w, L.self_attn.out_b, cur, L.norm1, nullptr, P[1], Ps[1]));
+        LADIFF_TRY(gemm_ln(att, D, L.self_attn.out_w, Ls.self_attn.out_w, L.self_attn.out_b, cur, L.norm1, nullptr, P[1], nullptr));   // only read in fp32 (dec_cross apply)
         // ---- cross-attention to the latent tokens, tokens >= ceil(len/48) masked, + residual + norm2   :373-376, :408-409
         // (the q / out projections are folded into the <= 8 keys / values per sample: dec_cross.hip; fp32 in both modes)
-        LADIFF_TRY(launch_gemm(lin(z, D, L.cross_attn.in_w + (size_t)D * D, L.cross_attn.in_b + D, kv, 2 * D, T * B, 2 * D, D), s));
-        LADIFF_TRY(launch_decoder_cross_block(P[1], kv, L.cross_attn.in_w, L.cross_attn.in_b, L.cross_attn.out_w, L.cross_attn.out_b,
-                                              L.norm2.g, L.norm2.b, counts, B, F, T, guws, P[2], Ps[2], s));
+        LADIFF_TRY(launch_decoder_cross_apply(P[1], L.cross_attn.out_b, L.norm2.g, L.norm2.b, counts, B, F, T, guws + l * gu_l, P[2],
+                                              Ps[2], s));
         // ---- feed-forward, GELU(erf)   :410-412
         {
             GemmArgs g = lin(sp ? Ps[2] : P[2], D, Ls.lin1.w, L.lin1.b, sp ? nullptr : hid, FF, M, FF, D, ACT_GELU);

@@ -123,7 +123,8 @@ size_t den_text_cache_floats(int B2, int n, int ntxt) {
 }
 size_t den_text_ws_floats(int B2, int n, int ntxt) {
     if (ntxt > 1) return (size_t)B2 * ntxt * (TEXT_DIM + 3 * D);
-    return (size_t)B2 * TEXT_DIM + (size_t)B2 * D + (size_t)B2 * D + (size_t)n * (B2 + 1) * D;
+    // relu(text) | per-layer LN(text projection) | c-table inputs of all layers (the per-layer launches are batched)
+    return (size_t)B2 * TEXT_DIM + (size_t)NL * B2 * D + (size_t)NL * n * (B2 + 1) * D;
 }
 
 static int denoiser_text_cache_general(const DenoiserW& w, const float* text, int B2, int N, float* cache, float* ws, size_t ws_floats,
@@ -160,24 +161,28 @@ const float* den_cache_ctab(const float* cache, int B2, int ntxt) {
 
 // the part of the text cache that does not depend on the step: once per call
 int denoiser_text_static(const DenoiserW& w, const float* text, int B2, float* cache, float* ws, size_t ws_floats, hipStream_t s) {
-    if (ws_floats < (size_t)B2 * (TEXT_DIM + D)) return LADIFF_ERR_WORKSPACE;
+    if (ws_floats < (size_t)B2 * (TEXT_DIM + NL * D)) return LADIFF_ERR_WORKSPACE;
     float* rl = ws;
-    float* tn = rl + (size_t)B2 * TEXT_DIM;
+    float* tn = rl + (size_t)B2 * TEXT_DIM;                  // [NL][B2][256]
     float* tproj = cache;
     float* tkv = cache + (size_t)B2 * D;
     float* nval = tkv + (size_t)NL * B2 * 2 * D;
     LADIFF_TRY(launch_relu(text, rl, (size_t)B2 * TEXT_DIM, s));
     LADIFF_TRY(launch_gemm(lin(rl, TEXT_DIM, w.emb_proj, tproj, D, B2, D, TEXT_DIM), s));
+    // the nine layers' projections of the text token are independent and tiny: one launch per kind, not per layer
+    GemmArgs kv[NL], val[NL];
+    RowBatch ln;
     for (int l = 0; l < NL; ++l) {
         const DenLayerW& L = w.layer[l];
         LinearW kvw{L.sa_attn.in_w + (size_t)D * D, L.sa_attn.in_b + D};
-        LADIFF_TRY(launch_gemm(lin(tproj, D, kvw, tkv + (size_t)l * B2 * 2 * D, 2 * D, B2, 2 * D, D), s));
-        LADIFF_TRY(launch_layernorm(tproj, L.ca_text_norm.g, L.ca_text_norm.b, tn, B2, s));
-        GemmArgs g = lin(tn, D, L.ca_value, nval + (size_t)l * B2 * D, D, B2, D, D);
-        g.ln_g = L.ca_proj.norm.g; g.ln_b = L.ca_proj.norm.b;
-        LADIFF_TRY(launch_gemm(g, s));
+        kv[l] = lin(tproj, D, kvw, tkv + (size_t)l * B2 * 2 * D, 2 * D, B2, 2 * D, D);
+        ln.a[l] = tproj; ln.g[l] = L.ca_text_norm.g; ln.b[l] = L.ca_text_norm.b; ln.y[l] = tn + (size_t)l * B2 * D;
+        val[l] = lin(tn + (size_t)l * B2 * D, D, L.ca_value, nval + (size_t)l * B2 * D, D, B2, D, D);
+        val[l].ln_g = L.ca_proj.norm.g; val[l].ln_b = L.ca_proj.norm.b;
     }
-    return 0;
+    LADIFF_TRY(launch_gemm_batch(kv, NL, s));
+    LADIFF_TRY(launch_layernorm_batch(ln, NL, B2, s));
+    return launch_gemm_batch(val, NL, s);
 }
 
 // c table rows of `n` consecutive steps; `tables_lo` = the time tables at the first of them.  Sampling loops with many steps
@@ -187,7 +192,20 @@ int denoiser_ctab(const DenoiserW& w, const float* tables_lo, int n, float* cach
     if (u_floats < (size_t)n * R * D) return LADIFF_ERR_WORKSPACE;
     const float* nval = cache + (size_t)B2 * D + (size_t)NL * B2 * 2 * D;
     float* ctab = const_cast<float*>(den_cache_ctab(cache, B2, 1));
-    for (int l = 0; l < NL; ++l) {
+    if (u_floats >= (size_t)NL * n * R * D) {                // all layers at once: one input launch, one batched GEMM
+        RowBatch rb;
+        GemmArgs g[NL];
+        for (int l = 0; l < NL; ++l) {
+            const DenLayerW& L = w.layer[l];
+            float* ul = u + (size_t)l * n * R * D;
+            rb.a[l] = nval + (size_t)l * B2 * D; rb.g[l] = L.ca_proj.norm.b;
+            rb.b[l] = tables_lo + (size_t)l * DEN_LAYER_STRIDE + DEN_OFF_CA_MOD; rb.y[l] = ul;
+            g[l] = lin(ul, D, L.ca_proj.out, ctab + (size_t)l * n * R * D, D, n * R, D, D);
+        }
+        LADIFF_TRY(launch_ca_table_input_batch(rb, NL, DEN_STEP_STRIDE, n, B2, s));
+        return launch_gemm_batch(g, NL, s);
+    }
+    for (int l = 0; l < NL; ++l) {                           // scratch for one layer only
         const DenLayerW& L = w.layer[l];
         LADIFF_TRY(launch_ca_table_input(nval + (size_t)l * B2 * D, L.ca_proj.norm.b, tables_lo + (size_t)l * DEN_LAYER_STRIDE + DEN_OFF_CA_MOD,
                                          DEN_STEP_STRIDE, n, B2, u, s));
@@ -201,8 +219,8 @@ int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, const flo
     if (ntxt > 1) return denoiser_text_cache_general(w, text, B2, ntxt, cache, ws, ws_floats, s);
     if (ws_floats < den_text_ws_floats(B2, n)) return LADIFF_ERR_WORKSPACE;
     LADIFF_TRY(denoiser_text_static(w, text, B2, cache, ws, ws_floats, s));
-    float* u = ws + (size_t)B2 * (TEXT_DIM + D);
-    return denoiser_ctab(w, tables, n, cache, B2, u, ws_floats - (size_t)B2 * (TEXT_DIM + D), s);
+    float* u = ws + (size_t)B2 * (TEXT_DIM + NL * D);
+    return denoiser_ctab(w, tables, n, cache, B2, u, ws_floats - (size_t)B2 * (TEXT_DIM + NL * D), s);
 }
 
 // ------------------------------------------------------------------ one ca_block, literal (unit entry for the N > 1 path)

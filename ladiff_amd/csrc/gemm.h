@@ -28,6 +28,12 @@ struct GemmArgs {
 };
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
+// n <= GEMM_BATCH_MAX independent GEMMs of ONE shape (M, N, K, the same epilogue kind; pointers differ) as one launch:
+// the per-layer projections of a prologue are each too small to fill the chip and would otherwise run one after another
+constexpr int GEMM_BATCH_MAX = 9;
+struct GemmBatch { GemmArgs a[GEMM_BATCH_MAX]; };
+int launch_gemm_batch(const GemmArgs* list, int n, hipStream_t stream);
+int launch_gemm_big_batch(const GemmBatch& b, int n, hipStream_t stream);
 bool gemm_big_supported(const GemmArgs& a);          // gemm_big.hip: large-M LDS-DMA kernels
 int launch_gemm_big(const GemmArgs& a, hipStream_t stream);
 

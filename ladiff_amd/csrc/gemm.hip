@@ -54,7 +54,7 @@ template <> struct Mfma<16> {
 __device__ __forceinline__ int lds_off(int r, int c) { return r * BK + ((c ^ ((r >> 1) & 7)) << 2); }
 
 template <int BM, int BN, int WM, int WN, int MT, bool LN>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs p) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& p) {
     typedef Mfma<MT> MM;
     typedef typename MM::Acc Acc;
     constexpr int NT = WM * WN * 64;
@@ -287,9 +287,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs p) {
 }
 
 template <int BM, int BN, int WM, int WN, int MT, bool LN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs p) { gemm_body<BM, BN, WM, WN, MT, LN>(p); }
+template <int BM, int BN, int WM, int WN, int MT, bool LN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_batch_kernel(const GemmBatch b) { gemm_body<BM, BN, WM, WN, MT, LN>(b.a[blockIdx.y]); }
+
+template <int BM, int BN, int WM, int WN, int MT, bool LN>
 static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, MT, LN>), dim3(nbm * nbn), dim3(WM * WN * 64), 0, stream, a);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+template <int BM, int BN, int WM, int WN, int MT, bool LN>
+static int launch_cfg_batch(const GemmBatch& b, int n, hipStream_t stream) {
+    const int nbm = (b.a[0].M + BM - 1) / BM, nbn = (b.a[0].N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_batch_kernel<BM, BN, WM, WN, MT, LN>), dim3(nbm * nbn, n), dim3(WM * WN * 64), 0, stream, b);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
@@ -315,6 +327,33 @@ int launch_gemm(const GemmArgs& a0, hipStream_t stream) {
     if (a.M >= 4096) return launch_cfg<128, 128, 2, 2, 32, false>(a, stream);
     if (a.N >= 512) return launch_cfg<64, 64, 2, 2, 32, false>(a, stream);
     return launch_cfg<32, 32, 2, 2, 16, false>(a, stream);
+}
+
+int launch_gemm_batch(const GemmArgs* list, int n, hipStream_t stream) {
+    LADIFF_CHECK_ARG(list != nullptr && n >= 1 && n <= GEMM_BATCH_MAX);
+    GemmBatch b;
+    for (int i = 0; i < n; ++i) {
+        GemmArgs a = list[i];
+        if (a.A2 == nullptr) a.K1 = a.K;
+        LADIFF_CHECK_ARG(a.A && a.W && a.Y && !a.Ys && !a.split && a.M >= 0 && a.N > 0 && a.K > 0);
+        // one shape, one epilogue kind: the launch configuration is chosen once
+        LADIFF_CHECK_ARG(a.M == list[0].M && a.N == list[0].N && a.K == list[0].K && (a.ln_g != nullptr) == (list[0].ln_g != nullptr));
+        if (a.K % BK != 0 || a.K1 % BK != 0 || a.K1 > a.K) return LADIFF_ERR_SHAPE;
+        if ((a.lda % 4) || (a.ldw % 4) || (a.A2 && (a.lda2 % 4))) return LADIFF_ERR_SHAPE;
+        if (a.ln_g == nullptr && (a.ln2_g || a.mod)) return LADIFF_ERR_ARG;
+        if (a.ln_g != nullptr && (a.N != 256 || a.ln_b == nullptr)) return LADIFF_ERR_SHAPE;
+        b.a[i] = a;
+    }
+    const GemmArgs& a = b.a[0];
+    if (a.M == 0) return 0;
+    if (gemm_big_supported(a)) return launch_gemm_big_batch(b, n, stream);
+    if (a.ln_g != nullptr) {
+        if (a.M >= 4096) return launch_cfg_batch<64, 256, 2, 1, 32, true>(b, n, stream);
+        return launch_cfg_batch<16, 256, 1, 4, 16, true>(b, n, stream);
+    }
+    if (a.M >= 4096) return launch_cfg_batch<128, 128, 2, 2, 32, false>(b, n, stream);
+    if (a.N >= 512) return launch_cfg_batch<64, 64, 2, 2, 32, false>(b, n, stream);
+    return launch_cfg_batch<32, 32, 2, 2, 16, false>(b, n, stream);
 }
 
 }  // namespace ladiff

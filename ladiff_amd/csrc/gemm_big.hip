@@ -24,7 +24,7 @@ __device__ __forceinline__ void dma16(const float* g, float* l) {
 }  // namespace
 
 template <int BM, int BN, int WM, int WN, bool LN>
-__global__ __launch_bounds__(256) void gemm_big_kernel(const GemmArgs p) {
+__device__ __forceinline__ void gemm_big_body(const GemmArgs& p) {
     constexpr int NW = 4;
     static_assert(WM * WN == NW, "four waves");
     constexpr int TMW = BM / WM, TNW = BN / WN, RM = TMW / 32, RN = TNW / 32;
@@ -335,6 +335,21 @@ __global__ __launch_bounds__(256, 2) void gemm_big_split_kernel(const GemmArgs p
 }
 
 template <int BM, int BN, int WM, int WN, bool LN>
+__global__ __launch_bounds__(256) void gemm_big_kernel(const GemmArgs p) { gemm_big_body<BM, BN, WM, WN, LN>(p); }
+template <int BM, int BN, int WM, int WN, bool LN>
+__global__ __launch_bounds__(256) void gemm_big_batch_kernel(const GemmBatch b) { gemm_big_body<BM, BN, WM, WN, LN>(b.a[blockIdx.y]); }
+
+template <int BM, int BN, int WM, int WN, bool LN>
+static int launch_big_batch(const GemmBatch& b, int n, hipStream_t s) {
+    const GemmArgs& a = b.a[0];
+    const int nbm = (a.M + BM - 1) / BM, nbn = a.N / BN;
+    const int grid = ((nbm + 7) / 8) * 8 * nbn;
+    hipLaunchKernelGGL((gemm_big_batch_kernel<BM, BN, WM, WN, LN>), dim3(grid, n), dim3(256), 0, s, b);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int BM, int BN, int WM, int WN, bool LN>
 static int launch_big(const GemmArgs& a, hipStream_t s) {
     const int nbm = (a.M + BM - 1) / BM, nbn = a.N / BN;
     const int grid = ((nbm + 7) / 8) * 8 * nbn;
@@ -362,6 +377,13 @@ int launch_gemm_big(const GemmArgs& a, hipStream_t s) {
     }
     if (a.ln_g != nullptr) return launch_big<64, 256, 2, 2, true>(a, s);
     return launch_big<128, 128, 2, 2, false>(a, s);
+}
+
+// fp32-input path only (the caller checked gemm_big_supported on the common shape)
+int launch_gemm_big_batch(const GemmBatch& b, int n, hipStream_t s) {
+    if (b.a[0].split) return LADIFF_ERR_ARG;
+    if (b.a[0].ln_g != nullptr) return launch_big_batch<64, 256, 2, 2, true>(b, n, s);
+    return launch_big_batch<128, 128, 2, 2, false>(b, n, s);
 }
 
 }  // namespace ladiff

@@ -12,6 +12,15 @@ int launch_reduce_rows(const float* P, int S, int M, const float* bias, const fl
                        const int32_t* d_base = nullptr);
 int launch_split_rows(const float* x, float* y, int R, int K, hipStream_t s);
 int launch_layernorm(const float* x, const float* g, const float* b, float* y, int M, hipStream_t s);
+constexpr int DEC_PREP_MAX = 9;
+struct DecCrossPrepBatch { const float* kv[DEC_PREP_MAX]; const float* wq[DEC_PREP_MAX]; const float* bq[DEC_PREP_MAX];
+                           const float* wo[DEC_PREP_MAX]; float* gu[DEC_PREP_MAX]; };
+// the same op on up to ROW_BATCH_MAX independent (x, g, b, y) sets of one M, one launch (grid.y = set)
+constexpr int ROW_BATCH_MAX = 9;
+struct RowBatch { const float* a[ROW_BATCH_MAX]; const float* g[ROW_BATCH_MAX]; const float* b[ROW_BATCH_MAX]; float* y[ROW_BATCH_MAX]; };
+int launch_layernorm_batch(const RowBatch& rb, int n, int M, hipStream_t s);
+// ca_table_input for n_layers layers at once: a = nval, g = beta, b = mod (step 0) , y = u of each layer
+int launch_ca_table_input_batch(const RowBatch& rb, int n_layers, int step_stride, int n, int B2, hipStream_t s);
 int launch_ca_table_input(const float* nval, const float* beta, const float* mod, int step_stride, int n, int B2, float* u,
                           hipStream_t s);
 int launch_add_pe(const float* sample, const float* pe, int Bs, int b_off, int b_n, int T, float* x, float* xs, hipStream_t s);
@@ -45,9 +54,9 @@ int launch_denoiser_self_attention_general(const float* qkv, const float* text_k
 // dec_cross.hip: the decoder's cross-attention block (q projection, attention over <= 8 memory tokens, out projection,
 // residual, norm2) as a per-sample low-rank map
 size_t dec_cross_ws_floats(int B, int T);
-int launch_decoder_cross_block(const float* x, const float* kv, const float* wq, const float* bq, const float* wo, const float* bo,
-                               const float* g2, const float* b2, const int32_t* counts, int B, int F, int T, float* gu_ws, float* y,
-                               float* ys, hipStream_t s);
+int launch_decoder_cross_prep(const DecCrossPrepBatch& pb, int n, int B, int T, hipStream_t s);
+int launch_decoder_cross_apply(const float* x, const float* bo, const float* g2, const float* b2, const int32_t* counts, int B, int F,
+                               int T, const float* gu_ws, float* y, float* ys, hipStream_t s);
 
 // feats2joints.hip
 int launch_feats2joints(const float* feats, const float* mean, const float* stdv, int B, int F, int C, int J, float* joints,

@@ -31,6 +31,27 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     st4(y + (size_t)row * D + c, v);
 }
 
+__global__ __launch_bounds__(256) void layernorm_batch_kernel(const RowBatch rb, int M) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int c = (threadIdx.x & 63) * 4;
+    if (row >= M) return;
+    const int k = blockIdx.y;
+    f32x4 v = ld4(rb.a[k] + (size_t)row * D + c);
+    float mean, rstd;
+    row_stats(v, mean, rstd);
+    const f32x4 gg = ld4(rb.g[k] + c), bb = ld4(rb.b[k] + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i];
+    st4(rb.y[k] + (size_t)row * D + c, v);
+}
+int launch_layernorm_batch(const RowBatch& rb, int n, int M, hipStream_t s) {
+    if (M == 0 || n == 0) return 0;
+    LADIFF_CHECK_ARG(n >= 1 && n <= ROW_BATCH_MAX);
+    hipLaunchKernelGGL(layernorm_batch_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, n), dim3(256), 0, s, rb, M);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_layernorm(const float* x, const float* g, const float* b, float* y, int M, hipStream_t s) {
     if (M == 0) return 0;
     hipLaunchKernelGGL(layernorm_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, x, g, b, y, M);
@@ -140,6 +161,29 @@ __global__ __launch_bounds__(256) void ca_table_input_kernel(const float* __rest
     for (int i = 0; i < 4; ++i) v[i] = silu(v[i] * (1.f + sc[i]) + sh[i]);
     st4(u + (size_t)row * D + c, v);
 }
+__global__ __launch_bounds__(256) void ca_table_input_batch_kernel(const RowBatch rb, int step_stride, int B2, int M) {
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int c = (threadIdx.x & 63) * 4;
+    if (row >= M) return;
+    const int k = blockIdx.y;
+    const int step = row / (B2 + 1), b = row % (B2 + 1);
+    const float* m = rb.b[k] + (size_t)step * step_stride;
+    const f32x4 sc = ld4(m + c), sh = ld4(m + 256 + c);
+    f32x4 v = b < B2 ? ld4(rb.a[k] + (size_t)b * D + c) : ld4(rb.g[k] + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = silu(v[i] * (1.f + sc[i]) + sh[i]);
+    st4(rb.y[k] + (size_t)row * D + c, v);
+}
+int launch_ca_table_input_batch(const RowBatch& rb, int n_layers, int step_stride, int n, int B2, hipStream_t s) {
+    const int M = n * (B2 + 1);
+    if (M == 0 || n_layers == 0) return 0;
+    LADIFF_CHECK_ARG(n_layers >= 1 && n_layers <= ROW_BATCH_MAX);
+    hipLaunchKernelGGL(ca_table_input_batch_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, n_layers), dim3(256), 0, s, rb,
+                       step_stride, B2, M);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_ca_table_input(const float* nval, const float* beta, const float* mod, int step_stride, int n, int B2, float* u,
                           hipStream_t s) {
     const int M = n * (B2 + 1);

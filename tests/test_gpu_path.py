@@ -184,7 +184,8 @@ def test_module_level_loop_matches_fused_loop(denoiser, vae):
     lat = lat.permute(1, 0, 2).clone()
     for i, m in enumerate(counts.tolist()):
         lat[m:, i] = 0
-    assert maxdiff(z, lat) < 1e-4
+    # fp32 rounding only (the pipeline and the launch-per-stage forward order their sums differently): same bound as the goldens
+    assert maxdiff(z, lat) < 2e-5 * max(1.0, lat.abs().max().item())
 
 
 # ---------------------------------------------------------------- full-size properties (BASELINE configs)
