@@ -241,13 +241,15 @@ size_t ladiff_decoder_workspace_bytes(int B, int F, int T, int C);
 int ladiff_vae_decode(const float* const* w, const float* const* w_split /*or NULL: fp32 MFMA*/, const float* z,
                       const int32_t* lengths, const int32_t* counts, int B, int F, int T, int C, float* feats,
                       void* ws, size_t ws_bytes, ladiff_stream_t stream);
-/* One LENGTH BUCKET of a mixed-length batch: the B samples of the bucket (z[T,B,256], lengths, counts gathered by the
- * caller) are decoded with the bucket's own F and written to rows out_index[i] (device int32 [B]) of feats[*,F_out,C],
- * frames < F only; the caller zero-fills feats once.  Same arithmetic per sample as ladiff_vae_decode: the padded
- * frames of a sample are masked keys there (cross_attention.py:367-371) and zeroed at the end (ladiff_vae.py:356-360). */
-int ladiff_vae_decode_bucket(const float* const* w, const float* const* w_split /*or NULL*/, const float* z,
-                             const int32_t* lengths, const int32_t* counts, const int32_t* out_index, int B, int F,
-                             int F_out, int T, int C, float* feats, void* ws, size_t ws_bytes, ladiff_stream_t stream);
+/* The same decode computing ONLY the valid frames of a mixed-length batch (ragged rows): row_off[b] (device int32,
+ * B + 1 entries, exclusive prefix sum of lengths, row_off[B] = total_rows) places sample b's frames in the packed row
+ * space the decoder works in; the result is scattered to feats[B,F,C] (frames >= lengths[b] zero, as above).  A sample's
+ * frames do not depend on the other samples or on padding - padded frames are masked keys (cross_attention.py:367-371)
+ * and zeroed at the end (ladiff_vae.py:356-360) - so the output equals ladiff_vae_decode's.  The workspace of
+ * ladiff_decoder_workspace_bytes(B, F, T, C) is enough. */
+int ladiff_vae_decode_ragged(const float* const* w, const float* const* w_split /*or NULL*/, const float* z,
+                             const int32_t* lengths, const int32_t* counts, const int32_t* row_off, int total_rows, int B,
+                             int F, int T, int C, float* feats, void* ws, size_t ws_bytes, ladiff_stream_t stream);
 
 /* ------------------------------------------------------------------ LA-VAE encoder
  * LADiffVae.encode, ladiff_vae.py:162-286 (call sites ladiff.py:269, :324, :1096): features[B,F,C] ->

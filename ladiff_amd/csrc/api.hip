@@ -578,7 +578,7 @@ int ladiff_feats2joints(const float* feats, const float* mean, const float* std,
 // ------------------------------------------------------------------ LA-VAE decoder
 size_t ladiff_decoder_workspace_bytes(int B, int F, int T, int C) {
     (void)C;
-    return dec_ws_floats(B, F, T) * sizeof(float);
+    return dec_ws_floats(B, (size_t)B * F, T) * sizeof(float);
 }
 
 int ladiff_vae_decode(const float* const* w, const float* const* w_split, const float* z, const int32_t* lengths,
@@ -587,17 +587,19 @@ int ladiff_vae_decode(const float* const* w, const float* const* w_split, const 
     DecoderW W, WS;
     LADIFF_CHECK_ARG(load_weights(W, w) && z && lengths && feats && ws && B >= 0);
     if (w_split != nullptr) LADIFF_CHECK_ARG(load_weights(WS, w_split));
-    return vae_decode(W, w_split ? &WS : nullptr, z, lengths, counts, nullptr, B, F, F, T, C, feats, (float*)ws, ws_bytes / sizeof(float),
+    return vae_decode(W, w_split ? &WS : nullptr, z, lengths, counts, nullptr, 0, B, F, T, C, feats, (float*)ws, ws_bytes / sizeof(float),
                       S(stream));
 }
 
-int ladiff_vae_decode_bucket(const float* const* w, const float* const* w_split, const float* z, const int32_t* lengths,
-                             const int32_t* counts, const int32_t* out_index, int B, int F, int F_out, int T, int C, float* feats,
+int ladiff_vae_decode_ragged(const float* const* w, const float* const* w_split, const float* z, const int32_t* lengths,
+                             const int32_t* counts, const int32_t* row_off, int total_rows, int B, int F, int T, int C, float* feats,
                              void* ws, size_t ws_bytes, ladiff_stream_t stream) {
     DecoderW W, WS;
-    LADIFF_CHECK_ARG(load_weights(W, w) && z && lengths && out_index && feats && ws && B >= 0);
+    LADIFF_CHECK_ARG(load_weights(W, w) && z && lengths && row_off && feats && ws && B >= 0 && total_rows >= 0);
     if (w_split != nullptr) LADIFF_CHECK_ARG(load_weights(WS, w_split));
-    return vae_decode(W, w_split ? &WS : nullptr, z, lengths, counts, out_index, B, F, F_out, T, C, feats, (float*)ws,
+    // frames past each length: zero, whatever the buffer held (ladiff_vae.py:356-360)
+    LADIFF_HIP(hipMemsetAsync(feats, 0, (size_t)B * F * C * sizeof(float), S(stream)));
+    return vae_decode(W, w_split ? &WS : nullptr, z, lengths, counts, row_off, total_rows, B, F, T, C, feats, (float*)ws,
                       ws_bytes / sizeof(float), S(stream));
 }
 

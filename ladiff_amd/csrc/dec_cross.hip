@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void dec_cross_apply_kernel(const float* __res
                                                               const float* __restrict__ cc, const int32_t* __restrict__ counts,
                                                               const float* __restrict__ bo, const float* __restrict__ g2,
                                                               const float* __restrict__ b2, int F, int rows_per_wg,
-                                                              float* __restrict__ y, float* __restrict__ ys) {
+                                                              float* __restrict__ y, float* __restrict__ ys,
+                                                              const int32_t* __restrict__ row_off) {
     extern __shared__ __attribute__((aligned(16))) float sm[];                    // [H][TT][2][256], then c [H][TT]
     constexpr int T = TT, HT = H * TT;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -81,10 +82,12 @@ __global__ __launch_bounds__(256) void dec_cross_apply_kernel(const float* __res
     __syncthreads();
     const int c4 = 4 * lane;
     const f32x4 bo4 = ld4(bo + c4), gg = ld4(g2 + c4), bb = ld4(b2 + c4);
+    size_t row0 = (size_t)b * F;
+    if (row_off != nullptr) { row0 = row_off[b]; F = row_off[b + 1] - row_off[b]; }     // ragged rows: only the sample's own frames
     const int f0 = blockIdx.y * rows_per_wg;
     const int f1 = f0 + rows_per_wg < F ? f0 + rows_per_wg : F;
     for (int f = f0 + wave; f < f1; f += 4) {
-        const size_t row = (size_t)b * F + f;
+        const size_t row = row0 + f;
         const f32x4 xv = ld4(x + row * D + c4);
         f32x4 acc = {bo4[0] + xv[0], bo4[1] + xv[1], bo4[2] + xv[2], bo4[3] + xv[3]};      // out_proj bias + residual
 #pragma unroll
@@ -139,7 +142,7 @@ int launch_decoder_cross_prep(const DecCrossPrepBatch& pb, int n, int B, int T, 
 
 // y = LN2(x + cross_attention(x, kv)) from the layer's prepared G | U | c (gu_ws, launch_decoder_cross_prep)
 int launch_decoder_cross_apply(const float* x, const float* bo, const float* g2, const float* b2, const int32_t* counts, int B, int F,
-                               int T, const float* gu_ws, float* y, float* ys, hipStream_t s) {
+                               int T, const float* gu_ws, float* y, float* ys, hipStream_t s, const int32_t* row_off) {
     if (B == 0 || F == 0) return 0;
     if (T < 1 || T > TM) return LADIFF_ERR_SHAPE;
     const float* gu = gu_ws;
@@ -160,7 +163,7 @@ int launch_decoder_cross_apply(const float* x, const float* bo, const float* g2,
 #define LADIFF_DC_CASE(TT)                                                                                                   \
     case TT:                                                                                                                 \
         hipLaunchKernelGGL(dec_cross_apply_kernel<TT>, dim3(B, chunks), dim3(256), lds, s, x, gu, cc, counts, bo, g2, b2, F, \
-                           rows_per_wg, y, ys);                                                                              \
+                           rows_per_wg, y, ys, row_off);                                                                              \
         break;
     switch (T) {
         LADIFF_DC_CASE(1) LADIFF_DC_CASE(2) LADIFF_DC_CASE(3) LADIFF_DC_CASE(4)

@@ -12,21 +12,24 @@ static GemmArgs lin(const float* A, int lda, const float* W, const float* bias, 
     return g;
 }
 
-size_t dec_ws_floats(int B, int F, int T) {
-    const size_t M = (size_t)B * F;
-    return M * (16 * D + 3 * D + D + FF) + (size_t)NL * ((size_t)T * B * 2 * D + dec_cross_ws_floats(B, T));
+// rows = B * F for the padded layout, or the sum of the lengths for the ragged one
+size_t dec_ws_floats(int B, size_t rows, int T) {
+    return rows * (16 * D + 3 * D + D + FF + 1) + (size_t)NL * ((size_t)T * B * 2 * D + dec_cross_ws_floats(B, T));
 }
 
 // wsp != nullptr selects the bf16x3 matrix path (S-format copies of the weight matrices in `wsp`, GEMM operands in
 // S-format, LayerNorm as a row kernel after each fused GEMM); see denoiser.hip and common.h.
-// out_index != nullptr: sample i is written to feats row block out_index[i] of a [*, F_out, C] tensor (frames < F only) - the
-// length-bucketed decode of a mixed batch, where each bucket runs with its own F.
+// row_off != nullptr (B + 1 entries, row_off[B] = R): RAGGED rows - sample b owns rows [row_off[b], row_off[b] + lengths[b]) and
+// only the R valid frames of a mixed-length batch are computed.  Every op of the decoder is per row or per sample (padded
+// frames are masked keys, cross_attention.py:367-371, and zeroed at the end, ladiff_vae.py:356-360), so a sample's frames come
+// out as in the padded layout; they are scattered to feats[b, f < length] of a [B, F, C] tensor the caller has zero-filled.
 int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int32_t* lengths, const int32_t* counts,
-               const int32_t* out_index, int B, int F, int F_out, int T, int C, float* feats, float* ws, size_t ws_floats, hipStream_t s) {
+               const int32_t* row_off, int R, int B, int F, int T, int C, float* feats, float* ws, size_t ws_floats, hipStream_t s) {
     if (F < 1 || F > LADIFF_MAX_FRAMES || T < 1 || T > LADIFF_MAX_LATENTS || C < 1) return LADIFF_ERR_SHAPE;
-    if (out_index != nullptr && F_out < F) return LADIFF_ERR_SHAPE;
-    if (ws_floats < dec_ws_floats(B, F, T)) return LADIFF_ERR_WORKSPACE;
-    const int M = B * F;
+    const bool ragged = row_off != nullptr;
+    if (ragged && (R < 0 || (size_t)R > (size_t)B * F)) return LADIFF_ERR_SHAPE;
+    const int M = ragged ? R : B * F;
+    if (ws_floats < dec_ws_floats(B, (size_t)M, T)) return LADIFF_ERR_WORKSPACE;
     if (M == 0) return 0;
     const bool sp = wsp != nullptr;
     const size_t MD = (size_t)M * D;
@@ -40,7 +43,8 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
     float* att = p; p += MD;
     float* hid = p; p += (size_t)M * FF;
     float* kv = p; p += (size_t)NL * T * B * 2 * D;      // memory K | V of every layer
-    float* guws = p;                                      // G | U | c of the folded cross-attention of every layer (dec_cross.hip)
+    float* guws = p; p += (size_t)NL * dec_cross_ws_floats(B, T);   // G | U | c of the folded cross-attention of every layer (dec_cross.hip)
+    int32_t* row_out = reinterpret_cast<int32_t*>(p);     // ragged: place of each row in the padded output
     const size_t kv_l = (size_t)T * B * 2 * D, gu_l = dec_cross_ws_floats(B, T);
 
     // The memory side of every layer's cross-attention depends on z and the weights only: the nine K | V projections and the
@@ -82,7 +86,8 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
     };
 
     // queries = zeros + query_pos_decoder.pe[:F]     ladiff_vae.py:299, :334
-    LADIFF_TRY(launch_broadcast_pe(w.query_pe, B, F, P[0], Ps[0], s));
+    if (ragged) LADIFF_TRY(launch_broadcast_pe_ragged(w.query_pe, row_off, B, F, F, P[0], Ps[0], row_out, s));
+    else LADIFF_TRY(launch_broadcast_pe(w.query_pe, B, F, P[0], Ps[0], s));
     const float* cur = P[0]; const float* curs = Ps[0];
     for (int l = 0; l < NL; ++l) {
         const DecLayerW& L = w.layer[l];
@@ -102,13 +107,13 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
             g.split = sp ? 1 : 0;
             LADIFF_TRY(launch_gemm(g, s));
         }
-        if (sp) LADIFF_TRY(launch_self_attention_bf16x3(qkv, lengths, nullptr, att, B, F, H, 0, 1, s));
-        else LADIFF_TRY(launch_decoder_self_attention(qkv, lengths, nullptr, att, B, F, 0, s));
+        if (sp) LADIFF_TRY(launch_self_attention_bf16x3(qkv, lengths, nullptr, att, B, F, H, 0, 1, s, row_off));
+        else LADIFF_TRY(launch_decoder_self_attention(qkv, lengths, nullptr, att, B, F, 0, s, row_off));
         LADIFF_TRY(gemm_ln(att, D, L.self_attn.out_w, Ls.self_attn.out_w, L.self_attn.out_b, cur, L.norm1, nullptr, P[1], nullptr));   // only read in fp32 (dec_cross apply)
         // ---- cross-attention to the latent tokens, tokens >= ceil(len/48) masked, + residual + norm2   :373-376, :408-409
         // (the q / out projections are folded into the <= 8 keys / values per sample: dec_cross.hip; fp32 in both modes)
         LADIFF_TRY(launch_decoder_cross_apply(P[1], L.cross_attn.out_b, L.norm2.g, L.norm2.b, counts, B, F, T, guws + l * gu_l, P[2],
-                                              Ps[2], s));
+                                              Ps[2], s, row_off));
         // ---- feed-forward, GELU(erf)   :410-412
         {
             GemmArgs g = lin(sp ? Ps[2] : P[2], D, Ls.lin1.w, L.lin1.b, sp ? nullptr : hid, FF, M, FF, D, ACT_GELU);
@@ -123,8 +128,8 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
     }
     // final_layer + zero padded frames, written as [B, F, C]   ladiff_vae.py:356-360
     GemmArgs g = lin(cur, D, w.final_layer.w, w.final_layer.b, feats, C, M, C, D);
-    g.row_len = lengths; g.rows_per_item = F;
-    g.item_out = out_index; g.out_rows_per_item = F_out;
+    if (ragged) g.row_map = row_out;                      // every computed row is a valid frame
+    else { g.row_len = lengths; g.rows_per_item = F; }
     return launch_gemm(g, s);
 }
 

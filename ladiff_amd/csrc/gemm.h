@@ -24,7 +24,7 @@ struct GemmArgs {
     const int32_t* d_step = nullptr; int mod_stride = 0;
     int post_act = ACT_NONE;                     // activation after LN / modulation
     const int32_t* row_len = nullptr; int rows_per_item = 0;     // zero rows with (row % rows_per_item) >= row_len[row / rows_per_item]
-    const int32_t* item_out = nullptr; int out_rows_per_item = 0;   // with row_len: row (item, f) is written to Y row item_out[item] * out_rows_per_item + f
+    const int32_t* row_map = nullptr;            // row r is written to Y row row_map[r] (ragged rows scattered into a padded tensor)
 };
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream);

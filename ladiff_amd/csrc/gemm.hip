@@ -270,11 +270,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p) {
             if (gr >= p.M) continue;
             bool zero = false;
             size_t orow = gr;
-            if (p.row_len != nullptr) {
-                const int item = gr / p.rows_per_item, f = gr - item * p.rows_per_item;
-                zero = f >= p.row_len[item];
-                if (p.item_out != nullptr) orow = (size_t)p.item_out[item] * p.out_rows_per_item + f;
-            }
+            if (p.row_len != nullptr) zero = (gr % p.rows_per_item) >= p.row_len[gr / p.rows_per_item];
+            if (p.row_map != nullptr) orow = (size_t)p.row_map[gr];
 #pragma unroll
             for (int j = 0; j < RN; ++j) {
                 const int gc = acol_base + j * MT;

@@ -361,9 +361,9 @@ static int launch_big(const GemmArgs& a, hipStream_t s) {
 // true when the shape is served by this kernel family (otherwise the caller uses the staged kernel of gemm.hip)
 bool gemm_big_supported(const GemmArgs& a) {
     if (a.split) return a.M > 0 && a.K % 64 == 0 && a.K1 % 64 == 0 && a.N % 128 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0 && (!a.A2 || a.lda2 % 4 == 0) &&
-                        a.ldy % 64 == 0 && !a.ln_g && !a.mod && !a.row_len && a.post_act == ACT_NONE && (a.Y || a.Ys);
+                        a.ldy % 64 == 0 && !a.ln_g && !a.mod && !a.row_len && !a.row_map && a.post_act == ACT_NONE && (a.Y || a.Ys);
     if (a.M < 4096 || a.K % BKB || a.K1 % BKB || (a.lda % 4) || (a.ldw % 4) || (a.A2 && (a.lda2 % 4))) return false;
-    if ((a.ldy % 4) || (a.res && (a.ldres % 4)) || a.mod || a.row_len || a.post_act != ACT_NONE) return false;
+    if ((a.ldy % 4) || (a.res && (a.ldres % 4)) || a.mod || a.row_len || a.row_map || a.post_act != ACT_NONE) return false;
     if (a.ln_g != nullptr) return a.N == 256;
     return a.N % 128 == 0;
 }

@@ -25,6 +25,9 @@ int launch_ca_table_input(const float* nval, const float* beta, const float* mod
                           hipStream_t s);
 int launch_add_pe(const float* sample, const float* pe, int Bs, int b_off, int b_n, int T, float* x, float* xs, hipStream_t s);
 int launch_broadcast_pe(const float* pe, int B, int F, float* x, float* xs, hipStream_t s);
+// ragged form: sample b owns rows [row_off[b], row_off[b + 1]); also writes each row's place in a [B, F_out, *] tensor to row_out
+int launch_broadcast_pe_ragged(const float* pe, const int32_t* row_off, int B, int F, int F_out, float* x, float* xs, int32_t* row_out,
+                               hipStream_t s);
 int launch_relu(const float* x, float* y, size_t n, hipStream_t s);
 int launch_silu(const float* x, float* y, size_t n, hipStream_t s);
 int launch_sinusoid(const int64_t* t, int n, float* out, hipStream_t s);
@@ -56,7 +59,7 @@ int launch_denoiser_self_attention_general(const float* qkv, const float* text_k
 size_t dec_cross_ws_floats(int B, int T);
 int launch_decoder_cross_prep(const DecCrossPrepBatch& pb, int n, int B, int T, hipStream_t s);
 int launch_decoder_cross_apply(const float* x, const float* bo, const float* g2, const float* b2, const int32_t* counts, int B, int F,
-                               int T, const float* gu_ws, float* y, float* ys, hipStream_t s);
+                               int T, const float* gu_ws, float* y, float* ys, hipStream_t s, const int32_t* row_off = nullptr);
 
 // feats2joints.hip
 int launch_feats2joints(const float* feats, const float* mean, const float* stdv, int B, int F, int C, int J, float* joints,
@@ -66,12 +69,13 @@ int launch_feats2joints(const float* feats, const float* mean, const float* stdv
 int launch_denoiser_self_attention(const float* qkv, const float* text_kv, const float* tables, int kv_off,
                                    int step_stride, const int32_t* d_step, const int32_t* counts, int Bs, int b_off,
                                    int b_n, int T, float* out, int split_out, hipStream_t s);
+// row_off (optional, B + 1 entries): ragged rows - sample b owns rows [row_off[b], row_off[b + 1]) and F only bounds the lengths
 int launch_decoder_self_attention(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
-                                  int split_out, hipStream_t s);
+                                  int split_out, hipStream_t s, const int32_t* row_off = nullptr);
 int launch_self_attention(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F, int nheads,
                           int causal, int split_out, hipStream_t s);
 int launch_self_attention_bf16x3(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
-                                 int nheads, int causal, int split_out, hipStream_t s);
+                                 int nheads, int causal, int split_out, hipStream_t s, const int32_t* row_off = nullptr);
 int launch_decoder_cross_attention(const float* q, const float* kv, const int32_t* counts, float* out, int B, int F,
                                    int T, int split_out, hipStream_t s);
 

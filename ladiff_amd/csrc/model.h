@@ -35,9 +35,9 @@ int linear_cross_attention(const DenoiserW& w, int layer, const float* x, const 
 size_t linear_cross_attention_ws_floats(int B, int T, int N);
 void den_loop_io(float* ws, int rows, float** x, float** xs);
 
-size_t dec_ws_floats(int B, int F, int T);
+size_t dec_ws_floats(int B, size_t rows, int T);
 int vae_decode(const DecoderW& w, const DecoderW* w_split, const float* z, const int32_t* lengths, const int32_t* counts,
-               const int32_t* out_index, int B, int F, int F_out, int T, int C, float* feats, float* ws, size_t ws_floats, hipStream_t s);
+               const int32_t* row_off, int R, int B, int F, int T, int C, float* feats, float* ws, size_t ws_floats, hipStream_t s);
 
 size_t enc_ws_floats(int B, int F, int T, int C);
 int vae_encode(const EncoderW& w, const EncoderW* w_split, const float* features, const int32_t* lengths,

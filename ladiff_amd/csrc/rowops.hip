@@ -226,6 +226,28 @@ __global__ __launch_bounds__(256) void broadcast_pe_kernel(const float* __restri
     if (xs != nullptr) store_split4(xs + (size_t)row * D, c, v);
 }
 
+__global__ __launch_bounds__(256) void broadcast_pe_ragged_kernel(const float* __restrict__ pe, const int32_t* __restrict__ row_off,
+                                                                  int F, int F_out, float* __restrict__ x, float* __restrict__ xs,
+                                                                  int32_t* __restrict__ row_out) {
+    const int b = blockIdx.y, f = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int c = (threadIdx.x & 63) * 4;
+    const int r0 = row_off[b];
+    if (f >= F || f >= row_off[b + 1] - r0) return;
+    const size_t row = (size_t)r0 + f;
+    const f32x4 v = ld4(pe + (size_t)f * D + c);
+    st4(x + row * D + c, v);
+    if (xs != nullptr) store_split4(xs + row * D, c, v);
+    if (c == 0) row_out[row] = b * F_out + f;
+}
+int launch_broadcast_pe_ragged(const float* pe, const int32_t* row_off, int B, int F, int F_out, float* x, float* xs, int32_t* row_out,
+                               hipStream_t s) {
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(broadcast_pe_ragged_kernel, dim3((F + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, B), dim3(256), 0, s, pe, row_off, F,
+                       F_out, x, xs, row_out);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_broadcast_pe(const float* pe, int B, int F, float* x, float* xs, hipStream_t s) {
     const int M = B * F;
     hipLaunchKernelGGL(broadcast_pe_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, pe, F, M, x, xs);

@@ -182,7 +182,7 @@ class LADiffVae(_HipModule):
         self.max_it = int(_get(ablation, "MAX_IT", 5))
         self.frame_per_latent = int(_get(ablation, "FRAME_PER_LATENT", 48))
         self.test_efficiency = bool(_get(ablation, "TEST_EFFICIENCY", False))
-        self.length_aware = True        # decode mixed-length batches per length bucket (same results, fewer padded frame rows)
+        self.length_aware = True        # decode only the valid frames of a mixed-length batch (same results, fewer rows)
         if _get(ablation, "PE_TYPE", "mld") != "mld":
             raise ValueError("Not Support PE type")
         if arch not in ("all_encoder", "encoder_decoder"):
@@ -255,46 +255,6 @@ class LADiffVae(_HipModule):
         dist = torch.distributions.Normal(mu, std)
         return latent.to(features.dtype), dist, torch.tensor(counts, dtype=torch.long)
 
-    # decode cost model for the bucketing below, in frame rows: a bucket of n samples costs n * F + BUCKET_OVERHEAD_ROWS
-    # (buckets run concurrently, so a bucket's ~1 ms launch floor mostly overlaps with the others; what is left is about
-    # as much as 1500 frame rows on an MI355X)
-    BUCKET_OVERHEAD_ROWS = 1500
-    MAX_BUCKETS = 4
-
-    @classmethod
-    def length_buckets(cls, lengths):
-        """Partition of range(len(lengths)) into <= MAX_BUCKETS groups of similar length, minimising the frame rows the
-        decoder computes (each group runs padded to ITS longest motion) plus a per-group overhead.  Returns a list of
-        (sample indices, F of the group), longest group first; one group [(all, max)] when splitting does not pay."""
-        order = sorted(range(len(lengths)), key=lambda i: -lengths[i])
-        n = len(order)
-        if n == 0:
-            return []
-        # cut points only where the length changes
-        cuts = [0] + [i for i in range(1, n) if lengths[order[i]] != lengths[order[i - 1]]] + [n]
-        m = len(cuts) - 1                                  # runs of equal length
-        INF = float("inf")
-        # best[k][j]: cost of covering runs [0, j) with k groups; a group [i, j) costs (cuts[j] - cuts[i]) * len(run i)
-        best = [[INF] * (m + 1) for _ in range(cls.MAX_BUCKETS + 1)]
-        back = [[0] * (m + 1) for _ in range(cls.MAX_BUCKETS + 1)]
-        best[0][0] = 0.0
-        for k in range(1, cls.MAX_BUCKETS + 1):
-            for j in range(1, m + 1):
-                for i in range(j):
-                    if best[k - 1][i] == INF:
-                        continue
-                    c = best[k - 1][i] + (cuts[j] - cuts[i]) * lengths[order[cuts[i]]] + cls.BUCKET_OVERHEAD_ROWS
-                    if c < best[k][j]:
-                        best[k][j] = c
-                        back[k][j] = i
-        k = min(range(1, cls.MAX_BUCKETS + 1), key=lambda kk: best[kk][m])
-        groups, j = [], m
-        while k > 0:
-            i = back[k][j]
-            groups.append((order[cuts[i]:cuts[j]], lengths[order[cuts[i]]]))
-            j, k = i, k - 1
-        return groups[::-1]
-
     def decode(self, z, lengths, plot_att_map=None, latentwise_gen=None):
         """z [max_it,B,256], lengths list[int] -> feats [B, max(lengths), nfeats]; frames >= len are zero."""
         if plot_att_map:
@@ -321,44 +281,21 @@ class LADiffVae(_HipModule):
         wt = self._weight_table()
         wsplit = wt.split_array() if self.precision == "bf16x3" else None
         zz = z.detach().to(torch.float32).contiguous()
-        groups = self.length_buckets(lengths) if self.length_aware else [(list(range(B)), F)]
-        if len(groups) <= 1:
-            wsb = L.ladiff_decoder_workspace_bytes(B, F, T, self.nfeats)
-            ws = _lib.workspace(wsb, dev)
-            feats = torch.empty(B, F, self.nfeats, dtype=torch.float32, device=dev)
+        feats = torch.empty(B, F, self.nfeats, dtype=torch.float32, device=dev)
+        wsb = L.ladiff_decoder_workspace_bytes(B, F, T, self.nfeats)
+        ws = _lib.workspace(wsb, dev)
+        rows = sum(lengths)
+        if self.length_aware and rows < B * F:
+            # mixed lengths: only the valid frames are computed (ragged rows, ladiff_vae_decode_ragged); same frames out
+            off = [0] * (B + 1)
+            for i, l in enumerate(lengths):
+                off[i + 1] = off[i] + l
+            _lib.check(L.ladiff_vae_decode_ragged(wt.array, wsplit, _lib.ptr(zz), lens_t.data_ptr(),
+                                                  None if counts_t is None else counts_t.data_ptr(),
+                                                  _lib.device_ints(off, dev).data_ptr(), rows, B, F, T, self.nfeats,
+                                                  _lib.ptr(feats), _lib.ptr(ws), wsb, _lib.stream_ptr()))
+        else:
             _lib.check(L.ladiff_vae_decode(wt.array, wsplit, _lib.ptr(zz), lens_t.data_ptr(),
                                            None if counts_t is None else counts_t.data_ptr(), B, F, T, self.nfeats,
                                            _lib.ptr(feats), _lib.ptr(ws), wsb, _lib.stream_ptr()))
-            return feats.to(z.dtype)
-        # mixed lengths: one decoder pass per length bucket with the bucket's own F, written in place (ladiff_vae_decode_bucket);
-        # a sample's arithmetic does not depend on the other samples or on F beyond its own length.  The buckets are
-        # independent and each is too small to fill the chip, so they run side by side on forked streams.
-        feats = torch.zeros(B, F, self.nfeats, dtype=torch.float32, device=dev)
-        main = torch.cuda.current_stream(dev)
-        jobs = []
-        for idx, Fg in groups:                             # inputs of every bucket first, on the caller's stream
-            idx_t = _lib.device_ints(idx, dev)
-            zg = zz.index_select(1, idx_t).contiguous()    # plumbing: the bucket's latent columns
-            lens_g = _lib.device_ints([lengths[i] for i in idx], dev)
-            counts_g = None if counts_t is None else _lib.device_ints([counts[i] for i in idx], dev)
-            wsb_g = L.ladiff_decoder_workspace_bytes(len(idx), Fg, T, self.nfeats)
-            jobs.append((idx_t, zg, lens_g, counts_g, len(idx), Fg, _lib.workspace(wsb_g, dev), wsb_g))
-        sides = self._side_streams(dev, len(jobs) - 1)
-        for k, (idx_t, zg, lens_g, counts_g, n, Fg, ws_g, wsb_g) in enumerate(jobs):
-            st = main if k == 0 else sides[k - 1]
-            if k > 0:
-                st.wait_stream(main)
-            _lib.check(L.ladiff_vae_decode_bucket(wt.array, wsplit, _lib.ptr(zg), lens_g.data_ptr(),
-                                                  None if counts_g is None else counts_g.data_ptr(), idx_t.data_ptr(),
-                                                  n, Fg, F, T, self.nfeats, _lib.ptr(feats), _lib.ptr(ws_g), wsb_g,
-                                                  st.cuda_stream))
-        for st in sides[:len(jobs) - 1]:
-            main.wait_stream(st)                           # join: everything the caller enqueues next sees all buckets
         return feats.to(z.dtype)
-
-    def _side_streams(self, dev, n):
-        pool = self.__dict__.setdefault("_sides", {})
-        key = str(dev)
-        while len(pool.setdefault(key, [])) < n:
-            pool[key].append(torch.cuda.Stream(device=dev))
-        return pool[key]

@@ -81,26 +81,27 @@ def test_packed_blocks_many(nets, precision, name, lens):
     assert (za - z16).abs().max().item() < (2e-4 if precision == "bf16x3" else 1e-5) * max(1.0, za.abs().max().item())
 
 
-def test_bucketed_decode_matches_single_pass(nets):
-    """LADiffVae.decode on a mixed-length batch: one decoder pass per length bucket (own F, forked streams, written in
-    place) against the single padded pass - same frames on the valid rows, exact zeros after each motion's length."""
+def test_ragged_decode_matches_padded_pass(nets):
+    """LADiffVae.decode on a mixed-length batch computes only the valid frames (ragged rows, ladiff_vae_decode_ragged);
+    against the padded pass: same frames on the valid rows, exact zeros after each motion's length."""
     _, vae = nets
-    lens = ([60, 120, 196, 33, 150] * 13)[:64]
-    z = torch.randn(5, 64, 256, generator=torch.Generator().manual_seed(3)).to(DEV)
-    for i, l in enumerate(lens):
-        z[-(-l // 48):, i] = 0
-    assert len(vae.length_buckets(lens)) > 1
     old = vae.precision
-    for precision, tol in (("fp32", 1e-5), ("bf16x3", 2e-5)):
-        vae.precision = precision
-        vae.length_aware = False
-        one = vae.decode(z, lens)
-        vae.length_aware = True
-        many = vae.decode(z, lens)
-        assert one.shape == many.shape == (64, 196, 263)
-        assert (one - many).abs().max().item() < tol * max(1.0, one.abs().max().item())
+    for lens in (([60, 120, 196, 33, 150] * 13)[:64], [1, 196, 2, 47, 48, 49, 195], [17]):
+        B = len(lens)
+        z = torch.randn(5, B, 256, generator=torch.Generator().manual_seed(3)).to(DEV)
         for i, l in enumerate(lens):
-            assert many[i, l:].abs().max().item() == 0 if l < 196 else True
+            z[-(-l // 48):, i] = 0
+        for precision, tol in (("fp32", 1e-5), ("bf16x3", 2e-5)):
+            vae.precision = precision
+            vae.length_aware = False
+            one = vae.decode(z, lens)
+            vae.length_aware = True
+            many = vae.decode(z, lens)
+            assert one.shape == many.shape == (B, max(lens), 263)
+            assert (one - many).abs().max().item() < tol * max(1.0, one.abs().max().item())
+            for i, l in enumerate(lens):
+                if l < max(lens):
+                    assert many[i, l:].abs().max().item() == 0
     vae.precision = old
 
 
