@@ -37,6 +37,7 @@
 #include <vector>
 
 #include "model.h"
+#include "tile_mma.h"
 
 namespace ladiff {
 
@@ -44,7 +45,6 @@ namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int CLD = D + 4;                // row stride of the fp32 staging tile in LDS (floats)
 constexpr int NSLICE = 8;                 // hidden slices of the two MLPs (128 columns each)
 constexpr int HS = FF / NSLICE;           // 128
 constexpr int NRED = 3;                   // row parts of the two reduce stages
@@ -190,19 +190,7 @@ __device__ __forceinline__ unsigned* flag_of(const SysArgs& p, int group, int b,
     return p.flags + ((size_t)(group * p.NB + b) * FLAG_SLOTS + slot) * FLAG_STRIDE;
 }
 
-// ---------------------------------------------------------------- LDS images
-// S-format operand tile: row = KB blocks of 256 B, block = 8 hi slots + 8 lo slots of 16 B, slot index XORed with (row & 15)
-template <int KB>
-__device__ __forceinline__ char* a_slot(char* tile, int row, int kb, int slot) {
-    return tile + row * (KB * 256) + kb * 256 + (((slot ^ row) & 15) << 4);
-}
-__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        hi[e] = (__bf16)a[e]; lo[e] = (__bf16)(a[e] - (float)hi[e]);
-        hi[4 + e] = (__bf16)b[e]; lo[4 + e] = (__bf16)(b[e] - (float)hi[4 + e]);
-    }
-}
+// ---------------------------------------------------------------- LDS images (tile_mma.h) of hand-off rows
 // A [16 MR][256] fp32 block of rows held in registers between its loads and its LDS image: thread t owns the 8-column
 // units id = t + 256 u (row id / 32, columns 8 (id % 32) ..)
 template <int MR> struct Rows256 { f32x4 v[2 * MR][2]; };
@@ -215,37 +203,6 @@ __device__ __forceinline__ void issue_rows(Rows256<MR>& x, __amdgpu_buffer_rsrc_
         x.v[u][1] = ld_sc1(r, base + row * 1024 + c8 * 32 + 16);
     }
 }
-// ---- arithmetic policy AR: 0 = bf16x3 (S-format operand tiles, 3 x v_mfma_f32_16x16x32_bf16 per product),
-//                           1 = fp32 (fp32 operand tiles, v_mfma_f32_16x16x4_f32: exact fp32 fma chains, the strict-parity mode)
-// fp32 tile: row stride K + 4 floats, element k of a row at (k & 3) * (K / 4) + (k >> 2): the lane (row l & 15, k-phase l >> 4) of
-// the 16x16x4 MFMA reads its A values of four consecutive k-steps with ONE conflict-free ds_read_b128.
-template <int AR, int KB> constexpr int tile_bytes(int rows) { return AR == 0 ? rows * KB * 256 : rows * (KB * 64 + 4) * 4; }
-
-template <int AR, int KB>
-__device__ __forceinline__ void tile_put4(char* tile, int row, int k0, const f32x4 v) {            // k0 % 4 == 0
-    if constexpr (AR == 0) {
-        bf16x4 h4, l4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { h4[e] = (__bf16)v[e]; l4[e] = (__bf16)(v[e] - (float)h4[e]); }
-        *reinterpret_cast<bf16x4*>(a_slot<KB>(tile, row, k0 >> 6, (k0 & 63) >> 3) + (k0 & 7) * 2) = h4;
-        *reinterpret_cast<bf16x4*>(a_slot<KB>(tile, row, k0 >> 6, 8 + ((k0 & 63) >> 3)) + (k0 & 7) * 2) = l4;
-    } else {
-        float* r = reinterpret_cast<float*>(tile) + row * (KB * 64 + 4) + (k0 >> 2);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r[e * (KB * 16)] = v[e];
-    }
-}
-template <int AR, int KB>
-__device__ __forceinline__ void tile_put1(char* tile, int row, int k, float v) {
-    if constexpr (AR == 0) {
-        const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
-        *(reinterpret_cast<__bf16*>(a_slot<KB>(tile, row, k >> 6, (k & 63) >> 3)) + (k & 7)) = hi;
-        *(reinterpret_cast<__bf16*>(a_slot<KB>(tile, row, k >> 6, 8 + ((k & 63) >> 3))) + (k & 7)) = lo;
-    } else {
-        reinterpret_cast<float*>(tile)[row * (KB * 64 + 4) + (k & 3) * (KB * 16) + (k >> 2)] = v;
-    }
-}
-
 template <int AR, int KB, int MR>
 __device__ __forceinline__ void commit_rows(char* tile, int kb0, const Rows256<MR>& x) {
 #pragma unroll
@@ -261,114 +218,6 @@ __device__ __forceinline__ void commit_rows(char* tile, int kb0, const Rows256<M
             tile_put4<1, KB>(tile, row, kb0 * 64 + c8 * 8 + 4, x.v[u][1]);
         }
     }
-}
-
-// weights of NT column tiles x KS k-steps (of 32) for this wave, register resident: 8 VGPRs per (tile, step) in both modes
-template <int AR, int NT, int KS> struct WFrag;
-template <int NT, int KS> struct WFrag<0, NT, KS> { bf16x8 hi[NT][KS], lo[NT][KS]; };
-template <int NT, int KS> struct WFrag<1, NT, KS> { float w[NT][KS * 8]; };
-
-// w: weight matrix (S-format for AR 0, fp32 for AR 1), row stride ldw floats; tile j covers matrix rows row_of(j) + (lane & 15);
-// the k range starts at k block kb0 (64 columns per block)
-template <int AR, int NT, int KS, class RowOf>
-__device__ __forceinline__ void load_w(WFrag<AR, NT, KS>& f, const float* w, int ldw, int kb0, RowOf row_of) {
-    const int lane = threadIdx.x & 63, frow = lane & 15, fk = lane >> 4;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        if constexpr (AR == 0) {
-            const char* rp = reinterpret_cast<const char*>(w + (size_t)(row_of(j) + frow) * ldw);
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const char* bp = rp + (kb0 + (s >> 1)) * 256 + ((4 * (s & 1) + fk) << 4);
-                f.hi[j][s] = *reinterpret_cast<const bf16x8*>(bp);
-                f.lo[j][s] = *reinterpret_cast<const bf16x8*>(bp + 128);
-            }
-        } else {
-            const float* rp = w + (size_t)(row_of(j) + frow) * ldw + kb0 * 64 + fk;
-#pragma unroll
-            for (int s4 = 0; s4 < KS * 8; ++s4) f.w[j][s4] = rp[4 * s4];
-        }
-    }
-}
-
-// acc[i][j] += A(tile rows 16 i ..) . W(tile j)^T over KS k-steps of 32; MR = row tiles.  The operand fragments of the next
-// step are requested before the MFMAs of the current one are issued, so their LDS latency hides under the MFMAs.
-template <int AR, int KB, int NT, int KS, int MR>
-__device__ __forceinline__ void mma(const char* tile, const WFrag<AR, NT, KS>& f, f32x4 (&acc)[MR][NT]) {
-    const int lane = threadIdx.x & 63, frow = lane & 15, fk = lane >> 4;
-    char* const t = const_cast<char*>(tile);
-    if constexpr (AR == 0) {
-        bf16x8 ah[2][MR], al[2][MR];
-#pragma unroll
-        for (int i = 0; i < MR; ++i) {
-            ah[0][i] = *reinterpret_cast<const bf16x8*>(a_slot<KB>(t, 16 * i + frow, 0, fk));
-            al[0][i] = *reinterpret_cast<const bf16x8*>(a_slot<KB>(t, 16 * i + frow, 0, 8 + fk));
-        }
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            if (s + 1 < KS) {
-#pragma unroll
-                for (int i = 0; i < MR; ++i) {
-                    ah[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(a_slot<KB>(t, 16 * i + frow, (s + 1) >> 1, 4 * ((s + 1) & 1) + fk));
-                    al[(s + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(a_slot<KB>(t, 16 * i + frow, (s + 1) >> 1, 8 + 4 * ((s + 1) & 1) + fk));
-                }
-            }
-            // the three products of a split operand pair go to the same accumulator: one product at a time over all MR x NT
-            // accumulators, so that consecutive MFMAs never depend on each other
-#pragma unroll
-            for (int i = 0; i < MR; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s & 1][i], f.hi[j][s], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < MR; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1][i], f.lo[j][s], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < MR; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s & 1][i], f.hi[j][s], acc[i][j], 0, 0, 0);
-        }
-    } else {
-        constexpr int LD = KB * 64 + 4, NG = KS * 2;                     // groups of four k-steps of 4
-        const float* base = reinterpret_cast<const float*>(t) + frow * LD + fk * (KB * 16);
-        f32x4 a[2][MR];
-#pragma unroll
-        for (int i = 0; i < MR; ++i) a[0][i] = ld4(base + 16 * i * LD);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) {
-#pragma unroll
-                for (int i = 0; i < MR; ++i) a[(g + 1) & 1][i] = ld4(base + 16 * i * LD + 4 * (g + 1));
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < MR; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g & 1][i][e], f.w[j][4 * g + e], acc[i][j], 0, 0, 0);
-        }
-    }
-}
-
-template <int MR, int NT>
-__device__ __forceinline__ void zero_acc(f32x4 (&acc)[MR][NT]) {
-#pragma unroll
-    for (int i = 0; i < MR; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-}
-
-// accumulators -> fp32 staging tile [rows][CLD]; tile j of this wave holds columns col_of(j) + (lane & 15)
-template <int MR, int NT, class ColOf>
-__device__ __forceinline__ void stage_c(float* ct, const f32x4 (&acc)[MR][NT], ColOf col_of) {
-    const int lane = threadIdx.x & 63, frow = lane & 15, fk = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < MR; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ct[(16 * i + 4 * fk + r) * CLD + col_of(j) + frow] = acc[i][j][r];
 }
 
 __device__ __forceinline__ void row_stats4(const f32x4 v, float& mean, float& rstd) {   // as rowops.hip: two-pass, fp32
