@@ -590,11 +590,12 @@ struct MlpRole {
         zero_acc(acc2);
         mma<AR, 2, 4, 4, MR>(htile, w2, acc2);
         stage_c(ct, acc2, [&](int j) { return 64 * wave + 16 * j; });
-        __syncthreads();
+        // each wave stores the 64 columns it staged itself (256 B per row, four rows per instruction): no barrier - LDS serves a
+        // wave's accesses in order, and the next block's hidden tile is only written behind the stage loop's barrier
 #pragma unroll
         for (int q = 0; q < RPW; ++q) {
-            const int row = wave + 4 * q;
-            st_sc1(rout, plane + base + row * 1024 + lane * 16, ld4(ct + row * CLD + 4 * lane));
+            const int row = 4 * q + (lane >> 4), cc = 64 * wave + 4 * (lane & 15);
+            st_sc1(rout, plane + base + row * 1024 + cc * 4, ld4(ct + row * CLD + cc));
         }
     }
 };
