@@ -47,7 +47,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int NSLICE = 8;                 // hidden slices of the two MLPs (128 columns each)
 constexpr int HS = FF / NSLICE;           // 128
-constexpr int NRED = 3;                   // row parts of the two reduce stages
+constexpr int NRED = 3;                   // workgroups per layer of each of the two reduce stages (how they share the work: red_parts())
 constexpr int NTAIL = 4;                  // tail workgroups (block b belongs to tail b % NTAIL)
 constexpr int FLAG_SLOTS = 8;
 constexpr int FLAG_STRIDE = 32;             // words between the flags of two producers: every flag on a 128-byte line of its own
@@ -59,6 +59,7 @@ enum Role : int { R_QKV = 0, R_OUT = 1, R_LIN = 2, R_RED2 = 3, R_FFN = 4, R_STYL
 struct Stage {                            // one per workgroup
     int role, layer, slice, act;
     int wait_group, wait_n, out_group, out_slot;
+    int blk0, blkstride, pad0, pad1;      // the blocks this workgroup visits: blk0, blk0 + blkstride, ...
     const float *w0, *w1;                 // S-format matrices
     const float *b0, *b1;                 // biases
     const float *g, *be;                  // LayerNorm gamma / beta
@@ -84,6 +85,11 @@ struct BlockDesc {
     int pair_lat[16], pair_t[16], pair_rc[16];
 };
 static_assert(NRED == 3, "BlockDesc::part_pk");
+// How the reduce workgroups of a layer share a block's rows.  32-row blocks: NRED row parts each (<= 11 rows, 3 per wave).
+// 16-row blocks: a part can take 8 rows (2 per wave), so RED2 needs only two workgroups and the freed one goes to STYL, the
+// busiest stage of that plan: two GROUPS of two parts, group g visiting the blocks b = g (mod 2) - it sees every other block.
+struct RedPlan { int red2_parts, styl_parts, styl_groups; };
+inline RedPlan red_plan(int MR) { return MR == 1 ? RedPlan{2, 2, 2} : RedPlan{NRED, NRED, 1}; }
 
 struct SysArgs {
     const Stage* stages;
@@ -427,6 +433,12 @@ struct QkvRole {
         __syncthreads();
         mid.after_barrier();
         SYS_STAMP(6);
+        // the shipped models have T = 5 latent tokens (7 keys): the loops are unrolled over the keys, so the bound is compile time
+        if (T <= 5) attention<7>(b); else attention<TK>(b);
+    }
+    template <int NKEY>
+    __device__ __forceinline__ void attention(int b) {
+        const int tid = threadIdx.x;
         const int nrows = gd[0];
         // attention of a row on 16 lanes (4 of the head's 64 columns each): the scores are reduced across the lanes with DPP,
         // softmax and the weighted sum of the values stay in registers - no barrier, no score tile
@@ -441,32 +453,32 @@ struct QkvRole {
             const float* xm = xt + 15 * 128 + c4;                        // the time token
             // every load below is unconditional (a masked or absent key reads a valid dummy address): straight-line code, all the
             // LDS reads of a row in flight at once
-            float e[TK];
-            f32x4 k4[TK], v4[TK];
+            float e[NKEY];
+            f32x4 k4[NKEY], v4[NKEY];
 #pragma unroll
-            for (int j = 0; j < TK; ++j) {
+            for (int j = 0; j < NKEY; ++j) {
                 const bool on = live && j < nkeys && (j >= T || j < nk);     // keys >= the latent count: masked
                 const float* kp = j < T ? kt + j * QLD : (j == T ? xs : xm);
                 k4[j] = ld4(on ? kp : qt + c4);
                 v4[j] = ld4(on ? kp + 64 : qt + c4);
             }
 #pragma unroll
-            for (int j = 0; j < TK; ++j)
+            for (int j = 0; j < NKEY; ++j)
                 e[j] = row16_sum(fmaf(q4[0], k4[j][0], fmaf(q4[1], k4[j][1], fmaf(q4[2], k4[j][2], q4[3] * k4[j][3]))));
             float m = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < TK; ++j) {
+            for (int j = 0; j < NKEY; ++j) {
                 const bool on = j < nkeys && (j >= T || j < nk);
                 e[j] = on ? e[j] : -INFINITY;
                 m = fmaxf(m, e[j]);
             }
             float l = 0.f;
 #pragma unroll
-            for (int j = 0; j < TK; ++j) { e[j] = __builtin_amdgcn_exp2f((e[j] - m) * 1.4426950408889634f); l += e[j]; }   // masked: exp2(-inf) = 0
+            for (int j = 0; j < NKEY; ++j) { e[j] = __builtin_amdgcn_exp2f((e[j] - m) * 1.4426950408889634f); l += e[j]; }   // masked: exp2(-inf) = 0
             const float inv = 1.f / l;
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < TK; ++j) {
+            for (int j = 0; j < NKEY; ++j) {
                 const float pj = e[j] * inv;                            // exactly 0 for a masked key
                 o[0] = fmaf(pj, v4[j][0], o[0]); o[1] = fmaf(pj, v4[j][1], o[1]); o[2] = fmaf(pj, v4[j][2], o[2]); o[3] = fmaf(pj, v4[j][3], o[3]);
             }
@@ -1001,13 +1013,13 @@ __global__ __launch_bounds__(256, 1) void systolic_loop_kernel(const SysArgs p) 
     Ctl* const ctl = reinterpret_cast<Ctl*>(lds + SYS_LDS_BYTES - 16);
     const Stage st = p.stages[blockIdx.x];
     switch (st.role) {
-        case R_QKV: { QkvRole<MR, AR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
-        case R_OUT: { OutRole<MR, AR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
-        case R_LIN: { MlpRole<MR, ACT_RELU, AR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
-        case R_RED2: { Red2Role<MR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
-        case R_FFN: { MlpRole<MR, ACT_GELU, AR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
-        case R_STYL: { StylRole<MR, AR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
-        case R_SKIP: { SkipRole<MR, AR> r(p, st, lds); stage_loop(p, st, r, ctl, 0, 1); break; }
+        case R_QKV: { QkvRole<MR, AR> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
+        case R_OUT: { OutRole<MR, AR> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
+        case R_LIN: { MlpRole<MR, ACT_RELU, AR> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
+        case R_RED2: { Red2Role<MR> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
+        case R_FFN: { MlpRole<MR, ACT_GELU, AR> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
+        case R_STYL: { StylRole<MR, AR> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
+        case R_SKIP: { SkipRole<MR, AR> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
         case R_TAIL: { TailRole<MR> r(p, st, lds); tail_loop(p, st, r, ctl); break; }
         default: break;
     }
@@ -1085,13 +1097,14 @@ void sys_pack_blocks(int B, int T, int want_mr, const int32_t* h_counts, bool ma
                       for (int r = 0; r < 32; ++r) { d.row_b2[r] = -1; d.row_lat[r] = -1; } return d; };
     // derived tables: the reduce parts' slots (the live rows split evenly over NRED parts) and the tail's (prompt, latent) pairs
     auto finish = [&](BlockDesc& d, const int* row_cnt, int npairs, int rc_off) {
-        const int per = (d.nrows + NRED - 1) / NRED;
+        const int nparts = red_plan(MR).red2_parts;               // RED2 and STYL split a block's rows the same way
+        const int per = (d.nrows + nparts - 1) / nparts;
         for (int part = 0; part < NRED; ++part) {
             const int lo = part * per < d.nrows ? part * per : d.nrows, hi = lo + per < d.nrows ? lo + per : d.nrows;
             for (int k = 0; k < 12; ++k) {
                 const int r = lo + k;
                 d.part_pk[part][k] = -1; d.part_b2[part][k] = -1;
-                if (r < hi) {
+                if (part < nparts && r < hi) {
                     d.part_pk[part][k] = r | d.row_t[r] << 8 | (row_cnt[r] < 0 ? 0xff : row_cnt[r]) << 16;
                     d.part_b2[part][k] = d.row_b2[r];
                 }
@@ -1160,6 +1173,7 @@ void sys_pack_blocks(int B, int T, int want_mr, const int32_t* h_counts, bool ma
 int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR, int NB, std::vector<unsigned char>& host) {
     // WS = the S-format weight table in bf16x3 mode; in fp32 mode the caller passes the fp32 table twice
     const SysLayout L = sys_layout(MR, NB);
+    const RedPlan rp = red_plan(MR);
     std::vector<Stage> st;
     float* xin0 = ws + L.off_xin0;
     float* att = ws + L.off_att; float* x1 = ws + L.off_x1; float* x2 = ws + L.off_x2;
@@ -1172,13 +1186,13 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR,
         const DenLayerW& ws_ = WS.layer[l];
         const float* xin; int xg, xn;
         if (l == 0) { xin = xin0; xg = G(0, G_XIN); xn = 1; }
-        else if (l <= NSKIP) { xin = XO(l - 1); xg = G(l - 1, G_XO); xn = NRED; }
+        else if (l <= NSKIP) { xin = XO(l - 1); xg = G(l - 1, G_XO); xn = rp.styl_parts; }
         else { xin = XS(l); xg = G(l, G_XIN); xn = 2; }
         if (l > NSKIP) {
             const int i = l - NSKIP - 1;
             for (int c = 0; c < 2; ++c) {
                 Stage s{};
-                s.role = R_SKIP; s.layer = l; s.slice = c; s.wait_group = G(l - 1, G_XO); s.wait_n = NRED;
+                s.role = R_SKIP; s.layer = l; s.slice = c; s.wait_group = G(l - 1, G_XO); s.wait_n = rp.styl_parts;
                 s.out_group = G(l, G_XIN); s.out_slot = c;
                 s.w0 = WS.skip[i].w; s.b0 = W.skip[i].b; s.in0 = XO(l - 1); s.in1 = XO(NL - 1 - l); s.out = XS(l);
                 st.push_back(s);
@@ -1202,7 +1216,7 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR,
             s.w0 = ws_.sa_lin1.w; s.w1 = ws_.sa_lin2.w; s.b0 = w.sa_lin1.b; s.in0 = x1; s.out = pc;
             st.push_back(s);
         }
-        for (int q = 0; q < NRED; ++q) {
+        for (int q = 0; q < rp.red2_parts; ++q) {
             Stage s{};
             s.role = R_RED2; s.layer = l; s.slice = q; s.wait_group = G(l, G_PC); s.wait_n = NSLICE; s.out_group = G(l, G_X2); s.out_slot = q;
             s.b0 = w.sa_lin2.b; s.g = w.sa_norm2.g; s.be = w.sa_norm2.b; s.in0 = pc; s.in1 = x1; s.out = x2;
@@ -1210,24 +1224,28 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR,
         }
         for (int j = 0; j < NSLICE; ++j) {
             Stage s{};
-            s.role = R_FFN; s.layer = l; s.slice = j; s.wait_group = G(l, G_X2); s.wait_n = NRED; s.out_group = G(l, G_PE); s.out_slot = j;
+            s.role = R_FFN; s.layer = l; s.slice = j; s.wait_group = G(l, G_X2); s.wait_n = rp.red2_parts; s.out_group = G(l, G_PE); s.out_slot = j;
             s.w0 = ws_.ffn1.w; s.w1 = ws_.ffn2.w; s.b0 = w.ffn1.b; s.in0 = x2; s.out = pe;
             st.push_back(s);
         }
-        for (int q = 0; q < NRED; ++q) {
-            Stage s{};
-            s.role = R_STYL; s.layer = l; s.slice = q; s.wait_group = G(l, G_PE); s.wait_n = NSLICE; s.out_group = G(l, G_XO); s.out_slot = q;
-            s.w0 = ws_.ffn_proj.out.w; s.b0 = w.ffn_proj.out.b; s.b1 = w.ffn2.b; s.g = w.ffn_proj.norm.g; s.be = w.ffn_proj.norm.b;
-            s.in0 = pe; s.in1 = x2; s.out = XO(l);
-            st.push_back(s);
-        }
+        for (int g = 0; g < rp.styl_groups; ++g)
+            for (int q = 0; q < rp.styl_parts; ++q) {
+                Stage s{};
+                s.role = R_STYL; s.layer = l; s.slice = q; s.wait_group = G(l, G_PE); s.wait_n = NSLICE; s.out_group = G(l, G_XO); s.out_slot = q;
+                s.blk0 = g; s.blkstride = rp.styl_groups;
+                s.w0 = ws_.ffn_proj.out.w; s.b0 = w.ffn_proj.out.b; s.b1 = w.ffn2.b; s.g = w.ffn_proj.norm.g; s.be = w.ffn_proj.norm.b;
+                s.in0 = pe; s.in1 = x2; s.out = XO(l);
+                st.push_back(s);
+            }
     }
     for (int k = 0; k < NTAIL; ++k) {
         Stage s{};
-        s.role = R_TAIL; s.layer = NL; s.slice = k; s.wait_group = G(NL - 1, G_XO); s.wait_n = NRED; s.out_group = G(0, G_XIN); s.out_slot = 0;
+        s.role = R_TAIL; s.layer = NL; s.slice = k; s.wait_group = G(NL - 1, G_XO); s.wait_n = rp.styl_parts; s.out_group = G(0, G_XIN); s.out_slot = 0;
         s.in0 = XO(NL - 1); s.out = xin0;
         st.push_back(s);
     }
+    for (Stage& s : st)
+        if (s.blkstride == 0) s.blkstride = 1;                        // every other stage visits every block
     if ((int)st.size() != L.nwg || st.size() > 256) return LADIFF_ERR_SHAPE;
     host.resize(st.size() * sizeof(Stage));
     std::memcpy(host.data(), st.data(), host.size());

@@ -34,8 +34,10 @@ t = st[:256 * 4 * 4 * 8].reshape(256, 4, 4, 8).cpu().double() * 0.01          # 
 names = []
 for l in range(9):
     if l > 4: names += [f"L{l} SKIP{c}" for c in range(2)]
-    names += [f"L{l} QKV{h}" for h in range(4)] + [f"L{l} OUT"] + [f"L{l} LIN{j}" for j in range(8)] + [f"L{l} RED2.{q}" for q in range(3)]
-    names += [f"L{l} FFN{j}" for j in range(8)] + [f"L{l} STYL.{q}" for q in range(3)]
+    names += [f"L{l} QKV{h}" for h in range(4)] + [f"L{l} OUT"] + [f"L{l} LIN{j}" for j in range(8)]
+    # 16-row plan: RED2 x 2, STYL 2 groups (even / odd blocks) x 2 parts; 32-row plan: 3 + 3 (systolic.hip, red_plan)
+    names += [f"L{l} RED2.{q}" for q in range(2 if mode == "pipeline16" else 3)] + [f"L{l} FFN{j}" for j in range(8)]
+    names += ([f"L{l} STYL.{q}" for q in range(2)] + [f"L{l} STYLb.{q}" for q in range(2)]) if mode == "pipeline16" else [f"L{l} STYL.{q}" for q in range(3)]
 names += [f"TAIL{k}" for k in range(4)]
 step, blk = min(1, steps - 1), 0
 tail = len(names) - 4 + blk % 4
