@@ -144,7 +144,7 @@ def pipeline_kernel_roofline(pipe, loop_ms_samples, summary):
     traffic, util, share, src = profiled(summary, "systolic_loop_kernel")
     return {"bound": "mfma", "achieved": round(flops / ms / 1e9, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flops / ms / 1e9 / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": traffic,
-            "kernel": "systolic_loop_kernel<2> (all 50 guided DDIM steps of 128 prompts in one persistent launch)",
+            "kernel": "systolic_loop_kernel (all 50 guided DDIM steps of 128 prompts in one persistent launch; the profiled instantiation is named in traffic_source)",
             "us_per_launch": round(ms * 1e3, 1), "flops_per_launch": flops, "mfma_flops_per_launch": mfma_flops,
             "mfma_frac": round(mfma_flops / ms / 1e9 / PEAK_BF16_MFMA_TFLOPS, 4), "mfma_util_pmc": util, "share_of_pass": share,
             "traffic_source": src}
