@@ -159,17 +159,17 @@ constexpr unsigned long long TIMEOUT_TICKS = 150000000ull;     // s_memrealtime 
 struct Ctl { int abort, ready, pad0, pad1; };
 
 // Every wave polls flags[0 .. n) by itself until all are >= epoch and goes on to its own loads at once (no barrier, no LDS
-// round trip after the flag is seen).  Two polls are kept in flight: a flag is then sampled every half round trip to the
-// memory side.  Returns false on abort; waves that leave end the kernel, and a barrier only counts the waves still running.
+// round trip after the flag is seen).  ONE poll in flight per wave: the memory side serves flags and data alike, and two polls in
+// flight per wave made every hand-off of the chip slower (4 % on the loop), four much slower; relaying wave 0's poll to the other
+// waves through LDS was no faster than letting them poll.  Returns false on abort; waves that leave end the kernel, and a
+// barrier only counts the waves still running.
 __device__ __forceinline__ bool wait_epoch(const unsigned* flags, int n, unsigned epoch, unsigned* status, Ctl*) {
     const int lane = threadIdx.x & 63;
     const gu32* f = (const gu32*)flags + (lane < n ? lane : 0) * FLAG_STRIDE;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (unsigned spins = 1;; ++spins) {
-        const unsigned w = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (__all(v >= epoch)) return true;
-        v = w;
         if ((spins & 63u) == 0u) {
             const unsigned a = __hip_atomic_load((const gu32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a != 0u) return false;
@@ -957,16 +957,13 @@ __device__ __forceinline__ void tail_loop(const SysArgs& p, const Stage& st, Tai
     for (int s = 0; s < p.n_steps; ++s)
         for (int u = u0; u < nu; u += NTAIL) {
             if (!have) {
-                {                                                        // as wait_epoch (every wave), on the flags of the unit's blocks
+                {                                                        // every wave of the four tails polls the flags of the unit's blocks
                     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                     const gu32* f = flag_ptr(u);
-                    unsigned v = 0xffffffffu;
-                    if (lane < nflag) v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     for (unsigned spins = 1;; ++spins) {
-                        unsigned w = 0xffffffffu;
-                        if (lane < nflag) w = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        unsigned v = 0xffffffffu;
+                        if (lane < nflag) v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (__all(v >= (unsigned)(s + 1))) break;
-                        v = w;
                         if ((spins & 63u) == 0u) {
                             if (__hip_atomic_load((const gu32*)p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
                             if (__builtin_amdgcn_s_memrealtime() - t0 > TIMEOUT_TICKS) {
@@ -1011,6 +1008,8 @@ __global__ __launch_bounds__(256, 1) void systolic_loop_kernel(const SysArgs p) 
     // all LDS is dynamic (a static variable would shift the dynamic base off its 16-byte alignment, cdna_hip_programming.md G17)
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     Ctl* const ctl = reinterpret_cast<Ctl*>(lds + SYS_LDS_BYTES - 16);
+    if (threadIdx.x == 0) { ctl->abort = 0; ctl->ready = 0; }
+    __syncthreads();
     const Stage st = p.stages[blockIdx.x];
     switch (st.role) {
         case R_QKV: { QkvRole<MR, AR> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
