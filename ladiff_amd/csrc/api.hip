@@ -376,8 +376,8 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
     const bool pipeline = sp != nullptr && sp->loop == 1 && n_text == 1 && sys_supported(B, T, cfg, WSp != nullptr);
     // Block geometry of the pipeline for THIS call's lengths.  16-row blocks carry only the valid latent rows of each prompt
     // (length-aware packing; needs the counts on the host), 32-row blocks the padded T rows.  Measured (profiles/r2): a stage costs
-    // ~3.45 us per 16-row block and ~5.3 us per 32-row block (fp32: 6.8 / 13.0), and a step cannot be faster than one block's trip
-    // through the 59 stages: ~240 us with 16-row tiles, ~315 us with 32-row tiles (fp32: 430 / 430).  Pick the cheaper plan.
+    // ~3.4 us per 16-row block and ~5.3 us per 32-row block (fp32: 5.9 / 12.5), and a step cannot be faster than one block's trip
+    // through the 59 stages: ~228 us with 16-row tiles, ~304 us with 32-row tiles (fp32: 385 / 430).  Pick the cheaper plan.
     std::vector<unsigned char> plan;
     int plan_mr = 2, plan_nb = 0;
     if (pipeline) {
@@ -388,7 +388,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
         int want = sp->loop_mode == 2 ? 1 : (sp->loop_mode == 3 ? 2 : 0);
         if (want != 2) sys_pack_blocks(B, T, 1, h_counts, masked, p16, &mr16, &nb16);
         if (want == 0) {
-            const double c16 = WSp ? 3.45 : 6.8, c32 = WSp ? 5.3 : 13.0, lat16 = WSp ? 240.0 : 430.0, lat32 = WSp ? 315.0 : 430.0;
+            const double c16 = WSp ? 3.4 : 5.9, c32 = WSp ? 5.3 : 12.5, lat16 = WSp ? 228.0 : 385.0, lat32 = WSp ? 304.0 : 430.0;
             const double e16 = mr16 == 1 ? std::max(lat16, nb16 * c16) : 1e30, e32 = std::max(lat32, nb32 * c32);
             want = e16 < e32 ? 1 : 2;
         }
