@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256) void dec_cross_prep_kernel(const DecCrossPrepB
     }
 }
 
-// grid (B, chunks): the sample's G | U in LDS, one wave per frame row; TT = number of memory tokens (compile time, so the
-// TT score reductions of a head are independent chains the scheduler can interleave)
+// grid (B, chunks): the sample's G | U in LDS, 16 frame rows per workgroup pass; TT = number of memory tokens (compile time, so
+// the TT score reductions of a head are independent chains the scheduler can interleave)
 template <int TT>
 __global__ __launch_bounds__(256) void dec_cross_apply_kernel(const float* __restrict__ x, const float* __restrict__ gu,
                                                               const float* __restrict__ cc, const int32_t* __restrict__ counts,
@@ -80,26 +80,43 @@ __global__ __launch_bounds__(256) void dec_cross_apply_kernel(const float* __res
     int nv = counts != nullptr ? counts[b] : T;
     nv = nv > T ? T : nv;
     __syncthreads();
-    const int c4 = 4 * lane;
-    const f32x4 bo4 = ld4(bo + c4), gg = ld4(g2 + c4), bb = ld4(b2 + c4);
+    // a frame row on 16 lanes (lane l: columns 4 l + 64 k, k < 4), four rows per wave: the 4 T score reductions of a row are
+    // four DPP steps each (one wave per row needed six steps + a readlane per reduction, and was bound by them)
+    const int l16 = lane & 15, grp = lane >> 4, c0 = 4 * l16;
+    f32x4 bo4[4], gg[4], bb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { bo4[k] = ld4(bo + c0 + 64 * k); gg[k] = ld4(g2 + c0 + 64 * k); bb[k] = ld4(b2 + c0 + 64 * k); }
     size_t row0 = (size_t)b * F;
     if (row_off != nullptr) { row0 = row_off[b]; F = row_off[b + 1] - row_off[b]; }     // ragged rows: only the sample's own frames
     const int f0 = blockIdx.y * rows_per_wg;
     const int f1 = f0 + rows_per_wg < F ? f0 + rows_per_wg : F;
-    for (int f = f0 + wave; f < f1; f += 4) {
-        const size_t row = row0 + f;
-        const f32x4 xv = ld4(x + row * D + c4);
-        f32x4 acc = {bo4[0] + xv[0], bo4[1] + xv[1], bo4[2] + xv[2], bo4[3] + xv[3]};      // out_proj bias + residual
+    for (int fb = f0; fb < f1; fb += 16) {
+        const int f = fb + 4 * wave + grp;
+        const bool live = f < f1;
+        const size_t row = row0 + (live ? f : f1 - 1);
+        f32x4 xv[4], acc[4];
 #pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            xv[k] = ld4(x + row * D + c0 + 64 * k);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[k][i] = bo4[k][i] + xv[k][i];                   // out_proj bias + residual
+        }
+#pragma unroll 1                                  // one head at a time: unrolled over the heads the 8 T LDS reads per head pile up (spills)
         for (int h = 0; h < H; ++h) {
             float sc[T];
 #pragma unroll
             for (int j = 0; j < T; ++j) {
-                const f32x4 g4 = ld4(sm + ((size_t)(h * T + j) * 2) * D + c4);
-                sc[j] = xv[0] * g4[0] + xv[1] * g4[1] + xv[2] * g4[2] + xv[3] * g4[3];
+                const float* gp = sm + ((size_t)(h * T + j) * 2) * D + c0;
+                float d = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 g4 = ld4(gp + 64 * k);
+                    d = fmaf(xv[k][0], g4[0], fmaf(xv[k][1], g4[1], fmaf(xv[k][2], g4[2], fmaf(xv[k][3], g4[3], d))));
+                }
+                sc[j] = d;
             }
 #pragma unroll
-            for (int j = 0; j < T; ++j) sc[j] = wave_sum(sc[j]) + cs[h * T + j];
+            for (int j = 0; j < T; ++j) sc[j] = row16_sum(sc[j]) + cs[h * T + j];
             float m = -INFINITY;
 #pragma unroll
             for (int j = 0; j < T; ++j) { sc[j] = j < nv ? sc[j] : -INFINITY; m = fmaxf(m, sc[j]); }   // tokens >= count masked (:408-409)
@@ -110,22 +127,36 @@ __global__ __launch_bounds__(256) void dec_cross_apply_kernel(const float* __res
 #pragma unroll
             for (int j = 0; j < T; ++j) {
                 const float pj = sc[j] * inv;
-                const f32x4 u4 = ld4(sm + ((size_t)(h * T + j) * 2 + 1) * D + c4);
-                acc[0] = fmaf(pj, u4[0], acc[0]); acc[1] = fmaf(pj, u4[1], acc[1]);
-                acc[2] = fmaf(pj, u4[2], acc[2]); acc[3] = fmaf(pj, u4[3], acc[3]);
+                const float* up = sm + ((size_t)(h * T + j) * 2 + 1) * D + c0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 u4 = ld4(up + 64 * k);
+                    acc[k][0] = fmaf(pj, u4[0], acc[k][0]); acc[k][1] = fmaf(pj, u4[1], acc[k][1]);
+                    acc[k][2] = fmaf(pj, u4[2], acc[k][2]); acc[k][3] = fmaf(pj, u4[3], acc[k][3]);
+                }
             }
         }
         // norm2 over the row (two-pass, as rowops.hip)
-        const float mean = wave_sum(acc[0] + acc[1] + acc[2] + acc[3]) * (1.f / 256.f);
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sum += (acc[k][0] + acc[k][1]) + (acc[k][2] + acc[k][3]);
+        const float mean = row16_sum(sum) * (1.f / 256.f);
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const float dlt = acc[i] - mean; q += dlt * dlt; }
-        const float rstd = rsqrtf(wave_sum(q) * (1.f / 256.f) + LN_EPS);
-        f32x4 o;
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (acc[i] - mean) * rstd * gg[i] + bb[i];
-        st4(y + row * D + c4, o);
-        if (ys != nullptr) store_split4(ys + row * D, c4, o);
+            for (int i = 0; i < 4; ++i) { const float dlt = acc[k][i] - mean; q += dlt * dlt; }
+        const float rstd = rsqrtf(row16_sum(q) * (1.f / 256.f) + LN_EPS);
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                f32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (acc[k][i] - mean) * rstd * gg[k][i] + bb[k][i];
+                st4(y + row * D + c0 + 64 * k, o);
+                if (ys != nullptr) store_split4(ys + row * D, c0 + 64 * k, o);
+            }
+        }
     }
 }
 
@@ -151,7 +182,7 @@ int launch_decoder_cross_apply(const float* x, const float* bo, const float* g2,
     int chunks = (512 + B - 1) / B;
     if (chunks < 1) chunks = 1;
     if (chunks > (F + 3) / 4) chunks = (F + 3) / 4;
-    const int rows_per_wg = ((F + chunks - 1) / chunks + 3) / 4 * 4;
+    const int rows_per_wg = ((F + chunks - 1) / chunks + 15) / 16 * 16;
     chunks = (F + rows_per_wg - 1) / rows_per_wg;
     const size_t lds = ((size_t)H * T * 2 * D + H * T) * sizeof(float);
     static bool attr_set = false;
