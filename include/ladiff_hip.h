@@ -217,6 +217,11 @@ int ladiff_sampler_destroy(void* sampler);
  * as many prompts as fit with only their valid latent rows; needs h_counts) - whichever the stage-time model predicts faster;
  * 2 / 3 force the 16- / 32-row plan; 0 = one launch per stage, captured in a hipGraph of up to 10 steps. */
 int ladiff_sampler_set_loop(void* sampler, int mode);
+/* The block plan ladiff_diffusion_reverse would use for a batch (host arithmetic only, no GPU call): rows per block (16 = the
+ * length-aware packing, 32 = padded blocks) and the number of blocks.  h_counts = latent counts on the host or NULL, masked = the
+ * call passes device counts, loop_mode 1 / 2 / 3 as ladiff_sampler_set_loop, bf16x3 = the call passes w_split. */
+int ladiff_reverse_plan(int B, int T, const int32_t* h_counts, int masked, int loop_mode, int bf16x3, int* rows_per_block,
+                        int* n_blocks);
 /* Device time of the N-step loop of the sampler's last call (HIP events recorded on the call's stream right around the
  * pipeline kernel, or around the graph replays); blocks until it has finished.  Measurement aid (bench.py). */
 int ladiff_sampler_loop_ms(void* sampler, float* ms);

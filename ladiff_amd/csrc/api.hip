@@ -294,6 +294,36 @@ int ladiff_sampler_destroy(void* sampler) {
     return 0;
 }
 
+}  // extern "C"
+
+// Block plan of the pipeline loop for one call (host only).  loop_mode: 1 = pick by the cost model, 2 / 3 = force 16- / 32-row blocks.
+static void choose_plan(int B, int T, const int32_t* h_counts, bool masked, int loop_mode, bool bf16x3, std::vector<unsigned char>& plan,
+                        int* plan_mr, int* plan_nb) {
+    int mr16 = 1, nb16 = 0, mr32 = 2, nb32 = 0;
+    std::vector<unsigned char> p16, p32;
+    sys_pack_blocks(B, T, 2, h_counts, masked, p32, &mr32, &nb32);
+    int want = loop_mode == 2 ? 1 : (loop_mode == 3 ? 2 : 0);
+    if (want != 2) sys_pack_blocks(B, T, 1, h_counts, masked, p16, &mr16, &nb16);
+    if (want == 0) {
+        const double c16 = bf16x3 ? 3.4 : 5.9, c32 = bf16x3 ? 5.3 : 12.5, lat16 = bf16x3 ? 228.0 : 385.0, lat32 = bf16x3 ? 304.0 : 430.0;
+        const double e16 = mr16 == 1 ? std::max(lat16, nb16 * c16) : 1e30, e32 = std::max(lat32, nb32 * c32);
+        want = e16 < e32 ? 1 : 2;
+    }
+    if (want == 1 && mr16 == 1) { plan.swap(p16); *plan_mr = 1; *plan_nb = nb16; }
+    else { plan.swap(p32); *plan_mr = 2; *plan_nb = nb32; }
+}
+
+extern "C" {
+
+int ladiff_reverse_plan(int B, int T, const int32_t* h_counts, int masked, int loop_mode, int bf16x3, int* rows_per_block, int* n_blocks) {
+    LADIFF_CHECK_ARG(B >= 1 && T >= 1 && T <= LADIFF_MAX_LATENTS && loop_mode >= 1 && loop_mode <= 3 && rows_per_block && n_blocks);
+    std::vector<unsigned char> plan;
+    int mr = 2, nb = 0;
+    choose_plan(B, T, h_counts, masked != 0, loop_mode, bf16x3 != 0, plan, &mr, &nb);
+    *rows_per_block = 16 * mr; *n_blocks = nb;
+    return 0;
+}
+
 int ladiff_sampler_set_loop(void* sampler, int mode) {
     Sampler* sp = reinterpret_cast<Sampler*>(sampler);
     LADIFF_CHECK_ARG(sp != nullptr && mode >= 0 && mode <= 3);
@@ -380,21 +410,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
     // through the 59 stages: ~228 us with 16-row tiles, ~304 us with 32-row tiles (fp32: 385 / 430).  Pick the cheaper plan.
     std::vector<unsigned char> plan;
     int plan_mr = 2, plan_nb = 0;
-    if (pipeline) {
-        const bool masked = counts != nullptr;
-        int mr16 = 1, nb16 = 0, mr32 = 2, nb32 = 0;
-        std::vector<unsigned char> p16, p32;
-        sys_pack_blocks(B, T, 2, h_counts, masked, p32, &mr32, &nb32);
-        int want = sp->loop_mode == 2 ? 1 : (sp->loop_mode == 3 ? 2 : 0);
-        if (want != 2) sys_pack_blocks(B, T, 1, h_counts, masked, p16, &mr16, &nb16);
-        if (want == 0) {
-            const double c16 = WSp ? 3.4 : 5.9, c32 = WSp ? 5.3 : 12.5, lat16 = WSp ? 228.0 : 385.0, lat32 = WSp ? 304.0 : 430.0;
-            const double e16 = mr16 == 1 ? std::max(lat16, nb16 * c16) : 1e30, e32 = std::max(lat32, nb32 * c32);
-            want = e16 < e32 ? 1 : 2;
-        }
-        if (want == 1 && mr16 == 1) { plan.swap(p16); plan_mr = 1; plan_nb = nb16; }
-        else { plan.swap(p32); plan_mr = 2; plan_nb = nb32; }
-    }
+    if (pipeline) choose_plan(B, T, h_counts, counts != nullptr, sp->loop_mode, WSp != nullptr, plan, &plan_mr, &plan_nb);
     // c-table rows of the window that starts at step `lo` (plain launches, outside the graphs: `lo` changes per window)
     auto open_window = [&](int lo) -> int {
         if (n_text > 1) return 0;

@@ -81,6 +81,36 @@ def test_workspace_queries(lib):
     assert lib.ladiff_decoder_workspace_bytes(128, 196, 5, 263) >= 128 * 196 * 4096 * 4
 
 
+def test_block_plan_of_the_pipeline_loop(lib):
+    """Host arithmetic of the pipeline loop's block plan (ladiff_reverse_plan): padded 32-row blocks hold both guidance branches
+    of 3 prompts, the length-aware 16-row packing one branch of as many prompts as fit with only their valid latent rows."""
+    import ctypes
+    import math
+
+    def plan(lengths, mode, masked=True, host=True, T=5):
+        B = len(lengths)
+        counts = (ctypes.c_int32 * B)(*[math.ceil(l / 48) for l in lengths])
+        rows, nb = ctypes.c_int(0), ctypes.c_int(0)
+        rc = lib.ladiff_reverse_plan(B, T, ctypes.cast(counts, ctypes.c_void_p) if host else None, int(masked), mode, 1,
+                                     ctypes.byref(rows), ctypes.byref(nb))
+        assert rc == 0
+        return rows.value, nb.value
+
+    uniform = [196] * 128
+    assert plan(uniform, 3) == (32, 43)                       # ceil(128 / 3) blocks of 30 rows
+    assert plan(uniform, 2) == (16, 86)                       # 43 groups of 3 prompts x 2 branches
+    mixed = ([60, 120, 196] * 43)[:128]                       # latent counts 2 / 3 / 5
+    rows, nb = plan(mixed, 2)
+    assert rows == 16
+    live = sum(math.ceil(l / 48) for l in mixed)
+    assert 2 * math.ceil(live / 16) <= nb <= 62               # 427 valid rows per branch: >= 27 blocks, packing reaches 30
+    assert plan(mixed, 1)[0] == 16 and plan(uniform, 1)[0] == 16          # the cost model takes the packed plan for both
+    assert plan([196], 1) == (16, 2) and plan([196], 3) == (32, 1)    # one prompt: the 16-row plan's trip through the stages is shorter
+    assert plan(mixed, 2, host=False) == (32, 43)              # counts on the device only: the packing needs them on the host
+    assert plan([40] * 40, 2) == (16, 10)                      # one-row prompts: 8 per block (text K|V slots), 5 groups x 2 branches
+    assert lib.ladiff_reverse_plan(0, 5, None, 0, 1, 1, None, None) != 0
+
+
 def test_argument_errors_do_not_touch_the_gpu(lib):
     assert lib.ladiff_layernorm(None, None, None, None, 4, None) == -1
     assert lib.ladiff_gemm(None, 0, None, 0, 0, None, 0, None, None, 0, None, None, None, 0, 1, 1, 32, 0, None) == -1
