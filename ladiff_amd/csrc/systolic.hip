@@ -34,6 +34,7 @@
 // differs (8 hidden slices instead of 4 K-slices).
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "model.h"
@@ -1277,6 +1278,17 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
 #ifdef LADIFF_STAMPS
     a.stamps = g_sys_stamps;
 #endif
+    // A pipeline kernel needs its 255 workgroups resident at once: two of them launched on different streams of one process
+    // could each hold part of the chip and wait for the rest (they would time out, not hang, but the results are lost).  Launches are
+    // therefore chained through one event per device: the next one, on whatever stream, starts after the previous one has ended.
+    static std::mutex mu;
+    static hipEvent_t done[64] = {};
+    int dev = 0;
+    LADIFF_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return LADIFF_ERR_ARG;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done[dev] == nullptr) LADIFF_HIP(hipEventCreateWithFlags(&done[dev], hipEventDisableTiming));
+    else LADIFF_HIP(hipStreamWaitEvent(s, done[dev], 0));
     // the abort word and the flags: two memset nodes (the block descriptors sit between them)
     LADIFF_HIP(hipMemsetAsync(a.status, 0, 64 * sizeof(float), s));
     LADIFF_HIP(hipMemsetAsync(a.flags, 0, (L.off_xin0 - L.off_flags) * sizeof(float), s));
@@ -1288,6 +1300,7 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
         else hipLaunchKernelGGL((systolic_loop_kernel<2, 0>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
     }
     LADIFF_LAUNCH_CHECK();
+    LADIFF_HIP(hipEventRecord(done[dev], s));
     return 0;
 }
 

@@ -105,6 +105,33 @@ def test_ragged_decode_matches_padded_pass(nets):
     vae.precision = old
 
 
+def test_two_samplers_on_two_streams(nets):
+    """A pipeline kernel needs the whole chip resident: launches from different streams of one process are chained through an
+    event (systolic.hip), so two samplers enqueued back to back on two streams both complete with the right result."""
+    den, vae = nets
+    lens = [196, 60, 120, 100, 48, 150, 196, 30]
+    B = len(lens)
+    text = syn.text_embeddings(B, seed=77).to(DEV)
+    noise = torch.randn(B, 5, 256, generator=torch.Generator().manual_seed(5)).to(DEV)
+    sched = lambda: DDIMScheduler(set_alpha_to_one=False, steps_offset=1, **SCHED_KW)
+    ref = LADIFF(denoiser=den, vae=vae, scheduler=sched(), guidance_scale=7.5, num_inference_timesteps=20, eta=0.0, max_it=5,
+                 precision="bf16x3", loop="launches")._diffusion_reverse(text, lens, init_noise=noise)
+    pipes = [LADIFF(denoiser=den, vae=vae, scheduler=sched(), guidance_scale=7.5, num_inference_timesteps=20, eta=0.0, max_it=5,
+                    precision="bf16x3", loop="pipeline") for _ in range(2)]
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(3):                                             # interleaved launches, nothing synchronises in between
+        for pipe, st in zip(pipes, streams):
+            with torch.cuda.stream(st):
+                outs.append(pipe._diffusion_reverse(text, lens, init_noise=noise))
+    torch.cuda.synchronize()
+    for pipe in pipes:
+        assert pipe.loop_status() == (0, 0)
+    for z in outs:
+        assert (z - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+
+
 def test_pipeline_ddpm_windows(nets):
     """A 200-step DDPM schedule runs as four 50-step windows (the c table is rebuilt per window, the latents carry over),
     with the per-step noise stream: pipeline == launches."""
