@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256) void dec_cross_apply_kernel(const float* __res
                                                               const float* __restrict__ bo, const float* __restrict__ g2,
                                                               const float* __restrict__ b2, int F, int rows_per_wg,
                                                               float* __restrict__ y, float* __restrict__ ys,
-                                                              const int32_t* __restrict__ row_off) {
+                                                              const int32_t* __restrict__ row_off, const float* __restrict__ g1,
+                                                              const float* __restrict__ b1) {
     extern __shared__ __attribute__((aligned(16))) float sm[];                    // [H][TT][2][256], then c [H][TT]
     constexpr int T = TT, HT = H * TT;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -96,11 +97,29 @@ __global__ __launch_bounds__(256) void dec_cross_apply_kernel(const float* __res
         const size_t row = row0 + (live ? f : f1 - 1);
         f32x4 xv[4], acc[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            xv[k] = ld4(x + row * D + c0 + 64 * k);
+        for (int k = 0; k < 4; ++k) xv[k] = ld4(x + row * D + c0 + 64 * k);
+        if (g1 != nullptr) {                                                                // the row arrives before norm1: apply it here (two-pass)
+            float s1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s1 += (xv[k][0] + xv[k][1]) + (xv[k][2] + xv[k][3]);
+            const float mean1 = row16_sum(s1) * (1.f / 256.f);
+            float q1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const float dlt = xv[k][i] - mean1; q1 += dlt * dlt; }
+            const float rstd1 = rsqrtf(row16_sum(q1) * (1.f / 256.f) + LN_EPS);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 ga = ld4(g1 + c0 + 64 * k), be = ld4(b1 + c0 + 64 * k);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xv[k][i] = (xv[k][i] - mean1) * rstd1 * ga[i] + be[i];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[k][i] = bo4[k][i] + xv[k][i];                   // out_proj bias + residual
-        }
 #pragma unroll 1                                  // one head at a time: unrolled over the heads the 8 T LDS reads per head pile up (spills)
         for (int h = 0; h < H; ++h) {
             float sc[T];
@@ -173,7 +192,8 @@ int launch_decoder_cross_prep(const DecCrossPrepBatch& pb, int n, int B, int T, 
 
 // y = LN2(x + cross_attention(x, kv)) from the layer's prepared G | U | c (gu_ws, launch_decoder_cross_prep)
 int launch_decoder_cross_apply(const float* x, const float* bo, const float* g2, const float* b2, const int32_t* counts, int B, int F,
-                               int T, const float* gu_ws, float* y, float* ys, hipStream_t s, const int32_t* row_off) {
+                               int T, const float* gu_ws, float* y, float* ys, hipStream_t s, const int32_t* row_off, const float* g1,
+                               const float* b1) {
     if (B == 0 || F == 0) return 0;
     if (T < 1 || T > TM) return LADIFF_ERR_SHAPE;
     const float* gu = gu_ws;
@@ -194,7 +214,7 @@ int launch_decoder_cross_apply(const float* x, const float* bo, const float* g2,
 #define LADIFF_DC_CASE(TT)                                                                                                   \
     case TT:                                                                                                                 \
         hipLaunchKernelGGL(dec_cross_apply_kernel<TT>, dim3(B, chunks), dim3(256), lds, s, x, gu, cc, counts, bo, g2, b2, F, \
-                           rows_per_wg, y, ys, row_off);                                                                              \
+                           rows_per_wg, y, ys, row_off, g1, b1);                                                                              \
         break;
     switch (T) {
         LADIFF_DC_CASE(1) LADIFF_DC_CASE(2) LADIFF_DC_CASE(3) LADIFF_DC_CASE(4)

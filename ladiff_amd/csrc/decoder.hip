@@ -109,11 +109,21 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
         }
         if (sp) LADIFF_TRY(launch_self_attention_bf16x3(qkv, lengths, nullptr, att, B, F, H, 0, 1, s, row_off));
         else LADIFF_TRY(launch_decoder_self_attention(qkv, lengths, nullptr, att, B, F, 0, s, row_off));
-        LADIFF_TRY(gemm_ln(att, D, L.self_attn.out_w, Ls.self_attn.out_w, L.self_attn.out_b, cur, L.norm1, nullptr, P[1], nullptr));   // only read in fp32 (dec_cross apply)
+        // norm1: fused in the GEMM epilogue in fp32 mode; in bf16x3 mode the GEMM writes x + out_proj(att) and the only reader of
+        // norm1's output, the cross-attention kernel below, normalises its rows as it loads them (one row kernel pass less)
+        const NormW* n1_late = nullptr;
+        if (sp) {
+            GemmArgs g = lin(att, D, Ls.self_attn.out_w, L.self_attn.out_b, P[1], D, M, D, D);
+            g.res = cur; g.ldres = D; g.split = 1;
+            LADIFF_TRY(launch_gemm(g, s));
+            n1_late = &L.norm1;
+        } else {
+            LADIFF_TRY(gemm_ln(att, D, L.self_attn.out_w, Ls.self_attn.out_w, L.self_attn.out_b, cur, L.norm1, nullptr, P[1], nullptr));
+        }
         // ---- cross-attention to the latent tokens, tokens >= ceil(len/48) masked, + residual + norm2   :373-376, :408-409
         // (the q / out projections are folded into the <= 8 keys / values per sample: dec_cross.hip; fp32 in both modes)
         LADIFF_TRY(launch_decoder_cross_apply(P[1], L.cross_attn.out_b, L.norm2.g, L.norm2.b, counts, B, F, T, guws + l * gu_l, P[2],
-                                              Ps[2], s, row_off));
+                                              Ps[2], s, row_off, n1_late ? n1_late->g : nullptr, n1_late ? n1_late->b : nullptr));
         // ---- feed-forward, GELU(erf)   :410-412
         {
             GemmArgs g = lin(sp ? Ps[2] : P[2], D, Ls.lin1.w, L.lin1.b, sp ? nullptr : hid, FF, M, FF, D, ACT_GELU);
