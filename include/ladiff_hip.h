@@ -217,6 +217,9 @@ int ladiff_sampler_destroy(void* sampler);
  * as many prompts as fit with only their valid latent rows; needs h_counts) - whichever the stage-time model predicts faster;
  * 2 / 3 force the 16- / 32-row plan; 0 = one launch per stage, captured in a hipGraph of up to 10 steps. */
 int ladiff_sampler_set_loop(void* sampler, int mode);
+/* Measurement switch (process-wide): waves per SIMD of the stage workgroups of the 16-row plan, 2 (default: 512-thread workgroups,
+ * each stage's weight slice split over the two waves of a SIMD) or 1 (256 threads). */
+int ladiff_debug_set_stage_waves(int waves_per_simd);
 /* The block plan ladiff_diffusion_reverse would use for a batch (host arithmetic only, no GPU call): rows per block (16 = the
  * length-aware packing, 32 = padded blocks) and the number of blocks.  h_counts = latent counts on the host or NULL, masked = the
  * call passes device counts, loop_mode 1 / 2 / 3 as ladiff_sampler_set_loop, bf16x3 = the call passes w_split. */

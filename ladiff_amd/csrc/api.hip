@@ -324,6 +324,12 @@ int ladiff_reverse_plan(int B, int T, const int32_t* h_counts, int masked, int l
     return 0;
 }
 
+int ladiff_debug_set_stage_waves(int waves_per_simd) {
+    LADIFF_CHECK_ARG(waves_per_simd == 1 || waves_per_simd == 2);
+    g_waves16 = waves_per_simd;
+    return 0;
+}
+
 int ladiff_sampler_set_loop(void* sampler, int mode) {
     Sampler* sp = reinterpret_cast<Sampler*>(sampler);
     LADIFF_CHECK_ARG(sp != nullptr && mode >= 0 && mode <= 3);

@@ -198,23 +198,23 @@ __device__ __forceinline__ unsigned* flag_of(const SysArgs& p, int group, int b,
 }
 
 // ---------------------------------------------------------------- LDS images (tile_mma.h) of hand-off rows
-// A [16 MR][256] fp32 block of rows held in registers between its loads and its LDS image: thread t owns the 8-column
-// units id = t + 256 u (row id / 32, columns 8 (id % 32) ..)
-template <int MR> struct Rows256 { f32x4 v[2 * MR][2]; };
-template <int MR>
-__device__ __forceinline__ void issue_rows(Rows256<MR>& x, __amdgpu_buffer_rsrc_t r, unsigned base) {
+// A [16 MR][256] fp32 block of rows held in registers between its loads and its LDS image: thread t of the 256 WS threads owns
+// the 8-column units id = t + 256 WS u (row id / 32, columns 8 (id % 32) ..).  WS = waves per SIMD of the stage workgroup.
+template <int MR, int WS> struct Rows256 { f32x4 v[2 * MR / WS][2]; };
+template <int MR, int WS>
+__device__ __forceinline__ void issue_rows(Rows256<MR, WS>& x, __amdgpu_buffer_rsrc_t r, unsigned base) {
 #pragma unroll
-    for (int u = 0; u < 2 * MR; ++u) {
-        const int id = threadIdx.x + 256 * u, row = id >> 5, c8 = id & 31;
+    for (int u = 0; u < 2 * MR / WS; ++u) {
+        const int id = threadIdx.x + 256 * WS * u, row = id >> 5, c8 = id & 31;
         x.v[u][0] = ld_sc1(r, base + row * 1024 + c8 * 32);
         x.v[u][1] = ld_sc1(r, base + row * 1024 + c8 * 32 + 16);
     }
 }
-template <int AR, int KB, int MR>
-__device__ __forceinline__ void commit_rows(char* tile, int kb0, const Rows256<MR>& x) {
+template <int AR, int KB, int MR, int WS>
+__device__ __forceinline__ void commit_rows(char* tile, int kb0, const Rows256<MR, WS>& x) {
 #pragma unroll
-    for (int u = 0; u < 2 * MR; ++u) {
-        const int id = threadIdx.x + 256 * u, row = id >> 5, c8 = id & 31;
+    for (int u = 0; u < 2 * MR / WS; ++u) {
+        const int id = threadIdx.x + 256 * WS * u, row = id >> 5, c8 = id & 31;
         if constexpr (AR == 0) {
             bf16x8 hi, lo;
             split8(x.v[u][0], x.v[u][1], hi, lo);
@@ -349,19 +349,29 @@ __device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R&
 // ---------------------------------------------------------------- roles
 // QKV: one head.  in_proj rows {q,k,v} x 64 of head `slice` on the block, then softmax(q k^T / 8) v over the valid latent
 // keys of the row's sample-branch, the text token and the time token.  Geometry comes from the block descriptor (LDS copy).
-template <int MR, int AR>
+// WS = waves per SIMD.  The head's 192 columns are 12 MFMA tiles, three per SIMD: with one wave per SIMD the wave takes all three;
+// with two, wave s (< 4) takes the first two of SIMD s and wave s + 4 the third - two instruction streams per SIMD cover each
+// other's LDS / DPP / barrier latencies.
+template <int MR, int AR, int WS>
 struct QkvRole {
     static constexpr int RT = 16 * MR, QLD = 196, TK = LADIFF_MAX_LATENTS + 2;   // keys of a row: <= 8 latents, text, time
+    static constexpr int NTH = 256 * WS, NTW = WS == 1 ? 3 : 2, NX = 2 / WS;      // threads; column tiles a wave can hold; 16-byte text K|V units per thread
     static constexpr bool PREFETCH = true;
-    struct Geo { int gw, rb2, b2[2]; };                                  // descriptor word `tid` (+ its row's sample-branch); sample-branch of this thread's text slots
-    struct Pay { Rows256<MR> x; f32x4 xk[2]; };
+    struct Geo { int gw, rb2, b2[NX]; };                                 // descriptor word `tid` (+ its row's sample-branch); sample-branch of this thread's text slots
+    struct Pay { Rows256<MR, WS> x; f32x4 xk[NX]; };
     const SysArgs& p; const Stage& st;
     char* atile; float *qt, *xt; int* gd;
-    WFrag<AR, 3, 8> wf;
-    float bcol[3];
+    WFrag<AR, NTW, 8> wf;
+    float bcol[NTW];
     __amdgpu_buffer_rsrc_t rin, rout;
     const float* tkv;
-    int h, T, nkeys;
+    int h, T, nkeys, nvt;                                                // nvt: column tiles this wave really has
+    // tile column of this wave's tile j (j >= nvt: a duplicate of a valid one, loaded but never used)
+    __device__ __forceinline__ int tile_col(int j) const {
+        const int wave = threadIdx.x >> 6;
+        if constexpr (WS == 1) return 48 * wave + 16 * j;
+        else return 48 * (wave & 3) + (wave < 4 ? 16 * j : 32);
+    }
 
     __device__ __forceinline__ QkvRole(const SysArgs& p_, const Stage& st_, char* lds) : p(p_), st(st_) {
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frow = lane & 15;
@@ -370,10 +380,11 @@ struct QkvRole {
         qt = reinterpret_cast<float*>(lds + tile_bytes<AR, 4>(RT));      // [RT][QLD] q | k | v (fp32)
         xt = qt + RT * QLD;                                              // [16][128]: text k|v per sample-branch, slot 15: time k|v
         gd = reinterpret_cast<int*>(xt + 16 * 128);                      // [0] rows of this block, [1 + r] row_pk (counts resolved)
-        // tile column tc = 48 wave + 16 j + frow: part tc / 64 (q, k, v), matrix row part * 256 + h * 64 + tc % 64
-        load_w(wf, st.w0, D, 0, [&](int j) { const int tc = 48 * wave + 16 * j; return (tc >> 6) * 256 + h * 64 + (tc & 63); });
+        nvt = WS == 1 ? 3 : (wave < 4 ? 2 : 1);
+        // tile column tc (+ frow): part tc / 64 (q, k, v), matrix row part * 256 + h * 64 + tc % 64
+        load_w(wf, st.w0, D, 0, [&](int j) { const int tc = tile_col(j); return (tc >> 6) * 256 + h * 64 + (tc & 63); });
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { const int tc = 48 * wave + 16 * j + frow; bcol[j] = st.b0[(tc >> 6) * 256 + h * 64 + (tc & 63)]; }
+        for (int j = 0; j < NTW; ++j) { const int tc = tile_col(j) + frow; bcol[j] = st.b0[(tc >> 6) * 256 + h * 64 + (tc & 63)]; }
         rin = rsrc_of(st.in0); rout = rsrc_of(st.out);
         tkv = p.tkv + (size_t)st.layer * 2 * p.B * 512;
     }
@@ -381,7 +392,7 @@ struct QkvRole {
         const int tid = threadIdx.x;
         const BlockDesc* d = p.blocks + b;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) { const int sx = (tid + 256 * u) >> 5; g.b2[u] = sx < 15 ? d->b2[sx] : -1; }
+        for (int u = 0; u < NX; ++u) { const int sx = (tid + NTH * u) >> 5; g.b2[u] = sx < 15 ? d->b2[sx] : -1; }
         // one load per value (two loads into one register from different branches would make the second wait for the first -
         // and for every load issued before it)
         const int* src = tid == 0 ? &d->nrows : &d->row_pk[tid <= RT ? tid - 1 : 0];
@@ -400,35 +411,45 @@ struct QkvRole {
         const int tid = threadIdx.x;
         const float* timekv = p.tables + (size_t)(p.step_lo + s) * DEN_STEP_STRIDE + st.layer * DEN_LAYER_STRIDE + DEN_OFF_TIME_KV;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {                                    // text K|V slices of this head per sample-branch, slot 15: time
-            const int f4 = tid + 256 * u, sx = f4 >> 5, c4 = (f4 & 31) * 4;
+        for (int u = 0; u < NX; ++u) {                                   // text K|V slices of this head per sample-branch, slot 15: time
+            const int f4 = tid + NTH * u, sx = f4 >> 5, c4 = (f4 & 31) * 4;
             y.xk[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (sx == 15) y.xk[u] = ld4(timekv + (c4 < 64 ? c4 : 192 + c4) + h * 64);
             else if (g.b2[u] >= 0) y.xk[u] = ld4(tkv + (size_t)g.b2[u] * 512 + (c4 < 64 ? c4 : 192 + c4) + h * 64);
         }
-        issue_rows<MR>(y.x, rin, (unsigned)b * RT * 1024);
+        issue_rows<MR, WS>(y.x, rin, (unsigned)b * RT * 1024);
     }
-    __device__ __forceinline__ void commit(const Pay& y) { commit_rows<AR, 4, MR>(atile, 0, y.x); }
+    __device__ __forceinline__ void commit(const Pay& y) { commit_rows<AR, 4, MR, WS>(atile, 0, y.x); }
     template <class M>
     __device__ __forceinline__ void compute(int s, int b, const Geo& g, const Pay& y, M& mid) {
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frow = lane & 15;
-        f32x4 acc[MR][3];
+        const int tid = threadIdx.x, lane = tid & 63, frow = lane & 15;
+        f32x4 acc[MR][NTW];
         zero_acc(acc);
-        mma<AR, 4, 3, 8, MR>(atile, wf, acc);
+        if (nvt == NTW) {
+            mma<AR, 4, NTW, 8, MR>(atile, wf, acc);
+        } else {                                                         // the SIMD's second wave: one tile (the fragment set's first)
+            f32x4 a1[MR][1];
+            zero_acc(a1);
+            mma<AR, 4, 1, 8, MR, NTW>(atile, wf, a1);
+#pragma unroll
+            for (int i = 0; i < MR; ++i) acc[i][0] = a1[i][0];
+        }
         SYS_STAMP(3);
         // text / time K|V and the descriptor are read by the attention phases below, up to the END of the previous block's
         // compute: they go to LDS here, behind the stage loop's barrier, not in commit()
 #pragma unroll
-        for (int u = 0; u < 2; ++u) st4(xt + (tid + 256 * u) * 4, y.xk[u]);
+        for (int u = 0; u < NX; ++u) st4(xt + (tid + NTH * u) * 4, y.xk[u]);
         if (tid <= RT) gd[tid] = g.gw;
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int tc = 48 * wave + 16 * j + frow;
-                const float scl = tc < 64 ? 0.125f : 1.f;               // q / sqrt(64), exact
+            for (int j = 0; j < NTW; ++j) {
+                if (j < nvt) {
+                    const int tc = tile_col(j) + frow;
+                    const float scl = tc < 64 ? 0.125f : 1.f;           // q / sqrt(64), exact
 #pragma unroll
-                for (int r = 0; r < 4; ++r) qt[(16 * i + 4 * (lane >> 4) + r) * QLD + tc] = (acc[i][j][r] + bcol[j]) * scl;
+                    for (int r = 0; r < 4; ++r) qt[(16 * i + 4 * (lane >> 4) + r) * QLD + tc] = (acc[i][j][r] + bcol[j]) * scl;
+                }
             }
         mid.before_barrier();
         __syncthreads();
@@ -444,8 +465,9 @@ struct QkvRole {
         // attention of a row on 16 lanes (4 of the head's 64 columns each): the scores are reduced across the lanes with DPP,
         // softmax and the weighted sum of the values stay in registers - no barrier, no score tile
 #pragma unroll
-        for (int u = 0; u < MR; ++u) {
-            const int id = tid + 256 * u, row = id >> 4, c4 = (id & 15) * 4;
+        for (int u = 0; u < (256 * MR + NTH - 1) / NTH; ++u) {           // 16 lanes per row: 256 MR items over NTH threads (whole waves may have none)
+            const int id = tid + NTH * u, row = id >> 4, c4 = (id & 15) * 4;
+            if (id >= 256 * MR) continue;
             const bool live = row < nrows;
             const int pk = live ? gd[1 + row] : 0, sx = pk & 0xff, r0 = (pk >> 8) & 0xff, nk = pk >> 16;
             const f32x4 q4 = ld4(qt + (live ? row : 0) * QLD + c4);
@@ -461,11 +483,20 @@ struct QkvRole {
                 const bool on = live && j < nkeys && (j >= T || j < nk);     // keys >= the latent count: masked
                 const float* kp = j < T ? kt + j * QLD : (j == T ? xs : xm);
                 k4[j] = ld4(on ? kp : qt + c4);
-                v4[j] = ld4(on ? kp + 64 : qt + c4);
+                if constexpr (WS == 1) v4[j] = ld4(on ? kp + 64 : qt + c4);
             }
 #pragma unroll
             for (int j = 0; j < NKEY; ++j)
                 e[j] = row16_sum(fmaf(q4[0], k4[j][0], fmaf(q4[1], k4[j][1], fmaf(q4[2], k4[j][2], q4[3] * k4[j][3]))));
+            if constexpr (WS == 2) {                                     // 256 registers per wave: the values are fetched once the keys are done with
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NKEY; ++j) {
+                    const bool on = live && j < nkeys && (j >= T || j < nk);
+                    const float* kp = j < T ? kt + j * QLD : (j == T ? xs : xm);
+                    v4[j] = ld4(on ? kp + 64 : qt + c4);
+                }
+            }
             float m = -INFINITY;
 #pragma unroll
             for (int j = 0; j < NKEY; ++j) {
@@ -490,21 +521,21 @@ struct QkvRole {
 };
 
 // OUT: X1 = LN1(x + out_proj(att))
-template <int MR, int AR>
+template <int MR, int AR, int WS>
 struct OutRole {
-    static constexpr int RT = 16 * MR, RPW = RT / 4;
+    static constexpr int RT = 16 * MR, NW = 4 * WS, RPW = RT / NW, NTW = 16 / NW;     // rows / column tiles per wave
     static constexpr bool PREFETCH = true;
     struct Geo {};
-    struct Pay { Rows256<MR> att; f32x4 res[RPW]; };
+    struct Pay { Rows256<MR, WS> att; f32x4 res[RPW]; };
     const SysArgs& p; const Stage& st;
     char* atile; float* ct;
-    WFrag<AR, 4, 8> wf;
+    WFrag<AR, NTW, 8> wf;
     f32x4 bias, gg, bb;
     __amdgpu_buffer_rsrc_t ratt, rx, rout;
     __device__ __forceinline__ OutRole(const SysArgs& p_, const Stage& st_, char* lds) : p(p_), st(st_) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         atile = lds; ct = reinterpret_cast<float*>(lds + tile_bytes<AR, 4>(RT));
-        load_w(wf, st.w0, D, 0, [&](int j) { return 64 * wave + 16 * j; });
+        load_w(wf, st.w0, D, 0, [&](int j) { return 16 * NTW * wave + 16 * j; });
         bias = ld4(st.b0 + 4 * lane); gg = ld4(st.g + 4 * lane); bb = ld4(st.be + 4 * lane);
         ratt = rsrc_of(st.in0); rx = rsrc_of(st.in1); rout = rsrc_of(st.out);
     }
@@ -513,26 +544,26 @@ struct OutRole {
     __device__ __forceinline__ void issue(int, int b, const Geo&, Pay& y) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const unsigned base = (unsigned)b * RT * 1024;
-        issue_rows<MR>(y.att, ratt, base);
+        issue_rows<MR, WS>(y.att, ratt, base);
 #pragma unroll
-        for (int q = 0; q < RPW; ++q) y.res[q] = ld_sc1(rx, base + (wave + 4 * q) * 1024 + lane * 16);
+        for (int q = 0; q < RPW; ++q) y.res[q] = ld_sc1(rx, base + (wave + NW * q) * 1024 + lane * 16);
     }
-    __device__ __forceinline__ void commit(const Pay& y) { commit_rows<AR, 4, MR>(atile, 0, y.att); }
+    __device__ __forceinline__ void commit(const Pay& y) { commit_rows<AR, 4, MR, WS>(atile, 0, y.att); }
     template <class M>
     __device__ __forceinline__ void compute(int s, int b, const Geo&, const Pay& y, M& mid) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
         const unsigned base = (unsigned)b * RT * 1024;
-        f32x4 acc[MR][4];
+        f32x4 acc[MR][NTW];
         zero_acc(acc);
-        mma<AR, 4, 4, 8, MR>(atile, wf, acc);
+        mma<AR, 4, NTW, 8, MR>(atile, wf, acc);
         SYS_STAMP(3);
-        stage_c(ct, acc, [&](int j) { return 64 * wave + 16 * j; });
+        stage_c(ct, acc, [&](int j) { return 16 * NTW * wave + 16 * j; });
         mid.before_barrier();
         __syncthreads();
         mid.after_barrier();
 #pragma unroll
         for (int q = 0; q < RPW; ++q) {
-            const int row = wave + 4 * q;
+            const int row = wave + NW * q;
             f32x4 v = ld4(ct + row * CLD + c);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[i] + y.res[q][i];
@@ -546,17 +577,17 @@ struct OutRole {
 };
 
 // LIN / FFN: hidden slice = act(x W1_slice^T + b1_slice) (128 columns), partial = hidden . W2[:, slice]^T (256 columns)
-template <int MR, int ACT, int AR>
+template <int MR, int ACT, int AR, int WS>
 struct MlpRole {
-    static constexpr int RT = 16 * MR, RPW = RT / 4;
+    static constexpr int RT = 16 * MR, NW = 4 * WS, NT1 = 8 / NW, NT2 = 16 / NW;       // hidden / output column tiles per wave
     static constexpr bool PREFETCH = true;
     struct Geo {};
-    struct Pay { Rows256<MR> x; };
+    struct Pay { Rows256<MR, WS> x; };
     const SysArgs& p; const Stage& st;
     char *atile, *htile; float* ct;
-    WFrag<AR, 2, 8> w1;
-    WFrag<AR, 4, 4> w2;
-    float b1[2];
+    WFrag<AR, NT1, 8> w1;
+    WFrag<AR, NT2, 4> w2;
+    float b1[NT1];
     __amdgpu_buffer_rsrc_t rin, rout;
     unsigned plane;
     __device__ __forceinline__ MlpRole(const SysArgs& p_, const Stage& st_, char* lds) : p(p_), st(st_) {
@@ -565,31 +596,31 @@ struct MlpRole {
         htile = lds + tile_bytes<AR, 4>(RT);                             // [RT] x K=128 (hidden slice, operand format)
         ct = reinterpret_cast<float*>(lds + tile_bytes<AR, 4>(RT) + tile_bytes<AR, 2>(RT));
         const int j0 = st.slice * HS;
-        load_w(w1, st.w0, D, 0, [&](int j) { return j0 + 32 * wave + 16 * j; });
-        load_w(w2, st.w1, FF, 2 * st.slice, [&](int j) { return 64 * wave + 16 * j; });
+        load_w(w1, st.w0, D, 0, [&](int j) { return j0 + 16 * NT1 * wave + 16 * j; });
+        load_w(w2, st.w1, FF, 2 * st.slice, [&](int j) { return 16 * NT2 * wave + 16 * j; });
 #pragma unroll
-        for (int j = 0; j < 2; ++j) b1[j] = st.b0[j0 + 32 * wave + 16 * j + frow];
+        for (int j = 0; j < NT1; ++j) b1[j] = st.b0[j0 + 16 * NT1 * wave + 16 * j + frow];
         rin = rsrc_of(st.in0); rout = rsrc_of(st.out);
         plane = (unsigned)st.slice * p.NB * RT * 1024;
     }
     __device__ __forceinline__ void geo(int, Geo&) {}
     __device__ __forceinline__ void geo_fix(Geo&) {}
-    __device__ __forceinline__ void issue(int, int b, const Geo&, Pay& y) { issue_rows<MR>(y.x, rin, (unsigned)b * RT * 1024); }
-    __device__ __forceinline__ void commit(const Pay& y) { commit_rows<AR, 4, MR>(atile, 0, y.x); }
+    __device__ __forceinline__ void issue(int, int b, const Geo&, Pay& y) { issue_rows<MR, WS>(y.x, rin, (unsigned)b * RT * 1024); }
+    __device__ __forceinline__ void commit(const Pay& y) { commit_rows<AR, 4, MR, WS>(atile, 0, y.x); }
     template <class M>
     __device__ __forceinline__ void compute(int s, int b, const Geo&, const Pay&, M& mid) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, frow = lane & 15, fk = lane >> 4;
         const unsigned base = (unsigned)b * RT * 1024;
-        f32x4 acc1[MR][2];
+        f32x4 acc1[MR][NT1];
         zero_acc(acc1);
-        mma<AR, 4, 2, 8, MR>(atile, w1, acc1);
+        mma<AR, 4, NT1, 8, MR>(atile, w1, acc1);
         SYS_STAMP(3);
         // hidden slice -> S-format operand tile (k = hidden column within the slice)
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int k = 32 * wave + 16 * j + frow;                 // 0..127
+            for (int j = 0; j < NT1; ++j) {
+                const int k = 16 * NT1 * wave + 16 * j + frow;           // 0..127
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * i + 4 * fk + r;
@@ -599,26 +630,28 @@ struct MlpRole {
         mid.before_barrier();
         __syncthreads();
         mid.after_barrier();
-        f32x4 acc2[MR][4];
+        f32x4 acc2[MR][NT2];
         zero_acc(acc2);
-        mma<AR, 2, 4, 4, MR>(htile, w2, acc2);
-        stage_c(ct, acc2, [&](int j) { return 64 * wave + 16 * j; });
-        // each wave stores the 64 columns it staged itself (256 B per row, four rows per instruction): no barrier - LDS serves a
-        // wave's accesses in order, and the next block's hidden tile is only written behind the stage loop's barrier
+        mma<AR, 2, NT2, 4, MR>(htile, w2, acc2);
+        stage_c(ct, acc2, [&](int j) { return 16 * NT2 * wave + 16 * j; });
+        // each wave stores the columns it staged itself (64 or 32 of them: 256 / 128 B per row, 4 / 8 rows per instruction): no
+        // barrier - LDS serves a wave's accesses in order, and the next block's hidden tile is only written behind the stage loop's
+        // barrier
+        constexpr int CW = 16 * NT2, LPR = CW / 4, RPI = 64 / LPR;
 #pragma unroll
-        for (int q = 0; q < RPW; ++q) {
-            const int row = 4 * q + (lane >> 4), cc = 64 * wave + 4 * (lane & 15);
+        for (int q = 0; q < RT / RPI; ++q) {
+            const int row = RPI * q + lane / LPR, cc = CW * wave + 4 * (lane % LPR);
             st_sc1(rout, plane + base + row * 1024 + cc * 4, ld4(ct + row * CLD + cc));
         }
     }
 };
 
 // RED2: X2 = LN2(X1 + sum_j partial_j + b2) + c[step, layer, sample | pad]
-template <int MR>
+template <int MR, int WS>
 struct Red2Role {
-    static constexpr int RT = 16 * MR, PQ = MR + 1;                       // rows per wave: <= 11 rows / 4 waves (MR 2), <= 6 / 4 (MR 1)
+    static constexpr int RT = 16 * MR, NW = 4 * WS, PQ = ((MR == 1 ? 8 : 12) + NW - 1) / NW;   // rows per wave: a part has <= 8 (16-row blocks) / <= 11 rows
     static constexpr bool PREFETCH = true;
-    struct Geo { int pk[PQ], b2[PQ], row[PQ], t[PQ], cnt[PQ]; };          // slot wave + 4 q of this part: raw words, then decoded
+    struct Geo { int pk[PQ], b2[PQ], row[PQ], t[PQ], cnt[PQ]; };          // slot wave + NW q of this part: raw words, then decoded
     struct Pay { f32x4 pl[PQ][NSLICE], rs[PQ], tv[PQ], tp[PQ]; };
     const SysArgs& p; const Stage& st;
     f32x4 bias, gg, bb;
@@ -634,7 +667,7 @@ struct Red2Role {
         const int wave = threadIdx.x >> 6;
         const BlockDesc* d = p.blocks + b;
 #pragma unroll
-        for (int q = 0; q < PQ; ++q) { g.pk[q] = d->part_pk[st.slice][wave + 4 * q]; g.b2[q] = d->part_b2[st.slice][wave + 4 * q]; }
+        for (int q = 0; q < PQ; ++q) { g.pk[q] = d->part_pk[st.slice][wave + NW * q]; g.b2[q] = d->part_b2[st.slice][wave + NW * q]; }
     }
     __device__ __forceinline__ void geo_fix(Geo& g) {
 #pragma unroll
@@ -689,22 +722,25 @@ struct Red2Role {
 };
 
 // STYL: x' = X2 + out( SiLU( LN(sum_j partial_j + b2) * (1 + scale_t) + shift_t ) )
-template <int MR, int AR>
+template <int MR, int AR, int WS>
 struct StylRole {
-    static constexpr int RT = 16 * MR, PQ = MR + 1;
-    static constexpr bool PREFETCH = MR == 1;       // 256 weight registers + two images of 27 x 16 bytes per lane do not fit
-    struct Geo { int pk[PQ], row[PQ]; };                                 // tile row of slot wave + 4 q of this part (-1: none)
+    static constexpr int RT = 16 * MR, NW = 4 * WS, PQ = ((MR == 1 ? 8 : 12) + NW - 1) / NW, NTW = 16 / NW;
+    // no prefetch image with 32-row blocks (256 weight registers + two images of 27 x 16 bytes per lane do not fit) nor with two
+    // waves per SIMD (256 registers per wave: 128 of weights + two images of 11 x 16 bytes spilled; that plan runs STYL as two
+    // groups on alternating blocks, which have the slack)
+    static constexpr bool PREFETCH = MR == 1 && WS == 1;
+    struct Geo { int pk[PQ], row[PQ]; };                                 // tile row of slot wave + NW q of this part (-1: none)
     struct Pay { f32x4 pl[PQ][NSLICE], rs[PQ], scl, shf; };
     const SysArgs& p; const Stage& st;
     char* atile; float* ct;
-    WFrag<AR, 4, 8> wf;
+    WFrag<AR, NTW, 8> wf;
     f32x4 bias2, bias, gg, bb;
     __amdgpu_buffer_rsrc_t rp, rx, rout;
     unsigned pstride;
     __device__ __forceinline__ StylRole(const SysArgs& p_, const Stage& st_, char* lds) : p(p_), st(st_) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         atile = lds; ct = reinterpret_cast<float*>(lds + tile_bytes<AR, 4>(16));
-        load_w(wf, st.w0, D, 0, [&](int j) { return 64 * wave + 16 * j; });
+        load_w(wf, st.w0, D, 0, [&](int j) { return 16 * NTW * wave + 16 * j; });
         bias2 = ld4(st.b1 + 4 * lane); bias = ld4(st.b0 + 4 * lane); gg = ld4(st.g + 4 * lane); bb = ld4(st.be + 4 * lane);
         rp = rsrc_of(st.in0); rx = rsrc_of(st.in1); rout = rsrc_of(st.out);
         pstride = (unsigned)p.NB * RT * 1024;
@@ -712,7 +748,7 @@ struct StylRole {
     __device__ __forceinline__ void geo(int b, Geo& g) {
         const int wave = threadIdx.x >> 6;
 #pragma unroll
-        for (int q = 0; q < PQ; ++q) g.pk[q] = p.blocks[b].part_pk[st.slice][wave + 4 * q];
+        for (int q = 0; q < PQ; ++q) g.pk[q] = p.blocks[b].part_pk[st.slice][wave + NW * q];
     }
     __device__ __forceinline__ void geo_fix(Geo& g) {
 #pragma unroll
@@ -741,8 +777,8 @@ struct StylRole {
         const unsigned base = (unsigned)b * RT * 1024;
         const f32x4 scl = y.scl, shf = y.shf;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {                                    // the 16 rows of the operand tile: local row wave + 4 q
-            const int lr = wave + 4 * q;
+        for (int q = 0; q < 16 / NW; ++q) {                              // the 16 rows of the operand tile: local row wave + NW q
+            const int lr = wave + NW * q;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (q < PQ && g.row[q < PQ ? q : 0] >= 0) {
                 v = sum8(y.pl[q < PQ ? q : 0]);
@@ -758,14 +794,14 @@ struct StylRole {
         mid.before_barrier();
         __syncthreads();
         mid.after_barrier();
-        f32x4 acc[1][4];
+        f32x4 acc[1][NTW];
         zero_acc(acc);
-        mma<AR, 4, 4, 8, 1>(atile, wf, acc);
-        stage_c(ct, acc, [&](int j) { return 64 * wave + 16 * j; });
+        mma<AR, 4, NTW, 8, 1>(atile, wf, acc);
+        stage_c(ct, acc, [&](int j) { return 16 * NTW * wave + 16 * j; });
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
-            const int lr = wave + 4 * q, row = g.row[q];
+            const int lr = wave + NW * q, row = g.row[q];
             if (row >= 0) {
                 f32x4 v = ld4(ct + lr * CLD + c);
 #pragma unroll
@@ -777,15 +813,15 @@ struct StylRole {
 };
 
 // SKIP: half of the 256 output columns of linear_blocks[i](cat(x, skip))
-template <int MR, int AR>
+template <int MR, int AR, int WS>
 struct SkipRole {
-    static constexpr int RT = 16 * MR;
+    static constexpr int RT = 16 * MR, NW = 4 * WS, NTH = 64 * NW, NTW = 8 / NW;      // column tiles per wave of this half's 128 columns
     static constexpr bool PREFETCH = true;
     struct Geo {};
-    struct Pay { Rows256<MR> x, k; };
+    struct Pay { Rows256<MR, WS> x, k; };
     const SysArgs& p; const Stage& st;
     char* atile; float* ct;
-    WFrag<AR, 2, 16> wf;
+    WFrag<AR, NTW, 16> wf;
     __amdgpu_buffer_rsrc_t rx, rs, rout;
     f32x4 bias;                                                          // columns n0 + 4 (tid & 31) ..: the same for both of a thread's rows
     int n0;
@@ -793,31 +829,31 @@ struct SkipRole {
         const int wave = threadIdx.x >> 6;
         atile = lds; ct = reinterpret_cast<float*>(lds + tile_bytes<AR, 8>(RT));     // [RT] x K=512 operand tile first
         n0 = st.slice * 128;
-        load_w(wf, st.w0, 2 * D, 0, [&](int j) { return n0 + 32 * wave + 16 * j; });
+        load_w(wf, st.w0, 2 * D, 0, [&](int j) { return n0 + 16 * NTW * wave + 16 * j; });
         rx = rsrc_of(st.in0); rs = rsrc_of(st.in1); rout = rsrc_of(st.out);
         bias = ld4(st.b0 + n0 + (threadIdx.x & 31) * 4);
     }
     __device__ __forceinline__ void geo(int, Geo&) {}
     __device__ __forceinline__ void geo_fix(Geo&) {}
     __device__ __forceinline__ void issue(int, int b, const Geo&, Pay& y) {
-        issue_rows<MR>(y.x, rx, (unsigned)b * RT * 1024);
-        issue_rows<MR>(y.k, rs, (unsigned)b * RT * 1024);
+        issue_rows<MR, WS>(y.x, rx, (unsigned)b * RT * 1024);
+        issue_rows<MR, WS>(y.k, rs, (unsigned)b * RT * 1024);
     }
-    __device__ __forceinline__ void commit(const Pay& y) { commit_rows<AR, 8, MR>(atile, 0, y.x); commit_rows<AR, 8, MR>(atile, 4, y.k); }
+    __device__ __forceinline__ void commit(const Pay& y) { commit_rows<AR, 8, MR, WS>(atile, 0, y.x); commit_rows<AR, 8, MR, WS>(atile, 4, y.k); }
     template <class M>
     __device__ __forceinline__ void compute(int, int b, const Geo&, const Pay&, M& mid) {
         const int tid = threadIdx.x, wave = tid >> 6;
         const unsigned base = (unsigned)b * RT * 1024;
-        f32x4 acc[MR][2];
+        f32x4 acc[MR][NTW];
         zero_acc(acc);
-        mma<AR, 8, 2, 16, MR>(atile, wf, acc);
-        stage_c(ct, acc, [&](int j) { return n0 + 32 * wave + 16 * j; });
+        mma<AR, 8, NTW, 16, MR>(atile, wf, acc);
+        stage_c(ct, acc, [&](int j) { return n0 + 16 * NTW * wave + 16 * j; });
         mid.before_barrier();
         __syncthreads();
         mid.after_barrier();
 #pragma unroll
-        for (int u = 0; u < 2 * MR; ++u) {                               // (row, 4 columns) of this half
-            const int id = tid + 256 * u, row = id >> 5, cc = n0 + (id & 31) * 4;
+        for (int u = 0; u < 2 * MR / WS; ++u) {                          // (row, 4 columns) of this half
+            const int id = tid + NTH * u, row = id >> 5, cc = n0 + (id & 31) * 4;
             f32x4 v = ld4(ct + row * CLD + cc);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] += bias[i];
@@ -830,9 +866,9 @@ struct SkipRole {
 // A tail works on UNITS: unit u = block u when a block holds both guidance branches (32-row tiles: unconditional rows first,
 // the conditional row of (prompt, t) nrows / 2 further), or blocks 2u (unconditional) and 2u + 1 (conditional, same row) when
 // blocks hold one branch (16-row tiles).  Tail workgroup k owns the units u = k (mod NTAIL).
-template <int MR>
+template <int MR, int WS>
 struct TailRole {
-    static constexpr int RT = 16 * MR, NQ = 4;                           // (prompt, latent) pairs per wave: <= 16 per unit
+    static constexpr int RT = 16 * MR, NW = 4 * WS, NQ = 16 / NW;        // (prompt, latent) pairs per wave: <= 16 per unit
     struct Geo { int lat[NQ], t[NQ], rc[NQ]; };                         // latent row, position, conditional-branch row of pair q
     struct Pay { f32x4 eu[NQ], ec[NQ], lt[NQ], zz[NQ], pe[NQ]; };
     const SysArgs& p; const Stage& st;
@@ -865,7 +901,7 @@ struct TailRole {
                 const int b = p.split ? 2 * u + half : u;
                 const BlockDesc* d = p.blocks + b;
                 const unsigned base = (unsigned)b * RT * 1024;
-                for (int q = wave; q < RT; q += 4) {
+                for (int q = wave; q < RT; q += NW) {
                     f32x4 xn = {0.f, 0.f, 0.f, 0.f};
                     const int lat = d->row_lat[q];
                     if (lat >= 0) {
@@ -883,7 +919,7 @@ struct TailRole {
         const int wave = threadIdx.x >> 6;
         const BlockDesc* d = p.blocks + blk_u(u);
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) { const int q = wave + 4 * i; g.lat[i] = d->pair_lat[q]; g.t[i] = d->pair_t[q]; g.rc[i] = d->pair_rc[q]; }
+        for (int i = 0; i < NQ; ++i) { const int q = wave + NW * i; g.lat[i] = d->pair_lat[q]; g.t[i] = d->pair_t[q]; g.rc[i] = d->pair_rc[q]; }
     }
     __device__ __forceinline__ void issue(int s, int u, const Geo& g, Pay& y) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
@@ -892,7 +928,7 @@ struct TailRole {
         const float kn = p.coef[(size_t)step * LADIFF_COEF_STRIDE + 5];
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            const int q = wave + 4 * i;
+            const int q = wave + NW * i;
             y.zz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (g.lat[i] >= 0) {
                 y.eu[i] = ld_sc1(rin, bu + q * 1024 + c * 4);
@@ -910,7 +946,7 @@ struct TailRole {
         const float sa = cf[0], sb = cf[1], kx0 = cf[2], kx = cf[3], ke = cf[4], kn = cf[5];
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            const int q = wave + 4 * i;
+            const int q = wave + NW * i;
             if (g.lat[i] >= 0) {
                 f32x4 eu = y.eu[i], ec = y.ec[i], l = y.lt[i], xn;
                 float mean, rstd;
@@ -939,10 +975,10 @@ struct TailRole {
 // blocks, and a unit's latents are read in `issue` and written in `compute` of the SAME unit one step earlier - with other
 // units in between, so a prefetch never overtakes the update it depends on as long as a tail owns more than one unit; with
 // one unit it does not prefetch.
-template <int MR>
-__device__ __forceinline__ void tail_loop(const SysArgs& p, const Stage& st, TailRole<MR>& r, Ctl* ctl) {
-    typename TailRole<MR>::Pay cur, nxt;
-    typename TailRole<MR>::Geo gcur, gnxt;
+template <int MR, int WS>
+__device__ __forceinline__ void tail_loop(const SysArgs& p, const Stage& st, TailRole<MR, WS>& r, Ctl* ctl) {
+    typename TailRole<MR, WS>::Pay cur, nxt;
+    typename TailRole<MR, WS>::Geo gcur, gnxt;
     bool have = false;
     const int lane = threadIdx.x & 63, u0 = st.slice;
     const int nu = p.split ? p.NB / 2 : p.NB;
@@ -953,7 +989,7 @@ __device__ __forceinline__ void tail_loop(const SysArgs& p, const Stage& st, Tai
         return (const gu32*)flag_of(p, st.wait_group, b, 0) + (lane < st.wait_n ? lane : lane - st.wait_n) * FLAG_STRIDE;
     };
     r.prime(nu);
-    typename TailRole<MR>::Geo gnn;
+    typename TailRole<MR, WS>::Geo gnn;
     if (u0 < nu) { r.geo(u0, gcur); r.geo(u0 + NTAIL < nu ? u0 + NTAIL : u0, gnxt); gnn = gnxt; }
     for (int s = 0; s < p.n_steps; ++s)
         for (int u = u0; u < nu; u += NTAIL) {
@@ -1004,8 +1040,10 @@ __device__ __forceinline__ void tail_loop(const SysArgs& p, const Stage& st, Tai
 
 }  // namespace
 
-template <int MR, int AR>
-__global__ __launch_bounds__(256, 1) void systolic_loop_kernel(const SysArgs p) {
+// WS = waves per SIMD of a stage workgroup: 1 = 256 threads (32-row blocks: 256 weight registers + two row tiles of everything else
+// per wave), 2 = 512 threads with the stage's weight slice split over the two waves of a SIMD (16-row blocks)
+template <int MR, int AR, int WS>
+__global__ __launch_bounds__(256 * WS, 1) void systolic_loop_kernel(const SysArgs p) {
     // all LDS is dynamic (a static variable would shift the dynamic base off its 16-byte alignment, cdna_hip_programming.md G17)
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     Ctl* const ctl = reinterpret_cast<Ctl*>(lds + SYS_LDS_BYTES - 16);
@@ -1013,14 +1051,14 @@ __global__ __launch_bounds__(256, 1) void systolic_loop_kernel(const SysArgs p) 
     __syncthreads();
     const Stage st = p.stages[blockIdx.x];
     switch (st.role) {
-        case R_QKV: { QkvRole<MR, AR> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
-        case R_OUT: { OutRole<MR, AR> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
-        case R_LIN: { MlpRole<MR, ACT_RELU, AR> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
-        case R_RED2: { Red2Role<MR> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
-        case R_FFN: { MlpRole<MR, ACT_GELU, AR> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
-        case R_STYL: { StylRole<MR, AR> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
-        case R_SKIP: { SkipRole<MR, AR> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
-        case R_TAIL: { TailRole<MR> r(p, st, lds); tail_loop(p, st, r, ctl); break; }
+        case R_QKV: { QkvRole<MR, AR, WS> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
+        case R_OUT: { OutRole<MR, AR, WS> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
+        case R_LIN: { MlpRole<MR, ACT_RELU, AR, WS> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
+        case R_RED2: { Red2Role<MR, WS> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
+        case R_FFN: { MlpRole<MR, ACT_GELU, AR, WS> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
+        case R_STYL: { StylRole<MR, AR, WS> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
+        case R_SKIP: { SkipRole<MR, AR, WS> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
+        case R_TAIL: { TailRole<MR, WS> r(p, st, lds); tail_loop(p, st, r, ctl); break; }
         default: break;
     }
 }
@@ -1254,15 +1292,19 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR,
 
 // One launch = local steps [step_lo, step_lo + n) of the loop on the latents in `lat`.  The stage table must already be in
 // the workspace (sys_upload_stages); `ctab` holds the hoisted cross-attention rows of n_ctab >= n steps starting at step_lo.
+// waves per SIMD of the 16-row plan's stage workgroups (measurement switch: ladiff_debug_set_stage_waves)
+int g_waves16 = 2;
+
 int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, const float* tkv, const float* ctab, int n_ctab,
                          const float* coef, const float* noise, float* lat, const int32_t* counts, float gscale, int B, int T,
                          int step_lo, int n, int fp32, int MR, int NB, hipStream_t s) {
     const SysLayout L = sys_layout(MR, NB);
     static bool attr_set = false;
     if (!attr_set) {
-        const void* k[4] = {reinterpret_cast<const void*>(systolic_loop_kernel<1, 0>), reinterpret_cast<const void*>(systolic_loop_kernel<2, 0>),
-                            reinterpret_cast<const void*>(systolic_loop_kernel<1, 1>), reinterpret_cast<const void*>(systolic_loop_kernel<2, 1>)};
-        for (int i = 0; i < 4; ++i) LADIFF_HIP(hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, SYS_LDS_BYTES));
+        const void* k[6] = {reinterpret_cast<const void*>(systolic_loop_kernel<1, 0, 2>), reinterpret_cast<const void*>(systolic_loop_kernel<2, 0, 1>),
+                            reinterpret_cast<const void*>(systolic_loop_kernel<1, 1, 2>), reinterpret_cast<const void*>(systolic_loop_kernel<2, 1, 1>),
+                            reinterpret_cast<const void*>(systolic_loop_kernel<1, 0, 1>), reinterpret_cast<const void*>(systolic_loop_kernel<1, 1, 1>)};
+        for (int i = 0; i < 6; ++i) LADIFF_HIP(hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, SYS_LDS_BYTES));
         attr_set = true;
     }
     SysArgs a;
@@ -1293,11 +1335,13 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     LADIFF_HIP(hipMemsetAsync(a.status, 0, 64 * sizeof(float), s));
     LADIFF_HIP(hipMemsetAsync(a.flags, 0, (L.off_xin0 - L.off_flags) * sizeof(float), s));
     if (fp32) {
-        if (MR == 1) hipLaunchKernelGGL((systolic_loop_kernel<1, 1>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
-        else hipLaunchKernelGGL((systolic_loop_kernel<2, 1>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
+        if (MR == 1 && g_waves16 == 2) hipLaunchKernelGGL((systolic_loop_kernel<1, 1, 2>), dim3(L.nwg), dim3(512), SYS_LDS_BYTES, s, a);
+        else if (MR == 1) hipLaunchKernelGGL((systolic_loop_kernel<1, 1, 1>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
+        else hipLaunchKernelGGL((systolic_loop_kernel<2, 1, 1>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
     } else {
-        if (MR == 1) hipLaunchKernelGGL((systolic_loop_kernel<1, 0>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
-        else hipLaunchKernelGGL((systolic_loop_kernel<2, 0>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
+        if (MR == 1 && g_waves16 == 2) hipLaunchKernelGGL((systolic_loop_kernel<1, 0, 2>), dim3(L.nwg), dim3(512), SYS_LDS_BYTES, s, a);
+        else if (MR == 1) hipLaunchKernelGGL((systolic_loop_kernel<1, 0, 1>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
+        else hipLaunchKernelGGL((systolic_loop_kernel<2, 0, 1>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
     }
     LADIFF_LAUNCH_CHECK();
     LADIFF_HIP(hipEventRecord(done[dev], s));

@@ -105,8 +105,9 @@ __device__ __forceinline__ void lds_wait(u32x4_t& a) { asm volatile("s_waitcnt l
 
 // acc[i][j] += A(tile rows 16 i ..) . W(tile j)^T over KS k-steps of 32; MR = row tiles.  The operand fragments of the next
 // step are requested before the MFMAs of the current one are issued, so their LDS latency hides under the MFMAs.
-template <int AR, int KB, int NT, int KS, int MR>
-__device__ __forceinline__ void mma(const char* tile, const WFrag<AR, NT, KS>& f, f32x4 (&acc)[MR][NT]) {
+// NTF >= NT: the fragment set may hold more column tiles than are multiplied (its first NT are used)
+template <int AR, int KB, int NT, int KS, int MR, int NTF = NT>
+__device__ __forceinline__ void mma(const char* tile, const WFrag<AR, NTF, KS>& f, f32x4 (&acc)[MR][NT]) {
     const int lane = threadIdx.x & 63, frow = lane & 15, fk = lane >> 4;
     if constexpr (AR == 0) {
         // lane part of the four slot addresses a step can need: hi / lo plane x even / odd step of a 64-column block
