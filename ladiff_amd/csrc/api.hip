@@ -305,7 +305,8 @@ static void choose_plan(int B, int T, const int32_t* h_counts, bool masked, int 
     int want = loop_mode == 2 ? 1 : (loop_mode == 3 ? 2 : 0);
     if (want != 2) sys_pack_blocks(B, T, 1, h_counts, masked, p16, &mr16, &nb16);
     if (want == 0) {
-        const double c16 = bf16x3 ? 3.4 : 5.9, c32 = bf16x3 ? 5.3 : 12.5, lat16 = bf16x3 ? 228.0 : 385.0, lat32 = bf16x3 ? 304.0 : 430.0;
+        // measured (profiles/r2): stage time per block and one block's trip through the 59 stages, in us, for 16- / 32-row blocks
+        const double c16 = bf16x3 ? 3.1 : 5.5, c32 = bf16x3 ? 5.3 : 12.5, lat16 = bf16x3 ? 216.0 : 347.0, lat32 = bf16x3 ? 304.0 : 430.0;
         const double e16 = mr16 == 1 ? std::max(lat16, nb16 * c16) : 1e30, e32 = std::max(lat32, nb32 * c32);
         want = e16 < e32 ? 1 : 2;
     }
@@ -411,9 +412,8 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
     };
     const bool pipeline = sp != nullptr && sp->loop == 1 && n_text == 1 && sys_supported(B, T, cfg, WSp != nullptr);
     // Block geometry of the pipeline for THIS call's lengths.  16-row blocks carry only the valid latent rows of each prompt
-    // (length-aware packing; needs the counts on the host), 32-row blocks the padded T rows.  Measured (profiles/r2): a stage costs
-    // ~3.4 us per 16-row block and ~5.3 us per 32-row block (fp32: 5.9 / 12.5), and a step cannot be faster than one block's trip
-    // through the 59 stages: ~228 us with 16-row tiles, ~304 us with 32-row tiles (fp32: 385 / 430).  Pick the cheaper plan.
+    // (length-aware packing; needs the counts on the host), 32-row blocks the padded T rows.  A step costs the larger of (blocks x
+    // the busiest stage's time per block) and one block's trip through the 59 stages: choose_plan() picks the cheaper plan.
     std::vector<unsigned char> plan;
     int plan_mr = 2, plan_nb = 0;
     if (pipeline) choose_plan(B, T, h_counts, counts != nullptr, sp->loop_mode, WSp != nullptr, plan, &plan_mr, &plan_nb);
