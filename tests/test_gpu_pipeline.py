@@ -105,6 +105,24 @@ def test_ragged_decode_matches_padded_pass(nets):
     vae.precision = old
 
 
+def test_stage_workgroups_of_four_and_eight_waves_agree(nets):
+    """The 16-row plan runs its stage workgroups with two waves per SIMD (each stage's weight slice split over them); the
+    one-wave-per-SIMD form of the same kernel is kept behind a measurement switch: identical bits."""
+    from ladiff_amd import _lib
+    lens = [196, 60, 120, 100, 48, 150, 196, 30, 77, 196, 13]
+    L = _lib.lib()
+    try:
+        for precision in ("bf16x3", "fp32"):
+            assert L.ladiff_debug_set_stage_waves(2) == 0
+            z8 = run(nets, "pipeline16", precision, 11, 5, 6, lens)
+            assert L.ladiff_debug_set_stage_waves(1) == 0
+            z4 = run(nets, "pipeline16", precision, 11, 5, 6, lens)
+            assert torch.equal(z8, z4), precision
+        assert L.ladiff_debug_set_stage_waves(3) != 0
+    finally:
+        L.ladiff_debug_set_stage_waves(2)
+
+
 def test_two_samplers_on_two_streams(nets):
     """A pipeline kernel needs the whole chip resident: launches from different streams of one process are chained through an
     event (systolic.hip), so two samplers enqueued back to back on two streams both complete with the right result."""
