@@ -1044,6 +1044,7 @@ __device__ __forceinline__ void tail_loop(const SysArgs& p, const Stage& st, Tai
 // per wave), 2 = 512 threads with the stage's weight slice split over the two waves of a SIMD (16-row blocks)
 template <int MR, int AR, int WS>
 __global__ __launch_bounds__(256 * WS, 1) void systolic_loop_kernel(const SysArgs p) {
+    static_assert(WS == 1 || MR == 1, "two waves per SIMD: 16-row blocks only (the reduce parts' slot tables hold 12 slots: wave + 8 q needs q < 1)");
     // all LDS is dynamic (a static variable would shift the dynamic base off its 16-byte alignment, cdna_hip_programming.md G17)
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     Ctl* const ctl = reinterpret_cast<Ctl*>(lds + SYS_LDS_BYTES - 16);
