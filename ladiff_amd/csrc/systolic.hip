@@ -257,27 +257,31 @@ __device__ __forceinline__ f32x4 sum8(const f32x4 (&pl)[NSLICE]) {       // fixe
 // the next block's loads and the early poll issued (a `vmcnt(0)` placed after them would wait for them as well).
 template <class R>
 struct Mid {
-    const SysArgs& p; const Stage& st; R& r; typename R::Pay& nxt; typename R::Geo& gnxt; typename R::Geo& gnn;
-    unsigned* pending; unsigned pending_epoch; bool have; int s2, b2, s3, b3;
-    unsigned early; bool early_valid;
-    __device__ __forceinline__ void before_barrier() const {
+    const SysArgs& p; const Stage& st; R& r; typename R::Pay& nxt; typename R::Geo& gnxt; typename R::Geo& gnn; Ctl* ctl;
+    unsigned* pending; unsigned pending_epoch; bool has_next; int s2, b2, s3, b3;
+    unsigned early;                       // wave 0, lanes < wait_n: the next block's flags, polled at the top of this iteration
+    bool have;                            // out: the next block's loads have been issued
+    __device__ __forceinline__ void before_barrier() {
         if (pending != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (R::PREFETCH) {
+            if (threadIdx.x < 64) {       // is the next block's input there?  (a poll about a microsecond old: it came back under this block's first phase)
+                const int ok = has_next && __all(early >= (unsigned)(s2 + 1));
+                if ((threadIdx.x & 63) == 0) ctl->ready = ok;
+            }
+        }
     }
     __device__ __forceinline__ void after_barrier() {
         if (pending != nullptr) {
             if (threadIdx.x == 0) __hip_atomic_store((gu32*)pending, pending_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             pending = nullptr;
         }
+        have = false;
+        if constexpr (R::PREFETCH) have = ctl->ready != 0;
         // block geometry (descriptor words) is fetched TWO blocks ahead: what the next block's loads need arrived an
         // iteration ago, so nothing here waits on a load issued in this phase
         r.geo_fix(gnxt);
         if constexpr (R::PREFETCH) { if (have) r.issue(s2, b2, gnxt, nxt); }
         if (s3 < p.n_steps) r.geo(b3, gnn);
-        early_valid = R::PREFETCH && s3 < p.n_steps;
-        early = 0xffffffffu;
-        if (early_valid && threadIdx.x < 64 && (int)(threadIdx.x & 63) < st.wait_n)
-            early = __hip_atomic_load((const gu32*)flag_of(p, st.wait_group, b3, 0) + (threadIdx.x & 63) * FLAG_STRIDE, __ATOMIC_RELAXED,
-                                      __HIP_MEMORY_SCOPE_AGENT);
     }
 };
 
@@ -295,11 +299,9 @@ __device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R&
     }
     unsigned* pending = nullptr;                                         // flag of the previous block, its stores still draining
     unsigned pending_epoch = 0;
-    // The poll that decides whether the NEXT block can be prefetched was issued one iteration earlier (a flag load is a ~1 us
-    // round trip to the memory side: waited for in place it was a quarter of a saturated stage's time per block).  A miss
-    // costs nothing: the next iteration then waits for its flags the normal way.
-    unsigned early = 0;
-    bool early_valid = false;
+    // Whether the NEXT block can be prefetched is decided by a poll issued at the top of the iteration and read at the block's first
+    // compute barrier (a flag load is a ~1 us round trip to the memory side: it comes back under the commit and the first MFMA
+    // phase).  A miss costs nothing: the next iteration then waits for its flags the normal way.
     SYS_STAT_DECL;
     for (int s = 0; s < p.n_steps; ++s)
         for (int b = b0; b < p.NB; b += bstride) {
@@ -317,18 +319,17 @@ __device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R&
             int s3 = s2, b3 = b2 + bstride;
             if (b3 >= p.NB) { s3 = s2 + 1; b3 = b0; }
             const bool has_next = R::PREFETCH && s2 < p.n_steps;
+            unsigned early = 0xffffffffu;
+            if (has_next && threadIdx.x < 64 && lane < st.wait_n)
+                early = __hip_atomic_load((const gu32*)flag_of(p, st.wait_group, b2, 0) + lane * FLAG_STRIDE, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
             r.commit(cur);
-            if (threadIdx.x < 64) {
-                const int ok = has_next && early_valid && __all(early >= (unsigned)(s2 + 1));
-                if (lane == 0) ctl->ready = ok;
-            }
             __syncthreads();
-            have = R::PREFETCH && ctl->ready != 0;
             SYS_STAMP(2);
-            Mid<R> mid{p, st, r, nxt, gnxt, gnn, pending, pending_epoch, have, s2, b2, s3, b3, 0u, false};
+            Mid<R> mid{p, st, r, nxt, gnxt, gnn, ctl, pending, pending_epoch, has_next, s2, b2, s3, b3, early, false};
             r.compute(s, b, gcur, cur, mid);
+            have = mid.have;
             gcur = gnxt; gnxt = gnn;
-            early = mid.early; early_valid = mid.early_valid;
             SYS_STAMP(4);
             if (have) {
                 // backlogged (the next block is already here): throughput counts, so this block's flag goes out at the next
@@ -702,7 +703,8 @@ struct Red2Role {
     __device__ __forceinline__ void compute(int, int b, const Geo& g, const Pay& y, M& mid) {
         const int lane = threadIdx.x & 63, c = 4 * lane;
         const unsigned base = (unsigned)b * RT * 1024;
-        if (mid.pending != nullptr) { mid.before_barrier(); __syncthreads(); }      // no barrier of its own in this stage
+        mid.before_barrier();
+        __syncthreads();                  // the stage's only barrier: the workgroup agrees on whether the next block is prefetched
         mid.after_barrier();
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
