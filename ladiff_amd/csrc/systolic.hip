@@ -164,8 +164,11 @@ struct Ctl { int abort, ready, pad0, pad1; };
 // flight per wave made every hand-off of the chip slower (4 % on the loop), four much slower; relaying wave 0's poll to the other
 // waves through LDS was no faster than letting them poll.  Returns false on abort; waves that leave end the kernel, and a
 // barrier only counts the waves still running.
-__device__ __forceinline__ bool wait_epoch(const unsigned* flags, int n, unsigned epoch, unsigned* status, Ctl*) {
+// `first`: a sample of this lane's flag taken earlier (stage_loop polls the next block's flags while the current block's stores
+// drain), 0 = none: when the flags were already up then, the wait costs no round trip at all.
+__device__ __forceinline__ bool wait_epoch(const unsigned* flags, int n, unsigned epoch, unsigned* status, Ctl*, unsigned first) {
     const int lane = threadIdx.x & 63;
+    if (__all((lane < n ? first : epoch) >= epoch)) return true;
     const gu32* f = (const gu32*)flags + (lane < n ? lane : 0) * FLAG_STRIDE;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (unsigned spins = 1;; ++spins) {
@@ -186,9 +189,11 @@ __device__ __forceinline__ bool wait_epoch(const unsigned* flags, int n, unsigne
     }
 }
 
-// all rows of this workgroup are stored: drain (every wave), meet, publish
+// all rows of this workgroup are stored: drain (every wave), meet, publish.  YOUNGER = vector-memory operations the wave has issued
+// after its stores (vmcnt counts in issue order: they are left in flight)
+template <int YOUNGER = 0>
 __device__ __forceinline__ void publish(unsigned* flag, unsigned epoch) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store((gu32*)flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -299,6 +304,7 @@ __device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R&
     }
     unsigned* pending = nullptr;                                         // flag of the previous block, its stores still draining
     unsigned pending_epoch = 0;
+    unsigned pre = 0u;                                                   // an early sample of the next wait's flags (0: none)
     // Whether the NEXT block can be prefetched is decided by a poll issued at the top of the iteration and read at the block's first
     // compute barrier (a flag load is a ~1 us round trip to the memory side: it comes back under the commit and the first MFMA
     // phase).  A miss costs nothing: the next iteration then waits for its flags the normal way.
@@ -309,7 +315,7 @@ __device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R&
             SYS_STAT_ITER(have);
             if (!have) {
                 SYS_STAT_T0;
-                if (!wait_epoch(flag_of(p, st.wait_group, b, 0), st.wait_n, s + 1, p.status, ctl)) return;
+                if (!wait_epoch(flag_of(p, st.wait_group, b, 0), st.wait_n, s + 1, p.status, ctl, pre)) return;
                 SYS_STAT_WAIT;
                 r.issue(s, b, gcur, cur);
             }
@@ -336,9 +342,20 @@ __device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R&
                 // block's first compute barrier instead of stalling the stage on the write-through drain now
                 pending = flag_of(p, st.out_group, b, st.out_slot);
                 pending_epoch = s + 1;
+                pre = 0u;
             } else {
                 pending = nullptr;
-                publish(flag_of(p, st.out_group, b, st.out_slot), s + 1);
+                // not prefetched: every wave samples the next block's flags now, under the drain of this block's stores (always exactly
+                // one load, so that the drain can leave it in flight; past the last block it reads a flag nobody waits for)
+                if constexpr (R::PREPOLL) {
+                    const unsigned sample = __hip_atomic_load((const gu32*)flag_of(p, st.wait_group, b2, 0) + (lane < st.wait_n ? lane : 0) * FLAG_STRIDE,
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    publish<1>(flag_of(p, st.out_group, b, st.out_slot), s + 1);
+                    pre = s2 < p.n_steps && lane < st.wait_n ? sample : 0u;
+                } else {                 // four-wave workgroups (32-row plan): the extra poll per block cost more than it saved
+                    pre = 0u;
+                    publish(flag_of(p, st.out_group, b, st.out_slot), s + 1);
+                }
             }
             SYS_STAMP(5);
             if constexpr (R::PREFETCH) { if (have) cur = nxt; }
@@ -358,6 +375,7 @@ struct QkvRole {
     static constexpr int RT = 16 * MR, QLD = 196, TK = LADIFF_MAX_LATENTS + 2;   // keys of a row: <= 8 latents, text, time
     static constexpr int NTH = 256 * WS, NTW = WS == 1 ? 3 : 2, NX = 2 / WS;      // threads; column tiles a wave can hold; 16-byte text K|V units per thread
     static constexpr bool PREFETCH = true;
+    static constexpr bool PREPOLL = WS == 2;
     struct Geo { int gw, rb2, b2[NX]; };                                 // descriptor word `tid` (+ its row's sample-branch); sample-branch of this thread's text slots
     struct Pay { Rows256<MR, WS> x; f32x4 xk[NX]; };
     const SysArgs& p; const Stage& st;
@@ -526,6 +544,7 @@ template <int MR, int AR, int WS>
 struct OutRole {
     static constexpr int RT = 16 * MR, NW = 4 * WS, RPW = RT / NW, NTW = 16 / NW;     // rows / column tiles per wave
     static constexpr bool PREFETCH = true;
+    static constexpr bool PREPOLL = WS == 2;
     struct Geo {};
     struct Pay { Rows256<MR, WS> att; f32x4 res[RPW]; };
     const SysArgs& p; const Stage& st;
@@ -582,6 +601,7 @@ template <int MR, int ACT, int AR, int WS>
 struct MlpRole {
     static constexpr int RT = 16 * MR, NW = 4 * WS, NT1 = 8 / NW, NT2 = 16 / NW;       // hidden / output column tiles per wave
     static constexpr bool PREFETCH = true;
+    static constexpr bool PREPOLL = WS == 2;
     struct Geo {};
     struct Pay { Rows256<MR, WS> x; };
     const SysArgs& p; const Stage& st;
@@ -652,6 +672,7 @@ template <int MR, int WS>
 struct Red2Role {
     static constexpr int RT = 16 * MR, NW = 4 * WS, PQ = ((MR == 1 ? 8 : 12) + NW - 1) / NW;   // rows per wave: a part has <= 8 (16-row blocks) / <= 11 rows
     static constexpr bool PREFETCH = true;
+    static constexpr bool PREPOLL = WS == 2;
     struct Geo { int pk[PQ], b2[PQ], row[PQ], t[PQ], cnt[PQ]; };          // slot wave + NW q of this part: raw words, then decoded
     struct Pay { f32x4 pl[PQ][NSLICE], rs[PQ], tv[PQ], tp[PQ]; };
     const SysArgs& p; const Stage& st;
@@ -731,6 +752,7 @@ struct StylRole {
     // waves per SIMD (256 registers per wave: 128 of weights + two images of 11 x 16 bytes spilled; that plan runs STYL as two
     // groups on alternating blocks, which have the slack)
     static constexpr bool PREFETCH = MR == 1 && WS == 1;
+    static constexpr bool PREPOLL = WS == 2;
     struct Geo { int pk[PQ], row[PQ]; };                                 // tile row of slot wave + NW q of this part (-1: none)
     struct Pay { f32x4 pl[PQ][NSLICE], rs[PQ], scl, shf; };
     const SysArgs& p; const Stage& st;
@@ -819,6 +841,7 @@ template <int MR, int AR, int WS>
 struct SkipRole {
     static constexpr int RT = 16 * MR, NW = 4 * WS, NTH = 64 * NW, NTW = 8 / NW;      // column tiles per wave of this half's 128 columns
     static constexpr bool PREFETCH = true;
+    static constexpr bool PREPOLL = WS == 2;
     struct Geo {};
     struct Pay { Rows256<MR, WS> x, k; };
     const SysArgs& p; const Stage& st;
