@@ -25,7 +25,7 @@ struct AttnGeom { int nheads, ld, koff, voff, out_ld, causal; };
 __global__ __launch_bounds__(256) void dec_self_attn_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ lengths,
                                                             const uint32_t* __restrict__ keybits, float* __restrict__ out,
                                                             int B, int F, int split_out, const AttnGeom g,
-                                                            const int32_t* __restrict__ row_off) {
+                                                            const int32_t* __restrict__ row_off, int shared_qkv) {
     __shared__ __attribute__((aligned(16))) float Ks[SA_FMAX * DH];   // chunk c of row r at slot c ^ (r & 15)
     __shared__ __attribute__((aligned(16))) float Vs[SA_FMAX * DH];   // plain [key][d]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const float* __restr
     const int nkt = (len + 31) >> 5;
     size_t row0 = (size_t)b * F;
     if (row_off != nullptr) { row0 = row_off[b]; F = row_off[b + 1] - row_off[b]; }     // ragged rows: the sample's own F = its length
-    const size_t base = row0 * g.ld + h * DH;
+    // shared_qkv: every sample reads the SAME [F] rows of q|k|v (decoder layer 0: its input is the position table, ladiff_vae.py:299)
+    const size_t base = (shared_qkv ? (size_t)0 : row0) * g.ld + h * DH;
 
     for (int id = tid; id < nkt * 32 * 16; id += 256) {
         const int r = id >> 4, c = id & 15;
@@ -176,7 +177,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
 __global__ __launch_bounds__(512) void self_attn_bf16x3_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ lengths,
                                                                const uint32_t* __restrict__ keybits, float* __restrict__ out,
                                                                int B, int F, int split_out, const AttnGeom g,
-                                                               const int32_t* __restrict__ row_off) {
+                                                               const int32_t* __restrict__ row_off, int shared_qkv) {
     __shared__ __attribute__((aligned(16))) __bf16 Kp[2 * SA_FMAX * DH];      // hi plane, lo plane; first the fp32 staging of V
     __shared__ __attribute__((aligned(16))) __bf16 Vt[2 * DH * SB_VLD];       // hi plane, lo plane, [d][key]
     __bf16* const Kh = Kp; __bf16* const Kl = Kp + SA_FMAX * DH;
@@ -203,7 +204,8 @@ __global__ __launch_bounds__(512) void self_attn_bf16x3_kernel(const float* __re
     const int nkt = (len + 31) >> 5;
     size_t row0 = (size_t)b * F;
     if (row_off != nullptr) { row0 = row_off[b]; F = row_off[b + 1] - row_off[b]; }     // ragged rows: the sample's own F = its length
-    const size_t base = row0 * g.ld + h * DH;
+    // shared_qkv: every sample reads the SAME [F] rows of q|k|v (decoder layer 0: its input is the position table, ladiff_vae.py:299)
+    const size_t base = (shared_qkv ? (size_t)0 : row0) * g.ld + h * DH;
 
     const int qt = wave;                      // query tile of this wave; its q rows are fetched together with K / V
     const int q = lane & 31, h2 = lane >> 5;
@@ -377,12 +379,12 @@ __global__ __launch_bounds__(512) void self_attn_bf16x3_kernel(const float* __re
 
 // bf16x3 entry (same arguments as launch_self_attention)
 int launch_self_attention_bf16x3(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
-                                 int nheads, int causal, int split_out, hipStream_t s, const int32_t* row_off) {
+                                 int nheads, int causal, int split_out, hipStream_t s, const int32_t* row_off, int shared_qkv) {
     if (F > SA_FMAX || F < 1 || nheads < 1) return LADIFF_ERR_SHAPE;
     if (B == 0) return 0;
     const int W = nheads * DH;
     const AttnGeom g{nheads, 3 * W, W, 2 * W, W, causal};
-    hipLaunchKernelGGL(self_attn_bf16x3_kernel, dim3(B * nheads), dim3(512), 0, s, qkv, lengths, keybits, out, B, F, split_out, g, row_off);
+    hipLaunchKernelGGL(self_attn_bf16x3_kernel, dim3(B * nheads), dim3(512), 0, s, qkv, lengths, keybits, out, B, F, split_out, g, row_off, shared_qkv);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
@@ -396,20 +398,20 @@ int launch_self_attention(const float* qkv, const int32_t* lengths, const uint32
     const AttnGeom g{nheads, 3 * W, W, 2 * W, W, causal};
     const int nqt = (F + 31) / 32;
     hipLaunchKernelGGL(dec_self_attn_kernel, dim3((nqt + 3) / 4, B * nheads), dim3(256), 0, s, qkv, lengths, keybits, out, B, F,
-                       split_out, g, (const int32_t*)nullptr);
+                       split_out, g, (const int32_t*)nullptr, 0);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_decoder_self_attention(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
-                                  int split_out, hipStream_t s, const int32_t* row_off) {
+                                  int split_out, hipStream_t s, const int32_t* row_off, int shared_qkv) {
     if (F > SA_FMAX || F < 1) return LADIFF_ERR_SHAPE;
     if (lengths == nullptr && keybits == nullptr) return LADIFF_ERR_ARG;
     if (B == 0) return 0;
     const AttnGeom g{H, 3 * D, D, 2 * D, D, 0};
     const int nqt = (F + 31) / 32;
     hipLaunchKernelGGL(dec_self_attn_kernel, dim3((nqt + 3) / 4, B * H), dim3(256), 0, s, qkv, lengths, keybits, out, B, F,
-                       split_out, g, row_off);
+                       split_out, g, row_off, shared_qkv);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }

@@ -14,7 +14,8 @@ static GemmArgs lin(const float* A, int lda, const float* W, const float* bias, 
 
 // rows = B * F for the padded layout, or the sum of the lengths for the ragged one
 size_t dec_ws_floats(int B, size_t rows, int T) {
-    return rows * (16 * D + 3 * D + D + FF + 1) + (size_t)NL * ((size_t)T * B * 2 * D + dec_cross_ws_floats(B, T));
+    return rows * (16 * D + 3 * D + D + FF + 1) + (size_t)NL * ((size_t)T * B * 2 * D + dec_cross_ws_floats(B, T)) +
+           (size_t)LADIFF_MAX_FRAMES * (2 * D + 3 * D);       // layer 0: the position table as a GEMM operand and its q|k|v
 }
 
 // wsp != nullptr selects the bf16x3 matrix path (S-format copies of the weight matrices in `wsp`, GEMM operands in
@@ -44,7 +45,10 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
     float* hid = p; p += (size_t)M * FF;
     float* kv = p; p += (size_t)NL * T * B * 2 * D;      // memory K | V of every layer
     float* guws = p; p += (size_t)NL * dec_cross_ws_floats(B, T);   // G | U | c of the folded cross-attention of every layer (dec_cross.hip)
-    int32_t* row_out = reinterpret_cast<int32_t*>(p);     // ragged: place of each row in the padded output
+    int32_t* row_out = reinterpret_cast<int32_t*>(p); p += M;   // ragged: place of each row in the padded output
+    float* pex = p; p += (size_t)LADIFF_MAX_FRAMES * D;   // layer 0: pe[:F] (+ S-format twin) and its in_proj, shared by all samples
+    float* pexs = p; p += (size_t)LADIFF_MAX_FRAMES * D;
+    float* qkv0 = p;
     const size_t kv_l = (size_t)T * B * 2 * D, gu_l = dec_cross_ws_floats(B, T);
 
     // The memory side of every layer's cross-attention depends on z and the weights only: the nine K | V projections and the
@@ -102,13 +106,22 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
             cur = P[3]; curs = Ps[3];
         }
         // ---- self-attention over frames, keys >= len masked   cross_attention.py:367-371
-        {
+        // Layer 0's input is the position table for every sample (queries = zeros + pe, ladiff_vae.py:299, :334): its in_proj runs on
+        // the F table rows once and every sample's attention reads those q | k | v (its own length still masks the keys).
+        const bool shared = l == 0;
+        if (shared) {
+            LADIFF_TRY(launch_broadcast_pe(w.query_pe, 1, F, pex, sp ? pexs : nullptr, s));
+            GemmArgs g = lin(sp ? pexs : pex, D, Ls.self_attn.in_w, L.self_attn.in_b, qkv0, 3 * D, F, 3 * D, D);
+            g.split = sp ? 1 : 0;
+            LADIFF_TRY(launch_gemm(g, s));
+        } else {
             GemmArgs g = lin(sp ? curs : cur, D, Ls.self_attn.in_w, L.self_attn.in_b, qkv, 3 * D, M, 3 * D, D);
             g.split = sp ? 1 : 0;
             LADIFF_TRY(launch_gemm(g, s));
         }
-        if (sp) LADIFF_TRY(launch_self_attention_bf16x3(qkv, lengths, nullptr, att, B, F, H, 0, 1, s, row_off));
-        else LADIFF_TRY(launch_decoder_self_attention(qkv, lengths, nullptr, att, B, F, 0, s, row_off));
+        const float* qkv_l = shared ? qkv0 : qkv;
+        if (sp) LADIFF_TRY(launch_self_attention_bf16x3(qkv_l, lengths, nullptr, att, B, F, H, 0, 1, s, row_off, shared));
+        else LADIFF_TRY(launch_decoder_self_attention(qkv_l, lengths, nullptr, att, B, F, 0, s, row_off, shared));
         // norm1: fused in the GEMM epilogue in fp32 mode; in bf16x3 mode the GEMM writes x + out_proj(att) and the only reader of
         // norm1's output, the cross-attention kernel below, normalises its rows as it loads them (one row kernel pass less)
         const NormW* n1_late = nullptr;

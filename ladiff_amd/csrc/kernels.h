@@ -73,11 +73,11 @@ int launch_denoiser_self_attention(const float* qkv, const float* text_kv, const
                                    int b_n, int T, float* out, int split_out, hipStream_t s);
 // row_off (optional, B + 1 entries): ragged rows - sample b owns rows [row_off[b], row_off[b + 1]) and F only bounds the lengths
 int launch_decoder_self_attention(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
-                                  int split_out, hipStream_t s, const int32_t* row_off = nullptr);
+                                  int split_out, hipStream_t s, const int32_t* row_off = nullptr, int shared_qkv = 0);
 int launch_self_attention(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F, int nheads,
                           int causal, int split_out, hipStream_t s);
 int launch_self_attention_bf16x3(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
-                                 int nheads, int causal, int split_out, hipStream_t s, const int32_t* row_off = nullptr);
+                                 int nheads, int causal, int split_out, hipStream_t s, const int32_t* row_off = nullptr, int shared_qkv = 0);
 int launch_decoder_cross_attention(const float* q, const float* kv, const int32_t* counts, float* out, int B, int F,
                                    int T, int split_out, hipStream_t s);
 
