@@ -79,12 +79,9 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
         }
         g.split = 1;
         LADIFF_TRY(launch_gemm(g, s));
-        if (n2) {
-            LADIFF_TRY(launch_reduce_rows(dst, 1, M, nullptr, nullptr, RED_LN, n1.g, n1.b, nullptr, 0, nullptr, nullptr, 1, 1, 0,
-                                          0, dst, nullptr, s));
-            return launch_reduce_rows(dst, 1, M, nullptr, nullptr, RED_LN, n2->g, n2->b, nullptr, 0, nullptr, nullptr, 1, 1, 0,
-                                      0, dst, dsts, s);
-        }
+        if (n2)      // norm3, then decoder.norm: one row pass
+            return launch_reduce_rows(dst, 1, M, nullptr, nullptr, RED_LN, n1.g, n1.b, nullptr, 0, nullptr, nullptr, 1, 1, 0,
+                                      0, dst, dsts, s, nullptr, n2->g, n2->b);
         return launch_reduce_rows(dst, 1, M, nullptr, nullptr, RED_LN, n1.g, n1.b, nullptr, 0, nullptr, nullptr, 1, 1, 0, 0,
                                   dst, dsts, s);
     };

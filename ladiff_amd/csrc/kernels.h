@@ -9,7 +9,7 @@ enum RedMode : int { RED_PLAIN = 0, RED_LN = 1, RED_LN_ADD = 2, RED_LN_MOD = 3 }
 int launch_reduce_rows(const float* P, int S, int M, const float* bias, const float* res, int mode, const float* g,
                        const float* b, const float* tab, int tab_step_stride, const int32_t* d_step,
                        const int32_t* counts, int Bs, int T, int pad_row, int b_off, float* out, float* outs, hipStream_t s,
-                       const int32_t* d_base = nullptr);
+                       const int32_t* d_base = nullptr, const float* g2 = nullptr, const float* b2 = nullptr);   // g2 / b2: RED_LN twice
 int launch_split_rows(const float* x, float* y, int R, int K, hipStream_t s);
 int launch_layernorm(const float* x, const float* g, const float* b, float* y, int M, hipStream_t s);
 constexpr int DEC_PREP_MAX = 9;

@@ -69,6 +69,7 @@ struct RedArgs {
     const float* P; const float* bias; const float* res; const float* g; const float* b; const float* tab;
     const int32_t* d_step; const int32_t* counts; float* out; float* outs;
     const int32_t* d_base;            // RED_LN_ADD: the table's first row belongs to step *d_base (windowed c table), NULL = 0
+    const float* g2; const float* b2; // RED_LN: a second LayerNorm on the result (the decoder's last layer: norm3, then decoder.norm)
     size_t plane;
     int S, mode, tab_step_stride, Bs, T, pad_row, b_off, M;
 };
@@ -97,8 +98,10 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const RedArgs p) {
     for (int s = 0; s < 4; ++s) pl[s] = s < S ? ld4g(prow + s * plane) : zero;
     const f32x4 bi = bias != nullptr ? ld4g(bias + c) : zero;
     const f32x4 rs = res != nullptr ? ld4g(res + (size_t)row * D + c) : zero;
-    f32x4 gg = zero, bb = zero;
+    f32x4 gg = zero, bb = zero, gg2 = zero, bb2 = zero;
     if (mode != RED_PLAIN) { gg = ld4g(g + c); bb = ld4g(b + c); }
+    const bool twice = mode == RED_LN && p.g2 != nullptr;
+    if (twice) { gg2 = ld4g(p.g2 + c); bb2 = ld4g(p.b2 + c); }
     int step = d_step != nullptr ? *(const __attribute__((address_space(1))) int32_t*)d_step : 0;
     if (d_base != nullptr) step -= *(const __attribute__((address_space(1))) int32_t*)d_base;
     const int b2 = b_off + row / T, tt = row % T;
@@ -117,6 +120,11 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const RedArgs p) {
         row_stats(v, mean, rstd);
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i];
+        if (twice) {
+            row_stats(v, mean, rstd);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg2[i] + bb2[i];
+        }
         if (mode == RED_LN_ADD) {
             const bool valid = tt < cnt;
 #pragma unroll
@@ -133,9 +141,10 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const RedArgs p) {
 int launch_reduce_rows(const float* P, int S, int M, const float* bias, const float* res, int mode, const float* g,
                        const float* b, const float* tab, int tab_step_stride, const int32_t* d_step,
                        const int32_t* counts, int Bs, int T, int pad_row, int b_off, float* out, float* outs, hipStream_t s,
-                       const int32_t* d_base) {
+                       const int32_t* d_base, const float* g2, const float* b2) {
     if (S < 1 || S > 4) return LADIFF_ERR_SHAPE;       // split-K planes: K / 256 <= 4
     RedArgs a;
+    a.g2 = g2; a.b2 = b2;
     a.P = P; a.bias = bias; a.res = res; a.g = g; a.b = b; a.tab = tab; a.d_step = d_step; a.counts = counts; a.out = out;
     a.outs = outs; a.plane = (size_t)M * D; a.S = S; a.mode = mode; a.tab_step_stride = tab_step_stride; a.Bs = Bs; a.T = T;
     a.pad_row = pad_row; a.b_off = b_off; a.M = M; a.d_base = d_base;
