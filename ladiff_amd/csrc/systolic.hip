@@ -157,7 +157,7 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 constexpr unsigned long long TIMEOUT_TICKS = 150000000ull;     // s_memrealtime runs at 100 MHz: 1.5 s per wait
 
 // LDS words of the hand-off protocol (last 16 bytes of the dynamic region)
-struct Ctl { int abort, ready, pad0, pad1; };
+struct Ctl { int abort, ready; unsigned arrive; int pad1; };      // arrive: attention waves of the QKV stage that have drained, over all blocks
 
 // Every wave polls flags[0 .. n) by itself until all are >= epoch and goes on to its own loads at once (no barrier, no LDS
 // round trip after the flag is seen).  ONE poll in flight per wave: the memory side serves flags and data alike, and two polls in
@@ -439,9 +439,9 @@ struct QkvRole {
         issue_rows<MR, WS>(y.x, rin, (unsigned)b * RT * 1024);
     }
     __device__ __forceinline__ void commit(const Pay& y) { commit_rows<AR, 4, MR, WS>(atile, 0, y.x); }
-    template <class M>
-    __device__ __forceinline__ void compute(int s, int b, const Geo& g, const Pay& y, M& mid) {
-        const int tid = threadIdx.x, lane = tid & 63, frow = lane & 15;
+    // in_proj of this wave's column tiles on the operand tile -> q | k | v tile (fp32, q scaled)
+    __device__ __forceinline__ void project() {
+        const int lane = threadIdx.x & 63, frow = lane & 15;
         f32x4 acc[MR][NTW];
         zero_acc(acc);
         if (nvt == NTW) {
@@ -453,12 +453,6 @@ struct QkvRole {
 #pragma unroll
             for (int i = 0; i < MR; ++i) acc[i][0] = a1[i][0];
         }
-        SYS_STAMP(3);
-        // text / time K|V and the descriptor are read by the attention phases below, up to the END of the previous block's
-        // compute: they go to LDS here, behind the stage loop's barrier, not in commit()
-#pragma unroll
-        for (int u = 0; u < NX; ++u) st4(xt + (tid + NTH * u) * 4, y.xk[u]);
-        if (tid <= RT) gd[tid] = g.gw;
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -470,12 +464,101 @@ struct QkvRole {
                     for (int r = 0; r < 4; ++r) qt[(16 * i + 4 * (lane >> 4) + r) * QLD + tc] = (acc[i][j][r] + bcol[j]) * scl;
                 }
             }
+    }
+    template <class M>
+    __device__ __forceinline__ void compute(int s, int b, const Geo& g, const Pay& y, M& mid) {
+        const int tid = threadIdx.x;
+        // text / time K|V and the descriptor are read by the attention phases below, up to the END of the previous block's
+        // compute: they go to LDS here, behind the stage loop's barrier, not in commit()
+#pragma unroll
+        for (int u = 0; u < NX; ++u) st4(xt + (tid + NTH * u) * 4, y.xk[u]);
+        if (tid <= RT) gd[tid] = g.gw;
+        project();
+        SYS_STAMP(3);
         mid.before_barrier();
         __syncthreads();
         mid.after_barrier();
         SYS_STAMP(6);
         // the shipped models have T = 5 latent tokens (7 keys): the loops are unrolled over the keys, so the bound is compile time
         if (T <= 5) attention<7>(b); else attention<TK>(b);
+    }
+    // ---- two waves per SIMD: the role runs as TWO WAVE GROUPS instead of the generic stage loop.  Waves 4-7 ("loaders") wait for
+    // a block's flags, load it and write its operand tile while waves 0-3 still run the attention of the PREVIOUS block (the
+    // operand tile is free once every wave is past the projection); all eight waves then do the projection; waves 0-3 do the
+    // attention, drain their stores, count themselves in (LDS) and the last one publishes.  Per block the stage then costs
+    // projection + max(attention + drain, wait + load + commit) instead of their sum.  A lone block's latency is unchanged.
+    __device__ __forceinline__ void split_loop(Ctl* ctl) {
+        static_assert(WS == 2 && MR == 1, "wave groups: the eight-wave, 16-row form only");
+        const int tid = threadIdx.x, lane = tid & 63, tl = tid - 256;
+        const bool loader = tid >= 256;
+        typedef __attribute__((address_space(3))) unsigned lu32;
+        auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        for (int s = 0; s < p.n_steps; ++s)
+            for (int b = st.blk0; b < p.NB; b += st.blkstride) {
+                f32x4 xk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                int gw = 0;
+                if (loader) {
+                    const BlockDesc* d = p.blocks + b;
+                    // geometry words first: they arrive while the flags are polled (one load per value, QkvRole::geo)
+                    int b2[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) { const int sx = (tl + 256 * u) >> 5; b2[u] = sx < 15 ? d->b2[sx] : -1; }
+                    const int* src = tl == 0 ? &d->nrows : &d->row_pk[tl <= RT ? tl - 1 : 0];
+                    gw = *src;
+                    const int rb2 = d->row_b2[tl >= 1 && tl <= RT ? tl - 1 : 0];
+                    if (!wait_epoch(flag_of(p, st.wait_group, b, 0), st.wait_n, s + 1, p.status, ctl, 0u)) return;
+                    const float* timekv = p.tables + (size_t)(p.step_lo + s) * DEN_STEP_STRIDE + st.layer * DEN_LAYER_STRIDE + DEN_OFF_TIME_KV;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {                        // text K|V slices of this head per sample-branch, slot 15: time
+                        const int f4 = tl + 256 * u, sx = f4 >> 5, c4 = (f4 & 31) * 4;
+                        if (sx == 15) xk[u] = ld4(timekv + (c4 < 64 ? c4 : 192 + c4) + h * 64);
+                        else if (b2[u] >= 0) xk[u] = ld4(tkv + (size_t)b2[u] * 512 + (c4 < 64 ? c4 : 192 + c4) + h * 64);
+                    }
+                    f32x4 x[2][2];
+                    const unsigned base = (unsigned)b * RT * 1024;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int id = tl + 256 * u, row = id >> 5, c8 = id & 31;
+                        x[u][0] = ld_sc1(rin, base + row * 1024 + c8 * 32);
+                        x[u][1] = ld_sc1(rin, base + row * 1024 + c8 * 32 + 16);
+                    }
+                    if (tl >= 1 && tl <= RT && ((gw >> 16) & 0xff) == 0xff) {        // a latent count that lives on the device only
+                        int c = T;
+                        if (rb2 >= 0 && p.counts != nullptr) { c = p.counts[rb2 % p.B]; c = c > T ? T : c; }
+                        gw = (gw & 0xffff) | (c << 16);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {                        // rows -> operand tile (as commit_rows)
+                        const int id = tl + 256 * u, row = id >> 5, c8 = id & 31;
+                        if constexpr (AR == 0) {
+                            bf16x8 hi, lo;
+                            split8(x[u][0], x[u][1], hi, lo);
+                            *reinterpret_cast<bf16x8*>(a_slot<4>(atile, row, c8 >> 3, c8 & 7)) = hi;
+                            *reinterpret_cast<bf16x8*>(a_slot<4>(atile, row, c8 >> 3, 8 + (c8 & 7))) = lo;
+                        } else {
+                            tile_put4<1, 4>(atile, row, c8 * 8, x[u][0]);
+                            tile_put4<1, 4>(atile, row, c8 * 8 + 4, x[u][1]);
+                        }
+                    }
+                }
+                lds_barrier();                                           // the operand tile is there; the previous block's attention is over
+                if (loader) {                                            // text / time K|V and the geometry words of THIS block
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) st4(xt + (tl + 256 * u) * 4, xk[u]);
+                    if (tl <= RT) gd[tl] = gw;
+                }
+                project();
+                lds_barrier();
+                if (!loader) {
+                    if (T <= 5) attention<7>(b); else attention<TK>(b);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows have landed
+                    if (lane == 0) {
+                        const unsigned old = __hip_atomic_fetch_add((lu32*)&ctl->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if ((old & 3u) == 3u)                            // the last of the four attention waves
+                            __hip_atomic_store((gu32*)flag_of(p, st.out_group, b, st.out_slot), (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
     }
     template <int NKEY>
     __device__ __forceinline__ void attention(int b) {
@@ -1073,11 +1156,16 @@ __global__ __launch_bounds__(256 * WS, 1) void systolic_loop_kernel(const SysArg
     // all LDS is dynamic (a static variable would shift the dynamic base off its 16-byte alignment, cdna_hip_programming.md G17)
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     Ctl* const ctl = reinterpret_cast<Ctl*>(lds + SYS_LDS_BYTES - 16);
-    if (threadIdx.x == 0) { ctl->abort = 0; ctl->ready = 0; }
+    if (threadIdx.x == 0) { ctl->abort = 0; ctl->ready = 0; ctl->arrive = 0u; }
     __syncthreads();
     const Stage st = p.stages[blockIdx.x];
     switch (st.role) {
-        case R_QKV: { QkvRole<MR, AR, WS> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
+        case R_QKV: {
+            QkvRole<MR, AR, WS> r(p, st, lds);
+            if constexpr (WS == 2) r.split_loop(ctl);
+            else stage_loop(p, st, r, ctl, st.blk0, st.blkstride);
+            break;
+        }
         case R_OUT: { OutRole<MR, AR, WS> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
         case R_LIN: { MlpRole<MR, ACT_RELU, AR, WS> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
         case R_RED2: { Red2Role<MR, WS> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
