@@ -50,7 +50,7 @@ constexpr int NSLICE = 8;                 // hidden slices of the two MLPs (128 
 constexpr int HS = FF / NSLICE;           // 128
 constexpr int NRED = 3;                   // workgroups per layer of each of the two reduce stages (how they share the work: red_parts())
 constexpr int NTAIL = 4;                  // tail workgroups (block b belongs to tail b % NTAIL)
-constexpr int FLAG_SLOTS = 8;
+constexpr int FLAG_SLOTS = 16;
 constexpr int FLAG_STRIDE = 32;             // words between the flags of two producers: every flag on a 128-byte line of its own
 constexpr int SYS_LDS_BYTES = 100 * 1024;   // > 80 KiB: one workgroup per CU, so the <= 256 workgroups sit on distinct CUs
 constexpr int GROUPS_PER_LAYER = 7;
@@ -60,7 +60,11 @@ enum Role : int { R_QKV = 0, R_OUT = 1, R_LIN = 2, R_RED2 = 3, R_FFN = 4, R_STYL
 struct Stage {                            // one per workgroup
     int role, layer, slice, act;
     int wait_group, wait_n, out_group, out_slot;
-    int blk0, blkstride, pad0, pad1;      // the blocks this workgroup visits: blk0, blk0 + blkstride, ...
+    int blk0, blkstride;                  // the blocks this workgroup visits: blk0, blk0 + blkstride, ...
+    // A flag with many consumer workgroups is REPLICATED, one 128-byte line per consumer: the producer raises out_rep flags (slots
+    // out_slot + i out_rep_stride) with one store instruction, a consumer polls wait_n slots from wait_slot0.  Sixty-four waves
+    // polling one line made every poll of that line slow - and those were the inputs of the two busiest stage types (LIN, FFN).
+    int wait_slot0, out_rep, out_rep_stride, pad0, pad1, pad2;
     const float *w0, *w1;                 // S-format matrices
     const float *b0, *b1;                 // biases
     const float *g, *be;                  // LayerNorm gamma / beta
@@ -191,11 +195,17 @@ __device__ __forceinline__ bool wait_epoch(const unsigned* flags, int n, unsigne
 
 // all rows of this workgroup are stored: drain (every wave), meet, publish.  YOUNGER = vector-memory operations the wave has issued
 // after its stores (vmcnt counts in issue order: they are left in flight)
+// raise the out_rep replicas of a stage's flag (flag = replica 0): lanes of ONE wave call this
+__device__ __forceinline__ void raise(const Stage& st, unsigned* flag, unsigned epoch) {
+    const int lane = threadIdx.x & 63;
+    if (lane < st.out_rep)
+        __hip_atomic_store((gu32*)flag + lane * st.out_rep_stride * FLAG_STRIDE, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <int YOUNGER = 0>
-__device__ __forceinline__ void publish(unsigned* flag, unsigned epoch) {
+__device__ __forceinline__ void publish(const Stage& st, unsigned* flag, unsigned epoch) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store((gu32*)flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 64) raise(st, flag, epoch);
 }
 
 __device__ __forceinline__ unsigned* flag_of(const SysArgs& p, int group, int b, int slot) {      // group = layer * 7 + Group
@@ -277,7 +287,7 @@ struct Mid {
     }
     __device__ __forceinline__ void after_barrier() {
         if (pending != nullptr) {
-            if (threadIdx.x == 0) __hip_atomic_store((gu32*)pending, pending_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x < 64) raise(st, pending, pending_epoch);
             pending = nullptr;
         }
         have = false;
@@ -315,7 +325,7 @@ __device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R&
             SYS_STAT_ITER(have);
             if (!have) {
                 SYS_STAT_T0;
-                if (!wait_epoch(flag_of(p, st.wait_group, b, 0), st.wait_n, s + 1, p.status, ctl, pre)) return;
+                if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, pre)) return;
                 SYS_STAT_WAIT;
                 r.issue(s, b, gcur, cur);
             }
@@ -327,7 +337,7 @@ __device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R&
             const bool has_next = R::PREFETCH && s2 < p.n_steps;
             unsigned early = 0xffffffffu;
             if (has_next && threadIdx.x < 64 && lane < st.wait_n)
-                early = __hip_atomic_load((const gu32*)flag_of(p, st.wait_group, b2, 0) + lane * FLAG_STRIDE, __ATOMIC_RELAXED,
+                early = __hip_atomic_load((const gu32*)flag_of(p, st.wait_group, b2, st.wait_slot0) + lane * FLAG_STRIDE, __ATOMIC_RELAXED,
                                           __HIP_MEMORY_SCOPE_AGENT);
             r.commit(cur);
             __syncthreads();
@@ -348,19 +358,19 @@ __device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R&
                 // not prefetched: every wave samples the next block's flags now, under the drain of this block's stores (always exactly
                 // one load, so that the drain can leave it in flight; past the last block it reads a flag nobody waits for)
                 if constexpr (R::PREPOLL) {
-                    const unsigned sample = __hip_atomic_load((const gu32*)flag_of(p, st.wait_group, b2, 0) + (lane < st.wait_n ? lane : 0) * FLAG_STRIDE,
+                    const unsigned sample = __hip_atomic_load((const gu32*)flag_of(p, st.wait_group, b2, st.wait_slot0) + (lane < st.wait_n ? lane : 0) * FLAG_STRIDE,
                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    publish<1>(flag_of(p, st.out_group, b, st.out_slot), s + 1);
+                    publish<1>(st, flag_of(p, st.out_group, b, st.out_slot), s + 1);
                     pre = s2 < p.n_steps && lane < st.wait_n ? sample : 0u;
                 } else {                 // four-wave workgroups (32-row plan): the extra poll per block cost more than it saved
                     pre = 0u;
-                    publish(flag_of(p, st.out_group, b, st.out_slot), s + 1);
+                    publish(st, flag_of(p, st.out_group, b, st.out_slot), s + 1);
                 }
             }
             SYS_STAMP(5);
             if constexpr (R::PREFETCH) { if (have) cur = nxt; }
         }
-    if (pending != nullptr) publish(pending, pending_epoch);
+    if (pending != nullptr) publish(st, pending, pending_epoch);
     SYS_STAT_END;
 }
 
@@ -506,7 +516,7 @@ struct QkvRole {
                     const int* src = tl == 0 ? &d->nrows : &d->row_pk[tl <= RT ? tl - 1 : 0];
                     gw = *src;
                     const int rb2 = d->row_b2[tl >= 1 && tl <= RT ? tl - 1 : 0];
-                    if (!wait_epoch(flag_of(p, st.wait_group, b, 0), st.wait_n, s + 1, p.status, ctl, 0u)) return;
+                    if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, 0u)) return;
                     const float* timekv = p.tables + (size_t)(p.step_lo + s) * DEN_STEP_STRIDE + st.layer * DEN_LAYER_STRIDE + DEN_OFF_TIME_KV;
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {                        // text K|V slices of this head per sample-branch, slot 15: time
@@ -676,6 +686,73 @@ struct OutRole {
             for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i];
             st_sc1(rout, base + row * 1024 + c * 4, v);
         }
+    }
+    // ---- two waves per SIMD: two wave groups, as QkvRole::split_loop.  Waves 4-7 wait for a block's flags, load the attention rows
+    // and write the operand tile while waves 0-3 still run the PREVIOUS block's residual + LayerNorm epilogue, drain their stores
+    // and publish; all eight waves do the out-projection.  Per block: projection + max(epilogue + drain, wait + load + commit).
+    __device__ __forceinline__ void split_loop(Ctl* ctl) {
+        static_assert(WS == 2 && MR == 1, "wave groups: the eight-wave, 16-row form only");
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tl = tid - 256, c = 4 * lane;
+        const bool loader = tid >= 256;
+        typedef __attribute__((address_space(3))) unsigned lu32;
+        auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        for (int s = 0; s < p.n_steps; ++s)
+            for (int b = st.blk0; b < p.NB; b += st.blkstride) {
+                const unsigned base = (unsigned)b * RT * 1024;
+                if (loader) {
+                    if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, 0u)) return;
+                    f32x4 x[2][2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int id = tl + 256 * u, row = id >> 5, c8 = id & 31;
+                        x[u][0] = ld_sc1(ratt, base + row * 1024 + c8 * 32);
+                        x[u][1] = ld_sc1(ratt, base + row * 1024 + c8 * 32 + 16);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {                        // rows -> operand tile (as commit_rows)
+                        const int id = tl + 256 * u, row = id >> 5, c8 = id & 31;
+                        if constexpr (AR == 0) {
+                            bf16x8 hi, lo;
+                            split8(x[u][0], x[u][1], hi, lo);
+                            *reinterpret_cast<bf16x8*>(a_slot<4>(atile, row, c8 >> 3, c8 & 7)) = hi;
+                            *reinterpret_cast<bf16x8*>(a_slot<4>(atile, row, c8 >> 3, 8 + (c8 & 7))) = lo;
+                        } else {
+                            tile_put4<1, 4>(atile, row, c8 * 8, x[u][0]);
+                            tile_put4<1, 4>(atile, row, c8 * 8 + 4, x[u][1]);
+                        }
+                    }
+                }
+                lds_barrier();                                           // the operand tile is there (the loaders saw the block's flags); the previous epilogue is over
+                f32x4 res[4];
+                if (!loader) {                                           // the residual rows come in under the projection
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) res[q] = ld_sc1(rx, base + (wave + 4 * q) * 1024 + lane * 16);
+                }
+                f32x4 acc[MR][NTW];
+                zero_acc(acc);
+                mma<AR, 4, NTW, 8, MR>(atile, wf, acc);
+                stage_c(ct, acc, [&](int j) { return 16 * NTW * wave + 16 * j; });
+                lds_barrier();
+                if (!loader) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = wave + 4 * q;
+                        f32x4 v = ld4(ct + row * CLD + c);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[i] + res[q][i];
+                        float mean, rstd;
+                        row_stats4(v, mean, rstd);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i];
+                        st_sc1(rout, base + row * 1024 + c * 4, v);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows have landed
+                    unsigned old = 0u;
+                    if (lane == 0) old = __hip_atomic_fetch_add((lu32*)&ctl->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    old = __builtin_amdgcn_readfirstlane(old);
+                    if ((old & 3u) == 3u) raise(st, flag_of(p, st.out_group, b, st.out_slot), (unsigned)(s + 1));   // the last of the four epilogue waves
+                }
+            }
     }
 };
 
@@ -1166,7 +1243,12 @@ __global__ __launch_bounds__(256 * WS, 1) void systolic_loop_kernel(const SysArg
             else stage_loop(p, st, r, ctl, st.blk0, st.blkstride);
             break;
         }
-        case R_OUT: { OutRole<MR, AR, WS> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
+        case R_OUT: {
+            OutRole<MR, AR, WS> r(p, st, lds);
+            if constexpr (WS == 2) r.split_loop(ctl);
+            else stage_loop(p, st, r, ctl, st.blk0, st.blkstride);
+            break;
+        }
         case R_LIN: { MlpRole<MR, ACT_RELU, AR, WS> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
         case R_RED2: { Red2Role<MR, WS> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
         case R_FFN: { MlpRole<MR, ACT_GELU, AR, WS> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
@@ -1333,6 +1415,7 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR,
     auto XO = [&](int l) { return ws + L.off_xo + (size_t)l * L.blk; };
     auto XS = [&](int l) { return ws + L.off_xs + (size_t)(l - NSKIP - 1) * L.blk; };
     auto G = [&](int l, int g) { return l * GROUPS_PER_LAYER + g; };
+    const bool x2_rep = rp.red2_parts * NSLICE <= FLAG_SLOTS;
     for (int l = 0; l < NL; ++l) {
         const DenLayerW& w = W.layer[l];
         const DenLayerW& ws_ = WS.layer[l];
@@ -1359,24 +1442,28 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR,
         {
             Stage s{};
             s.role = R_OUT; s.layer = l; s.wait_group = G(l, G_ATT); s.wait_n = H; s.out_group = G(l, G_X1); s.out_slot = 0;
+            s.out_rep = NSLICE; s.out_rep_stride = 1;                     // one flag line per LIN workgroup
             s.w0 = ws_.sa_attn.out_w; s.b0 = w.sa_attn.out_b; s.g = w.sa_norm1.g; s.be = w.sa_norm1.b; s.in0 = att; s.in1 = xin; s.out = x1;
             st.push_back(s);
         }
         for (int j = 0; j < NSLICE; ++j) {
             Stage s{};
             s.role = R_LIN; s.layer = l; s.slice = j; s.wait_group = G(l, G_X1); s.wait_n = 1; s.out_group = G(l, G_PC); s.out_slot = j;
+            s.wait_slot0 = j;
             s.w0 = ws_.sa_lin1.w; s.w1 = ws_.sa_lin2.w; s.b0 = w.sa_lin1.b; s.in0 = x1; s.out = pc;
             st.push_back(s);
         }
         for (int q = 0; q < rp.red2_parts; ++q) {
             Stage s{};
             s.role = R_RED2; s.layer = l; s.slice = q; s.wait_group = G(l, G_PC); s.wait_n = NSLICE; s.out_group = G(l, G_X2); s.out_slot = q;
+            if (x2_rep) { s.out_rep = NSLICE; s.out_rep_stride = rp.red2_parts; }   // FFN workgroup j polls slots j parts + q
             s.b0 = w.sa_lin2.b; s.g = w.sa_norm2.g; s.be = w.sa_norm2.b; s.in0 = pc; s.in1 = x1; s.out = x2;
             st.push_back(s);
         }
         for (int j = 0; j < NSLICE; ++j) {
             Stage s{};
             s.role = R_FFN; s.layer = l; s.slice = j; s.wait_group = G(l, G_X2); s.wait_n = rp.red2_parts; s.out_group = G(l, G_PE); s.out_slot = j;
+            if (x2_rep) s.wait_slot0 = j * rp.red2_parts;
             s.w0 = ws_.ffn1.w; s.w1 = ws_.ffn2.w; s.b0 = w.ffn1.b; s.in0 = x2; s.out = pe;
             st.push_back(s);
         }
@@ -1396,8 +1483,10 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR,
         s.in0 = XO(NL - 1); s.out = xin0;
         st.push_back(s);
     }
-    for (Stage& s : st)
+    for (Stage& s : st) {
         if (s.blkstride == 0) s.blkstride = 1;                        // every other stage visits every block
+        if (s.out_rep == 0) s.out_rep = 1;                            // one flag, one line
+    }
     if ((int)st.size() != L.nwg || st.size() > 256) return LADIFF_ERR_SHAPE;
     host.resize(st.size() * sizeof(Stage));
     std::memcpy(host.data(), st.data(), host.size());
