@@ -137,7 +137,25 @@ struct SysArgs {
             o[0] = st_wait; o[1] = st_hit; o[2] = st_n;                                                                \
         }                                                                                                              \
     } while (0)
+// wave-group loops (QKV, OUT): [0] ticks the loader waves were blocked on flags, [2] blocks, [3] ticks the other waves stood at the
+// tile barrier waiting for the loaders
+#define SYS_SPLIT_DECL unsigned long long sp_wait = 0, sp_idle = 0, sp_n = 0, sp_t = 0
+#define SYS_SPLIT_T0 sp_t = __builtin_amdgcn_s_memrealtime()
+#define SYS_SPLIT_WAIT sp_wait += __builtin_amdgcn_s_memrealtime() - sp_t
+#define SYS_SPLIT_IDLE do { sp_idle += __builtin_amdgcn_s_memrealtime() - sp_t; sp_n += 1; } while (0)
+#define SYS_SPLIT_END                                                                                                  \
+    do {                                                                                                               \
+        if (p.stamps != nullptr && (threadIdx.x == 0 || threadIdx.x == 256)) {                                         \
+            unsigned long long* o = p.stamps + (size_t)256 * 4 * 4 * 8 + (size_t)blockIdx.x * 4;                       \
+            if (threadIdx.x == 256) { o[0] = sp_wait; o[1] = 0; } else { o[2] = sp_n; o[3] = sp_idle; }                \
+        }                                                                                                              \
+    } while (0)
 #else
+#define SYS_SPLIT_DECL do { } while (0)
+#define SYS_SPLIT_T0 do { } while (0)
+#define SYS_SPLIT_WAIT do { } while (0)
+#define SYS_SPLIT_IDLE do { } while (0)
+#define SYS_SPLIT_END do { } while (0)
 #define SYS_STAMP(i) do { } while (0)
 #define SYS_STAT_DECL do { } while (0)
 #define SYS_STAT_T0 do { } while (0)
@@ -503,6 +521,7 @@ struct QkvRole {
         const bool loader = tid >= 256;
         typedef __attribute__((address_space(3))) unsigned lu32;
         auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        SYS_SPLIT_DECL;
         for (int s = 0; s < p.n_steps; ++s)
             for (int b = st.blk0; b < p.NB; b += st.blkstride) {
                 f32x4 xk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -516,7 +535,9 @@ struct QkvRole {
                     const int* src = tl == 0 ? &d->nrows : &d->row_pk[tl <= RT ? tl - 1 : 0];
                     gw = *src;
                     const int rb2 = d->row_b2[tl >= 1 && tl <= RT ? tl - 1 : 0];
+                    SYS_SPLIT_T0;
                     if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, 0u)) return;
+                    SYS_SPLIT_WAIT;
                     const float* timekv = p.tables + (size_t)(p.step_lo + s) * DEN_STEP_STRIDE + st.layer * DEN_LAYER_STRIDE + DEN_OFF_TIME_KV;
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {                        // text K|V slices of this head per sample-branch, slot 15: time
@@ -551,7 +572,9 @@ struct QkvRole {
                         }
                     }
                 }
+                if (!loader) SYS_SPLIT_T0;
                 lds_barrier();                                           // the operand tile is there; the previous block's attention is over
+                if (!loader) SYS_SPLIT_IDLE;
                 if (loader) {                                            // text / time K|V and the geometry words of THIS block
 #pragma unroll
                     for (int u = 0; u < 2; ++u) st4(xt + (tl + 256 * u) * 4, xk[u]);
@@ -569,6 +592,7 @@ struct QkvRole {
                     }
                 }
             }
+        SYS_SPLIT_END;
     }
     template <int NKEY>
     __device__ __forceinline__ void attention(int b) {
@@ -696,11 +720,14 @@ struct OutRole {
         const bool loader = tid >= 256;
         typedef __attribute__((address_space(3))) unsigned lu32;
         auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        SYS_SPLIT_DECL;
         for (int s = 0; s < p.n_steps; ++s)
             for (int b = st.blk0; b < p.NB; b += st.blkstride) {
                 const unsigned base = (unsigned)b * RT * 1024;
                 if (loader) {
+                    SYS_SPLIT_T0;
                     if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, 0u)) return;
+                    SYS_SPLIT_WAIT;
                     f32x4 x[2][2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
@@ -722,7 +749,9 @@ struct OutRole {
                         }
                     }
                 }
+                if (!loader) SYS_SPLIT_T0;
                 lds_barrier();                                           // the operand tile is there (the loaders saw the block's flags); the previous epilogue is over
+                if (!loader) SYS_SPLIT_IDLE;
                 f32x4 res[4];
                 if (!loader) {                                           // the residual rows come in under the projection
 #pragma unroll
@@ -753,6 +782,7 @@ struct OutRole {
                     if ((old & 3u) == 3u) raise(st, flag_of(p, st.out_group, b, st.out_slot), (unsigned)(s + 1));   // the last of the four epilogue waves
                 }
             }
+        SYS_SPLIT_END;
     }
 };
 

@@ -61,6 +61,8 @@ for i, n in enumerate(names):
     kind = n.split()[-1].rstrip("0123456789.")
     if stats[i, 2] > 0:
         agg[kind].append((float(stats[i, 0]) * 0.01 / steps, float(stats[i, 1]) / float(stats[i, 2])))
+        if kind in ("QKV", "OUT"):          # wave-group loops: the other waves' time at the tile barrier (waiting for the loader waves)
+            agg[kind + " compute waves at the tile barrier"].append((float(stats[i, 3]) * 0.01 / steps, 0.0))
 for k, v in agg.items():
     print(f"  {k:6s} blocked {sum(a for a, _ in v) / len(v):8.1f} us/step (min {min(a for a, _ in v):8.1f})   prefetch hit rate {sum(h for _, h in v) / len(v):.2f}")
 
