@@ -220,6 +220,10 @@ int ladiff_sampler_set_loop(void* sampler, int mode);
 /* Measurement switch (process-wide): waves per SIMD of the stage workgroups of the 16-row plan, 2 (default: 512-thread workgroups,
  * each stage's weight slice split over the two waves of a SIMD) or 1 (256 threads). */
 int ladiff_debug_set_stage_waves(int waves_per_simd);
+/* Measurement switch (process-wide, read when a sampler builds its stage table): 1 (default) = the pipeline stages are dealt to
+ * the XCDs in chain order and a stage whose readers share its XCD hands its rows over through that XCD's L2 (plain stores);
+ * 0 = every hand-off writes through to the memory side, stages in table order. */
+int ladiff_debug_set_xcd_local(int on);
 /* The block plan ladiff_diffusion_reverse would use for a batch (host arithmetic only, no GPU call): rows per block (16 = the
  * length-aware packing, 32 = padded blocks) and the number of blocks.  h_counts = latent counts on the host or NULL, masked = the
  * call passes device counts, loop_mode 1 / 2 / 3 as ladiff_sampler_set_loop, bf16x3 = the call passes w_split. */

@@ -331,6 +331,12 @@ int ladiff_debug_set_stage_waves(int waves_per_simd) {
     return 0;
 }
 
+int ladiff_debug_set_xcd_local(int on) {
+    LADIFF_CHECK_ARG(on == 0 || on == 1);
+    g_xcd_local = on;
+    return 0;
+}
+
 int ladiff_sampler_set_loop(void* sampler, int mode) {
     Sampler* sp = reinterpret_cast<Sampler*>(sampler);
     LADIFF_CHECK_ARG(sp != nullptr && mode >= 0 && mode <= 3);

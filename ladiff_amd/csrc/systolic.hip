@@ -51,6 +51,13 @@ constexpr int HS = FF / NSLICE;           // 128
 constexpr int NRED = 3;                   // workgroups per layer of each of the two reduce stages (how they share the work: red_parts())
 constexpr int NTAIL = 4;                  // tail workgroups (block b belongs to tail b % NTAIL)
 constexpr int FLAG_SLOTS = 16;
+// The eight partial planes of a layer's two K-split matrices (LIN -> RED2, FFN -> STYL) are RINGS of PRING block slots, not NB:
+// with a buffer set per layer (sys_layout) they would otherwise be most of a working set larger than the 256 MiB memory-side
+// cache.  A producer may therefore run at most PRING blocks ahead of its consumer: every PRING / 2 blocks it waits for the
+// consumer's flag of the block PRING / 2 back (MlpRole::backpressure; the stages visit their blocks in order).  The slot of
+// block b of local step s is (s NB + b) % PRING: blocks are counted THROUGH the steps, so that the reuse distance is PRING
+// blocks at the wrap from one step to the next as well.
+constexpr int PRING = 16;
 constexpr int FLAG_STRIDE = 32;             // words between the flags of two producers: every flag on a 128-byte line of its own
 constexpr int SYS_LDS_BYTES = 100 * 1024;   // > 80 KiB: one workgroup per CU, so the <= 256 workgroups sit on distinct CUs
 constexpr int GROUPS_PER_LAYER = 7;
@@ -64,7 +71,14 @@ struct Stage {                            // one per workgroup
     // A flag with many consumer workgroups is REPLICATED, one 128-byte line per consumer: the producer raises out_rep flags (slots
     // out_slot + i out_rep_stride) with one store instruction, a consumer polls wait_n slots from wait_slot0.  Sixty-four waves
     // polling one line made every poll of that line slow - and those were the inputs of the two busiest stage types (LIN, FFN).
-    int wait_slot0, out_rep, out_rep_stride, pad0, pad1, pad2;
+    int wait_slot0, out_rep, out_rep_stride;
+    // XCD placement (sys_place_stages): workgroup i runs on XCD i % 8 and each XCD has an L2 of its own.  out_local = every reader
+    // of this stage's output (rows and flags) sits on the SAME XCD: the stage then stores plainly - the rows stay in that L2, the
+    // store is acknowledged by the L2 instead of the memory side (a hop of 0.5 us instead of 0.9 - 1.2 us,
+    // scripts/ubench_xcd_handoff.hip) - otherwise it writes through (sc1).  Loads are sc1 either way: they are served by the
+    // reader's L2 when the line is there.  xcd = the XCD the plan put this workgroup on (-1: not checked).
+    int out_local, xcd, pad0;
+    int bp_group, bp_slot0, bp_n, bp_blocks;   // LIN / FFN: the consumer's flags (group, first slot, count) and how many consecutive blocks make "all consumers"
     const float *w0, *w1;                 // S-format matrices
     const float *b0, *b1;                 // biases
     const float *g, *be;                  // LayerNorm gamma / beta
@@ -175,6 +189,11 @@ __device__ __forceinline__ void st_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, f
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 16);
 }
 typedef __attribute__((address_space(1))) unsigned gu32;
+// a stage's output rows: plain when every reader shares this XCD's L2, write-through otherwise
+__device__ __forceinline__ void st_out(const Stage& st, __amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
+    if (st.out_local) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+    else st_sc1(r, off, v);
+}
 
 constexpr unsigned long long TIMEOUT_TICKS = 150000000ull;     // s_memrealtime runs at 100 MHz: 1.5 s per wait
 
@@ -216,8 +235,10 @@ __device__ __forceinline__ bool wait_epoch(const unsigned* flags, int n, unsigne
 // raise the out_rep replicas of a stage's flag (flag = replica 0): lanes of ONE wave call this
 __device__ __forceinline__ void raise(const Stage& st, unsigned* flag, unsigned epoch) {
     const int lane = threadIdx.x & 63;
-    if (lane < st.out_rep)
-        __hip_atomic_store((gu32*)flag + lane * st.out_rep_stride * FLAG_STRIDE, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < st.out_rep) {
+        if (st.out_local) __builtin_amdgcn_raw_buffer_store_b32(epoch, rsrc_of(flag), (unsigned)(lane * st.out_rep_stride * FLAG_STRIDE * 4), 0, 0);
+        else __hip_atomic_store((gu32*)flag + lane * st.out_rep_stride * FLAG_STRIDE, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 template <int YOUNGER = 0>
 __device__ __forceinline__ void publish(const Stage& st, unsigned* flag, unsigned epoch) {
@@ -341,6 +362,7 @@ __device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R&
         for (int b = b0; b < p.NB; b += bstride) {
             SYS_STAMP(0);
             SYS_STAT_ITER(have);
+            if constexpr (R::BACKP) { if (!r.backpressure(s, b, ctl)) return; }
             if (!have) {
                 SYS_STAT_T0;
                 if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, pre)) return;
@@ -404,6 +426,7 @@ struct QkvRole {
     static constexpr int NTH = 256 * WS, NTW = WS == 1 ? 3 : 2, NX = 2 / WS;      // threads; column tiles a wave can hold; 16-byte text K|V units per thread
     static constexpr bool PREFETCH = true;
     static constexpr bool PREPOLL = WS == 2;
+    static constexpr bool BACKP = false;
     struct Geo { int gw, rb2, b2[NX]; };                                 // descriptor word `tid` (+ its row's sample-branch); sample-branch of this thread's text slots
     struct Pay { Rows256<MR, WS> x; f32x4 xk[NX]; };
     const SysArgs& p; const Stage& st;
@@ -585,11 +608,10 @@ struct QkvRole {
                 if (!loader) {
                     if (T <= 5) attention<7>(b); else attention<TK>(b);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows have landed
-                    if (lane == 0) {
-                        const unsigned old = __hip_atomic_fetch_add((lu32*)&ctl->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if ((old & 3u) == 3u)                            // the last of the four attention waves
-                            __hip_atomic_store((gu32*)flag_of(p, st.out_group, b, st.out_slot), (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
+                    unsigned old = 0u;
+                    if (lane == 0) old = __hip_atomic_fetch_add((lu32*)&ctl->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    old = __builtin_amdgcn_readfirstlane(old);
+                    if ((old & 3u) == 3u) raise(st, flag_of(p, st.out_group, b, st.out_slot), (unsigned)(s + 1));   // the last of the four attention waves
                 }
             }
         SYS_SPLIT_END;
@@ -651,7 +673,7 @@ struct QkvRole {
                 o[0] = fmaf(pj, v4[j][0], o[0]); o[1] = fmaf(pj, v4[j][1], o[1]); o[2] = fmaf(pj, v4[j][2], o[2]); o[3] = fmaf(pj, v4[j][3], o[3]);
             }
             if (!live) o = f32x4{0.f, 0.f, 0.f, 0.f};
-            st_sc1(rout, ((unsigned)b * RT + row) * 1024 + (h * 64 + c4) * 4, o);
+            st_out(st, rout, ((unsigned)b * RT + row) * 1024 + (h * 64 + c4) * 4, o);
         }
     }
 };
@@ -662,6 +684,7 @@ struct OutRole {
     static constexpr int RT = 16 * MR, NW = 4 * WS, RPW = RT / NW, NTW = 16 / NW;     // rows / column tiles per wave
     static constexpr bool PREFETCH = true;
     static constexpr bool PREPOLL = WS == 2;
+    static constexpr bool BACKP = false;
     struct Geo {};
     struct Pay { Rows256<MR, WS> att; f32x4 res[RPW]; };
     const SysArgs& p; const Stage& st;
@@ -708,7 +731,7 @@ struct OutRole {
             row_stats4(v, mean, rstd);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i];
-            st_sc1(rout, base + row * 1024 + c * 4, v);
+            st_out(st, rout, base + row * 1024 + c * 4, v);
         }
     }
     // ---- two waves per SIMD: two wave groups, as QkvRole::split_loop.  Waves 4-7 wait for a block's flags, load the attention rows
@@ -773,7 +796,7 @@ struct OutRole {
                         row_stats4(v, mean, rstd);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i];
-                        st_sc1(rout, base + row * 1024 + c * 4, v);
+                        st_out(st, rout, base + row * 1024 + c * 4, v);
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows have landed
                     unsigned old = 0u;
@@ -792,6 +815,7 @@ struct MlpRole {
     static constexpr int RT = 16 * MR, NW = 4 * WS, NT1 = 8 / NW, NT2 = 16 / NW;       // hidden / output column tiles per wave
     static constexpr bool PREFETCH = true;
     static constexpr bool PREPOLL = WS == 2;
+    static constexpr bool BACKP = true;
     struct Geo {};
     struct Pay { Rows256<MR, WS> x; };
     const SysArgs& p; const Stage& st;
@@ -812,16 +836,30 @@ struct MlpRole {
 #pragma unroll
         for (int j = 0; j < NT1; ++j) b1[j] = st.b0[j0 + 16 * NT1 * wave + 16 * j + frow];
         rin = rsrc_of(st.in0); rout = rsrc_of(st.out);
-        plane = (unsigned)st.slice * p.NB * RT * 1024;
+        plane = (unsigned)st.slice * PRING * RT * 1024;
     }
     __device__ __forceinline__ void geo(int, Geo&) {}
     __device__ __forceinline__ void geo_fix(Geo&) {}
     __device__ __forceinline__ void issue(int, int b, const Geo&, Pay& y) { issue_rows<MR, WS>(y.x, rin, (unsigned)b * RT * 1024); }
     __device__ __forceinline__ void commit(const Pay& y) { commit_rows<AR, 4, MR, WS>(atile, 0, y.x); }
+    // the partial planes are rings of PRING slots: block b's slot was block b - PRING's.  Every PRING / 2 blocks: has the
+    // consumer (both reduce parts / both block groups of it) finished block b - PRING / 2?  Its stages run in block order, so
+    // it has then finished everything the next PRING / 2 blocks of this stage overwrite.
+    __device__ __forceinline__ bool backpressure(int s, int b, Ctl* ctl) {
+        const int g = s * p.NB + b;                                      // blocks counted through the steps
+        if (g % (PRING / 2) != 0) return true;
+        for (int i = 0; i < st.bp_blocks; ++i) {
+            const int gx = g - PRING / 2 - i;
+            if (gx < 0) continue;
+            const int sx = gx / p.NB, x = gx - sx * p.NB;
+            if (!wait_epoch(flag_of(p, st.bp_group, x, st.bp_slot0), st.bp_n, (unsigned)(sx + 1), p.status, ctl, 0u)) return false;
+        }
+        return true;
+    }
     template <class M>
     __device__ __forceinline__ void compute(int s, int b, const Geo&, const Pay&, M& mid) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, frow = lane & 15, fk = lane >> 4;
-        const unsigned base = (unsigned)b * RT * 1024;
+        const unsigned base = (unsigned)((s * p.NB + b) % PRING) * RT * 1024;     // ring slot of this block
         f32x4 acc1[MR][NT1];
         zero_acc(acc1);
         mma<AR, 4, NT1, 8, MR>(atile, w1, acc1);
@@ -852,7 +890,7 @@ struct MlpRole {
 #pragma unroll
         for (int q = 0; q < RT / RPI; ++q) {
             const int row = RPI * q + lane / LPR, cc = CW * wave + 4 * (lane % LPR);
-            st_sc1(rout, plane + base + row * 1024 + cc * 4, ld4(ct + row * CLD + cc));
+            st_out(st, rout, plane + base + row * 1024 + cc * 4, ld4(ct + row * CLD + cc));
         }
     }
 };
@@ -863,6 +901,7 @@ struct Red2Role {
     static constexpr int RT = 16 * MR, NW = 4 * WS, PQ = ((MR == 1 ? 8 : 12) + NW - 1) / NW;   // rows per wave: a part has <= 8 (16-row blocks) / <= 11 rows
     static constexpr bool PREFETCH = true;
     static constexpr bool PREPOLL = WS == 2;
+    static constexpr bool BACKP = false;
     struct Geo { int pk[PQ], b2[PQ], row[PQ], t[PQ], cnt[PQ]; };          // slot wave + NW q of this part: raw words, then decoded
     struct Pay { f32x4 pl[PQ][NSLICE], rs[PQ], tv[PQ], tp[PQ]; };
     const SysArgs& p; const Stage& st;
@@ -873,7 +912,7 @@ struct Red2Role {
         const int lane = threadIdx.x & 63;
         bias = ld4(st.b0 + 4 * lane); gg = ld4(st.g + 4 * lane); bb = ld4(st.be + 4 * lane);
         rp = rsrc_of(st.in0); rx = rsrc_of(st.in1); rout = rsrc_of(st.out);
-        pstride = (unsigned)p.NB * RT * 1024;
+        pstride = (unsigned)PRING * RT * 1024;
     }
     __device__ __forceinline__ void geo(int b, Geo& g) {
         const int wave = threadIdx.x >> 6;
@@ -894,7 +933,7 @@ struct Red2Role {
     __device__ __forceinline__ void issue(int s, int b, const Geo& g, Pay& y) {
         const int lane = threadIdx.x & 63, c = 4 * lane;
         const float* ct = p.ctab + ((size_t)st.layer * p.n_ctab + s) * (2 * p.B + 1) * D;
-        const unsigned base = (unsigned)b * RT * 1024;
+        const unsigned base = (unsigned)b * RT * 1024, pbase = (unsigned)((s * p.NB + b) % PRING) * RT * 1024;   // partial planes: rings of PRING slots
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
             const int row = g.row[q];
@@ -904,7 +943,7 @@ struct Red2Role {
                 y.tv[q] = y.tp[q];
                 if (g.b2[q] >= 0 && g.t[q] < g.cnt[q]) y.tv[q] = ld4(ct + (size_t)g.b2[q] * D + c);
 #pragma unroll
-                for (int j = 0; j < NSLICE; ++j) y.pl[q][j] = ld_sc1(rp, j * pstride + base + row * 1024 + c * 4);
+                for (int j = 0; j < NSLICE; ++j) y.pl[q][j] = ld_sc1(rp, j * pstride + pbase + row * 1024 + c * 4);
                 y.rs[q] = ld_sc1(rx, base + row * 1024 + c * 4);
             }
         }
@@ -928,7 +967,7 @@ struct Red2Role {
                 row_stats4(v, mean, rstd);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i] + y.tv[q][i];
-                st_sc1(rout, base + row * 1024 + c * 4, v);
+                st_out(st, rout, base + row * 1024 + c * 4, v);
             }
         }
     }
@@ -943,6 +982,7 @@ struct StylRole {
     // groups on alternating blocks, which have the slack)
     static constexpr bool PREFETCH = MR == 1 && WS == 1;
     static constexpr bool PREPOLL = WS == 2;
+    static constexpr bool BACKP = false;
     struct Geo { int pk[PQ], row[PQ]; };                                 // tile row of slot wave + NW q of this part (-1: none)
     struct Pay { f32x4 pl[PQ][NSLICE], rs[PQ], scl, shf; };
     const SysArgs& p; const Stage& st;
@@ -957,7 +997,7 @@ struct StylRole {
         load_w(wf, st.w0, D, 0, [&](int j) { return 16 * NTW * wave + 16 * j; });
         bias2 = ld4(st.b1 + 4 * lane); bias = ld4(st.b0 + 4 * lane); gg = ld4(st.g + 4 * lane); bb = ld4(st.be + 4 * lane);
         rp = rsrc_of(st.in0); rx = rsrc_of(st.in1); rout = rsrc_of(st.out);
-        pstride = (unsigned)p.NB * RT * 1024;
+        pstride = (unsigned)PRING * RT * 1024;
     }
     __device__ __forceinline__ void geo(int b, Geo& g) {
         const int wave = threadIdx.x >> 6;
@@ -970,7 +1010,7 @@ struct StylRole {
     }
     __device__ __forceinline__ void issue(int s, int b, const Geo& g, Pay& y) {
         const int lane = threadIdx.x & 63, c = 4 * lane;
-        const unsigned base = (unsigned)b * RT * 1024;
+        const unsigned base = (unsigned)b * RT * 1024, pbase = (unsigned)((s * p.NB + b) % PRING) * RT * 1024;
         const float* mod = p.tables + (size_t)(p.step_lo + s) * DEN_STEP_STRIDE + st.layer * DEN_LAYER_STRIDE + DEN_OFF_FFN_MOD;
         y.scl = ld4(mod + c); y.shf = ld4(mod + D + c);                  // AdaLN scale | shift of this step (time tables)
 #pragma unroll
@@ -979,7 +1019,7 @@ struct StylRole {
             y.rs[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (row >= 0) {
 #pragma unroll
-                for (int j = 0; j < NSLICE; ++j) y.pl[q][j] = ld_sc1(rp, j * pstride + base + row * 1024 + c * 4);
+                for (int j = 0; j < NSLICE; ++j) y.pl[q][j] = ld_sc1(rp, j * pstride + pbase + row * 1024 + c * 4);
                 y.rs[q] = ld_sc1(rx, base + row * 1024 + c * 4);
             }
         }
@@ -1020,7 +1060,7 @@ struct StylRole {
                 f32x4 v = ld4(ct + lr * CLD + c);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[i] + y.rs[q][i];
-                st_sc1(rout, base + row * 1024 + c * 4, v);
+                st_out(st, rout, base + row * 1024 + c * 4, v);
             }
         }
     }
@@ -1032,6 +1072,7 @@ struct SkipRole {
     static constexpr int RT = 16 * MR, NW = 4 * WS, NTH = 64 * NW, NTW = 8 / NW;      // column tiles per wave of this half's 128 columns
     static constexpr bool PREFETCH = true;
     static constexpr bool PREPOLL = WS == 2;
+    static constexpr bool BACKP = false;
     struct Geo {};
     struct Pay { Rows256<MR, WS> x, k; };
     const SysArgs& p; const Stage& st;
@@ -1072,7 +1113,7 @@ struct SkipRole {
             f32x4 v = ld4(ct + row * CLD + cc);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] += bias[i];
-            st_sc1(rout, base + row * 1024 + cc * 4, v);
+            st_out(st, rout, base + row * 1024 + cc * 4, v);
         }
     }
 };
@@ -1124,7 +1165,7 @@ struct TailRole {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) xn[i] = l[i] + pe[i];
                     }
-                    st_sc1(rout, base + q * 1024 + c * 4, xn);
+                    st_out(st, rout, base + q * 1024 + c * 4, xn);
                 }
             }
             publish_unit(u, 1);
@@ -1179,8 +1220,8 @@ struct TailRole {
                     xn[k] = l[k] + y.pe[i][k];
                 }
                 st4(p.lat + (size_t)g.lat[i] * D + c, l);
-                st_sc1(rout, bu + q * 1024 + c * 4, xn);               // after the last step nobody reads it
-                st_sc1(rout, bc + g.rc[i] * 1024 + c * 4, xn);
+                st_out(st, rout, bu + q * 1024 + c * 4, xn);               // after the last step nobody reads it
+                st_out(st, rout, bc + g.rc[i] * 1024 + c * 4, xn);
             }
         }
     }
@@ -1263,9 +1304,31 @@ __global__ __launch_bounds__(256 * WS, 1) void systolic_loop_kernel(const SysArg
     // all LDS is dynamic (a static variable would shift the dynamic base off its 16-byte alignment, cdna_hip_programming.md G17)
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     Ctl* const ctl = reinterpret_cast<Ctl*>(lds + SYS_LDS_BYTES - 16);
-    if (threadIdx.x == 0) { ctl->abort = 0; ctl->ready = 0; ctl->arrive = 0u; }
-    __syncthreads();
     const Stage st = p.stages[blockIdx.x];
+    if (threadIdx.x == 0) {
+        ctl->abort = 0; ctl->ready = 0; ctl->arrive = 0u;
+        if (st.xcd >= 0) {
+            // The plan only needs workgroups i and j to share an XCD exactly when i = j (mod 8).  The dispatcher deals a launch's
+            // workgroups to the XCDs round robin but starts where the previous launch stopped, so XCC_ID - i (mod 8) is one
+            // number per launch: the first workgroup to get here records it, every other one compares.
+            const unsigned rot = ((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf) + 8u - (blockIdx.x & 7u)) & 7u;
+            unsigned seen = 0u;
+            __hip_atomic_compare_exchange_strong((gu32*)p.status + 8, &seen, rot + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (seen != 0u && seen != rot + 1u) {
+                ctl->abort = 1;
+                __hip_atomic_store((gu32*)p.status + 1, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store((gu32*)p.status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    __syncthreads();
+    if (ctl->abort) return;
+#ifdef LADIFF_STAMPS
+    if (p.stamps != nullptr && threadIdx.x == 0)         // who runs here (the stage table is permuted by the XCD placement)
+        p.stamps[(size_t)256 * 4 * 4 * 8 + 256 * 4 + 256 * 4 * 8 + blockIdx.x] =
+            1ull | (unsigned long long)st.role << 8 | (unsigned long long)st.layer << 16 | (unsigned long long)st.slice << 24 |
+            (unsigned long long)st.blk0 << 32 | (unsigned long long)(st.out_local & 1) << 40 | (unsigned long long)(st.xcd & 0xff) << 48;
+#endif
     switch (st.role) {
         case R_QKV: {
             QkvRole<MR, AR, WS> r(p, st, lds);
@@ -1295,7 +1358,7 @@ unsigned long long* g_sys_stamps = nullptr;
 #endif
 namespace {
 struct SysLayout {
-    size_t blk;                   // floats of one [NB][RT][256] buffer
+    size_t blk, ring;             // floats of one [NB][RT][256] buffer / of one [PRING][RT][256] partial plane
     size_t off_stages, off_blocks, off_flags, off_status, off_xin0, off_xs, off_xo, off_att, off_x1, off_x2, off_pc, off_pe, total;
     int nwg, NB, split;
 };
@@ -1322,11 +1385,14 @@ SysLayout sys_layout(int MR, int NB) {
     L.off_xin0 = take(L.blk);
     L.off_xs = take(NSKIP * L.blk);
     L.off_xo = take(NL * L.blk);
-    L.off_att = take(L.blk);
-    L.off_x1 = take(L.blk);
-    L.off_x2 = take(L.blk);
-    L.off_pc = take(NSLICE * L.blk);
-    L.off_pe = take(NSLICE * L.blk);
+    // one set per LAYER: a buffer is then written by the workgroups of one stage group only - on one XCD when the group stores
+    // plainly (Stage::out_local), so that no line is ever dirty in two L2s
+    L.off_att = take(NL * L.blk);
+    L.off_x1 = take(NL * L.blk);
+    L.off_x2 = take(NL * L.blk);
+    L.ring = (size_t)PRING * RT * D;                                  // floats of one partial plane: a ring of PRING block slots
+    L.off_pc = take((size_t)NL * NSLICE * L.ring);
+    L.off_pe = take((size_t)NL * NSLICE * L.ring);
     L.total = off;
     return L;
 }
@@ -1434,14 +1500,69 @@ void sys_pack_blocks(int B, int T, int want_mr, const int32_t* h_counts, bool ma
 }
 
 // Builds the stage table (host) for this call's pointers.  `ws` = the systolic region of the reverse workspace.
+// ---- XCD placement.  The dispatcher hands workgroup i of a launch to XCD i % 8 (from wherever the previous launch
+// stopped; checked once per device by a probe launch of the same shape, and by every pipeline workgroup when it starts: status 3).  `st` comes in CHAIN order (the order a block
+// flows through the stages); the stages are dealt to the XCDs in that order, 32 (31) to each, so that a layer's hand-offs stay
+// inside one XCD's L2 and the chain crosses an XCD boundary only 7 times (+ the skip connections and the tail).  A stage whose
+// readers all sit on its own XCD stores plainly (Stage::out_local); everything else works as before (write-through).
+int g_xcd_local = 1;              // measurement switch: ladiff_debug_set_xcd_local
+
+__global__ __launch_bounds__(512, 1) void xcd_probe_kernel(unsigned* xcc) {
+    extern __shared__ char lds[];
+    if (threadIdx.x == 0) xcc[blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;
+}
+static bool xcd_round_robin() {
+    static std::mutex mu;
+    static int known[64] = {};    // per device: 0 unknown, 1 round robin over 8 XCDs, 2 anything else
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (known[dev] == 0) {
+        known[dev] = 2;
+        unsigned* d = nullptr;
+        unsigned h[NWG];
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess && hipMalloc(&d, sizeof(h)) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(xcd_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SYS_LDS_BYTES) == hipSuccess) {
+            hipLaunchKernelGGL(xcd_probe_kernel, dim3(NWG), dim3(512), SYS_LDS_BYTES, s, d);
+            if (hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
+                bool ok = true;
+                for (int i = 0; i < NWG; ++i) ok = ok && h[i] < 8u && h[i] == (h[0] + (unsigned)i) % 8u;   // any start, then round robin
+                if (ok) known[dev] = 1;
+            }
+        }
+        if (d) (void)hipFree(d);
+        if (s) (void)hipStreamDestroy(s);
+    }
+    return known[dev] == 1;
+}
+static void sys_place_stages(std::vector<Stage>& st) {
+    const int n = (int)st.size();
+    std::vector<Stage> placed(n);
+    int cnt[8] = {}, k = 0;
+    for (int j = 0; j < n; ++j) {
+        while (cnt[k] == (n - k + 7) / 8) ++k;                        // XCD k runs workgroups k, k + 8, ...
+        st[j].xcd = k;
+        placed[k + 8 * cnt[k]++] = st[j];
+    }
+    for (Stage& p : placed) {
+        bool local = true;
+        for (const Stage& c : placed) {
+            const bool reads = c.in0 == p.out || c.in1 == p.out || c.in2 == p.out;                       // its rows
+            const bool polls = c.wait_group == p.out_group || (c.bp_n > 0 && c.bp_group == p.out_group);  // its flags
+            if ((reads || polls) && c.xcd != p.xcd) local = false;
+        }
+        p.out_local = local ? 1 : 0;
+    }
+    st.swap(placed);
+}
+
 int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR, int NB, std::vector<unsigned char>& host) {
     // WS = the S-format weight table in bf16x3 mode; in fp32 mode the caller passes the fp32 table twice
     const SysLayout L = sys_layout(MR, NB);
     const RedPlan rp = red_plan(MR);
     std::vector<Stage> st;
     float* xin0 = ws + L.off_xin0;
-    float* att = ws + L.off_att; float* x1 = ws + L.off_x1; float* x2 = ws + L.off_x2;
-    float* pc = ws + L.off_pc; float* pe = ws + L.off_pe;
     auto XO = [&](int l) { return ws + L.off_xo + (size_t)l * L.blk; };
     auto XS = [&](int l) { return ws + L.off_xs + (size_t)(l - NSKIP - 1) * L.blk; };
     auto G = [&](int l, int g) { return l * GROUPS_PER_LAYER + g; };
@@ -1449,6 +1570,8 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR,
     for (int l = 0; l < NL; ++l) {
         const DenLayerW& w = W.layer[l];
         const DenLayerW& ws_ = WS.layer[l];
+        float* att = ws + L.off_att + (size_t)l * L.blk; float* x1 = ws + L.off_x1 + (size_t)l * L.blk; float* x2 = ws + L.off_x2 + (size_t)l * L.blk;
+        float* pc = ws + L.off_pc + (size_t)l * NSLICE * L.ring; float* pe = ws + L.off_pe + (size_t)l * NSLICE * L.ring;
         const float* xin; int xg, xn;
         if (l == 0) { xin = xin0; xg = G(0, G_XIN); xn = 1; }
         else if (l <= NSKIP) { xin = XO(l - 1); xg = G(l - 1, G_XO); xn = rp.styl_parts; }
@@ -1480,6 +1603,7 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR,
             Stage s{};
             s.role = R_LIN; s.layer = l; s.slice = j; s.wait_group = G(l, G_X1); s.wait_n = 1; s.out_group = G(l, G_PC); s.out_slot = j;
             s.wait_slot0 = j;
+            s.bp_group = G(l, G_X2); s.bp_slot0 = x2_rep ? j * rp.red2_parts : 0; s.bp_n = rp.red2_parts; s.bp_blocks = 1;
             s.w0 = ws_.sa_lin1.w; s.w1 = ws_.sa_lin2.w; s.b0 = w.sa_lin1.b; s.in0 = x1; s.out = pc;
             st.push_back(s);
         }
@@ -1494,6 +1618,7 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR,
             Stage s{};
             s.role = R_FFN; s.layer = l; s.slice = j; s.wait_group = G(l, G_X2); s.wait_n = rp.red2_parts; s.out_group = G(l, G_PE); s.out_slot = j;
             if (x2_rep) s.wait_slot0 = j * rp.red2_parts;
+            s.bp_group = G(l, G_XO); s.bp_slot0 = 0; s.bp_n = rp.styl_parts; s.bp_blocks = rp.styl_groups;
             s.w0 = ws_.ffn1.w; s.w1 = ws_.ffn2.w; s.b0 = w.ffn1.b; s.in0 = x2; s.out = pe;
             st.push_back(s);
         }
@@ -1516,8 +1641,10 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR,
     for (Stage& s : st) {
         if (s.blkstride == 0) s.blkstride = 1;                        // every other stage visits every block
         if (s.out_rep == 0) s.out_rep = 1;                            // one flag, one line
+        s.xcd = -1;
     }
     if ((int)st.size() != L.nwg || st.size() > 256) return LADIFF_ERR_SHAPE;
+    if (g_xcd_local && xcd_round_robin()) sys_place_stages(st);
     host.resize(st.size() * sizeof(Stage));
     std::memcpy(host.data(), st.data(), host.size());
     return 0;

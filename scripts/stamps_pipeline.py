@@ -19,7 +19,7 @@ pipe = bench.build_pipe(dev, B)
 pipe.precision = "bf16x3"; pipe.num_inference_timesteps = steps; pipe.loop = mode
 lens = [196] * B
 text, noise = syn.text_embeddings(B).to(dev), syn.init_noise(lens).to(dev)
-st = torch.zeros(256 * 4 * 4 * 8 + 256 * 4 + 256 * 4 * 8, dtype=torch.int64, device=dev)
+st = torch.zeros(256 * 4 * 4 * 8 + 256 * 4 + 256 * 4 * 8 + 256, dtype=torch.int64, device=dev)
 s = torch.cuda.Stream(device=dev)
 with torch.cuda.stream(s), torch.no_grad():
     pipe._diffusion_reverse(text, lens, init_noise=noise)
@@ -29,7 +29,8 @@ with torch.cuda.stream(s), torch.no_grad():
     torch.cuda.synchronize()
 print("status", pipe.loop_status())
 stats = st[256 * 4 * 4 * 8:256 * 4 * 4 * 8 + 256 * 4].cpu().reshape(256, 4)
-mid = st[256 * 4 * 4 * 8 + 256 * 4:].cpu().reshape(256, 4, 8).double() * 0.01
+mid = st[256 * 4 * 4 * 8 + 256 * 4:256 * 4 * 4 * 8 + 256 * 4 + 256 * 4 * 8].cpu().reshape(256, 4, 8).double() * 0.01
+ident = st[-256:].cpu().tolist()
 t = st[:256 * 4 * 4 * 8].reshape(256, 4, 4, 8).cpu().double() * 0.01          # 100 MHz ticks -> us
 names = []
 for l in range(9):
@@ -39,6 +40,21 @@ for l in range(9):
     names += [f"L{l} RED2.{q}" for q in range(2 if mode == "pipeline16" else 3)] + [f"L{l} FFN{j}" for j in range(8)]
     names += ([f"L{l} STYL.{q}" for q in range(2)] + [f"L{l} STYLb.{q}" for q in range(2)]) if mode == "pipeline16" else [f"L{l} STYL.{q}" for q in range(3)]
 names += [f"TAIL{k}" for k in range(4)]
+# the stage table is permuted by the XCD placement: every workgroup wrote who it is; bring the rows back into chain order
+def name_of(w):
+    role, l, sl, b0 = (w >> 8) & 0xff, (w >> 16) & 0xff, (w >> 24) & 0xff, (w >> 32) & 0xff
+    return {0: f"L{l} QKV{sl}", 1: f"L{l} OUT", 2: f"L{l} LIN{sl}", 3: f"L{l} RED2.{sl}", 4: f"L{l} FFN{sl}",
+            5: f"L{l} STYL{'b' if b0 else ''}.{sl}", 6: f"L{l} SKIP{sl}", 7: f"TAIL{sl}"}[role]
+where = {name_of(w): i for i, w in enumerate(ident) if w & 1}
+assert all(n in where for n in names), [n for n in names if n not in where][:5]
+order = [where[n] for n in names]
+stats, mid, t = stats[order], mid[order], t[order]
+xcd = [(ident[i] >> 48) & 0xff for i in order]
+local = [(ident[i] >> 40) & 1 for i in order]
+if any(x != 0xff for x in xcd):
+    print("placement (XCD of each stage of layers 0-2, * = hands over through the XCD's L2): " +
+          " ".join(f"{n.replace(' ', '.')}@{x}{'*' if lo else ''}" for n, x, lo in zip(names, xcd, local) if n[:2] in ("L0", "L1", "L2")))
+    print(f"stages that store plainly: {sum(local)} of {len(local)}")
 step, blk = min(1, steps - 1), 0
 tail = len(names) - 4 + blk % 4
 t0 = t[tail, step - 1, blk, 4] if step > 0 else t[:, step, blk, 1][t[:, step, blk, 1] > 0].min()
@@ -66,6 +82,8 @@ for i, n in enumerate(names):
 for k, v in agg.items():
     print(f"  {k:6s} blocked {sum(a for a, _ in v) / len(v):8.1f} us/step (min {min(a for a, _ in v):8.1f})   prefetch hit rate {sum(h for _, h in v) / len(v):.2f}")
 
+busy = sorted((float(stats[i, 0]) * 0.01 / steps, n, xcd[i], local[i]) for i, n in enumerate(names) if stats[i, 2] > 0)
+print("least blocked workgroups (us/step blocked, stage, XCD, * = plain stores): " + "  ".join(f"{a:.1f} {n.replace(' ', '.')}@{x}{'*' if lo else ''}" for a, n, x, lo in busy[:16]))
 print("steady state (mid-run, four consecutive blocks): us since the first block's loop top; stamps 0 top, 1 operands issued, 2 committed, 3 mfma, 6/7 (QKV: tile in LDS / scores), 4 stored, 5 published-or-deferred")
 for i, n in enumerate(names):
     if n in ("L4 QKV0", "L4 OUT", "L4 LIN0", "L4 RED2.0", "L4 FFN0", "L4 STYL.0"):

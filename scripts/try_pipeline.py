@@ -11,7 +11,11 @@ pipe = bench.build_pipe(dev, 128)
 pipe.precision = "fp32" if "fp32" in sys.argv[1:] else "bf16x3"
 UNIFORM = "uniform" in sys.argv[1:]                      # every prompt 196 frames (the benchmark workload) instead of mixed lengths
 FP32 = "fp32" in sys.argv[1:]                            # the strict-parity arithmetic mode instead of bf16x3
-args = [a for a in sys.argv[1:] if a not in ("uniform", "fp32")]
+NOLOCAL = "nolocal" in sys.argv[1:]                      # every hand-off writes through (no XCD placement)
+args = [a for a in sys.argv[1:] if a not in ("uniform", "fp32", "nolocal")]
+if NOLOCAL:
+    from ladiff_amd import _lib
+    _lib.check(_lib.lib().ladiff_debug_set_xcd_local(0))
 cases = [(3, 2), (3, 5), (7, 5), (128, 50)] if not args else [tuple(int(v) for v in a.split(",")) for a in args]
 stream = torch.cuda.Stream(device=dev)
 for B, steps in cases:
