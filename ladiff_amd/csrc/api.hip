@@ -305,8 +305,9 @@ static void choose_plan(int B, int T, const int32_t* h_counts, bool masked, int 
     int want = loop_mode == 2 ? 1 : (loop_mode == 3 ? 2 : 0);
     if (want != 2) sys_pack_blocks(B, T, 1, h_counts, masked, p16, &mr16, &nb16);
     if (want == 0) {
-        // measured (profiles/r2): stage time per block and one block's trip through the 59 stages, in us, for 16- / 32-row blocks
-        const double c16 = bf16x3 ? 3.1 : 5.5, c32 = bf16x3 ? 5.3 : 12.5, lat16 = bf16x3 ? 216.0 : 347.0, lat32 = bf16x3 ? 304.0 : 430.0;
+        // measured (scripts/try_pipeline.py uniform, 1 ... 128 prompts, final build of round 2): the busiest stage's time per block
+        // and one block's unloaded trip through the 59 stages, in us, for 16- / 32-row blocks
+        const double c16 = bf16x3 ? 2.45 : 5.05, c32 = bf16x3 ? 5.3 : 12.1, lat16 = bf16x3 ? 172.0 : 310.0, lat32 = bf16x3 ? 282.0 : 525.0;
         const double e16 = mr16 == 1 ? std::max(lat16, nb16 * c16) : 1e30, e32 = std::max(lat32, nb32 * c32);
         want = e16 < e32 ? 1 : 2;
     }

@@ -123,6 +123,28 @@ def test_stage_workgroups_of_four_and_eight_waves_agree(nets):
         L.ladiff_debug_set_stage_waves(2)
 
 
+def test_xcd_placement_on_and_off_agree(nets):
+    """The stage table is dealt to the XCDs in chain order and stages whose readers share their XCD store plainly (through that
+    XCD's L2); with the placement switched off every hand-off writes through as before.  Same bits either way, in both plans and
+    both arithmetic modes, on batches with more blocks than the partial planes' ring has slots (back-pressure active) - and the
+    same bits when the call is repeated (the ring's slot sequence runs through the steps)."""
+    from ladiff_amd import _lib
+    L = _lib.lib()
+    lens = [196] * 70 + [60, 120, 49, 1, 100, 150, 196, 48, 30, 77]
+    try:
+        for precision in ("bf16x3", "fp32"):
+            for loop in ("pipeline16", "pipeline32"):
+                assert L.ladiff_debug_set_xcd_local(1) == 0
+                za = run(nets, loop, precision, len(lens), 5, 7, lens)
+                zb = run(nets, loop, precision, len(lens), 5, 7, lens)
+                assert L.ladiff_debug_set_xcd_local(0) == 0
+                zc = run(nets, loop, precision, len(lens), 5, 7, lens)
+                assert torch.equal(za, zb) and torch.equal(za, zc), (precision, loop)
+        assert L.ladiff_debug_set_xcd_local(2) != 0
+    finally:
+        L.ladiff_debug_set_xcd_local(1)
+
+
 def test_two_samplers_on_two_streams(nets):
     """A pipeline kernel needs the whole chip resident: launches from different streams of one process are chained through an
     event (systolic.hip), so two samplers enqueued back to back on two streams both complete with the right result."""
