@@ -222,7 +222,9 @@ int ladiff_sampler_set_loop(void* sampler, int mode);
 int ladiff_debug_set_stage_waves(int waves_per_simd);
 /* Measurement switch (process-wide, read when a sampler builds its stage table): 1 (default) = the pipeline stages are dealt to
  * the XCDs in chain order and a stage whose readers share its XCD hands its rows over through that XCD's L2 (plain stores);
- * 0 = every hand-off writes through to the memory side, stages in table order. */
+ * 0 = every hand-off writes through to the memory side, stages in table order; 2 = as 1, but one workgroup of every launch
+ * reports a placement that disagrees with the others (test aid: the launch must then agree to write through everywhere and still
+ * give the same bits; ladiff_reverse_status reports code 0, info -1 for such a launch). */
 int ladiff_debug_set_xcd_local(int on);
 /* The block plan ladiff_diffusion_reverse would use for a batch (host arithmetic only, no GPU call): rows per block (16 = the
  * length-aware packing, 32 = padded blocks) and the number of blocks.  h_counts = latent counts on the host or NULL, masked = the
@@ -233,7 +235,8 @@ int ladiff_reverse_plan(int B, int T, const int32_t* h_counts, int masked, int l
  * pipeline kernel, or around the graph replays); blocks until it has finished.  Measurement aid (bench.py). */
 int ladiff_sampler_loop_ms(void* sampler, float* ms);
 /* Blocking read of the pipeline kernel's status word of the last call in this workspace: code 0 = completed,
- * 2 = a stage timed out waiting for its producer (info = workgroup).  Debug / test aid. */
+ * 2 = a stage timed out waiting for its producer (info = workgroup); code 0 with info -1 = completed, but the workgroups
+ * were not on the XCDs the plan assumed and every hand-off was written through (slower, same results).  Debug / test aid. */
 int ladiff_reverse_status(void* ws, int B, int T, int n_steps, int n_text, int* code, int* info);
 size_t ladiff_reverse_workspace_bytes(int B, int T, int n_steps, int n_text);
 int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* const* w_split /*or NULL*/,

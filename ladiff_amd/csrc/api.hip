@@ -333,7 +333,7 @@ int ladiff_debug_set_stage_waves(int waves_per_simd) {
 }
 
 int ladiff_debug_set_xcd_local(int on) {
-    LADIFF_CHECK_ARG(on == 0 || on == 1);
+    LADIFF_CHECK_ARG(on >= 0 && on <= 2);
     g_xcd_local = on;
     return 0;
 }

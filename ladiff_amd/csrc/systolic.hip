@@ -123,6 +123,7 @@ struct SysArgs {
     const int32_t* counts;
     float gscale;
     int B, T, P, NB, step_lo, n_steps, n_ctab;
+    int force_mismatch;                   // test aid: one workgroup reports a placement that disagrees (ladiff_debug_set_xcd_local(2))
     int split;                            // 1: a block holds ONE guidance branch of its P prompts (block 2g + br), 0: both
     unsigned long long* stamps;           // diagnostic twin build only (-DLADIFF_STAMPS): [workgroup][step][block][8] realtime ticks
 };
@@ -198,7 +199,7 @@ __device__ __forceinline__ void st_out(const Stage& st, __amdgpu_buffer_rsrc_t r
 constexpr unsigned long long TIMEOUT_TICKS = 150000000ull;     // s_memrealtime runs at 100 MHz: 1.5 s per wait
 
 // LDS words of the hand-off protocol (last 16 bytes of the dynamic region)
-struct Ctl { int abort, ready; unsigned arrive; int pad1; };      // arrive: attention waves of the QKV stage that have drained, over all blocks
+struct Ctl { int abort, ready; unsigned arrive; int local_ok; };      // arrive: attention waves of the QKV stage that have drained, over all blocks
 
 // Every wave polls flags[0 .. n) by itself until all are >= epoch and goes on to its own loads at once (no barrier, no LDS
 // round trip after the flag is seen).  ONE poll in flight per wave: the memory side serves flags and data alike, and two polls in
@@ -1304,25 +1305,41 @@ __global__ __launch_bounds__(256 * WS, 1) void systolic_loop_kernel(const SysArg
     // all LDS is dynamic (a static variable would shift the dynamic base off its 16-byte alignment, cdna_hip_programming.md G17)
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     Ctl* const ctl = reinterpret_cast<Ctl*>(lds + SYS_LDS_BYTES - 16);
-    const Stage st = p.stages[blockIdx.x];
+    Stage st = p.stages[blockIdx.x];
     if (threadIdx.x == 0) {
-        ctl->abort = 0; ctl->ready = 0; ctl->arrive = 0u;
+        ctl->abort = 0; ctl->ready = 0; ctl->arrive = 0u; ctl->local_ok = 1;
         if (st.xcd >= 0) {
             // The plan only needs workgroups i and j to share an XCD exactly when i = j (mod 8).  The dispatcher deals a launch's
             // workgroups to the XCDs round robin but starts where the previous launch stopped, so XCC_ID - i (mod 8) is one
-            // number per launch: the first workgroup to get here records it, every other one compares.
-            const unsigned rot = ((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf) + 8u - (blockIdx.x & 7u)) & 7u;
+            // number per launch: the first workgroup to get here records it, every other one compares - and ALL of them agree on
+            // the outcome before anything is stored (the kernel needs all its workgroups resident anyway): were a single one
+            // somewhere else (another queue's dispatch in between), the whole launch runs with write-through hand-offs, which
+            // are right wherever a workgroup sits.  status[1] then reads -1 (ladiff_reverse_status: code 0, info -1).
+            unsigned rot = ((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf) + 8u - (blockIdx.x & 7u)) & 7u;
+            if (p.force_mismatch && blockIdx.x == 5) rot = (rot + 1u) & 7u;
             unsigned seen = 0u;
             __hip_atomic_compare_exchange_strong((gu32*)p.status + 8, &seen, rot + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (seen != 0u && seen != rot + 1u) {
-                ctl->abort = 1;
-                __hip_atomic_store((gu32*)p.status + 1, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store((gu32*)p.status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (seen != 0u && seen != rot + 1u) __hip_atomic_store((gu32*)p.status + 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add((gu32*)p.status + 9, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__hip_atomic_load((const gu32*)p.status + 9, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+                if (__builtin_amdgcn_s_memrealtime() - t0 > TIMEOUT_TICKS) {
+                    ctl->abort = 1;
+                    __hip_atomic_store((gu32*)p.status + 1, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store((gu32*)p.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (__hip_atomic_load((const gu32*)p.status + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                ctl->local_ok = 0;
+                if (blockIdx.x == 0) __hip_atomic_store((gu32*)p.status + 1, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
     __syncthreads();
     if (ctl->abort) return;
+    if (!ctl->local_ok) st.out_local = 0;
 #ifdef LADIFF_STAMPS
     if (p.stamps != nullptr && threadIdx.x == 0)         // who runs here (the stage table is permuted by the XCD placement)
         p.stamps[(size_t)256 * 4 * 4 * 8 + 256 * 4 + 256 * 4 * 8 + blockIdx.x] =
@@ -1676,6 +1693,7 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     a.lat = lat; a.counts = counts; a.gscale = gscale; a.B = B; a.T = T; a.P = 0; a.NB = NB; a.step_lo = step_lo; a.n_steps = n;
     a.n_ctab = n_ctab;
     a.split = L.split;
+    a.force_mismatch = g_xcd_local == 2 ? 1 : 0;
     a.stamps = nullptr;
 #ifdef LADIFF_STAMPS
     a.stamps = g_sys_stamps;

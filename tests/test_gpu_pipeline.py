@@ -140,7 +140,20 @@ def test_xcd_placement_on_and_off_agree(nets):
                 assert L.ladiff_debug_set_xcd_local(0) == 0
                 zc = run(nets, loop, precision, len(lens), 5, 7, lens)
                 assert torch.equal(za, zb) and torch.equal(za, zc), (precision, loop)
-        assert L.ladiff_debug_set_xcd_local(2) != 0
+        assert L.ladiff_debug_set_xcd_local(3) != 0
+        # one workgroup somewhere else than planned: the launch agrees to write through everywhere (status info -1), same bits
+        den, vae = nets
+        for precision in ("bf16x3", "fp32"):
+            outs = []
+            for mode in (1, 2):
+                assert L.ladiff_debug_set_xcd_local(mode) == 0
+                pipe = LADIFF(denoiser=den, vae=vae, scheduler=DDIMScheduler(set_alpha_to_one=False, steps_offset=1, **SCHED_KW),
+                              guidance_scale=7.5, num_inference_timesteps=5, eta=0.0, max_it=5, precision=precision, loop="pipeline16")
+                text = syn.text_embeddings(len(lens), seed=31).to(DEV)
+                noise = torch.randn(len(lens), 5, 256, generator=torch.Generator().manual_seed(32)).to(DEV)
+                outs.append(pipe._diffusion_reverse(text, lens, init_noise=noise))
+                assert pipe.loop_status() == ((0, 0) if mode == 1 else (0, -1)), (precision, mode, pipe.loop_status())
+            assert torch.equal(outs[0], outs[1]), precision
     finally:
         L.ladiff_debug_set_xcd_local(1)
 
