@@ -68,6 +68,8 @@ def test_pipeline16_variant_and_replay(nets):
     ("ten-row last block", [196] * 128),
     ("c5 per-rank mix", ([60, 120, 196] * 43)[:128]),
     ("all counts", ([196, 60, 120, 100, 48, 150, 196] * 19)[:128]),
+    ("172 blocks: the partial planes' ring wraps off a slot boundary at every step", [196] * 256),
+    ("an odd number of blocks", [196] * 127 + [60, 100]),
 ])
 def test_packed_blocks_many(nets, precision, name, lens):
     """Length-aware packing at sizes where the stages are backlogged (blocks prefetched, flags deferred) and blocks leave
