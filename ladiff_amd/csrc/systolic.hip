@@ -140,6 +140,13 @@ struct SysArgs {
                 p.stamps[(size_t)256 * 4 * 4 * 8 + 256 * 4 + ((size_t)blockIdx.x * 4 + (b - bm_)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
         }                                                                                                              \
     } while (0)
+// the same from the first loader thread of a wave-group loop (threads 256 ..)
+#define SYS_STAMP_L(i)                                                                                                 \
+    do {                                                                                                               \
+        if (p.stamps != nullptr && threadIdx.x == 256) {                                                               \
+            if (s < 4 && b < 4) p.stamps[(((size_t)blockIdx.x * 4 + s) * 4 + b) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                                                              \
+    } while (0)
 // per-workgroup totals behind the timeline: ticks blocked in wait_epoch, prefetch hits, blocks processed
 #define SYS_STAT_DECL unsigned long long st_wait = 0, st_hit = 0, st_n = 0, st_t = 0
 #define SYS_STAT_T0 st_t = __builtin_amdgcn_s_memrealtime()
@@ -171,6 +178,7 @@ struct SysArgs {
 #define SYS_SPLIT_WAIT do { } while (0)
 #define SYS_SPLIT_IDLE do { } while (0)
 #define SYS_SPLIT_END do { } while (0)
+#define SYS_STAMP_L(i) do { } while (0)
 #define SYS_STAMP(i) do { } while (0)
 #define SYS_STAT_DECL do { } while (0)
 #define SYS_STAT_T0 do { } while (0)
@@ -559,9 +567,8 @@ struct QkvRole {
                     const int* src = tl == 0 ? &d->nrows : &d->row_pk[tl <= RT ? tl - 1 : 0];
                     gw = *src;
                     const int rb2 = d->row_b2[tl >= 1 && tl <= RT ? tl - 1 : 0];
-                    SYS_SPLIT_T0;
-                    if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, 0u)) return;
-                    SYS_SPLIT_WAIT;
+                    // the text / time K|V rows do not depend on the block's flags (the per-call tables): they are requested BEFORE the
+                    // wait - these are plain loads of rows nobody touched since the prologue, often a trip to the memory side
                     const float* timekv = p.tables + (size_t)(p.step_lo + s) * DEN_STEP_STRIDE + st.layer * DEN_LAYER_STRIDE + DEN_OFF_TIME_KV;
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {                        // text K|V slices of this head per sample-branch, slot 15: time
@@ -569,6 +576,10 @@ struct QkvRole {
                         if (sx == 15) xk[u] = ld4(timekv + (c4 < 64 ? c4 : 192 + c4) + h * 64);
                         else if (b2[u] >= 0) xk[u] = ld4(tkv + (size_t)b2[u] * 512 + (c4 < 64 ? c4 : 192 + c4) + h * 64);
                     }
+                    SYS_SPLIT_T0;
+                    if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, 0u)) return;
+                    SYS_SPLIT_WAIT;
+                    SYS_STAMP_L(1);
                     f32x4 x[2][2];
                     const unsigned base = (unsigned)b * RT * 1024;
 #pragma unroll
@@ -599,6 +610,7 @@ struct QkvRole {
                 if (!loader) SYS_SPLIT_T0;
                 lds_barrier();                                           // the operand tile is there; the previous block's attention is over
                 if (!loader) SYS_SPLIT_IDLE;
+                SYS_STAMP(2);
                 if (loader) {                                            // text / time K|V and the geometry words of THIS block
 #pragma unroll
                     for (int u = 0; u < 2; ++u) st4(xt + (tl + 256 * u) * 4, xk[u]);
@@ -606,13 +618,16 @@ struct QkvRole {
                 }
                 project();
                 lds_barrier();
+                SYS_STAMP(3);
                 if (!loader) {
                     if (T <= 5) attention<7>(b); else attention<TK>(b);
+                    SYS_STAMP(4);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows have landed
                     unsigned old = 0u;
                     if (lane == 0) old = __hip_atomic_fetch_add((lu32*)&ctl->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     old = __builtin_amdgcn_readfirstlane(old);
                     if ((old & 3u) == 3u) raise(st, flag_of(p, st.out_group, b, st.out_slot), (unsigned)(s + 1));   // the last of the four attention waves
+                    SYS_STAMP(5);
                 }
             }
         SYS_SPLIT_END;
@@ -752,6 +767,7 @@ struct OutRole {
                     SYS_SPLIT_T0;
                     if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, 0u)) return;
                     SYS_SPLIT_WAIT;
+                    SYS_STAMP_L(1);
                     f32x4 x[2][2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
@@ -776,6 +792,7 @@ struct OutRole {
                 if (!loader) SYS_SPLIT_T0;
                 lds_barrier();                                           // the operand tile is there (the loaders saw the block's flags); the previous epilogue is over
                 if (!loader) SYS_SPLIT_IDLE;
+                SYS_STAMP(2);
                 f32x4 res[4];
                 if (!loader) {                                           // the residual rows come in under the projection
 #pragma unroll
@@ -786,6 +803,7 @@ struct OutRole {
                 mma<AR, 4, NTW, 8, MR>(atile, wf, acc);
                 stage_c(ct, acc, [&](int j) { return 16 * NTW * wave + 16 * j; });
                 lds_barrier();
+                SYS_STAMP(3);
                 if (!loader) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -804,6 +822,7 @@ struct OutRole {
                     if (lane == 0) old = __hip_atomic_fetch_add((lu32*)&ctl->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     old = __builtin_amdgcn_readfirstlane(old);
                     if ((old & 3u) == 3u) raise(st, flag_of(p, st.out_group, b, st.out_slot), (unsigned)(s + 1));   // the last of the four epilogue waves
+                    SYS_STAMP(5);
                 }
             }
         SYS_SPLIT_END;
