@@ -290,14 +290,37 @@ __device__ __forceinline__ void commit_rows(char* tile, int kb0, const Rows256<M
     }
 }
 
-__device__ __forceinline__ void row_stats4(const f32x4 v, float& mean, float& rstd) {   // as rowops.hip: two-pass, fp32
-    const float s = wave_sum(v[0] + v[1] + v[2] + v[3]);
-    mean = s * (1.f / 256.f);
+// LayerNorm statistics of a 256-column row, two-pass, fp32 (as rowops.hip).  The per-lane parts are shared by the two layouts
+// below so that both sum in the same order: a lane's four consecutive columns first, then 16 lanes (row16_sum), then the four
+// 64-column quarters as (q3 + q2) + (q1 + q0) - what wave_sum does with its two row broadcasts.
+// Every multiply-add here is spelled out (__fmul_rn / __fsub_rn / __fmaf_rn): left to -ffp-contract the compiler fuses `mean = s / 256`
+// into the subtractions that use it in one inlining context and not in another, and the two layouts then differ in the last bit
+// of a few deviations - which the bf16x3 splits of nine layers turn into 1e-4 on the latents.
+__device__ __forceinline__ float part_sum4(const f32x4 v) { return v[0] + v[1] + v[2] + v[3]; }
+__device__ __forceinline__ float part_sq4(const f32x4 v, float mean) {
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const float d = v[i] - mean; q += d * d; }
-    q = wave_sum(q);
-    rstd = rsqrtf(q * (1.f / 256.f) + LN_EPS);
+    for (int i = 0; i < 4; ++i) { const float d = __fsub_rn(v[i], mean); q = __fmaf_rn(d, d, q); }
+    return q;
+}
+__device__ __forceinline__ float ln_apply(float v, float mean, float rstd, float g, float b) {
+    return __fmaf_rn(__fmul_rn(__fsub_rn(v, mean), rstd), g, b);
+}
+__device__ __forceinline__ void row_stats4(const f32x4 v, float& mean, float& rstd) {   // a row on 64 lanes: lane l holds columns 4 l ..
+    const float s = wave_sum(part_sum4(v));
+    mean = __fmul_rn(s, 1.f / 256.f);
+    const float q = wave_sum(part_sq4(v, mean));
+    rstd = rsqrtf(__fmaf_rn(q, 1.f / 256.f, LN_EPS));
+}
+// a row on 16 lanes (four rows per wave at once): lane l16 holds columns 64 k + 4 l16 .. of quarter k in v[k]; same bits as row_stats4
+__device__ __forceinline__ void row_stats16(const f32x4 (&v)[4], float& mean, float& rstd) {
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = row16_sum(part_sum4(v[k]));
+    mean = __fmul_rn((r[3] + r[2]) + (r[1] + r[0]), 1.f / 256.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = row16_sum(part_sq4(v[k], mean));
+    rstd = rsqrtf(__fmaf_rn((r[3] + r[2]) + (r[1] + r[0]), 1.f / 256.f, LN_EPS));
 }
 __device__ __forceinline__ f32x4 sum8(const f32x4 (&pl)[NSLICE]) {       // fixed summation tree of the eight hidden slices
     f32x4 v;
@@ -746,7 +769,7 @@ struct OutRole {
             float mean, rstd;
             row_stats4(v, mean, rstd);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i];
+            for (int i = 0; i < 4; ++i) v[i] = ln_apply(v[i], mean, rstd, gg[i], bb[i]);
             st_out(st, rout, base + row * 1024 + c * 4, v);
         }
     }
@@ -755,8 +778,14 @@ struct OutRole {
     // and publish; all eight waves do the out-projection.  Per block: projection + max(epilogue + drain, wait + load + commit).
     __device__ __forceinline__ void split_loop(Ctl* ctl) {
         static_assert(WS == 2 && MR == 1, "wave groups: the eight-wave, 16-row form only");
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tl = tid - 256, c = 4 * lane;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tl = tid - 256;
         const bool loader = tid >= 256;
+        f32x4 ebias[4], egg[4], ebb[4];                                  // bias / LayerNorm gamma, beta in the epilogue layout
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cc = 64 * k + 4 * (lane & 15);
+            ebias[k] = ld4(st.b0 + cc); egg[k] = ld4(st.g + cc); ebb[k] = ld4(st.be + cc);
+        }
         typedef __attribute__((address_space(3))) unsigned lu32;
         auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
         SYS_SPLIT_DECL;
@@ -793,10 +822,14 @@ struct OutRole {
                 lds_barrier();                                           // the operand tile is there (the loaders saw the block's flags); the previous epilogue is over
                 if (!loader) SYS_SPLIT_IDLE;
                 SYS_STAMP(2);
+                // epilogue layout: a row on 16 lanes (lane l16: columns 64 k + 4 l16 .., k < 4), rows 4 wave .. 4 wave + 3 of waves 0-3
+                // at once - the LayerNorm reductions of the four rows are then four-step DPP chains running side by side instead
+                // of four six-step chains one after the other (same summation order, same bits: row_stats16)
+                const int erow = 4 * (wave & 3) + (lane >> 4), ec = 4 * (lane & 15);
                 f32x4 res[4];
-                if (!loader) {                                           // the residual rows come in under the projection
+                if (!loader) {                                           // the residual row comes in under the projection
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) res[q] = ld_sc1(rx, base + (wave + 4 * q) * 1024 + lane * 16);
+                    for (int k = 0; k < 4; ++k) res[k] = ld_sc1(rx, base + erow * 1024 + (64 * k + ec) * 4);
                 }
                 f32x4 acc[MR][NTW];
                 zero_acc(acc);
@@ -805,17 +838,20 @@ struct OutRole {
                 lds_barrier();
                 SYS_STAMP(3);
                 if (!loader) {
+                    f32x4 v[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int row = wave + 4 * q;
-                        f32x4 v = ld4(ct + row * CLD + c);
+                    for (int k = 0; k < 4; ++k) {
+                        v[k] = ld4(ct + erow * CLD + 64 * k + ec);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[i] + res[q][i];
-                        float mean, rstd;
-                        row_stats4(v, mean, rstd);
+                        for (int i = 0; i < 4; ++i) v[k][i] = v[k][i] + ebias[k][i] + res[k][i];
+                    }
+                    float mean, rstd;
+                    row_stats16(v, mean, rstd);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i];
-                        st_out(st, rout, base + row * 1024 + c * 4, v);
+                    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[k][i] = ln_apply(v[k][i], mean, rstd, egg[k][i], ebb[k][i]);
+                        st_out(st, rout, base + erow * 1024 + (64 * k + ec) * 4, v[k]);
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows have landed
                     unsigned old = 0u;
