@@ -1374,19 +1374,22 @@ __global__ __launch_bounds__(256 * WS, 1) void systolic_loop_kernel(const SysArg
             if (p.force_mismatch && blockIdx.x == 5) rot = (rot + 1u) & 7u;
             unsigned seen = 0u;
             __hip_atomic_compare_exchange_strong((gu32*)p.status + 8, &seen, rot + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (seen != 0u && seen != rot + 1u) __hip_atomic_store((gu32*)p.status + 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add((gu32*)p.status + 9, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            // one word carries both the head count (low half) and the number of workgroups that disagree (high half): a single
+            // atomic per workgroup, relaxed polls (an acquire in the spin would invalidate the L2 on every turn)
+            const unsigned mine = (seen != 0u && seen != rot + 1u) ? 0x10001u : 1u;
+            __hip_atomic_fetch_add((gu32*)p.status + 9, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while (__hip_atomic_load((const gu32*)p.status + 9, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+            unsigned v = 0u;
+            while (((v = __hip_atomic_load((const gu32*)p.status + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffu) < gridDim.x) {
                 if (__builtin_amdgcn_s_memrealtime() - t0 > TIMEOUT_TICKS) {
                     ctl->abort = 1;
                     __hip_atomic_store((gu32*)p.status + 1, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store((gu32*)p.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(2);
             }
-            if (__hip_atomic_load((const gu32*)p.status + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            if ((v >> 16) != 0u) {
                 ctl->local_ok = 0;
                 if (blockIdx.x == 0) __hip_atomic_store((gu32*)p.status + 1, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
