@@ -1,29 +1,39 @@
 #!/usr/bin/env python3
 """Benchmark of the LADiff sampling hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config headline|c1|c2|c3|c4|c5]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
 
-One "step" = one pass of the hot path over one batch of synthetic prompts: 128 prompts per GPU, 196 frames,
-50-step DDIM with classifier-free guidance 7.5 (`_diffusion_reverse`), LA-VAE decode to [128,196,263] and, for
-N > 1, the final RCCL all-gather of the frames.  Inputs (random-init weights, random "CLIP" embeddings, seeded
-noise: ladiff_amd/synthetic.py) are resident in HBM before the timed region.  Metric: motions/s, whole job.
+One "step" = one pass of the hot path over one batch of synthetic prompts.  Default workload (BASELINE.json's metric, also
+config c4's per-rank slice): 128 prompts per GPU, 196 frames, 50-step DDIM with classifier-free guidance 7.5
+(`_diffusion_reverse`), LA-VAE decode to [128,196,263] and, for N > 1, the final RCCL all-gather of the frames.  Inputs
+(random-init weights, random "CLIP" embeddings, seeded noise: ladiff_amd/synthetic.py) are resident in HBM before the timed
+region.  Metric: motions/s, whole job.  `--config` runs the other BASELINE.json configurations in the same JSON shape
+(SURVEY.md §8a/§8d): c1 decode only (8 motions of 60 frames), c2 64 prompts, c3 1000-step DDPM on 128 prompts (per-step
+noise streamed from a resident [1000,128,5,256] tensor; 20 windows of 50 steps), c5 128 prompts of {60,120,196} frames with
+the KIT 251-dim decoder (the slice one of 8 ranks runs); c4 = the default workload (meant for --gpus 8).
+
+After the timed region (never inside it) the run is CHECKED: the last timed pass must equal the warm-up pass bit for bit,
+the pipeline's status word must read "completed", and a few prompts of the timed batch are compared with the CPU oracle
+(`parity.max_abs_diff_frames_vs_oracle`, gate 1e-3).
 
 Extra objects on the JSON line:
-  roofline     the DOMINANT KERNEL.  bf16x3 mode: the persistent pipeline kernel that runs all 50 guided steps in one launch
-               (csrc/systolic.hip, ~85 % of the device time): achieved = algorithmic FLOPs of one launch (reference-equivalent
-               denoiser arithmetic, SURVEY.md §8d: 358.27 MFLOP per motion and step) / its duration measured live with HIP
-               events recorded around the launch on the bench stream (ladiff_sampler_loop_ms).  fp32 mode: ffn.linear1's GEMM,
-               timed live over back-to-back launches.  peak = dense MFMA peak of the timed mode's dtype.  traffic, mfma_util_pmc
-               and share_of_pass are READ from profiles/r2/summary.json (rocprofv3 runs of scripts/profile_pass.py, stamped
-               with the commit they were taken at) - null when that file has no entry for the kernel.
-               roofline.whole_pass: the same for the whole pass - reference-equivalent FLOPs (21.757 GFLOP
-               per motion at F=196, C=263, 50 steps) / the pass's device time; executed_tflops counts the FLOPs the
-               kernels really execute after hoisting so the two cannot be conflated.
+  roofline     the DOMINANT KERNEL: the persistent pipeline kernel that runs the guided steps (csrc/systolic.hip): achieved =
+               algorithmic FLOPs of one launch (reference-equivalent denoiser arithmetic, SURVEY.md §8d: 358.27 MFLOP per motion
+               and step) / its duration measured live with HIP events recorded around the launch on the bench stream
+               (ladiff_sampler_loop_ms; per window for c3).  peak = dense MFMA peak of the timed mode's dtype.  traffic,
+               mfma_util_pmc and share_of_pass are READ from profiles/rN/summary.json (rocprofv3 runs of scripts/profile_pass.py)
+               - null when that file has no entry for the kernel, and `traffic_source_stale` says whether the kernel sources
+               have changed since (content hash of ladiff_amd/csrc).  roofline.whole_pass: the same for the whole pass -
+               reference-equivalent FLOPs per motion / the pass's device time; executed_tflops counts the FLOPs
+               the kernels really execute after hoisting so the two cannot be conflated.
   cpu_baseline the CPU oracle (oracle/ladiff_oracle.py, a port of the reference's op sequence, fp32 PyTorch) timed on
-               the host cores of this box on a bounded sample of the same workload.  Baseline only.
+               the host cores of this box on a bounded sample of the same workload (N = 1 only; an N > 1 line refers to
+               the newest N = 1 line committed under profiles/).  Baseline only.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -35,16 +45,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from ladiff_amd import LADIFF, DDIMScheduler, LADiffDenoiser, LADiffVae, distributed as D, synthetic as syn  # noqa: E402
+from ladiff_amd import LADIFF, DDIMScheduler, DDPMScheduler, LADiffDenoiser, LADiffVae, distributed as D, synthetic as syn  # noqa: E402
 
 FRAMES, NFEATS, STEPS_DDIM, BATCH = 196, 263, 50, 128
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1 sparsity figure)
+DEN_FLOPS_PER_MOTION_STEP = 358.27e6  # reference-equivalent, guidance x2 included
+FRAME_TOL = 1e-3                      # BASELINE.json north_star: decoded-frame max abs diff vs the fp32 reference
+
+# BASELINE.json `configs`: prompts PER GPU, frames, feature width, scheduler, steps, length pattern
+CONFIGS = {
+    "headline": dict(batch=128, frames=196, nfeats=263, sched="ddim", steps=50, lens="uniform", decode_only=False,
+                     metric="motions/sec (196-frame, 50-step DDIM, bs128)", tag="ddim50_cfg7.5"),
+    "c1": dict(batch=8, frames=60, nfeats=263, sched=None, steps=0, lens="uniform", decode_only=True,
+               metric="motions/sec (c1: LA-VAE decode only, bs8, 60 frames)", tag="decode_only"),
+    "c2": dict(batch=64, frames=196, nfeats=263, sched="ddim", steps=50, lens="uniform", decode_only=False,
+               metric="motions/sec (c2: 196-frame, 50-step DDIM, bs64)", tag="ddim50_cfg7.5"),
+    "c3": dict(batch=128, frames=196, nfeats=263, sched="ddpm", steps=1000, lens="uniform", decode_only=False,
+               metric="motions/sec (c3: 196-frame, 1000-step DDPM, bs128)", tag="ddpm1000_cfg7.5"),
+    "c5": dict(batch=128, frames=196, nfeats=251, sched="ddim", steps=50, lens="mixed", decode_only=False,
+               metric="motions/sec (c5: mixed {60,120,196} frames, KIT 251-dim, 50-step DDIM, bs128 per GPU)", tag="ddim50_cfg7.5_mixed"),
+}
+CONFIGS["c4"] = dict(CONFIGS["headline"])          # B = 1024 over 8 GPUs = the default workload at --gpus 8
 
 
 def ref_flops_per_motion(F=FRAMES, C=NFEATS, n_steps=STEPS_DDIM):
-    """Reference-equivalent FLOPs (flop-counted on the reference modules; CFG x2 included)."""
-    return n_steps * 358.27e6 + (17609728 + 512 * C) * F + 9216 * F * F + 11796480
+    """Reference-equivalent FLOPs (flop-counted on the reference modules; CFG x2 included).  The reference pads
+    every motion of a mixed batch to F = max(lengths) and runs all 5 latent rows, so F is the batch maximum."""
+    return n_steps * DEN_FLOPS_PER_MOTION_STEP + (17609728 + 512 * C) * F + 9216 * F * F + 11796480
 
 
 def executed_flops_per_motion(F=FRAMES, C=NFEATS, n_steps=STEPS_DDIM, T=5):
@@ -58,64 +86,119 @@ def executed_flops_per_motion(F=FRAMES, C=NFEATS, n_steps=STEPS_DDIM, T=5):
     return den + dec
 
 
-def build_pipe(dev, batch):
+def build_pipe(dev, batch=BATCH, cfg=None):
     from test_abi import ABL, DEN_KW, VAE_KW
+    cfg = cfg or CONFIGS["headline"]
     den = LADiffDenoiser(ABL, **DEN_KW)
     den.load_state_dict(syn.denoiser_weights())
-    vae = LADiffVae(ABL, **VAE_KW)
-    vae.load_state_dict(syn.vae_weights(NFEATS))
-    sch = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
-                        clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    vae = LADiffVae(ABL, **{**VAE_KW, "nfeats": cfg["nfeats"]})
+    vae.load_state_dict(syn.vae_weights(cfg["nfeats"]))
+    kw = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False)
+    if cfg["sched"] == "ddpm":
+        sch = DDPMScheduler(variance_type="fixed_small", **kw)                 # configs/modules_novae/scheduler.yaml:16-29
+    else:
+        sch = DDIMScheduler(set_alpha_to_one=False, steps_offset=1, **kw)       # configs/modules/scheduler.yaml:5-14
     return LADIFF(denoiser=den.to(dev).eval(), vae=vae.to(dev).eval(), scheduler=sch, guidance_scale=7.5,
-                  num_inference_timesteps=STEPS_DDIM, eta=0.0)
+                  num_inference_timesteps=max(1, cfg["steps"]), eta=0.0)
 
 
-def dominant_kernel_roofline(dev, stream, precision, summary, launches=400):
-    """Live HIP-event timing of the kernel that dominates the pass (profiles/r1: gemm_kp_kernel<80,64,2,2> / gemm_kr_kernel<80,64,...>, ~36-40 % of the
-    device time): the denoiser's 256->1024 linear (ffn.linear1, GELU) at M = 2*128*5 rows, launched back to back on the
-    bench stream, in the arithmetic of the timed mode."""
-    from ladiff_amd import _lib
-    L = _lib.lib()
-    M, N, K = 2 * BATCH * 5, 1024, 256
-    split = 1 if precision == "bf16x3" else 0
-    A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) / 16; b = torch.randn(N, device=dev)
-    Y = torch.empty(M, N, device=dev)
-    with torch.cuda.stream(stream):
-        if split:
-            As, Ws = torch.empty_like(A), torch.empty_like(W)
-            _lib.check(L.ladiff_split_rows(A.data_ptr(), As.data_ptr(), M, K, stream.cuda_stream))
-            _lib.check(L.ladiff_split_rows(W.data_ptr(), Ws.data_ptr(), N, K, stream.cuda_stream))
-            A, W = As, Ws
-        args = (A.data_ptr(), K, None, 0, K, W.data_ptr(), K, b.data_ptr(), None, 0, None if split else Y.data_ptr(), N, M, N, K,
-                2, split, Y.data_ptr() if split else None, stream.cuda_stream)
-        for _ in range(20):
-            _lib.check(L.ladiff_gemm_resident(*args))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(launches):
-            L.ladiff_gemm_resident(*args)
-        e1.record(stream)
-        torch.cuda.synchronize(dev)
-    us = e0.elapsed_time(e1) * 1e3 / launches
-    flops = 2.0 * M * N * K
-    peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-    mfma_flops = flops * (3 if split else 1)
-    return {"name": ("gemm_kp_kernel<80,64,2,2>" if split else "gemm_kr_kernel<80,64,1,4,16>") + " (ffn.linear1: M=1280, N=1024, K=256, GELU)",
-            "flops_per_launch": flops, "mfma_flops_per_launch": mfma_flops, "us_per_launch": round(us, 2),
-            "achieved": round(flops / us / 1e6, 2), "unit": "TFLOP/s", "peak": peak,
-            "frac": round(flops / us / 1e6 / peak, 4), "mfma_frac": round(mfma_flops / us / 1e6 / peak, 4),
-            **dict(zip(("traffic", "mfma_util_pmc", "share_of_pass", "traffic_source"),
-                       profiled(summary, "gemm_kp_kernel<80, 64" if split else "gemm_kr_kernel<80, 64")))}
+def config_lengths(cfg, n):
+    return syn.mixed_lengths(n) if cfg["lens"] == "mixed" else [cfg["frames"]] * n
+
+
+# ---------------------------------------------------------------------------------------------------------------- the pass
+class Workload:
+    """One rank's share of a GLOBAL synthetic batch (results do not depend on the sharding) and the pass over it:
+    `pipe.sample` (or `vae.decode` for c1) and, when a process group is up, ONE all-gather of the frames.  The bench, the
+    profiling target (scripts/profile_pass.py) and the gloo tests (tests/test_distributed.py, with a mocked `pipe`) all run
+    THIS plumbing."""
+
+    def __init__(self, cfg, dev, rank, world, batch=None, total=None, use_dist=None):
+        self.cfg, self.dev, self.rank, self.world = cfg, dev, rank, world
+        # `batch` prompts per rank (weak scaling, the bench) or `total` prompts over all ranks (uneven shards when it does not divide)
+        self.total = total if total is not None else (batch if batch is not None else cfg["batch"]) * world
+        self.glens = config_lengths(cfg, self.total)          # every rank knows the global lengths: the gather needs no metadata exchange
+        self.lo, self.hi = D.shard_range(self.total, rank, world)
+        self.lens = self.glens[self.lo:self.hi]
+        self.B = self.hi - self.lo
+        self.use_dist = (torch.distributed.is_available() and torch.distributed.is_initialized()) if use_dist is None else use_dist
+        gtext = syn.text_embeddings(self.total)
+        self.text_cpu = torch.cat([gtext[:self.total][self.lo:self.hi], gtext[self.total:][self.lo:self.hi]])
+        self.noise_cpu = syn.init_noise(self.lens, offset=self.lo, total=self.total) if self.B else torch.zeros(0, 5, 256)
+        self.text, self.noise = self.text_cpu.to(dev), self.noise_cpu.to(dev)
+        self.step_noise = None
+        self.z_in = None
+        self.gather_buf = None
+        if cfg["sched"] == "ddpm":
+            # per-step noise of the GLOBAL batch, drawn on the device from one seed and sliced (655 MB per 128 prompts: resident)
+            g = torch.Generator(device=dev) if torch.device(dev).type == "cuda" else torch.Generator()
+            g.manual_seed(syn.DDPM_NOISE_SEED)
+            sn = torch.randn(cfg["steps"], self.total, 5, 256, generator=g, device=dev)
+            self.step_noise = sn[:, self.lo:self.hi].contiguous()
+        if cfg["decode_only"]:
+            z = torch.randn(5, self.total, 256, generator=torch.Generator().manual_seed(syn.NOISE_SEED))
+            for i, m in enumerate(syn.max_iter_elements(self.glens)):
+                z[m:, i] = 0
+            self.z_cpu = z[:, self.lo:self.hi].contiguous()
+            self.z_in = self.z_cpu.to(dev)
+        if self.use_dist:      # all_gather_into_tensor takes equal shards: world x the largest shard (uneven totals are trimmed by gather_feats)
+            bmax = max(hi - lo for lo, hi in (D.shard_range(self.total, r, world) for r in range(world)))
+            self.gather_buf = torch.empty(world * bmax, max(self.glens), cfg["nfeats"], device=dev)
+
+    def one_pass(self, pipe):
+        if self.cfg["decode_only"]:
+            feats = pipe.vae.decode(self.z_in, self.lens)
+        else:
+            _, feats = pipe.sample(self.text, self.lens, init_noise=self.noise, step_noise=self.step_noise)
+        if self.use_dist:      # final gather of the decoded frames (RCCL over xGMI); also exercised at world size 1 under torchrun
+            feats = D.gather_feats(feats, self.total, self.world, out=self.gather_buf, lengths=self.glens)
+        return feats
+
+    def local_rows(self, feats):
+        return feats[self.lo:self.hi] if self.use_dist else feats
+
+    def oracle_check(self, feats, n_prompts):
+        """A few of THIS rank's prompts through the CPU oracle (outside any timing): max |frames - oracle|."""
+        from oracle import ladiff_oracle as orc
+        cfg, B = self.cfg, self.B
+        idx = sorted({0, B // 3, (2 * B) // 3, B - 1})[:n_prompts]
+        sub_lens = [self.lens[i] for i in idx]
+        vae_sd = syn.vae_weights(cfg["nfeats"])
+        with torch.no_grad():
+            if cfg["decode_only"]:
+                f_o = orc.vae_decode(vae_sd, self.z_cpu[:, idx], sub_lens)
+            else:
+                sub_text = torch.cat([self.text_cpu[:B][idx], self.text_cpu[B:][idx]])
+                sn = None if self.step_noise is None else self.step_noise[:, idx].cpu().contiguous()
+                _, f_o = orc.sample_motions(syn.denoiser_weights(), vae_sd, sub_text, sub_lens, self.noise_cpu[idx], cfg["steps"],
+                                            cfg["sched"], step_noise=sn)
+        mine = self.local_rows(feats).cpu()
+        err = 0.0
+        for j, i in enumerate(idx):
+            l = self.lens[i]
+            err = max(err, (mine[i, :l].double() - f_o[j, :l].double()).abs().max().item())
+        return err, idx
+
+
+# ---------------------------------------------------------------------------------------------------------------- profiles
+def csrc_hash():
+    """Content hash of the kernel sources: what a profile summary was taken at, independent of git (the GPU box has no .git)."""
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "ladiff_amd", "csrc", "*.h*")) + [os.path.join(ROOT, "include", "ladiff_hip.h")]):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def profile_summary():
     """profiles/rN/summary.json of the newest round that has one (written by scripts/pmc_summary.py)."""
-    import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "summary.json")), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
             d["_path"] = os.path.relpath(path, ROOT)
+            d["_stale"] = d.get("csrc_hash") != csrc_hash()
             return d
         except Exception:
             continue
@@ -135,54 +218,98 @@ def profiled(summary, kernel_key):
     return None, None, None, f"{summary['_path']} has no kernel matching {kernel_key!r}"
 
 
-def pipeline_kernel_roofline(pipe, loop_ms_samples, summary):
-    """The persistent pipeline kernel: one launch = 50 guided steps on the rank's 128 prompts."""
-    ms = sorted(loop_ms_samples)[len(loop_ms_samples) // 2]
-    flops = BATCH * STEPS_DDIM * 358.27e6                      # reference-equivalent (guidance x2 included), SURVEY.md §8d
+def recorded_cpu_baseline(config_name):
+    """The cpu_baseline of the newest N = 1 line of this config committed under profiles/ (for N > 1 lines: the oracle is timed
+    on rank 0 at N = 1 only)."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"bench_{config_name}*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.loads(f.readline())
+            if d.get("n_gpus") == 1 and "cpu_baseline" in d:
+                cb = dict(d["cpu_baseline"])
+                cb.pop("gpu_over_cpu", None)
+                cb["measured_in_this_run"] = False
+                cb["source"] = os.path.relpath(path, ROOT) + " (N = 1 run)"
+                return cb
+        except Exception:
+            continue
+    return {"value": None, "unit": "motions/s", "cores": None, "kind": "port", "measured_in_this_run": False,
+            "sample": "measured on rank 0 at N = 1 only: no N = 1 line of this config under profiles/ in this tree"}
+
+
+def pipeline_kernel_roofline(B, steps_per_launch, ms_per_launch, launches, precision, summary, desc):
+    """The persistent pipeline kernel: one launch = `steps_per_launch` guided steps on the rank's B prompts."""
+    flops = B * steps_per_launch * DEN_FLOPS_PER_MOTION_STEP             # reference-equivalent (guidance x2 included), SURVEY.md §8d
     per_row_layer = 2 * 256 * (768 + 256 + 2048 + 256 + 2048 + 256)
-    mfma_flops = 3.0 * BATCH * STEPS_DDIM * 2 * 5 * (9 * per_row_layer + 4 * 2 * 512 * 256)     # executed, 3 bf16 MFMAs per product
+    mult = 3.0 if precision == "bf16x3" else 1.0                         # executed MFMAs per product
+    mfma_flops = mult * B * steps_per_launch * 2 * 5 * (9 * per_row_layer + 4 * 2 * 512 * 256)
+    peak = PEAK_BF16_MFMA_TFLOPS if precision == "bf16x3" else PEAK_F32_MFMA_TFLOPS
     traffic, util, share, src = profiled(summary, "systolic_loop_kernel")
-    return {"bound": "mfma", "achieved": round(flops / ms / 1e9, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(flops / ms / 1e9 / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": traffic,
-            "kernel": "systolic_loop_kernel (all 50 guided DDIM steps of 128 prompts in one persistent launch; the profiled instantiation is named in traffic_source)",
-            "us_per_launch": round(ms * 1e3, 1), "flops_per_launch": flops, "mfma_flops_per_launch": mfma_flops,
-            "mfma_frac": round(mfma_flops / ms / 1e9 / PEAK_BF16_MFMA_TFLOPS, 4), "mfma_util_pmc": util, "share_of_pass": share,
-            "traffic_source": src}
+    profiled_matches = desc.get("profiled_workload", True) and precision == "bf16x3"
+    return {"bound": "mfma", "achieved": round(flops / ms_per_launch / 1e9, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(flops / ms_per_launch / 1e9 / peak, 4), "traffic": traffic if profiled_matches else None,
+            "kernel": f"systolic_loop_kernel ({steps_per_launch} guided steps of {B} prompts in one persistent launch, {launches} launch(es) per pass; "
+                      "the profiled instantiation is named in traffic_source)",
+            "us_per_launch": round(ms_per_launch * 1e3, 1), "launches_per_pass": launches, "flops_per_launch": flops,
+            "mfma_flops_per_launch": mfma_flops, "mfma_frac": round(mfma_flops / ms_per_launch / 1e9 / peak, 4),
+            "mfma_util_pmc": util if profiled_matches else None, "share_of_pass": share if profiled_matches else None,
+            "traffic_source": src if profiled_matches else "profiles hold the default workload in bf16x3 mode only",
+            "traffic_source_stale": (summary or {}).get("_stale") if profiled_matches else None}
 
 
-def cpu_baseline(sample_b):
-    """Oracle on the host cores, bounded sample: `sample_b` motions of the same shape (196 frames, 50 steps)."""
+def cpu_baseline(cfg, sample_b):
+    """Oracle on the host cores, bounded sample: `sample_b` motions of the config's shape."""
     from oracle import ladiff_oracle as orc
-    lens = [FRAMES] * sample_b
+    lens = config_lengths(cfg, sample_b)
     # the reference path is a chain of small fp32 ops: it stops scaling (and then slows down) beyond ~16 threads
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     text, noise = syn.text_embeddings(sample_b), syn.init_noise(lens)
-    den_sd, vae_sd = syn.denoiser_weights(), syn.vae_weights(NFEATS)
+    den_sd, vae_sd = syn.denoiser_weights(), syn.vae_weights(cfg["nfeats"])
     with torch.no_grad():
-        warm = torch.cat([text[:2], text[sample_b:sample_b + 2]])
-        orc.sample_motions(den_sd, vae_sd, warm, lens[:2], noise[:2], 2, "ddim")   # warm-up (threads, allocator)
-        t0 = time.perf_counter()
-        orc.sample_motions(den_sd, vae_sd, text, lens, noise, STEPS_DDIM, "ddim")
-        dt = time.perf_counter() - t0
+        if cfg["decode_only"]:
+            z = torch.randn(5, sample_b, 256, generator=torch.Generator().manual_seed(1))
+            orc.vae_decode(vae_sd, z[:, :2], lens[:2])
+            reps = 0
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 10.0:
+                orc.vae_decode(vae_sd, z, lens)
+                reps += 1
+            dt = (time.perf_counter() - t0) / reps
+            what = f"{sample_b} motions, {cfg['frames']} frames, decode only, {reps} repetitions"
+        else:
+            sn = syn.ddpm_noise(cfg["steps"], sample_b) if cfg["sched"] == "ddpm" else None
+            warm = torch.cat([text[:2], text[sample_b:sample_b + 2]])
+            orc.sample_motions(den_sd, vae_sd, warm, lens[:2], noise[:2], 2, "ddim")   # warm-up (threads, allocator)
+            t0 = time.perf_counter()
+            orc.sample_motions(den_sd, vae_sd, text, lens, noise, cfg["steps"], cfg["sched"], step_noise=sn)
+            dt = time.perf_counter() - t0
+            what = f"{sample_b} motions, lengths {sorted(set(lens))}, {cfg['steps']}-step {cfg['sched'].upper()} + decode"
     return {"value": sample_b / dt, "unit": "motions/s", "cores": torch.get_num_threads(), "kind": "port",
-            "host_cpus": os.cpu_count(),
-            "sample": f"{sample_b} motions, 196 frames, 50-step DDIM + decode, fp32 PyTorch CPU oracle, {dt:.1f} s"}
+            "host_cpus": os.cpu_count(), "measured_in_this_run": True,
+            "sample": f"{what}, fp32 PyTorch CPU oracle, {dt:.1f} s"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=BATCH, help="prompts per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=32, help="motions in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--steps", type=int, default=None, help="timed passes (default 10; 3 for c3)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed passes (default 3; 1 for c3)")
+    ap.add_argument("--config", default="headline", choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration (default: the headline metric's workload = c4's per-rank slice)")
+    ap.add_argument("--batch", type=int, default=None, help="prompts per GPU (default: the config's)")
+    ap.add_argument("--cpu-sample", type=int, default=None, help="motions in the CPU-baseline sample (0 = skip; default per config)")
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
                     help="matrix-product arithmetic of the timed mode (DESIGN.md §1); the other mode is timed after it. "
                          "BASELINE.json's 'bf16' (config c2) and 'fp16' (c5) labels are served by bf16x3: plain bf16 / fp16 operands "
                          "miss the 1e-3 decoded-frame gate by 50x / 7x on this network (DESIGN.md §1), three bf16 MFMAs per product do not")
     ap.add_argument("--loop", default="pipeline", choices=["pipeline", "launches"],
-                    help="bf16x3 mode: the 50 steps as one persistent pipeline kernel (default) or as hipGraph replays of one launch per stage")
+                    help="the guided steps as one persistent pipeline kernel (default) or as hipGraph replays of one launch per stage")
+    ap.add_argument("--no-other-mode", action="store_true", help="skip the second arithmetic mode")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    long_run = cfg["steps"] >= 200
+    steps = args.steps if args.steps is not None else (3 if long_run else 10)
+    warmup = args.warmup if args.warmup is not None else (1 if long_run else 3)
 
     # the JSON line must be the ONLY thing on stdout: RCCL prints a version banner to fd 1 when the process group comes
     # up, so everything but the final line goes to stderr
@@ -199,26 +326,12 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    B = args.batch
-    total = B * world
-    lens = [FRAMES] * B
-    glens = [FRAMES] * total          # every rank knows the global lengths: the gather needs no metadata exchange
-    # global inputs, sliced per rank: results do not depend on the sharding
-    lo, hi = D.shard_range(total, rank, world)
-    gtext = syn.text_embeddings(total)
-    text = torch.cat([gtext[:total][lo:hi], gtext[total:][lo:hi]]).to(dev)
-    noise = syn.init_noise(lens, offset=lo, total=total).to(dev)
-    pipe = build_pipe(dev, B)
+    wl = Workload(cfg, dev, rank, world, batch=args.batch)
+    B, total = wl.B, wl.total
+    F, C, n_steps = max(wl.glens), cfg["nfeats"], cfg["steps"]
+    pipe = build_pipe(dev, B, cfg)
     pipe.loop = args.loop
-    gather_buf = torch.empty(total, FRAMES, NFEATS, device=dev) if use_dist else None
-
     stream = torch.cuda.Stream(device=dev)        # hipGraph capture needs a non-null stream; events go on it too
-
-    def one_pass():
-        z, feats = pipe.sample(text, lens, init_noise=noise)
-        if use_dist:      # final gather of the decoded frames (RCCL over xGMI); also exercised at world size 1 under torchrun
-            feats = D.gather_feats(feats, total, world, out=gather_buf, lengths=glens)
-        return feats
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -226,101 +339,149 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed(precision, steps, warmup):
-        """W warm-up passes, then exactly K passes between fences; returns (max-over-ranks wall s, device ms, frames)."""
+    def timed(precision, k, w):
+        """w warm-up passes, then exactly k passes between fences; returns (max-over-ranks wall s, device ms, last frames,
+        warm-up frames)."""
         pipe.precision = precision
         with torch.cuda.stream(stream), torch.no_grad():
-            for _ in range(warmup):
-                one_pass()
+            warm = None
+            for _ in range(w):
+                warm = wl.one_pass(pipe)
+            warm = None if warm is None else warm.clone()
             fence()
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
             ev0.record(stream)
-            for _ in range(steps):
-                feats = one_pass()
+            for _ in range(k):
+                feats = wl.one_pass(pipe)
             ev1.record(stream)
             fence()
             wall = time.perf_counter() - t0
         tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
         if use_dist:
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        return float(tmax.item()), ev0.elapsed_time(ev1), feats.clone()
+        return float(tmax.item()), ev0.elapsed_time(ev1), feats.clone(), warm
 
-    wall, dev_ms, feats = timed(args.precision, args.steps, args.warmup)
+    wall, dev_ms, feats, warm = timed(args.precision, steps, warmup)
+    # ---- checks, outside the timed region
+    if not cfg["decode_only"]:
+        pipe.check()                                   # raises when the pipeline loop of the last pass was abandoned
     assert torch.isfinite(feats).all()
+    identical = None if warm is None else bool(torch.equal(feats, warm))
+    if identical is False:
+        raise SystemExit("the last timed pass differs from the warm-up pass: the path is not deterministic")
     # device time of the N-step loop alone (HIP events around it on the bench stream), sampled outside the timed region
-    loop_ms = []
-    with torch.cuda.stream(stream), torch.no_grad():
-        for _ in range(5):
-            one_pass()
-            loop_ms.append(pipe.loop_ms())
-    status = pipe.loop_status()
-    if status[0] != 0:
-        raise SystemExit(f"pipeline loop aborted: status {status}")
+    loop_ms, win = [], None
+    pipelined, rows_per_block, n_blocks = False, 0, 0
+    if not cfg["decode_only"]:
+        with torch.cuda.stream(stream), torch.no_grad():
+            for _ in range(2 if long_run else 5):
+                wl.one_pass(pipe)
+                loop_ms.append(pipe.loop_ms())
+            pipelined, rows_per_block, n_blocks = pipe.last_loop()
+            if long_run:                               # per-window event pairs: what the table rebuilds between windows cost
+                pipe.window_ms(enable=True)
+                wl.one_pass(pipe)
+                total_ms = pipe.loop_ms()
+                win = pipe.window_ms() + (total_ms,)
+                pipe.window_ms(enable=False)
+        status = pipe.loop_status()
+        if status[0] != 0:
+            raise SystemExit(f"pipeline loop aborted: status {status}")
+    oracle_err, oracle_idx = wl.oracle_check(feats, 2 if long_run else 4) if rank == 0 else (None, None)
+    if oracle_err is not None and not oracle_err < FRAME_TOL:
+        raise SystemExit(f"decoded frames differ from the CPU oracle by {oracle_err:.3e} (gate {FRAME_TOL})")
     other = "fp32" if args.precision == "bf16x3" else "bf16x3"
-    o_wall, o_dev_ms, o_feats = timed(other, max(2, args.steps // 2), 1)        # second mode: shorter, reported beside
-    mode_diff = (feats - o_feats).abs().max().item()
+    o = None
+    if not args.no_other_mode:
+        o_steps = max(1 if long_run else 2, steps // 2)
+        o_wall, o_dev_ms, o_feats, _ = timed(other, o_steps, 1)        # second mode: shorter, reported beside
+        if not cfg["decode_only"]:
+            pipe.check()
+        o = (o_steps, o_wall, o_dev_ms, (feats - o_feats).abs().max().item())
 
     if rank == 0:
         summary = profile_summary()
-        motions_per_s = total * args.steps / wall
-        dev_s_per_pass = dev_ms / 1e3 / args.steps
-        ref_tf = B * ref_flops_per_motion() / dev_s_per_pass / 1e12
-        exe_tf = B * executed_flops_per_motion() / dev_s_per_pass / 1e12
+        motions_per_s = total * steps / wall
+        dev_s_per_pass = dev_ms / 1e3 / steps
+        ref_f = ref_flops_per_motion(F, C, n_steps)
+        exe_f = executed_flops_per_motion(F, C, n_steps)
+        ref_tf = B * ref_f / dev_s_per_pass / 1e12
+        exe_tf = B * exe_f / dev_s_per_pass / 1e12
         peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
-        pipelined = args.precision == "bf16x3" and pipe.loop != "launches"
+        is_default = args.config in ("headline", "c4") and B == BATCH and args.precision == "bf16x3"
         whole_traffic = None
-        if summary is not None and args.precision == "bf16x3":
+        if summary is not None and is_default:
             wp = summary.get("whole_pass", {})
             if "fetch_bytes_per_pass" in wp:
                 whole_traffic = wp["fetch_bytes_per_pass"] + wp["write_bytes_per_pass"]
+        loop_desc = ("LA-VAE decode only" if cfg["decode_only"] else
+                     (f"persistent pipeline kernel ({rows_per_block}-row blocks x {n_blocks})" if pipelined else "hipGraph steps, one launch per stage"))
         whole = {"bound": "mfma", "achieved": round(ref_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ref_tf / peak, 4),
-                 "kernel": "whole pass (" + ("pipeline loop kernel" if pipelined else "hipGraph steps x50") + " + decode)",
-                 "device_ms_per_pass": round(dev_ms / args.steps, 3),
-                 "flops_per_motion_reference_equivalent": ref_flops_per_motion(),
+                 "kernel": f"whole pass ({loop_desc}" + ("" if cfg["decode_only"] else " + decode") + ")",
+                 "device_ms_per_pass": round(dev_ms / steps, 3),
+                 "flops_per_motion_reference_equivalent": ref_f,
                  "executed_tflops": round(exe_tf, 2),
                  "executed_frac": round(exe_tf * (1 if args.precision == "fp32" else 3) / peak, 4),
                  "traffic": whole_traffic,
                  "traffic_source": (summary["_path"] + f" (commit {summary.get('git_sha', '?')})") if whole_traffic is not None else None,
-                 "mfma_util_pmc": summary.get("whole_pass", {}).get("mfma_util_pmc") if (summary and args.precision == "bf16x3") else None,
+                 "traffic_source_stale": summary.get("_stale") if whole_traffic is not None else None,
+                 "mfma_util_pmc": summary.get("whole_pass", {}).get("mfma_util_pmc") if (summary and is_default) else None,
                  "peak_note": "fp32-input MFMA 157.3 TF/s" if args.precision == "fp32" else
                  "bf16 MFMA 2500 TF/s dense; every fp32-equivalent product costs 3 bf16 MFMAs (833 TF/s fp32-equivalent)"}
         line = {
-            "metric": "motions/sec (196-frame, 50-step DDIM, bs128)", "value": round(motions_per_s, 2),
-            "unit": "motions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(wall / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "metric": cfg["metric"], "value": round(motions_per_s, 2),
+            "unit": "motions/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(wall / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16x3+f32", "data": "synthetic",
-            "config": {"workload": f"ddim50_cfg7.5_b{B}_f{FRAMES}_c{NFEATS}_humanml3d", "prompts_per_gpu": B,
-                       "global_batch": total, "frames": FRAMES, "ddim_steps": STEPS_DDIM, "parallelism": f"dp{world}",
-                       "loop": "persistent pipeline kernel (one launch for the 50 steps)" if pipelined else "hipGraph, 10 steps per replay"},
+            "config": {"workload": f"{args.config}:{cfg['tag']}_b{B}_f{F}_c{C}_{'kit' if C == 251 else 'humanml3d'}", "baseline_config": args.config,
+                       "prompts_per_gpu": B, "global_batch": total, "frames": F, "lengths": sorted(set(wl.glens)),
+                       "scheduler": cfg["sched"], "denoising_steps": n_steps, "parallelism": f"dp{world}", "loop": loop_desc},
             "roofline": whole,
         }
-        o_steps = max(2, args.steps // 2)
-        o_tf = B * ref_flops_per_motion() / (o_dev_ms / 1e3 / o_steps) / 1e12
-        o_peak = PEAK_F32_MFMA_TFLOPS if other == "fp32" else PEAK_BF16_MFMA_TFLOPS
-        line["other_mode"] = {"precision": other, "value": round(total * o_steps / o_wall, 2), "unit": "motions/s",
-                              "ms_per_step": round(o_wall / o_steps * 1e3, 3), "roofline_achieved_tflops": round(o_tf, 2),
-                              "roofline_peak": o_peak, "roofline_frac": round(o_tf / o_peak, 4)}
-        line["parity"] = {"max_abs_diff_frames_between_modes": mode_diff, "tolerance": 1e-3,
-                          "note": "fp32 mode is within 1e-4 of the reference goldens, bf16x3 within 5e-4 (tests/test_gpu_path.py)"}
-        if world == 1:
-            # the contract's `roofline` describes the DOMINANT KERNEL (algorithmic FLOPs of one launch / its live HIP-event
-            # duration); the whole-pass figures computed above move under roofline.whole_pass
-            if pipelined:
-                dk = pipeline_kernel_roofline(pipe, loop_ms, summary)
-            else:
-                d = dominant_kernel_roofline(dev, stream, args.precision, summary)
-                dk = {"bound": "mfma", "achieved": d["achieved"], "peak": d["peak"], "unit": "TFLOP/s", "frac": d["frac"],
-                      "traffic": d["traffic"], "kernel": d["name"], "us_per_launch": d["us_per_launch"],
-                      "flops_per_launch": d["flops_per_launch"], "mfma_flops_per_launch": d["mfma_flops_per_launch"],
-                      "mfma_frac": d["mfma_frac"], "mfma_util_pmc": d["mfma_util_pmc"], "share_of_pass": d["share_of_pass"],
-                      "traffic_source": d["traffic_source"]}
+        if o is not None:
+            o_steps, o_wall, o_dev_ms, mode_diff = o
+            o_tf = B * ref_f / (o_dev_ms / 1e3 / o_steps) / 1e12
+            o_peak = PEAK_F32_MFMA_TFLOPS if other == "fp32" else PEAK_BF16_MFMA_TFLOPS
+            line["other_mode"] = {"precision": other, "value": round(total * o_steps / o_wall, 2), "unit": "motions/s",
+                                  "ms_per_step": round(o_wall / o_steps * 1e3, 3), "roofline_achieved_tflops": round(o_tf, 2),
+                                  "roofline_peak": o_peak, "roofline_frac": round(o_tf / o_peak, 4),
+                                  "roofline_note": "reference-equivalent FLOPs (SURVEY.md §8d), not executed FLOPs"}
+        line["parity"] = {"max_abs_diff_frames_vs_oracle": oracle_err, "oracle_prompts": oracle_idx, "tolerance": FRAME_TOL,
+                          "timed_pass_equals_warmup_pass": identical,
+                          "max_abs_diff_frames_between_modes": o[3] if o is not None else None,
+                          "note": "prompts of the timed batch against the CPU oracle, computed after the timed region; "
+                                  "fp32 mode is within 1e-4 of the reference goldens, bf16x3 within 5e-4 (tests/test_gpu_path.py)"}
+        # the contract's `roofline` describes the DOMINANT KERNEL (algorithmic FLOPs of one launch / its live HIP-event
+        # duration) of rank 0; the whole-pass figures computed above move under roofline.whole_pass
+        if pipelined:
+            ms = sorted(loop_ms)[len(loop_ms) // 2]
+            launches = 1
+            steps_per_launch = n_steps
+            if win is not None and win[1] > 0:
+                ksum, nwin, tot = win
+                launches, steps_per_launch, ms = nwin, n_steps // nwin, ksum / nwin
+            dk = pipeline_kernel_roofline(B, steps_per_launch, ms, launches, args.precision, summary, {"profiled_workload": is_default})
+            if win is not None and win[1] > 1:
+                ksum, nwin, tot = win
+                noise_bytes = n_steps * B * 5 * 256 * 4
+                dk["windows"] = {"n": nwin, "steps_per_window": n_steps // nwin, "loop_kernel_ms_per_window": round(ksum / nwin, 3),
+                                 "table_rebuild_ms_between_windows": round((tot - ksum) / (nwin - 1), 4),
+                                 "loop_ms_total": round(tot, 3),
+                                 "noise_stream_GBps": round(noise_bytes / (tot / 1e3) / 1e9, 2),
+                                 "noise_bytes_per_pass": noise_bytes}
             dk["peak_note"] = whole["peak_note"]
             dk["whole_pass"] = whole
             line["roofline"] = dk
-        if world == 1 and args.cpu_sample > 0:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
-            line["cpu_baseline"]["gpu_over_cpu"] = round(motions_per_s / line["cpu_baseline"]["value"], 1)
+        if world == 1:
+            sample = args.cpu_sample
+            if sample is None:
+                sample = {"c1": 8, "c3": 2}.get(args.config, 32)
+            if sample > 0:
+                line["cpu_baseline"] = cpu_baseline(cfg, sample)
+                line["cpu_baseline"]["gpu_over_cpu"] = round(motions_per_s / line["cpu_baseline"]["value"], 1)
+        else:
+            line["cpu_baseline"] = recorded_cpu_baseline(args.config)
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
         torch.distributed.barrier()

@@ -11,10 +11,23 @@
  *   - extern "C", plain pointers and sizes only; no torch / C++ types.
  *   - every pointer is a DEVICE pointer (fp32 unless typed otherwise) except those named h_*.
  *   - return 0 = ok, < 0 = argument / shape / workspace error (LADIFF_ERR_*), > 0 = hipError_t.
- *   - nothing allocates, frees or synchronises: work is enqueued on the given stream, scratch comes
- *     from the caller's workspace (size from the *_workspace_bytes query), so every call is
- *     hipGraph-capturable.  Calls are re-entrant across distinct (workspace, stream) pairs.
- *   - tensors are dense row-major; the arithmetic type is fp32 (fp32-input MFMA, fp32 accumulate).
+ *   - work is enqueued on the given stream and scratch comes from the caller's workspace (size from the
+ *     *_workspace_bytes query).  The unit kernels, the denoiser / decoder / encoder / CLIP / evaluator entries and
+ *     ladiff_diffusion_reverse with sampler == NULL neither allocate, free nor synchronise and are hipGraph-capturable;
+ *     calls are re-entrant across distinct (workspace, stream) pairs.  EXCEPTIONS, each stated again at the entry:
+ *       ladiff_diffusion_reverse with a sampler  instantiates hipGraphs and creates two events on first use; when its capture
+ *                                    key changes it calls hipStreamSynchronize(stream) before destroying the old graphs and after
+ *                                    uploading a new stage table; it is NOT capturable itself (it captures); a pipeline launch
+ *                                    takes a process-wide mutex and chains through one event per device, so that two pipeline
+ *                                    kernels (which each need every CU) never share the GPU
+ *       ladiff_sampler_destroy       hipDeviceSynchronize
+ *       ladiff_sampler_loop_ms       hipEventSynchronize on the loop's end event
+ *       ladiff_reverse_status        blocking hipMemcpy (use ladiff_reverse_status_offset_bytes + an async copy to poll)
+ *       the first pipeline launch on a device  runs a probe kernel on a private stream (hipMalloc / hipFree / stream create)
+ *   - tensors are dense row-major fp32.  Arithmetic: w_split == NULL -> fp32-input MFMA, fp32 accumulate (bit-exact fp32
+ *     fma chains); w_split != NULL (and ladiff_gemm_split / ladiff_self_attention_bf16x3 / split = 1) -> "bf16x3": operands as
+ *     bf16 hi + lo pairs, three bf16 MFMAs per product, fp32 accumulate; softmax, LayerNorm statistics, guidance and the
+ *     scheduler are fp32 in both.
  *   - weights are passed as an array of device pointers, one per state-dict tensor, in the order
  *     given by ladiff_{denoiser,decoder}_param_name(i) (names = the reference's state-dict keys,
  *     SURVEY.md Appendix A).
@@ -43,7 +56,7 @@ enum {
 enum { LADIFF_ACT_NONE = 0, LADIFF_ACT_RELU = 1, LADIFF_ACT_GELU = 2, LADIFF_ACT_SILU = 3, LADIFF_ACT_QGELU = 4 /* x*sigmoid(1.702x) */,
        LADIFF_ACT_LRELU = 5 /* LeakyReLU(0.2) */ };
 
-#define LADIFF_ABI_VERSION 2
+#define LADIFF_ABI_VERSION 3
 #define LADIFF_LATENT_DIM 256     /* model.latent_dim[-1], config_ladiff_humanml3d.yaml:132 */
 #define LADIFF_NUM_HEADS 4        /* configs/modules/denoiser.yaml:7 */
 #define LADIFF_NUM_LAYERS 9       /* configs/modules/denoiser.yaml:6, motion_vae.yaml:5 */
@@ -187,7 +200,8 @@ int ladiff_advance_step(int32_t* d_step, ladiff_stream_t stream);
 /* latents[B,T,256] = noise * valid * sigma  (ladiff.py:380-390, :407) */
 int ladiff_init_latents(const float* noise, const int32_t* counts, float init_noise_sigma, float* latents,
                         int B, int T, ladiff_stream_t stream);
-/* z[T,B,256] = permute(latents) with rows >= counts[b] zeroed  (ladiff.py:500, :562-566) */
+/* z[T,B,256] = permute(latents) with rows >= counts[b] zeroed  (ladiff.py:500, :562-566).  (Inside
+ * ladiff_diffusion_reverse the same kernel also reads the pipeline's abort word and writes NaN when the loop was abandoned.) */
 int ladiff_finalize_latents(const float* latents, const int32_t* counts, float* z, int B, int T,
                             ladiff_stream_t stream);
 
@@ -207,7 +221,11 @@ int ladiff_finalize_latents(const float* latents, const int32_t* counts, float* 
  *                latent count so that padded latent rows are not computed at all (they never influence valid rows: masked as
  *                keys, every other op is per row, and the final zeroing removes them)
  * reuse_time_tables = 1 tells the call that `ws` still holds the time tables of a previous call with the same weights
- * and schedule. */
+ * and schedule.
+ * Synchronisation / allocation: with sampler == NULL the call only enqueues.  With a sampler it instantiates graphs and creates
+ * events on first use, calls hipStreamSynchronize(stream) whenever its capture key changes (before the old graphs are destroyed,
+ * after a new stage table is uploaded, before a changed block plan replaces the previous host copy), and a pipeline launch takes
+ * a process-wide mutex and waits (on the stream, not the host) for the previous pipeline launch of the device. */
 int ladiff_sampler_create(void** sampler);
 int ladiff_sampler_destroy(void* sampler);
 /* How a sampler runs the N steps: 1 (default) = ONE persistent pipeline kernel for the whole loop when the call qualifies
@@ -234,10 +252,28 @@ int ladiff_reverse_plan(int B, int T, const int32_t* h_counts, int masked, int l
 /* Device time of the N-step loop of the sampler's last call (HIP events recorded on the call's stream right around the
  * pipeline kernel, or around the graph replays); blocks until it has finished.  Measurement aid (bench.py). */
 int ladiff_sampler_loop_ms(void* sampler, float* ms);
-/* Blocking read of the pipeline kernel's status word of the last call in this workspace: code 0 = completed,
- * 2 = a stage timed out waiting for its producer (info = workgroup); code 0 with info -1 = completed, but the workgroups
- * were not on the XCDs the plan assumed and every hand-off was written through (slower, same results).  Debug / test aid. */
+/* Measurement aids (bench.py --config c3).  A schedule longer than 64 steps runs as several windows (the hoisted cross-attention
+ * table is rebuilt per window, the latents carry over): with window timing on, every window's loop launches are bracketed by
+ * their own event pair, and ladiff_sampler_window_ms returns their sum and count for the last call (blocks until they have
+ * completed) - ladiff_sampler_loop_ms minus that sum is what the table rebuilds between the windows cost.
+ * ladiff_sampler_last_loop: whether the last call ran the persistent pipeline kernel (1) or launch-per-stage graphs (0), and
+ * the pipeline's block plan (rows per block, blocks; 0 otherwise). */
+int ladiff_sampler_set_window_timing(void* sampler, int on);
+int ladiff_sampler_window_ms(void* sampler, float* loop_ms_sum, int* n_windows);
+int ladiff_sampler_last_loop(void* sampler, int* pipeline, int* rows_per_block, int* n_blocks);
+/* Blocking read (hipMemcpy: synchronises the device) of the pipeline kernel's status words of the last call in this workspace:
+ * code 0 = completed, 2 = a stage timed out waiting for its producer (info = workgroup) - the loop was abandoned, every later
+ * window of the call ended at once and z was filled with NaN; code 0 with info -1 = completed, but the workgroups were not on
+ * the XCDs the plan assumed and every hand-off was written through (slower, same results).  The words are cleared once per
+ * ladiff_diffusion_reverse call and are sticky over its windows; loop forms other than the pipeline leave them at 0. */
 int ladiff_reverse_status(void* ws, int B, int T, int n_steps, int n_text, int* code, int* info);
+/* Where those two uint32 words {code, info} live: byte offset from the workspace base (0 = bad arguments).  A caller that must
+ * not block copies the 8 bytes to pinned host memory with an async copy on the call's stream and reads them once an event
+ * recorded behind the copy has completed (ladiff_amd/pipeline.py does, and raises / re-runs the call launch-per-stage). */
+size_t ladiff_reverse_status_offset_bytes(int B, int T, int n_steps, int n_text);
+/* Test aid (process-wide): workgroup >= 0 makes that pipeline workgroup leave right after the start-up handshake of every
+ * launch, so that its consumers time out (-1: off); timeout_ms > 0 replaces the 1.5 s bound of every wait (0: default). */
+int ladiff_debug_set_pipeline_fault(int workgroup, int timeout_ms);
 size_t ladiff_reverse_workspace_bytes(int B, int T, int n_steps, int n_text);
 int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* const* w_split /*or NULL*/,
                              uint64_t weights_generation, const float* text_emb /*[2B or B,n_text,768]*/,

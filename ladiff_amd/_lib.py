@@ -65,7 +65,12 @@ _SIGNATURES = {
     "ladiff_sampler_destroy": (c_int, [c_void_p]),
     "ladiff_sampler_set_loop": (c_int, [c_void_p, c_int]),
     "ladiff_sampler_loop_ms": (c_int, [c_void_p, ctypes.POINTER(c_float)]),
+    "ladiff_sampler_set_window_timing": (c_int, [c_void_p, c_int]),
+    "ladiff_sampler_window_ms": (c_int, [c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int)]),
+    "ladiff_sampler_last_loop": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "ladiff_reverse_status": (c_int, [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "ladiff_reverse_status_offset_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "ladiff_debug_set_pipeline_fault": (c_int, [c_int, c_int]),
     "ladiff_reverse_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ladiff_diffusion_reverse": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_int, c_int,

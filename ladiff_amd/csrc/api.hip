@@ -28,7 +28,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct ReverseWs {
     float *tables, *cache, *latents, *eps, *fwd, *sys, *cws;
     int32_t* d_step;
-    size_t fwd_floats, cws_floats, total_bytes;
+    size_t fwd_floats, cws_floats, total_bytes, sys_off;      // sys_off: floats from the workspace base to `sys`
     int window;                            // steps whose c-table rows are resident at a time
 };
 // The hoisted cross-attention table is [9][steps][2B+1][256] floats: 118 MB for 50 steps at B = 128, but 2.4 GB for a
@@ -58,6 +58,7 @@ ReverseWs carve_reverse(void* ws, int B, int T, int n, int ntxt = 1) {
     r.fwd_floats = den_forward_ws_floats(B2, T);
     if (pre > r.fwd_floats) r.fwd_floats = pre;
     r.fwd = take(r.fwd_floats);
+    r.sys_off = off;
     r.sys = take(sys_ws_floats(B, T));                                 // block buffers, flags and stage table of the pipeline loop
     r.cws_floats = (size_t)NL * r.window * (B2 + 1) * D;               // scratch of the c-table builder (all layers' input rows)
     r.cws = take(r.cws_floats);
@@ -75,6 +76,10 @@ struct Sampler {
     int loop = 1;                         // 1: persistent pipeline kernel when the call qualifies (systolic.hip), 0: launch per stage
     std::vector<unsigned char> stages;    // host copy of the pipeline's stage table (source of the upload)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // bracket the N-step loop (pipeline kernel or graph replays) of the last call
+    bool time_windows = false;            // measurement aid: one event pair per window of the schedule (ladiff_sampler_set_window_timing)
+    std::vector<hipEvent_t> wev;          // [2 i], [2 i + 1]: around the loop launches of window i of the last call
+    int n_windows = 0;
+    int last_pipeline = 0;                // the last call ran the persistent pipeline kernel (1) or launch-per-stage graphs (0)
     // capture key: a graph bakes pointers, shapes and scalars into its kernel nodes.  The weight tables are identified by
     // a hash over EVERY pointer of both tables plus the caller's generation id (bumped whenever a table is rebuilt), not
     // by the address of the host array (which a rebuilt table can land on again).
@@ -290,6 +295,7 @@ int ladiff_sampler_destroy(void* sampler) {
     if (sp->setup) (void)hipGraphExecDestroy(sp->setup);
     if (sp->ev0) (void)hipEventDestroy(sp->ev0);
     if (sp->ev1) (void)hipEventDestroy(sp->ev1);
+    for (hipEvent_t e : sp->wev) (void)hipEventDestroy(e);
     delete sp;
     return 0;
 }
@@ -354,6 +360,49 @@ int ladiff_sampler_loop_ms(void* sampler, float* ms) {
     return 0;
 }
 
+int ladiff_sampler_set_window_timing(void* sampler, int on) {
+    Sampler* sp = reinterpret_cast<Sampler*>(sampler);
+    LADIFF_CHECK_ARG(sp != nullptr);
+    sp->time_windows = on != 0;
+    return 0;
+}
+
+int ladiff_sampler_window_ms(void* sampler, float* loop_ms_sum, int* n_windows) {
+    Sampler* sp = reinterpret_cast<Sampler*>(sampler);
+    LADIFF_CHECK_ARG(sp != nullptr && loop_ms_sum != nullptr && n_windows != nullptr);
+    float sum = 0.f;
+    for (int i = 0; i < sp->n_windows; ++i) {
+        float ms = 0.f;
+        LADIFF_HIP(hipEventSynchronize(sp->wev[2 * i + 1]));
+        LADIFF_HIP(hipEventElapsedTime(&ms, sp->wev[2 * i], sp->wev[2 * i + 1]));
+        sum += ms;
+    }
+    *loop_ms_sum = sum; *n_windows = sp->n_windows;
+    return 0;
+}
+
+int ladiff_sampler_last_loop(void* sampler, int* pipeline, int* rows_per_block, int* n_blocks) {
+    Sampler* sp = reinterpret_cast<Sampler*>(sampler);
+    LADIFF_CHECK_ARG(sp != nullptr && pipeline != nullptr);
+    *pipeline = sp->last_pipeline;
+    if (rows_per_block) *rows_per_block = sp->last_pipeline ? 16 * sp->plan_mr : 0;
+    if (n_blocks) *n_blocks = sp->last_pipeline ? sp->plan_nb : 0;
+    return 0;
+}
+
+int ladiff_debug_set_pipeline_fault(int workgroup, int timeout_ms) {
+    LADIFF_CHECK_ARG(workgroup >= -1 && workgroup < 256 && timeout_ms >= 0);
+    g_fault_wg = workgroup;
+    g_timeout_ticks = (unsigned long long)timeout_ms * 100000ull;      // s_memrealtime: 100 MHz
+    return 0;
+}
+
+size_t ladiff_reverse_status_offset_bytes(int B, int T, int n_steps, int n_text) {
+    if (B < 1 || T < 1 || T > LADIFF_MAX_LATENTS || n_steps < 1 || n_text < 1) return 0;
+    const ReverseWs r = carve_reverse(nullptr, B, T, n_steps, n_text);
+    return (r.sys_off + sys_status_offset_floats(B, T)) * sizeof(float);
+}
+
 int ladiff_reverse_status(void* ws, int B, int T, int n_steps, int n_text, int* code, int* info) {
     LADIFF_CHECK_ARG(ws && code && B > 0 && n_steps > 0);
     if (T < 1 || T > LADIFF_MAX_LATENTS) return LADIFF_ERR_SHAPE;
@@ -400,6 +449,9 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
     // The time tables depend on (weights, schedule) only: a caller that re-runs with both unchanged in the same workspace
     // may keep them (saves ~30 small GEMM launches per call).  The rest (~50 small launches) depends on this call's text
     // and noise; with a sampler it is replayed as a graph so that the host does not pace the GPU through it.
+    // abort / diagnostic words of the pipeline loop: cleared once per call (they are sticky over the call's windows; every
+    // other loop form leaves them at "completed")
+    LADIFF_TRY(sys_reset_status(r.sys, s));
     if (!reuse_time_tables) LADIFF_TRY(denoiser_time_tables(W, sinusoid, n_steps, r.tables, r.fwd, r.fwd_floats, s));
     auto prologue = [&](hipStream_t st) -> int {
         if (n_text > 1) LADIFF_TRY(denoiser_text_cache(W, text_emb, B2, r.tables, n_steps, r.cache, r.fwd, r.fwd_floats, st, n_text));
@@ -499,23 +551,30 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
             LADIFF_HIP(hipMemcpyAsync(r.sys + sys_blocks_offset_floats(plan_mr, plan_nb), sp->blocks.data(), sp->blocks.size(),
                                       hipMemcpyHostToDevice, s));
         }
+        sp->last_pipeline = pipeline ? 1 : 0;
+        sp->n_windows = 0;
         for (int lo = 0; lo < n_steps; lo += r.window) {
             LADIFF_TRY(open_window(lo));
             if (lo == 0) LADIFF_HIP(hipEventRecord(sp->ev0, s));       // the loop itself: from the first step's first launch
+            const int wi = lo / r.window;
+            if (sp->time_windows) {
+                while ((int)sp->wev.size() < 2 * (wi + 1)) { hipEvent_t e; LADIFF_HIP(hipEventCreate(&e)); sp->wev.push_back(e); }
+                LADIFF_HIP(hipEventRecord(sp->wev[2 * wi], s));
+            }
             if (pipeline) {
                 LADIFF_TRY(launch_systolic_loop(W, r.sys, r.tables, den_cache_tkv(r.cache, B2, 1), den_cache_ctab(r.cache, B2, 1), r.window,
                                                 coef, step_noise, r.latents, counts, guidance_scale, B, T, lo, r.window, WSp ? 0 : 1, plan_mr, plan_nb, s));
             } else {
                 for (int i = 0; i < r.window / sp->unroll; ++i) LADIFF_HIP(hipGraphLaunch(sp->exec, s));
             }
+            if (sp->time_windows) { LADIFF_HIP(hipEventRecord(sp->wev[2 * wi + 1], s)); sp->n_windows = wi + 1; }
         }
         LADIFF_HIP(hipEventRecord(sp->ev1, s));
     }
-    if (!pipeline)       // the pipeline kernel's status word reads "completed" for every other loop form (ladiff_reverse_status)
-        LADIFF_HIP(hipMemsetAsync(r.sys + sys_status_offset_floats(B, T), 0, 2 * sizeof(unsigned), s));
     // final zeroing of the rows past each motion's latent count: applied even when the denoiser ran unmasked
-    // (TEST_EFFICIENCY), as ladiff.py:559-566 does
-    return launch_finalize_latents(r.latents, final_counts, z, B, T, s);
+    // (TEST_EFFICIENCY), as ladiff.py:559-566 does.  An aborted pipeline launch leaves partial latents: z is then NaN.
+    return launch_finalize_latents(r.latents, final_counts, z, B, T, s,
+                                   reinterpret_cast<const unsigned*>(r.sys + sys_status_offset_floats(B, T)));
 }
 
 // ------------------------------------------------------------------ LA-VAE encoder

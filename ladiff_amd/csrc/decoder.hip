@@ -14,7 +14,7 @@ static GemmArgs lin(const float* A, int lda, const float* W, const float* bias, 
 
 // rows = B * F for the padded layout, or the sum of the lengths for the ragged one
 size_t dec_ws_floats(int B, size_t rows, int T) {
-    return rows * (16 * D + 3 * D + D + FF + 1) + (size_t)NL * ((size_t)T * B * 2 * D + dec_cross_ws_floats(B, T)) +
+    return rows * (16 * D + 3 * D + D + FF) + (rows + 63) / 64 * 64 + (size_t)NL * ((size_t)T * B * 2 * D + dec_cross_ws_floats(B, T)) +
            (size_t)LADIFF_MAX_FRAMES * (2 * D + 3 * D);       // layer 0: the position table as a GEMM operand and its q|k|v
 }
 
@@ -45,7 +45,7 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
     float* hid = p; p += (size_t)M * FF;
     float* kv = p; p += (size_t)NL * T * B * 2 * D;      // memory K | V of every layer
     float* guws = p; p += (size_t)NL * dec_cross_ws_floats(B, T);   // G | U | c of the folded cross-attention of every layer (dec_cross.hip)
-    int32_t* row_out = reinterpret_cast<int32_t*>(p); p += M;   // ragged: place of each row in the padded output
+    int32_t* row_out = reinterpret_cast<int32_t*>(p); p += ((size_t)M + 63) / 64 * 64;   // ragged: place of each row in the padded output (rounded: what follows is read 16 bytes at a time and by LDS-DMA)
     float* pex = p; p += (size_t)LADIFF_MAX_FRAMES * D;   // layer 0: pe[:F] (+ S-format twin) and its in_proj, shared by all samples
     float* pexs = p; p += (size_t)LADIFF_MAX_FRAMES * D;
     float* qkv0 = p;

@@ -37,7 +37,7 @@ int launch_advance(int32_t* d_step, hipStream_t s);
 int launch_step_tail(float* x, float* xs, const float* ng, const float* nb, float* lat, const float* coef, int32_t* d_step,
                      const float* noise, const float* pe, float g, int cfg, int B, int T, hipStream_t s);
 int launch_init_latents(const float* noise, const int32_t* counts, float sigma, float* lat, int B, int T, hipStream_t s);
-int launch_finalize_latents(const float* lat, const int32_t* counts, float* z, int B, int T, hipStream_t s);
+int launch_finalize_latents(const float* lat, const int32_t* counts, float* z, int B, int T, hipStream_t s, const unsigned* status = nullptr);
 
 int launch_pad_cols(const float* x, float* y, int R, int C, int Cp, hipStream_t s);
 int launch_encoder_assemble(const float* token, const float* emb, const float* pe, const int32_t* lengths,

@@ -51,6 +51,9 @@ extern unsigned long long* g_sys_stamps;
 size_t sys_ws_floats(int B, int T);
 bool sys_supported(int B, int T, int cfg, bool split);
 extern int g_waves16;
+extern int g_fault_wg;
+extern unsigned long long g_timeout_ticks;
+int sys_reset_status(float* ws, hipStream_t s);
 extern int g_xcd_local;
 void sys_pack_blocks(int B, int T, int want_mr, const int32_t* h_counts, bool masked, std::vector<unsigned char>& out, int* mr, int* nb);
 int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR, int NB, std::vector<unsigned char>& host);

@@ -535,8 +535,11 @@ int launch_init_latents(const float* noise, const int32_t* counts, float sigma, 
 }
 
 // z[t,b,:] = latents[b,t,:] with rows t >= counts[b] zeroed   (ladiff.py:500, :562-566)
+// status (optional): the pipeline loop's abort word.  When it is non-zero the loop did not finish and the latents are partial:
+// the result is POISONED with NaN so that a caller who never reads the status cannot mistake it for a sample.
 __global__ __launch_bounds__(256) void finalize_latents_kernel(const float* __restrict__ lat, const int32_t* __restrict__ counts,
-                                                               int B, int T, int M, float* __restrict__ z) {
+                                                               int B, int T, int M, float* __restrict__ z,
+                                                               const unsigned* __restrict__ status) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     const int c = (threadIdx.x & 63) * 4;
     if (row >= M) return;
@@ -544,11 +547,12 @@ __global__ __launch_bounds__(256) void finalize_latents_kernel(const float* __re
     f32x4 v = ld4(lat + (size_t)row * D + c);
     const bool valid = counts == nullptr || t < counts[b];
     if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (status != nullptr && status[0] != 0u) { const float q = __builtin_nanf(""); v = f32x4{q, q, q, q}; }
     st4(z + ((size_t)t * B + b) * D + c, v);
 }
-int launch_finalize_latents(const float* lat, const int32_t* counts, float* z, int B, int T, hipStream_t s) {
+int launch_finalize_latents(const float* lat, const int32_t* counts, float* z, int B, int T, hipStream_t s, const unsigned* status) {
     const int M = B * T;
-    hipLaunchKernelGGL(finalize_latents_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, lat, counts, B, T, M, z);
+    hipLaunchKernelGGL(finalize_latents_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, lat, counts, B, T, M, z, status);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }

@@ -125,6 +125,8 @@ struct SysArgs {
     int B, T, P, NB, step_lo, n_steps, n_ctab;
     int force_mismatch;                   // test aid: one workgroup reports a placement that disagrees (ladiff_debug_set_xcd_local(2))
     int split;                            // 1: a block holds ONE guidance branch of its P prompts (block 2g + br), 0: both
+    int fault_wg;                         // test aid: this workgroup leaves right after the start-up handshake and never publishes (-1: none)
+    unsigned long long timeout_ticks;     // bound of every spin, in s_memrealtime ticks (100 MHz)
     unsigned long long* stamps;           // diagnostic twin build only (-DLADIFF_STAMPS): [workgroup][step][block][8] realtime ticks
 };
 
@@ -204,7 +206,7 @@ __device__ __forceinline__ void st_out(const Stage& st, __amdgpu_buffer_rsrc_t r
     else st_sc1(r, off, v);
 }
 
-constexpr unsigned long long TIMEOUT_TICKS = 150000000ull;     // s_memrealtime runs at 100 MHz: 1.5 s per wait
+constexpr unsigned long long TIMEOUT_TICKS = 150000000ull;     // default bound of a wait: s_memrealtime runs at 100 MHz, 1.5 s (SysArgs::timeout_ticks)
 
 // LDS words of the hand-off protocol (last 16 bytes of the dynamic region)
 struct Ctl { int abort, ready; unsigned arrive; int local_ok; };      // arrive: attention waves of the QKV stage that have drained, over all blocks
@@ -216,7 +218,8 @@ struct Ctl { int abort, ready; unsigned arrive; int local_ok; };      // arrive:
 // barrier only counts the waves still running.
 // `first`: a sample of this lane's flag taken earlier (stage_loop polls the next block's flags while the current block's stores
 // drain), 0 = none: when the flags were already up then, the wait costs no round trip at all.
-__device__ __forceinline__ bool wait_epoch(const unsigned* flags, int n, unsigned epoch, unsigned* status, Ctl*, unsigned first) {
+__device__ __forceinline__ bool wait_epoch(const unsigned* flags, int n, unsigned epoch, unsigned* status, Ctl*, unsigned first,
+                                           unsigned long long timeout) {
     const int lane = threadIdx.x & 63;
     if (__all((lane < n ? first : epoch) >= epoch)) return true;
     const gu32* f = (const gu32*)flags + (lane < n ? lane : 0) * FLAG_STRIDE;
@@ -227,7 +230,7 @@ __device__ __forceinline__ bool wait_epoch(const unsigned* flags, int n, unsigne
         if ((spins & 63u) == 0u) {
             const unsigned a = __hip_atomic_load((const gu32*)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a != 0u) return false;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > TIMEOUT_TICKS) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > timeout) {
                 if (lane == 0) {
                     __hip_atomic_store((gu32*)status + 1, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store((gu32*)status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -397,7 +400,7 @@ __device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R&
             if constexpr (R::BACKP) { if (!r.backpressure(s, b, ctl)) return; }
             if (!have) {
                 SYS_STAT_T0;
-                if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, pre)) return;
+                if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, pre, p.timeout_ticks)) return;
                 SYS_STAT_WAIT;
                 r.issue(s, b, gcur, cur);
             }
@@ -600,7 +603,7 @@ struct QkvRole {
                         else if (b2[u] >= 0) xk[u] = ld4(tkv + (size_t)b2[u] * 512 + (c4 < 64 ? c4 : 192 + c4) + h * 64);
                     }
                     SYS_SPLIT_T0;
-                    if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, 0u)) return;
+                    if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, 0u, p.timeout_ticks)) return;
                     SYS_SPLIT_WAIT;
                     SYS_STAMP_L(1);
                     f32x4 x[2][2];
@@ -794,7 +797,7 @@ struct OutRole {
                 const unsigned base = (unsigned)b * RT * 1024;
                 if (loader) {
                     SYS_SPLIT_T0;
-                    if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, 0u)) return;
+                    if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, 0u, p.timeout_ticks)) return;
                     SYS_SPLIT_WAIT;
                     SYS_STAMP_L(1);
                     f32x4 x[2][2];
@@ -908,7 +911,7 @@ struct MlpRole {
             const int gx = g - PRING / 2 - i;
             if (gx < 0) continue;
             const int sx = gx / p.NB, x = gx - sx * p.NB;
-            if (!wait_epoch(flag_of(p, st.bp_group, x, st.bp_slot0), st.bp_n, (unsigned)(sx + 1), p.status, ctl, 0u)) return false;
+            if (!wait_epoch(flag_of(p, st.bp_group, x, st.bp_slot0), st.bp_n, (unsigned)(sx + 1), p.status, ctl, 0u, p.timeout_ticks)) return false;
         }
         return true;
     }
@@ -1315,7 +1318,7 @@ __device__ __forceinline__ void tail_loop(const SysArgs& p, const Stage& st, Tai
                         if (__all(v >= (unsigned)(s + 1))) break;
                         if ((spins & 63u) == 0u) {
                             if (__hip_atomic_load((const gu32*)p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
-                            if (__builtin_amdgcn_s_memrealtime() - t0 > TIMEOUT_TICKS) {
+                            if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {
                                 if (lane == 0) {
                                     __hip_atomic_store((gu32*)p.status + 1, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                     __hip_atomic_store((gu32*)p.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1363,7 +1366,10 @@ __global__ __launch_bounds__(256 * WS, 1) void systolic_loop_kernel(const SysArg
     Stage st = p.stages[blockIdx.x];
     if (threadIdx.x == 0) {
         ctl->abort = 0; ctl->ready = 0; ctl->arrive = 0u; ctl->local_ok = 1;
-        if (st.xcd >= 0) {
+        // the abort word is STICKY over the launches of one ladiff_diffusion_reverse call (a long schedule runs window by window:
+        // the host clears it once per call, not per launch): after an abort the remaining windows end at once
+        if (__hip_atomic_load((const gu32*)p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ctl->abort = 1;
+        if (st.xcd >= 0 && !ctl->abort) {
             // The plan only needs workgroups i and j to share an XCD exactly when i = j (mod 8).  The dispatcher deals a launch's
             // workgroups to the XCDs round robin but starts where the previous launch stopped, so XCC_ID - i (mod 8) is one
             // number per launch: the first workgroup to get here records it, every other one compares - and ALL of them agree on
@@ -1381,7 +1387,7 @@ __global__ __launch_bounds__(256 * WS, 1) void systolic_loop_kernel(const SysArg
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             unsigned v = 0u;
             while (((v = __hip_atomic_load((const gu32*)p.status + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffu) < gridDim.x) {
-                if (__builtin_amdgcn_s_memrealtime() - t0 > TIMEOUT_TICKS) {
+                if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {
                     ctl->abort = 1;
                     __hip_atomic_store((gu32*)p.status + 1, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store((gu32*)p.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1397,6 +1403,7 @@ __global__ __launch_bounds__(256 * WS, 1) void systolic_loop_kernel(const SysArg
     }
     __syncthreads();
     if (ctl->abort) return;
+    if ((int)blockIdx.x == p.fault_wg) return;       // injected fault (ladiff_debug_set_pipeline_fault): its consumers time out
     if (!ctl->local_ok) st.out_local = 0;
 #ifdef LADIFF_STAMPS
     if (p.stamps != nullptr && threadIdx.x == 0)         // who runs here (the stage table is permuted by the XCD placement)
@@ -1729,19 +1736,20 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR,
 // the workspace (sys_upload_stages); `ctab` holds the hoisted cross-attention rows of n_ctab >= n steps starting at step_lo.
 // waves per SIMD of the 16-row plan's stage workgroups (measurement switch: ladiff_debug_set_stage_waves)
 int g_waves16 = 2;
+// test aids (ladiff_debug_set_pipeline_fault): a workgroup that never publishes, and the bound of a wait in s_memrealtime ticks (0: default)
+int g_fault_wg = -1;
+unsigned long long g_timeout_ticks = 0;
+
+int sys_reset_status(float* ws, hipStream_t s) {
+    const SysLayout L = sys_layout(2, 1);            // the status words sit at a fixed offset (before everything sized by the plan)
+    LADIFF_HIP(hipMemsetAsync(ws + L.off_status, 0, 64 * sizeof(float), s));
+    return 0;
+}
 
 int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, const float* tkv, const float* ctab, int n_ctab,
                          const float* coef, const float* noise, float* lat, const int32_t* counts, float gscale, int B, int T,
                          int step_lo, int n, int fp32, int MR, int NB, hipStream_t s) {
     const SysLayout L = sys_layout(MR, NB);
-    static bool attr_set = false;
-    if (!attr_set) {
-        const void* k[6] = {reinterpret_cast<const void*>(systolic_loop_kernel<1, 0, 2>), reinterpret_cast<const void*>(systolic_loop_kernel<2, 0, 1>),
-                            reinterpret_cast<const void*>(systolic_loop_kernel<1, 1, 2>), reinterpret_cast<const void*>(systolic_loop_kernel<2, 1, 1>),
-                            reinterpret_cast<const void*>(systolic_loop_kernel<1, 0, 1>), reinterpret_cast<const void*>(systolic_loop_kernel<1, 1, 1>)};
-        for (int i = 0; i < 6; ++i) LADIFF_HIP(hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, SYS_LDS_BYTES));
-        attr_set = true;
-    }
     SysArgs a;
     a.stages = reinterpret_cast<const Stage*>(ws + L.off_stages);
     a.blocks = reinterpret_cast<const BlockDesc*>(ws + L.off_blocks);
@@ -1752,6 +1760,8 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     a.n_ctab = n_ctab;
     a.split = L.split;
     a.force_mismatch = g_xcd_local == 2 ? 1 : 0;
+    a.fault_wg = g_fault_wg;
+    a.timeout_ticks = g_timeout_ticks > 0 ? g_timeout_ticks : TIMEOUT_TICKS;
     a.stamps = nullptr;
 #ifdef LADIFF_STAMPS
     a.stamps = g_sys_stamps;
@@ -1761,14 +1771,24 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     // therefore chained through one event per device: the next one, on whatever stream, starts after the previous one has ended.
     static std::mutex mu;
     static hipEvent_t done[64] = {};
+    static bool attr_set[64] = {};             // hipFuncSetAttribute is per DEVICE: a process driving several GPUs opts in on each
     int dev = 0;
     LADIFF_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return LADIFF_ERR_ARG;
     std::lock_guard<std::mutex> lock(mu);
+    if (!attr_set[dev]) {
+        const void* k[6] = {reinterpret_cast<const void*>(systolic_loop_kernel<1, 0, 2>), reinterpret_cast<const void*>(systolic_loop_kernel<2, 0, 1>),
+                            reinterpret_cast<const void*>(systolic_loop_kernel<1, 1, 2>), reinterpret_cast<const void*>(systolic_loop_kernel<2, 1, 1>),
+                            reinterpret_cast<const void*>(systolic_loop_kernel<1, 0, 1>), reinterpret_cast<const void*>(systolic_loop_kernel<1, 1, 1>)};
+        for (int i = 0; i < 6; ++i) LADIFF_HIP(hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, SYS_LDS_BYTES));
+        attr_set[dev] = true;
+    }
     if (done[dev] == nullptr) LADIFF_HIP(hipEventCreateWithFlags(&done[dev], hipEventDisableTiming));
     else LADIFF_HIP(hipStreamWaitEvent(s, done[dev], 0));
-    // the abort word and the flags: two memset nodes (the block descriptors sit between them)
-    LADIFF_HIP(hipMemsetAsync(a.status, 0, 64 * sizeof(float), s));
+    // Per launch: the placement handshake words ([8], [9]) and the flags.  The abort / diagnostic words ([0], [1]) are cleared ONCE per
+    // ladiff_diffusion_reverse call (sys_reset_status): a schedule longer than one window is several launches, and an abort in an
+    // early window must neither be erased by the next launch's memset nor let the later windows iterate on corrupt latents.
+    LADIFF_HIP(hipMemsetAsync(a.status + 8, 0, 2 * sizeof(unsigned), s));
     LADIFF_HIP(hipMemsetAsync(a.flags, 0, (L.off_xin0 - L.off_flags) * sizeof(float), s));
     if (fp32) {
         if (MR == 1 && g_waves16 == 2) hipLaunchKernelGGL((systolic_loop_kernel<1, 1, 2>), dim3(L.nwg), dim3(512), SYS_LDS_BYTES, s, a);

@@ -67,7 +67,7 @@ def remove_padding(tensors, lengths):
 class LADIFF(nn.Module):
     def __init__(self, cfg=None, datamodule=None, *, denoiser=None, vae=None, scheduler=None, text_encoder=None,
                  guidance_scale=None, num_inference_timesteps=None, eta=None, max_it=None, frame_per_latent=None,
-                 test_efficiency=None, use_graph=True, precision=None, loop="pipeline", **kwargs):
+                 test_efficiency=None, use_graph=True, precision=None, loop="pipeline", fallback=False, **kwargs):
         super().__init__()
         self.cfg = cfg
         self.datamodule = datamodule
@@ -110,6 +110,15 @@ class LADIFF(nn.Module):
         self.loop = loop
         # matrix-product arithmetic of the denoiser loop: "fp32" (fp32-input MFMA) or "bf16x3" (3-term bf16 split)
         self.precision = precision if precision is not None else getattr(self.denoiser, "precision", "fp32")
+        # What happens when the persistent pipeline kernel abandons a call (a stage timed out on its producer: the GPU was shared with
+        # another process, or a long kernel on another stream kept a CU busy).  The 8-byte status is copied to pinned host memory
+        # behind every call; it is read when the host next synchronises anyway (forward, t2m_eval, loop_ms, check()) and at the start
+        # of the NEXT call, and z is NaN in the meantime.  fallback=False: raise LadiffHipError.  fallback=True: the call waits for
+        # its own status and, when it aborted, runs again launch-per-stage in this process (same library, same arithmetic; counted
+        # in `fallback_count`).
+        self.fallback = bool(fallback)
+        self.fallback_count = 0
+        self._pending = None          # (event, pinned status words, plan key) of the last call, not yet looked at
         self._sampler = None
         self._stream = None
         self._plan = None
@@ -134,6 +143,15 @@ class LADIFF(nn.Module):
         return next(self.denoiser.parameters()).device
 
     def __del__(self):
+        try:
+            if self._pending is not None:
+                ev, host, _ = self._pending
+                ev.synchronize()
+                if int(host[0]) != 0:
+                    import warnings
+                    warnings.warn(f"LADIFF: the last pipeline loop aborted (workgroup {int(host[1])} timed out) and its result was never checked")
+        except Exception:
+            pass
         try:
             if self._sampler is not None:
                 _lib.lib().ladiff_sampler_destroy(self._sampler)
@@ -165,8 +183,33 @@ class LADIFF(nn.Module):
             "ws": _lib.workspace(wsb, dev), "ws_bytes": wsb,
             "tables_key": None,      # weights the time tables inside `ws` were built from
         }
+        # the pipeline kernel's {code, info} words inside the workspace, and where the host reads them
+        off = L.ladiff_reverse_status_offset_bytes(B, T, n_steps, n_text)
+        if off == 0 or off % 4:
+            raise _lib.LadiffHipError("ladiff_reverse_status_offset_bytes rejected the plan's shape")
+        plan["status_dev"] = plan["ws"][off // 4: off // 4 + 2].view(torch.int32)
+        plan["status_host"] = torch.zeros(2, dtype=torch.int32).pin_memory()
+        plan["status_event"] = torch.cuda.Event()
         self._plan = plan
         return plan
+
+    def check(self, wait=True):
+        """Look at the status of the last `_diffusion_reverse` call: raises LadiffHipError when its pipeline loop was abandoned
+        (the returned z is NaN then).  wait=False only looks if the copy has already arrived.  Returns True when looked at."""
+        if self._pending is None:
+            return True
+        ev, host, _ = self._pending
+        if not wait and not ev.query():
+            return False
+        ev.synchronize()
+        self._pending = None
+        code, info = int(host[0]), int(host[1])
+        if code != 0:
+            raise _lib.LadiffHipError(
+                f"the persistent pipeline loop was abandoned (status {code}: workgroup {info} timed out waiting for its producer - "
+                "is the GPU shared, or was a long kernel running on another stream?); the latents of that call are NaN.  "
+                "Run again, construct LADIFF(fallback=True) to re-run such a call launch-per-stage automatically, or use loop='launches'")
+        return True
 
     def _counts(self, lengths):
         return [int(math.ceil(l / self.frame_per_latent)) for l in lengths]
@@ -178,6 +221,7 @@ class LADIFF(nn.Module):
         dev = encoder_hidden_states.device
         if not encoder_hidden_states.is_cuda:
             raise _lib.LadiffHipError("_diffusion_reverse needs GPU tensors; there is no CPU fallback")
+        self.check()          # the previous call's status (its loop has long finished: the copy sits right behind it on the stream)
         n_text = int(encoder_hidden_states.shape[1])          # 1: CLIP pooled token; > 1: clip_hidden / bert (mld_clip.py:80-86)
         if n_text > 1 and self.precision != "fp32":
             raise NotImplementedError("more than one text token per prompt runs in fp32 arithmetic only: precision='fp32'")
@@ -198,8 +242,6 @@ class LADIFF(nn.Module):
             h = c_void_p()
             _lib.check(L.ladiff_sampler_create(byref(h)))
             self._sampler = h
-        if self._sampler is not None:
-            _lib.check(L.ladiff_sampler_set_loop(self._sampler, {"pipeline": 1, "pipeline16": 2, "pipeline32": 3, "launches": 0}[self.loop]))
         if init_noise is None:
             init_noise = torch.randn(B, T, 256, device=dev, dtype=torch.float32)       # ladiff.py:380-385
         if need_noise and step_noise is None:
@@ -211,12 +253,11 @@ class LADIFF(nn.Module):
         run = cur if cur.cuda_stream != 0 else self._stream
         if run is not cur:
             run.wait_stream(cur)
-        with torch.cuda.stream(run):
-            plan["text"][:dup * B].copy_(encoder_hidden_states.reshape(dup * B, n_text, 768))
-            plan["noise"].copy_(init_noise)
-            plan["counts"].copy_(_lib.device_ints(counts, dev))       # device-to-device: the graph bakes plan["counts"] in
-            if need_noise:
-                plan["step_noise"].copy_(step_noise)
+        loop_codes = {"pipeline": 1, "pipeline16": 2, "pipeline32": 3, "launches": 0}
+
+        def enqueue(loop):
+            if self._sampler is not None:
+                _lib.check(L.ladiff_sampler_set_loop(self._sampler, loop_codes[loop]))
             _lib.check(L.ladiff_diffusion_reverse(
                 self._sampler if self.use_graph else None, wt.array,
                 wt.split_array() if self.precision == "bf16x3" else None, wt.generation, _lib.ptr(plan["text"]),
@@ -229,6 +270,25 @@ class LADIFF(nn.Module):
                 self.guidance_scale, float(sch.init_noise_sigma), 1 if cfg else 0, B, T, n_text, n, _lib.ptr(plan["z"]),
                 _lib.ptr(plan["ws"]), plan["ws_bytes"], 1 if plan["tables_key"] == wt.key else 0, run.cuda_stream))
             plan["tables_key"] = wt.key
+            # the loop's status words follow it on the stream into pinned memory: 8 bytes, no host synchronisation here
+            plan["status_host"].copy_(plan["status_dev"], non_blocking=True)
+            plan["status_event"].record(run)
+            self._pending = (plan["status_event"], plan["status_host"], plan["key"])
+
+        with torch.cuda.stream(run):
+            plan["text"][:dup * B].copy_(encoder_hidden_states.reshape(dup * B, n_text, 768))
+            plan["noise"].copy_(init_noise)
+            plan["counts"].copy_(_lib.device_ints(counts, dev))       # device-to-device: the graph bakes plan["counts"] in
+            if need_noise:
+                plan["step_noise"].copy_(step_noise)
+            enqueue(self.loop)
+            if self.fallback and self.loop != "launches":
+                try:
+                    self.check()                                      # waits for THIS call's loop
+                except _lib.LadiffHipError:
+                    self.fallback_count += 1
+                    enqueue("launches")                               # same call, one launch per stage (never the CPU, never a re-exec)
+                    self.check()
         if run is not cur:
             cur.wait_stream(run)
         return plan["z"].clone()
@@ -238,7 +298,33 @@ class LADIFF(nn.Module):
         from ctypes import c_float
         ms = c_float(0.0)
         _lib.check(_lib.lib().ladiff_sampler_loop_ms(self._sampler, byref(ms)))
+        self.check()                  # the loop has ended: its status is there (an abandoned loop must not be reported as a timing)
         return ms.value
+
+    def window_ms(self, enable=None):
+        """(sum of the per-window loop times in ms, windows) of the last call; `enable=True/False` switches the per-window events on
+        or off for the following calls (measurement aid: a 1000-step schedule runs as 20 windows of 50 steps)."""
+        from ctypes import c_float, c_int
+        L = _lib.lib()
+        if enable is not None:
+            if self._sampler is None:
+                h = c_void_p()
+                _lib.check(L.ladiff_sampler_create(byref(h)))
+                self._sampler = h
+            _lib.check(L.ladiff_sampler_set_window_timing(self._sampler, 1 if enable else 0))
+            return None
+        ms, n = c_float(0.0), c_int(0)
+        _lib.check(L.ladiff_sampler_window_ms(self._sampler, byref(ms), byref(n)))
+        return ms.value, n.value
+
+    def last_loop(self):
+        """(ran as the persistent pipeline kernel?, rows per block, blocks) of the last `_diffusion_reverse` call."""
+        from ctypes import c_int
+        if self._sampler is None:
+            return False, 0, 0
+        pl, rows, nb = c_int(0), c_int(0), c_int(0)
+        _lib.check(_lib.lib().ladiff_sampler_last_loop(self._sampler, byref(pl), byref(rows), byref(nb)))
+        return bool(pl.value), rows.value, nb.value
 
     def loop_status(self):
         """(code, info) of the persistent pipeline kernel of the last `_diffusion_reverse` call; blocks until the stream has
@@ -265,8 +351,7 @@ class LADIFF(nn.Module):
             raise RuntimeError("LADIFF.forward needs a text_encoder callable and datamodule.feats2joints; "
                                "use .sample(text_emb, lengths) for embeddings -> features")
         start = time.time()
-        texts = [""] * len(texts) + list(texts)                     # ladiff.py:258-264
-        text_emb = self.text_encoder(texts)
+        text_emb = self.text_encoder(self._guided_texts(texts))
         z = self._diffusion_reverse(text_emb, lengths)
         with torch.no_grad():
             if latentwise_gen:                                      # ladiff.py:274-283
@@ -281,12 +366,43 @@ class LADIFF(nn.Module):
         if self.feats2joints_device is not None:
             joints = self.feats2joints_device(feats_rst.detach())
             torch.cuda.synchronize()
+            self.check()
             self.times.append(time.time() - start)
             return remove_padding(joints.cpu(), lengths)
         torch.cuda.synchronize()
+        self.check()
         self.times.append(time.time() - start)
         joints = self.feats2joints(feats_rst.detach().cpu())
         return remove_padding(joints, lengths)
+
+    def _guided_texts(self, texts):
+        """`[""] * B + texts` when classifier-free guidance is on, the texts alone otherwise (ladiff.py:258-264, :1039-1047, :1135-1142)."""
+        texts = list(texts)
+        return [""] * len(texts) + texts if self.do_classifier_free_guidance else texts
+
+    def test_diffusion_forward(self, batch, finetune_decoder=False):
+        """`LADIFF.test_diffusion_forward` (ladiff.py:1035-1109, `condition == 'text'`, a VAE present): text -> latents -> features
+        -> joints, and - when the batch carries the ground-truth motion - both motions through the LA-VAE encoder.  Returns the
+        reference's `rs_set`: m_rst [B,F,C], lat_t [B,max_it,256], joints_rst, (m_ref, lat_m, lat_rm, joints_ref)."""
+        if self.text_encoder is None or (self.feats2joints is None and self.feats2joints_device is None):
+            raise RuntimeError("test_diffusion_forward needs a text_encoder callable and datamodule.feats2joints")
+        lengths = [int(l) for l in batch["length"]]
+        cond_emb = self.text_encoder(self._guided_texts(batch["text"]))                  # :1038-1048
+        f2j = self.feats2joints_device or (lambda f: self.feats2joints(f.detach().cpu()))
+        with torch.no_grad():
+            z = self._diffusion_reverse(cond_emb, lengths)                               # :1060-1061
+            feats_rst = self.vae.decode(z, lengths)                                      # :1064-1067
+        rs_set = {"m_rst": feats_rst, "lat_t": z.permute(1, 0, 2), "joints_rst": f2j(feats_rst)}      # :1083-1090
+        if "motion" in batch and not finetune_decoder:                                   # :1092-1108
+            feats_ref = batch["motion"].detach().to(feats_rst.device)
+            with torch.no_grad():
+                motion_z, _, _ = self.vae.encode(feats_ref, lengths)
+                recons_z, _, _ = self.vae.encode(feats_rst, lengths)
+            rs_set["m_ref"] = feats_ref
+            rs_set["lat_m"] = motion_z.permute(1, 0, 2)
+            rs_set["lat_rm"] = recons_z.permute(1, 0, 2)
+            rs_set["joints_ref"] = f2j(feats_ref)
+        return rs_set
 
     def set_t2m_evaluators(self, text_encoder, movement_encoder, motion_encoder, unit_len=4):
         """The three frozen evaluator networks of `_get_t2m_evaluator` (ladiff.py:179-223); `unit_len` =
@@ -305,11 +421,12 @@ class LADIFF(nn.Module):
         dev = self.device
         motions = batch["motion"].detach().clone().to(dev)
         start = time.time()
-        text_emb = self.text_encoder([""] * len(texts) + texts)                       # ladiff.py:1135-1144
+        text_emb = self.text_encoder(self._guided_texts(texts))                       # ladiff.py:1135-1144
         z = self._diffusion_reverse(text_emb, lengths)
         with torch.no_grad():
             feats_rst = self.vae.decode(z, lengths)        # [B, max(lengths), nfeats], frames >= length are zero (:1196-1207)
         torch.cuda.synchronize()
+        self.check()
         self.times.append(time.time() - start)
         f2j = self.feats2joints_device or (lambda f: self.feats2joints(f.detach().cpu()))
         joints_rst, joints_ref = f2j(feats_rst), f2j(motions)

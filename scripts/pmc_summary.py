@@ -32,12 +32,27 @@ def short(name):
     return name.split("(")[0].replace("void ", "").replace("ladiff::", "")
 
 
+MARKER = "init_latents_kernel"        # one per pass, in its prologue
+
+
+def steady(rows, name_key):
+    """(rows of the STEADY-STATE passes, their number): everything from the second pass's marker kernel to the last pass's - the
+    warm-up pass (weight uploads, S-format splits, graph capture, the XCD probe) and the tail of the last pass are left out; the
+    cut is a cyclic shift of whole passes, every kernel of a steady pass is counted exactly once per pass."""
+    marks = sorted({int(r["Start_Timestamp"]) for r in rows if MARKER in r[name_key]})
+    if len(marks) < 3:
+        return rows, None
+    lo, hi = marks[1], marks[-1]
+    return [r for r in rows if lo <= int(r["Start_Timestamp"]) < hi], len(marks) - 2
+
+
 def load_counter(root, name):
     files = glob.glob(f"{root}/{name}/**/*_counter_collection.csv", recursive=True)
     if not files:
         return None
     val = defaultdict(lambda: defaultdict(float)); n = defaultdict(int); dur = defaultdict(float)
-    for r in csv.DictReader(open(files[0])):
+    rows, _ = steady(list(csv.DictReader(open(files[0]))), "Kernel_Name")
+    for r in rows:
         k = short(r["Kernel_Name"])
         val[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == name:
@@ -49,18 +64,19 @@ def load_counter(root, name):
 def load_trace(root):
     files = glob.glob(f"{root}/stats/**/*_kernel_trace.csv", recursive=True)
     n = defaultdict(int); dur = defaultdict(float)
-    for r in csv.DictReader(open(files[0])):
+    rows, passes = steady(list(csv.DictReader(open(files[0]))), "Kernel_Name")
+    for r in rows:
         k = short(r["Kernel_Name"])
         n[k] += 1
         dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    return n, dur
+    return n, dur, passes
 
 
 def main():
     root, passes, out_md, out_json = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4]
     sha = sys.argv[5] if len(sys.argv) > 5 else "unknown"
-    runs = passes + 1                                   # warm-up pass included in every count
-    tn, tdur = load_trace(root)
+    tn, tdur, steady_passes = load_trace(root)
+    runs = steady_passes if steady_passes else passes + 1          # steady-state passes only (fallback: every pass, warm-up included)
     mf = load_counter(root, "SQ_VALU_MFMA_BUSY_CYCLES")
     fe = load_counter(root, "FETCH_SIZE")
     wr = load_counter(root, "WRITE_SIZE")
@@ -86,12 +102,15 @@ def main():
              "mfma_util_pmc": sum(e.get("mfma_busy_cycles_per_launch", 0) * e["launches_per_pass"] for e in kernels.values())
                               / (N_SIMD * total_us / runs * 1e3 * CLOCK_GHZ)}
     dominant = next(iter(kernels))
-    summary = {"git_sha": sha, "command": "rocprofv3 ... -- python3 scripts/profile_pass.py bf16x3 %d" % passes,
+    sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+    import bench
+    summary = {"git_sha": sha, "csrc_hash": bench.csrc_hash(), "steady_state_passes": steady_passes, "command": "rocprofv3 ... -- python3 scripts/profile_pass.py bf16x3 %d" % passes,
                "normalisation": "util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x 2.4 GHz); traffic = 2 x FETCH_SIZE + WRITE_SIZE",
                "dominant_kernel": dominant, "kernels": kernels, "whole_pass": whole}
     json.dump(summary, open(out_json, "w"), indent=1)
     with open(out_md, "w") as f:
-        f.write(f"# PMC + kernel-trace summary (commit {sha}; {passes} passes + 1 warm-up per run)\n\n")
+        f.write(f"# PMC + kernel-trace summary (commit {sha}, csrc hash {summary['csrc_hash']}; {passes} passes + 1 warm-up per run; "
+                f"counts and shares over the {steady_passes} steady-state passes between the second and the last prologue)\n\n")
         f.write("Separate rocprofv3 runs: `--kernel-trace --stats`, `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE`, `--pmc FETCH_SIZE`, "
                 "`--pmc WRITE_SIZE`, each `-- python3 scripts/profile_pass.py bf16x3 N`.\n")
         f.write("MFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x 2.4 GHz) - calibrated in 02_mfma_calibration.md; "

@@ -17,6 +17,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: soak tests (a few seconds each on the GPU; `-m gpu` still selects them)")
 
 
 def load_golden(name):

@@ -74,3 +74,95 @@ def test_gather_feats_world2_gloo(total, with_lengths):
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, total, ret, with_lengths), nprocs=2, join=True)
     assert ret[0] and ret[1]
+
+
+# ---------------------------------------------------------------- bench.py's own pass plumbing at world size 4, uneven shards
+class _MockPipe:
+    """Stands in for LADIFF on a CPU rank: `sample` returns frames that encode which text row / noise row / length each prompt
+    was given, so the gathered result shows that every rank ran ITS slice of the global batch, in global order."""
+    class _Vae:
+        def decode(self, z, lens):
+            F = max(lens)
+            out = torch.zeros(len(lens), F, 251)
+            for i, l in enumerate(lens):
+                out[i, :l, 0] = z[0, i, 0]
+            return out
+    vae = _Vae()
+
+    def __init__(self):
+        self.calls = 0
+
+    def sample(self, text, lens, init_noise=None, step_noise=None):
+        self.calls += 1
+        B = len(lens)
+        assert text.shape == (2 * B, 1, 768) and init_noise.shape == (B, 5, 256)
+        F = max(lens)
+        feats = torch.zeros(B, F, 251)
+        for i, l in enumerate(lens):
+            feats[i, :l, 0] = text[i, 0, 0]               # unconditional row of prompt i
+            feats[i, :l, 1] = text[B + i, 0, 0]           # its conditional row: the pair stays together on one rank
+            feats[i, :l, 2] = init_noise[i, 0, 0]
+            feats[i, :l, 3] = float(l)
+        return None, feats
+
+
+def _bench_worker(rank, world, port, total, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, w, _ = D.init_from_env("gloo")
+    calls = {"into": 0, "other": 0}
+    real_into, real_ag = dist.all_gather_into_tensor, dist.all_gather
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.__setitem__("into", calls["into"] + 1), real_into(*a, **k))[1]
+    dist.all_gather = lambda *a, **k: (calls.__setitem__("other", calls["other"] + 1), real_ag(*a, **k))[1]
+    try:
+        wl = bench.Workload(bench.CONFIGS["c5"], "cpu", r, w, total=total)        # mixed {60,120,196}, 251 features
+        pipe = _MockPipe()
+        out = wl.one_pass(pipe)
+        out2 = wl.one_pass(pipe)
+    finally:
+        dist.all_gather_into_tensor, dist.all_gather = real_into, real_ag
+    lens = syn.mixed_lengths(total)
+    gtext, gnoise = syn.text_embeddings(total), syn.init_noise(lens)
+    ok = out.shape == (total, max(lens), 251) and calls == {"into": 2, "other": 0} and pipe.calls == 2 and torch.equal(out, out2)
+    ok = ok and wl.glens == lens and (wl.lo, wl.hi) == D.shard_range(total, r, w) and wl.B == wl.hi - wl.lo
+    for i, l in enumerate(lens):
+        want = torch.tensor([gtext[i, 0, 0], gtext[total + i, 0, 0], gnoise[i, 0, 0], float(l)])
+        ok = ok and bool((out[i, :l, :4] == want).all()) and bool((out[i, l:] == 0).all())
+    ok = ok and torch.equal(wl.local_rows(out), out[wl.lo:wl.hi])
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [10, 7])
+def test_bench_pass_plumbing_world4_uneven_shards(total):
+    """bench.py's `Workload.one_pass` (what the timed loop calls) on 4 gloo ranks with a batch that does not divide evenly
+    (10 -> 3,3,2,2; 7 -> 2,2,2,1): global inputs sliced per rank, guidance pairs kept together, ONE all_gather_into_tensor per
+    pass, frames back in global prompt order with zeros past each length."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bench_worker, args=(4, port, total, ret), nprocs=4, join=True)
+    assert all(ret[r] for r in range(4)), dict(ret)
+
+
+def test_bench_n_gt_1_line_refers_to_a_recorded_cpu_baseline(tmp_path, monkeypatch):
+    """The N > 1 bench line carries a `cpu_baseline` object: the newest N = 1 line of the config under profiles/, marked as not
+    measured in this run - or an explicit "not available" record."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    cb = bench.recorded_cpu_baseline("headline")
+    assert cb["measured_in_this_run"] is False and cb["kind"] == "port" and "sample" in cb
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    cb = bench.recorded_cpu_baseline("headline")
+    assert cb["value"] is None and cb["measured_in_this_run"] is False
+    os.makedirs(tmp_path / "profiles" / "r9")
+    line = {"n_gpus": 1, "cpu_baseline": {"value": 17.5, "unit": "motions/s", "cores": 16, "kind": "port", "sample": "x", "gpu_over_cpu": 500}}
+    (tmp_path / "profiles" / "r9" / "bench_headline_n1.json").write_text(__import__("json").dumps(line) + "\n")
+    cb = bench.recorded_cpu_baseline("headline")
+    assert cb["value"] == 17.5 and cb["cores"] == 16 and "gpu_over_cpu" not in cb and "bench_headline_n1.json" in cb["source"]

@@ -189,6 +189,29 @@ def test_module_level_loop_matches_fused_loop(denoiser, vae):
 
 
 # ---------------------------------------------------------------- full-size properties (BASELINE configs)
+def _direct_oracle_check(z, feats, idx, lens, z_o, f_o, tol=FRAME_TOL):
+    """Rows `idx` of a full-batch run (z [T,B,256], feats [B,F,C]) against the oracle's run on those prompts alone."""
+    Fs = f_o.shape[1]
+    err = 0.0
+    for j, i in enumerate(idx):
+        l = lens[i]
+        err = max(err, maxdiff(feats[i, :min(l, Fs)], f_o[j, :min(l, Fs)]))
+        assert feats[i, l:].abs().max().item() == 0 if l < feats.shape[1] else True
+    assert err < tol, err
+    assert maxdiff(z[:, idx], z_o) < 5e-4 * max(1.0, z_o.abs().max().item())
+    return err
+
+
+_ORACLE_CACHE = {}
+
+
+def _oracle(key, fn):
+    """The CPU oracle's result for a (workload, sub-batch) is the same for both arithmetic modes: computed once per session."""
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = fn()
+    return _ORACLE_CACHE[key]
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 def test_full_size_batch_properties(denoiser, vae, precision):
     """B=128, F=196, 50-step DDIM (the benchmark's workload): samples are independent of batch composition, so a
@@ -218,6 +241,10 @@ def test_full_size_batch_properties(denoiser, vae, precision):
     z_o, f_o = orc.sample_motions(syn.denoiser_weights(), syn.vae_weights(263), sub_text, [lens[i] for i in idx],
                                   noise[idx], 50, "ddim")
     assert maxdiff(f_s, f_o) < FRAME_TOL
+    # ... and the rows of the FULL batch against the oracle directly: prompts are independent, so the oracle's run on the
+    # sub-batch is the oracle for rows `idx` of the 128-prompt run (the backlogged pipeline: 84 blocks, prefetch, deferred flags)
+    err = _direct_oracle_check(z, feats, idx, lens, z_o, f_o)
+    print(f"B=128 pipeline run, {precision}: max |frames[idx] - oracle| = {err:.3e}")
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
@@ -245,6 +272,36 @@ def test_ddpm_1000_steps_full_batch_properties(denoiser, vae, precision):
     scale = max(1.0, z.abs().max().item())
     tol = 1e-4 if precision == "fp32" else 2e-3          # 1000 stochastic guided steps amplify rounding differences between tilings
     assert maxdiff(z_s, z[:, idx]) < tol * scale
+    # the full batch's rows against the CPU oracle (config c3 at its stated size: 16 windows of the pipeline kernel)
+    oidx = [3, 126]
+    o_text = torch.cat([text[:B][oidx], text[B:][oidx]])
+    z_o, f_o = _oracle(("c3", tuple(oidx)), lambda: orc.sample_motions(
+        syn.denoiser_weights(), syn.vae_weights(263), o_text, [lens[i] for i in oidx], noise[oidx], 1000, "ddpm",
+        step_noise=sn[:, oidx].cpu().contiguous()))
+    err = 0.0
+    for j, i in enumerate(oidx):
+        err = max(err, maxdiff(feats[i, :lens[i]], f_o[j, :lens[i]]))
+    print(f"c3 (DDPM-1000, B=128), {precision}: max |frames[idx] - oracle| = {err:.3e}")
+    assert err < FRAME_TOL, err
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_256_prompts_172_blocks_against_oracle(denoiser, vae, precision):
+    """Twice the benchmark batch in one call (172 length-aware blocks: more than the rings hold, every stage backlogged): rows of
+    the full run against the CPU oracle directly."""
+    B = 256
+    lens = [196] * 250 + [60, 120, 49, 1, 100, 150]
+    text, noise = syn.text_embeddings(B, seed=21), syn.init_noise(lens, seed=22)
+    pipe = make_pipe(denoiser, vae, "ddim", 50, precision=precision)
+    z, feats = pipe.sample(text.to(DEV), lens, init_noise=noise.to(DEV))
+    pipe.check()
+    assert feats.shape == (B, 196, 263) and torch.isfinite(feats).all()
+    idx = [0, 129, 249, 250, 253, 255]
+    sub_text = torch.cat([text[:B][idx], text[B:][idx]])
+    z_o, f_o = _oracle(("b256", tuple(idx)), lambda: orc.sample_motions(
+        syn.denoiser_weights(), syn.vae_weights(263), sub_text, [lens[i] for i in idx], noise[idx], 50, "ddim"))
+    err = _direct_oracle_check(z, feats, idx, lens, z_o, f_o)
+    print(f"256 prompts, {precision}: max |frames[idx] - oracle| = {err:.3e}")
 
 
 def test_drop_in_via_yaml_style_config(denoiser):
@@ -373,7 +430,8 @@ def _subbatch_check(pipe_factory, text, lens, noise, idx, nfeats, z, feats, prec
     z_o, f_o = orc.sample_motions(syn.denoiser_weights(), syn.vae_weights(nfeats), sub_text, sub_lens, noise[idx], n_steps, sched)
     err = maxdiff(f_s, f_o)
     assert err < FRAME_TOL, err
-    return err
+    # the FULL batch's rows against the oracle directly (the oracle on the sub-batch is the oracle for those rows of the full run)
+    return max(err, _direct_oracle_check(z, feats, idx, lens, z_o, f_o))
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
@@ -583,3 +641,45 @@ def test_sampling_loop_many_text_tokens(denoiser, vae):
     z_o, f_o = orc.sample_motions(syn.denoiser_weights(), syn.vae_weights(263), text, lens, noise, 10, "ddim")
     assert maxdiff(z, z_o) < 2e-5 * max(1.0, z_o.abs().max().item())
     assert maxdiff(feats, f_o) < 1e-4
+
+
+# ---------------------------------------------------------------- test_diffusion_forward (A1: ladiff.py:1035-1109)
+def test_test_diffusion_forward_rs_set(denoiser, vae):
+    """The reference's evaluation-time caller: text -> latents -> features -> joints, and both the ground-truth and the generated
+    motion through the LA-VAE encoder; every entry of `rs_set` against the CPU oracle."""
+    lens = [196, 60, 130]
+    B = len(lens)
+    gen = torch.Generator().manual_seed(97)
+    enc_out = torch.randn(2 * B, 1, 768, generator=gen)
+    motion = torch.randn(B, 196, 263, generator=gen)
+    noise = syn.init_noise(lens, seed=98)
+    mean, std = torch.zeros(263), torch.ones(263)
+    dm = SimpleNamespace(feats2joints=None, hparams=SimpleNamespace(mean=mean.numpy(), std=std.numpy()), njoints=22)
+    seen = {}
+    def enc(texts):
+        seen["texts"] = list(texts)
+        return enc_out.to(DEV)
+    model = LADIFF(None, dm, denoiser=denoiser, vae=vae, text_encoder=enc, guidance_scale=7.5, num_inference_timesteps=5,
+                   scheduler=DDIMScheduler(set_alpha_to_one=False, steps_offset=1, **SCHED_KW))
+    orig = model._diffusion_reverse
+    model._diffusion_reverse = lambda emb, lengths: orig(emb, lengths, init_noise=noise.to(DEV))
+    torch.manual_seed(1234)
+    rs = model.test_diffusion_forward({"text": ["a", "b", "c"], "length": lens, "motion": motion.to(DEV)})
+    assert seen["texts"] == ["", "", "", "a", "b", "c"]                       # ladiff.py:1039-1047
+    assert set(rs) == {"m_rst", "lat_t", "joints_rst", "m_ref", "lat_m", "lat_rm", "joints_ref"}
+    torch.manual_seed(1234)                                                    # the two rsample() draws of the two encode calls, in order
+    e1 = torch.randn(5, B, 256, device=DEV).cpu()
+    e2 = torch.randn(5, B, 256, device=DEV).cpu()
+    z_o, f_o = orc.sample_motions(syn.denoiser_weights(), syn.vae_weights(263), enc_out, lens, noise, 5, "ddim")
+    assert maxdiff(rs["m_rst"], f_o) < FRAME_TOL
+    assert maxdiff(rs["lat_t"], z_o.permute(1, 0, 2)) < 2e-5 * max(1.0, z_o.abs().max().item())
+    assert maxdiff(rs["joints_rst"], orc.feats2joints(f_o, mean, std, 22)) < 1e-3
+    _, _, lm = orc.vae_encode(syn.vae_weights(263), motion, lens, e1)
+    _, _, lrm = orc.vae_encode(syn.vae_weights(263), f_o, lens, e2)
+    assert maxdiff(rs["lat_m"], lm.permute(1, 0, 2)) < 1e-4 * max(1.0, lm.abs().max().item())
+    assert maxdiff(rs["lat_rm"], lrm.permute(1, 0, 2)) < 1e-3 * max(1.0, lrm.abs().max().item())
+    assert torch.equal(rs["m_ref"].cpu(), motion)
+    assert maxdiff(rs["joints_ref"], orc.feats2joints(motion, mean, std, 22)) < 1e-3
+    # finetune_decoder=True / no ground truth: the three generation entries only (:1092)
+    rs2 = model.test_diffusion_forward({"text": ["a", "b", "c"], "length": lens})
+    assert set(rs2) == {"m_rst", "lat_t", "joints_rst"}

@@ -160,6 +160,7 @@ def test_xcd_placement_on_and_off_agree(nets):
         L.ladiff_debug_set_xcd_local(1)
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
 def test_repeated_full_size_calls_are_identical(nets, precision):
     """The loop is deterministic: the benchmark-size call (84 length-aware blocks, 50 steps - the partial planes' 16-slot rings
@@ -174,7 +175,7 @@ def test_repeated_full_size_calls_are_identical(nets, precision):
     text, noise = syn.text_embeddings(128, seed=5).to(DEV), syn.init_noise(lens, seed=6).to(DEV)
     text_s, noise_s = syn.text_embeddings(len(sub), seed=7).to(DEV), syn.init_noise(sub, seed=8).to(DEV)
     ref = ref_s = None
-    for it in range(12):
+    for it in range(100):                                          # a soak: ~4 s per arithmetic mode
         z = pipe._diffusion_reverse(text, lens, init_noise=noise)
         assert pipe.loop_status() == (0, 0)
         zs = pipe._diffusion_reverse(text_s, sub, init_noise=noise_s)
@@ -220,3 +221,74 @@ def test_pipeline_ddpm_windows(nets):
     za = run(nets, "launches", "bf16x3", B, T, n, lens, sched="ddpm", step_noise=sn)
     zb = run(nets, "pipeline", "bf16x3", B, T, n, lens, sched="ddpm", step_noise=sn)
     assert (za - zb).abs().max().item() < 5e-4 * max(1.0, za.abs().max().item())
+
+
+# ---------------------------------------------------------------- an abandoned pipeline launch
+def _fault_pipe(nets, **kw):
+    den, vae = nets
+    return LADIFF(denoiser=den, vae=vae, scheduler=DDIMScheduler(set_alpha_to_one=False, steps_offset=1, **SCHED_KW),
+                  guidance_scale=7.5, num_inference_timesteps=8, eta=0.0, max_it=5, precision="bf16x3", loop="pipeline", **kw)
+
+
+def test_aborted_pipeline_launch_raises_poisons_and_recovers(nets):
+    """One stage workgroup never publishes (test switch) and the waits are bounded to 20 ms: the loop is abandoned.  The product
+    path must not hand back partial latents: z is NaN, `check()` / the next call / `loop_ms()` raise LadiffHipError, the status is
+    sticky over a windowed schedule, and the next call - fault removed - is clean and bit-identical to a run that never failed."""
+    from ladiff_amd import _lib
+    L = _lib.lib()
+    lens = [196, 60, 120, 100, 48, 150, 196, 30, 77, 196, 13]
+    B = len(lens)
+    text, noise = syn.text_embeddings(B, seed=41), syn.init_noise(lens, seed=42)
+    good = _fault_pipe(nets)._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV))
+    pipe = _fault_pipe(nets)
+    try:
+        assert L.ladiff_debug_set_pipeline_fault(17, 20) == 0          # workgroup 17 of 255 leaves at once; waits time out after 20 ms
+        z = pipe._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV))
+        assert torch.isnan(z).all()                                    # poisoned, not "plausible garbage"
+        with pytest.raises(_lib.LadiffHipError, match="abandoned"):
+            pipe.check()
+        pipe.check()                                                   # reported once
+        z = pipe._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV))
+        with pytest.raises(_lib.LadiffHipError):                       # the NEXT call notices by itself
+            pipe._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV))
+        # fallback=True: the same call is re-run launch-per-stage in this process and matches the oracle
+        fb = _fault_pipe(nets, fallback=True)
+        zf = fb._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV))
+        assert fb.fallback_count == 1 and torch.isfinite(zf).all()
+        assert (zf - good).abs().max().item() < 2e-4 * max(1.0, good.abs().max().item())     # launches vs pipeline: summation order only
+        # a windowed schedule (200 DDPM steps = 4 launches): the abort of the first window is not erased by the later ones
+        sn = syn.ddpm_noise(200, B, seed=5).to(DEV)
+        den, vae = nets
+        wp = LADIFF(denoiser=den, vae=vae, scheduler=DDPMScheduler(variance_type="fixed_small", **SCHED_KW), guidance_scale=7.5,
+                    num_inference_timesteps=200, eta=0.0, max_it=5, precision="bf16x3", loop="pipeline")
+        zw = wp._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV), step_noise=sn)
+        assert torch.isnan(zw).all() and wp.loop_status()[0] == 2
+        with pytest.raises(_lib.LadiffHipError):
+            wp.check()
+    finally:
+        assert L.ladiff_debug_set_pipeline_fault(-1, 0) == 0
+    # fault removed: clean, and the same bits as the run that never failed
+    z2 = pipe._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV))
+    pipe.check()
+    assert pipe.loop_status() == (0, 0) and torch.equal(z2, good)
+    assert fb.fallback_count == 1
+    zf2 = fb._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV))
+    assert fb.fallback_count == 1 and torch.equal(zf2, good)
+
+
+def test_fallback_result_matches_oracle(nets):
+    """The in-process fallback (launch-per-stage re-run of an abandoned call) against the CPU oracle on the decoded frames."""
+    from ladiff_amd import _lib
+    from oracle import ladiff_oracle as orc
+    L = _lib.lib()
+    lens = [196, 60, 130]
+    text, noise = syn.text_embeddings(3, seed=43), syn.init_noise(lens, seed=44)
+    fb = _fault_pipe(nets, fallback=True)
+    try:
+        assert L.ladiff_debug_set_pipeline_fault(100, 20) == 0
+        z, feats = fb.sample(text.to(DEV), lens, init_noise=noise.to(DEV))
+    finally:
+        L.ladiff_debug_set_pipeline_fault(-1, 0)
+    assert fb.fallback_count == 1
+    z_o, f_o = orc.sample_motions(syn.denoiser_weights(), syn.vae_weights(263), text, lens, noise, 8, "ddim")
+    assert (feats.cpu() - f_o).abs().max().item() < 1e-3
