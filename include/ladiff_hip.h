@@ -108,6 +108,15 @@ int ladiff_gemm_split(const float* A, int lda, const float* A2, int lda2, int K1
  * S-format, Y (may then be NULL) in fp32.  ladiff_split_rows converts fp32 [R,K] -> S-format [R,K]. */
 int ladiff_split_rows(const float* x, float* y, int R, int K, ladiff_stream_t stream);
 
+/* The decoder layer's feed-forward block as ONE kernel, bf16x3 arithmetic (csrc/dec_mlp.hip):
+ *   y / ys [M,256] = LN( x + W2 gelu(W1 x + b1) + b2 ), then a second LayerNorm when ln2_gamma != NULL
+ * TransformerDecoderLayer.forward_post, cross_attention.py:410-412 (tgt = norm3(tgt + linear2(gelu(linear1(tgt))))) and, on the
+ * last layer, decoder.norm (:150-151).  xs = S-format twin of x (the operand; x is the fp32 residual), w1s [1024,256] and
+ * w2s [256,1024] S-format (ladiff_split_rows), b1 [1024], b2 [256]; y fp32 and / or ys S-format (either may be NULL). */
+int ladiff_mlp_ln_fused(const float* xs, const float* x, const float* w1s, const float* b1, const float* w2s, const float* b2,
+                        const float* ln_gamma, const float* ln_beta, const float* ln2_gamma, const float* ln2_beta, float* y,
+                        float* ys, int M, ladiff_stream_t stream);
+
 /* Rows of 256: x = sum of n_planes partial planes [n_planes][M][256] + bias (+ res), then
  *   mode 0: x;   mode 1: LN(x);   mode 2: LN(x) + table[sample row | pad_row] (rows grouped T per sample, sample = row / T, padded when
  *   row % T >= counts[sample % Bs]);   mode 3: SiLU(LN(x) * (1 + table[0:256]) + table[256:512]).
@@ -244,6 +253,9 @@ int ladiff_debug_set_stage_waves(int waves_per_simd);
  * reports a placement that disagrees with the others (test aid: the launch must then agree to write through everywhere and still
  * give the same bits; ladiff_reverse_status reports code 0, info -1 for such a launch). */
 int ladiff_debug_set_xcd_local(int on);
+/* Measurement switch (process-wide): 1 (default) = the decoder's feed-forward block runs as the fused kernel of csrc/dec_mlp.hip in
+ * bf16x3 mode, 0 = as linear1 GEMM + linear2 GEMM + LayerNorm row kernel (the round-2 path; same arithmetic per product). */
+int ladiff_debug_set_decoder_fusion(int on);
 /* The block plan ladiff_diffusion_reverse would use for a batch (host arithmetic only, no GPU call): rows per block (16 = the
  * length-aware packing, 32 = padded blocks) and the number of blocks.  h_counts = latent counts on the host or NULL, masked = the
  * call passes device counts, loop_mode 1 / 2 / 3 as ladiff_sampler_set_loop, bf16x3 = the call passes w_split. */

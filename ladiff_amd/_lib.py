@@ -37,6 +37,8 @@ _SIGNATURES = {
                                      c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ladiff_gemm_split": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                   c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ladiff_mlp_ln_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_int, c_void_p]),
     "ladiff_split_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ladiff_combine_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -105,6 +107,7 @@ _SIGNATURES = {
                                   c_void_p, c_size_t, c_void_p]),
     "ladiff_debug_set_stage_waves": (c_int, [c_int]),
     "ladiff_debug_set_xcd_local": (c_int, [c_int]),
+    "ladiff_debug_set_decoder_fusion": (c_int, [c_int]),
     "ladiff_reverse_plan": (c_int, [c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ladiff_vae_decode_ragged": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                          c_int, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -338,6 +338,12 @@ int ladiff_debug_set_stage_waves(int waves_per_simd) {
     return 0;
 }
 
+int ladiff_debug_set_decoder_fusion(int on) {
+    LADIFF_CHECK_ARG(on == 0 || on == 1);
+    g_dec_fused_mlp = on;
+    return 0;
+}
+
 int ladiff_debug_set_xcd_local(int on) {
     LADIFF_CHECK_ARG(on >= 0 && on <= 2);
     g_xcd_local = on;
@@ -415,6 +421,14 @@ int ladiff_reverse_status(void* ws, int B, int T, int n_steps, int n_text, int* 
 }
 
 size_t ladiff_reverse_workspace_bytes(int B, int T, int n_steps, int n_text) { return carve_reverse(nullptr, B, T, n_steps, n_text).total_bytes; }
+
+int ladiff_mlp_ln_fused(const float* xs, const float* x, const float* w1s, const float* b1, const float* w2s, const float* b2,
+                        const float* ln_gamma, const float* ln_beta, const float* ln2_gamma, const float* ln2_beta, float* y, float* ys,
+                        int M, ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(xs && x && w1s && b1 && w2s && b2 && ln_gamma && ln_beta && (y || ys) && M >= 0);
+    if ((ln2_gamma == nullptr) != (ln2_beta == nullptr)) return LADIFF_ERR_ARG;
+    return launch_dec_mlp(xs, x, w1s, b1, w2s, b2, ln_gamma, ln_beta, ln2_gamma, ln2_beta, y, ys, M, S(stream));
+}
 
 int ladiff_split_rows(const float* x, float* y, int R, int K, ladiff_stream_t stream) {
     LADIFF_CHECK_ARG(x && y && R >= 0 && K > 0);

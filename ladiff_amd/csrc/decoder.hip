@@ -5,6 +5,8 @@
 
 namespace ladiff {
 
+int g_dec_fused_mlp = 1;          // measurement switch (ladiff_debug_set_decoder_fusion): 0 = linear1 / linear2 / LayerNorm as three launches
+
 static GemmArgs lin(const float* A, int lda, const float* W, const float* bias, float* Y, int ldy, int M, int N, int K,
                     int act = ACT_NONE) {
     GemmArgs g;
@@ -134,16 +136,18 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
         // (the q / out projections are folded into the <= 8 keys / values per sample: dec_cross.hip; fp32 in both modes)
         LADIFF_TRY(launch_decoder_cross_apply(P[1], L.cross_attn.out_b, L.norm2.g, L.norm2.b, counts, B, F, T, guws + l * gu_l, P[2],
                                               Ps[2], s, row_off, n1_late ? n1_late->g : nullptr, n1_late ? n1_late->b : nullptr));
-        // ---- feed-forward, GELU(erf)   :410-412
-        {
+        // ---- feed-forward, GELU(erf), + residual + norm3 (+ decoder.norm on the last layer, cross_attention.py:150-151)   :410-412
+        float* dst = is_in ? SK[l] : P[0];
+        float* dsts = is_in ? SKs[l] : Ps[0];
+        if (sp && g_dec_fused_mlp) {     // one kernel: the hidden rows never leave the registers (dec_mlp.hip)
+            LADIFF_TRY(launch_dec_mlp(Ps[2], P[2], Ls.lin1.w, L.lin1.b, Ls.lin2.w, L.lin2.b, L.norm3.g, L.norm3.b,
+                                      last ? w.norm.g : nullptr, last ? w.norm.b : nullptr, dst, dsts, M, s));
+        } else {
             GemmArgs g = lin(sp ? Ps[2] : P[2], D, Ls.lin1.w, L.lin1.b, sp ? nullptr : hid, FF, M, FF, D, ACT_GELU);
             g.split = sp ? 1 : 0; if (sp) g.Ys = hid;
             LADIFF_TRY(launch_gemm(g, s));
+            LADIFF_TRY(gemm_ln(hid, FF, L.lin2.w, Ls.lin2.w, L.lin2.b, P[2], L.norm3, last ? &w.norm : nullptr, dst, dsts));
         }
-        float* dst = is_in ? SK[l] : P[0];
-        float* dsts = is_in ? SKs[l] : Ps[0];
-        // norm3 (+ decoder.norm on the last layer, cross_attention.py:150-151)
-        LADIFF_TRY(gemm_ln(hid, FF, L.lin2.w, Ls.lin2.w, L.lin2.b, P[2], L.norm3, last ? &w.norm : nullptr, dst, dsts));
         cur = dst; curs = dsts;
     }
     // final_layer + zero padded frames, written as [B, F, C]   ladiff_vae.py:356-360

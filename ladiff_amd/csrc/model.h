@@ -35,9 +35,14 @@ int linear_cross_attention(const DenoiserW& w, int layer, const float* x, const 
 size_t linear_cross_attention_ws_floats(int B, int T, int N);
 void den_loop_io(float* ws, int rows, float** x, float** xs);
 
+extern int g_dec_fused_mlp;
 size_t dec_ws_floats(int B, size_t rows, int T);
 int vae_decode(const DecoderW& w, const DecoderW* w_split, const float* z, const int32_t* lengths, const int32_t* counts,
                const int32_t* row_off, int R, int B, int F, int T, int C, float* feats, float* ws, size_t ws_floats, hipStream_t s);
+
+// dec_mlp.hip: the decoder layer's feed-forward block (linear1, GELU, linear2, residual, LayerNorm[s]) as one kernel, bf16x3 mode
+int launch_dec_mlp(const float* xs, const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* g3,
+                   const float* be3, const float* g4, const float* be4, float* y, float* ys, int M, hipStream_t s);
 
 size_t enc_ws_floats(int B, int F, int T, int C);
 int vae_encode(const EncoderW& w, const EncoderW* w_split, const float* features, const int32_t* lengths,

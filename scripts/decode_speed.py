@@ -1,0 +1,33 @@
+"""LA-VAE decode alone at the benchmark size (128 x 196 frames) and at config c1's (8 x 60), both arithmetic modes, with the
+decoder's feed-forward block fused (csrc/dec_mlp.hip) and as three launches: HIP-event ms per decode."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from ladiff_amd import LADiffVae, _lib, synthetic as syn
+from test_abi import ABL, VAE_KW
+dev = "cuda:0"
+vae = LADiffVae(ABL, **VAE_KW); vae.load_state_dict(syn.vae_weights(263)); vae = vae.to(dev).eval()
+L = _lib.lib()
+for B, F in ((128, 196), (8, 60)):
+    lens = [F] * B
+    z = torch.randn(5, B, 256, generator=torch.Generator().manual_seed(1)).to(dev)
+    for i, m in enumerate(syn.max_iter_elements(lens)):
+        z[m:, i] = 0
+    for prec in ("bf16x3", "fp32"):
+        vae.precision = prec
+        for fused in ((1, 0) if prec == "bf16x3" else (1,)):
+            L.ladiff_debug_set_decoder_fusion(fused)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s), torch.no_grad():
+                for _ in range(3):
+                    out = vae.decode(z, lens)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                n = 20
+                e0.record(s)
+                for _ in range(n):
+                    out = vae.decode(z, lens)
+                e1.record(s)
+                torch.cuda.synchronize()
+            print(f"decode B={B} F={F} {prec} fused_mlp={fused}: {e0.elapsed_time(e1) / n:.3f} ms  (max |feats| {out.abs().max().item():.3f})")
+L.ladiff_debug_set_decoder_fusion(1)

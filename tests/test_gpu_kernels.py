@@ -377,3 +377,76 @@ def test_self_attention_bf16x3_key_bitmap_matches_fp32_kernel():
     _lib.check(lib().ladiff_self_attention_bf16x3(_lib.ptr(qd), None, bits.data_ptr(), _lib.ptr(b_), B, Fr, 4, 0, _lib.stream_ptr()))
     sync()
     assert (a - b_).abs().max().item() < 2e-4 and (a - b_).abs().max().item() > 0
+
+
+# ---------------------------------------------------------------- fused decoder feed-forward block (csrc/dec_mlp.hip)
+def split_rows(t):
+    """fp32 [R,K] on the GPU -> its S-format twin (bf16 hi | lo blocks)."""
+    s = torch.empty_like(t)
+    _lib.check(lib().ladiff_split_rows(_lib.ptr(t), _lib.ptr(s), t.shape[0], t.shape[1], _lib.stream_ptr()))
+    return s
+
+
+def unsplit_rows(s):
+    """S-format [R,K] -> fp32 (hi + lo), on the CPU."""
+    R, K = s.shape
+    b = s.cpu().contiguous().view(torch.bfloat16).view(R, K // 64, 2, 64).float()
+    return (b[:, :, 0] + b[:, :, 1]).reshape(R, K)
+
+
+@pytest.mark.parametrize("M,second_ln", [(1, False), (17, True), (480, False), (1000, True), (4133, False)])
+def test_fused_mlp_layernorm(M, second_ln):
+    """y = LN(x + W2 gelu(W1 x + b1) + b2) [then a second LN] in one kernel (bf16x3 products, everything else fp32) against
+    fp64: row counts that leave waves / lanes of the last 128-row workgroup without rows; fp32 and S-format outputs agree.
+    Asymmetric weights and inputs: a wrong row permutation of a weight panel or a wrong k order shows up as O(1) errors."""
+    x = rnd(M, 256, scale=2.0, seed=1)
+    w1, b1 = rnd(1024, 256, scale=1 / 16, seed=2), rnd(1024, scale=0.5, seed=3)
+    w2, b2 = rnd(256, 1024, scale=1 / 32, seed=4), rnd(256, scale=0.5, seed=5)
+    g3, be3 = 1 + 0.1 * rnd(256, seed=6), 0.1 * rnd(256, seed=7)
+    g4, be4 = 1 + 0.1 * rnd(256, seed=8), 0.1 * rnd(256, seed=9)
+    d = lambda t: t.to(DEV).contiguous()
+    xd, w1d, w2d = d(x), d(w1), d(w2)
+    xs, w1s, w2s = split_rows(xd), split_rows(w1d), split_rows(w2d)
+    b1d, b2d, g3d, be3d, g4d, be4d = d(b1), d(b2), d(g3), d(be3), d(g4), d(be4)
+    y = torch.full((M, 256), float("nan"), device=DEV)
+    ys = torch.zeros(M, 256, device=DEV)
+    _lib.check(lib().ladiff_mlp_ln_fused(_lib.ptr(xs), _lib.ptr(xd), _lib.ptr(w1s), _lib.ptr(b1d), _lib.ptr(w2s), _lib.ptr(b2d),
+                                         _lib.ptr(g3d), _lib.ptr(be3d), _lib.ptr(g4d) if second_ln else None,
+                                         _lib.ptr(be4d) if second_ln else None, _lib.ptr(y), _lib.ptr(ys), M, _lib.stream_ptr()))
+    sync()
+    h = F.gelu(F.linear(x.double(), w1.double(), b1.double()))
+    want = F.layer_norm(x.double() + F.linear(h, w2.double(), b2.double()), (256,), g3.double(), be3.double(), 1e-5)
+    if second_ln:
+        want = F.layer_norm(want, (256,), g4.double(), be4.double(), 1e-5)
+    err = (y.cpu().double() - want).abs().max().item()
+    assert torch.isfinite(y).all() and err < 2e-4, err                    # ~2^-16 per product, O(1) normalised outputs
+    assert (unsplit_rows(ys).double() - y.cpu().double()).abs().max().item() < 1e-4     # the S-format twin: 16 significant bits
+    # only one of the two outputs requested
+    y2 = torch.full((M, 256), float("nan"), device=DEV)
+    _lib.check(lib().ladiff_mlp_ln_fused(_lib.ptr(xs), _lib.ptr(xd), _lib.ptr(w1s), _lib.ptr(b1d), _lib.ptr(w2s), _lib.ptr(b2d),
+                                         _lib.ptr(g3d), _lib.ptr(be3d), _lib.ptr(g4d) if second_ln else None,
+                                         _lib.ptr(be4d) if second_ln else None, _lib.ptr(y2), None, M, _lib.stream_ptr()))
+    sync()
+    assert torch.equal(y, y2)
+
+
+def test_fused_mlp_matches_three_launch_path_on_a_decode():
+    """LADiffVae.decode in bf16x3 mode with the feed-forward block fused (default) and as linear1 / linear2 / LayerNorm launches
+    (the round-2 path, same products): the frames agree to rounding."""
+    from ladiff_amd import LADiffVae, synthetic as syn
+    from test_abi import ABL, VAE_KW
+    vae = LADiffVae(ABL, **VAE_KW); vae.load_state_dict(syn.vae_weights(263)); vae = vae.to(DEV).eval()
+    vae.precision = "bf16x3"
+    lens = [196, 60, 120, 1, 77, 196, 48, 150, 33]
+    z = torch.randn(5, len(lens), 256, generator=torch.Generator().manual_seed(4)).to(DEV)
+    for i, l in enumerate(lens):
+        z[-(-l // 48):, i] = 0
+    try:
+        assert lib().ladiff_debug_set_decoder_fusion(0) == 0
+        a = vae.decode(z, lens)
+        assert lib().ladiff_debug_set_decoder_fusion(1) == 0
+        b = vae.decode(z, lens)
+    finally:
+        lib().ladiff_debug_set_decoder_fusion(1)
+    assert torch.isfinite(b).all() and (a - b).abs().max().item() < 5e-5 * max(1.0, a.abs().max().item())
+    assert lib().ladiff_debug_set_decoder_fusion(2) != 0

@@ -673,13 +673,17 @@ def test_test_diffusion_forward_rs_set(denoiser, vae):
     z_o, f_o = orc.sample_motions(syn.denoiser_weights(), syn.vae_weights(263), enc_out, lens, noise, 5, "ddim")
     assert maxdiff(rs["m_rst"], f_o) < FRAME_TOL
     assert maxdiff(rs["lat_t"], z_o.permute(1, 0, 2)) < 2e-5 * max(1.0, z_o.abs().max().item())
-    assert maxdiff(rs["joints_rst"], orc.feats2joints(f_o, mean, std, 22)) < 1e-3
+    # joints integrate the root velocity / yaw over the frames (recover_from_ric's cumulative sums amplify a 1e-5 feature
+    # difference): the joints are held to the oracle's feats2joints of the SAME features, relative to their size
+    j_o = orc.feats2joints(rs["m_rst"].cpu(), mean, std, 22)
+    assert maxdiff(rs["joints_rst"], j_o) < 1e-4 * max(1.0, j_o.abs().max().item())
     _, _, lm = orc.vae_encode(syn.vae_weights(263), motion, lens, e1)
     _, _, lrm = orc.vae_encode(syn.vae_weights(263), f_o, lens, e2)
     assert maxdiff(rs["lat_m"], lm.permute(1, 0, 2)) < 1e-4 * max(1.0, lm.abs().max().item())
     assert maxdiff(rs["lat_rm"], lrm.permute(1, 0, 2)) < 1e-3 * max(1.0, lrm.abs().max().item())
     assert torch.equal(rs["m_ref"].cpu(), motion)
-    assert maxdiff(rs["joints_ref"], orc.feats2joints(motion, mean, std, 22)) < 1e-3
+    j_r = orc.feats2joints(motion, mean, std, 22)
+    assert maxdiff(rs["joints_ref"], j_r) < 1e-4 * max(1.0, j_r.abs().max().item())
     # finetune_decoder=True / no ground truth: the three generation entries only (:1092)
     rs2 = model.test_diffusion_forward({"text": ["a", "b", "c"], "length": lens})
     assert set(rs2) == {"m_rst", "lat_t", "joints_rst"}
