@@ -254,8 +254,12 @@ int ladiff_debug_set_stage_waves(int waves_per_simd);
  * give the same bits; ladiff_reverse_status reports code 0, info -1 for such a launch). */
 int ladiff_debug_set_xcd_local(int on);
 /* Measurement switch (process-wide): 1 (default) = the decoder's feed-forward block runs as the fused kernel of csrc/dec_mlp.hip in
- * bf16x3 mode, 0 = as linear1 GEMM + linear2 GEMM + LayerNorm row kernel (the round-2 path; same arithmetic per product). */
+ * bf16x3 mode from 10,000 frame rows up, 2 = at every size, 0 = as linear1 GEMM + linear2 GEMM + LayerNorm row kernel (the round-2
+ * path; same arithmetic per product). */
 int ladiff_debug_set_decoder_fusion(int on);
+/* Measurement switch (process-wide) of the fused feed-forward kernel's form: 0 (default) = chosen by the row count, 1 = 128-row
+ * workgroups of eight waves x 16 rows, 2 = 64-row workgroups of four waves x 16 rows, 3 = 128-row workgroups of four waves x 32 rows. */
+int ladiff_debug_set_mlp_variant(int v);
 /* The block plan ladiff_diffusion_reverse would use for a batch (host arithmetic only, no GPU call): rows per block (16 = the
  * length-aware packing, 32 = padded blocks) and the number of blocks.  h_counts = latent counts on the host or NULL, masked = the
  * call passes device counts, loop_mode 1 / 2 / 3 as ladiff_sampler_set_loop, bf16x3 = the call passes w_split. */

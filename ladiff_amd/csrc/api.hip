@@ -338,8 +338,14 @@ int ladiff_debug_set_stage_waves(int waves_per_simd) {
     return 0;
 }
 
+int ladiff_debug_set_mlp_variant(int v) {
+    LADIFF_CHECK_ARG((v >= 0 && v <= 3) || (v >= 11 && v <= 13));
+    g_mlp_variant = v;
+    return 0;
+}
+
 int ladiff_debug_set_decoder_fusion(int on) {
-    LADIFF_CHECK_ARG(on == 0 || on == 1);
+    LADIFF_CHECK_ARG(on >= 0 && on <= 2);
     g_dec_fused_mlp = on;
     return 0;
 }

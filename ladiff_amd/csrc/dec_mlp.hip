@@ -28,7 +28,6 @@ namespace ladiff {
 
 namespace {
 
-constexpr int MLP_BM = 128;                    // rows per workgroup
 constexpr int MLP_NS = 8;                      // ring stages
 constexpr int MLP_STAGE = 16384;               // bytes: 128 weight rows x 128 B
 constexpr int MLP_AHEAD = 6;                   // stages in flight behind the one being multiplied
@@ -65,46 +64,61 @@ __device__ __forceinline__ bf16x8 as_bf(const u32x4_m v) { return __builtin_bit_
 
 }  // namespace
 
-__global__ __launch_bounds__(512, 2) void dec_mlp_kernel(const MlpArgs p) {
+// NW = waves per workgroup, RT = 16-row tiles per wave: a workgroup owns 16 RT NW rows.
+//   <4, 2>: 128 rows, ONE wave per SIMD with 32 rows: every weight fragment read from LDS feeds two row tiles (6 MFMAs per 2 KB
+//           instead of 3: with 16 rows per wave the kernel ran at the LDS-read latency, 1100 - 1800 cycles per stage for 384 - 768 of
+//           MFMA, profiles/r3), the wave's four LDS-DMA pieces of a stage are issued one after each group of 12 MFMAs;
+//   <8, 1>: 128 rows, two waves per SIMD with 16 rows each (the first half of the waves issues its DMA early in a stage, the second
+//           half late: partners must not do the same thing at the same time);
+//   <4, 1>: 64 rows (twice as many workgroups when there are few rows).
+// DIAG (timing experiments only, results are garbage): 1 = no LDS-DMA inside the stage loop, 2 = no MFMAs, 3 = no LDS fragment reads
+template <int NW, int RT, int DIAG = 0>
+__global__ __launch_bounds__(64 * NW, NW / 4) void dec_mlp_kernel(const MlpArgs p) {
+    constexpr int NT = 64 * NW, RW = 16 * RT, BM = RW * NW, PPW = 16 / NW;   // threads, rows per wave / workgroup, DMA pieces per wave and stage
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     float* const b1s = reinterpret_cast<float*>(lds + MLP_NS * MLP_STAGE);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fk = lane >> 4;
-    const int row0 = blockIdx.x * MLP_BM + 16 * wave;
     const int M = p.M;
-    int myrow = row0 + frow;
-    const bool live = myrow < M;
-    myrow = live ? myrow : M - 1;
+    int myrow[RT]; bool live[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        myrow[rt] = blockIdx.x * BM + RW * wave + 16 * rt + frow;
+        live[rt] = myrow[rt] < M;
+        myrow[rt] = live[rt] ? myrow[rt] : M - 1;
+    }
 
     // ---- this wave's x rows as operand fragments: k-step s (32 columns) -> hi / lo 16 bytes of lane (row frow, k 8 fk .. + 7)
-    bf16x8 xh[8], xl[8];
-    {
-        const char* xr = reinterpret_cast<const char*>(p.xs) + (size_t)myrow * 1024 + fk * 16;
+    bf16x8 xh[RT][8], xl[RT][8];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const char* xr = reinterpret_cast<const char*>(p.xs) + (size_t)myrow[rt] * 1024 + fk * 16;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            xh[s] = *reinterpret_cast<const bf16x8*>(xr + (s >> 1) * 256 + (s & 1) * 64);
-            xl[s] = *reinterpret_cast<const bf16x8*>(xr + (s >> 1) * 256 + (s & 1) * 64 + 128);
+            xh[rt][s] = *reinterpret_cast<const bf16x8*>(xr + (s >> 1) * 256 + (s & 1) * 64);
+            xl[rt][s] = *reinterpret_cast<const bf16x8*>(xr + (s >> 1) * 256 + (s & 1) * 64 + 128);
         }
     }
-    for (int i = tid; i < FF / 4; i += 512) st4(b1s + 4 * i, ld4(p.b1 + 4 * i));
+    for (int i = tid; i < FF / 4; i += NT) st4(b1s + 4 * i, ld4(p.b1 + 4 * i));
 
-    // ---- LDS-DMA of one stage: wave w brings LDS rows 64 g + 8 w + (lane >> 3), g = 0, 1 (a piece = 8 rows x 128 B)
-    const int prow = 8 * wave + (lane >> 3);                             // LDS row within a 64-row half
-    const int cs = (lane & 7) ^ ((prow >> 1) & 7);                       // source slot that lands in LDS slot (lane & 7)
+    // ---- LDS-DMA of one stage: wave w brings the PPW pieces (a piece = 8 LDS rows x 128 B) q = w + NW i: LDS rows 8 q + (lane >> 3)
+    const int cs = (lane & 7) ^ ((lane >> 4) & 3) ^ (4 * (wave & 1));    // source slot that lands in LDS slot (lane & 7): slot ^ ((row >> 1) & 7), row = 8 q + (lane >> 3), q = wave (mod 2) for even NW
     const int koff = (cs < 4 ? cs * 4 : 32 + (cs - 4) * 4);              // floats inside the 64-float S-block: hi | lo halves
-    const int src0 = pi_row(prow), src1 = pi_row(64 + prow);            // weight rows (within the panel) of this lane's two pieces
-    char* const dma_dst = lds + prow * 0 + (8 * wave) * 128;             // + 64 g rows; the hardware adds lane * 16
-    // stage (hs, u): u < 8: W1 rows 128 hs .., k-step u;  u >= 8: v = u - 8, k-step c = v >> 1 of the hidden slice, W2 rows 128 (v & 1) ..
-    auto issue = [&](int hs, auto uc, auto slotc) __attribute__((always_inline)) {
-        constexpr int u = decltype(uc)::value, slot = decltype(slotc)::value;
+    int src[PPW];                                                        // weight rows (within the panel) behind this lane's pieces
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) src[i] = pi_row(8 * (wave + NW * i) + (lane >> 3));
+    char* const dma_dst = lds + (8 * wave) * 128;                        // + 8 NW i rows; the hardware adds lane * 16
+    // piece i of stage (hs, u): u < 8: W1 rows 128 hs .., k-step u;  u >= 8: v = u - 8, k-step c = v >> 1 of the hidden slice, W2 rows 128 (v & 1) ..
+    auto issue = [&](int hs, auto uc, auto slotc, auto ic) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value, slot = decltype(slotc)::value, i = decltype(ic)::value;
         const float* base; int ldw, n0, kb, half;
-        if constexpr (u < 8) { base = p.w1; ldw = D; n0 = 128 * hs; kb = u >> 1; half = u & 1; }
-        else { constexpr int v = u - 8, c = v >> 1; base = p.w2; ldw = FF; n0 = 128 * (v & 1); kb = 2 * hs + (c >> 1); half = c & 1; }
-        const float* s0 = base + (size_t)(n0 + src0) * ldw + kb * 64 + half * 16 + koff;
-        const float* s1 = base + (size_t)(n0 + src1) * ldw + kb * 64 + half * 16 + koff;
-        __builtin_amdgcn_global_load_lds(s0, (__attribute__((address_space(3))) void*)(dma_dst + slot * MLP_STAGE), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(s1, (__attribute__((address_space(3))) void*)(dma_dst + slot * MLP_STAGE + 64 * 128), 16, 0, 0);
+        const int hsv = hs < 0 ? 0 : hs;
+        if constexpr (u < 8) { base = p.w1; ldw = D; n0 = 128 * hsv; kb = u >> 1; half = u & 1; }
+        else { constexpr int v = u - 8, c = v >> 1; base = p.w2; ldw = FF; n0 = 128 * (v & 1); kb = 2 * hsv + (c >> 1); half = c & 1; }
+        const float* s0 = base + (size_t)(n0 + src[i]) * ldw + kb * 64 + half * 16 + koff;
+        if constexpr (DIAG == 1) { if (hs >= 0) return; }
+        __builtin_amdgcn_global_load_lds(s0, (__attribute__((address_space(3))) void*)(dma_dst + slot * MLP_STAGE + 8 * NW * i * 128), 16, 0, 0);
     };
 
     // fragment read addresses: tile j of a stage = LDS rows 16 j + frow; hi slot fk, lo slot 4 + fk, XORed with (frow >> 1) & 7
@@ -113,20 +127,24 @@ __global__ __launch_bounds__(512, 2) void dec_mlp_kernel(const MlpArgs p) {
     const unsigned rd_lo = lds_addr(lds) + frow * 128 + (((4 + fk) ^ sw) << 4);
     const unsigned rd_hi2 = rd_hi + 4 * MLP_STAGE, rd_lo2 = rd_lo + 4 * MLP_STAGE;     // slots 4..7: the offset field holds 16 bits
 
-    f32x4 hacc[8], oacc[16];
-    bf16x8 hh[4], hl[4];
+    f32x4 hacc[RT][8], oacc[RT][16];
+    bf16x8 hh[RT][4], hl[RT][4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) oacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) oacc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // one stage's products: acc[j0 + j] += W(tile j) . b^T over its 32 k, j < 8; three bf16 MFMAs per product (x_lo W_hi, x_hi W_lo,
-    // x_hi W_hi: the order of gemm_big_split_kernel).  The fragments of the next tile pair are requested before a pair's MFMAs.
-    auto stage_mma = [&](auto slotc, f32x4* acc, const bf16x8 bh, const bf16x8 bl) __attribute__((always_inline)) {
-        constexpr int slot = decltype(slotc)::value;
+    // one stage's products: acc[rt][J0 + j] += W(tile j) . b[rt]^T over its 32 k, j < 8; three bf16 MFMAs per product (x_lo W_hi,
+    // x_hi W_lo, x_hi W_hi: the order of gemm_big_split_kernel), one product at a time over a tile pair's 2 RT accumulators.  The
+    // fragments of the next tile pair are requested before a pair's MFMAs; between(g) runs after the MFMAs of pair g.
+    auto stage_mma = [&](auto slotc, auto& acc, auto j0c, const bf16x8 (&bh)[RT], const bf16x8 (&bl)[RT], auto&& between) __attribute__((always_inline)) {
+        constexpr int slot = decltype(slotc)::value, J0 = decltype(j0c)::value;
         const unsigned ah = slot < 4 ? rd_hi : rd_hi2, al = slot < 4 ? rd_lo : rd_lo2;
         constexpr int so = (slot & 3) * MLP_STAGE;
         u32x4_m wh[2][2], wl[2][2];
         auto fetch = [&](auto prc, auto bc) __attribute__((always_inline)) {
             constexpr int pr = decltype(prc)::value, bf = decltype(bc)::value;
+            if constexpr (DIAG == 3) return;
             fetch16<so + (2 * pr) * 2048>(wh[bf][0], ah); fetch16<so + (2 * pr) * 2048>(wl[bf][0], al);
             fetch16<so + (2 * pr + 1) * 2048>(wh[bf][1], ah); fetch16<so + (2 * pr + 1) * 2048>(wl[bf][1], al);
         };
@@ -134,107 +152,146 @@ __global__ __launch_bounds__(512, 2) void dec_mlp_kernel(const MlpArgs p) {
         static_for<4>([&](auto prc) {
             constexpr int pr = decltype(prc)::value, cur = pr & 1;
             if constexpr (pr + 1 < 4) fetch(IntC<pr + 1>{}, IntC<cur ^ 1>{});
-            wait_lgkm<(pr + 1 < 4 ? 4 : 0)>(wh[cur][0], wl[cur][0], wh[cur][1], wl[cur][1]);
+            if constexpr (DIAG != 3) wait_lgkm<(pr + 1 < 4 ? 4 : 0)>(wh[cur][0], wl[cur][0], wh[cur][1], wl[cur][1]);
             __builtin_amdgcn_sched_barrier(0);
-            f32x4 a0 = acc[2 * pr], a1 = acc[2 * pr + 1];
-            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wh[cur][0]), bl, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wh[cur][1]), bl, a1, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wl[cur][0]), bh, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wl[cur][1]), bh, a1, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wh[cur][0]), bh, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wh[cur][1]), bh, a1, 0, 0, 0);
-            acc[2 * pr] = a0; acc[2 * pr + 1] = a1;
+            if constexpr (DIAG != 2) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt][J0 + 2 * pr + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wh[cur][t]), bl[rt], acc[rt][J0 + 2 * pr + t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt][J0 + 2 * pr + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wl[cur][t]), bh[rt], acc[rt][J0 + 2 * pr + t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt][J0 + 2 * pr + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wh[cur][t]), bh[rt], acc[rt][J0 + 2 * pr + t], 0, 0, 0);
+            } else { acc[0][J0 + 2 * pr][0] += __builtin_bit_cast(float, wh[cur][0][0]) + __builtin_bit_cast(float, wl[cur][1][1]); }
             __builtin_amdgcn_sched_barrier(0);
+            between(prc);
         });
     };
 
     // prologue: stages 0 .. AHEAD-1 of hidden slice 0
-    static_for<MLP_AHEAD>([&](auto uc) { constexpr int u = decltype(uc)::value; issue(0, IntC<u>{}, IntC<u % MLP_NS>{}); });
+    static_for<MLP_AHEAD>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        static_for<PPW>([&](auto ic) { issue(DIAG == 1 ? -1 : 0, IntC<u>{}, IntC<u % MLP_NS>{}, ic); });
+    });
     __syncthreads();                                                     // linear1's bias is in LDS (plain stores: lgkmcnt, compiler-tracked)
 
-    const bool early = wave < 4;                                         // waves 0-3 issue their DMA before the MFMAs, 4-7 after
+    // which MFMA group of a stage a wave's DMA piece i follows: the first half of the waves issues early in a stage, the second half
+    // late (with one wave per SIMD: one piece after each of the four groups)
+    const int g_first = (wave < NW / 2 || PPW == 4) ? 0 : 4 - PPW;
 #pragma unroll 1
     for (int hs = 0; hs < 8; ++hs) {
         static_for<16>([&](auto uc) {
             constexpr int u = decltype(uc)::value, slot = u % MLP_NS;
             constexpr int ut = (u + MLP_AHEAD) % 16, slot_t = (u + MLP_AHEAD) % MLP_NS;
             const int hs_t = (hs + (u + MLP_AHEAD >= 16 ? 1 : 0)) & 7;  // past the last slice: a harmless re-fetch keeps the counts uniform
-            // the stage AHEAD further goes into the slot consumed two stages ago (every wave left it before the previous barrier)
-            if (early) issue(hs_t, IntC<ut>{}, IntC<slot_t>{});
-            // this wave's pieces of stage (hs, u) have landed: all but the youngest AHEAD (early) / AHEAD - 1 (late) stages' pieces
-            if (early) wait_vm<2 * MLP_AHEAD>(); else wait_vm<2 * (MLP_AHEAD - 1)>();
+            // this wave's pieces of stage (hs, u) have landed: all but the pieces of the youngest AHEAD - 1 stages ...
+            wait_vm<PPW * (MLP_AHEAD - 1)>();
             __builtin_amdgcn_s_barrier();                                // ... and every other wave's
+            // The stage AHEAD further goes into the slot consumed two stages ago (every wave left it before the previous barrier), a
+            // piece at a time behind the MFMA groups: an LDS-DMA piece costs its wave 60 - 180 cycles of issue, which should fall where
+            // the matrix pipe has queued work (or the SIMD partner's)
+            auto between = [&](auto gc) __attribute__((always_inline)) {
+                constexpr int g = decltype(gc)::value;
+                static_for<PPW>([&](auto ic) { constexpr int i = decltype(ic)::value; if (g == g_first + i) issue(hs_t, IntC<ut>{}, IntC<slot_t>{}, ic); });
+            };
             if constexpr (u < 8) {
                 if constexpr (u == 0) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) hacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) hacc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                stage_mma(IntC<slot>{}, hacc, xh[u], xl[u]);
+                bf16x8 bh[RT], bl[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) { bh[rt] = xh[rt][u]; bl[rt] = xl[rt][u]; }
+                stage_mma(IntC<slot>{}, hacc, IntC<0>{}, bh, bl, between);
             } else {
                 constexpr int v = u - 8, c = v >> 1, nh = v & 1;
                 if constexpr (nh == 0) {
                     // hidden columns 32 c + 8 fk .. + 7 of the slice (tiles 2c, 2c+1): + bias, GELU, split -> operand fragment of k-step c
                     const f32x4 ba = ld4(b1s + 128 * hs + 32 * c + 8 * fk), bb = ld4(b1s + 128 * hs + 32 * c + 8 * fk + 4);
-                    f32x4 va, vb;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { va[e] = gelu_erf(hacc[2 * c][e] + ba[e]); vb[e] = gelu_erf(hacc[2 * c + 1][e] + bb[e]); }
-                    split8(va, vb, hh[c], hl[c]);
+                    for (int rt = 0; rt < RT; ++rt) {
+                        f32x4 va, vb;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { va[e] = gelu_erf(hacc[rt][2 * c][e] + ba[e]); vb[e] = gelu_erf(hacc[rt][2 * c + 1][e] + bb[e]); }
+                        split8(va, vb, hh[rt][c], hl[rt][c]);
+                    }
                 }
-                stage_mma(IntC<slot>{}, oacc + 8 * nh, hh[c], hl[c]);
+                bf16x8 bh[RT], bl[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) { bh[rt] = hh[rt][c]; bl[rt] = hl[rt][c]; }
+                stage_mma(IntC<slot>{}, oacc, IntC<8 * nh>{}, bh, bl, between);
             }
-            if (!early) issue(hs_t, IntC<ut>{}, IntC<slot_t>{});
         });
     }
     wait_vm<0>();                                                        // no LDS-DMA may land after the workgroup has gone
 
-    // ---- epilogue, per lane: row frow of the wave, columns col(jj) .. + 3 of accumulator jj:  + bias + residual, LayerNorm(s), store
-    const size_t rbase = (size_t)myrow * D;
-    f32x4 v[16];
-    float s = 0.f;
+    // ---- epilogue, per lane and row tile: row frow, columns col(jj) .. + 3 of accumulator jj:  + bias + residual, LayerNorm(s), store
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-        const int col = 32 * (jj >> 1) + 8 * fk + 4 * (jj & 1);
-        const f32x4 bv = ld4(p.b2 + col), rv = ld4(p.x + rbase + col);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[jj][e] = oacc[jj][e] + bv[e] + rv[e]; }
-        s += (v[jj][0] + v[jj][1]) + (v[jj][2] + v[jj][3]);
-    }
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        const float* gp = pass == 0 ? p.g3 : p.g4;
-        const float* bp = pass == 0 ? p.be3 : p.be4;
-        if (gp == nullptr) break;
-        if (pass == 1) {
-            s = 0.f;
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj) s += (v[jj][0] + v[jj][1]) + (v[jj][2] + v[jj][3]);
-        }
-        s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);          // the row's four lane groups
-        const float mean = s * (1.f / 256.f);
-        float q = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < 16; ++jj)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[jj][e] - mean; q = fmaf(d, d, q); }
-        q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-        const float rstd = rsqrtf(q * (1.f / 256.f) + LN_EPS);
+    for (int rt = 0; rt < RT; ++rt) {
+        const size_t rbase = (size_t)myrow[rt] * D;
+        f32x4 (&v)[16] = oacc[rt];
+        float s = 0.f;
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj) {
             const int col = 32 * (jj >> 1) + 8 * fk + 4 * (jj & 1);
-            const f32x4 ga = ld4(gp + col), be = ld4(bp + col);
+            const f32x4 bv = ld4(p.b2 + col), rv = ld4(p.x + rbase + col);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[jj][e] = (v[jj][e] - mean) * rstd * ga[e] + be[e];
+            for (int e = 0; e < 4; ++e) { v[jj][e] = v[jj][e] + bv[e] + rv[e]; }
+            s += (v[jj][0] + v[jj][1]) + (v[jj][2] + v[jj][3]);
         }
-    }
-    if (live) {
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) {
-            const int col = 32 * (jj >> 1) + 8 * fk + 4 * (jj & 1);
-            if (p.y != nullptr) st4(p.y + rbase + col, v[jj]);
-            if (p.ys != nullptr) store_split4(p.ys + rbase, col, v[jj]);
+        for (int pass = 0; pass < 2; ++pass) {
+            const float* gp = pass == 0 ? p.g3 : p.g4;
+            const float* bp = pass == 0 ? p.be3 : p.be4;
+            if (gp == nullptr) break;
+            if (pass == 1) {
+                s = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) s += (v[jj][0] + v[jj][1]) + (v[jj][2] + v[jj][3]);
+            }
+            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);      // the row's four lane groups
+            const float mean = s * (1.f / 256.f);
+            float q = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[jj][e] - mean; q = fmaf(d, d, q); }
+            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+            const float rstd = rsqrtf(q * (1.f / 256.f) + LN_EPS);
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const int col = 32 * (jj >> 1) + 8 * fk + 4 * (jj & 1);
+                const f32x4 ga = ld4(gp + col), be = ld4(bp + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[jj][e] = (v[jj][e] - mean) * rstd * ga[e] + be[e];
+            }
+        }
+        if (live[rt]) {
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const int col = 32 * (jj >> 1) + 8 * fk + 4 * (jj & 1);
+                if (p.y != nullptr) st4(p.y + rbase + col, v[jj]);
+                if (p.ys != nullptr) store_split4(p.ys + rbase, col, v[jj]);
+            }
         }
     }
 }
+
+int g_mlp_variant = 0;            // measurement switch (ladiff_debug_set_mlp_variant)
+// Rows from which the fused kernel beats linear1 + linear2 + LayerNorm as three launches: a workgroup streams all 2 MB of weights
+// whatever its share of the rows, ~60 us even alone on the chip, while the three launches scale down with the rows (6272 rows: 56 us
+// against 64, 12544 rows: 78 against 71, profiles/r3)
+int dec_mlp_min_rows() { return 10000; }
 
 // y / ys [M,256] = LN3(x + lin2(gelu(lin1(x)))) (then LN4 when g4 != NULL); xs = S-format twin of x, w1 / w2 S-format
 int launch_dec_mlp(const float* xs, const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* g3,
@@ -245,11 +302,32 @@ int launch_dec_mlp(const float* xs, const float* x, const float* w1, const float
     LADIFF_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return LADIFF_ERR_ARG;
     if (!attr_set[dev]) {
-        LADIFF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
+        const void* k[3] = {reinterpret_cast<const void*>(dec_mlp_kernel<4, 2>), reinterpret_cast<const void*>(dec_mlp_kernel<8, 1>),
+                            reinterpret_cast<const void*>(dec_mlp_kernel<4, 1>)};
+        for (int i = 0; i < 3; ++i) LADIFF_HIP(hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
         attr_set[dev] = true;
     }
     MlpArgs a{xs, x, w1, b1, w2, b2, g3, be3, g4, be4, y, ys, M};
-    hipLaunchKernelGGL(dec_mlp_kernel, dim3((M + MLP_BM - 1) / MLP_BM), dim3(512), MLP_LDS, s, a);
+    // every workgroup streams all 2 MB of weights: 128-row workgroups when they fill the chip, 64-row ones (twice as many) otherwise
+    // (measured, profiles/r3: 25088 rows 111 us <4,2> / 116 <8,1> / 137 <4,1>; 12544 rows 106 / 108 / 71; the caller keeps the
+    // three-launch form below dec_mlp_min_rows())
+    int form = g_mlp_variant;                      // 0: by size, 1: <8, 1>, 2: <4, 1>, 3: <4, 2>
+    if (form == 0) form = (M + 127) / 128 < 160 ? 2 : 3;
+    if (form >= 11 && form <= 13) {                // timing experiments (garbage results): <4, 2> without DMA / MFMAs / fragment reads
+        static bool dset = false;
+        if (!dset) {
+            const void* k[3] = {reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 1>), reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 2>),
+                                reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 3>)};
+            for (int i = 0; i < 3; ++i) LADIFF_HIP(hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
+            dset = true;
+        }
+        if (form == 11) hipLaunchKernelGGL((dec_mlp_kernel<4, 2, 1>), dim3((M + 127) / 128), dim3(256), MLP_LDS, s, a);
+        else if (form == 12) hipLaunchKernelGGL((dec_mlp_kernel<4, 2, 2>), dim3((M + 127) / 128), dim3(256), MLP_LDS, s, a);
+        else hipLaunchKernelGGL((dec_mlp_kernel<4, 2, 3>), dim3((M + 127) / 128), dim3(256), MLP_LDS, s, a);
+    } else
+    if (form == 3) hipLaunchKernelGGL((dec_mlp_kernel<4, 2>), dim3((M + 127) / 128), dim3(256), MLP_LDS, s, a);
+    else if (form == 1) hipLaunchKernelGGL((dec_mlp_kernel<8, 1>), dim3((M + 127) / 128), dim3(512), MLP_LDS, s, a);
+    else hipLaunchKernelGGL((dec_mlp_kernel<4, 1>), dim3((M + 63) / 64), dim3(256), MLP_LDS, s, a);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }

@@ -5,7 +5,7 @@
 
 namespace ladiff {
 
-int g_dec_fused_mlp = 1;          // measurement switch (ladiff_debug_set_decoder_fusion): 0 = linear1 / linear2 / LayerNorm as three launches
+int g_dec_fused_mlp = 1;          // measurement switch (ladiff_debug_set_decoder_fusion): 0 = linear1 / linear2 / LayerNorm as three launches, 1 = fused from dec_mlp_min_rows() rows, 2 = fused always
 
 static GemmArgs lin(const float* A, int lda, const float* W, const float* bias, float* Y, int ldy, int M, int N, int K,
                     int act = ACT_NONE) {
@@ -139,7 +139,7 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
         // ---- feed-forward, GELU(erf), + residual + norm3 (+ decoder.norm on the last layer, cross_attention.py:150-151)   :410-412
         float* dst = is_in ? SK[l] : P[0];
         float* dsts = is_in ? SKs[l] : Ps[0];
-        if (sp && g_dec_fused_mlp) {     // one kernel: the hidden rows never leave the registers (dec_mlp.hip)
+        if (sp && g_dec_fused_mlp && (M >= dec_mlp_min_rows() || g_dec_fused_mlp == 2)) {     // one kernel: the hidden rows never leave the registers (dec_mlp.hip)
             LADIFF_TRY(launch_dec_mlp(Ps[2], P[2], Ls.lin1.w, L.lin1.b, Ls.lin2.w, L.lin2.b, L.norm3.g, L.norm3.b,
                                       last ? w.norm.g : nullptr, last ? w.norm.b : nullptr, dst, dsts, M, s));
         } else {

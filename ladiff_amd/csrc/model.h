@@ -36,6 +36,8 @@ size_t linear_cross_attention_ws_floats(int B, int T, int N);
 void den_loop_io(float* ws, int rows, float** x, float** xs);
 
 extern int g_dec_fused_mlp;
+extern int g_mlp_variant;
+int dec_mlp_min_rows();
 size_t dec_ws_floats(int B, size_t rows, int T);
 int vae_decode(const DecoderW& w, const DecoderW* w_split, const float* z, const int32_t* lengths, const int32_t* counts,
                const int32_t* row_off, int R, int B, int F, int T, int C, float* feats, float* ws, size_t ws_floats, hipStream_t s);

@@ -16,7 +16,7 @@ for B, F in ((128, 196), (8, 60)):
         z[m:, i] = 0
     for prec in ("bf16x3", "fp32"):
         vae.precision = prec
-        for fused in ((1, 0) if prec == "bf16x3" else (1,)):
+        for fused in ((2, 0) if prec == "bf16x3" else (1,)):
             L.ladiff_debug_set_decoder_fusion(fused)
             s = torch.cuda.Stream()
             with torch.cuda.stream(s), torch.no_grad():

@@ -394,8 +394,9 @@ def unsplit_rows(s):
     return (b[:, :, 0] + b[:, :, 1]).reshape(R, K)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("M,second_ln", [(1, False), (17, True), (480, False), (1000, True), (4133, False)])
-def test_fused_mlp_layernorm(M, second_ln):
+def test_fused_mlp_layernorm(M, second_ln, variant):
     """y = LN(x + W2 gelu(W1 x + b1) + b2) [then a second LN] in one kernel (bf16x3 products, everything else fp32) against
     fp64: row counts that leave waves / lanes of the last 128-row workgroup without rows; fp32 and S-format outputs agree.
     Asymmetric weights and inputs: a wrong row permutation of a weight panel or a wrong k order shows up as O(1) errors."""
@@ -410,6 +411,16 @@ def test_fused_mlp_layernorm(M, second_ln):
     b1d, b2d, g3d, be3d, g4d, be4d = d(b1), d(b2), d(g3), d(be3), d(g4), d(be4)
     y = torch.full((M, 256), float("nan"), device=DEV)
     ys = torch.zeros(M, 256, device=DEV)
+    # variant 0: the launcher's own choice (64-row workgroups at these sizes); 1 / 2 / 3: eight waves x 16 rows, four waves x 16 rows,
+    # four waves x 32 rows
+    assert lib().ladiff_debug_set_mlp_variant(variant) == 0
+    try:
+        _fused_mlp_case(M, second_ln, x, w1, b1, w2, b2, g3, be3, g4, be4, xd, xs, w1s, w2s, b1d, b2d, g3d, be3d, g4d, be4d, y, ys)
+    finally:
+        lib().ladiff_debug_set_mlp_variant(0)
+
+
+def _fused_mlp_case(M, second_ln, x, w1, b1, w2, b2, g3, be3, g4, be4, xd, xs, w1s, w2s, b1d, b2d, g3d, be3d, g4d, be4d, y, ys):
     _lib.check(lib().ladiff_mlp_ln_fused(_lib.ptr(xs), _lib.ptr(xd), _lib.ptr(w1s), _lib.ptr(b1d), _lib.ptr(w2s), _lib.ptr(b2d),
                                          _lib.ptr(g3d), _lib.ptr(be3d), _lib.ptr(g4d) if second_ln else None,
                                          _lib.ptr(be4d) if second_ln else None, _lib.ptr(y), _lib.ptr(ys), M, _lib.stream_ptr()))
@@ -444,9 +455,9 @@ def test_fused_mlp_matches_three_launch_path_on_a_decode():
     try:
         assert lib().ladiff_debug_set_decoder_fusion(0) == 0
         a = vae.decode(z, lens)
-        assert lib().ladiff_debug_set_decoder_fusion(1) == 0
+        assert lib().ladiff_debug_set_decoder_fusion(2) == 0              # fused at every size (the default fuses from 10,000 rows up)
         b = vae.decode(z, lens)
     finally:
         lib().ladiff_debug_set_decoder_fusion(1)
     assert torch.isfinite(b).all() and (a - b).abs().max().item() < 5e-5 * max(1.0, a.abs().max().item())
-    assert lib().ladiff_debug_set_decoder_fusion(2) != 0
+    assert lib().ladiff_debug_set_decoder_fusion(3) != 0
