@@ -304,12 +304,16 @@ int ladiff_sampler_destroy(void* sampler) {
 
 // Block plan of the pipeline loop for one call (host only).  loop_mode: 1 = pick by the cost model, 2 / 3 = force 16- / 32-row blocks.
 static void choose_plan(int B, int T, const int32_t* h_counts, bool masked, int loop_mode, bool bf16x3, std::vector<unsigned char>& plan,
-                        int* plan_mr, int* plan_nb) {
+                        int* plan_mr, int* plan_nb, bool cfg = true) {
     int mr16 = 1, nb16 = 0, mr32 = 2, nb32 = 0;
     std::vector<unsigned char> p16, p32;
-    sys_pack_blocks(B, T, 2, h_counts, masked, p32, &mr32, &nb32);
+    if (!cfg) {             // no guidance: one-branch 16-row blocks only (the caller made sure the counts are on the host, or absent)
+        sys_pack_blocks(B, T, 1, h_counts, masked, false, plan, plan_mr, plan_nb);
+        return;
+    }
+    sys_pack_blocks(B, T, 2, h_counts, masked, true, p32, &mr32, &nb32);
     int want = loop_mode == 2 ? 1 : (loop_mode == 3 ? 2 : 0);
-    if (want != 2) sys_pack_blocks(B, T, 1, h_counts, masked, p16, &mr16, &nb16);
+    if (want != 2) sys_pack_blocks(B, T, 1, h_counts, masked, true, p16, &mr16, &nb16);
     if (want == 0) {
         // measured (scripts/try_pipeline.py uniform, 1 ... 128 prompts, final build of round 2): the busiest stage's time per block
         // and one block's unloaded trip through the 59 stages, in us, for 16- / 32-row blocks
@@ -453,7 +457,6 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
     if (w_split != nullptr) LADIFF_CHECK_ARG(load_weights(WS, w_split));
     const DenoiserW* WSp = w_split ? &WS : nullptr;
     if (T < 1 || T > LADIFF_MAX_LATENTS || n_text < 1) return LADIFF_ERR_SHAPE;
-    if (n_text > 1 && WSp != nullptr) return LADIFF_ERR_UNSUPPORTED;   // more than one text token: fp32 arithmetic only
     ReverseWs r = carve_reverse(ws, B, T, n_steps, n_text);
     if (ws_bytes < r.total_bytes) return LADIFF_ERR_WORKSPACE;
     hipStream_t s = S(stream);
@@ -489,13 +492,15 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
         return launch_step_tail(xio, xios, W.norm.g, W.norm.b, r.latents, coef, r.d_step, step_noise, W.query_pe,
                                 guidance_scale, cfg, B, T, st);
     };
-    const bool pipeline = sp != nullptr && sp->loop == 1 && n_text == 1 && sys_supported(B, T, cfg, WSp != nullptr);
+    // without guidance the pipeline runs one-branch 16-row blocks, which need the latent counts on the host (or no masking at all)
+    const bool pipeline = sp != nullptr && sp->loop == 1 && n_text == 1 && sys_supported(B, T, cfg, WSp != nullptr) &&
+                          (cfg || counts == nullptr || h_counts != nullptr);
     // Block geometry of the pipeline for THIS call's lengths.  16-row blocks carry only the valid latent rows of each prompt
     // (length-aware packing; needs the counts on the host), 32-row blocks the padded T rows.  A step costs the larger of (blocks x
     // the busiest stage's time per block) and one block's trip through the 59 stages: choose_plan() picks the cheaper plan.
     std::vector<unsigned char> plan;
     int plan_mr = 2, plan_nb = 0;
-    if (pipeline) choose_plan(B, T, h_counts, counts != nullptr, sp->loop_mode, WSp != nullptr, plan, &plan_mr, &plan_nb);
+    if (pipeline) choose_plan(B, T, h_counts, counts != nullptr, sp->loop_mode, WSp != nullptr, plan, &plan_mr, &plan_nb, cfg != 0);
     // c-table rows of the window that starts at step `lo` (plain launches, outside the graphs: `lo` changes per window)
     auto open_window = [&](int lo) -> int {
         if (n_text > 1) return 0;
@@ -583,7 +588,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
             }
             if (pipeline) {
                 LADIFF_TRY(launch_systolic_loop(W, r.sys, r.tables, den_cache_tkv(r.cache, B2, 1), den_cache_ctab(r.cache, B2, 1), r.window,
-                                                coef, step_noise, r.latents, counts, guidance_scale, B, T, lo, r.window, WSp ? 0 : 1, plan_mr, plan_nb, s));
+                                                coef, step_noise, r.latents, counts, guidance_scale, B, T, lo, r.window, WSp ? 0 : 1, plan_mr, plan_nb, s, cfg));
             } else {
                 for (int i = 0; i < r.window / sp->unroll; ++i) LADIFF_HIP(hipGraphLaunch(sp->exec, s));
             }

@@ -293,7 +293,6 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tabl
                      int n_steps, const float* sample, int Bs, int dup, int T, const int32_t* counts, float* eps, float* ws,
                      size_t ws_floats, hipStream_t s, int b_lo, int b_n, int loop_mode, int ntxt, const int32_t* d_base) {
     const int B2 = Bs * dup;
-    if (ntxt > 1 && wsp != nullptr) return LADIFF_ERR_UNSUPPORTED;      // general-N conditioning is built in fp32 arithmetic only
     if (b_n < 0) { b_lo = 0; b_n = B2; }
     const int M = b_n * T;
     if (T < 1 || T > LADIFF_MAX_LATENTS || b_lo < 0 || b_lo + b_n > B2) return LADIFF_ERR_SHAPE;
@@ -344,21 +343,25 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tabl
             }
             cur = P[3]; curs = Ps[3];
         }
-        if (sp) {   // in_proj + attention core in one launch (qkv_attn.hip)
+        const float* att_op = att;                    // the attention output as out_proj's operand
+        if (sp && ntxt == 1) {   // in_proj + attention core in one launch (qkv_attn.hip)
             LADIFF_TRY(launch_qkv_attention(curs, Ls.sa_attn.in_w, L.sa_attn.in_b, tkv + (size_t)l * B2 * 2 * D, tl,
                                             DEN_OFF_TIME_KV, DEN_STEP_STRIDE, d_step, counts, Bs, b_lo, b_n, T, att, s));
         } else {
-            LADIFF_TRY(gemm(kr(cur, D, Ls.sa_attn.in_w, L.sa_attn.in_b, qkv, 3 * D, M, 3 * D, D)));
-            if (ntxt > 1)
+            LADIFF_TRY(gemm(kr(sp ? curs : cur, D, Ls.sa_attn.in_w, L.sa_attn.in_b, qkv, 3 * D, M, 3 * D, D)));
+            if (ntxt > 1) {
+                // N text tokens as N extra keys (fp32 softmax in both modes); bf16x3 mode: the S-format twin of the result goes to
+                // the (still unused) hidden buffer
                 LADIFF_TRY(launch_denoiser_self_attention_general(qkv, tkv + (size_t)l * B2 * ntxt * 2 * D, ntxt, tl, DEN_OFF_TIME_KV,
                                                                   DEN_STEP_STRIDE, d_step, counts, Bs, b_lo, b_n, T, att, s));
-            else
+                if (sp) { LADIFF_TRY(launch_split_rows(att, hid, M, D, s)); att_op = hid; }
+            } else
                 LADIFF_TRY(launch_denoiser_self_attention(qkv, tkv + (size_t)l * B2 * 2 * D, tl, DEN_OFF_TIME_KV, DEN_STEP_STRIDE,
                                                           d_step, counts, Bs, b_lo, b_n, T, att, 0, s));
         }
         if (sp) {   // X1 = LN1(x + out_proj(att)) -> P[2] / Ps[2], one launch (gemm_rowln.hip)
             RowLnArgs g;
-            g.A = att; g.lda = D; g.W = Ls.sa_attn.out_w; g.ldw = D; g.bias = L.sa_attn.out_b; g.res = cur; g.ldres = D;
+            g.A = att_op; g.lda = D; g.W = Ls.sa_attn.out_w; g.ldw = D; g.bias = L.sa_attn.out_b; g.res = cur; g.ldres = D;
             g.ln_g = L.sa_norm1.g; g.ln_b = L.sa_norm1.b; g.Y = P[2]; g.Ys = Ps[2]; g.ldy = D; g.M = M; g.K = D;
             LADIFF_TRY(launch_gemm_rowln(g, s));
         } else {
@@ -382,14 +385,18 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tabl
         if (ntxt > 1) {
             // literal LinearTemporalCrossAttention (mdiff_transformer.py:219-247): X2 = LN2(..) -> P[1]; q = query(LN(X2));
             // u = SiLU(AdaLN(LN(softmax_d(q) . att_b)));  X3 = X2 + out(u) -> first M x 256 of the qkv buffer
+            // bf16x3 mode: the two projections run on S-format operands (3 bf16 MFMAs per product), softmax / LayerNorm / AdaLN fp32
             LADIFF_TRY(launch_reduce_rows(part, 4, M, L.sa_lin2.b, P[2], RED_LN, L.sa_norm2.g, L.sa_norm2.b, nullptr, 0, nullptr,
                                           nullptr, 1, 1, 0, 0, P[1], nullptr, s));
-            LADIFF_TRY(launch_layernorm(P[1], L.ca_norm.g, L.ca_norm.b, P[2], M, s));
-            LADIFF_TRY(gemm(kr(P[2], D, L.ca_query.w, L.ca_query.b, att, D, M, D, D)));
+            if (sp) LADIFF_TRY(launch_reduce_rows(P[1], 1, M, nullptr, nullptr, RED_LN, L.ca_norm.g, L.ca_norm.b, nullptr, 0, nullptr,
+                                                  nullptr, 1, 1, 0, 0, P[2], Ps[2], s));
+            else LADIFF_TRY(launch_layernorm(P[1], L.ca_norm.g, L.ca_norm.b, P[2], M, s));
+            LADIFF_TRY(gemm(kr(sp ? Ps[2] : P[2], D, Ls.ca_query.w, L.ca_query.b, att, D, M, D, D)));
             LADIFF_TRY(launch_lca_apply(att, ctab + (size_t)l * B2 * H * DH * DH, counts, Bs, b_lo, b_n, T, tl + DEN_OFF_CA_MOD,
                                         DEN_STEP_STRIDE, 0, d_step, L.ca_proj.norm.g, L.ca_proj.norm.b, P[2], s));
-            KrArgs g = kr(P[2], D, L.ca_proj.out.w, L.ca_proj.out.b, qkv, D, M, D, D);
-            g.res = P[1]; g.ldres = D;
+            if (sp) LADIFF_TRY(launch_split_rows(P[2], Ps[2], M, D, s));
+            KrArgs g = kr(sp ? Ps[2] : P[2], D, Ls.ca_proj.out.w, L.ca_proj.out.b, qkv, D, M, D, D);
+            g.res = P[1]; g.ldres = D; g.Ys = sp ? Ps[1] : nullptr;      // X3 (fp32: residual of the ffn block) + its S-format twin (ffn.linear1's operand)
             LADIFF_TRY(gemm(g));
             x3 = qkv;
         } else {
@@ -409,7 +416,7 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tabl
             CombineGemmArgs g;
             g.P = part; g.plane = MD; g.S = 4; g.bias2 = L.ffn2.b; g.ln_g = L.ffn_proj.norm.g; g.ln_b = L.ffn_proj.norm.b;
             g.tab = tl + DEN_OFF_FFN_MOD; g.tab_step_stride = DEN_STEP_STRIDE; g.d_step = d_step;
-            g.W = Ls.ffn_proj.out.w; g.ldw = D; g.bias = L.ffn_proj.out.b; g.res = P[1]; g.ldres = D;
+            g.W = Ls.ffn_proj.out.w; g.ldw = D; g.bias = L.ffn_proj.out.b; g.res = x3; g.ldres = D;
             g.Y = dst; g.Ys = dsts; g.ldy = D; g.M = M;
             LADIFF_TRY(launch_combine_gemm(g, s));
         } else {

@@ -62,13 +62,13 @@ extern int g_fault_wg;
 extern unsigned long long g_timeout_ticks;
 int sys_reset_status(float* ws, hipStream_t s);
 extern int g_xcd_local;
-void sys_pack_blocks(int B, int T, int want_mr, const int32_t* h_counts, bool masked, std::vector<unsigned char>& out, int* mr, int* nb);
+void sys_pack_blocks(int B, int T, int want_mr, const int32_t* h_counts, bool masked, bool cfg, std::vector<unsigned char>& out, int* mr, int* nb);
 int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR, int NB, std::vector<unsigned char>& host);
 size_t sys_blocks_offset_floats(int MR, int NB);
 size_t sys_status_offset_floats(int B, int T);
 int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, const float* tkv, const float* ctab, int n_ctab,
                          const float* coef, const float* noise, float* lat, const int32_t* counts, float gscale, int B, int T,
-                         int step_lo, int n, int fp32, int MR, int NB, hipStream_t s);
+                         int step_lo, int n, int fp32, int MR, int NB, hipStream_t s, int cfg = 1);
 
 // qkv_attn.hip: in_proj GEMM + self-attention of the denoiser's sa_block in one launch (bf16x3 mode, S-format in / out)
 int launch_qkv_attention(const float* x, const float* w, const float* bias, const float* text_kv, const float* tables,

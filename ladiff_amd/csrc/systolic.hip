@@ -122,7 +122,7 @@ struct SysArgs {
     float* lat;                           // latents [B][T][256]
     const int32_t* counts;
     float gscale;
-    int B, T, P, NB, step_lo, n_steps, n_ctab;
+    int B, B2, T, P, NB, step_lo, n_steps, n_ctab;          // B2 = sample-branches: 2 B with guidance (uncond | cond), B without
     int force_mismatch;                   // test aid: one workgroup reports a placement that disagrees (ladiff_debug_set_xcd_local(2))
     int split;                            // 1: a block holds ONE guidance branch of its P prompts (block 2g + br), 0: both
     int fault_wg;                         // test aid: this workgroup leaves right after the start-up handshake and never publishes (-1: none)
@@ -491,7 +491,7 @@ struct QkvRole {
 #pragma unroll
         for (int j = 0; j < NTW; ++j) { const int tc = tile_col(j) + frow; bcol[j] = st.b0[(tc >> 6) * 256 + h * 64 + (tc & 63)]; }
         rin = rsrc_of(st.in0); rout = rsrc_of(st.out);
-        tkv = p.tkv + (size_t)st.layer * 2 * p.B * 512;
+        tkv = p.tkv + (size_t)st.layer * p.B2 * 512;
     }
     __device__ __forceinline__ void geo(int b, Geo& g) {
         const int tid = threadIdx.x;
@@ -991,14 +991,14 @@ struct Red2Role {
     }
     __device__ __forceinline__ void issue(int s, int b, const Geo& g, Pay& y) {
         const int lane = threadIdx.x & 63, c = 4 * lane;
-        const float* ct = p.ctab + ((size_t)st.layer * p.n_ctab + s) * (2 * p.B + 1) * D;
+        const float* ct = p.ctab + ((size_t)st.layer * p.n_ctab + s) * (p.B2 + 1) * D;
         const unsigned base = (unsigned)b * RT * 1024, pbase = (unsigned)((s * p.NB + b) % PRING) * RT * 1024;   // partial planes: rings of PRING slots
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
             const int row = g.row[q];
             if (row >= 0) {
                 // the row's cross-attention vector is its sample's table row while t < latent count, the pad row otherwise
-                y.tp[q] = ld4(ct + (size_t)(2 * p.B) * D + c);
+                y.tp[q] = ld4(ct + (size_t)p.B2 * D + c);
                 y.tv[q] = y.tp[q];
                 if (g.b2[q] >= 0 && g.t[q] < g.cnt[q]) y.tv[q] = ld4(ct + (size_t)g.b2[q] * D + c);
 #pragma unroll
@@ -1486,8 +1486,8 @@ size_t sys_ws_floats(int B, int T) {
 }
 
 bool sys_supported(int B, int T, int cfg, bool split) {
-    (void)split;                  // both arithmetic modes have a pipeline kernel
-    if (!cfg || B < 1 || T < 1 || T > LADIFF_MAX_LATENTS) return false;
+    (void)split; (void)cfg;       // both arithmetic modes and both guidance settings have a pipeline form
+    if (B < 1 || T < 1 || T > LADIFF_MAX_LATENTS) return false;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
@@ -1500,11 +1500,14 @@ bool sys_supported(int B, int T, int cfg, bool split) {
 //   MR 1: LENGTH-AWARE packing - prompts sorted by latent count, a block = one guidance branch of as many prompts as fit in 16
 //         rows with ONLY their count[b] valid rows (padded latent rows are never computed); needs the counts on the host.
 // Returns the plan: `blocks`, and in `mr` the tile size actually planned (MR 1 falls back to 2 when the counts are device-only).
-void sys_pack_blocks(int B, int T, int want_mr, const int32_t* h_counts, bool masked, std::vector<unsigned char>& out, int* mr, int* nb) {
+// cfg = false (no classifier-free guidance, ladiff.py:472-490: the network sees the B latents once): 16-row blocks of ONE branch, no
+// partner block - the tail treats a block as a unit whose "conditional" row is the row itself (guidance then adds g * 0 exactly).
+void sys_pack_blocks(int B, int T, int want_mr, const int32_t* h_counts, bool masked, bool cfg, std::vector<unsigned char>& out, int* mr, int* nb) {
     std::vector<BlockDesc> blocks;
     auto count_of = [&](int b) { int c = (masked && h_counts) ? h_counts[b] : T; return c > T ? T : (c < 1 ? 1 : c); };
     int MR = want_mr;
-    if (MR == 1 && masked && h_counts == nullptr) MR = 2;
+    if (!cfg) MR = 1;                                                  // the caller checked sys_plan_possible()
+    if (MR == 1 && masked && h_counts == nullptr && cfg) MR = 2;
     auto fresh = [] { BlockDesc d; std::memset(&d, 0, sizeof(d)); for (int i = 0; i < 16; ++i) d.b2[i] = -1;
                       for (int r = 0; r < 32; ++r) { d.row_b2[r] = -1; d.row_lat[r] = -1; } return d; };
     // derived tables: the reduce parts' slots (the live rows split evenly over NRED parts) and the tail's (prompt, latent) pairs
@@ -1557,7 +1560,7 @@ void sys_pack_blocks(int B, int T, int want_mr, const int32_t* h_counts, bool ma
             std::vector<int> group;
             int rows = 0;
             while (i < order.size() && group.size() < 8 && rows + count_of(order[i]) <= 16) { rows += count_of(order[i]); group.push_back(order[i]); ++i; }
-            for (int br = 0; br < 2; ++br) {
+            for (int br = 0; br < (cfg ? 2 : 1); ++br) {
                 BlockDesc d = fresh();
                 d.nsb = (int)group.size(); d.nrows = rows;
                 int r0 = 0, row_cnt[32];
@@ -1748,7 +1751,7 @@ int sys_reset_status(float* ws, hipStream_t s) {
 
 int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, const float* tkv, const float* ctab, int n_ctab,
                          const float* coef, const float* noise, float* lat, const int32_t* counts, float gscale, int B, int T,
-                         int step_lo, int n, int fp32, int MR, int NB, hipStream_t s) {
+                         int step_lo, int n, int fp32, int MR, int NB, hipStream_t s, int cfg) {
     const SysLayout L = sys_layout(MR, NB);
     SysArgs a;
     a.stages = reinterpret_cast<const Stage*>(ws + L.off_stages);
@@ -1756,9 +1759,9 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     a.flags = reinterpret_cast<unsigned*>(ws + L.off_flags);
     a.status = reinterpret_cast<unsigned*>(ws + L.off_status);
     a.tables = tables; a.tkv = tkv; a.ctab = ctab; a.coef = coef; a.noise = noise; a.pe = W.query_pe; a.ng = W.norm.g; a.nb = W.norm.b;
-    a.lat = lat; a.counts = counts; a.gscale = gscale; a.B = B; a.T = T; a.P = 0; a.NB = NB; a.step_lo = step_lo; a.n_steps = n;
+    a.lat = lat; a.counts = counts; a.gscale = gscale; a.B = B; a.B2 = cfg ? 2 * B : B; a.T = T; a.P = 0; a.NB = NB; a.step_lo = step_lo; a.n_steps = n;
     a.n_ctab = n_ctab;
-    a.split = L.split;
+    a.split = cfg ? L.split : 0;       // no guidance: every block is a unit of its own (sys_pack_blocks)
     a.force_mismatch = g_xcd_local == 2 ? 1 : 0;
     a.fault_wg = g_fault_wg;
     a.timeout_ticks = g_timeout_ticks > 0 ? g_timeout_ticks : TIMEOUT_TICKS;

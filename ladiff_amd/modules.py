@@ -132,9 +132,6 @@ class LADiffDenoiser(_HipModule):
         if enclat is not None or enclat_future is not None:
             raise NotImplementedError("autoregressive conditioning (ARDIFF) is not built")
         n_text = int(encoder_hidden_states.shape[1])
-        if n_text > 1 and self.precision != "fp32":
-            raise NotImplementedError("more than one text token per prompt (clip_hidden / bert, mld_clip.py:80-86) runs in "
-                                      "fp32 arithmetic only: set precision='fp32'")
         L = _lib.lib()
         dev = sample.device
         B2, T, Dm = sample.shape

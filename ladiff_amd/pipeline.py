@@ -67,7 +67,8 @@ def remove_padding(tensors, lengths):
 class LADIFF(nn.Module):
     def __init__(self, cfg=None, datamodule=None, *, denoiser=None, vae=None, scheduler=None, text_encoder=None,
                  guidance_scale=None, num_inference_timesteps=None, eta=None, max_it=None, frame_per_latent=None,
-                 test_efficiency=None, use_graph=True, precision=None, loop="pipeline", fallback=False, **kwargs):
+                 test_efficiency=None, use_graph=True, precision=None, loop="pipeline", fallback=False,
+                 max_prompts_per_launch=320, **kwargs):
         super().__init__()
         self.cfg = cfg
         self.datamodule = datamodule
@@ -118,10 +119,14 @@ class LADIFF(nn.Module):
         # in `fallback_count`).
         self.fallback = bool(fallback)
         self.fallback_count = 0
-        self._pending = None          # (event, pinned status words, plan key) of the last call, not yet looked at
-        self._sampler = None
+        self._pending = []            # (event, pinned status words, plan key) per launch of the last call, not yet looked at
         self._stream = None
-        self._plan = None
+        self._plans = {}              # plan key -> persistent buffers + sampler (a few shapes stay cached: chunks, alternating batches)
+        self._last = []               # the plans the last call ran on, in order
+        # Batches larger than this are run as several launches of the loop (balanced chunks of <= 256 prompts): the pipeline's
+        # per-layer buffers of more than ~170 blocks fall out of the 256 MiB memory-side cache (512 prompts in one launch cost 11.5 ms
+        # per 128 against 9.8 ms at 256).  None = never split.
+        self.max_prompts_per_launch = max_prompts_per_launch
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -142,10 +147,17 @@ class LADIFF(nn.Module):
     def device(self):
         return next(self.denoiser.parameters()).device
 
+    @property
+    def _plan(self):
+        return self._last[-1] if self._last else None
+
+    @property
+    def _sampler(self):
+        return self._last[-1]["sampler"] if self._last else None
+
     def __del__(self):
         try:
-            if self._pending is not None:
-                ev, host, _ = self._pending
+            for ev, host, _ in self._pending:
                 ev.synchronize()
                 if int(host[0]) != 0:
                     import warnings
@@ -153,18 +165,21 @@ class LADIFF(nn.Module):
         except Exception:
             pass
         try:
-            if self._sampler is not None:
-                _lib.lib().ladiff_sampler_destroy(self._sampler)
+            for plan in self._plans.values():
+                if plan.get("sampler") is not None:
+                    _lib.lib().ladiff_sampler_destroy(plan["sampler"])
         except Exception:
             pass
 
     def _get_plan(self, B, T, n_steps, eta, dev, n_text=1):
-        """Persistent device buffers + scheduler tables for one (B, T, schedule): hipGraph kernel nodes bake
+        """Persistent device buffers + scheduler tables + sampler for one (B, T, schedule): hipGraph kernel nodes bake
         pointers in, and the per-step scalar tables are built once, not per call."""
         sch = self.scheduler
         key = (B, T, n_steps, float(eta), str(dev), id(sch), n_text)
-        if self._plan is not None and self._plan["key"] == key:
-            return self._plan
+        plan = self._plans.get(key)
+        if plan is not None:
+            self._plans[key] = self._plans.pop(key)          # most recently used last
+            return plan
         L = _lib.lib()
         sch.set_timesteps(n_steps)
         n_steps = len(sch.timesteps)
@@ -182,66 +197,109 @@ class LADIFF(nn.Module):
             "z": torch.empty(T, B, 256, dtype=torch.float32, device=dev),
             "ws": _lib.workspace(wsb, dev), "ws_bytes": wsb,
             "tables_key": None,      # weights the time tables inside `ws` were built from
+            "sampler": None,
         }
+        if self.use_graph:
+            h = c_void_p()
+            _lib.check(L.ladiff_sampler_create(byref(h)))
+            plan["sampler"] = h
         # the pipeline kernel's {code, info} words inside the workspace, and where the host reads them
         off = L.ladiff_reverse_status_offset_bytes(B, T, n_steps, n_text)
         if off == 0 or off % 4:
             raise _lib.LadiffHipError("ladiff_reverse_status_offset_bytes rejected the plan's shape")
         plan["status_dev"] = plan["ws"][off // 4: off // 4 + 2].view(torch.int32)
-        plan["status_host"] = torch.zeros(2, dtype=torch.int32).pin_memory()
-        plan["status_event"] = torch.cuda.Event()
-        self._plan = plan
+        # one pinned {code, info} slot + event per launch of a call (a chunked batch can run the same plan several times)
+        plan["status_host"] = torch.zeros(8, 2, dtype=torch.int32).pin_memory()
+        plan["status_event"] = [torch.cuda.Event() for _ in range(8)]
+        plan["launches"] = 0
+        while len(self._plans) >= 4:                         # a few shapes stay cached; the oldest goes (its graphs with it)
+            old = self._plans.pop(next(iter(self._plans)))
+            if old.get("sampler") is not None:
+                _lib.check(L.ladiff_sampler_destroy(old["sampler"]))
+        self._plans[key] = plan
         return plan
 
     def check(self, wait=True):
-        """Look at the status of the last `_diffusion_reverse` call: raises LadiffHipError when its pipeline loop was abandoned
-        (the returned z is NaN then).  wait=False only looks if the copy has already arrived.  Returns True when looked at."""
-        if self._pending is None:
+        """Look at the status of the last `_diffusion_reverse` call: raises LadiffHipError when a pipeline loop of it was abandoned
+        (the returned z is NaN then).  wait=False only looks if the copies have already arrived.  Returns True when looked at."""
+        if not self._pending:
             return True
-        ev, host, _ = self._pending
-        if not wait and not ev.query():
+        if not wait and not all(ev.query() for ev, _, _ in self._pending):
             return False
-        ev.synchronize()
-        self._pending = None
-        code, info = int(host[0]), int(host[1])
-        if code != 0:
-            raise _lib.LadiffHipError(
-                f"the persistent pipeline loop was abandoned (status {code}: workgroup {info} timed out waiting for its producer - "
-                "is the GPU shared, or was a long kernel running on another stream?); the latents of that call are NaN.  "
-                "Run again, construct LADIFF(fallback=True) to re-run such a call launch-per-stage automatically, or use loop='launches'")
+        pending, self._pending = self._pending, []
+        for ev, host, _ in pending:
+            ev.synchronize()
+            code, info = int(host[0]), int(host[1])
+            if code != 0:
+                raise _lib.LadiffHipError(
+                    f"the persistent pipeline loop was abandoned (status {code}: workgroup {info} timed out waiting for its producer - "
+                    "is the GPU shared, or was a long kernel running on another stream?); the latents of that call are NaN.  "
+                    "Run again, construct LADIFF(fallback=True) to re-run such a call launch-per-stage automatically, or use loop='launches'")
         return True
 
     def _counts(self, lengths):
         return [int(math.ceil(l / self.frame_per_latent)) for l in lengths]
 
     # ------------------------------------------------------------------ the hot loop
+    def _chunks(self, B):
+        """[lo, hi) prompt ranges of the launches a batch of B prompts runs as (balanced chunks of <= 256 prompts)."""
+        cap = self.max_prompts_per_launch
+        if cap is None or B <= cap or self.loop == "launches":
+            return [(0, B)]
+        n = -(-B // 256)
+        base, extra = divmod(B, n)
+        spans, lo = [], 0
+        for i in range(n):
+            hi = lo + base + (1 if i < extra else 0)
+            spans.append((lo, hi))
+            lo = hi
+        return spans
+
     def _diffusion_reverse(self, encoder_hidden_states, lengths=None, init_noise=None, step_noise=None):
         """text_emb [2B,1,768] (unconditional half first), lengths list[int] -> z [max_it, B, 256]  (ladiff.py:333-571)."""
-        L = _lib.lib()
         dev = encoder_hidden_states.device
         if not encoder_hidden_states.is_cuda:
             raise _lib.LadiffHipError("_diffusion_reverse needs GPU tensors; there is no CPU fallback")
         self.check()          # the previous call's status (its loop has long finished: the copy sits right behind it on the stream)
         n_text = int(encoder_hidden_states.shape[1])          # 1: CLIP pooled token; > 1: clip_hidden / bert (mld_clip.py:80-86)
-        if n_text > 1 and self.precision != "fp32":
-            raise NotImplementedError("more than one text token per prompt runs in fp32 arithmetic only: precision='fp32'")
         cfg = bool(self.do_classifier_free_guidance)        # ladiff.py:339-340, :472-490
         dup = 2 if cfg else 1
         B = encoder_hidden_states.shape[0] // dup
         lengths = [int(l) for l in lengths]
-        counts = self._counts(lengths)
-        T = counts[0] if self.test_efficiency else self.max_it     # ladiff.py:381
-        sch = self.scheduler
         if encoder_hidden_states.shape[0] != dup * len(lengths):
             raise ValueError(f"{encoder_hidden_states.shape[0]} text rows for {len(lengths)} lengths (guidance: {cfg})")
+        counts = self._counts(lengths)
+        T = counts[0] if self.test_efficiency else self.max_it     # ladiff.py:381
+        self._last = []
+        spans = self._chunks(B)
+        if len(spans) == 1:
+            return self._reverse_one(encoder_hidden_states, lengths, counts, T, init_noise, step_noise)
+        # prompts are independent (attention is per sample, guidance pairs the two branches of one prompt): a large batch is
+        # several launches of the loop on contiguous prompt ranges, the noise drawn for the whole batch and sliced
+        if init_noise is None:
+            init_noise = torch.randn(B, T, 256, device=dev, dtype=torch.float32)       # ladiff.py:380-385
+        text = encoder_hidden_states.reshape(dup, B, n_text, 768)
+        zs = []
+        for lo, hi in spans:
+            zs.append(self._reverse_one(text[:, lo:hi].reshape(dup * (hi - lo), n_text, 768), lengths[lo:hi], counts[lo:hi], T,
+                                        init_noise[lo:hi], None if step_noise is None else step_noise[:, lo:hi], keep_pending=True))
+        return torch.cat(zs, dim=1)
+
+    def _reverse_one(self, encoder_hidden_states, lengths, counts, T, init_noise, step_noise, keep_pending=False):
+        """One launch sequence of the loop on B prompts: prologue graph, N steps (pipeline kernel or step graphs), final masking."""
+        L = _lib.lib()
+        dev = encoder_hidden_states.device
+        n_text = int(encoder_hidden_states.shape[1])
+        cfg = bool(self.do_classifier_free_guidance)
+        dup = 2 if cfg else 1
+        B = len(lengths)
+        sch = self.scheduler
         plan = self._get_plan(B, T, self.num_inference_timesteps, self.eta, dev, n_text)
+        self._last.append(plan)
         n, need_noise = plan["n"], plan["need_noise"]
+        sampler = plan["sampler"]
         if self._stream is None or self._stream.device != dev:
             self._stream = torch.cuda.Stream(device=dev)
-        if self.use_graph and self._sampler is None:
-            h = c_void_p()
-            _lib.check(L.ladiff_sampler_create(byref(h)))
-            self._sampler = h
         if init_noise is None:
             init_noise = torch.randn(B, T, 256, device=dev, dtype=torch.float32)       # ladiff.py:380-385
         if need_noise and step_noise is None:
@@ -254,12 +312,14 @@ class LADIFF(nn.Module):
         if run is not cur:
             run.wait_stream(cur)
         loop_codes = {"pipeline": 1, "pipeline16": 2, "pipeline32": 3, "launches": 0}
+        if not keep_pending:
+            self._pending = []
 
         def enqueue(loop):
-            if self._sampler is not None:
-                _lib.check(L.ladiff_sampler_set_loop(self._sampler, loop_codes[loop]))
+            if sampler is not None:
+                _lib.check(L.ladiff_sampler_set_loop(sampler, loop_codes[loop]))
             _lib.check(L.ladiff_diffusion_reverse(
-                self._sampler if self.use_graph else None, wt.array,
+                sampler, wt.array,
                 wt.split_array() if self.precision == "bf16x3" else None, wt.generation, _lib.ptr(plan["text"]),
                 _lib.ptr(plan["noise"]),
                 # TEST_EFFICIENCY: no masks inside the denoiser and no zeroing of the initial noise (ladiff.py:381-390,
@@ -271,9 +331,14 @@ class LADIFF(nn.Module):
                 _lib.ptr(plan["ws"]), plan["ws_bytes"], 1 if plan["tables_key"] == wt.key else 0, run.cuda_stream))
             plan["tables_key"] = wt.key
             # the loop's status words follow it on the stream into pinned memory: 8 bytes, no host synchronisation here
-            plan["status_host"].copy_(plan["status_dev"], non_blocking=True)
-            plan["status_event"].record(run)
-            self._pending = (plan["status_event"], plan["status_host"], plan["key"])
+            slot = plan["launches"] % 8
+            plan["launches"] += 1
+            if len(self._pending) >= 8:
+                self.check()                                          # more than eight launches in one call: look at the oldest first
+            host, ev = plan["status_host"][slot], plan["status_event"][slot]
+            host.copy_(plan["status_dev"], non_blocking=True)
+            ev.record(run)
+            self._pending.append((ev, host, plan["key"]))
 
         with torch.cuda.stream(run):
             plan["text"][:dup * B].copy_(encoder_hidden_states.reshape(dup * B, n_text, 768))
@@ -294,12 +359,18 @@ class LADIFF(nn.Module):
         return plan["z"].clone()
 
     def loop_ms(self):
-        """Device milliseconds of the N-step loop of the last `_diffusion_reverse` call (HIP events on its stream)."""
+        """Device milliseconds of the N-step loop(s) of the last `_diffusion_reverse` call (HIP events on its stream; summed over the
+        launches of a chunked batch)."""
         from ctypes import c_float
-        ms = c_float(0.0)
-        _lib.check(_lib.lib().ladiff_sampler_loop_ms(self._sampler, byref(ms)))
+        total = 0.0
+        for plan in self._last:           # a plan that ran k times in the call holds the events of its last run: counted k times
+            if plan["sampler"] is None:
+                raise _lib.LadiffHipError("loop_ms needs use_graph=True (the events live in the sampler)")
+            ms = c_float(0.0)
+            _lib.check(_lib.lib().ladiff_sampler_loop_ms(plan["sampler"], byref(ms)))
+            total += ms.value
         self.check()                  # the loop has ended: its status is there (an abandoned loop must not be reported as a timing)
-        return ms.value
+        return total
 
     def window_ms(self, enable=None):
         """(sum of the per-window loop times in ms, windows) of the last call; `enable=True/False` switches the per-window events on
@@ -307,11 +378,9 @@ class LADIFF(nn.Module):
         from ctypes import c_float, c_int
         L = _lib.lib()
         if enable is not None:
-            if self._sampler is None:
-                h = c_void_p()
-                _lib.check(L.ladiff_sampler_create(byref(h)))
-                self._sampler = h
-            _lib.check(L.ladiff_sampler_set_window_timing(self._sampler, 1 if enable else 0))
+            for plan in self._plans.values():
+                if plan["sampler"] is not None:
+                    _lib.check(L.ladiff_sampler_set_window_timing(plan["sampler"], 1 if enable else 0))
             return None
         ms, n = c_float(0.0), c_int(0)
         _lib.check(L.ladiff_sampler_window_ms(self._sampler, byref(ms), byref(n)))

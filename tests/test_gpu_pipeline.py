@@ -20,17 +20,20 @@ def nets():
     return den.to(DEV).eval(), vae.to(DEV).eval()
 
 
-def run(nets, loop, precision, B, T, steps, lens, sched="ddim", step_noise=None):
+def run(nets, loop, precision, B, T, steps, lens, sched="ddim", step_noise=None, guidance=7.5):
     den, vae = nets
     s = (DDIMScheduler(set_alpha_to_one=False, steps_offset=1, **SCHED_KW) if sched == "ddim"
          else DDPMScheduler(variance_type="fixed_small", **SCHED_KW))
-    pipe = LADIFF(denoiser=den, vae=vae, scheduler=s, guidance_scale=7.5, num_inference_timesteps=steps, eta=0.0, max_it=T,
+    pipe = LADIFF(denoiser=den, vae=vae, scheduler=s, guidance_scale=guidance, num_inference_timesteps=steps, eta=0.0, max_it=T,
                   precision=precision, loop=loop)
     text = syn.text_embeddings(B, seed=900 + B).to(DEV)
+    if guidance <= 1.0:
+        text = text[B:].contiguous()                               # no guidance: the conditional rows only (ladiff.py:472-490)
     noise = torch.randn(B, T, 256, generator=torch.Generator().manual_seed(B * 10 + T)).to(DEV)
     z = pipe._diffusion_reverse(text, lens, init_noise=noise, step_noise=step_noise)
     code, info = pipe.loop_status()
     assert (code, info) == (0, 0), f"pipeline kernel aborted: code {code}, workgroup {info}"
+    assert pipe.last_loop()[0] == (loop != "launches")
     return z
 
 
@@ -292,3 +295,20 @@ def test_fallback_result_matches_oracle(nets):
     assert fb.fallback_count == 1
     z_o, f_o = orc.sample_motions(syn.denoiser_weights(), syn.vae_weights(263), text, lens, noise, 8, "ddim")
     assert (feats.cpu() - f_o).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-4), ("fp32", 1e-5)])
+@pytest.mark.parametrize("B,T", [(1, 5), (3, 5), (7, 5), (40, 5), (130, 5), (9, 2), (5, 8)])
+def test_pipeline_without_guidance_matches_launches(nets, precision, tol, B, T):
+    """guidance_scale <= 1 (ladiff.py:472-490): the network sees the B latents once.  The pipeline runs it as one-branch 16-row
+    blocks whose tail unit is the block itself; against the launch-per-stage loop over the block geometries (one block, a partial
+    last block, more blocks than ring slots, every latent count)."""
+    lens = [max(1, min(196, 48 * ((i % T) + 1) - 5 * (i % 3))) for i in range(B)]
+    za = run(nets, "launches", precision, B, T, 6, lens, guidance=1.0)
+    zb = run(nets, "pipeline", precision, B, T, 6, lens, guidance=1.0)
+    assert torch.isfinite(zb).all()
+    assert (za - zb).abs().max().item() < tol * max(1.0, za.abs().max().item())
+    for i, l in enumerate(lens):
+        c = -(-l // 48)
+        if c < T:
+            assert zb[c:, i].abs().max().item() == 0
