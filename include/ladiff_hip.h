@@ -255,7 +255,8 @@ int ladiff_debug_set_stage_waves(int waves_per_simd);
 int ladiff_debug_set_xcd_local(int on);
 /* Measurement switch (process-wide): 1 (default) = the decoder's feed-forward block runs as the fused kernel of csrc/dec_mlp.hip in
  * bf16x3 mode from 10,000 frame rows up, 2 = at every size, 0 = as linear1 GEMM + linear2 GEMM + LayerNorm row kernel (the round-2
- * path; same arithmetic per product). */
+ * path; same arithmetic per product).  + 4: decodes of fewer than 4,096 frame rows keep the large-M GEMM kernels instead of the
+ * small-M ones (the round-2 routing). */
 int ladiff_debug_set_decoder_fusion(int on);
 /* Measurement switch (process-wide) of the fused feed-forward kernel's form: 0 (default) = chosen by the row count, 1 = 128-row
  * workgroups of eight waves x 16 rows, 2 = 64-row workgroups of four waves x 16 rows, 3 = 128-row workgroups of four waves x 32 rows. */
@@ -317,6 +318,20 @@ int ladiff_vae_decode(const float* const* w, const float* const* w_split /*or NU
 int ladiff_vae_decode_ragged(const float* const* w, const float* const* w_split /*or NULL*/, const float* z,
                              const int32_t* lengths, const int32_t* counts, const int32_t* row_off, int total_rows, int B,
                              int F, int T, int C, float* feats, void* ws, size_t ws_bytes, ladiff_stream_t stream);
+
+/* The same decode (padded when row_off == NULL, ragged otherwise) captured into a hipGraph on first use and replayed: for batches
+ * of few frame rows, where the ~110 launches of a decode are a few microseconds each and the host's launch rate, not the GPU, sets
+ * the time (config c1: 8 motions x 60 frames).  `graph` comes from ladiff_decoder_graph_create; the graph is keyed on every pointer
+ * argument (z, lengths, counts, row_off, feats, ws, stream), the shapes and the weight tables (hash of their pointers +
+ * `weights_generation`, as ladiff_diffusion_reverse) and is re-captured - after a hipStreamSynchronize(stream) - when any of them
+ * changes, so callers keep z / feats / ws in persistent buffers.  `stream` must not be the null stream (capture is illegal there).
+ * ladiff_decoder_graph_destroy synchronises the device. */
+int ladiff_decoder_graph_create(void** graph);
+int ladiff_decoder_graph_destroy(void* graph);
+int ladiff_vae_decode_graphed(void* graph, const float* const* w, const float* const* w_split /*or NULL*/, uint64_t weights_generation,
+                              const float* z, const int32_t* lengths, const int32_t* counts, const int32_t* row_off /*or NULL*/,
+                              int total_rows, int B, int F, int T, int C, float* feats, void* ws, size_t ws_bytes,
+                              ladiff_stream_t stream);
 
 /* ------------------------------------------------------------------ LA-VAE encoder
  * LADiffVae.encode, ladiff_vae.py:162-286 (call sites ladiff.py:269, :324, :1096): features[B,F,C] ->

@@ -110,6 +110,10 @@ _SIGNATURES = {
     "ladiff_debug_set_decoder_fusion": (c_int, [c_int]),
     "ladiff_debug_set_mlp_variant": (c_int, [c_int]),
     "ladiff_reverse_plan": (c_int, [c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ladiff_decoder_graph_create": (c_int, [ctypes.POINTER(c_void_p)]),
+    "ladiff_decoder_graph_destroy": (c_int, [c_void_p]),
+    "ladiff_vae_decode_graphed": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                          c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ladiff_vae_decode_ragged": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                          c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
 }

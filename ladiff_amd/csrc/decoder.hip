@@ -5,6 +5,8 @@
 
 namespace ladiff {
 
+constexpr int DEC_SMALL_ROWS = 4096;
+int g_dec_small_rows_path = 1;    // measurement switch (ladiff_debug_set_decoder_fusion bit 2 clear / set): the small-M GEMM routing
 int g_dec_fused_mlp = 1;          // measurement switch (ladiff_debug_set_decoder_fusion): 0 = linear1 / linear2 / LayerNorm as three launches, 1 = fused from dec_mlp_min_rows() rows, 2 = fused always
 
 static GemmArgs lin(const float* A, int lda, const float* W, const float* bias, float* Y, int ldy, int M, int N, int K,
@@ -68,6 +70,19 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
         LADIFF_TRY(launch_decoder_cross_prep(pb, NL, B, T, s));
     }
 
+    // Few frame rows (config c1: 8 x 60 = 480): a 128x128-tile launch is then 8 - 32 workgroups that each walk the whole K, ~16 us per
+    // GEMM whatever its size (profiles/r3: 40 of them were 0.63 of a 0.9 ms decode).  Below DEC_SMALL_ROWS the bf16x3 path runs its
+    // GEMMs on the denoiser's small-M kernels instead (gemm_kr.hip: K-resident 32 / 64 / 80-row tiles, K = 1024 as four partial planes
+    // that the LayerNorm row pass sums) - the same S-format operands and products, 3 - 4x the workgroups.
+    const bool small = sp && M < DEC_SMALL_ROWS && g_dec_small_rows_path;
+    auto krs = [&](const float* A, int K, const float* W, const float* bias, float* Y, float* Ys, int ldy, int N, int act,
+                   const float* res, int rows) -> int {
+        KrArgs g;
+        g.A = A; g.lda = K; g.W = W; g.ldw = K; g.bias = bias; g.Y = Y; g.Ys = Ys; g.ldy = ldy; g.M = rows; g.N = N; g.K = K; g.act = act;
+        g.res = res; g.ldres = D; g.split = 1;
+        return launch_gemm_kr(g, s);
+    };
+
     // GEMM + (residual) + LayerNorm: fused epilogue in the fp32 path; GEMM(+residual) then a LayerNorm row kernel in the
     // bf16x3 path.  `A`/`As`: operand in fp32 / S-format; result (fp32 + S-format twin) goes to dst / dsts.
     auto gemm_ln = [&](const float* A, int K, const float* W, const float* Wsp, const float* bias, const float* res,
@@ -98,10 +113,17 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
         const bool is_in = l < NSKIP, is_out = l > NSKIP, last = l == NL - 1;
         if (is_out) {   // x = linear(cat([x, xs.pop()]))   cross_attention.py:140-142
             const LinearW& sk = w.skip[l - NSKIP - 1];
+            if (small) {        // whole 256-wide rows per workgroup, K = 512 streamed (gemm_rowln.hip, as the denoiser's skip layers)
+                RowLnArgs g;
+                g.A = curs; g.lda = D; g.A2 = SKs[NL - 1 - l]; g.lda2 = D; g.K1 = D; g.W = wsp->skip[l - NSKIP - 1].w; g.ldw = 2 * D; g.bias = sk.b;
+                g.Y = P[3]; g.Ys = Ps[3]; g.ldy = D; g.M = M; g.K = 2 * D;
+                LADIFF_TRY(launch_gemm_rowln(g, s));
+            } else {
             GemmArgs g = lin(sp ? curs : cur, D, sp ? wsp->skip[l - NSKIP - 1].w : sk.w, sk.b, P[3], D, M, D, 2 * D);
             g.A2 = sp ? SKs[NL - 1 - l] : SK[NL - 1 - l]; g.lda2 = D; g.K1 = D;
             g.split = sp ? 1 : 0; g.Ys = Ps[3];
             LADIFF_TRY(launch_gemm(g, s));
+            }
             cur = P[3]; curs = Ps[3];
         }
         // ---- self-attention over frames, keys >= len masked   cross_attention.py:367-371
@@ -110,9 +132,14 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
         const bool shared = l == 0;
         if (shared) {
             LADIFF_TRY(launch_broadcast_pe(w.query_pe, 1, F, pex, sp ? pexs : nullptr, s));
+            if (small) LADIFF_TRY(krs(pexs, D, Ls.self_attn.in_w, L.self_attn.in_b, qkv0, nullptr, 3 * D, 3 * D, ACT_NONE, nullptr, F));
+            else {
             GemmArgs g = lin(sp ? pexs : pex, D, Ls.self_attn.in_w, L.self_attn.in_b, qkv0, 3 * D, F, 3 * D, D);
             g.split = sp ? 1 : 0;
             LADIFF_TRY(launch_gemm(g, s));
+            }
+        } else if (small) {
+            LADIFF_TRY(krs(curs, D, Ls.self_attn.in_w, L.self_attn.in_b, qkv, nullptr, 3 * D, 3 * D, ACT_NONE, nullptr, M));
         } else {
             GemmArgs g = lin(sp ? curs : cur, D, Ls.self_attn.in_w, L.self_attn.in_b, qkv, 3 * D, M, 3 * D, D);
             g.split = sp ? 1 : 0;
@@ -125,9 +152,12 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
         // norm1's output, the cross-attention kernel below, normalises its rows as it loads them (one row kernel pass less)
         const NormW* n1_late = nullptr;
         if (sp) {
+            if (small) LADIFF_TRY(krs(att, D, Ls.self_attn.out_w, L.self_attn.out_b, P[1], nullptr, D, D, ACT_NONE, cur, M));
+            else {
             GemmArgs g = lin(att, D, Ls.self_attn.out_w, L.self_attn.out_b, P[1], D, M, D, D);
             g.res = cur; g.ldres = D; g.split = 1;
             LADIFF_TRY(launch_gemm(g, s));
+            }
             n1_late = &L.norm1;
         } else {
             LADIFF_TRY(gemm_ln(att, D, L.self_attn.out_w, Ls.self_attn.out_w, L.self_attn.out_b, cur, L.norm1, nullptr, P[1], nullptr));
@@ -142,6 +172,12 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
         if (sp && g_dec_fused_mlp && (M >= dec_mlp_min_rows() || g_dec_fused_mlp == 2)) {     // one kernel: the hidden rows never leave the registers (dec_mlp.hip)
             LADIFF_TRY(launch_dec_mlp(Ps[2], P[2], Ls.lin1.w, L.lin1.b, Ls.lin2.w, L.lin2.b, L.norm3.g, L.norm3.b,
                                       last ? w.norm.g : nullptr, last ? w.norm.b : nullptr, dst, dsts, M, s));
+        } else if (small) {
+            LADIFF_TRY(krs(Ps[2], D, Ls.lin1.w, L.lin1.b, nullptr, hid, FF, FF, ACT_GELU, nullptr, M));
+            // linear2: K = 1024 as four partial planes (the q|k|v + attention buffers are free by now), summed by the LayerNorm pass
+            LADIFF_TRY(krs(hid, FF, Ls.lin2.w, nullptr, qkv, nullptr, D, D, ACT_NONE, nullptr, M));
+            LADIFF_TRY(launch_reduce_rows(qkv, 4, M, L.lin2.b, P[2], RED_LN, L.norm3.g, L.norm3.b, nullptr, 0, nullptr, nullptr, 1, 1, 0, 0,
+                                          dst, dsts, s, nullptr, last ? w.norm.g : nullptr, last ? w.norm.b : nullptr));
         } else {
             GemmArgs g = lin(sp ? Ps[2] : P[2], D, Ls.lin1.w, L.lin1.b, sp ? nullptr : hid, FF, M, FF, D, ACT_GELU);
             g.split = sp ? 1 : 0; if (sp) g.Ys = hid;

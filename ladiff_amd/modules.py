@@ -180,6 +180,13 @@ class LADiffVae(_HipModule):
         self.frame_per_latent = int(_get(ablation, "FRAME_PER_LATENT", 48))
         self.test_efficiency = bool(_get(ablation, "TEST_EFFICIENCY", False))
         self.length_aware = True        # decode only the valid frames of a mixed-length batch (same results, fewer rows)
+        # Opt-in: decodes of fewer frame rows than this are replayed from a hipGraph over persistent buffers (0 = never, the default).
+        # Measured on config c1 (8 x 60 frames, profiles/r3): 0.467 ms replayed against 0.458 ms launched directly - with the small-M
+        # GEMM routing the ~110 launches are paced by the GPU (kernel + dependent-boundary time), not by the host, so the graph only
+        # frees host time; and a batch whose lengths change from call to call would re-capture every time (milliseconds).
+        self.graph_rows = 0
+        self._dec_plans = {}
+        self._graph_stream = None
         if _get(ablation, "PE_TYPE", "mld") != "mld":
             raise ValueError("Not Support PE type")
         if arch not in ("all_encoder", "encoder_decoder"):
@@ -252,6 +259,60 @@ class LADiffVae(_HipModule):
         dist = torch.distributions.Normal(mu, std)
         return latent.to(features.dtype), dist, torch.tensor(counts, dtype=torch.long)
 
+    def __del__(self):
+        try:
+            for plan in self._dec_plans.values():
+                _lib.lib().ladiff_decoder_graph_destroy(plan["graph"])
+        except Exception:
+            pass
+
+    def _decode_graphed(self, zz, lengths, counts, counts_t, lens_t, ragged_rows, wt, wsplit):
+        """Few frame rows: the decode is ~110 launches of a few microseconds each, paced by the host.  It is captured once per
+        (shape, lengths, weights) into a hipGraph over persistent buffers and replayed (ladiff_vae_decode_graphed)."""
+        from ctypes import byref, c_void_p
+        L = _lib.lib()
+        dev = zz.device
+        T, B, _ = zz.shape
+        F = max(lengths)
+        cur = torch.cuda.current_stream(dev)
+        if self._graph_stream is None or self._graph_stream.device != dev:
+            self._graph_stream = torch.cuda.Stream(device=dev)
+        run = cur if cur.cuda_stream != 0 else self._graph_stream           # capture is illegal on the null stream
+        key = (B, F, T, tuple(lengths), tuple(counts), ragged_rows, str(dev), self.precision, bool(self.test_efficiency), run.cuda_stream)
+        plan = self._dec_plans.get(key)
+        if plan is None:
+            while len(self._dec_plans) >= 4:
+                old = self._dec_plans.pop(next(iter(self._dec_plans)))
+                _lib.check(L.ladiff_decoder_graph_destroy(old["graph"]))
+            h = c_void_p()
+            _lib.check(L.ladiff_decoder_graph_create(byref(h)))
+            wsb = L.ladiff_decoder_workspace_bytes(B, F, T, self.nfeats)
+            off_t = None
+            if ragged_rows:
+                off = [0] * (B + 1)
+                for i, l in enumerate(lengths):
+                    off[i + 1] = off[i] + l
+                off_t = torch.tensor(off, dtype=torch.int32, device=dev)
+            plan = {"graph": h, "z": torch.empty_like(zz), "feats": torch.empty(B, F, self.nfeats, dtype=torch.float32, device=dev),
+                    "ws": _lib.workspace(wsb, dev), "wsb": wsb, "off": off_t,
+                    # private copies: the graph bakes these pointers in (the shared device_ints cache may evict its entries)
+                    "lens": lens_t.clone(), "counts": None if counts_t is None else counts_t.clone()}
+            self._dec_plans[key] = plan
+        else:
+            self._dec_plans[key] = self._dec_plans.pop(key)
+        if run is not cur:
+            run.wait_stream(cur)
+        with torch.cuda.stream(run):
+            plan["z"].copy_(zz)
+            _lib.check(L.ladiff_vae_decode_graphed(
+                plan["graph"], wt.array, wsplit, wt.generation, _lib.ptr(plan["z"]), plan["lens"].data_ptr(),
+                None if plan["counts"] is None else plan["counts"].data_ptr(), None if plan["off"] is None else plan["off"].data_ptr(),
+                ragged_rows, B, F, T, self.nfeats, _lib.ptr(plan["feats"]), _lib.ptr(plan["ws"]), plan["wsb"], run.cuda_stream))
+            out = plan["feats"].clone()
+        if run is not cur:
+            cur.wait_stream(run)
+        return out
+
     def decode(self, z, lengths, plot_att_map=None, latentwise_gen=None):
         """z [max_it,B,256], lengths list[int] -> feats [B, max(lengths), nfeats]; frames >= len are zero."""
         if plot_att_map:
@@ -278,11 +339,14 @@ class LADiffVae(_HipModule):
         wt = self._weight_table()
         wsplit = wt.split_array() if self.precision == "bf16x3" else None
         zz = z.detach().to(torch.float32).contiguous()
+        rows = sum(lengths)
+        ragged = self.length_aware and rows < B * F
+        if self.graph_rows and (rows if ragged else B * F) < self.graph_rows:
+            return self._decode_graphed(zz, lengths, counts, counts_t, lens_t, rows if ragged else 0, wt, wsplit).to(z.dtype)
         feats = torch.empty(B, F, self.nfeats, dtype=torch.float32, device=dev)
         wsb = L.ladiff_decoder_workspace_bytes(B, F, T, self.nfeats)
         ws = _lib.workspace(wsb, dev)
-        rows = sum(lengths)
-        if self.length_aware and rows < B * F:
+        if ragged:
             # mixed lengths: only the valid frames are computed (ragged rows, ladiff_vae_decode_ragged); same frames out
             off = [0] * (B + 1)
             for i, l in enumerate(lengths):

@@ -461,3 +461,40 @@ def test_fused_mlp_matches_three_launch_path_on_a_decode():
         lib().ladiff_debug_set_decoder_fusion(1)
     assert torch.isfinite(b).all() and (a - b).abs().max().item() < 5e-5 * max(1.0, a.abs().max().item())
     assert lib().ladiff_debug_set_decoder_fusion(3) != 0
+    # few rows: the small-M GEMM routing (default) against the large-M kernels on the same decode
+    try:
+        assert lib().ladiff_debug_set_decoder_fusion(4) == 0
+        c = vae.decode(z, lens)
+    finally:
+        lib().ladiff_debug_set_decoder_fusion(1)
+    d = vae.decode(z, lens)
+    assert (c - d).abs().max().item() < 5e-5 * max(1.0, c.abs().max().item())
+
+
+def test_graphed_decode_matches_direct_decode():
+    """Decodes of few frame rows are replayed from a hipGraph over persistent buffers (LADiffVae.graph_rows): same bits as the direct
+    launch sequence, for padded and ragged batches, both arithmetic modes, changing inputs, alternating shapes (re-capture), and on
+    the null stream (a private side stream is fenced in)."""
+    from ladiff_amd import LADiffVae, synthetic as syn
+    from test_abi import ABL, VAE_KW
+    vae = LADiffVae(ABL, **VAE_KW); vae.load_state_dict(syn.vae_weights(263)); vae = vae.to(DEV).eval()
+    cases = [[60] * 8, [196, 60, 120, 1, 77], [48, 48]]
+    for precision in ("bf16x3", "fp32"):
+        vae.precision = precision
+        for rep in range(2):
+            for lens in cases:
+                z = torch.randn(5, len(lens), 256, generator=torch.Generator().manual_seed(10 * rep + len(lens))).to(DEV)
+                for i, l in enumerate(lens):
+                    z[-(-l // 48):, i] = 0
+                vae.graph_rows = 0
+                want = vae.decode(z, lens)
+                vae.graph_rows = 4096
+                got = vae.decode(z, lens)                      # null stream: runs on the fenced side stream
+                assert torch.equal(got, want), (precision, lens)
+                st = torch.cuda.Stream()
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    got2 = vae.decode(z, lens)
+                st.synchronize()
+                assert torch.equal(got2, want), (precision, lens)
+    assert len(vae._dec_plans) <= 4
