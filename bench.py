@@ -221,7 +221,7 @@ def profiled(summary, kernel_key):
 def recorded_cpu_baseline(config_name):
     """The cpu_baseline of the newest N = 1 line of this config committed under profiles/ (for N > 1 lines: the oracle is timed
     on rank 0 at N = 1 only)."""
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"bench_{config_name}*.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"*bench_{config_name}*.json")), reverse=True):
         try:
             with open(path) as f:
                 d = json.loads(f.readline())
