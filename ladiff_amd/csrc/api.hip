@@ -506,7 +506,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
     auto open_window = [&](int lo) -> int {
         if (n_text > 1) return 0;
         LADIFF_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(r.d_step + 2), lo, 1, s));
-        return denoiser_ctab(W, r.tables + (size_t)lo * DEN_STEP_STRIDE, r.window, r.cache, B2, r.cws, r.cws_floats, s);
+        return denoiser_ctab(W, r.tables + (size_t)lo * DEN_STEP_STRIDE, r.window, r.cache, B2, r.cws, r.cws_floats, s, WSp);
     };
     if (sp == nullptr) {
         LADIFF_TRY(prologue(s));

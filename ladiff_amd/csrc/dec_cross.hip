@@ -16,15 +16,13 @@ namespace {
 constexpr int TM = LADIFF_MAX_LATENTS;
 }
 
-// one workgroup per (group of PREP_SB samples, head, layer): G | U rows [T][2][256] of that head and the score offsets c [T] from each
-// sample's K|V rows.  The head's weights are fetched ONCE per workgroup - Wq rows h*64 .. into registers (read coalesced over the
-// output column), the Wo tile [256][64] into LDS (row stride 65: the per-thread row walk is conflict-free) - and reused for the
-// group's samples: one workgroup per sample re-read 128 KB of weights for 20 kFLOP each, 590 MB in all at B = 128 (139 us).
-constexpr int PREP_SB = 8;
+// one workgroup per (sample, head): G | U rows [T][2][256] of that head and the score offsets c [T] from the sample's K|V rows.
+// Wq rows h*64 .. are read coalesced over the output column; the Wo tile [256][64] goes through LDS (row stride 65: the
+// per-thread row walk is conflict-free).
 __global__ __launch_bounds__(256) void dec_cross_prep_kernel(const DecCrossPrepBatch pb, int B, int T) {
     __shared__ float wos[D * 65];
     __shared__ float ks[TM * DH], vs[TM * DH];
-    const int b0 = blockIdx.x * PREP_SB, h = blockIdx.y, n = threadIdx.x, layer = blockIdx.z;
+    const int b = blockIdx.x, h = blockIdx.y, n = threadIdx.x, layer = blockIdx.z;
     const float* __restrict__ kv = pb.kv[layer]; const float* __restrict__ wq = pb.wq[layer]; const float* __restrict__ bq = pb.bq[layer];
     const float* __restrict__ wo = pb.wo[layer]; float* __restrict__ gu = pb.gu[layer];
     float* __restrict__ cc = gu + (size_t)B * H * T * 2 * D;
@@ -32,37 +30,34 @@ __global__ __launch_bounds__(256) void dec_cross_prep_kernel(const DecCrossPrepB
 #pragma unroll
     for (int d = 0; d < DH; ++d) qv[d] = wq[(size_t)(h * DH + d) * D + n];
     for (int u = n; u < D * DH; u += 256) wos[(u >> 6) * 65 + (u & 63)] = wo[(size_t)(u >> 6) * D + h * DH + (u & 63)];
-    for (int b = b0; b < b0 + PREP_SB && b < B; ++b) {
-        __syncthreads();                                                           // the previous sample's ks / vs have been read (first pass: wos is being filled)
-        for (int u = n; u < T * DH; u += 256) {
-            const int j = u >> 6, d = u & 63;
-            ks[u] = kv[((size_t)j * B + b) * 2 * D + h * DH + d];
-            vs[u] = kv[((size_t)j * B + b) * 2 * D + D + h * DH + d];
-        }
-        __syncthreads();
-        float g[TM], u_[TM];
+    for (int u = n; u < T * DH; u += 256) {
+        const int j = u >> 6, d = u & 63;
+        ks[u] = kv[((size_t)j * B + b) * 2 * D + h * DH + d];
+        vs[u] = kv[((size_t)j * B + b) * 2 * D + D + h * DH + d];
+    }
+    __syncthreads();
+    float g[TM], u_[TM];
 #pragma unroll
-        for (int j = 0; j < TM; ++j) { g[j] = 0.f; u_[j] = 0.f; }
+    for (int j = 0; j < TM; ++j) { g[j] = 0.f; u_[j] = 0.f; }
 #pragma unroll
-        for (int d = 0; d < DH; ++d) {
-            const float q = qv[d];
-            const float w = wos[n * 65 + d];                                       // Wo[n][h*64 + d]
-#pragma unroll
-            for (int j = 0; j < TM; ++j)
-                if (j < T) { g[j] = fmaf(q, ks[j * DH + d], g[j]); u_[j] = fmaf(w, vs[j * DH + d], u_[j]); }
-        }
+    for (int d = 0; d < DH; ++d) {
+        const float q = qv[d];
+        const float w = wos[n * 65 + d];                                           // Wo[n][h*64 + d]
 #pragma unroll
         for (int j = 0; j < TM; ++j)
-            if (j < T) {
-                float* o = gu + ((((size_t)b * H + h) * T + j) * 2) * D;
-                o[n] = g[j] * 0.125f;                                              // 1 / sqrt(64), exact
-                o[D + n] = u_[j];
-            }
-        if (n < T) {                                                               // c[h][j] = bq_h . k[b,j,h] / 8
-            float c = 0.f;
-            for (int d = 0; d < DH; ++d) c = fmaf(bq[h * DH + d], ks[n * DH + d], c);
-            cc[((size_t)b * H + h) * T + n] = c * 0.125f;
+            if (j < T) { g[j] = fmaf(q, ks[j * DH + d], g[j]); u_[j] = fmaf(w, vs[j * DH + d], u_[j]); }
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+        if (j < T) {
+            float* o = gu + ((((size_t)b * H + h) * T + j) * 2) * D;
+            o[n] = g[j] * 0.125f;                                                  // 1 / sqrt(64), exact
+            o[D + n] = u_[j];
         }
+    if (n < T) {                                                                   // c[h][j] = bq_h . k[b,j,h] / 8
+        float c = 0.f;
+        for (int d = 0; d < DH; ++d) c = fmaf(bq[h * DH + d], ks[n * DH + d], c);
+        cc[((size_t)b * H + h) * T + n] = c * 0.125f;
     }
 }
 
@@ -190,7 +185,7 @@ size_t dec_cross_ws_floats(int B, int T) { return (size_t)B * H * T * (2 * D + 1
 int launch_decoder_cross_prep(const DecCrossPrepBatch& pb, int n, int B, int T, hipStream_t s) {
     if (B == 0 || n == 0) return 0;
     if (T < 1 || T > TM || n > DEC_PREP_MAX) return LADIFF_ERR_SHAPE;
-    hipLaunchKernelGGL(dec_cross_prep_kernel, dim3((B + PREP_SB - 1) / PREP_SB, H, n), dim3(256), 0, s, pb, B, T);
+    hipLaunchKernelGGL(dec_cross_prep_kernel, dim3(B, H, n), dim3(256), 0, s, pb, B, T);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }

@@ -187,7 +187,10 @@ int denoiser_text_static(const DenoiserW& w, const float* text, int B2, float* c
 
 // c table rows of `n` consecutive steps; `tables_lo` = the time tables at the first of them.  Sampling loops with many steps
 // build it one window at a time (ladiff_diffusion_reverse), so the table is O(window x B), not O(steps x B).
-int denoiser_ctab(const DenoiserW& w, const float* tables_lo, int n, float* cache, int B2, float* u, size_t u_floats, hipStream_t s) {
+// wsp != NULL (bf16x3 mode): the nine out-projections run as ONE batched bf16x3 launch on S-format inputs (the table is 15 GFLOP per
+// 50-step window at B = 128: 157 us on the fp32-input MFMA, profiles/r3/01)
+int denoiser_ctab(const DenoiserW& w, const float* tables_lo, int n, float* cache, int B2, float* u, size_t u_floats, hipStream_t s,
+                  const DenoiserW* wsp) {
     const int R = B2 + 1;
     if (u_floats < (size_t)n * R * D) return LADIFF_ERR_WORKSPACE;
     const float* nval = cache + (size_t)B2 * D + (size_t)NL * B2 * 2 * D;
@@ -201,8 +204,9 @@ int denoiser_ctab(const DenoiserW& w, const float* tables_lo, int n, float* cach
             rb.a[l] = nval + (size_t)l * B2 * D; rb.g[l] = L.ca_proj.norm.b;
             rb.b[l] = tables_lo + (size_t)l * DEN_LAYER_STRIDE + DEN_OFF_CA_MOD; rb.y[l] = ul;
             g[l] = lin(ul, D, L.ca_proj.out, ctab + (size_t)l * n * R * D, D, n * R, D, D);
+            if (wsp != nullptr) { g[l].W = wsp->layer[l].ca_proj.out.w; g[l].split = 1; }
         }
-        LADIFF_TRY(launch_ca_table_input_batch(rb, NL, DEN_STEP_STRIDE, n, B2, s));
+        LADIFF_TRY(launch_ca_table_input_batch(rb, NL, DEN_STEP_STRIDE, n, B2, s, wsp != nullptr ? 1 : 0));
         return launch_gemm_batch(g, NL, s);
     }
     for (int l = 0; l < NL; ++l) {                           // scratch for one layer only
@@ -220,7 +224,7 @@ int denoiser_text_cache(const DenoiserW& w, const float* text, int B2, const flo
     if (ws_floats < den_text_ws_floats(B2, n)) return LADIFF_ERR_WORKSPACE;
     LADIFF_TRY(denoiser_text_static(w, text, B2, cache, ws, ws_floats, s));
     float* u = ws + (size_t)B2 * (TEXT_DIM + NL * D);
-    return denoiser_ctab(w, tables, n, cache, B2, u, ws_floats - (size_t)B2 * (TEXT_DIM + NL * D), s);
+    return denoiser_ctab(w, tables, n, cache, B2, u, ws_floats - (size_t)B2 * (TEXT_DIM + NL * D), s, nullptr);
 }
 
 // ------------------------------------------------------------------ one ca_block, literal (unit entry for the N > 1 path)

@@ -332,9 +332,10 @@ int launch_gemm_batch(const GemmArgs* list, int n, hipStream_t stream) {
     for (int i = 0; i < n; ++i) {
         GemmArgs a = list[i];
         if (a.A2 == nullptr) a.K1 = a.K;
-        LADIFF_CHECK_ARG(a.A && a.W && a.Y && !a.Ys && !a.split && a.M >= 0 && a.N > 0 && a.K > 0);
+        LADIFF_CHECK_ARG(a.A && a.W && (a.Y || a.Ys) && (a.split || (a.Y && !a.Ys)) && a.M >= 0 && a.N > 0 && a.K > 0);
         // one shape, one epilogue kind: the launch configuration is chosen once
-        LADIFF_CHECK_ARG(a.M == list[0].M && a.N == list[0].N && a.K == list[0].K && (a.ln_g != nullptr) == (list[0].ln_g != nullptr));
+        LADIFF_CHECK_ARG(a.M == list[0].M && a.N == list[0].N && a.K == list[0].K && (a.ln_g != nullptr) == (list[0].ln_g != nullptr) &&
+                         a.split == list[0].split);
         if (a.K % BK != 0 || a.K1 % BK != 0 || a.K1 > a.K) return LADIFF_ERR_SHAPE;
         if ((a.lda % 4) || (a.ldw % 4) || (a.A2 && (a.lda2 % 4))) return LADIFF_ERR_SHAPE;
         if (a.ln_g == nullptr && (a.ln2_g || a.mod)) return LADIFF_ERR_ARG;
@@ -343,6 +344,11 @@ int launch_gemm_batch(const GemmArgs* list, int n, hipStream_t stream) {
     }
     const GemmArgs& a = b.a[0];
     if (a.M == 0) return 0;
+    if (a.split) {                                     // bf16x3 operands: the large-M kernel only, every set must qualify
+        for (int i = 0; i < n; ++i)
+            if (!gemm_big_supported(b.a[i])) return LADIFF_ERR_SHAPE;
+        return launch_gemm_big_batch(b, n, stream);
+    }
     if (gemm_big_supported(a)) return launch_gemm_big_batch(b, n, stream);
     if (a.ln_g != nullptr) {
         if (a.M >= 4096) return launch_cfg_batch<64, 256, 2, 1, 32, true>(b, n, stream);

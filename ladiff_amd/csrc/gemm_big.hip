@@ -190,7 +190,7 @@ __device__ __forceinline__ void gemm_big_body(const GemmArgs& p) {
 // conflict-free for the 16x16x32 operand layout.  Output: fp32 and/or S-format, bias / activation / residual fused;
 // LayerNorm runs as a row kernel afterwards (a 256-wide tile would move 4x the operand bytes per FLOP).
 template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void gemm_big_split_kernel(const GemmArgs p) {
+__device__ __forceinline__ void gemm_big_split_body(const GemmArgs& p) {
     constexpr int NW = 4, WM = 2, WN = 2;
     constexpr int TMW = BM / WM, TNW = BN / WN, RM = TMW / 16, RN = TNW / 16;
     constexpr int ROWS = BM + BN;
@@ -334,6 +334,12 @@ __global__ __launch_bounds__(256, 2) void gemm_big_split_kernel(const GemmArgs p
     });
 }
 
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_big_split_kernel(const GemmArgs p) { gemm_big_split_body<BM, BN>(p); }
+// up to GEMM_BATCH_MAX independent same-shape bf16x3 GEMMs as one launch (grid.y = argument set): the nine layers' c-table GEMMs
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_big_split_batch_kernel(const GemmBatch b) { gemm_big_split_body<BM, BN>(b.a[blockIdx.y]); }
+
 template <int BM, int BN, int WM, int WN, bool LN>
 __global__ __launch_bounds__(256) void gemm_big_kernel(const GemmArgs p) { gemm_big_body<BM, BN, WM, WN, LN>(p); }
 template <int BM, int BN, int WM, int WN, bool LN>
@@ -379,9 +385,15 @@ int launch_gemm_big(const GemmArgs& a, hipStream_t s) {
     return launch_big<128, 128, 2, 2, false>(a, s);
 }
 
-// fp32-input path only (the caller checked gemm_big_supported on the common shape)
+// (the caller checked gemm_big_supported on the common shape)
 int launch_gemm_big_batch(const GemmBatch& b, int n, hipStream_t s) {
-    if (b.a[0].split) return LADIFF_ERR_ARG;
+    if (b.a[0].split) {
+        const GemmArgs& a = b.a[0];
+        const int nbm = (a.M + 127) / 128, nbn = a.N / 128;
+        hipLaunchKernelGGL((gemm_big_split_batch_kernel<128, 128>), dim3(((nbm + 7) / 8) * 8 * nbn, n), dim3(256), 0, s, b);
+        LADIFF_LAUNCH_CHECK();
+        return 0;
+    }
     if (b.a[0].ln_g != nullptr) return launch_big_batch<64, 256, 2, 2, true>(b, n, s);
     return launch_big_batch<128, 128, 2, 2, false>(b, n, s);
 }

@@ -20,7 +20,7 @@ constexpr int ROW_BATCH_MAX = 9;
 struct RowBatch { const float* a[ROW_BATCH_MAX]; const float* g[ROW_BATCH_MAX]; const float* b[ROW_BATCH_MAX]; float* y[ROW_BATCH_MAX]; };
 int launch_layernorm_batch(const RowBatch& rb, int n, int M, hipStream_t s);
 // ca_table_input for n_layers layers at once: a = nval, g = beta, b = mod (step 0) , y = u of each layer
-int launch_ca_table_input_batch(const RowBatch& rb, int n_layers, int step_stride, int n, int B2, hipStream_t s);
+int launch_ca_table_input_batch(const RowBatch& rb, int n_layers, int step_stride, int n, int B2, hipStream_t s, int split_out = 0);
 int launch_ca_table_input(const float* nval, const float* beta, const float* mod, int step_stride, int n, int B2, float* u,
                           hipStream_t s);
 int launch_add_pe(const float* sample, const float* pe, int Bs, int b_off, int b_n, int T, float* x, float* xs, hipStream_t s);

@@ -29,7 +29,8 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* w_split, const float* 
 const float* den_cache_tkv(const float* cache, int B2, int ntxt);
 const float* den_cache_ctab(const float* cache, int B2, int ntxt);
 int denoiser_text_static(const DenoiserW& w, const float* text, int B2, float* cache, float* ws, size_t ws_floats, hipStream_t s);
-int denoiser_ctab(const DenoiserW& w, const float* tables_lo, int n, float* cache, int B2, float* u, size_t u_floats, hipStream_t s);
+int denoiser_ctab(const DenoiserW& w, const float* tables_lo, int n, float* cache, int B2, float* u, size_t u_floats, hipStream_t s,
+                  const DenoiserW* w_split = nullptr);
 int linear_cross_attention(const DenoiserW& w, int layer, const float* x, const float* xf, const float* emb, const int32_t* counts,
                            int B, int T, int N, float* out, float* ws, size_t ws_floats, hipStream_t s);
 size_t linear_cross_attention_ws_floats(int B, int T, int N);

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void ca_table_input_kernel(const float* __rest
     for (int i = 0; i < 4; ++i) v[i] = silu(v[i] * (1.f + sc[i]) + sh[i]);
     st4(u + (size_t)row * D + c, v);
 }
-__global__ __launch_bounds__(256) void ca_table_input_batch_kernel(const RowBatch rb, int step_stride, int B2, int M) {
+__global__ __launch_bounds__(256) void ca_table_input_batch_kernel(const RowBatch rb, int step_stride, int B2, int M, int split_out) {
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     const int c = (threadIdx.x & 63) * 4;
     if (row >= M) return;
@@ -181,14 +181,15 @@ __global__ __launch_bounds__(256) void ca_table_input_batch_kernel(const RowBatc
     f32x4 v = b < B2 ? ld4(rb.a[k] + (size_t)b * D + c) : ld4(rb.g[k] + c);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = silu(v[i] * (1.f + sc[i]) + sh[i]);
-    st4(rb.y[k] + (size_t)row * D + c, v);
+    if (split_out) store_split4(rb.y[k] + (size_t)row * D, c, v);       // the only reader is a bf16x3 GEMM: S-format operand rows
+    else st4(rb.y[k] + (size_t)row * D + c, v);
 }
-int launch_ca_table_input_batch(const RowBatch& rb, int n_layers, int step_stride, int n, int B2, hipStream_t s) {
+int launch_ca_table_input_batch(const RowBatch& rb, int n_layers, int step_stride, int n, int B2, hipStream_t s, int split_out) {
     const int M = n * (B2 + 1);
     if (M == 0 || n_layers == 0) return 0;
     LADIFF_CHECK_ARG(n_layers >= 1 && n_layers <= ROW_BATCH_MAX);
     hipLaunchKernelGGL(ca_table_input_batch_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, n_layers), dim3(256), 0, s, rb,
-                       step_stride, B2, M);
+                       step_stride, B2, M, split_out);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
