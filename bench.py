@@ -476,7 +476,9 @@ def main():
         if world == 1:
             sample = args.cpu_sample
             if sample is None:
-                sample = {"c1": 8, "c3": 2}.get(args.config, 32)
+                # ~10 - 30 s of CPU work on the GPU box's host (16 threads there run ~19 motions/s of 50-step DDIM, 0.23 motions/s of
+                # 1000-step DDPM; the decode-only sample repeats for 10 s)
+                sample = {"c1": 8, "c3": 4}.get(args.config, 256)
             if sample > 0:
                 line["cpu_baseline"] = cpu_baseline(cfg, sample)
                 line["cpu_baseline"]["gpu_over_cpu"] = round(motions_per_s / line["cpu_baseline"]["value"], 1)
