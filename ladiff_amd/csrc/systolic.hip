@@ -935,9 +935,11 @@ struct MlpRole {
                     tile_put1<AR, 2>(htile, row, k, act_c<ACT>(acc1[i][j][r] + b1[j]));
                 }
             }
+        SYS_STAMP(6);
         mid.before_barrier();
         __syncthreads();
         mid.after_barrier();
+        SYS_STAMP(7);
         f32x4 acc2[MR][NT2];
         zero_acc(acc2);
         mma<AR, 2, NT2, 4, MR>(htile, w2, acc2);

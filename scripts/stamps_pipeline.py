@@ -84,7 +84,7 @@ for k, v in agg.items():
 
 busy = sorted((float(stats[i, 0]) * 0.01 / steps, n, xcd[i], local[i]) for i, n in enumerate(names) if stats[i, 2] > 0)
 print("least blocked workgroups (us/step blocked, stage, XCD, * = plain stores): " + "  ".join(f"{a:.1f} {n.replace(' ', '.')}@{x}{'*' if lo else ''}" for a, n, x, lo in busy[:16]))
-print("steady state (mid-run, four consecutive blocks): us since the first block's loop top; stamps 0 top, 1 operands issued, 2 committed, 3 mfma, 6/7 (QKV: tile in LDS / scores), 4 stored, 5 published-or-deferred")
+print("steady state (mid-run, four consecutive blocks): us since the first block's loop top; stamps 0 top, 1 operands issued, 2 committed, 3 mfma, 6/7 (QKV: tile in LDS / scores; LIN, FFN: hidden slice written / past the mid barrier with the previous flag raised and the next loads issued), 4 stored, 5 published-or-deferred")
 for i, n in enumerate(names):
     if n in ("L4 QKV0", "L4 OUT", "L4 LIN0", "L4 RED2.0", "L4 FFN0", "L4 STYL.0"):
         m = mid[i]
