@@ -256,7 +256,7 @@ int ladiff_debug_set_xcd_local(int on);
 /* Measurement switch (process-wide): 1 (default) = the decoder's feed-forward block runs as the fused kernel of csrc/dec_mlp.hip in
  * bf16x3 mode from 10,000 frame rows up, 2 = at every size, 0 = as linear1 GEMM + linear2 GEMM + LayerNorm row kernel (the round-2
  * path; same arithmetic per product).  + 4: decodes of fewer than 4,096 frame rows keep the large-M GEMM kernels instead of the
- * small-M ones (the round-2 routing). */
+ * small-M ones (the round-2 routing).  + 8: final_layer on the fp32-input kernel in bf16x3 mode too (the round-2 path). */
 int ladiff_debug_set_decoder_fusion(int on);
 /* Measurement switch (process-wide) of the fused feed-forward kernel's form: 0 (default) = chosen by the row count, 1 = 128-row
  * workgroups of eight waves x 16 rows, 2 = 64-row workgroups of four waves x 16 rows, 3 = 128-row workgroups of four waves x 32 rows. */
@@ -305,6 +305,9 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
 /* ------------------------------------------------------------------ LA-VAE decoder (LADiffVae.decode)
  * feats[B,F,C] from z[T,B,256]; frames >= lengths[b] come out zero.  ladiff_vae.py:288-362
  * (call site ladiff.py:283).  lengths/counts are int32 device arrays of B entries. */
+/* w_split (bf16x3 mode): the S-format copies of the weight matrices as for the denoiser, EXCEPT final_layer.weight and
+ * final_layer.bias, which are padded with zero rows / zeros to ceil(C / 128) * 128 output features (384 for HumanML3D, 256 for KIT)
+ * before the conversion: from 4,096 frame rows up the final projection runs on whole 128-column bf16x3 tiles. */
 size_t ladiff_decoder_workspace_bytes(int B, int F, int T, int C);
 int ladiff_vae_decode(const float* const* w, const float* const* w_split /*or NULL: fp32 MFMA*/, const float* z,
                       const int32_t* lengths, const int32_t* counts, int B, int F, int T, int C, float* feats,

@@ -171,13 +171,16 @@ class WeightTable:
     array and device copies) a freed one used."""
     _next_generation = 1
 
-    def __init__(self, kind, tensors, n_names=None, no_split=()):
+    def __init__(self, kind, tensors, n_names=None, no_split=(), pad_rows=None):
         self.generation = WeightTable._next_generation
         WeightTable._next_generation += 1
         names = param_names(kind)
         if n_names is not None:      # a prefix of the table (CLIP with fewer than 12 layers); the tail stays NULL
             names = names[:n_names]
         self.no_split = set(no_split)
+        # name -> multiple: in the S-format table these tensors are padded with zero rows (matrices) / zeros (vectors) up to a multiple
+        # of that many output features (the decoder's final_layer: 263 / 251 features -> 384 / 256, whole 128-column GEMM tiles)
+        self.pad_rows = dict(pad_rows or {})
         self.names = names
         self.tensors = []   # keep the fp32 contiguous GPU tensors alive
         for n in names:
@@ -198,6 +201,11 @@ class WeightTable:
             L = lib()
             self.split_tensors = []
             for n, t in zip(self.names, self.tensors):
+                mult = self.pad_rows.get(n)
+                if mult and t.shape[0] % mult:
+                    padded = torch.zeros(((t.shape[0] + mult - 1) // mult * mult,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+                    padded[:t.shape[0]] = t
+                    t = padded
                 if t.dim() == 2 and t.shape[1] % 64 == 0 and n not in self.no_split:
                     s = torch.empty_like(t)
                     check(L.ladiff_split_rows(t.data_ptr(), s.data_ptr(), t.shape[0], t.shape[1], stream_ptr()))

@@ -6,6 +6,7 @@
 namespace ladiff {
 
 constexpr int DEC_SMALL_ROWS = 4096;
+int g_dec_final_split = 1;        // measurement switch (ladiff_debug_set_decoder_fusion + 8): final_layer on the fp32 kernel as in round 2
 int g_dec_small_rows_path = 1;    // measurement switch (ladiff_debug_set_decoder_fusion bit 2 clear / set): the small-M GEMM routing
 int g_dec_fused_mlp = 1;          // measurement switch (ladiff_debug_set_decoder_fusion): 0 = linear1 / linear2 / LayerNorm as three launches, 1 = fused from dec_mlp_min_rows() rows, 2 = fused always
 
@@ -187,6 +188,17 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
         cur = dst; curs = dsts;
     }
     // final_layer + zero padded frames, written as [B, F, C]   ladiff_vae.py:356-360
+    if (sp && M >= DEC_SMALL_ROWS && g_dec_final_split) {
+        // bf16x3 mode: the projection runs on the large-M bf16x3 kernel over whole 128-column tiles - the S-format table carries
+        // final_layer.weight / .bias padded with zero rows to Np = ceil(C / 128) 128 features - into the (free) hidden buffer, and a row
+        // kernel moves the C real columns into [B, F, C] (zeroing padded frames / scattering ragged rows): 94 us -> ~40 us at 25088 rows
+        const int Np = (C + 127) / 128 * 128;
+        if ((size_t)Np > (size_t)FF) return LADIFF_ERR_SHAPE;
+        GemmArgs g = lin(curs, D, wsp->final_layer.w, wsp->final_layer.b, hid, Np, M, Np, D);
+        g.split = 1;
+        LADIFF_TRY(launch_gemm(g, s));
+        return launch_scatter_feats(hid, Np, C, M, F, ragged ? nullptr : lengths, ragged ? row_out : nullptr, feats, s);
+    }
     GemmArgs g = lin(cur, D, w.final_layer.w, w.final_layer.b, feats, C, M, C, D);
     if (ragged) g.row_map = row_out;                      // every computed row is a valid frame
     else { g.row_len = lengths; g.rows_per_item = F; }

@@ -558,4 +558,27 @@ int launch_finalize_latents(const float* lat, const int32_t* counts, float* z, i
     return 0;
 }
 
+// feats[B, F, C] rows from the padded tile output tmp[M, ldt] of the final projection: row r goes to feats row row_map[r] (ragged rows:
+// the caller zero-filled feats) or to row r itself, zeroed when (r % F) >= row_len[r / F] (padded frames, ladiff_vae.py:356-360).
+// C = 263 / 251 is not a multiple of 4: 4-byte stores, a row per wave.
+__global__ __launch_bounds__(256) void scatter_feats_kernel(const float* __restrict__ tmp, int ldt, int C, int M, int F,
+                                                            const int32_t* __restrict__ row_len, const int32_t* __restrict__ row_map,
+                                                            float* __restrict__ feats) {
+    const int r = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= M) return;
+    const int dst = row_map != nullptr ? row_map[r] : r;
+    const bool valid = row_len == nullptr || (r % F) < row_len[r / F];
+    const float* src = tmp + (size_t)r * ldt;
+    float* out = feats + (size_t)dst * C;
+    for (int c = lane; c < C; c += 64) out[c] = valid ? src[c] : 0.f;
+}
+int launch_scatter_feats(const float* tmp, int ldt, int C, int M, int F, const int32_t* row_len, const int32_t* row_map, float* feats,
+                         hipStream_t s) {
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(scatter_feats_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, tmp, ldt, C, M, F, row_len, row_map, feats);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace ladiff

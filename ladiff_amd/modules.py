@@ -54,6 +54,9 @@ def _get(ablation, name, default=None):
 class _HipModule(_ParamTree):
     _KIND = None
 
+    # S-format table only: tensors padded to whole 128-column GEMM tiles (include/ladiff_hip.h, ladiff_vae_decode)
+    _PAD_ROWS = {"decoder": {"final_layer.weight": 128, "final_layer.bias": 128}}
+
     def _weight_table(self, kind=None):
         kind = kind or self._KIND
         sd = dict(self.named_parameters())
@@ -62,7 +65,7 @@ class _HipModule(_ParamTree):
         cache = self.__dict__.setdefault("_wt", {})
         tab = cache.get(kind)
         if tab is None or tab.key != key:
-            tab = _lib.WeightTable(kind, sd)
+            tab = _lib.WeightTable(kind, sd, pad_rows=self._PAD_ROWS.get(kind))
             cache[kind] = tab
         return tab
 

@@ -471,6 +471,32 @@ def test_fused_mlp_matches_three_launch_path_on_a_decode():
     assert (c - d).abs().max().item() < 5e-5 * max(1.0, c.abs().max().item())
 
 
+@pytest.mark.parametrize("nfeats", [263, 251])
+def test_final_layer_on_padded_bf16x3_tiles_matches_fp32_kernel(nfeats):
+    """From 4,096 frame rows up the bf16x3 decode runs final_layer on whole 128-column tiles of the zero-padded S-format weight and
+    scatters the real columns into [B, F, C]; + 8 keeps the round-2 fp32-input kernel.  Same frames to bf16x3 rounding, exact zeros on
+    padded frames, for a padded batch and a ragged one (row scatter) and both feature counts."""
+    from ladiff_amd import LADiffVae, synthetic as syn
+    from test_abi import ABL, VAE_KW
+    vae = LADiffVae(ABL, **{**VAE_KW, "nfeats": nfeats})
+    vae.load_state_dict(syn.vae_weights(nfeats)); vae = vae.to(DEV).eval()
+    vae.precision = "bf16x3"
+    for lens in ([196] * 24, [196, 60, 120, 1, 77, 196, 48, 150, 33] * 5):
+        z = torch.randn(5, len(lens), 256, generator=torch.Generator().manual_seed(len(lens))).to(DEV)
+        for i, l in enumerate(lens):
+            z[-(-l // 48):, i] = 0
+        try:
+            assert lib().ladiff_debug_set_decoder_fusion(1 + 8) == 0
+            a = vae.decode(z, lens)
+        finally:
+            lib().ladiff_debug_set_decoder_fusion(1)
+        b = vae.decode(z, lens)
+        assert b.shape == (len(lens), max(lens), nfeats) and torch.isfinite(b).all()
+        assert (a - b).abs().max().item() < 5e-5 * max(1.0, a.abs().max().item())
+        for i, l in enumerate(lens):
+            assert (b[i, l:] == 0).all()
+
+
 def test_graphed_decode_matches_direct_decode():
     """Decodes of few frame rows are replayed from a hipGraph over persistent buffers (LADiffVae.graph_rows): same bits as the direct
     launch sequence, for padded and ragged batches, both arithmetic modes, changing inputs, alternating shapes (re-capture), and on
