@@ -19,8 +19,19 @@
 //     128 hidden columns: 8 stages of W1 (k = the 256 model columns) then 8 stages of W2 (its 256 rows in two halves x the 128
 //     hidden columns in four k-steps).  Per 128 rows that is 2 MB of ingest for 403 MFLOP (bf16): 200 FLOP per byte, against
 //     96 for a 128x128x256 GEMM tile - the MFMA pipe, not the LDS fill, is the bound.
-//   * eight waves (two per SIMD): one wave's LDS-DMA issue, LDS reads, GELU and barrier waits hide under its partner's MFMAs; waves
-//     4-7 issue their DMA pieces after the stage's MFMAs, waves 0-3 before (partners must not do the same thing at the same time).
+//   * workgroup forms (template): four waves x 32 rows (default from 160 row tiles up: a weight fragment read from LDS feeds two row
+//     tiles), eight waves x 16 rows, four waves x 16 rows (64-row workgroups, twice as many, when there are few rows).
+//   * the weight fragments travel through a ring of four tile buffers in registers that runs ACROSS the stage boundaries (the
+//     barrier of stage u + 1 stands in front of tile 5 of stage u), each fragment requested 17 MFMAs ahead of its use, the two
+//     ds_read_b128 of a tile behind the previous tile's first MFMA.
+//   * epilogue: bias / residual / LayerNorm(s) in the accumulator layout with the per-column vectors in LDS; the tile then goes
+//     through the (now free) ring so that every store writes one whole 1-KiB row.
+// What the time is made of (profiles/r3/13, 25088 rows, 99 us): with the GELU replaced by the identity 84 us, without the epilogue
+// 84 us (of which ~10 us are the 77 MB all workgroups move at the same moment), without the LDS-DMA 94 us.  NOTE on the builds that
+// take the MFMA operands from registers nothing writes (no fragment reads: 78 us; reads issued and waited for but not used: 80 us):
+// they do not show that the reads cost 20 us - constant operands let the chip clock the matrix pipe ~25 % higher than random
+// weights do (MI355X_MICROARCH.md: 1.5 - 1.7 GHz in MFMA-dense loops on random data, 2.39 GHz on zeros).  Deeper fragment prefetch
+// (10 -> 17 MFMAs) moved the kernel by 2 us: the waits are not what binds.
 #include "model.h"
 #include "tile_mma.h"
 
@@ -31,7 +42,7 @@ namespace {
 constexpr int MLP_NS = 8;                      // ring stages
 constexpr int MLP_STAGE = 16384;               // bytes: 128 weight rows x 128 B
 constexpr int MLP_AHEAD = 6;                   // stages in flight behind the one being multiplied
-constexpr int MLP_LDS = MLP_NS * MLP_STAGE + FF * 4;      // ring + linear1's bias
+constexpr int MLP_LDS = MLP_NS * MLP_STAGE + FF * 4 + 5 * D * 4;      // ring + linear1's bias + b2, gamma / beta of the LayerNorm(s)
 
 typedef unsigned u32x4_m __attribute__((ext_vector_type(4)));
 
@@ -56,6 +67,10 @@ template <int OFF>
 __device__ __forceinline__ void fetch16(u32x4_m& v, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
 }
+template <int OFF>
+__device__ __forceinline__ void fetch16_keep(u32x4_m& v, unsigned addr) {   // the destination stays allocated between calls (DIAG 6: nothing else keeps it)
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(v) : "v"(addr), "n"(OFF) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_lgkm(u32x4_m& a, u32x4_m& b, u32x4_m& c, u32x4_m& d) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
@@ -71,7 +86,9 @@ __device__ __forceinline__ bf16x8 as_bf(const u32x4_m v) { return __builtin_bit_
 //   <8, 1>: 128 rows, two waves per SIMD with 16 rows each (the first half of the waves issues its DMA early in a stage, the second
 //           half late: partners must not do the same thing at the same time);
 //   <4, 1>: 64 rows (twice as many workgroups when there are few rows).
-// DIAG (timing experiments only, results are garbage): 1 = no LDS-DMA inside the stage loop, 2 = no MFMAs, 3 = no LDS fragment reads
+// DIAG (timing experiments only, results are garbage): 1 = no LDS-DMA inside the stage loop, 2 = no MFMAs, 3 = no LDS fragment reads,
+// 4 = no GELU (identity), 5 = no epilogue (residual loads, LayerNorm, stores), 6 = fragment reads issued but never waited for or used,
+// 7 = fragment reads waited for as usual, the MFMAs take other registers
 template <int NW, int RT, int DIAG = 0>
 __global__ __launch_bounds__(64 * NW, NW / 4) void dec_mlp_kernel(const MlpArgs p) {
     constexpr int NT = 64 * NW, RW = 16 * RT, BM = RW * NW, PPW = 16 / NW;   // threads, rows per wave / workgroup, DMA pieces per wave and stage
@@ -101,6 +118,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void dec_mlp_kernel(const MlpArgs 
         }
     }
     for (int i = tid; i < FF / 4; i += NT) st4(b1s + 4 * i, ld4(p.b1 + 4 * i));
+    // the epilogue's per-column vectors: from LDS a lane's 16 B cost a ds_read, from memory each was a scattered 16-row load (5 x 32
+    // of them per lane: ~6 us of the kernel)
+    float* const prm = b1s + FF;                                          // [5][256]: b2, g3, be3, g4, be4
+    for (int i = tid; i < 5 * D / 4; i += NT) {
+        const int which = i / (D / 4), c4 = i % (D / 4);
+        const float* src = which == 0 ? p.b2 : which == 1 ? p.g3 : which == 2 ? p.be3 : which == 3 ? p.g4 : p.be4;
+        if (src != nullptr) st4(prm + 4 * i, ld4(src + 4 * c4));
+    }
 
     // ---- LDS-DMA of one stage: wave w brings the PPW pieces (a piece = 8 LDS rows x 128 B) q = w + NW i: LDS rows 8 q + (lane >> 3)
     const int cs = (lane & 7) ^ ((lane >> 4) & 3) ^ (4 * (wave & 1));    // source slot that lands in LDS slot (lane & 7): slot ^ ((row >> 1) & 7), row = 8 q + (lane >> 3), q = wave (mod 2) for even NW
@@ -135,44 +160,53 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void dec_mlp_kernel(const MlpArgs 
         for (int j = 0; j < 16; ++j) oacc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // one stage's products: acc[rt][J0 + j] += W(tile j) . b[rt]^T over its 32 k, j < 8; three bf16 MFMAs per product (x_lo W_hi,
-    // x_hi W_lo, x_hi W_hi: the order of gemm_big_split_kernel), one product at a time over a tile pair's 2 RT accumulators.  The
-    // fragments of the next tile pair are requested before a pair's MFMAs; between(g) runs after the MFMAs of pair g.
-    auto stage_mma = [&](auto slotc, auto& acc, auto j0c, const bf16x8 (&bh)[RT], const bf16x8 (&bl)[RT], auto&& between) __attribute__((always_inline)) {
-        constexpr int slot = decltype(slotc)::value, J0 = decltype(j0c)::value;
+    // x_hi W_lo, x_hi W_hi: the order of gemm_big_split_kernel), a tile at a time over its RT accumulators.
+    // Weight fragments: a RING of four tile buffers (hi + lo, 32 registers) that runs through the stages - tile j + 4 is requested
+    // behind the first MFMA of tile j + 1 (its buffer is the one tile j has just left) and used three tiles = 18 MFMAs later; with
+    // two-tile double buffering (10 MFMAs ahead) a fragment wait still exposed LDS latency: the reads cost 24 of the kernel's 101 us.
+    // The ring crosses stage boundaries: `next()` - wait for this wave's DMA pieces of the next stage, the workgroup barrier - sits
+    // in front of tile 5, the first tile that requests a fragment of the next stage.  between(g) runs behind tile 2 g + 1.
+    u32x4_m wt[4][2];                                                    // [tile & 3][hi, lo]
+    u32x4_m dummy[4][2];                                                 // DIAG 6: the reads land here, nothing waits for them
+    if constexpr (DIAG == 3 || DIAG == 6 || DIAG == 7) {                  // opaque (not undefined) operands
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { asm volatile("" : "=v"(wt[i][0])); asm volatile("" : "=v"(wt[i][1])); asm volatile("" : "=v"(dummy[i][0])); asm volatile("" : "=v"(dummy[i][1])); }
+    }
+    auto fetch_tile = [&](auto slotc, auto jc) __attribute__((always_inline)) {
+        constexpr int slot = decltype(slotc)::value, j = decltype(jc)::value;
+        if constexpr (DIAG == 3) return;
         const unsigned ah = slot < 4 ? rd_hi : rd_hi2, al = slot < 4 ? rd_lo : rd_lo2;
         constexpr int so = (slot & 3) * MLP_STAGE;
-        u32x4_m wh[2][2], wl[2][2];
-        auto fetch = [&](auto prc, auto bc) __attribute__((always_inline)) {
-            constexpr int pr = decltype(prc)::value, bf = decltype(bc)::value;
-            if constexpr (DIAG == 3) return;
-            fetch16<so + (2 * pr) * 2048>(wh[bf][0], ah); fetch16<so + (2 * pr) * 2048>(wl[bf][0], al);
-            fetch16<so + (2 * pr + 1) * 2048>(wh[bf][1], ah); fetch16<so + (2 * pr + 1) * 2048>(wl[bf][1], al);
-        };
-        fetch(IntC<0>{}, IntC<0>{});
-        static_for<4>([&](auto prc) {
-            constexpr int pr = decltype(prc)::value, cur = pr & 1;
-            if constexpr (pr + 1 < 4) fetch(IntC<pr + 1>{}, IntC<cur ^ 1>{});
-            if constexpr (DIAG != 3) wait_lgkm<(pr + 1 < 4 ? 4 : 0)>(wh[cur][0], wl[cur][0], wh[cur][1], wl[cur][1]);
+        if constexpr (DIAG == 6) { fetch16_keep<so + j * 2048>(dummy[j & 3][0], ah); fetch16_keep<so + j * 2048>(dummy[j & 3][1], al); return; }
+        fetch16<so + j * 2048>(wt[j & 3][0], ah); fetch16<so + j * 2048>(wt[j & 3][1], al);
+    };
+    auto stage_mma = [&](auto slotc, auto& acc, auto j0c, const bf16x8 (&bh)[RT], const bf16x8 (&bl)[RT], auto&& between, auto&& next) __attribute__((always_inline)) {
+        constexpr int slot = decltype(slotc)::value, J0 = decltype(j0c)::value;
+        static_for<8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value, cur = j & 3;
+            if constexpr (j == 5) next();
+            // outstanding behind tile j's two reads: tiles j + 1, j + 2 (tile j + 3 follows this tile's first MFMA)
+            if constexpr (DIAG != 3 && DIAG != 6) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wt[cur][0]), "+v"(wt[cur][1]));
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (DIAG != 2) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][J0 + 2 * pr + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wh[cur][t]), bl[rt], acc[rt][J0 + 2 * pr + t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][J0 + 2 * pr + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wl[cur][t]), bh[rt], acc[rt][J0 + 2 * pr + t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][J0 + 2 * pr + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wh[cur][t]), bh[rt], acc[rt][J0 + 2 * pr + t], 0, 0, 0);
-            } else { acc[0][J0 + 2 * pr][0] += __builtin_bit_cast(float, wh[cur][0][0]) + __builtin_bit_cast(float, wl[cur][1][1]); }
+            static_for<3 * RT>([&](auto mc) {
+                constexpr int m = decltype(mc)::value, prod = m / RT, rt = m % RT;
+                if constexpr (DIAG == 7) {                               // waits as in the real kernel, operands that no read wrote
+                    acc[rt][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(dummy[cur][prod == 1]), prod == 0 ? bl[rt] : bh[rt], acc[rt][J0 + j], 0, 0, 0);
+                } else if constexpr (DIAG != 2) {
+                    if constexpr (prod == 0) acc[rt][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wt[cur][0]), bl[rt], acc[rt][J0 + j], 0, 0, 0);
+                    else if constexpr (prod == 1) acc[rt][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wt[cur][1]), bh[rt], acc[rt][J0 + j], 0, 0, 0);
+                    else acc[rt][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wt[cur][0]), bh[rt], acc[rt][J0 + j], 0, 0, 0);
+                }
+                if constexpr (m == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (j + 3 < 8) fetch_tile(slotc, IntC<j + 3>{});
+                    else fetch_tile(IntC<(slot + 1) % MLP_NS>{}, IntC<j + 3 - 8>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            if constexpr (DIAG == 2) acc[0][J0 + j][0] += __builtin_bit_cast(float, wt[cur][0][0]) + __builtin_bit_cast(float, wt[cur][1][1]);
             __builtin_amdgcn_sched_barrier(0);
-            between(prc);
+            if constexpr (j & 1) between(IntC<j / 2>{});
         });
     };
 
@@ -186,22 +220,34 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void dec_mlp_kernel(const MlpArgs 
     // which MFMA group of a stage a wave's DMA piece i follows: the first half of the waves issues early in a stage, the second half
     // late (with one wave per SIMD: one piece after each of the four groups)
     const int g_first = (wave < NW / 2 || PPW == 4) ? 0 : 4 - PPW;
+    // A stage's DMA pieces have landed when this wave's have (all but the pieces of the younger stages: vmcnt counts in issue order)
+    // and every other wave says the same (barrier).  The check of stage u + 1 stands in front of tile 5 of stage u: by then the wave has
+    // issued its pieces of stage u + AHEAD that follow groups 0 and 1.
+    auto landed = [&](bool first) __attribute__((always_inline)) {
+        // younger than the pieces waited for: first stage - the AHEAD - 1 stages behind it; otherwise the AHEAD - 2 whole stages
+        // u + 2 .. u + AHEAD - 1 and what this wave has issued of stage u + AHEAD so far
+        if (first) wait_vm<PPW * (MLP_AHEAD - 1)>();
+        else if (PPW == 4) wait_vm<PPW * (MLP_AHEAD - 2) + 2>();          // one piece behind each of groups 0, 1
+        else if (wave < NW / 2) wait_vm<PPW * (MLP_AHEAD - 2) + PPW>();   // issued behind groups 0 .. PPW - 1: all of them
+        else wait_vm<PPW * (MLP_AHEAD - 2)>();                            // issued behind groups 4 - PPW .. 3: none yet
+        __builtin_amdgcn_s_barrier();
+    };
+    landed(true);
+    static_for<3>([&](auto jc) { fetch_tile(IntC<0>{}, jc); });
 #pragma unroll 1
     for (int hs = 0; hs < 8; ++hs) {
         static_for<16>([&](auto uc) {
             constexpr int u = decltype(uc)::value, slot = u % MLP_NS;
             constexpr int ut = (u + MLP_AHEAD) % 16, slot_t = (u + MLP_AHEAD) % MLP_NS;
             const int hs_t = (hs + (u + MLP_AHEAD >= 16 ? 1 : 0)) & 7;  // past the last slice: a harmless re-fetch keeps the counts uniform
-            // this wave's pieces of stage (hs, u) have landed: all but the pieces of the youngest AHEAD - 1 stages ...
-            wait_vm<PPW * (MLP_AHEAD - 1)>();
-            __builtin_amdgcn_s_barrier();                                // ... and every other wave's
-            // The stage AHEAD further goes into the slot consumed two stages ago (every wave left it before the previous barrier), a
-            // piece at a time behind the MFMA groups: an LDS-DMA piece costs its wave 60 - 180 cycles of issue, which should fall where
-            // the matrix pipe has queued work (or the SIMD partner's)
+            // The stage AHEAD further goes into the slot consumed two stages ago (every wave left it before the barrier in front of
+            // the previous stage's last group), a piece at a time behind the MFMA groups: an LDS-DMA piece costs its wave 60 - 180
+            // cycles of issue, which should fall where the matrix pipe has queued work (or the SIMD partner's)
             auto between = [&](auto gc) __attribute__((always_inline)) {
                 constexpr int g = decltype(gc)::value;
                 static_for<PPW>([&](auto ic) { constexpr int i = decltype(ic)::value; if (g == g_first + i) issue(hs_t, IntC<ut>{}, IntC<slot_t>{}, ic); });
             };
+            auto next = [&]() __attribute__((always_inline)) { landed(false); };
             if constexpr (u < 8) {
                 if constexpr (u == 0) {
 #pragma unroll
@@ -212,7 +258,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void dec_mlp_kernel(const MlpArgs 
                 bf16x8 bh[RT], bl[RT];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) { bh[rt] = xh[rt][u]; bl[rt] = xl[rt][u]; }
-                stage_mma(IntC<slot>{}, hacc, IntC<0>{}, bh, bl, between);
+                stage_mma(IntC<slot>{}, hacc, IntC<0>{}, bh, bl, between, next);
             } else {
                 constexpr int v = u - 8, c = v >> 1, nh = v & 1;
                 if constexpr (nh == 0) {
@@ -222,20 +268,45 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void dec_mlp_kernel(const MlpArgs 
                     for (int rt = 0; rt < RT; ++rt) {
                         f32x4 va, vb;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { va[e] = gelu_erf(hacc[rt][2 * c][e] + ba[e]); vb[e] = gelu_erf(hacc[rt][2 * c + 1][e] + bb[e]); }
+                        for (int e = 0; e < 4; ++e) {
+                            if constexpr (DIAG == 4) { va[e] = hacc[rt][2 * c][e] + ba[e]; vb[e] = hacc[rt][2 * c + 1][e] + bb[e]; }
+                            else { va[e] = gelu_erf(hacc[rt][2 * c][e] + ba[e]); vb[e] = gelu_erf(hacc[rt][2 * c + 1][e] + bb[e]); }
+                        }
                         split8(va, vb, hh[rt][c], hl[rt][c]);
                     }
                 }
                 bf16x8 bh[RT], bl[RT];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) { bh[rt] = hh[rt][c]; bl[rt] = hl[rt][c]; }
-                stage_mma(IntC<slot>{}, oacc, IntC<8 * nh>{}, bh, bl, between);
+                stage_mma(IntC<slot>{}, oacc, IntC<8 * nh>{}, bh, bl, between, next);
             }
         });
     }
     wait_vm<0>();                                                        // no LDS-DMA may land after the workgroup has gone
+    if constexpr (DIAG == 6) {
+        wait_lgkm<0>(dummy[0][0], dummy[0][1], dummy[1][0], dummy[1][1]);
+        wait_lgkm<0>(dummy[2][0], dummy[2][1], dummy[3][0], dummy[3][1]);
+    } else if constexpr (DIAG != 3) {                                    // the fetches behind the last stage
+        wait_lgkm<0>(wt[0][0], wt[0][1], wt[1][0], wt[1][1]);
+        wait_lgkm<0>(wt[2][0], wt[2][1], wt[3][0], wt[3][1]);
+    }
 
-    // ---- epilogue, per lane and row tile: row frow, columns col(jj) .. + 3 of accumulator jj:  + bias + residual, LayerNorm(s), store
+    if constexpr (DIAG == 5) {                                            // no epilogue traffic: one word per lane
+        float s = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) s += oacc[rt][jj][0] + oacc[rt][jj][1] + oacc[rt][jj][2] + oacc[rt][jj][3];
+        if (live[0] && p.y != nullptr) p.y[(size_t)myrow[0] * D + fk] = s;
+        return;
+    }
+    // ---- epilogue, per lane and row tile: row frow, columns col(jj) .. + 3 of accumulator jj:  + bias + residual, LayerNorm(s) in
+    // the accumulator layout (an in-lane sum + two cross-lane steps per statistic); then the tile goes through LDS - the ring is free
+    // now, 16 KiB per wave - so that every store instruction writes ONE whole row (1 KiB contiguous) instead of 16-byte pieces of
+    // 16 rows (96 such stores per lane cost ~150 cycles of issue each).  LDS image of a tile: row r at 1 KiB r, 16-byte chunk ch at
+    // ch ^ r (conflict-free for the accumulator-layout writes - 16 rows, one chunk - and the row reads alike).
+    __syncthreads();                                                      // every wave is done with the ring
+    char* const stg = lds + wave * 16384;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const size_t rbase = (size_t)myrow[rt] * D;
@@ -244,16 +315,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void dec_mlp_kernel(const MlpArgs 
 #pragma unroll
         for (int jj = 0; jj < 16; ++jj) {
             const int col = 32 * (jj >> 1) + 8 * fk + 4 * (jj & 1);
-            const f32x4 bv = ld4(p.b2 + col), rv = ld4(p.x + rbase + col);
+            const f32x4 bv = ld4(prm + col), rv = ld4(p.x + rbase + col);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[jj][e] = v[jj][e] + bv[e] + rv[e]; }
             s += (v[jj][0] + v[jj][1]) + (v[jj][2] + v[jj][3]);
         }
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
-            const float* gp = pass == 0 ? p.g3 : p.g4;
-            const float* bp = pass == 0 ? p.be3 : p.be4;
-            if (gp == nullptr) break;
+            if (pass == 1 && p.g4 == nullptr) break;
+            const float* gp = prm + (pass == 0 ? 1 : 3) * D;
+            const float* bp = prm + (pass == 0 ? 2 : 4) * D;
             if (pass == 1) {
                 s = 0.f;
 #pragma unroll
@@ -276,12 +347,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void dec_mlp_kernel(const MlpArgs 
                 for (int e = 0; e < 4; ++e) v[jj][e] = (v[jj][e] - mean) * rstd * ga[e] + be[e];
             }
         }
-        if (live[rt]) {
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                const int col = 32 * (jj >> 1) + 8 * fk + 4 * (jj & 1);
-                if (p.y != nullptr) st4(p.y + rbase + col, v[jj]);
-                if (p.ys != nullptr) store_split4(p.ys + rbase, col, v[jj]);
+        for (int jj = 0; jj < 16; ++jj) {
+            const int ch = 8 * (jj >> 1) + 2 * fk + (jj & 1);
+            *reinterpret_cast<f32x4*>(stg + frow * 1024 + ((ch ^ frow) << 4)) = v[jj];
+        }
+        const int row0 = blockIdx.x * BM + RW * wave + 16 * rt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(stg + r * 1024 + ((lane ^ r) << 4));
+            if (row0 + r < M) {
+                if (p.y != nullptr) st4(p.y + (size_t)(row0 + r) * D + 4 * lane, o);
+                if (p.ys != nullptr) store_split4(p.ys + (size_t)(row0 + r) * D, 4 * lane, o);
             }
         }
     }
@@ -313,17 +390,18 @@ int launch_dec_mlp(const float* xs, const float* x, const float* w1, const float
     // three-launch form below dec_mlp_min_rows())
     int form = g_mlp_variant;                      // 0: by size, 1: <8, 1>, 2: <4, 1>, 3: <4, 2>
     if (form == 0) form = (M + 127) / 128 < 160 ? 2 : 3;
-    if (form >= 11 && form <= 13) {                // timing experiments (garbage results): <4, 2> without DMA / MFMAs / fragment reads
+    if (form >= 11 && form <= 17) {                // timing experiments (garbage results): <4, 2> without DMA / MFMAs / fragment reads / GELU / epilogue
         static bool dset = false;
+        const void* k[7] = {reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 1>), reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 2>),
+                            reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 3>), reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 4>),
+                            reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 5>), reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 6>),
+                            reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 7>)};
         if (!dset) {
-            const void* k[3] = {reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 1>), reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 2>),
-                                reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 3>)};
-            for (int i = 0; i < 3; ++i) LADIFF_HIP(hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
+            for (int i = 0; i < 7; ++i) LADIFF_HIP(hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
             dset = true;
         }
-        if (form == 11) hipLaunchKernelGGL((dec_mlp_kernel<4, 2, 1>), dim3((M + 127) / 128), dim3(256), MLP_LDS, s, a);
-        else if (form == 12) hipLaunchKernelGGL((dec_mlp_kernel<4, 2, 2>), dim3((M + 127) / 128), dim3(256), MLP_LDS, s, a);
-        else hipLaunchKernelGGL((dec_mlp_kernel<4, 2, 3>), dim3((M + 127) / 128), dim3(256), MLP_LDS, s, a);
+        void* args[] = {&a};
+        LADIFF_HIP(hipLaunchKernel(k[form - 11], dim3((M + 127) / 128), dim3(256), args, MLP_LDS, s));
     } else
     if (form == 3) hipLaunchKernelGGL((dec_mlp_kernel<4, 2>), dim3((M + 127) / 128), dim3(256), MLP_LDS, s, a);
     else if (form == 1) hipLaunchKernelGGL((dec_mlp_kernel<8, 1>), dim3((M + 127) / 128), dim3(512), MLP_LDS, s, a);

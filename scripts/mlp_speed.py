@@ -36,8 +36,9 @@ for M in (25088, 480):
         _lib.check(L.ladiff_gemm_split(_lib.ptr(hid), 1024, None, 0, 1024, _lib.ptr(w2s), 1024, _lib.ptr(b2), _lib.ptr(x), 256, _lib.ptr(y), None, 256, M, 256, 1024, 0, sp))
         _lib.check(L.ladiff_layernorm(_lib.ptr(y), _lib.ptr(g3), _lib.ptr(be3), _lib.ptr(ys), M, sp))
     out = [f"M={M:6d}: three launches {timeit(three):7.1f} us"]
-    for v in (1, 2, 3, 11, 12, 13):
+    for v in (1, 2, 3, 11, 12, 13, 14, 15, 16, 17):
         L.ladiff_debug_set_mlp_variant(v)
         out.append(f"v{v} {timeit(fused):7.1f}")
+        print(out[-1], file=sys.stderr, flush=True)
     L.ladiff_debug_set_mlp_variant(0)
     print(" | ".join(out), flush=True)
