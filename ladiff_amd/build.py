@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libladiff_hip.so")
-SOURCES = ["gemm.hip", "gemm_big.hip", "gemm_kr.hip", "gemm_rowln.hip", "rowops.hip", "attention.hip", "qkv_attn.hip", "systolic.hip", "linear_ca.hip", "dec_cross.hip", "dec_mlp.hip", "feats2joints.hip", "denoiser.hip", "decoder.hip", "encoder.hip", "clip.hip", "evaluator.hip", "api.hip"]
+SOURCES = ["gemm.hip", "gemm_big.hip", "gemm_kr.hip", "gemm_rowln.hip", "rowops.hip", "attention.hip", "qkv_attn.hip", "systolic.hip", "linear_ca.hip", "dec_cross.hip", "dec_mlp.hip", "dec_qkv_attn.hip", "feats2joints.hip", "denoiser.hip", "decoder.hip", "encoder.hip", "clip.hip", "evaluator.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

@@ -349,10 +349,11 @@ int ladiff_debug_set_mlp_variant(int v) {
 }
 
 int ladiff_debug_set_decoder_fusion(int on) {
-    LADIFF_CHECK_ARG(on >= 0 && on <= 14 && (on & 3) != 3);
+    LADIFF_CHECK_ARG(on >= 0 && on <= 62 && (on & 3) != 3 && (on & 48) != 48);
     g_dec_fused_mlp = on & 3;
     g_dec_small_rows_path = (on & 4) ? 0 : 1;
     g_dec_final_split = (on & 8) ? 0 : 1;
+    g_dec_fused_attn = (on & 16) ? 0 : (on & 32) ? 2 : 1;
     return 0;
 }
 
@@ -743,7 +744,7 @@ int ladiff_vae_decode_graphed(void* graph, const float* const* w, const float* c
     uint64_t h = hash_ptrs(w, DEC_NPARAMS, 1469598103934665603ull);
     if (w_split) h = hash_ptrs(w_split, DEC_NPARAMS, h ^ 0x9e3779b97f4a7c15ull);
     // the measurement switches change the launch sequence: part of the key
-    h ^= (uint64_t)(g_dec_fused_mlp + 4 * g_dec_small_rows_path + 8 * g_dec_final_split + 16 * g_mlp_variant) * 0x100000001b3ull;
+    h ^= (uint64_t)(g_dec_fused_mlp + 4 * g_dec_small_rows_path + 8 * g_dec_final_split + 16 * g_mlp_variant + 4096 * g_dec_fused_attn) * 0x100000001b3ull;
     const bool same = dg->exec && std::memcmp(kp, dg->key_ptrs, sizeof(kp)) == 0 && std::memcmp(ki, dg->key_ints, sizeof(ki)) == 0 &&
                       h == dg->key_hash && weights_generation == dg->key_gen;
     if (!same) {

@@ -6,6 +6,7 @@
 namespace ladiff {
 
 constexpr int DEC_SMALL_ROWS = 4096;
+int g_dec_fused_attn = 1;         // measurement switch (+ 16): in_proj GEMM + attention kernel as two launches (the path before)
 int g_dec_final_split = 1;        // measurement switch (ladiff_debug_set_decoder_fusion + 8): final_layer on the fp32 kernel as in round 2
 int g_dec_small_rows_path = 1;    // measurement switch (ladiff_debug_set_decoder_fusion bit 2 clear / set): the small-M GEMM routing
 int g_dec_fused_mlp = 1;          // measurement switch (ladiff_debug_set_decoder_fusion): 0 = linear1 / linear2 / LayerNorm as three launches, 1 = fused from dec_mlp_min_rows() rows, 2 = fused always
@@ -76,6 +77,9 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
     // GEMMs on the denoiser's small-M kernels instead (gemm_kr.hip: K-resident 32 / 64 / 80-row tiles, K = 1024 as four partial planes
     // that the LayerNorm row pass sums) - the same S-format operands and products, 3 - 4x the workgroups.
     const bool small = sp && M < DEC_SMALL_ROWS && g_dec_small_rows_path;
+    // in_proj inside the attention kernel (dec_qkv_attn.hip): from DEC_SMALL_ROWS frame rows up (8 x 60 frames: 0.47 ms against 0.45
+    // with the small-M in_proj + attention launches; 128 x 196: 2.28 against 2.41, profiles/r3/15)
+    const bool fused_attn = sp && g_dec_fused_attn && (M >= DEC_SMALL_ROWS || g_dec_fused_attn == 2);
     auto krs = [&](const float* A, int K, const float* W, const float* bias, float* Y, float* Ys, int ldy, int N, int act,
                    const float* res, int rows) -> int {
         KrArgs g;
@@ -139,6 +143,8 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
             g.split = sp ? 1 : 0;
             LADIFF_TRY(launch_gemm(g, s));
             }
+        } else if (fused_attn) {
+            // bf16x3 mode: in_proj inside the attention kernel (dec_qkv_attn.hip) - the [M, 768] q | k | v rows are never written
         } else if (small) {
             LADIFF_TRY(krs(curs, D, Ls.self_attn.in_w, L.self_attn.in_b, qkv, nullptr, 3 * D, 3 * D, ACT_NONE, nullptr, M));
         } else {
@@ -147,7 +153,8 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
             LADIFF_TRY(launch_gemm(g, s));
         }
         const float* qkv_l = shared ? qkv0 : qkv;
-        if (sp) LADIFF_TRY(launch_self_attention_bf16x3(qkv_l, lengths, nullptr, att, B, F, H, 0, 1, s, row_off, shared));
+        if (fused_attn && !shared) LADIFF_TRY(launch_dec_qkv_attn(curs, Ls.self_attn.in_w, L.self_attn.in_b, lengths, row_off, att, B, F, 1, s));
+        else if (sp) LADIFF_TRY(launch_self_attention_bf16x3(qkv_l, lengths, nullptr, att, B, F, H, 0, 1, s, row_off, shared));
         else LADIFF_TRY(launch_decoder_self_attention(qkv_l, lengths, nullptr, att, B, F, 0, s, row_off, shared));
         // norm1: fused in the GEMM epilogue in fp32 mode; in bf16x3 mode the GEMM writes x + out_proj(att) and the only reader of
         // norm1's output, the cross-attention kernel below, normalises its rows as it loads them (one row kernel pass less)

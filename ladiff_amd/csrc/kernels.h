@@ -39,6 +39,8 @@ int launch_step_tail(float* x, float* xs, const float* ng, const float* nb, floa
 int launch_init_latents(const float* noise, const int32_t* counts, float sigma, float* lat, int B, int T, hipStream_t s);
 int launch_finalize_latents(const float* lat, const int32_t* counts, float* z, int B, int T, hipStream_t s, const unsigned* status = nullptr);
 
+int launch_dec_qkv_attn(const float* xs, const float* w, const float* bias, const int32_t* lengths, const int32_t* row_off, float* out,
+                        int B, int F, int split_out, hipStream_t s);
 int launch_scatter_feats(const float* tmp, int ldt, int C, int M, int F, const int32_t* row_len, const int32_t* row_map, float* feats,
                          hipStream_t s);
 int launch_pad_cols(const float* x, float* y, int R, int C, int Cp, hipStream_t s);

@@ -39,6 +39,7 @@ void den_loop_io(float* ws, int rows, float** x, float** xs);
 extern int g_dec_fused_mlp;
 extern int g_dec_small_rows_path;
 extern int g_dec_final_split;
+extern int g_dec_fused_attn;
 extern int g_mlp_variant;
 int dec_mlp_min_rows();
 size_t dec_ws_floats(int B, size_t rows, int T);

@@ -497,6 +497,32 @@ def test_final_layer_on_padded_bf16x3_tiles_matches_fp32_kernel(nfeats):
             assert (b[i, l:] == 0).all()
 
 
+@pytest.mark.parametrize("lens", [[196] * 6, [196, 60, 120, 1, 77, 196, 48, 150, 33, 32, 64, 65], [1], [224, 200]])
+def test_attention_with_in_proj_inside_matches_two_launches(lens):
+    """bf16x3 decode with the self-attention kernel that computes its head's q | k | v itself (default) against in_proj GEMM +
+    attention kernel (+ 16): same frames to bf16x3 rounding - padded batches (keys >= length masked, all F query rows computed),
+    ragged batches, one-frame and 224-frame samples, lengths on both sides of a 32-row tile edge."""
+    from ladiff_amd import LADiffVae, synthetic as syn
+    from test_abi import ABL, VAE_KW
+    vae = LADiffVae(ABL, **VAE_KW); vae.load_state_dict(syn.vae_weights(263)); vae = vae.to(DEV).eval()
+    vae.precision = "bf16x3"
+    z = torch.randn(5, len(lens), 256, generator=torch.Generator().manual_seed(len(lens))).to(DEV)
+    for i, l in enumerate(lens):
+        z[-(-l // 48):, i] = 0
+    try:
+        assert lib().ladiff_debug_set_decoder_fusion(1 + 16) == 0
+        a = vae.decode(z, lens)
+        assert lib().ladiff_debug_set_decoder_fusion(1 + 32) == 0          # at every size (the default starts at 4,096 frame rows)
+        b = vae.decode(z, lens)
+    finally:
+        lib().ladiff_debug_set_decoder_fusion(1)
+    assert lib().ladiff_debug_set_decoder_fusion(1 + 16 + 32) != 0
+    assert b.shape == a.shape and torch.isfinite(b).all()
+    assert (a - b).abs().max().item() < 5e-5 * max(1.0, a.abs().max().item()), (a - b).abs().max().item()
+    for i, l in enumerate(lens):
+        assert (b[i, l:] == 0).all()
+
+
 def test_graphed_decode_matches_direct_decode():
     """Decodes of few frame rows are replayed from a hipGraph over persistent buffers (LADiffVae.graph_rows): same bits as the direct
     launch sequence, for padded and ragged batches, both arithmetic modes, changing inputs, alternating shapes (re-capture), and on
