@@ -343,7 +343,7 @@ int ladiff_debug_set_stage_waves(int waves_per_simd) {
 }
 
 int ladiff_debug_set_mlp_variant(int v) {
-    LADIFF_CHECK_ARG((v >= 0 && v <= 3) || (v >= 11 && v <= 17));
+    LADIFF_CHECK_ARG((v >= 0 && v <= 3) || (v >= 11 && v <= 17) || (v >= 21 && v <= 26));
     g_mlp_variant = v;
     return 0;
 }

@@ -389,6 +389,7 @@ int launch_dec_mlp(const float* xs, const float* x, const float* w1, const float
     // (measured, profiles/r3: 25088 rows 111 us <4,2> / 116 <8,1> / 137 <4,1>; 12544 rows 106 / 108 / 71; the caller keeps the
     // three-launch form below dec_mlp_min_rows())
     int form = g_mlp_variant;                      // 0: by size, 1: <8, 1>, 2: <4, 1>, 3: <4, 2>
+    if (form >= 21) form = 0;                      // 21 .. 23: timing builds of the attention kernel (dec_qkv_attn.hip)
     if (form == 0) form = (M + 127) / 128 < 160 ? 2 : 3;
     if (form >= 11 && form <= 17) {                // timing experiments (garbage results): <4, 2> without DMA / MFMAs / fragment reads / GELU / epilogue
         static bool dset = false;

@@ -5,7 +5,9 @@
 //   * wave w owns frame rows 32 w .. 32 w + 31 both as queries and as keys / values.  Its x rows are MFMA operand fragments in
 //     registers (16 k-steps x (hi, lo) bf16x8 per lane, loaded straight from the S-format rows).
 //   * the head's 192 in_proj rows (64 q, 64 k, 64 v) stream through LDS as twelve 16-KiB stages (32 weight rows x 128 k, hi and lo
-//     planes), double-buffered by LDS-DMA one stage ahead; a stage's fragment = one conflict-free ds_read_b128 per lane.
+//     planes) by LDS-DMA; a stage's fragment = one conflict-free ds_read_b128 per lane, issued by asm one k-step ahead of its MFMAs.
+//     The stages land in the K / V image areas while those are not written yet (eight of the twelve are requested before the
+//     loop starts, see slab_off), so no stage is requested less than two stages ahead although the images leave only 32 KiB.
 //   * q and k are computed TRANSPOSED (D^T = W x^T, v_mfma_f32_32x32x16_bf16: weight fragment first), v plainly (x first): the
 //     accumulator of a q^T / k^T tile then has the row's query / key on the lane and 16 of its d values in the registers, and since
 //     d is the contraction index of q.k ANY order of d is fine as long as q and k share it: registers 8 j .. 8 j + 7 of tile T ARE the
@@ -14,7 +16,16 @@
 //     register quad: an 8-byte write into the transposed V image the output product reads.
 //   * then the score / softmax / output core of self_attn_bf16x3_kernel (attention.hip), unchanged: S^T = K Q^T, fp32 softmax in
 //     base 2, O^T = V^T P^T, every product as lo*hi + hi*lo + hi*hi.
+//   * the four heads of a sample get block ids of one residue class mod 8 (one XCD, one L2: they read the same x rows); the S-format
+//     result leaves through the dead K image as whole 256-byte blocks.
 // Arithmetic: the products of the separate kernels (same splits, fp32 accumulate); q.k sums its 64 d in another order.
+// Measured (128 x 196 frames, profiles/r3/15_*): 70 us per layer against 46 (in_proj GEMM) + 41 (attention kernel); decode 2.41 ->
+// 2.26 ms.  What the 70 us are (timing builds, 2 rounds of 256 workgroups): x row fragments 20 us (16-byte pieces of 32 rows per
+// load instruction: the texture path moves them at a quarter of its rate; LDS has no room to stage 196 KiB of rows), projection
+// 25 us (its MFMAs 12), scores / softmax / output 27 us (MFMAs ~11, the rest is the softmax and bf16-split VALU of two waves per SIMD
+// that reach the same phase together).  Steps that did NOT move it: look-ahead of two stages instead of one (the compiler had put
+// `vmcnt(0)` in front of every plain LDS read - LDS-DMA may alias - so the first build never looked ahead at all; with asm reads
+// and counted waits the waits are simply not what binds), asm-pipelined K / V fragment reads in the core, whole-block stores.
 #include "model.h"
 #include "tile_mma.h"
 
@@ -41,6 +52,35 @@ struct QkvAttnArgs {
     int B, F, split_out;
 };
 
+// LDS byte offset of slab `slab` (0 .. 15) of weight stage G (see the kernel: stages land in the not-yet-written K / V images early on)
+template <int G>
+__device__ __forceinline__ constexpr int slab_off(int slab) {
+    constexpr int VREG = QA_K_BYTES, RING = QA_K_BYTES + QA_V_BYTES, VTL = DH * QA_VLD * 2, ROW32 = 32 * QA_VLD * 2;
+    if constexpr (G <= 2) return G * QA_STAGE + slab * 1024;
+    else if constexpr (G <= 5) return VREG + (G - 3) * QA_STAGE + slab * 1024;
+    else if constexpr (G == 6 || G == 9) return RING + slab * 1024;
+    else if constexpr (G == 7 || G == 10) return RING + QA_STAGE + slab * 1024;
+    else if constexpr (G == 8) return VREG + slab * 1024;
+    else return slab < 8 ? VREG + ROW32 + slab * 1024 : VREG + VTL + ROW32 + (slab - 8) * 1024;
+}
+static_assert(3 * QA_STAGE <= QA_K_BYTES && 3 * QA_STAGE <= QA_V_BYTES && 32 * QA_VLD * 2 + 8 * 1024 <= DH * QA_VLD * 2, "weight stages inside the images");
+
+typedef unsigned u32x4_q __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ void frag_read(u32x4_q& v, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536 * 4, "");
+    if constexpr (OFF < 65536) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    else if constexpr (OFF < 2 * 65536) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr + 65536u), "n"(OFF - 65536) : "memory");
+    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr + 131072u), "n"(OFF - 131072) : "memory");
+}
+
+// two 8-byte reads (offsets OFF8 and OFF8 + 2, in units of 8 bytes) into one register quad
+template <int OFF8>
+__device__ __forceinline__ void v_read2(u32x4_q& v, unsigned addr) {
+    static_assert(OFF8 >= 0 && OFF8 + 2 < 256, "");
+    asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(OFF8), "n"(OFF8 + 2) : "memory");
+}
+
 __device__ __forceinline__ void split8v(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { hi[e] = (__bf16)v[e]; lo[e] = (__bf16)(v[e] - (float)hi[e]); }
@@ -48,6 +88,9 @@ __device__ __forceinline__ void split8v(const float (&v)[8], bf16x8& hi, bf16x8&
 
 }  // namespace
 
+// DIAG (timing experiments, garbage results): 1 = the stage loop does not wait for its LDS-DMA, 2 = no score / softmax / output core,
+// 3 = no projection MFMAs, 4 = no projection at all (no weight stages), 5 = no x row loads, 6 = nothing but the x row loads and one store
+template <int DIAG = 0>
 __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     __bf16* const Kh = reinterpret_cast<__bf16*>(lds);
@@ -58,7 +101,13 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
     float* const bsm = reinterpret_cast<float*>(ring + 2 * QA_STAGE);          // [q 64 | k 64 | v 64] of this head
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    // Workgroup n runs on XCD n % 8 (round-robin dispatch) and each XCD has its own L2: the four heads of a sample read the SAME x
+    // rows, so they are given block ids of one residue class, 8 apart - sample 8 k + r, head j = block 8 (4 k + j) + r - and only the
+    // first of them fetches the rows from memory (with b = n / 4 the four heads sat on four XCDs: 4 x 25.7 MB from the memory side
+    // per layer, 24 us of the kernel)
+    const int xr = blockIdx.x & 7, xm = blockIdx.x >> 3;
+    const int b = 8 * (xm / H) + xr, h = xm % H;
+    if (b >= p.B) return;
     int F = p.F;
     size_t row0 = (size_t)b * F;
     if (p.row_off != nullptr) { row0 = p.row_off[b]; F = p.row_off[b + 1] - p.row_off[b]; }
@@ -75,6 +124,29 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
 
     if (tid < 3 * DH) bsm[tid] = p.bias[(tid >> 6) * D + h * DH + (tid & 63)];
 
+    // ---- LDS-DMA of stage g: slab (k-step s, plane) = 1 KiB = [half 2][row 32][16 B]; wave w brings slabs 2 w, 2 w + 1.
+    // DMA lane l lands at byte 16 l of the slab: it must fetch weight row (l & 31), half (l >> 5).
+    // WHERE a stage lands (slab_off): the K and V images are not written before stages 5 and 9, so the weight stages use them as
+    // ring space early on - stages 0 .. 7 are all requested before the loop starts (K region 0-2, V region 3-5, the two ring
+    // buffers 6, 7), stage 8 goes to the V region again, 9 / 10 to the ring buffers, 11 to the rows of the V planes that only ITS
+    // OWN epilogue writes (d 32 .. 63: a barrier stands between its products and that epilogue) - every stage is requested at
+    // least two stages ahead.  With two buffers and one stage of look-ahead every stage stood ~1.5 us waiting for its 16 KiB.
+    auto issue = [&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value, T = g >> 1, part = T >> 1, hf = T & 1;
+        const char* wrow = reinterpret_cast<const char*>(p.w) + (size_t)(part * D + h * DH + 32 * hf + (lane & 31)) * 1024 + (lane >> 5) * 16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int slab = 2 * wave + i, s = slab >> 1, pl = slab & 1, sa = 8 * (g & 1) + s;
+            const char* src = wrow + (sa >> 2) * 256 + pl * 128 + (sa & 3) * 32;
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), (__attribute__((address_space(3))) void*)(lds + slab_off<g>(slab)), 16, 0, 0);
+        }
+    };
+
+    bf16x8 qh[4], ql[4];
+    f32x16 acc;
+    const unsigned lds_lane = lds_addr(lds) + lane * 16;
+    if constexpr (DIAG != 4) static_for<8>([&](auto gc) { issue(gc); });
+
     // ---- x rows as operand fragments: k-step s (16 columns) -> lane (row q, half h2) holds columns 16 s + 8 h2 .. + 7, hi and lo
     bf16x8 xh[16], xl[16];
     {
@@ -85,7 +157,7 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
             bf16x8 a, c;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { a[e] = (__bf16)0.f; c[e] = (__bf16)0.f; }
-            if (live && active) {
+            if (live && active && DIAG != 5) {
                 a = *reinterpret_cast<const bf16x8*>(xr + (s >> 2) * 256 + (s & 3) * 32);
                 c = *reinterpret_cast<const bf16x8*>(xr + (s >> 2) * 256 + (s & 3) * 32 + 128);
             }
@@ -93,40 +165,58 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
         }
     }
 
-    // ---- LDS-DMA of stage g: slab (k-step s, plane) = 1 KiB = [half 2][row 32][16 B]; wave w brings slabs 2 w, 2 w + 1.
-    // DMA lane l lands at byte 16 l of the slab: it must fetch weight row (l & 31), half (l >> 5).
-    auto issue = [&](int g) __attribute__((always_inline)) {
-        const int T = g >> 1, part = T >> 1, hf = T & 1;
-        const char* wrow = reinterpret_cast<const char*>(p.w) + (size_t)(part * D + h * DH + 32 * hf + (lane & 31)) * 1024 + (lane >> 5) * 16;
+    // every x register is used here once, so the compiler waits for their loads HERE (vmcnt(0): the eight weight stages requested
+    // above land under the same wait): left to the first MFMA that reads a register, it put a `vmcnt(0)` - which also waits for
+    // every weight stage requested since - in front of each stage's first MFMA
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int slab = 2 * wave + i, s = slab >> 1, pl = slab & 1, sa = 8 * (g & 1) + s;
-            const char* src = wrow + (sa >> 2) * 256 + pl * 128 + (sa & 3) * 32;
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src),
-                                             (__attribute__((address_space(3))) void*)(ring + (g & 1) * QA_STAGE + slab * 1024), 16, 0, 0);
+    for (int s = 0; s < 16; ++s) asm volatile("" ::"v"(xh[s]), "v"(xl[s]));
+    if constexpr (DIAG == 4 || DIAG == 6) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qh[ks] = xh[ks]; ql[ks] = xl[4 + ks]; }
+        if constexpr (DIAG == 6) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) sacc += (float)xh[ks][0] + (float)xl[ks][1];
+            if (qrow < F && active) p.out[(row0 + qrow) * D + h * DH + h2] = sacc;
+            return;
         }
-    };
-
-    bf16x8 qh[4], ql[4];
-    f32x16 acc;
-    issue(0);
-    static_for<QA_NSTAGE>([&](auto gc) {
+    }
+    if constexpr (DIAG != 4) static_for<QA_NSTAGE>([&](auto gc) {
         constexpr int g = decltype(gc)::value, T = g >> 1, khalf = g & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's slabs of stage g (and, the first time, its x rows)
-        __syncthreads();                                                // every wave's; and every wave is done with the other buffer
-        if constexpr (g + 1 < QA_NSTAGE) issue(g + 1);
+        // this wave's slabs of stage g have landed (and, the first time, its x rows): all but the younger requests - stages
+        // g + 1 .. 7 up to stage 6, one stage (two instructions) from stage 7 on, none at the end
+        constexpr int younger = g <= 6 ? 2 * (7 - g) : (g < QA_NSTAGE - 1 ? 2 : 0);
+        if constexpr (DIAG != 1 || g == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(younger) : "memory");   // lgkmcnt: this wave's LDS writes (bias table, image rows)
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                   // every wave's have; and every wave is done with stage g - 1
+        asm volatile("" ::: "memory");
+        if constexpr (g >= 6 && g + 2 < QA_NSTAGE) issue(IntC<g + 2>{});
         if (active) {
             if constexpr (khalf == 0) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = 0.f;
             }
-            const char* st = ring + (g & 1) * QA_STAGE + lane * 16;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const bf16x8 wh = *reinterpret_cast<const bf16x8*>(st + (2 * s) * 1024);
-                const bf16x8 wl = *reinterpret_cast<const bf16x8*>(st + (2 * s + 1) * 1024);
+            // The weight fragments are read by asm (`ds_read_b128`, counted `lgkmcnt` waits tied to the registers): a plain LDS load
+            // makes the compiler wait for EVERY LDS-DMA in flight first (`vmcnt(0)`: the DMA writes LDS, it may alias) - which
+            // undid the look-ahead - and it read all sixteen fragments of a stage through one register quad, a full LDS round trip
+            // in front of every one or two MFMAs.  Two k-steps of fragments in registers, k-step s + 1 requested before the MFMAs of s.
+            u32x4_q fh[2], fl[2];
+            frag_read<slab_off<g>(0)>(fh[0], lds_lane);
+            frag_read<slab_off<g>(1)>(fl[0], lds_lane);
+            static_for<8>([&](auto sc) {
+                constexpr int s = decltype(sc)::value, cur = s & 1;
+                if constexpr (s + 1 < 8) {
+                    frag_read<slab_off<g>(2 * s + 2)>(fh[cur ^ 1], lds_lane);
+                    frag_read<slab_off<g>(2 * s + 3)>(fl[cur ^ 1], lds_lane);
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[cur]), "+v"(fl[cur]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh[cur]), "+v"(fl[cur]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 wh = __builtin_bit_cast(bf16x8, fh[cur]), wl = __builtin_bit_cast(bf16x8, fl[cur]);
                 const bf16x8 bh = xh[8 * khalf + s], bl = xl[8 * khalf + s];
-                if constexpr (T < 4) {             // q^T / k^T tile: [32 d x 32 rows] += W . x^T
+                if constexpr (DIAG == 3) { acc[s] += (float)wh[0] + (float)wl[1] + (float)bh[2] + (float)bl[3]; }
+                else if constexpr (T < 4) {        // q^T / k^T tile: [32 d x 32 rows] += W . x^T
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, bh, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bl, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, acc, 0, 0, 0);
@@ -135,7 +225,15 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, wl, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, wh, acc, 0, 0, 0);
                 }
-            }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        if constexpr (g == QA_NSTAGE - 1) {       // stage 11's slabs sit where its own epilogue writes: every wave must be done reading
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        if (active) {
             if constexpr (khalf == 1) {
                 if constexpr (T < 2) {             // q: + bias, / sqrt(64) * log2(e) (the scores come out in base-2 units), split
 #pragma unroll
@@ -185,43 +283,69 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
             }
         }
     });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                                    // the K / V images are complete
     if (!active) return;
+    if constexpr (DIAG == 2) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) sacc += (float)qh[ks][0] + (float)ql[ks][1];
+        if (qrow < F) p.out[(row0 + qrow) * D + h * DH + h2] = sacc + (float)Kh[qrow * DH] + (float)Vth[q * QA_VLD];
+        return;
+    }
 
-    // ---- scores, softmax, output: the core of self_attn_bf16x3_kernel
+    // ---- scores, softmax, output: the arithmetic of self_attn_bf16x3_kernel (attention.hip).  The K / V fragments are read by asm
+    // one step ahead of the MFMAs that use them (the compiler read every fragment through one register quad and waited for it in
+    // front of each MFMA group: ~280 exposed LDS round trips per wave, most of this phase).  A read past the last valid key tile
+    // fetches LDS bytes nobody uses.
     f32x16 sT[QA_NKT];
     float m = -INFINITY;
+    u32x4_q fa[2], fb[2];                          // [step parity]: K hi / lo, then V^T hi / lo
+    {
+        const int sw = (q >> 1) & 7;
+        unsigned ka[4];
 #pragma unroll
-    for (int kt = 0; kt < QA_NKT; ++kt) {
-        if (kt < nkt) {
-            f32x16 a;
+        for (int ks = 0; ks < 4; ++ks) ka[ks] = lds_addr(Kh) + q * (DH * 2) + ((((2 * ks + h2) ^ sw)) << 4);
+        constexpr int KLO = QA_FMAX * DH * 2;      // the lo plane
+        frag_read<0>(fa[0], ka[0]);
+        frag_read<KLO>(fb[0], ka[0]);
+        static_for<QA_NKT>([&](auto ktc) {
+            constexpr int kt = decltype(ktc)::value;
+            if (kt < nkt) {
+                f32x16 a;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) a[i] = 0.f;
-            const int r = kt * 32 + q;
+                for (int i = 0; i < 16; ++i) a[i] = 0.f;
+                static_for<4>([&](auto ksc) {
+                    constexpr int ks = decltype(ksc)::value, n = 4 * kt + ks, cur = n & 1;
+                    constexpr int kt2 = (n + 1) >> 2, ks2 = (n + 1) & 3;        // the step after this one (kt2 == 7: bytes behind the image)
+                    frag_read<kt2 * 32 * DH * 2>(fa[cur ^ 1], ka[ks2]);
+                    frag_read<kt2 * 32 * DH * 2 + KLO>(fb[cur ^ 1], ka[ks2]);
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[cur]), "+v"(fb[cur]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bf16x8 kh = __builtin_bit_cast(bf16x8, fa[cur]), kl = __builtin_bit_cast(bf16x8, fb[cur]);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[ks], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[ks], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], a, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                if (kb[kt] == 0xFFFFFFFFu) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int off = r * DH + (((2 * ks + h2) ^ ((r >> 1) & 7)) << 3);
-                const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + off);
-                const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + off);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[ks], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[ks], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], a, 0, 0, 0);
-            }
-            if (kb[kt] == 0xFFFFFFFFu) {
+                    for (int i = 0; i < 16; ++i) m = fmaxf(m, a[i]);
+                } else {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) m = fmaxf(m, a[i]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int kin = (i & 3) + 8 * (i >> 2) + 4 * h2;
-                    const float s = ((kb[kt] >> kin) & 1u) ? a[i] : -INFINITY;
-                    a[i] = s;
-                    m = fmaxf(m, s);
+                    for (int i = 0; i < 16; ++i) {
+                        const int kin = (i & 3) + 8 * (i >> 2) + 4 * h2;
+                        const float sc = ((kb[kt] >> kin) & 1u) ? a[i] : -INFINITY;
+                        a[i] = sc;
+                        m = fmaxf(m, sc);
+                    }
                 }
+                sT[kt] = a;
             }
-            sT[kt] = a;
-        }
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fb[0]), "+v"(fa[1]), "+v"(fb[1]));     // the read behind the last step
     }
+    if (p.split_out) __syncthreads();              // every wave still running has read its keys: the K image becomes the output staging area
     m = fmaxf(m, __shfl_xor(m, 32, 64));
 
     float l = 0.f;
@@ -241,35 +365,77 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
     f32x16 o0, o1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    {
+        // V^T fragment of (key tile kt, half mm, d tile t): keys k1 .. k1 + 3 and k1 + 8 .. k1 + 11 (k1 = 32 kt + 16 mm + 4 h2) of row
+        // d = 32 t + q: one ds_read2_b64 per plane
+        constexpr int VLO = DH * QA_VLD * 2;
+        unsigned va[2];
 #pragma unroll
-    for (int kt = 0; kt < QA_NKT; ++kt) {
-        if (kt < nkt) {
+        for (int t = 0; t < 2; ++t) va[t] = lds_addr(Vth) + ((32 * t + q) * QA_VLD + 4 * h2) * 2;
+        const unsigned vl0 = va[0] + VLO, vl1 = va[1] + VLO;
+        v_read2<0>(fa[0], va[0]);
+        v_read2<0>(fb[0], vl0);
+        static_for<QA_NKT>([&](auto ktc) {
+            constexpr int kt = decltype(ktc)::value;
+            if (kt < nkt) {
+                static_for<2>([&](auto mc) {
+                    constexpr int mm = decltype(mc)::value;
+                    float pv[8];
 #pragma unroll
-            for (int mm = 0; mm < 2; ++mm) {
-                float pv[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pv[j] = sT[kt][8 * mm + j];
-                bf16x8 ph, pl;
-                split8v(pv, ph, pl);
-                const int k1 = 32 * kt + 16 * mm + 4 * h2;            // keys k1 .. k1+3 and k1+8 .. k1+11
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int voff = (32 * t + q) * QA_VLD + k1;
-                    const bf16x4 h_a = *reinterpret_cast<const bf16x4*>(Vth + voff), h_b = *reinterpret_cast<const bf16x4*>(Vth + voff + 8);
-                    const bf16x4 l_a = *reinterpret_cast<const bf16x4*>(Vtl + voff), l_b = *reinterpret_cast<const bf16x4*>(Vtl + voff + 8);
-                    const bf16x8 vh = {h_a[0], h_a[1], h_a[2], h_a[3], h_b[0], h_b[1], h_b[2], h_b[3]};
-                    const bf16x8 vl = {l_a[0], l_a[1], l_a[2], l_a[3], l_b[0], l_b[1], l_b[2], l_b[3]};
-                    f32x16& o = t == 0 ? o0 : o1;
-                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o, 0, 0, 0);
-                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o, 0, 0, 0);
-                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o, 0, 0, 0);
-                }
+                    for (int j = 0; j < 8; ++j) pv[j] = sT[kt][8 * mm + j];
+                    bf16x8 ph, pl;
+                    split8v(pv, ph, pl);
+                    static_for<2>([&](auto tc) {
+                        constexpr int t = decltype(tc)::value, n = (2 * kt + mm) * 2 + t, cur = n & 1;
+                        constexpr int n2 = n + 1, t2 = n2 & 1, km2 = n2 >> 1;       // next step: d tile t2 of (kt, mm) pair km2
+                        v_read2<4 * km2>(fa[cur ^ 1], t2 == 0 ? va[0] : va[1]);
+                        v_read2<4 * km2>(fb[cur ^ 1], t2 == 0 ? vl0 : vl1);
+                        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[cur]), "+v"(fb[cur]));
+                        __builtin_amdgcn_sched_barrier(0);
+                        const bf16x8 vh = __builtin_bit_cast(bf16x8, fa[cur]), vl = __builtin_bit_cast(bf16x8, fb[cur]);
+                        f32x16& o = t == 0 ? o0 : o1;
+                        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o, 0, 0, 0);
+                        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o, 0, 0, 0);
+                        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
             }
-        }
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fb[0]), "+v"(fa[1]), "+v"(fb[1]));
     }
 
-    if (qrow < F) {
-        const float inv = 1.f / l;
+    const float inv = 1.f / l;
+    if (p.split_out) {
+        // S-format result: this head's 64 columns of a row are ONE 256-byte block of the row (128 B hi | 128 B lo).  Written from the
+        // accumulator layout that is sixteen 8-byte stores per lane, each instruction 64 pieces of 32 rows (~150 cycles of issue each:
+        // with the stores removed the phase was 27 us per layer shorter).  Instead the tile goes through the K image - dead once every
+        // wave has its scores (the barrier) - and leaves as whole 256-byte blocks, four rows per store instruction.
+        // LDS image of a wave's tile: row r at 256 r, 16-byte chunk c (0 .. 7 hi, 8 .. 15 lo) at (c & 8) | ((c ^ r) & 7).
+        char* const stg = lds + wave * 8192;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = (t == 0 ? o0[4 * rg + e] : o1[4 * rg + e]) * inv;
+                    hi[e] = (__bf16)v; lo[e] = (__bf16)(v - (float)hi[e]);
+                }
+                const int d = 32 * t + 8 * rg + 4 * h2;                     // four consecutive columns d .. d + 3 of row q
+                char* at = stg + q * 256 + ((((d >> 3) ^ q) & 7) << 4) + (d & 4) * 2;
+                *reinterpret_cast<bf16x4*>(at) = hi;
+                *reinterpret_cast<bf16x4*>(at + 128) = lo;
+            }
+        // (same wave writes and reads: program order; the compiler counts its own LDS operations)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = 4 * i + (lane >> 4), c = lane & 15;
+            const f32x4 blk = *reinterpret_cast<const f32x4*>(stg + r * 256 + (c & 8) * 16 + (((c ^ r) & 7) << 4));
+            if (qt * 32 + r < F) st4(p.out + (row0 + qt * 32 + r) * D + h * DH + 4 * c, blk);
+        }
+    } else if (qrow < F) {
         float* rowp = p.out + (row0 + qrow) * D;
         const int c0 = h * DH + 4 * h2;
 #pragma unroll
@@ -277,13 +443,8 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
             f32x4 v0, v1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v0[e] = o0[4 * rg + e] * inv; v1[e] = o1[4 * rg + e] * inv; }
-            if (p.split_out) {
-                store_split4(rowp, c0 + 8 * rg, v0);
-                store_split4(rowp, c0 + 32 + 8 * rg, v1);
-            } else {
-                st4(rowp + c0 + 8 * rg, v0);
-                st4(rowp + c0 + 32 + 8 * rg, v1);
-            }
+            st4(rowp + c0 + 8 * rg, v0);
+            st4(rowp + c0 + 32 + 8 * rg, v1);
         }
     }
 }
@@ -297,12 +458,18 @@ int launch_dec_qkv_attn(const float* xs, const float* w, const float* bias, cons
     int dev = 0;
     LADIFF_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return LADIFF_ERR_ARG;
+    const void* k[7] = {reinterpret_cast<const void*>(dec_qkv_attn_kernel<0>), reinterpret_cast<const void*>(dec_qkv_attn_kernel<1>),
+                        reinterpret_cast<const void*>(dec_qkv_attn_kernel<2>), reinterpret_cast<const void*>(dec_qkv_attn_kernel<3>),
+                        reinterpret_cast<const void*>(dec_qkv_attn_kernel<4>), reinterpret_cast<const void*>(dec_qkv_attn_kernel<5>),
+                        reinterpret_cast<const void*>(dec_qkv_attn_kernel<6>)};
     if (!attr_set[dev]) {
-        LADIFF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_qkv_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, QA_LDS));
+        for (int i = 0; i < 7; ++i) LADIFF_HIP(hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, QA_LDS));
         attr_set[dev] = true;
     }
-    const QkvAttnArgs a{xs, w, bias, lengths, row_off, out, B, F, split_out};
-    hipLaunchKernelGGL(dec_qkv_attn_kernel, dim3(B * H), dim3(512), QA_LDS, s, a);
+    QkvAttnArgs a{xs, w, bias, lengths, row_off, out, B, F, split_out};
+    void* args[] = {&a};
+    const int diag = g_mlp_variant >= 21 && g_mlp_variant <= 26 ? g_mlp_variant - 20 : 0;     // timing experiments: ladiff_debug_set_mlp_variant(21 .. 26)
+    LADIFF_HIP(hipLaunchKernel(k[diag], dim3(8 * H * ((B + 7) / 8)), dim3(512), args, QA_LDS, s));
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
