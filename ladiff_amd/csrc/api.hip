@@ -1,6 +1,9 @@
 // extern "C" surface of libladiff_hip.so (declared in include/ladiff_hip.h).
 #include <algorithm>
 #include <cstdlib>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -87,7 +90,22 @@ struct Sampler {
     int key_ints[4] = {0};
     float key_f[2] = {0.f, 0.f};
     uint64_t key_hash = 0, key_gen = 0;
+    uint64_t epoch = 0;                   // g_graph_epoch when these graphs were instantiated (see there)
+    std::vector<hipGraphExec_t> retired;  // replaced while a launch of them could still be queued: destroyed at the next drain
 };
+
+// A graph is only replayed while it is the NEWEST graph instantiation of the process.  Seen on ROCm 7.2 / MI355X
+// (scripts/repro_seq.py, tests/test_gpu_pipeline.py::test_old_step_graph_is_not_replayed_after_other_plans): the step graph of one
+// sampler (~150 kernel nodes), replayed after two OTHER samplers had instantiated their graphs and a blocking hipMemcpy had run in
+// between, dispatched kernels with garbage pointer arguments (memory access fault; every pointer the nodes were captured with was
+// still alive, and the same sequence without graphs is clean).  Whatever the runtime does to an older exec's argument storage,
+// re-instantiating costs a few hundred microseconds and only happens when samplers alternate.
+std::atomic<uint64_t> g_graph_epoch{0};
+
+void drain_retired(Sampler* sp) {            // call with the stream drained
+    for (hipGraphExec_t g : sp->retired) (void)hipGraphExecDestroy(g);
+    sp->retired.clear();
+}
 
 uint64_t hash_ptrs(const float* const* p, int n, uint64_t h) {            // FNV-1a over the pointer values
     for (int i = 0; i < n; ++i) {
@@ -291,6 +309,7 @@ int ladiff_sampler_destroy(void* sampler) {
     Sampler* sp = reinterpret_cast<Sampler*>(sampler);
     if (sp == nullptr) return 0;
     (void)hipDeviceSynchronize();         // a replay of these graphs may still be queued
+    drain_retired(sp);
     if (sp->exec) (void)hipGraphExecDestroy(sp->exec);
     if (sp->setup) (void)hipGraphExecDestroy(sp->setup);
     if (sp->ev0) (void)hipEventDestroy(sp->ev0);
@@ -525,11 +544,21 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
         const bool same = sp->setup && std::memcmp(kp, sp->key_ptrs, sizeof(kp)) == 0 &&
                           std::memcmp(ki, sp->key_ints, sizeof(ki)) == 0 && std::memcmp(kf, sp->key_f, sizeof(kf)) == 0 &&
                           h == sp->key_hash && weights_generation == sp->key_gen;
-        if (!same) {
-            // replays of the old graphs may still be queued (the host never paces the GPU): drain before destroying them
-            if (sp->exec || sp->setup) LADIFF_HIP(hipStreamSynchronize(s));
-            if (sp->exec) { (void)hipGraphExecDestroy(sp->exec); sp->exec = nullptr; }
-            if (sp->setup) { (void)hipGraphExecDestroy(sp->setup); sp->setup = nullptr; }
+        const bool newest = sp->epoch == g_graph_epoch.load();      // nothing else has been instantiated since (g_graph_epoch)
+        if (!same || !newest) {
+            if (!same) {
+                // replays of the old graphs may still be queued (the host never paces the GPU): drain before destroying them
+                if (sp->exec || sp->setup || !sp->retired.empty()) LADIFF_HIP(hipStreamSynchronize(s));
+                drain_retired(sp);
+                if (sp->exec) { (void)hipGraphExecDestroy(sp->exec); sp->exec = nullptr; }
+                if (sp->setup) { (void)hipGraphExecDestroy(sp->setup); sp->setup = nullptr; }
+            } else {
+                // same key, but another sampler has instantiated since: capture again.  No drain (a chunked batch alternates two
+                // samplers launch after launch): the old graphs are set aside and destroyed at the next drain
+                if (sp->retired.size() >= 8) { LADIFF_HIP(hipStreamSynchronize(s)); drain_retired(sp); }
+                if (sp->exec) { sp->retired.push_back(sp->exec); sp->exec = nullptr; }
+                if (sp->setup) { sp->retired.push_back(sp->setup); sp->setup = nullptr; }
+            }
             hipGraph_t graph = nullptr;
             {   // prologue graph
                 LADIFF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -542,7 +571,9 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
                 graph = nullptr;
                 LADIFF_HIP(i0);
             }
-            if (pipeline) {
+            if (pipeline && same) {
+                // only the prologue graph was renewed: the stage table in the workspace is this key's
+            } else if (pipeline) {
                 // stage table of the persistent pipeline (pointers of this call's weights and workspace): built and uploaded
                 // once per key; the host copy stays alive in the sampler until the next rebuild
                 LADIFF_TRY(sys_build_stages(W, WSp ? WS : W, r.sys, plan_mr, plan_nb, sp->stages));
@@ -569,6 +600,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
             std::memcpy(sp->key_f, kf, sizeof(kf));
             sp->key_hash = h;
             sp->key_gen = weights_generation;
+            sp->epoch = ++g_graph_epoch;
         }
         LADIFF_HIP(hipGraphLaunch(sp->setup, s));
         if (sp->ev0 == nullptr) { LADIFF_HIP(hipEventCreate(&sp->ev0)); LADIFF_HIP(hipEventCreate(&sp->ev1)); }
@@ -712,6 +744,7 @@ namespace {
 struct DecodeGraph {
     hipGraphExec_t exec = nullptr;
     const void* key_ptrs[7] = {nullptr};
+    uint64_t epoch = 0;                   // g_graph_epoch at instantiation: replayed only while it is the newest graph of the process
     int key_ints[6] = {0};
     uint64_t key_hash = 0, key_gen = 0;
 };
@@ -746,7 +779,7 @@ int ladiff_vae_decode_graphed(void* graph, const float* const* w, const float* c
     // the measurement switches change the launch sequence: part of the key
     h ^= (uint64_t)(g_dec_fused_mlp + 4 * g_dec_small_rows_path + 8 * g_dec_final_split + 16 * g_mlp_variant + 4096 * g_dec_fused_attn) * 0x100000001b3ull;
     const bool same = dg->exec && std::memcmp(kp, dg->key_ptrs, sizeof(kp)) == 0 && std::memcmp(ki, dg->key_ints, sizeof(ki)) == 0 &&
-                      h == dg->key_hash && weights_generation == dg->key_gen;
+                      h == dg->key_hash && weights_generation == dg->key_gen && dg->epoch == g_graph_epoch.load();
     if (!same) {
         if (dg->exec) { LADIFF_HIP(hipStreamSynchronize(s)); (void)hipGraphExecDestroy(dg->exec); dg->exec = nullptr; }
         hipGraph_t gr = nullptr;
@@ -767,6 +800,7 @@ int ladiff_vae_decode_graphed(void* graph, const float* const* w, const float* c
         std::memcpy(dg->key_ptrs, kp, sizeof(kp));
         std::memcpy(dg->key_ints, ki, sizeof(ki));
         dg->key_hash = h; dg->key_gen = weights_generation;
+        dg->epoch = ++g_graph_epoch;
     }
     LADIFF_HIP(hipGraphLaunch(dg->exec, s));
     return 0;

@@ -31,9 +31,13 @@ for precision, tol in (("bf16x3", 2e-4), ("fp32", 2e-5)):
         if not guided:
             text = text[B:].contiguous()
         out = {}
+        if os.environ.get("STRESS_VERBOSE"):
+            print(f"{precision} case {case}: B={B} {kind} steps={steps} guided={guided} lens[:6]={lens[:6]}", file=sys.stderr, flush=True)
         with torch.no_grad():
             for loop in ("launches", "pipeline16", "pipeline16", "pipeline32" if guided else "pipeline"):
                 pipe.loop = loop
+                if os.environ.get("STRESS_VERBOSE"):
+                    print(f"    {loop}", file=sys.stderr, flush=True)
                 z = pipe._diffusion_reverse(text, lens, init_noise=noise)
                 torch.cuda.synchronize()
                 st = pipe.loop_status()

@@ -188,6 +188,35 @@ def test_repeated_full_size_calls_are_identical(nets, precision):
         assert torch.equal(z, ref) and torch.equal(zs, ref_s), (precision, it)
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+def test_old_step_graph_is_not_replayed_after_other_plans(nets, precision):
+    """A hipGraph is replayed only while it is the newest graph instantiation of the process (api.hip, g_graph_epoch).  The sequence
+    that failed before: launch-per-stage loop at 200 prompts (its ~150-node step graph instantiated), a blocking status read, two
+    other batch shapes (two more samplers, their graphs, status reads), the first shape again - the replay of the FIRST step graph
+    dispatched kernels with garbage pointers (memory access fault; the same sequence without graphs was clean, every captured
+    pointer was alive).  Now the first shape captures again: same bits as its first run, for the three loop forms."""
+    den, vae = nets
+    pipe = LADIFF(denoiser=den, vae=vae, scheduler=DDIMScheduler(set_alpha_to_one=False, steps_offset=1, **SCHED_KW),
+                  guidance_scale=7.5, num_inference_timesteps=2, eta=0.0, max_it=5, precision=precision, loop="launches")
+    data = {B: (syn.text_embeddings(B, seed=B).to(DEV), syn.init_noise([196] * B, seed=B + 1).to(DEV)) for B in (200, 32, 16, 321)}
+
+    def call(B, loop):
+        pipe.loop = loop
+        z = pipe._diffusion_reverse(data[B][0], [196] * B, init_noise=data[B][1])
+        assert pipe.loop_status() == (0, 0)                       # a blocking device-to-host copy, as in the failing sequence
+        return z
+
+    first = call(200, "launches")
+    call(32, "launches"); call(16, "launches")
+    assert torch.equal(call(200, "launches"), first)
+    # the same with the other shapes run by the pipeline kernel, a chunked batch (two samplers alternating) among them
+    call(32, "pipeline16"); call(321, "pipeline16"); call(16, "pipeline32")
+    assert torch.equal(call(200, "launches"), first)
+    a = call(321, "pipeline16")
+    call(200, "launches"); call(32, "pipeline16")
+    assert torch.equal(call(321, "pipeline16"), a)
+
+
 def test_two_samplers_on_two_streams(nets):
     """A pipeline kernel needs the whole chip resident: launches from different streams of one process are chained through an
     event (systolic.hip), so two samplers enqueued back to back on two streams both complete with the right result."""
