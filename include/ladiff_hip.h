@@ -263,7 +263,10 @@ int ladiff_debug_set_decoder_fusion(int on);
 /* Measurement switch (process-wide) of the fused feed-forward kernel's form: 0 (default) = chosen by the row count, 1 = 128-row
  * workgroups of eight waves x 16 rows, 2 = 64-row workgroups of four waves x 16 rows, 3 = 128-row workgroups of four waves x 32 rows.
  * 11 .. 17: timing builds of form 3 with one ingredient removed (no LDS-DMA in the loop / no MFMAs / no fragment reads / no GELU / no
- * epilogue / reads never used / reads waited for but not used): the RESULTS ARE GARBAGE, scripts/mlp_speed.py only. */
+ * epilogue / reads never used / reads waited for but not used): the RESULTS ARE GARBAGE, scripts/mlp_speed.py only.
+ * 21 .. 26: timing builds of the decoder's attention kernel with in_proj inside (csrc/dec_qkv_attn.hip: no LDS-DMA waits / no score,
+ * softmax, output core / no projection MFMAs / no projection / no x row loads / x row loads only), GARBAGE results as well,
+ * scripts/attn_speed.py only; the feed-forward kernel keeps its default form under these values. */
 int ladiff_debug_set_mlp_variant(int v);
 /* The block plan ladiff_diffusion_reverse would use for a batch (host arithmetic only, no GPU call): rows per block (16 = the
  * length-aware packing, 32 = padded blocks) and the number of blocks.  h_counts = latent counts on the host or NULL, masked = the
