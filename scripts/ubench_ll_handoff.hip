@@ -6,6 +6,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o scripts/ubench_ll_handoff.bin scripts/ubench_ll_handoff.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -61,9 +62,10 @@ __global__ __launch_bounds__(512, 1) void pingpong(float* data, unsigned* flags,
                 y = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, src + 8192 + tid * 16, 0, 16));
             }
             acc += x[0] + y[3];
-            a[1] = x[1] + 1.f; a[3] = x[3] + 1.f; b[2] = y[2] + 1.f; b[3] = y[3] + 1.f;
+            // (the chain counts modulo 2^20 so that a soak of many rounds stays exact in fp32)
+            { const float nx = (float)(((int)x[1] + 1) & 0xfffff); a[1] = nx; a[3] = nx + 2.f; b[2] = nx + 5.f; b[3] = nx + 6.f; }
             // the chain: every hop adds one to these four words - a torn or stale unit shows here
-            const float expect = me == 1 ? (float)(2 * r - 1) : (float)(2 * (r - 1));
+            const float expect = me == 1 ? (float)((2 * r - 1) & 0xfffff) : (float)((2 * (r - 1)) & 0xfffff);
             if (x[1] != expect || x[3] != expect + 2.f || y[2] != expect + 5.f || y[3] != expect + 6.f) {
                 if (atomicCAS(fail, 0u, 2u) == 0u) {              // first failure: what was read
                     float* dbg = data + 200000;
@@ -95,9 +97,10 @@ __global__ __launch_bounds__(512, 1) void pingpong(float* data, unsigned* flags,
     if (acc == 12345.678f) data[100000 + tid] = acc;
 }
 
+static int g_rounds = 2001;
 template <int TAGGED, int ST>
 static void run(const char* name, float* data, unsigned* flags, unsigned* xcc, unsigned long long* ticks, unsigned* fail, unsigned* retries, int wa, int wb) {
-    const int rounds = 2001;
+    const int rounds = g_rounds;
     hipFuncSetAttribute(reinterpret_cast<const void*>(pingpong<TAGGED, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipMemset(flags, 0, 4096); hipMemset(fail, 0, 4); hipMemset(ticks, 0, 8); hipMemset(retries, 0, 4); hipMemset(data, 0, 1 << 20);
     hipLaunchKernelGGL((pingpong<TAGGED, ST>), dim3(64), dim3(512), 100 * 1024, 0, data, flags, xcc, ticks, wa, wb, rounds, fail, retries);
@@ -113,9 +116,11 @@ static void run(const char* name, float* data, unsigned* flags, unsigned* xcc, u
     if (hf) printf("%-34s workgroups %2d (XCC %u) <-> %2d (XCC %u): FAILED (%u: 1 = never seen, 2 = wrong data)\n", name, wa, hx[wa], wb, hx[wb], hf);
     else printf("%-34s workgroups %2d (XCC %u) <-> %2d (XCC %u): %.3f us per hop   (%.1f polls per wave-hop, every received word checked)\n", name, wa, hx[wa], wb, hx[wb],
                 ht * 0.01 / (2.0 * (rounds - 2)), hr / (16.0 * rounds) + 1.0);
+    fflush(stdout);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_rounds = atoi(argv[1]);     // rounds per configuration: a long run is the soak for torn units (every received word is checked)
     float* data; unsigned *flags, *xcc, *fail, *retries; unsigned long long* ticks;
     hipMalloc(&data, 1 << 20); hipMalloc(&flags, 4096); hipMalloc(&xcc, 4096); hipMalloc(&fail, 4); hipMalloc(&ticks, 8); hipMalloc(&retries, 4);
     for (int rep = 0; rep < 2; ++rep) {
