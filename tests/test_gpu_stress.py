@@ -1,0 +1,44 @@
+"""The random-shape stress programs of scripts/ as GPU tests (short runs; the long runs are logged under profiles/r3/16_*).  Each runs in a
+child process of its own - they build their own objects and switch process-wide measurement switches - and exits non-zero on the first
+shape that disagrees."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(script, *args, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script), *map(str, args)], cwd=ROOT, capture_output=True, text=True,
+                       timeout=timeout)
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-12:])
+    assert r.returncode == 0, tail
+    return r.stdout
+
+
+@pytest.mark.slow
+def test_random_decode_shapes():
+    """LADiffVae.decode on 80 random batches (1 ... 257 samples, five length patterns, both feature counts, ragged and padded): the default
+    bf16x3 path against each fusion switched off, against fp32 mode, twice (same bits), frames past each length exactly zero."""
+    out = _run("stress_decode.py", 80, 17)
+    assert "80 decode shapes done, 0 bad" in out
+
+
+@pytest.mark.slow
+def test_random_loop_shapes_and_forms():
+    """The reverse loop on random batches (1 ... 520 prompts, chunked batches included, with and without guidance), both arithmetic modes:
+    pipeline against launch-per-stage loop, repeat identical, 16- against 32-row plan identical, status clean after every call - the run
+    that found the stale step graph (api.hip, g_graph_epoch)."""
+    out = _run("stress_shapes.py", 24, 7)
+    assert "fp32: 24 shapes done, 0 bad so far" in out
+
+
+@pytest.mark.slow
+def test_random_sample_sequences_on_one_object():
+    """One LADIFF object through 60 random (arithmetic mode, loop form, guidance, batch shape, steps) calls of sample(), each against a
+    second object on the fp32 launch-per-stage path."""
+    out = _run("stress_sample.py", 60, 29)
+    assert "60 sample() cases done, 0 bad" in out
