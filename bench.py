@@ -2,7 +2,9 @@
 """Benchmark of the LADiff sampling hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W [--config headline|c1|c2|c3|c4|c5]
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+    N > 1: either under the launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...) or plainly - a plain `python bench.py --gpus N` starts exactly that launcher as a child
+    process before anything touches the GPU, relays rank 0's JSON line and returns the launcher's exit code (`self_launch`).
 
 One "step" = one pass of the hot path over one batch of synthetic prompts.  Default workload (BASELINE.json's metric, also
 config c4's per-rank slice): 128 prompts per GPU, 196 frames, 50-step DDIM with classifier-free guidance 7.5
@@ -39,7 +41,55 @@ import os
 import sys
 import time
 
-import torch
+
+# ------------------------------------------------------------------------------------------------ N > 1 without torchrun
+def launcher_command(argv, n_gpus, port):
+    """`python -m torch.distributed.run ... bench.py <same args>`: what a plain `python bench.py --gpus N` (N > 1) starts as a
+    CHILD process.  One rank per GPU of one node, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def self_launch(argv):
+    """A plain `python bench.py --gpus N` with N > 1 (no WORLD_SIZE / RANK in the environment) re-runs itself under
+    torch.distributed.run as a child process, relays rank 0's JSON line on its own stdout and returns the child's exit
+    code; None when this process is itself a rank (or N = 1).  Runs BEFORE torch or the HIP library is imported: the parent
+    never touches the GPU (and never execs - a process replaced after HIP is up takes the box down)."""
+    if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return None
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1:
+        return None
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = launcher_command(argv, n, port)
+    if os.environ.get("LADIFF_BENCH_PRINT_LAUNCH") == "1":       # tests: show what would be started, start nothing
+        print(json.dumps({"cmd": cmd, "torch_imported": "torch" in sys.modules}))
+        return 0
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print("bench.py: --gpus %d without WORLD_SIZE: starting %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    for line in child.stdout:                                    # the ranks send everything but the JSON line to stderr
+        is_json = line.lstrip().startswith("{") and '"metric"' in line
+        (sys.stdout if is_json else sys.stderr).write(line)
+        (sys.stdout if is_json else sys.stderr).flush()
+    return child.wait()
+
+
+if __name__ == "__main__":
+    _rc = self_launch(sys.argv[1:])
+    if _rc is not None:
+        sys.exit(_rc)
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -317,12 +367,16 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    rank, world, local = D.init_from_env()
-    use_dist = torch.distributed.is_available() and torch.distributed.is_initialized()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    env_world, env_local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    if env_world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env_world}: the launcher's --nproc-per-node must equal --gpus")
+    if env_local >= torch.cuda.device_count():      # counting devices does not initialise the GPU
+        raise SystemExit(f"not enough devices: local rank {env_local} of --gpus {args.gpus}, but this node shows "
+                         f"{torch.cuda.device_count()} GPU(s); bench.py needs one MI355X per rank (the hot path has no CPU implementation)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation")
+    rank, world, local = D.init_from_env()
+    use_dist = torch.distributed.is_available() and torch.distributed.is_initialized()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 

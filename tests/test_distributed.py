@@ -166,3 +166,49 @@ def test_bench_n_gt_1_line_refers_to_a_recorded_cpu_baseline(tmp_path, monkeypat
     (tmp_path / "profiles" / "r9" / "bench_headline_n1.json").write_text(__import__("json").dumps(line) + "\n")
     cb = bench.recorded_cpu_baseline("headline")
     assert cb["value"] == 17.5 and cb["cores"] == 16 and "gpu_over_cpu" not in cb and "bench_headline_n1.json" in cb["source"]
+
+
+# ---------------------------------------------------------------- a plain `python bench.py --gpus N` starts the launcher itself
+def _run_bench(args, env_extra):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], capture_output=True, text=True, env=env, timeout=300)
+
+
+def test_bench_self_launch_builds_the_torchrun_command_without_touching_torch():
+    """`python bench.py --gpus 8` is how the driver calls it.  The parent must start
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 ... bench.py <same args>` as a child
+    and must not have imported torch (or the HIP library) when it does."""
+    import json
+    r = _run_bench(["--gpus", "8", "--steps", "5", "--warmup", "2", "--config", "c4"], {"LADIFF_BENCH_PRINT_LAUNCH": "1"})
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    cmd = d["cmd"]
+    assert d["torch_imported"] is False
+    assert cmd[1:5] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8"]
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(next(c for c in cmd if c.endswith("bench.py")))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "2", "--config", "c4"]
+    # --gpus=N spelling; N = 1 and a process that already is a rank do not launch anything
+    r = _run_bench(["--gpus=2"], {"LADIFF_BENCH_PRINT_LAUNCH": "1"})
+    assert json.loads(r.stdout)["cmd"][4] == "--nproc-per-node=2"
+    import bench
+    assert bench.self_launch(["--gpus", "1"]) is None
+    os.environ["WORLD_SIZE"] = "2"
+    try:
+        assert bench.self_launch(["--gpus", "2"]) is None
+    finally:
+        del os.environ["WORLD_SIZE"]
+
+
+def test_bench_self_launch_propagates_the_ranks_failure():
+    """No GPU here: both ranks stop with "not enough devices", torchrun exits non-zero and so does the parent - and NOT with the
+    old `--gpus 2 but WORLD_SIZE=1` SystemExit."""
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {})
+    assert r.returncode != 0
+    assert "not enough devices" in r.stderr
+    assert "WORLD_SIZE=1" not in r.stderr
+    assert r.stdout.strip() == ""
