@@ -247,6 +247,11 @@ int ladiff_sampler_set_loop(void* sampler, int mode);
 /* Measurement switch (process-wide): waves per SIMD of the stage workgroups of the 16-row plan, 2 (default: 512-thread workgroups,
  * each stage's weight slice split over the two waves of a SIMD) or 1 (256 threads). */
 int ladiff_debug_set_stage_waves(int waves_per_simd);
+/* Measurement switch (process-wide): how the eight-wave stages of the 16-row plan hand a block's rows to the next stage.
+ * 1 (default) = the rows carry a parity tag in the last mantissa bit of every word and a consumer loads them until all its words
+ * show the parity of the step (no drain, no flag, no separate poll; csrc/systolic.hip, tag4); 0 = the flag protocol (write-through
+ * or XCD-local stores, drain, barrier, one epoch word per producer, polled by every consumer wave).  Both give the same bits. */
+int ladiff_debug_set_handoff(int tagged);
 /* Measurement switch (process-wide, read when a sampler builds its stage table): 1 (default) = the pipeline stages are dealt to
  * the XCDs in chain order and a stage whose readers share its XCD hands its rows over through that XCD's L2 (plain stores);
  * 0 = every hand-off writes through to the memory side, stages in table order; 2 = as 1, but one workgroup of every launch

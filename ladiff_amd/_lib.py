@@ -106,6 +106,7 @@ _SIGNATURES = {
     "ladiff_vae_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                   c_void_p, c_size_t, c_void_p]),
     "ladiff_debug_set_stage_waves": (c_int, [c_int]),
+    "ladiff_debug_set_handoff": (c_int, [c_int]),
     "ladiff_debug_set_xcd_local": (c_int, [c_int]),
     "ladiff_debug_set_decoder_fusion": (c_int, [c_int]),
     "ladiff_debug_set_mlp_variant": (c_int, [c_int]),

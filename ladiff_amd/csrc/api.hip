@@ -361,6 +361,12 @@ int ladiff_debug_set_stage_waves(int waves_per_simd) {
     return 0;
 }
 
+int ladiff_debug_set_handoff(int tagged) {
+    LADIFF_CHECK_ARG(tagged == 0 || tagged == 1);
+    g_handoff = tagged;
+    return 0;
+}
+
 int ladiff_debug_set_mlp_variant(int v) {
     LADIFF_CHECK_ARG((v >= 0 && v <= 3) || (v >= 11 && v <= 17) || (v >= 21 && v <= 26));
     g_mlp_variant = v;

@@ -62,6 +62,7 @@ extern unsigned long long* g_sys_stamps;
 size_t sys_ws_floats(int B, int T);
 bool sys_supported(int B, int T, int cfg, bool split);
 extern int g_waves16;
+extern int g_handoff;
 extern int g_fault_wg;
 extern unsigned long long g_timeout_ticks;
 int sys_reset_status(float* ws, hipStream_t s);

@@ -84,6 +84,7 @@ struct Stage {                            // one per workgroup
     const float *g, *be;                  // LayerNorm gamma / beta
     const float *in0, *in1, *in2;         // block-layout activations: [NB][RT][256] (partials: [8][NB][RT][256])
     float* out;
+    const float* bp_buf;                  // LIN / FFN, tagged hand-off: the consumer's OUTPUT rows (their tags are the ring's back-pressure)
 };
 
 // Geometry of one block, built on the host (sys_pack_blocks).  32-row tiles: both guidance branches of P prompts, T rows each
@@ -200,8 +201,34 @@ __device__ __forceinline__ void st_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, f
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 16);
 }
 typedef __attribute__((address_space(1))) unsigned gu32;
-// a stage's output rows: plain when every reader shares this XCD's L2, write-through otherwise
-__device__ __forceinline__ void st_out(const Stage& st, __amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
+
+// ---- tagged hand-off (template switch HO = 1; HO = 0 is the flag protocol above).  The DATA carries the epoch: the last
+// mantissa bit of EVERY fp32 word of a handed-off row is replaced by a parity bit - parity of the local step for a buffer that is
+// written once per step, parity of the slot's use count for the rings of partial planes.  A consumer loads the rows it needs
+// (sc1, 16 bytes per lane as before), looks at the parity bit of every word it loaded and loads again until all of them show
+// the parity it expects; then it clears the bits and computes.  What this removes from every hop: the producer's drain
+// (s_waitcnt vmcnt(0)), its barrier and flag store, and the consumer's separate poll round trip - the poll IS the load.
+// What it rests on: an aligned 4-byte word is written whole (each word carries its own bit, so nothing is assumed about the
+// 16-byte store being seen as one unit); a slot is written exactly once per use and not again before every reader of that use
+// has loaded it (the dependency chain through the tail stage for the per-step buffers, MlpRole::backpressure_tag for the
+// rings); the hand-off buffers are set to parity 1 before every launch (bytes 0x01) and the first use expects parity 0.
+// The value a consumer computes with has the bit CLEARED, whatever the parity was: results do not depend on the block plan, and
+// the flag protocol stores and clears the same way (parity 0), so the two protocols give the same bits.
+__device__ __forceinline__ f32x4 tag4(const f32x4 v, unsigned par) {
+    return __builtin_bit_cast(f32x4, (__builtin_bit_cast(u32x4, v) & 0xfffffffeu) | par);
+}
+__device__ __forceinline__ f32x4 untag4(const f32x4 v) { return __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, v) & 0xfffffffeu); }
+// bad |= (parity bit of any of the four words) != par   (only bit 0 of `bad` means anything)
+__device__ __forceinline__ void tag_acc(unsigned& bad, const f32x4 v, unsigned par) {
+    const u32x4 w = __builtin_bit_cast(u32x4, v) ^ par;
+    bad |= (w[0] | w[1]) | (w[2] | w[3]);
+}
+__device__ __forceinline__ unsigned ring_use_par(const SysArgs& p, int s, int b) { return (unsigned)(((s * p.NB + b) / PRING) & 1); }
+
+// a stage's output rows: plain when every reader shares this XCD's L2, write-through otherwise; par = the parity tag (0 under
+// the flag protocol)
+__device__ __forceinline__ void st_out(const Stage& st, __amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v, unsigned par) {
+    v = tag4(v, par);
     if (st.out_local) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
     else st_sc1(r, off, v);
 }
@@ -281,15 +308,27 @@ __device__ __forceinline__ void commit_rows(char* tile, int kb0, const Rows256<M
 #pragma unroll
     for (int u = 0; u < 2 * MR / WS; ++u) {
         const int id = threadIdx.x + 256 * WS * u, row = id >> 5, c8 = id & 31;
+        const f32x4 v0 = untag4(x.v[u][0]), v1 = untag4(x.v[u][1]);
         if constexpr (AR == 0) {
             bf16x8 hi, lo;
-            split8(x.v[u][0], x.v[u][1], hi, lo);
+            split8(v0, v1, hi, lo);
             *reinterpret_cast<bf16x8*>(a_slot<KB>(tile, row, kb0 + (c8 >> 3), c8 & 7)) = hi;
             *reinterpret_cast<bf16x8*>(a_slot<KB>(tile, row, kb0 + (c8 >> 3), 8 + (c8 & 7))) = lo;
         } else {
-            tile_put4<1, KB>(tile, row, kb0 * 64 + c8 * 8, x.v[u][0]);
-            tile_put4<1, KB>(tile, row, kb0 * 64 + c8 * 8 + 4, x.v[u][1]);
+            tile_put4<1, KB>(tile, row, kb0 * 64 + c8 * 8, v0);
+            tile_put4<1, KB>(tile, row, kb0 * 64 + c8 * 8 + 4, v1);
         }
+    }
+}
+// tagged hand-off: does every word of the rows below `nrows` (rows from there on are never written) show parity `par`?
+template <int MR, int WS>
+__device__ __forceinline__ void rows_bad(unsigned& bad, const Rows256<MR, WS>& x, int nrows, unsigned par) {
+#pragma unroll
+    for (int u = 0; u < 2 * MR / WS; ++u) {
+        const int row = (threadIdx.x + 256 * WS * u) >> 5;
+        unsigned t = 0u;
+        tag_acc(t, x.v[u][0], par); tag_acc(t, x.v[u][1], par);
+        bad |= row < nrows ? t : 0u;
     }
 }
 
@@ -449,20 +488,106 @@ __device__ __forceinline__ void stage_loop(const SysArgs& p, const Stage& st, R&
     SYS_STAT_END;
 }
 
+// ---------------------------------------------------------------- the stage loop of the tagged hand-off (HO = 1)
+// Same lattice order of (step, block).  No flags: a block's loads are ISSUED - mid-way through the previous block's compute, always,
+// whether its rows are there or not - and their tags are looked at when the block's turn comes (`settle`): a wave whose words do
+// not all show the expected parity loads them again.  Every wave settles by itself on exactly the words IT consumes; the waves
+// meet at the barrier behind the operand tile.  Nothing is drained and nothing is published: the stores of `compute` carry the
+// parity of their step.
+//   r.bad(s, b, geo, pay)  bit 0 set when a handed-off word of `pay` does not show the parity of (s, b)
+// A spin that has lasted `timeout` raises the abort word (as wait_epoch does) and every poller looks at that word every 64 turns.
+__device__ __forceinline__ bool spin_give_up(const SysArgs& p, unsigned spins, unsigned long long t0) {
+    if ((spins & 63u) != 0u) return false;
+    if (__hip_atomic_load((const gu32*)p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > p.timeout_ticks) {
+        if ((threadIdx.x & 63) == 0) {
+            __hip_atomic_store((gu32*)p.status + 1, (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((gu32*)p.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return true;
+    }
+    return false;
+}
+// `issued`: the loads of (s, b) are already in flight (requested during the previous block's compute).  ONE copy of the load and
+// check code in the loop (two - one in front of the loop, one inside - kept both sets of addresses alive and spilled weights)
+template <class R>
+__device__ __forceinline__ bool settle(const SysArgs& p, R& r, int s, int b, const typename R::Geo& g, typename R::Pay& y, bool issued) {
+    unsigned long long t0 = 0ull;
+    for (unsigned spins = 0;; ++spins) {
+        if (spins != 0u || !issued) r.issue(s, b, g, y);
+        if (__all((r.bad(s, b, g, y) & 1u) == 0u)) return true;
+        if (spins == 0u) t0 = __builtin_amdgcn_s_memrealtime();
+        else if (spin_give_up(p, spins, t0)) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+template <class R>
+struct MidTag {
+    const SysArgs& p; R& r; typename R::Pay& nxt; typename R::Geo& gnxt; typename R::Geo& gnn;
+    bool has_next; int s2, b2, s3, b3;
+    __device__ __forceinline__ void before_barrier() {}
+    __device__ __forceinline__ void after_barrier() {
+        // geometry words are fetched two blocks ahead (as stage_loop); the next block's rows are requested now, valid or not
+        r.geo_fix(gnxt);
+        if constexpr (R::PREFETCH) { if (has_next) r.issue(s2, b2, gnxt, nxt); }
+        if (s3 < p.n_steps) r.geo(b3, gnn);
+    }
+};
+template <class R>
+__device__ __forceinline__ void tag_loop(const SysArgs& p, const Stage& st, R& r, int b0, int bstride) {
+    typename R::Pay cur, nxt;
+    typename R::Geo gcur, gnxt, gnn;
+    bool have = false;
+    if (b0 < p.NB) {
+        r.geo(b0, gcur);
+        r.geo(b0 + bstride < p.NB ? b0 + bstride : b0, gnxt);
+        r.geo_fix(gcur);
+        gnn = gnxt;
+    }
+    SYS_STAT_DECL;
+    for (int s = 0; s < p.n_steps; ++s)
+        for (int b = b0; b < p.NB; b += bstride) {
+            SYS_STAMP(0);
+            SYS_STAT_ITER(have);
+            if constexpr (R::BACKP) { if (!r.backpressure_tag(s, b)) return; }
+            SYS_STAT_T0;
+            if (!settle(p, r, s, b, gcur, cur, have)) return;
+            SYS_STAT_WAIT;
+            SYS_STAMP(1);
+            int s2 = s, b2 = b + bstride;
+            if (b2 >= p.NB) { s2 = s + 1; b2 = b0; }
+            int s3 = s2, b3 = b2 + bstride;
+            if (b3 >= p.NB) { s3 = s2 + 1; b3 = b0; }
+            const bool has_next = s2 < p.n_steps;
+            r.commit(cur);
+            if constexpr (R::TILE) __syncthreads();                     // the operand tile is complete (roles without one: no barrier)
+            SYS_STAMP(2);
+            MidTag<R> mid{p, r, nxt, gnxt, gnn, has_next, s2, b2, s3, b3};
+            r.compute(s, b, gcur, cur, mid);
+            have = R::PREFETCH && has_next;
+            gcur = gnxt; gnxt = gnn;
+            SYS_STAMP(4);
+            if constexpr (R::PREFETCH) { if (have) cur = nxt; }
+            SYS_STAMP(5);
+        }
+    SYS_STAT_END;
+}
+
 // ---------------------------------------------------------------- roles
 // QKV: one head.  in_proj rows {q,k,v} x 64 of head `slice` on the block, then softmax(q k^T / 8) v over the valid latent
 // keys of the row's sample-branch, the text token and the time token.  Geometry comes from the block descriptor (LDS copy).
 // WS = waves per SIMD.  The head's 192 columns are 12 MFMA tiles, three per SIMD: with one wave per SIMD the wave takes all three;
 // with two, wave s (< 4) takes the first two of SIMD s and wave s + 4 the third - two instruction streams per SIMD cover each
 // other's LDS / DPP / barrier latencies.
-template <int MR, int AR, int WS>
+template <int MR, int AR, int WS, int HO>
 struct QkvRole {
     static constexpr int RT = 16 * MR, QLD = 196, TK = LADIFF_MAX_LATENTS + 2;   // keys of a row: <= 8 latents, text, time
     static constexpr int NTH = 256 * WS, NTW = WS == 1 ? 3 : 2, NX = 2 / WS;      // threads; column tiles a wave can hold; 16-byte text K|V units per thread
     static constexpr bool PREFETCH = true;
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = false;
-    struct Geo { int gw, rb2, b2[NX]; };                                 // descriptor word `tid` (+ its row's sample-branch); sample-branch of this thread's text slots
+    static constexpr bool TILE = true;
+    struct Geo { int gw, rb2, b2[NX], nrows; };                          // descriptor word `tid` (+ its row's sample-branch); sample-branch of this thread's text slots; live rows
     struct Pay { Rows256<MR, WS> x; f32x4 xk[NX]; };
     const SysArgs& p; const Stage& st;
     char* atile; float *qt, *xt; int* gd;
@@ -503,6 +628,12 @@ struct QkvRole {
         const int* src = tid == 0 ? &d->nrows : &d->row_pk[tid <= RT ? tid - 1 : 0];
         g.gw = *src;
         g.rb2 = d->row_b2[tid >= 1 && tid <= RT ? tid - 1 : 0];
+        g.nrows = d->nrows;
+    }
+    __device__ __forceinline__ unsigned bad(int s, int, const Geo& g, const Pay& y) const {
+        unsigned t = 0u;
+        rows_bad<MR, WS>(t, y.x, g.nrows, (unsigned)(s & 1));
+        return t;
     }
     __device__ __forceinline__ void geo_fix(Geo& g) {                    // a latent count that lives on the device only (0xff)
         const int tid = threadIdx.x;
@@ -566,7 +697,8 @@ struct QkvRole {
         mid.after_barrier();
         SYS_STAMP(6);
         // the shipped models have T = 5 latent tokens (7 keys): the loops are unrolled over the keys, so the bound is compile time
-        if (T <= 5) attention<7>(b); else attention<TK>(b);
+        const unsigned par = HO ? (unsigned)(s & 1) : 0u;
+        if (T <= 5) attention<7>(b, par); else attention<TK>(b, par);
     }
     // ---- two waves per SIMD: the role runs as TWO WAVE GROUPS instead of the generic stage loop.  Waves 4-7 ("loaders") wait for
     // a block's flags, load it and write its operand tile while waves 0-3 still run the attention of the PREVIOUS block (the
@@ -603,17 +735,38 @@ struct QkvRole {
                         else if (b2[u] >= 0) xk[u] = ld4(tkv + (size_t)b2[u] * 512 + (c4 < 64 ? c4 : 192 + c4) + h * 64);
                     }
                     SYS_SPLIT_T0;
-                    if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, 0u, p.timeout_ticks)) return;
-                    SYS_SPLIT_WAIT;
-                    SYS_STAMP_L(1);
+                    if constexpr (!HO) { if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, 0u, p.timeout_ticks)) return; }
                     f32x4 x[2][2];
                     const unsigned base = (unsigned)b * RT * 1024;
+                    auto load_x = [&] {
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int id = tl + 256 * u, row = id >> 5, c8 = id & 31;
-                        x[u][0] = ld_sc1(rin, base + row * 1024 + c8 * 32);
-                        x[u][1] = ld_sc1(rin, base + row * 1024 + c8 * 32 + 16);
+                        for (int u = 0; u < 2; ++u) {
+                            const int id = tl + 256 * u, row = id >> 5, c8 = id & 31;
+                            x[u][0] = ld_sc1(rin, base + row * 1024 + c8 * 32);
+                            x[u][1] = ld_sc1(rin, base + row * 1024 + c8 * 32 + 16);
+                        }
+                    };
+                    load_x();
+                    if constexpr (HO) {              // tagged hand-off: the rows are loaded until every word shows this step's parity
+                        const int nrows = d->nrows;
+                        const unsigned par = (unsigned)(s & 1);
+                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                        for (unsigned spins = 1;; ++spins) {
+                            unsigned t = 0u;
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                unsigned tu = 0u;
+                                tag_acc(tu, x[u][0], par); tag_acc(tu, x[u][1], par);
+                                t |= ((tl + 256 * u) >> 5) < nrows ? tu : 0u;
+                            }
+                            if (__all((t & 1u) == 0u)) break;
+                            if (spin_give_up(p, spins, t0)) return;
+                            __builtin_amdgcn_s_sleep(1);
+                            load_x();
+                        }
                     }
+                    SYS_SPLIT_WAIT;
+                    SYS_STAMP_L(1);
                     if (tl >= 1 && tl <= RT && ((gw >> 16) & 0xff) == 0xff) {        // a latent count that lives on the device only
                         int c = T;
                         if (rb2 >= 0 && p.counts != nullptr) { c = p.counts[rb2 % p.B]; c = c > T ? T : c; }
@@ -622,14 +775,15 @@ struct QkvRole {
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {                        // rows -> operand tile (as commit_rows)
                         const int id = tl + 256 * u, row = id >> 5, c8 = id & 31;
+                        const f32x4 v0 = untag4(x[u][0]), v1 = untag4(x[u][1]);
                         if constexpr (AR == 0) {
                             bf16x8 hi, lo;
-                            split8(x[u][0], x[u][1], hi, lo);
+                            split8(v0, v1, hi, lo);
                             *reinterpret_cast<bf16x8*>(a_slot<4>(atile, row, c8 >> 3, c8 & 7)) = hi;
                             *reinterpret_cast<bf16x8*>(a_slot<4>(atile, row, c8 >> 3, 8 + (c8 & 7))) = lo;
                         } else {
-                            tile_put4<1, 4>(atile, row, c8 * 8, x[u][0]);
-                            tile_put4<1, 4>(atile, row, c8 * 8 + 4, x[u][1]);
+                            tile_put4<1, 4>(atile, row, c8 * 8, v0);
+                            tile_put4<1, 4>(atile, row, c8 * 8 + 4, v1);
                         }
                     }
                 }
@@ -646,20 +800,23 @@ struct QkvRole {
                 lds_barrier();
                 SYS_STAMP(3);
                 if (!loader) {
-                    if (T <= 5) attention<7>(b); else attention<TK>(b);
+                    const unsigned par = HO ? (unsigned)(s & 1) : 0u;
+                    if (T <= 5) attention<7>(b, par); else attention<TK>(b, par);
                     SYS_STAMP(4);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows have landed
-                    unsigned old = 0u;
-                    if (lane == 0) old = __hip_atomic_fetch_add((lu32*)&ctl->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    old = __builtin_amdgcn_readfirstlane(old);
-                    if ((old & 3u) == 3u) raise(st, flag_of(p, st.out_group, b, st.out_slot), (unsigned)(s + 1));   // the last of the four attention waves
+                    if constexpr (!HO) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows have landed
+                        unsigned old = 0u;
+                        if (lane == 0) old = __hip_atomic_fetch_add((lu32*)&ctl->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        old = __builtin_amdgcn_readfirstlane(old);
+                        if ((old & 3u) == 3u) raise(st, flag_of(p, st.out_group, b, st.out_slot), (unsigned)(s + 1));   // the last of the four attention waves
+                    }
                     SYS_STAMP(5);
                 }
             }
         SYS_SPLIT_END;
     }
     template <int NKEY>
-    __device__ __forceinline__ void attention(int b) {
+    __device__ __forceinline__ void attention(int b, unsigned par) {
         const int tid = threadIdx.x;
         const int nrows = gd[0];
         // attention of a row on 16 lanes (4 of the head's 64 columns each): the scores are reduced across the lanes with DPP,
@@ -715,19 +872,20 @@ struct QkvRole {
                 o[0] = fmaf(pj, v4[j][0], o[0]); o[1] = fmaf(pj, v4[j][1], o[1]); o[2] = fmaf(pj, v4[j][2], o[2]); o[3] = fmaf(pj, v4[j][3], o[3]);
             }
             if (!live) o = f32x4{0.f, 0.f, 0.f, 0.f};
-            st_out(st, rout, ((unsigned)b * RT + row) * 1024 + (h * 64 + c4) * 4, o);
+            st_out(st, rout, ((unsigned)b * RT + row) * 1024 + (h * 64 + c4) * 4, o, par);
         }
     }
 };
 
 // OUT: X1 = LN1(x + out_proj(att))
-template <int MR, int AR, int WS>
+template <int MR, int AR, int WS, int HO>
 struct OutRole {
     static constexpr int RT = 16 * MR, NW = 4 * WS, RPW = RT / NW, NTW = 16 / NW;     // rows / column tiles per wave
     static constexpr bool PREFETCH = true;
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = false;
-    struct Geo {};
+    static constexpr bool TILE = true;
+    struct Geo { int nrows; };
     struct Pay { Rows256<MR, WS> att; f32x4 res[RPW]; };
     const SysArgs& p; const Stage& st;
     char* atile; float* ct;
@@ -741,8 +899,17 @@ struct OutRole {
         bias = ld4(st.b0 + 4 * lane); gg = ld4(st.g + 4 * lane); bb = ld4(st.be + 4 * lane);
         ratt = rsrc_of(st.in0); rx = rsrc_of(st.in1); rout = rsrc_of(st.out);
     }
-    __device__ __forceinline__ void geo(int, Geo&) {}
+    __device__ __forceinline__ void geo(int b, Geo& g) { g.nrows = p.blocks[b].nrows; }
     __device__ __forceinline__ void geo_fix(Geo&) {}
+    // attention rows: every row of the tile is written (dead rows as zeros); the residual rows only below nrows
+    __device__ __forceinline__ unsigned bad(int s, int, const Geo& g, const Pay& y) const {
+        const int wave = threadIdx.x >> 6;
+        unsigned t = 0u;
+        rows_bad<MR, WS>(t, y.att, RT, (unsigned)(s & 1));
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) { unsigned tq = 0u; tag_acc(tq, y.res[q], (unsigned)(s & 1)); t |= wave + NW * q < g.nrows ? tq : 0u; }
+        return t;
+    }
     __device__ __forceinline__ void issue(int, int b, const Geo&, Pay& y) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const unsigned base = (unsigned)b * RT * 1024;
@@ -755,6 +922,7 @@ struct OutRole {
     __device__ __forceinline__ void compute(int s, int b, const Geo&, const Pay& y, M& mid) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
         const unsigned base = (unsigned)b * RT * 1024;
+        const unsigned par = HO ? (unsigned)(s & 1) : 0u;
         f32x4 acc[MR][NTW];
         zero_acc(acc);
         mma<AR, 4, NTW, 8, MR>(atile, wf, acc);
@@ -767,13 +935,14 @@ struct OutRole {
         for (int q = 0; q < RPW; ++q) {
             const int row = wave + NW * q;
             f32x4 v = ld4(ct + row * CLD + c);
+            const f32x4 res = untag4(y.res[q]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[i] + y.res[q][i];
+            for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[i] + res[i];
             float mean, rstd;
             row_stats4(v, mean, rstd);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = ln_apply(v[i], mean, rstd, gg[i], bb[i]);
-            st_out(st, rout, base + row * 1024 + c * 4, v);
+            st_out(st, rout, base + row * 1024 + c * 4, v, par);
         }
     }
     // ---- two waves per SIMD: two wave groups, as QkvRole::split_loop.  Waves 4-7 wait for a block's flags, load the attention rows
@@ -795,29 +964,46 @@ struct OutRole {
         for (int s = 0; s < p.n_steps; ++s)
             for (int b = st.blk0; b < p.NB; b += st.blkstride) {
                 const unsigned base = (unsigned)b * RT * 1024;
+                const unsigned par = HO ? (unsigned)(s & 1) : 0u;
                 if (loader) {
                     SYS_SPLIT_T0;
-                    if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, 0u, p.timeout_ticks)) return;
+                    if constexpr (!HO) { if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, 0u, p.timeout_ticks)) return; }
+                    f32x4 x[2][2];
+                    auto load_x = [&] {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int id = tl + 256 * u, row = id >> 5, c8 = id & 31;
+                            x[u][0] = ld_sc1(ratt, base + row * 1024 + c8 * 32);
+                            x[u][1] = ld_sc1(ratt, base + row * 1024 + c8 * 32 + 16);
+                        }
+                    };
+                    load_x();
+                    if constexpr (HO) {              // tagged hand-off: all 16 attention rows (the four heads' columns) show this step's parity
+                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                        for (unsigned spins = 1;; ++spins) {
+                            unsigned t = 0u;
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) { tag_acc(t, x[u][0], par); tag_acc(t, x[u][1], par); }
+                            if (__all((t & 1u) == 0u)) break;
+                            if (spin_give_up(p, spins, t0)) return;
+                            __builtin_amdgcn_s_sleep(1);
+                            load_x();
+                        }
+                    }
                     SYS_SPLIT_WAIT;
                     SYS_STAMP_L(1);
-                    f32x4 x[2][2];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int id = tl + 256 * u, row = id >> 5, c8 = id & 31;
-                        x[u][0] = ld_sc1(ratt, base + row * 1024 + c8 * 32);
-                        x[u][1] = ld_sc1(ratt, base + row * 1024 + c8 * 32 + 16);
-                    }
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {                        // rows -> operand tile (as commit_rows)
                         const int id = tl + 256 * u, row = id >> 5, c8 = id & 31;
+                        const f32x4 v0 = untag4(x[u][0]), v1 = untag4(x[u][1]);
                         if constexpr (AR == 0) {
                             bf16x8 hi, lo;
-                            split8(x[u][0], x[u][1], hi, lo);
+                            split8(v0, v1, hi, lo);
                             *reinterpret_cast<bf16x8*>(a_slot<4>(atile, row, c8 >> 3, c8 & 7)) = hi;
                             *reinterpret_cast<bf16x8*>(a_slot<4>(atile, row, c8 >> 3, 8 + (c8 & 7))) = lo;
                         } else {
-                            tile_put4<1, 4>(atile, row, c8 * 8, x[u][0]);
-                            tile_put4<1, 4>(atile, row, c8 * 8 + 4, x[u][1]);
+                            tile_put4<1, 4>(atile, row, c8 * 8, v0);
+                            tile_put4<1, 4>(atile, row, c8 * 8 + 4, v1);
                         }
                     }
                 }
@@ -841,12 +1027,29 @@ struct OutRole {
                 lds_barrier();
                 SYS_STAMP(3);
                 if (!loader) {
+                    if constexpr (HO) {
+                        // the residual rows were consumed by this layer's QKV stages before any attention row existed: their tags are
+                        // checked all the same (every handed-off word is), and a miss loads them again
+                        const int nrows = p.blocks[b].nrows;
+                        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                        for (unsigned spins = 1;; ++spins) {
+                            unsigned t = 0u;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) tag_acc(t, res[k], par);
+                            if (__all(erow >= nrows || (t & 1u) == 0u)) break;
+                            if (spin_give_up(p, spins, t0)) return;
+                            __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) res[k] = ld_sc1(rx, base + erow * 1024 + (64 * k + ec) * 4);
+                        }
+                    }
                     f32x4 v[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         v[k] = ld4(ct + erow * CLD + 64 * k + ec);
+                        const f32x4 rk = untag4(res[k]);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[k][i] = v[k][i] + ebias[k][i] + res[k][i];
+                        for (int i = 0; i < 4; ++i) v[k][i] = v[k][i] + ebias[k][i] + rk[i];
                     }
                     float mean, rstd;
                     row_stats16(v, mean, rstd);
@@ -854,13 +1057,15 @@ struct OutRole {
                     for (int k = 0; k < 4; ++k) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[k][i] = ln_apply(v[k][i], mean, rstd, egg[k][i], ebb[k][i]);
-                        st_out(st, rout, base + erow * 1024 + (64 * k + ec) * 4, v[k]);
+                        st_out(st, rout, base + erow * 1024 + (64 * k + ec) * 4, v[k], par);
                     }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows have landed
-                    unsigned old = 0u;
-                    if (lane == 0) old = __hip_atomic_fetch_add((lu32*)&ctl->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    old = __builtin_amdgcn_readfirstlane(old);
-                    if ((old & 3u) == 3u) raise(st, flag_of(p, st.out_group, b, st.out_slot), (unsigned)(s + 1));   // the last of the four epilogue waves
+                    if constexpr (!HO) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows have landed
+                        unsigned old = 0u;
+                        if (lane == 0) old = __hip_atomic_fetch_add((lu32*)&ctl->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        old = __builtin_amdgcn_readfirstlane(old);
+                        if ((old & 3u) == 3u) raise(st, flag_of(p, st.out_group, b, st.out_slot), (unsigned)(s + 1));   // the last of the four epilogue waves
+                    }
                     SYS_STAMP(5);
                 }
             }
@@ -869,13 +1074,14 @@ struct OutRole {
 };
 
 // LIN / FFN: hidden slice = act(x W1_slice^T + b1_slice) (128 columns), partial = hidden . W2[:, slice]^T (256 columns)
-template <int MR, int ACT, int AR, int WS>
+template <int MR, int ACT, int AR, int WS, int HO>
 struct MlpRole {
     static constexpr int RT = 16 * MR, NW = 4 * WS, NT1 = 8 / NW, NT2 = 16 / NW;       // hidden / output column tiles per wave
     static constexpr bool PREFETCH = true;
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = true;
-    struct Geo {};
+    static constexpr bool TILE = true;
+    struct Geo { int nrows; };
     struct Pay { Rows256<MR, WS> x; };
     const SysArgs& p; const Stage& st;
     char *atile, *htile; float* ct;
@@ -897,10 +1103,41 @@ struct MlpRole {
         rin = rsrc_of(st.in0); rout = rsrc_of(st.out);
         plane = (unsigned)st.slice * PRING * RT * 1024;
     }
-    __device__ __forceinline__ void geo(int, Geo&) {}
+    __device__ __forceinline__ void geo(int b, Geo& g) { g.nrows = p.blocks[b].nrows; }
     __device__ __forceinline__ void geo_fix(Geo&) {}
+    __device__ __forceinline__ unsigned bad(int s, int, const Geo& g, const Pay& y) const {
+        unsigned t = 0u;
+        rows_bad<MR, WS>(t, y.x, g.nrows, (unsigned)(s & 1));
+        return t;
+    }
     __device__ __forceinline__ void issue(int, int b, const Geo&, Pay& y) { issue_rows<MR, WS>(y.x, rin, (unsigned)b * RT * 1024); }
     __device__ __forceinline__ void commit(const Pay& y) { commit_rows<AR, 4, MR, WS>(atile, 0, y.x); }
+    // tagged hand-off: the same ring rule, read from the consumer's OUTPUT rows - a row of block x that shows the parity of x's
+    // step was stored by a consumer wave that had loaded its partial rows of x before.  One word per row, all rows below nrows
+    // (every wave of the consumer group stores rows of its own).  Needed only when the ring is shorter than a step: a block's next
+    // step waits for its previous one through the tail stage, so no stage is ever more than NB blocks ahead of another.
+    __device__ __forceinline__ bool backpressure_tag(int s, int b) {
+        if (p.NB <= PRING) return true;
+        const int g = s * p.NB + b, lane = threadIdx.x & 63;
+        if (g % (PRING / 2) != 0) return true;
+        const __amdgpu_buffer_rsrc_t rb = rsrc_of(st.bp_buf);
+        for (int i = 0; i < st.bp_blocks; ++i) {
+            const int gx = g - PRING / 2 - i;
+            if (gx < 0) continue;
+            const int sx = gx / p.NB, x = gx - sx * p.NB;
+            const int nrows = p.blocks[x].nrows;
+            const unsigned par = (unsigned)(sx & 1);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (unsigned spins = 1;; ++spins) {
+                unsigned w = par;
+                if (lane < nrows) w = __builtin_amdgcn_raw_buffer_load_b32(rb, ((unsigned)x * RT + lane) * 1024, 0, 16);
+                if (__all(((w ^ par) & 1u) == 0u)) break;
+                if (spin_give_up(p, spins, t0)) return false;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        return true;
+    }
     // the partial planes are rings of PRING slots: block b's slot was block b - PRING's.  Every PRING / 2 blocks: has the
     // consumer (both reduce parts / both block groups of it) finished block b - PRING / 2?  Its stages run in block order, so
     // it has then finished everything the next PRING / 2 blocks of this stage overwrite.
@@ -919,6 +1156,7 @@ struct MlpRole {
     __device__ __forceinline__ void compute(int s, int b, const Geo&, const Pay&, M& mid) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, frow = lane & 15, fk = lane >> 4;
         const unsigned base = (unsigned)((s * p.NB + b) % PRING) * RT * 1024;     // ring slot of this block
+        const unsigned par = HO ? ring_use_par(p, s, b) : 0u;
         f32x4 acc1[MR][NT1];
         zero_acc(acc1);
         mma<AR, 4, NT1, 8, MR>(atile, w1, acc1);
@@ -951,18 +1189,21 @@ struct MlpRole {
 #pragma unroll
         for (int q = 0; q < RT / RPI; ++q) {
             const int row = RPI * q + lane / LPR, cc = CW * wave + 4 * (lane % LPR);
-            st_out(st, rout, plane + base + row * 1024 + cc * 4, ld4(ct + row * CLD + cc));
+            st_out(st, rout, plane + base + row * 1024 + cc * 4, ld4(ct + row * CLD + cc), par);
         }
     }
 };
 
 // RED2: X2 = LN2(X1 + sum_j partial_j + b2) + c[step, layer, sample | pad]
-template <int MR, int WS>
+template <int MR, int WS, int HO>
 struct Red2Role {
     static constexpr int RT = 16 * MR, NW = 4 * WS, PQ = ((MR == 1 ? 8 : 12) + NW - 1) / NW;   // rows per wave: a part has <= 8 (16-row blocks) / <= 11 rows
-    static constexpr bool PREFETCH = true;
+    // tagged hand-off: no operand tile, no barrier - every wave settles, reduces and stores its own rows; nothing to gain from
+    // requesting the next block's partial rows early (they are produced just in time)
+    static constexpr bool PREFETCH = HO == 0;
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = false;
+    static constexpr bool TILE = false;
     struct Geo { int pk[PQ], b2[PQ], row[PQ], t[PQ], cnt[PQ]; };          // slot wave + NW q of this part: raw words, then decoded
     struct Pay { f32x4 pl[PQ][NSLICE], rs[PQ], tv[PQ], tp[PQ]; };
     const SysArgs& p; const Stage& st;
@@ -1010,34 +1251,52 @@ struct Red2Role {
         }
     }
     __device__ __forceinline__ void commit(const Pay&) {}
+    __device__ __forceinline__ unsigned bad(int s, int b, const Geo& g, const Pay& y) const {
+        const unsigned rpar = ring_use_par(p, s, b), spar = (unsigned)(s & 1);
+        unsigned t = 0u;
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+            unsigned tq = 0u;
+#pragma unroll
+            for (int j = 0; j < NSLICE; ++j) tag_acc(tq, y.pl[q][j], rpar);
+            tag_acc(tq, y.rs[q], spar);
+            t |= g.row[q] >= 0 ? tq : 0u;
+        }
+        return t;
+    }
     template <class M>
-    __device__ __forceinline__ void compute(int, int b, const Geo& g, const Pay& y, M& mid) {
+    __device__ __forceinline__ void compute(int s, int b, const Geo& g, Pay& y, M& mid) {
         const int lane = threadIdx.x & 63, c = 4 * lane;
         const unsigned base = (unsigned)b * RT * 1024;
+        const unsigned par = HO ? (unsigned)(s & 1) : 0u;
         mid.before_barrier();
-        __syncthreads();                  // the stage's only barrier: the workgroup agrees on whether the next block is prefetched
+        if constexpr (!HO) __syncthreads();   // the stage's only barrier: the workgroup agrees on whether the next block is prefetched
         mid.after_barrier();
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
             const int row = g.row[q];
             if (row >= 0) {
-                f32x4 v = sum8(y.pl[q]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[i] + y.rs[q][i];
+                for (int j = 0; j < NSLICE; ++j) y.pl[q][j] = untag4(y.pl[q][j]);
+                f32x4 v = sum8(y.pl[q]);
+                const f32x4 rs = untag4(y.rs[q]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[i] + rs[i];
                 float mean, rstd;
                 row_stats4(v, mean, rstd);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i] + y.tv[q][i];
-                st_out(st, rout, base + row * 1024 + c * 4, v);
+                st_out(st, rout, base + row * 1024 + c * 4, v, par);
             }
         }
     }
 };
 
 // STYL: x' = X2 + out( SiLU( LN(sum_j partial_j + b2) * (1 + scale_t) + shift_t ) )
-template <int MR, int AR, int WS>
+template <int MR, int AR, int WS, int HO>
 struct StylRole {
     static constexpr int RT = 16 * MR, NW = 4 * WS, PQ = ((MR == 1 ? 8 : 12) + NW - 1) / NW, NTW = 16 / NW;
+    static constexpr bool TILE = false;                                  // its operand tile is built inside compute(), behind barriers of its own
     // no prefetch image with 32-row blocks (256 weight registers + two images of 27 x 16 bytes per lane do not fit) nor with two
     // waves per SIMD (256 registers per wave: 128 of weights + two images of 11 x 16 bytes spilled; that plan runs STYL as two
     // groups on alternating blocks, which have the slack)
@@ -1086,11 +1345,31 @@ struct StylRole {
         }
     }
     __device__ __forceinline__ void commit(const Pay&) {}
+    __device__ __forceinline__ unsigned bad(int s, int b, const Geo& g, const Pay& y) const {
+        const unsigned rpar = ring_use_par(p, s, b), spar = (unsigned)(s & 1);
+        unsigned t = 0u;
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+            unsigned tq = 0u;
+#pragma unroll
+            for (int j = 0; j < NSLICE; ++j) tag_acc(tq, y.pl[q][j], rpar);
+            tag_acc(tq, y.rs[q], spar);
+            t |= g.row[q] >= 0 ? tq : 0u;
+        }
+        return t;
+    }
     template <class M>
-    __device__ __forceinline__ void compute(int s, int b, const Geo& g, const Pay& y, M& mid) {
+    __device__ __forceinline__ void compute(int s, int b, const Geo& g, Pay& y, M& mid) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
         const unsigned base = (unsigned)b * RT * 1024;
+        const unsigned par = HO ? (unsigned)(s & 1) : 0u;
         const f32x4 scl = y.scl, shf = y.shf;
+#pragma unroll
+        for (int q = 0; q < PQ; ++q) {
+#pragma unroll
+            for (int j = 0; j < NSLICE; ++j) y.pl[q][j] = untag4(y.pl[q][j]);
+            y.rs[q] = untag4(y.rs[q]);
+        }
 #pragma unroll
         for (int q = 0; q < 16 / NW; ++q) {                              // the 16 rows of the operand tile: local row wave + NW q
             const int lr = wave + NW * q;
@@ -1121,20 +1400,21 @@ struct StylRole {
                 f32x4 v = ld4(ct + lr * CLD + c);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[i] + y.rs[q][i];
-                st_out(st, rout, base + row * 1024 + c * 4, v);
+                st_out(st, rout, base + row * 1024 + c * 4, v, par);
             }
         }
     }
 };
 
 // SKIP: half of the 256 output columns of linear_blocks[i](cat(x, skip))
-template <int MR, int AR, int WS>
+template <int MR, int AR, int WS, int HO>
 struct SkipRole {
     static constexpr int RT = 16 * MR, NW = 4 * WS, NTH = 64 * NW, NTW = 8 / NW;      // column tiles per wave of this half's 128 columns
     static constexpr bool PREFETCH = true;
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = false;
-    struct Geo {};
+    static constexpr bool TILE = true;
+    struct Geo { int nrows; };
     struct Pay { Rows256<MR, WS> x, k; };
     const SysArgs& p; const Stage& st;
     char* atile; float* ct;
@@ -1150,17 +1430,24 @@ struct SkipRole {
         rx = rsrc_of(st.in0); rs = rsrc_of(st.in1); rout = rsrc_of(st.out);
         bias = ld4(st.b0 + n0 + (threadIdx.x & 31) * 4);
     }
-    __device__ __forceinline__ void geo(int, Geo&) {}
+    __device__ __forceinline__ void geo(int b, Geo& g) { g.nrows = p.blocks[b].nrows; }
     __device__ __forceinline__ void geo_fix(Geo&) {}
+    __device__ __forceinline__ unsigned bad(int s, int, const Geo& g, const Pay& y) const {
+        unsigned t = 0u;
+        rows_bad<MR, WS>(t, y.x, g.nrows, (unsigned)(s & 1));
+        rows_bad<MR, WS>(t, y.k, g.nrows, (unsigned)(s & 1));
+        return t;
+    }
     __device__ __forceinline__ void issue(int, int b, const Geo&, Pay& y) {
         issue_rows<MR, WS>(y.x, rx, (unsigned)b * RT * 1024);
         issue_rows<MR, WS>(y.k, rs, (unsigned)b * RT * 1024);
     }
     __device__ __forceinline__ void commit(const Pay& y) { commit_rows<AR, 8, MR, WS>(atile, 0, y.x); commit_rows<AR, 8, MR, WS>(atile, 4, y.k); }
     template <class M>
-    __device__ __forceinline__ void compute(int, int b, const Geo&, const Pay&, M& mid) {
+    __device__ __forceinline__ void compute(int s, int b, const Geo&, const Pay&, M& mid) {
         const int tid = threadIdx.x, wave = tid >> 6;
         const unsigned base = (unsigned)b * RT * 1024;
+        const unsigned par = HO ? (unsigned)(s & 1) : 0u;
         f32x4 acc[MR][NTW];
         zero_acc(acc);
         mma<AR, 8, NTW, 16, MR>(atile, wf, acc);
@@ -1174,7 +1461,7 @@ struct SkipRole {
             f32x4 v = ld4(ct + row * CLD + cc);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] += bias[i];
-            st_out(st, rout, base + row * 1024 + cc * 4, v);
+            st_out(st, rout, base + row * 1024 + cc * 4, v, par);
         }
     }
 };
@@ -1183,7 +1470,7 @@ struct SkipRole {
 // A tail works on UNITS: unit u = block u when a block holds both guidance branches (32-row tiles: unconditional rows first,
 // the conditional row of (prompt, t) nrows / 2 further), or blocks 2u (unconditional) and 2u + 1 (conditional, same row) when
 // blocks hold one branch (16-row tiles).  Tail workgroup k owns the units u = k (mod NTAIL).
-template <int MR, int WS>
+template <int MR, int WS, int HO>
 struct TailRole {
     static constexpr int RT = 16 * MR, NW = 4 * WS, NQ = 16 / NW;        // (prompt, latent) pairs per wave: <= 16 per unit
     struct Geo { int lat[NQ], t[NQ], rc[NQ]; };                         // latent row, position, conditional-branch row of pair q
@@ -1226,11 +1513,21 @@ struct TailRole {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) xn[i] = l[i] + pe[i];
                     }
-                    st_out(st, rout, base + q * 1024 + c * 4, xn);
+                    st_out(st, rout, base + q * 1024 + c * 4, xn, 0u);    // the input of local step 0: parity 0
                 }
             }
-            publish_unit(u, 1);
+            if constexpr (!HO) publish_unit(u, 1);
         }
+    }
+    __device__ __forceinline__ unsigned bad(int s, const Geo& g, const Pay& y) const {
+        unsigned t = 0u;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            unsigned ti = 0u;
+            tag_acc(ti, y.eu[i], (unsigned)(s & 1)); tag_acc(ti, y.ec[i], (unsigned)(s & 1));
+            t |= g.lat[i] >= 0 ? ti : 0u;
+        }
+        return t;
     }
     __device__ __forceinline__ void geo(int u, Geo& g) {
         const int wave = threadIdx.x >> 6;
@@ -1265,7 +1562,7 @@ struct TailRole {
         for (int i = 0; i < NQ; ++i) {
             const int q = wave + NW * i;
             if (g.lat[i] >= 0) {
-                f32x4 eu = y.eu[i], ec = y.ec[i], l = y.lt[i], xn;
+                f32x4 eu = untag4(y.eu[i]), ec = untag4(y.ec[i]), l = y.lt[i], xn;
                 float mean, rstd;
                 row_stats4(eu, mean, rstd);
 #pragma unroll
@@ -1281,8 +1578,9 @@ struct TailRole {
                     xn[k] = l[k] + y.pe[i][k];
                 }
                 st4(p.lat + (size_t)g.lat[i] * D + c, l);
-                st_out(st, rout, bu + q * 1024 + c * 4, xn);               // after the last step nobody reads it
-                st_out(st, rout, bc + g.rc[i] * 1024 + c * 4, xn);
+                const unsigned par = HO ? (unsigned)((s + 1) & 1) : 0u;     // the input of the NEXT local step
+                st_out(st, rout, bu + q * 1024 + c * 4, xn, par);          // after the last step nobody reads it
+                st_out(st, rout, bc + g.rc[i] * 1024 + c * 4, xn, par);
             }
         }
     }
@@ -1293,9 +1591,9 @@ struct TailRole {
 // units in between, so a prefetch never overtakes the update it depends on as long as a tail owns more than one unit; with
 // one unit it does not prefetch.
 template <int MR, int WS>
-__device__ __forceinline__ void tail_loop(const SysArgs& p, const Stage& st, TailRole<MR, WS>& r, Ctl* ctl) {
-    typename TailRole<MR, WS>::Pay cur, nxt;
-    typename TailRole<MR, WS>::Geo gcur, gnxt;
+__device__ __forceinline__ void tail_loop(const SysArgs& p, const Stage& st, TailRole<MR, WS, 0>& r, Ctl* ctl) {
+    typename TailRole<MR, WS, 0>::Pay cur, nxt;
+    typename TailRole<MR, WS, 0>::Geo gcur, gnxt;
     bool have = false;
     const int lane = threadIdx.x & 63, u0 = st.slice;
     const int nu = p.split ? p.NB / 2 : p.NB;
@@ -1306,7 +1604,7 @@ __device__ __forceinline__ void tail_loop(const SysArgs& p, const Stage& st, Tai
         return (const gu32*)flag_of(p, st.wait_group, b, 0) + (lane < st.wait_n ? lane : lane - st.wait_n) * FLAG_STRIDE;
     };
     r.prime(nu);
-    typename TailRole<MR, WS>::Geo gnn;
+    typename TailRole<MR, WS, 0>::Geo gnn;
     if (u0 < nu) { r.geo(u0, gcur); r.geo(u0 + NTAIL < nu ? u0 + NTAIL : u0, gnxt); gnn = gnxt; }
     for (int s = 0; s < p.n_steps; ++s)
         for (int u = u0; u < nu; u += NTAIL) {
@@ -1355,11 +1653,44 @@ __device__ __forceinline__ void tail_loop(const SysArgs& p, const Stage& st, Tai
         }
 }
 
+// Tagged hand-off: no barrier and no flag - every wave owns the (prompt, latent) pairs `wave + NW i` of its units, settles on the
+// two rows of each pair, updates the latents and stores the next step's input rows with the next step's parity.
+template <int MR, int WS>
+__device__ __forceinline__ void tail_loop_tag(const SysArgs& p, const Stage& st, TailRole<MR, WS, 1>& r) {
+    typename TailRole<MR, WS, 1>::Pay cur;
+    typename TailRole<MR, WS, 1>::Geo gcur, gnxt, gnn;
+    const int u0 = st.slice;
+    const int nu = p.split ? p.NB / 2 : p.NB;
+    r.prime(nu);
+    if (u0 < nu) { r.geo(u0, gcur); r.geo(u0 + NTAIL < nu ? u0 + NTAIL : u0, gnxt); gnn = gnxt; }
+    for (int s = 0; s < p.n_steps; ++s)
+        for (int u = u0; u < nu; u += NTAIL) {
+            r.issue(s, u, gcur, cur);
+            int s2 = s, u2 = u + NTAIL;
+            if (u2 >= nu) { s2 = s + 1; u2 = u0; }
+            int s3 = s2, u3 = u2 + NTAIL;
+            if (u3 >= nu) { s3 = s2 + 1; u3 = u0; }
+            if (s3 < p.n_steps) r.geo(u3, gnn);                          // geometry two units ahead
+            if (!__all((r.bad(s, gcur, cur) & 1u) == 0u)) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                for (unsigned spins = 1;; ++spins) {
+                    __builtin_amdgcn_s_sleep(1);
+                    r.issue(s, u, gcur, cur);
+                    if (__all((r.bad(s, gcur, cur) & 1u) == 0u)) break;
+                    if (spin_give_up(p, spins, t0)) return;
+                }
+            }
+            r.compute(s, u, gcur, cur);
+            gcur = gnxt; gnxt = gnn;
+        }
+}
+
 }  // namespace
 
 // WS = waves per SIMD of a stage workgroup: 1 = 256 threads (32-row blocks: 256 weight registers + two row tiles of everything else
 // per wave), 2 = 512 threads with the stage's weight slice split over the two waves of a SIMD (16-row blocks)
-template <int MR, int AR, int WS>
+// HO = hand-off protocol: 0 = flags (drain, barrier, epoch word, poll), 1 = parity tags in the data (see tag4)
+template <int MR, int AR, int WS, int HO>
 __global__ __launch_bounds__(256 * WS, 1) void systolic_loop_kernel(const SysArgs p) {
     static_assert(WS == 1 || MR == 1, "two waves per SIMD: 16-row blocks only (the reduce parts' slot tables hold 12 slots: wave + 8 q needs q < 1)");
     // all LDS is dynamic (a static variable would shift the dynamic base off its 16-byte alignment, cdna_hip_programming.md G17)
@@ -1413,25 +1744,34 @@ __global__ __launch_bounds__(256 * WS, 1) void systolic_loop_kernel(const SysArg
             1ull | (unsigned long long)st.role << 8 | (unsigned long long)st.layer << 16 | (unsigned long long)st.slice << 24 |
             (unsigned long long)st.blk0 << 32 | (unsigned long long)(st.out_local & 1) << 40 | (unsigned long long)(st.xcd & 0xff) << 48;
 #endif
+    auto run = [&](auto& r) {
+        if constexpr (HO) tag_loop(p, st, r, st.blk0, st.blkstride);
+        else stage_loop(p, st, r, ctl, st.blk0, st.blkstride);
+    };
     switch (st.role) {
         case R_QKV: {
-            QkvRole<MR, AR, WS> r(p, st, lds);
+            QkvRole<MR, AR, WS, HO> r(p, st, lds);
             if constexpr (WS == 2) r.split_loop(ctl);
-            else stage_loop(p, st, r, ctl, st.blk0, st.blkstride);
+            else run(r);
             break;
         }
         case R_OUT: {
-            OutRole<MR, AR, WS> r(p, st, lds);
+            OutRole<MR, AR, WS, HO> r(p, st, lds);
             if constexpr (WS == 2) r.split_loop(ctl);
-            else stage_loop(p, st, r, ctl, st.blk0, st.blkstride);
+            else run(r);
             break;
         }
-        case R_LIN: { MlpRole<MR, ACT_RELU, AR, WS> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
-        case R_RED2: { Red2Role<MR, WS> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
-        case R_FFN: { MlpRole<MR, ACT_GELU, AR, WS> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
-        case R_STYL: { StylRole<MR, AR, WS> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
-        case R_SKIP: { SkipRole<MR, AR, WS> r(p, st, lds); stage_loop(p, st, r, ctl, st.blk0, st.blkstride); break; }
-        case R_TAIL: { TailRole<MR, WS> r(p, st, lds); tail_loop(p, st, r, ctl); break; }
+        case R_LIN: { MlpRole<MR, ACT_RELU, AR, WS, HO> r(p, st, lds); run(r); break; }
+        case R_RED2: { Red2Role<MR, WS, HO> r(p, st, lds); run(r); break; }
+        case R_FFN: { MlpRole<MR, ACT_GELU, AR, WS, HO> r(p, st, lds); run(r); break; }
+        case R_STYL: { StylRole<MR, AR, WS, HO> r(p, st, lds); run(r); break; }
+        case R_SKIP: { SkipRole<MR, AR, WS, HO> r(p, st, lds); run(r); break; }
+        case R_TAIL: {
+            TailRole<MR, WS, HO> r(p, st, lds);
+            if constexpr (HO) tail_loop_tag(p, st, r);
+            else tail_loop(p, st, r, ctl);
+            break;
+        }
         default: break;
     }
 }
@@ -1690,7 +2030,7 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR,
             Stage s{};
             s.role = R_LIN; s.layer = l; s.slice = j; s.wait_group = G(l, G_X1); s.wait_n = 1; s.out_group = G(l, G_PC); s.out_slot = j;
             s.wait_slot0 = j;
-            s.bp_group = G(l, G_X2); s.bp_slot0 = x2_rep ? j * rp.red2_parts : 0; s.bp_n = rp.red2_parts; s.bp_blocks = 1;
+            s.bp_group = G(l, G_X2); s.bp_slot0 = x2_rep ? j * rp.red2_parts : 0; s.bp_n = rp.red2_parts; s.bp_blocks = 1; s.bp_buf = x2;
             s.w0 = ws_.sa_lin1.w; s.w1 = ws_.sa_lin2.w; s.b0 = w.sa_lin1.b; s.in0 = x1; s.out = pc;
             st.push_back(s);
         }
@@ -1705,7 +2045,7 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR,
             Stage s{};
             s.role = R_FFN; s.layer = l; s.slice = j; s.wait_group = G(l, G_X2); s.wait_n = rp.red2_parts; s.out_group = G(l, G_PE); s.out_slot = j;
             if (x2_rep) s.wait_slot0 = j * rp.red2_parts;
-            s.bp_group = G(l, G_XO); s.bp_slot0 = 0; s.bp_n = rp.styl_parts; s.bp_blocks = rp.styl_groups;
+            s.bp_group = G(l, G_XO); s.bp_slot0 = 0; s.bp_n = rp.styl_parts; s.bp_blocks = rp.styl_groups; s.bp_buf = XO(l);
             s.w0 = ws_.ffn1.w; s.w1 = ws_.ffn2.w; s.b0 = w.ffn1.b; s.in0 = x2; s.out = pe;
             st.push_back(s);
         }
@@ -1741,6 +2081,8 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR,
 // the workspace (sys_upload_stages); `ctab` holds the hoisted cross-attention rows of n_ctab >= n steps starting at step_lo.
 // waves per SIMD of the 16-row plan's stage workgroups (measurement switch: ladiff_debug_set_stage_waves)
 int g_waves16 = 2;
+// hand-off protocol of the 16-row plan's eight-wave stages: 1 = parity tags in the data (default), 0 = flags (ladiff_debug_set_handoff)
+int g_handoff = 1;
 // test aids (ladiff_debug_set_pipeline_fault): a workgroup that never publishes, and the bound of a wait in s_memrealtime ticks (0: default)
 int g_fault_wg = -1;
 unsigned long long g_timeout_ticks = 0;
@@ -1782,10 +2124,11 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     if (dev < 0 || dev >= 64) return LADIFF_ERR_ARG;
     std::lock_guard<std::mutex> lock(mu);
     if (!attr_set[dev]) {
-        const void* k[6] = {reinterpret_cast<const void*>(systolic_loop_kernel<1, 0, 2>), reinterpret_cast<const void*>(systolic_loop_kernel<2, 0, 1>),
-                            reinterpret_cast<const void*>(systolic_loop_kernel<1, 1, 2>), reinterpret_cast<const void*>(systolic_loop_kernel<2, 1, 1>),
-                            reinterpret_cast<const void*>(systolic_loop_kernel<1, 0, 1>), reinterpret_cast<const void*>(systolic_loop_kernel<1, 1, 1>)};
-        for (int i = 0; i < 6; ++i) LADIFF_HIP(hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, SYS_LDS_BYTES));
+        const void* k[8] = {reinterpret_cast<const void*>(systolic_loop_kernel<1, 0, 2, 0>), reinterpret_cast<const void*>(systolic_loop_kernel<2, 0, 1, 0>),
+                            reinterpret_cast<const void*>(systolic_loop_kernel<1, 1, 2, 0>), reinterpret_cast<const void*>(systolic_loop_kernel<2, 1, 1, 0>),
+                            reinterpret_cast<const void*>(systolic_loop_kernel<1, 0, 1, 0>), reinterpret_cast<const void*>(systolic_loop_kernel<1, 1, 1, 0>),
+                            reinterpret_cast<const void*>(systolic_loop_kernel<1, 0, 2, 1>), reinterpret_cast<const void*>(systolic_loop_kernel<1, 1, 2, 1>)};
+        for (int i = 0; i < 8; ++i) LADIFF_HIP(hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, SYS_LDS_BYTES));
         attr_set[dev] = true;
     }
     if (done[dev] == nullptr) LADIFF_HIP(hipEventCreateWithFlags(&done[dev], hipEventDisableTiming));
@@ -1794,15 +2137,23 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     // ladiff_diffusion_reverse call (sys_reset_status): a schedule longer than one window is several launches, and an abort in an
     // early window must neither be erased by the next launch's memset nor let the later windows iterate on corrupt latents.
     LADIFF_HIP(hipMemsetAsync(a.status + 8, 0, 2 * sizeof(unsigned), s));
-    LADIFF_HIP(hipMemsetAsync(a.flags, 0, (L.off_xin0 - L.off_flags) * sizeof(float), s));
-    if (fp32) {
-        if (MR == 1 && g_waves16 == 2) hipLaunchKernelGGL((systolic_loop_kernel<1, 1, 2>), dim3(L.nwg), dim3(512), SYS_LDS_BYTES, s, a);
-        else if (MR == 1) hipLaunchKernelGGL((systolic_loop_kernel<1, 1, 1>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
-        else hipLaunchKernelGGL((systolic_loop_kernel<2, 1, 1>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
+    const bool tagged = MR == 1 && g_waves16 == 2 && g_handoff == 1;
+    if (tagged) {
+        // tagged hand-off: every word of the hand-off buffers starts with parity 1 (the first use of every slot expects 0)
+        LADIFF_HIP(hipMemsetAsync(ws + L.off_xin0, 0x01, (L.total - L.off_xin0) * sizeof(float), s));
     } else {
-        if (MR == 1 && g_waves16 == 2) hipLaunchKernelGGL((systolic_loop_kernel<1, 0, 2>), dim3(L.nwg), dim3(512), SYS_LDS_BYTES, s, a);
-        else if (MR == 1) hipLaunchKernelGGL((systolic_loop_kernel<1, 0, 1>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
-        else hipLaunchKernelGGL((systolic_loop_kernel<2, 0, 1>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
+        LADIFF_HIP(hipMemsetAsync(a.flags, 0, (L.off_xin0 - L.off_flags) * sizeof(float), s));
+    }
+    if (fp32) {
+        if (tagged) hipLaunchKernelGGL((systolic_loop_kernel<1, 1, 2, 1>), dim3(L.nwg), dim3(512), SYS_LDS_BYTES, s, a);
+        else if (MR == 1 && g_waves16 == 2) hipLaunchKernelGGL((systolic_loop_kernel<1, 1, 2, 0>), dim3(L.nwg), dim3(512), SYS_LDS_BYTES, s, a);
+        else if (MR == 1) hipLaunchKernelGGL((systolic_loop_kernel<1, 1, 1, 0>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
+        else hipLaunchKernelGGL((systolic_loop_kernel<2, 1, 1, 0>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
+    } else {
+        if (tagged) hipLaunchKernelGGL((systolic_loop_kernel<1, 0, 2, 1>), dim3(L.nwg), dim3(512), SYS_LDS_BYTES, s, a);
+        else if (MR == 1 && g_waves16 == 2) hipLaunchKernelGGL((systolic_loop_kernel<1, 0, 2, 0>), dim3(L.nwg), dim3(512), SYS_LDS_BYTES, s, a);
+        else if (MR == 1) hipLaunchKernelGGL((systolic_loop_kernel<1, 0, 1, 0>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
+        else hipLaunchKernelGGL((systolic_loop_kernel<2, 0, 1, 0>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
     }
     LADIFF_LAUNCH_CHECK();
     LADIFF_HIP(hipEventRecord(done[dev], s));
