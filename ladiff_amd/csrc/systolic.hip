@@ -99,11 +99,16 @@ struct BlockDesc {
     int row_pk[32], row_b2[32];
     int row_lat[32], row_t[32];           // latents row (prompt * T + t, -1: padding) and latent index of a tile row
     // reduce stages: part q of NRED handles slot k = wave + 4 i -> tile row | latent index << 8 | latent count << 16 (0xff: run
-    // time), -1: no row; and the row's cross-attention table row
+    // time), -1: no row; and the row's cross-attention table row.  The parts cover ALL rows of the tile: a row past nrows
+    // (PART_PAD | row) is stored as zeros - under the tagged hand-off every row of a tile carries the step's parity, so that a
+    // consumer checks whole tiles and needs no geometry.
     int part_pk[3][12], part_b2[3][12];
-    // tail: (prompt, latent) pair k = wave + 4 i -> latents row (-1: none), latent index, tile row of the conditional branch
-    int pair_lat[16], pair_t[16], pair_rc[16];
+    // tail: (prompt, latent) pair k = wave + 4 i -> latents row (-1: none), latent index, tile row of the conditional branch.
+    // A slot without a pair zeroes two padding rows instead: row pair_pad of the unconditional block and row pair_rc of the
+    // conditional one (-1: nothing left to pad)
+    int pair_lat[16], pair_t[16], pair_rc[16], pair_pad[16];
 };
+constexpr int PART_PAD = 0x40000000;
 static_assert(NRED == 3, "BlockDesc::part_pk");
 // How the reduce workgroups of a layer share a block's rows.  32-row blocks: NRED row parts each (<= 11 rows, 3 per wave).
 // 16-row blocks: a part can take 8 rows (2 per wave), so RED2 needs only two workgroups and the freed one goes to STYL, the
@@ -128,6 +133,7 @@ struct SysArgs {
     int split;                            // 1: a block holds ONE guidance branch of its P prompts (block 2g + br), 0: both
     int fault_wg;                         // test aid: this workgroup leaves right after the start-up handshake and never publishes (-1: none)
     unsigned long long timeout_ticks;     // bound of every spin, in s_memrealtime ticks (100 MHz)
+    int look_ahead;                       // tagged hand-off: stages may request the next block's rows early (see `settle`)
     unsigned long long* stamps;           // diagnostic twin build only (-DLADIFF_STAMPS): [workgroup][step][block][8] realtime ticks
 };
 
@@ -226,11 +232,19 @@ __device__ __forceinline__ void tag_acc(unsigned& bad, const f32x4 v, unsigned p
 __device__ __forceinline__ unsigned ring_use_par(const SysArgs& p, int s, int b) { return (unsigned)(((s * p.NB + b) / PRING) & 1); }
 
 // a stage's output rows: plain when every reader shares this XCD's L2, write-through otherwise; par = the parity tag (0 under
-// the flag protocol)
+// the flag protocol).  HO as the roles' template argument: 0 = flag protocol (the store form is picked at run time), 1 / 2 = tagged
+// hand-off with write-through / plain stores - there the form is a compile-time property of the role's loop, so that the loop
+// body is straight-line code and the compiler can COUNT the stores behind the next block's loads (`s_waitcnt vmcnt(n)`) instead of
+// draining them (`vmcnt(0)`) where those loads are first used.
+template <int HO>
 __device__ __forceinline__ void st_out(const Stage& st, __amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v, unsigned par) {
     v = tag4(v, par);
-    if (st.out_local) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
-    else st_sc1(r, off, v);
+    if constexpr (HO == 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+    else if constexpr (HO == 1) st_sc1(r, off, v);
+    else {
+        if (st.out_local) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+        else st_sc1(r, off, v);
+    }
 }
 
 constexpr unsigned long long TIMEOUT_TICKS = 150000000ull;     // default bound of a wait: s_memrealtime runs at 100 MHz, 1.5 s (SysArgs::timeout_ticks)
@@ -320,16 +334,11 @@ __device__ __forceinline__ void commit_rows(char* tile, int kb0, const Rows256<M
         }
     }
 }
-// tagged hand-off: does every word of the rows below `nrows` (rows from there on are never written) show parity `par`?
+// tagged hand-off: does every word of the tile show parity `par`?  (every row of a tile is written, padding rows as zeros)
 template <int MR, int WS>
-__device__ __forceinline__ void rows_bad(unsigned& bad, const Rows256<MR, WS>& x, int nrows, unsigned par) {
+__device__ __forceinline__ void rows_bad(unsigned& bad, const Rows256<MR, WS>& x, unsigned par) {
 #pragma unroll
-    for (int u = 0; u < 2 * MR / WS; ++u) {
-        const int row = (threadIdx.x + 256 * WS * u) >> 5;
-        unsigned t = 0u;
-        tag_acc(t, x.v[u][0], par); tag_acc(t, x.v[u][1], par);
-        bad |= row < nrows ? t : 0u;
-    }
+    for (int u = 0; u < 2 * MR / WS; ++u) { tag_acc(bad, x.v[u][0], par); tag_acc(bad, x.v[u][1], par); }
 }
 
 // LayerNorm statistics of a 256-column row, two-pass, fp32 (as rowops.hip).  The per-lane parts are shared by the two layouts
@@ -398,6 +407,7 @@ struct Mid {
             }
         }
     }
+    __device__ __forceinline__ void before_stores() {}
     __device__ __forceinline__ void after_barrier() {
         if (pending != nullptr) {
             if (threadIdx.x < 64) raise(st, pending, pending_epoch);
@@ -508,66 +518,98 @@ __device__ __forceinline__ bool spin_give_up(const SysArgs& p, unsigned spins, u
     }
     return false;
 }
-// `issued`: the loads of (s, b) are already in flight (requested during the previous block's compute).  ONE copy of the load and
-// check code in the loop (two - one in front of the loop, one inside - kept both sets of addresses alive and spilled weights)
+// Roles that request a block's rows ahead (R::PREFETCH): the rows of the NEXT block are requested at the start of this block's
+// compute phase (the operand tile is committed, the row registers are free) and their tags are looked at for the first time just
+// BEFORE this block's output stores (MidTag::before_stores): at that point the wave has no store in flight, so the wait for the
+// loads is exact whatever the compiler makes of it (merged with other paths it waits `vmcnt(0)`; behind the stores that would be
+// the drain this protocol exists to avoid).  Rows that were not there yet are loaded again when the block's turn comes (settle).
+// The other roles (STYL: 256 registers, no second image) load inside the loop: ONE copy of the load and check code (two - one in
+// front of the loop, one inside - kept both address sets alive and spilled weights).
+// Polling policy (measured, profiles/r4: scripts/handoff_knobs.py; loop kernel at 64 / 128 / 128 mixed-length / 256 prompts):
+//   * a poll IS the load of the rows (16 bytes per lane, every word checked); a wave polls back to back, one poll in flight.
+//     A separate sentinel word per producer wave in front of the 9-KiB row loads of the fan-in stages cost one more round trip
+//     per hop and lost everywhere (8.22 / 10.57 / 8.64 / 21.6 ms against 7.82 / 10.47 / 8.06 / 20.7), and so did a pause
+//     between polls (10.47 against 10.38 at 128 prompts);
+//   * a stage with a second row image (R::PREFETCH) may request the NEXT block's rows when this block's operand tile is complete
+//     and look at their tags just before this block's stores - at that point the wave has no store in flight, so the wait for
+//     those loads is exact whatever the compiler makes of it (`vmcnt(0)`; behind the stores that would be the drain this
+//     protocol exists to avoid).  That pays when rows queue up in front of the stage (128 prompts and more: 10.38 against 11.11
+//     ms) and costs when they arrive just in time (the speculative load misses, and the look at it stands in front of this
+//     block's stores: 64 prompts 7.84 against 7.40 ms, mixed lengths 8.06 against 7.64) - so it is ADAPTIVE: the next block's
+//     rows are requested early exactly when this block's rows were complete at the first look (10.20 ms at 128 prompts, 20.3 at
+//     256), and only in launches with enough blocks to queue at all (SysArgs::look_ahead: from LOOK_AHEAD_BLOCKS up; below, one
+//     block's trip through the stages bounds the step and a stage that looks ahead after a lucky hit loses: 7.62 against 7.40);
+//   * requesting the rows a second time behind the stores after a miss lost everywhere (more load traffic: 11.17 ms at 128).
 template <class R>
-__device__ __forceinline__ bool settle(const SysArgs& p, R& r, int s, int b, const typename R::Geo& g, typename R::Pay& y, bool issued) {
+__device__ __forceinline__ bool settle(const SysArgs& p, R& r, int s, int b, const typename R::Geo& g, typename R::Pay& y, bool issued,
+                                       bool& first_look) {
+    first_look = false;
     unsigned long long t0 = 0ull;
     for (unsigned spins = 0;; ++spins) {
         if (spins != 0u || !issued) r.issue(s, b, g, y);
-        if (__all((r.bad(s, b, g, y) & 1u) == 0u)) return true;
+        if (__all((r.bad(s, b, g, y) & 1u) == 0u)) { first_look = spins == 0u; return true; }
         if (spins == 0u) t0 = __builtin_amdgcn_s_memrealtime();
         else if (spin_give_up(p, spins, t0)) return false;
-        __builtin_amdgcn_s_sleep(1);
     }
 }
 template <class R>
 struct MidTag {
     const SysArgs& p; R& r; typename R::Pay& nxt; typename R::Geo& gnxt; typename R::Geo& gnn;
-    bool has_next; int s2, b2, s3, b3;
+    int s2, b2, s3, b3;
+    bool ahead;                           // in: request the next block's rows during this block's compute phase
+    bool settled;                         // out: every word of the next block's rows already shows its parity (this wave's words)
+    __device__ __forceinline__ void start() {                            // behind the barrier that completes the operand tile
+        if constexpr (R::PREFETCH) { r.geo_fix(gnxt); if (ahead) r.issue(s2, b2, gnxt, nxt); }
+    }
     __device__ __forceinline__ void before_barrier() {}
     __device__ __forceinline__ void after_barrier() {
-        // geometry words are fetched two blocks ahead (as stage_loop); the next block's rows are requested now, valid or not
-        r.geo_fix(gnxt);
-        if constexpr (R::PREFETCH) { if (has_next) r.issue(s2, b2, gnxt, nxt); }
+        // geometry words are fetched two blocks ahead (as stage_loop)
+        if constexpr (!R::PREFETCH) r.geo_fix(gnxt);
         if (s3 < p.n_steps) r.geo(b3, gnn);
+    }
+    __device__ __forceinline__ void before_stores() {
+        if constexpr (R::PREFETCH) { if (ahead) settled = __all((r.bad(s2, b2, gnxt, nxt) & 1u) == 0u); }
     }
 };
 template <class R>
 __device__ __forceinline__ void tag_loop(const SysArgs& p, const Stage& st, R& r, int b0, int bstride) {
     typename R::Pay cur, nxt;
     typename R::Geo gcur, gnxt, gnn;
-    bool have = false;
-    if (b0 < p.NB) {
-        r.geo(b0, gcur);
-        r.geo(b0 + bstride < p.NB ? b0 + bstride : b0, gnxt);
-        r.geo_fix(gcur);
-        gnn = gnxt;
-    }
+    if (b0 >= p.NB || p.n_steps < 1) return;
+    r.geo(b0, gcur);
+    r.geo(b0 + bstride < p.NB ? b0 + bstride : b0, gnxt);
+    r.geo_fix(gcur);
+    gnn = gnxt;
+    bool settled = false, issued = false, ahead = false;
     SYS_STAT_DECL;
     for (int s = 0; s < p.n_steps; ++s)
         for (int b = b0; b < p.NB; b += bstride) {
             SYS_STAMP(0);
-            SYS_STAT_ITER(have);
+            SYS_STAT_ITER(settled);
             if constexpr (R::BACKP) { if (!r.backpressure_tag(s, b)) return; }
             SYS_STAT_T0;
-            if (!settle(p, r, s, b, gcur, cur, have)) return;
+            if (!settled) {
+                bool first = false;
+                if (!settle(p, r, s, b, gcur, cur, issued, first)) return;
+                ahead = first && p.look_ahead != 0;                      // rows were waiting: the stage is behind - look ahead
+            }
             SYS_STAT_WAIT;
             SYS_STAMP(1);
             int s2 = s, b2 = b + bstride;
             if (b2 >= p.NB) { s2 = s + 1; b2 = b0; }
             int s3 = s2, b3 = b2 + bstride;
             if (b3 >= p.NB) { s3 = s2 + 1; b3 = b0; }
-            const bool has_next = s2 < p.n_steps;
+            const bool has_next = s2 < p.n_steps;                       // behind the last block: that block again (never used)
             r.commit(cur);
             if constexpr (R::TILE) __syncthreads();                     // the operand tile is complete (roles without one: no barrier)
             SYS_STAMP(2);
-            MidTag<R> mid{p, r, nxt, gnxt, gnn, has_next, s2, b2, s3, b3};
+            MidTag<R> mid{p, r, nxt, gnxt, gnn, has_next ? s2 : s, has_next ? b2 : b, s3, b3, R::PREFETCH && ahead, false};
+            mid.start();
             r.compute(s, b, gcur, cur, mid);
-            have = R::PREFETCH && has_next;
+            settled = mid.settled; issued = mid.ahead;
             gcur = gnxt; gnxt = gnn;
             SYS_STAMP(4);
-            if constexpr (R::PREFETCH) { if (have) cur = nxt; }
+            if constexpr (R::PREFETCH) { if (issued) cur = nxt; }
             SYS_STAMP(5);
         }
     SYS_STAT_END;
@@ -587,7 +629,7 @@ struct QkvRole {
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = false;
     static constexpr bool TILE = true;
-    struct Geo { int gw, rb2, b2[NX], nrows; };                          // descriptor word `tid` (+ its row's sample-branch); sample-branch of this thread's text slots; live rows
+    struct Geo { int gw, rb2, b2[NX]; };                                 // descriptor word `tid` (+ its row's sample-branch); sample-branch of this thread's text slots
     struct Pay { Rows256<MR, WS> x; f32x4 xk[NX]; };
     const SysArgs& p; const Stage& st;
     char* atile; float *qt, *xt; int* gd;
@@ -628,11 +670,10 @@ struct QkvRole {
         const int* src = tid == 0 ? &d->nrows : &d->row_pk[tid <= RT ? tid - 1 : 0];
         g.gw = *src;
         g.rb2 = d->row_b2[tid >= 1 && tid <= RT ? tid - 1 : 0];
-        g.nrows = d->nrows;
     }
-    __device__ __forceinline__ unsigned bad(int s, int, const Geo& g, const Pay& y) const {
+    __device__ __forceinline__ unsigned bad(int s, int, const Geo&, const Pay& y) const {
         unsigned t = 0u;
-        rows_bad<MR, WS>(t, y.x, g.nrows, (unsigned)(s & 1));
+        rows_bad<MR, WS>(t, y.x, (unsigned)(s & 1));
         return t;
     }
     __device__ __forceinline__ void geo_fix(Geo& g) {                    // a latent count that lives on the device only (0xff)
@@ -698,6 +739,7 @@ struct QkvRole {
         SYS_STAMP(6);
         // the shipped models have T = 5 latent tokens (7 keys): the loops are unrolled over the keys, so the bound is compile time
         const unsigned par = HO ? (unsigned)(s & 1) : 0u;
+        mid.before_stores();
         if (T <= 5) attention<7>(b, par); else attention<TK>(b, par);
     }
     // ---- two waves per SIMD: the role runs as TWO WAVE GROUPS instead of the generic stage loop.  Waves 4-7 ("loaders") wait for
@@ -748,17 +790,12 @@ struct QkvRole {
                     };
                     load_x();
                     if constexpr (HO) {              // tagged hand-off: the rows are loaded until every word shows this step's parity
-                        const int nrows = d->nrows;
                         const unsigned par = (unsigned)(s & 1);
                         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                         for (unsigned spins = 1;; ++spins) {
                             unsigned t = 0u;
 #pragma unroll
-                            for (int u = 0; u < 2; ++u) {
-                                unsigned tu = 0u;
-                                tag_acc(tu, x[u][0], par); tag_acc(tu, x[u][1], par);
-                                t |= ((tl + 256 * u) >> 5) < nrows ? tu : 0u;
-                            }
+                            for (int u = 0; u < 2; ++u) { tag_acc(t, x[u][0], par); tag_acc(t, x[u][1], par); }
                             if (__all((t & 1u) == 0u)) break;
                             if (spin_give_up(p, spins, t0)) return;
                             __builtin_amdgcn_s_sleep(1);
@@ -872,7 +909,7 @@ struct QkvRole {
                 o[0] = fmaf(pj, v4[j][0], o[0]); o[1] = fmaf(pj, v4[j][1], o[1]); o[2] = fmaf(pj, v4[j][2], o[2]); o[3] = fmaf(pj, v4[j][3], o[3]);
             }
             if (!live) o = f32x4{0.f, 0.f, 0.f, 0.f};
-            st_out(st, rout, ((unsigned)b * RT + row) * 1024 + (h * 64 + c4) * 4, o, par);
+            st_out<HO>(st, rout, ((unsigned)b * RT + row) * 1024 + (h * 64 + c4) * 4, o, par);
         }
     }
 };
@@ -885,7 +922,7 @@ struct OutRole {
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = false;
     static constexpr bool TILE = true;
-    struct Geo { int nrows; };
+    struct Geo {};
     struct Pay { Rows256<MR, WS> att; f32x4 res[RPW]; };
     const SysArgs& p; const Stage& st;
     char* atile; float* ct;
@@ -899,15 +936,13 @@ struct OutRole {
         bias = ld4(st.b0 + 4 * lane); gg = ld4(st.g + 4 * lane); bb = ld4(st.be + 4 * lane);
         ratt = rsrc_of(st.in0); rx = rsrc_of(st.in1); rout = rsrc_of(st.out);
     }
-    __device__ __forceinline__ void geo(int b, Geo& g) { g.nrows = p.blocks[b].nrows; }
+    __device__ __forceinline__ void geo(int, Geo&) {}
     __device__ __forceinline__ void geo_fix(Geo&) {}
-    // attention rows: every row of the tile is written (dead rows as zeros); the residual rows only below nrows
-    __device__ __forceinline__ unsigned bad(int s, int, const Geo& g, const Pay& y) const {
-        const int wave = threadIdx.x >> 6;
+    __device__ __forceinline__ unsigned bad(int s, int, const Geo&, const Pay& y) const {
         unsigned t = 0u;
-        rows_bad<MR, WS>(t, y.att, RT, (unsigned)(s & 1));
+        rows_bad<MR, WS>(t, y.att, (unsigned)(s & 1));
 #pragma unroll
-        for (int q = 0; q < RPW; ++q) { unsigned tq = 0u; tag_acc(tq, y.res[q], (unsigned)(s & 1)); t |= wave + NW * q < g.nrows ? tq : 0u; }
+        for (int q = 0; q < RPW; ++q) tag_acc(t, y.res[q], (unsigned)(s & 1));
         return t;
     }
     __device__ __forceinline__ void issue(int, int b, const Geo&, Pay& y) {
@@ -931,6 +966,7 @@ struct OutRole {
         mid.before_barrier();
         __syncthreads();
         mid.after_barrier();
+        mid.before_stores();
 #pragma unroll
         for (int q = 0; q < RPW; ++q) {
             const int row = wave + NW * q;
@@ -942,7 +978,7 @@ struct OutRole {
             row_stats4(v, mean, rstd);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = ln_apply(v[i], mean, rstd, gg[i], bb[i]);
-            st_out(st, rout, base + row * 1024 + c * 4, v, par);
+            st_out<HO>(st, rout, base + row * 1024 + c * 4, v, par);
         }
     }
     // ---- two waves per SIMD: two wave groups, as QkvRole::split_loop.  Waves 4-7 wait for a block's flags, load the attention rows
@@ -1030,13 +1066,12 @@ struct OutRole {
                     if constexpr (HO) {
                         // the residual rows were consumed by this layer's QKV stages before any attention row existed: their tags are
                         // checked all the same (every handed-off word is), and a miss loads them again
-                        const int nrows = p.blocks[b].nrows;
                         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                         for (unsigned spins = 1;; ++spins) {
                             unsigned t = 0u;
 #pragma unroll
                             for (int k = 0; k < 4; ++k) tag_acc(t, res[k], par);
-                            if (__all(erow >= nrows || (t & 1u) == 0u)) break;
+                            if (__all((t & 1u) == 0u)) break;
                             if (spin_give_up(p, spins, t0)) return;
                             __builtin_amdgcn_s_sleep(1);
 #pragma unroll
@@ -1057,7 +1092,7 @@ struct OutRole {
                     for (int k = 0; k < 4; ++k) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[k][i] = ln_apply(v[k][i], mean, rstd, egg[k][i], ebb[k][i]);
-                        st_out(st, rout, base + erow * 1024 + (64 * k + ec) * 4, v[k], par);
+                        st_out<HO>(st, rout, base + erow * 1024 + (64 * k + ec) * 4, v[k], par);
                     }
                     if constexpr (!HO) {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows have landed
@@ -1081,7 +1116,7 @@ struct MlpRole {
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = true;
     static constexpr bool TILE = true;
-    struct Geo { int nrows; };
+    struct Geo {};
     struct Pay { Rows256<MR, WS> x; };
     const SysArgs& p; const Stage& st;
     char *atile, *htile; float* ct;
@@ -1103,18 +1138,18 @@ struct MlpRole {
         rin = rsrc_of(st.in0); rout = rsrc_of(st.out);
         plane = (unsigned)st.slice * PRING * RT * 1024;
     }
-    __device__ __forceinline__ void geo(int b, Geo& g) { g.nrows = p.blocks[b].nrows; }
+    __device__ __forceinline__ void geo(int, Geo&) {}
     __device__ __forceinline__ void geo_fix(Geo&) {}
-    __device__ __forceinline__ unsigned bad(int s, int, const Geo& g, const Pay& y) const {
+    __device__ __forceinline__ unsigned bad(int s, int, const Geo&, const Pay& y) const {
         unsigned t = 0u;
-        rows_bad<MR, WS>(t, y.x, g.nrows, (unsigned)(s & 1));
+        rows_bad<MR, WS>(t, y.x, (unsigned)(s & 1));
         return t;
     }
     __device__ __forceinline__ void issue(int, int b, const Geo&, Pay& y) { issue_rows<MR, WS>(y.x, rin, (unsigned)b * RT * 1024); }
     __device__ __forceinline__ void commit(const Pay& y) { commit_rows<AR, 4, MR, WS>(atile, 0, y.x); }
     // tagged hand-off: the same ring rule, read from the consumer's OUTPUT rows - a row of block x that shows the parity of x's
-    // step was stored by a consumer wave that had loaded its partial rows of x before.  One word per row, all rows below nrows
-    // (every wave of the consumer group stores rows of its own).  Needed only when the ring is shorter than a step: a block's next
+    // step was stored by a consumer wave that had loaded its partial rows of x before.  One word per row, all RT rows (every
+    // wave of the consumer group stores rows of its own, padding rows included).  Needed only when the ring is shorter than a step: a block's next
     // step waits for its previous one through the tail stage, so no stage is ever more than NB blocks ahead of another.
     __device__ __forceinline__ bool backpressure_tag(int s, int b) {
         if (p.NB <= PRING) return true;
@@ -1125,12 +1160,11 @@ struct MlpRole {
             const int gx = g - PRING / 2 - i;
             if (gx < 0) continue;
             const int sx = gx / p.NB, x = gx - sx * p.NB;
-            const int nrows = p.blocks[x].nrows;
             const unsigned par = (unsigned)(sx & 1);
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             for (unsigned spins = 1;; ++spins) {
                 unsigned w = par;
-                if (lane < nrows) w = __builtin_amdgcn_raw_buffer_load_b32(rb, ((unsigned)x * RT + lane) * 1024, 0, 16);
+                if (lane < RT) w = __builtin_amdgcn_raw_buffer_load_b32(rb, ((unsigned)x * RT + lane) * 1024, 0, 16);
                 if (__all(((w ^ par) & 1u) == 0u)) break;
                 if (spin_give_up(p, spins, t0)) return false;
                 __builtin_amdgcn_s_sleep(1);
@@ -1182,6 +1216,7 @@ struct MlpRole {
         zero_acc(acc2);
         mma<AR, 2, NT2, 4, MR>(htile, w2, acc2);
         stage_c(ct, acc2, [&](int j) { return 16 * NT2 * wave + 16 * j; });
+        mid.before_stores();
         // each wave stores the columns it staged itself (64 or 32 of them: 256 / 128 B per row, 4 / 8 rows per instruction): no
         // barrier - LDS serves a wave's accesses in order, and the next block's hidden tile is only written behind the stage loop's
         // barrier
@@ -1189,7 +1224,7 @@ struct MlpRole {
 #pragma unroll
         for (int q = 0; q < RT / RPI; ++q) {
             const int row = RPI * q + lane / LPR, cc = CW * wave + 4 * (lane % LPR);
-            st_out(st, rout, plane + base + row * 1024 + cc * 4, ld4(ct + row * CLD + cc), par);
+            st_out<HO>(st, rout, plane + base + row * 1024 + cc * 4, ld4(ct + row * CLD + cc), par);
         }
     }
 };
@@ -1225,7 +1260,8 @@ struct Red2Role {
     __device__ __forceinline__ void geo_fix(Geo& g) {
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
-            g.row[q] = g.pk[q] < 0 ? -1 : (g.pk[q] & 0xff);
+            // a live row: its tile row; a padding row r: -2 - r (stored as zeros); no row: -1
+            g.row[q] = g.pk[q] < 0 ? -1 : ((g.pk[q] & PART_PAD) ? -2 - (g.pk[q] & 0xff) : (g.pk[q] & 0xff));
             g.t[q] = (g.pk[q] >> 8) & 0xff;
             g.cnt[q] = (g.pk[q] >> 16) & 0xff;
             if (g.pk[q] < 0 || g.b2[q] < 0) g.cnt[q] = 0;
@@ -1247,6 +1283,11 @@ struct Red2Role {
 #pragma unroll
                 for (int j = 0; j < NSLICE; ++j) y.pl[q][j] = ld_sc1(rp, j * pstride + pbase + row * 1024 + c * 4);
                 y.rs[q] = ld_sc1(rx, base + row * 1024 + c * 4);
+            } else if (HO && row <= -2) {
+                // A padding row is stored as zeros, but not before this step's input of the block exists: the same row of the
+                // residual buffer (every producer writes all rows of its tiles) is the wave's ticket.  Without it a wave that owns
+                // nothing but padding would run through the steps by itself and rewrite rows whose readers are a step behind.
+                y.rs[q] = ld_sc1(rx, base + (-2 - row) * 1024 + c * 4);
             }
         }
     }
@@ -1256,11 +1297,11 @@ struct Red2Role {
         unsigned t = 0u;
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
-            unsigned tq = 0u;
+            unsigned tq = 0u, tr = 0u;
 #pragma unroll
             for (int j = 0; j < NSLICE; ++j) tag_acc(tq, y.pl[q][j], rpar);
-            tag_acc(tq, y.rs[q], spar);
-            t |= g.row[q] >= 0 ? tq : 0u;
+            tag_acc(tr, y.rs[q], spar);
+            t |= g.row[q] >= 0 ? (tq | tr) : (g.row[q] <= -2 ? tr : 0u);
         }
         return t;
     }
@@ -1286,7 +1327,9 @@ struct Red2Role {
                 row_stats4(v, mean, rstd);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = (v[i] - mean) * rstd * gg[i] + bb[i] + y.tv[q][i];
-                st_out(st, rout, base + row * 1024 + c * 4, v, par);
+                st_out<HO>(st, rout, base + row * 1024 + c * 4, v, par);
+            } else if (row <= -2) {
+                st_out<HO>(st, rout, base + (-2 - row) * 1024 + c * 4, f32x4{0.f, 0.f, 0.f, 0.f}, par);
             }
         }
     }
@@ -1326,7 +1369,7 @@ struct StylRole {
     }
     __device__ __forceinline__ void geo_fix(Geo& g) {
 #pragma unroll
-        for (int q = 0; q < PQ; ++q) g.row[q] = g.pk[q] < 0 ? -1 : (g.pk[q] & 0xff);
+        for (int q = 0; q < PQ; ++q) g.row[q] = g.pk[q] < 0 ? -1 : ((g.pk[q] & PART_PAD) ? -2 - (g.pk[q] & 0xff) : (g.pk[q] & 0xff));
     }
     __device__ __forceinline__ void issue(int s, int b, const Geo& g, Pay& y) {
         const int lane = threadIdx.x & 63, c = 4 * lane;
@@ -1341,6 +1384,8 @@ struct StylRole {
 #pragma unroll
                 for (int j = 0; j < NSLICE; ++j) y.pl[q][j] = ld_sc1(rp, j * pstride + pbase + row * 1024 + c * 4);
                 y.rs[q] = ld_sc1(rx, base + row * 1024 + c * 4);
+            } else if (HO && row <= -2) {
+                y.rs[q] = ld_sc1(rx, base + (-2 - row) * 1024 + c * 4);     // a padding row's ticket (Red2Role::issue)
             }
         }
     }
@@ -1350,11 +1395,11 @@ struct StylRole {
         unsigned t = 0u;
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
-            unsigned tq = 0u;
+            unsigned tq = 0u, tr = 0u;
 #pragma unroll
             for (int j = 0; j < NSLICE; ++j) tag_acc(tq, y.pl[q][j], rpar);
-            tag_acc(tq, y.rs[q], spar);
-            t |= g.row[q] >= 0 ? tq : 0u;
+            tag_acc(tr, y.rs[q], spar);
+            t |= g.row[q] >= 0 ? (tq | tr) : (g.row[q] <= -2 ? tr : 0u);
         }
         return t;
     }
@@ -1368,7 +1413,6 @@ struct StylRole {
         for (int q = 0; q < PQ; ++q) {
 #pragma unroll
             for (int j = 0; j < NSLICE; ++j) y.pl[q][j] = untag4(y.pl[q][j]);
-            y.rs[q] = untag4(y.rs[q]);
         }
 #pragma unroll
         for (int q = 0; q < 16 / NW; ++q) {                              // the 16 rows of the operand tile: local row wave + NW q
@@ -1398,9 +1442,12 @@ struct StylRole {
             const int lr = wave + NW * q, row = g.row[q];
             if (row >= 0) {
                 f32x4 v = ld4(ct + lr * CLD + c);
+                const f32x4 rs = untag4(y.rs[q]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[i] + y.rs[q][i];
-                st_out(st, rout, base + row * 1024 + c * 4, v, par);
+                for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[i] + rs[i];
+                st_out<HO>(st, rout, base + row * 1024 + c * 4, v, par);
+            } else if (row <= -2) {
+                st_out<HO>(st, rout, base + (-2 - row) * 1024 + c * 4, f32x4{0.f, 0.f, 0.f, 0.f}, par);
             }
         }
     }
@@ -1414,7 +1461,7 @@ struct SkipRole {
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = false;
     static constexpr bool TILE = true;
-    struct Geo { int nrows; };
+    struct Geo {};
     struct Pay { Rows256<MR, WS> x, k; };
     const SysArgs& p; const Stage& st;
     char* atile; float* ct;
@@ -1430,12 +1477,12 @@ struct SkipRole {
         rx = rsrc_of(st.in0); rs = rsrc_of(st.in1); rout = rsrc_of(st.out);
         bias = ld4(st.b0 + n0 + (threadIdx.x & 31) * 4);
     }
-    __device__ __forceinline__ void geo(int b, Geo& g) { g.nrows = p.blocks[b].nrows; }
+    __device__ __forceinline__ void geo(int, Geo&) {}
     __device__ __forceinline__ void geo_fix(Geo&) {}
-    __device__ __forceinline__ unsigned bad(int s, int, const Geo& g, const Pay& y) const {
+    __device__ __forceinline__ unsigned bad(int s, int, const Geo&, const Pay& y) const {
         unsigned t = 0u;
-        rows_bad<MR, WS>(t, y.x, g.nrows, (unsigned)(s & 1));
-        rows_bad<MR, WS>(t, y.k, g.nrows, (unsigned)(s & 1));
+        rows_bad<MR, WS>(t, y.x, (unsigned)(s & 1));
+        rows_bad<MR, WS>(t, y.k, (unsigned)(s & 1));
         return t;
     }
     __device__ __forceinline__ void issue(int, int b, const Geo&, Pay& y) {
@@ -1455,13 +1502,14 @@ struct SkipRole {
         mid.before_barrier();
         __syncthreads();
         mid.after_barrier();
+        mid.before_stores();
 #pragma unroll
         for (int u = 0; u < 2 * MR / WS; ++u) {                          // (row, 4 columns) of this half
             const int id = tid + NTH * u, row = id >> 5, cc = n0 + (id & 31) * 4;
             f32x4 v = ld4(ct + row * CLD + cc);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] += bias[i];
-            st_out(st, rout, base + row * 1024 + cc * 4, v, par);
+            st_out<HO>(st, rout, base + row * 1024 + cc * 4, v, par);
         }
     }
 };
@@ -1473,7 +1521,7 @@ struct SkipRole {
 template <int MR, int WS, int HO>
 struct TailRole {
     static constexpr int RT = 16 * MR, NW = 4 * WS, NQ = 16 / NW;        // (prompt, latent) pairs per wave: <= 16 per unit
-    struct Geo { int lat[NQ], t[NQ], rc[NQ]; };                         // latent row, position, conditional-branch row of pair q
+    struct Geo { int lat[NQ], t[NQ], rc[NQ], pad[NQ]; };                // latent row, position, conditional-branch row of pair q; padding row of a slot without a pair
     struct Pay { f32x4 eu[NQ], ec[NQ], lt[NQ], zz[NQ], pe[NQ]; };
     const SysArgs& p; const Stage& st;
     f32x4 gg, bb;
@@ -1513,7 +1561,7 @@ struct TailRole {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) xn[i] = l[i] + pe[i];
                     }
-                    st_out(st, rout, base + q * 1024 + c * 4, xn, 0u);    // the input of local step 0: parity 0
+                    st_out<HO>(st, rout, base + q * 1024 + c * 4, xn, 0u);    // the input of local step 0: parity 0
                 }
             }
             if constexpr (!HO) publish_unit(u, 1);
@@ -1523,9 +1571,9 @@ struct TailRole {
         unsigned t = 0u;
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            unsigned ti = 0u;
-            tag_acc(ti, y.eu[i], (unsigned)(s & 1)); tag_acc(ti, y.ec[i], (unsigned)(s & 1));
-            t |= g.lat[i] >= 0 ? ti : 0u;
+            unsigned tu = 0u, tc = 0u;
+            tag_acc(tu, y.eu[i], (unsigned)(s & 1)); tag_acc(tc, y.ec[i], (unsigned)(s & 1));
+            t |= (g.lat[i] >= 0 || g.pad[i] >= 0 ? tu : 0u) | (g.lat[i] >= 0 || g.rc[i] >= 0 ? tc : 0u);
         }
         return t;
     }
@@ -1533,7 +1581,7 @@ struct TailRole {
         const int wave = threadIdx.x >> 6;
         const BlockDesc* d = p.blocks + blk_u(u);
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) { const int q = wave + NW * i; g.lat[i] = d->pair_lat[q]; g.t[i] = d->pair_t[q]; g.rc[i] = d->pair_rc[q]; }
+        for (int i = 0; i < NQ; ++i) { const int q = wave + NW * i; g.lat[i] = d->pair_lat[q]; g.t[i] = d->pair_t[q]; g.rc[i] = d->pair_rc[q]; g.pad[i] = d->pair_pad[q]; }
     }
     __device__ __forceinline__ void issue(int s, int u, const Geo& g, Pay& y) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
@@ -1550,6 +1598,9 @@ struct TailRole {
                 y.lt[i] = ld4(p.lat + (size_t)g.lat[i] * D + c);
                 y.pe[i] = ld4(p.pe + (size_t)g.t[i] * D + c);
                 if (p.noise != nullptr && kn != 0.f) y.zz[i] = ld4(p.noise + ((size_t)step * p.B * T + g.lat[i]) * D + c);
+            } else if (HO) {                                             // the tickets of a slot that only pads (Red2Role::issue)
+                if (g.pad[i] >= 0) y.eu[i] = ld_sc1(rin, bu + g.pad[i] * 1024 + c * 4);
+                if (g.rc[i] >= 0) y.ec[i] = ld_sc1(rin, bc + g.rc[i] * 1024 + c * 4);
             }
         }
     }
@@ -1579,8 +1630,12 @@ struct TailRole {
                 }
                 st4(p.lat + (size_t)g.lat[i] * D + c, l);
                 const unsigned par = HO ? (unsigned)((s + 1) & 1) : 0u;     // the input of the NEXT local step
-                st_out(st, rout, bu + q * 1024 + c * 4, xn, par);          // after the last step nobody reads it
-                st_out(st, rout, bc + g.rc[i] * 1024 + c * 4, xn, par);
+                st_out<HO>(st, rout, bu + q * 1024 + c * 4, xn, par);          // after the last step nobody reads it
+                st_out<HO>(st, rout, bc + g.rc[i] * 1024 + c * 4, xn, par);
+            } else {                                                       // padding rows of the unit's tiles: zeros, next step's parity
+                const unsigned par = HO ? (unsigned)((s + 1) & 1) : 0u;
+                if (g.pad[i] >= 0) st_out<HO>(st, rout, bu + g.pad[i] * 1024 + c * 4, f32x4{0.f, 0.f, 0.f, 0.f}, par);
+                if (g.rc[i] >= 0) st_out<HO>(st, rout, bc + g.rc[i] * 1024 + c * 4, f32x4{0.f, 0.f, 0.f, 0.f}, par);
             }
         }
     }
@@ -1655,10 +1710,10 @@ __device__ __forceinline__ void tail_loop(const SysArgs& p, const Stage& st, Tai
 
 // Tagged hand-off: no barrier and no flag - every wave owns the (prompt, latent) pairs `wave + NW i` of its units, settles on the
 // two rows of each pair, updates the latents and stores the next step's input rows with the next step's parity.
-template <int MR, int WS>
-__device__ __forceinline__ void tail_loop_tag(const SysArgs& p, const Stage& st, TailRole<MR, WS, 1>& r) {
-    typename TailRole<MR, WS, 1>::Pay cur;
-    typename TailRole<MR, WS, 1>::Geo gcur, gnxt, gnn;
+template <int MR, int WS, int HO>
+__device__ __forceinline__ void tail_loop_tag(const SysArgs& p, const Stage& st, TailRole<MR, WS, HO>& r) {
+    typename TailRole<MR, WS, HO>::Pay cur;
+    typename TailRole<MR, WS, HO>::Geo gcur, gnxt, gnn;
     const int u0 = st.slice;
     const int nu = p.split ? p.NB / 2 : p.NB;
     r.prime(nu);
@@ -1744,34 +1799,43 @@ __global__ __launch_bounds__(256 * WS, 1) void systolic_loop_kernel(const SysArg
             1ull | (unsigned long long)st.role << 8 | (unsigned long long)st.layer << 16 | (unsigned long long)st.slice << 24 |
             (unsigned long long)st.blk0 << 32 | (unsigned long long)(st.out_local & 1) << 40 | (unsigned long long)(st.xcd & 0xff) << 48;
 #endif
+    // HO of the roles: 0 = flags, 1 / 2 = tags with write-through / plain stores (st_out): the store form of a tagged stage is a
+    // compile-time property of its loop
+    auto with_ho = [&](auto&& f) {
+        if constexpr (HO) { if (st.out_local) f(IntC<2>{}); else f(IntC<1>{}); }
+        else f(IntC<0>{});
+    };
     auto run = [&](auto& r) {
         if constexpr (HO) tag_loop(p, st, r, st.blk0, st.blkstride);
         else stage_loop(p, st, r, ctl, st.blk0, st.blkstride);
     };
     switch (st.role) {
-        case R_QKV: {
-            QkvRole<MR, AR, WS, HO> r(p, st, lds);
-            if constexpr (WS == 2) r.split_loop(ctl);
-            else run(r);
+        case R_QKV:
+            with_ho([&](auto hc) {
+                QkvRole<MR, AR, WS, decltype(hc)::value> r(p, st, lds);
+                if constexpr (WS == 2) r.split_loop(ctl);
+                else run(r);
+            });
             break;
-        }
-        case R_OUT: {
-            OutRole<MR, AR, WS, HO> r(p, st, lds);
-            if constexpr (WS == 2) r.split_loop(ctl);
-            else run(r);
+        case R_OUT:
+            with_ho([&](auto hc) {
+                OutRole<MR, AR, WS, decltype(hc)::value> r(p, st, lds);
+                if constexpr (WS == 2) r.split_loop(ctl);
+                else run(r);
+            });
             break;
-        }
-        case R_LIN: { MlpRole<MR, ACT_RELU, AR, WS, HO> r(p, st, lds); run(r); break; }
-        case R_RED2: { Red2Role<MR, WS, HO> r(p, st, lds); run(r); break; }
-        case R_FFN: { MlpRole<MR, ACT_GELU, AR, WS, HO> r(p, st, lds); run(r); break; }
-        case R_STYL: { StylRole<MR, AR, WS, HO> r(p, st, lds); run(r); break; }
-        case R_SKIP: { SkipRole<MR, AR, WS, HO> r(p, st, lds); run(r); break; }
-        case R_TAIL: {
-            TailRole<MR, WS, HO> r(p, st, lds);
-            if constexpr (HO) tail_loop_tag(p, st, r);
-            else tail_loop(p, st, r, ctl);
+        case R_LIN: with_ho([&](auto hc) { MlpRole<MR, ACT_RELU, AR, WS, decltype(hc)::value> r(p, st, lds); run(r); }); break;
+        case R_RED2: with_ho([&](auto hc) { Red2Role<MR, WS, decltype(hc)::value> r(p, st, lds); run(r); }); break;
+        case R_FFN: with_ho([&](auto hc) { MlpRole<MR, ACT_GELU, AR, WS, decltype(hc)::value> r(p, st, lds); run(r); }); break;
+        case R_STYL: with_ho([&](auto hc) { StylRole<MR, AR, WS, decltype(hc)::value> r(p, st, lds); run(r); }); break;
+        case R_SKIP: with_ho([&](auto hc) { SkipRole<MR, AR, WS, decltype(hc)::value> r(p, st, lds); run(r); }); break;
+        case R_TAIL:
+            with_ho([&](auto hc) {
+                TailRole<MR, WS, decltype(hc)::value> r(p, st, lds);
+                if constexpr (HO) tail_loop_tag(p, st, r);
+                else tail_loop(p, st, r, ctl);
+            });
             break;
-        }
         default: break;
     }
 }
@@ -1855,21 +1919,33 @@ void sys_pack_blocks(int B, int T, int want_mr, const int32_t* h_counts, bool ma
     // derived tables: the reduce parts' slots (the live rows split evenly over NRED parts) and the tail's (prompt, latent) pairs
     auto finish = [&](BlockDesc& d, const int* row_cnt, int npairs, int rc_off) {
         const int nparts = red_plan(MR).red2_parts;               // RED2 and STYL split a block's rows the same way
-        const int per = (d.nrows + nparts - 1) / nparts;
+        const int RT = 16 * MR, per = (RT + nparts - 1) / nparts; // all rows of the tile, padding included (stored as zeros)
         for (int part = 0; part < NRED; ++part) {
-            const int lo = part * per < d.nrows ? part * per : d.nrows, hi = lo + per < d.nrows ? lo + per : d.nrows;
+            const int lo = part * per < RT ? part * per : RT, hi = lo + per < RT ? lo + per : RT;
             for (int k = 0; k < 12; ++k) {
                 const int r = lo + k;
                 d.part_pk[part][k] = -1; d.part_b2[part][k] = -1;
                 if (part < nparts && r < hi) {
-                    d.part_pk[part][k] = r | d.row_t[r] << 8 | (row_cnt[r] < 0 ? 0xff : row_cnt[r]) << 16;
-                    d.part_b2[part][k] = d.row_b2[r];
+                    if (r < d.nrows) {
+                        d.part_pk[part][k] = r | d.row_t[r] << 8 | (row_cnt[r] < 0 ? 0xff : row_cnt[r]) << 16;
+                        d.part_b2[part][k] = d.row_b2[r];
+                    } else {
+                        d.part_pk[part][k] = PART_PAD | r;
+                    }
                 }
             }
         }
+        // tail: pairs first; the slots behind them pad.  One-branch blocks (rc_off 0): slot q pads row q of both blocks of the unit;
+        // two-branch blocks: the pad slots share the rows from nrows up, two each (both in the unit's one block)
         for (int q = 0; q < 16; ++q) {
-            d.pair_lat[q] = -1; d.pair_t[q] = 0; d.pair_rc[q] = 0;
+            d.pair_lat[q] = -1; d.pair_t[q] = 0; d.pair_rc[q] = -1; d.pair_pad[q] = -1;
             if (q < npairs) { d.pair_lat[q] = d.row_lat[q]; d.pair_t[q] = d.row_t[q]; d.pair_rc[q] = q + rc_off; }
+            else if (rc_off == 0) { if (q < RT) { d.pair_pad[q] = q; d.pair_rc[q] = q; } }
+            else {
+                const int r = d.nrows + 2 * (q - npairs);
+                if (r < RT) d.pair_pad[q] = r;
+                if (r + 1 < RT) d.pair_rc[q] = r + 1;
+            }
         }
     };
     if (MR == 2) {
@@ -2083,6 +2159,7 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR,
 int g_waves16 = 2;
 // hand-off protocol of the 16-row plan's eight-wave stages: 1 = parity tags in the data (default), 0 = flags (ladiff_debug_set_handoff)
 int g_handoff = 1;
+constexpr int LOOK_AHEAD_BLOCKS = 72;      // see `settle`: 58 blocks (128 prompts of mixed lengths) lose with it, 86 win
 // test aids (ladiff_debug_set_pipeline_fault): a workgroup that never publishes, and the bound of a wait in s_memrealtime ticks (0: default)
 int g_fault_wg = -1;
 unsigned long long g_timeout_ticks = 0;
@@ -2109,6 +2186,7 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     a.force_mismatch = g_xcd_local == 2 ? 1 : 0;
     a.fault_wg = g_fault_wg;
     a.timeout_ticks = g_timeout_ticks > 0 ? g_timeout_ticks : TIMEOUT_TICKS;
+    a.look_ahead = NB >= LOOK_AHEAD_BLOCKS ? 1 : 0;
     a.stamps = nullptr;
 #ifdef LADIFF_STAMPS
     a.stamps = g_sys_stamps;
