@@ -32,7 +32,11 @@ def build(force=False, verbose=False, stamps=False):
     flags = list(FLAGS)
     if stamps:
         OBJ, LIB = OBJ + "_stamps", LIB.replace(".so", "_stamps.so")
-        flags.append("-DLADIFF_STAMPS")
+        # LADIFF_STAMPS=1: per-workgroup totals only (blocked / busy time: undistorted); LADIFF_STAMPS_LEVEL=2 in the environment adds
+        # the per-block timeline stamps (~0.1 us each: read intervals from it, not totals)
+        lvl = os.environ.get("LADIFF_STAMPS_LEVEL", "1")
+        OBJ += lvl if lvl != "1" else ""
+        flags.append("-DLADIFF_STAMPS=" + lvl)
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "ladiff_hip.h"))

@@ -139,7 +139,7 @@ struct SysArgs {
 
 // In-kernel timeline (diagnostic twin build; the shipped library executes no stamp): s_memrealtime is one 100 MHz counter
 // for the whole chip, so stamps of different workgroups order the hand-offs between CUs.
-#ifdef LADIFF_STAMPS
+#if defined(LADIFF_STAMPS) && LADIFF_STAMPS + 0 >= 2   // per-block timeline: -DLADIFF_STAMPS=2 (each stamp costs ~0.1 us: it distorts the busy / blocked totals)
 #define SYS_STAMP(i)                                                                                                   \
     do {                                                                                                               \
         if (p.stamps != nullptr && threadIdx.x == 0) {                                                                 \
@@ -156,6 +156,11 @@ struct SysArgs {
             if (s < 4 && b < 4) p.stamps[(((size_t)blockIdx.x * 4 + s) * 4 + b) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
         }                                                                                                              \
     } while (0)
+#elif defined(LADIFF_STAMPS)
+#define SYS_STAMP(i) do { } while (0)
+#define SYS_STAMP_L(i) do { } while (0)
+#endif
+#ifdef LADIFF_STAMPS
 // per-workgroup totals behind the timeline: ticks blocked in wait_epoch, prefetch hits, blocks processed
 #define SYS_STAT_DECL unsigned long long st_wait = 0, st_hit = 0, st_n = 0, st_t = 0
 #define SYS_STAT_T0 st_t = __builtin_amdgcn_s_memrealtime()

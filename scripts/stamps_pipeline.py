@@ -3,6 +3,8 @@ the shipped library executes no stamp).  python scripts/stamps_pipeline.py [B] [
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+# the twin is built by `python -m ladiff_amd.build --stamps` (totals only) or with LADIFF_STAMPS_LEVEL=2 in the environment (per-block
+# timeline too: each stamp costs ~0.1 us, so read INTERVALS from that build and busy / blocked TOTALS from the other)
 subprocess.check_call([sys.executable, "-m", "ladiff_amd.build", "--stamps"], cwd=ROOT, stdout=subprocess.DEVNULL)
 import torch
 from ladiff_amd import _lib
