@@ -267,16 +267,16 @@ int ladiff_debug_set_xcd_local(int on);
 int ladiff_debug_set_decoder_fusion(int on);
 /* Measurement switch (process-wide) of the fused feed-forward kernel's form: 0 (default) = chosen by the row count, 1 = 128-row
  * workgroups of eight waves x 16 rows, 2 = 64-row workgroups of four waves x 16 rows, 3 = 128-row workgroups of four waves x 32 rows.
- * 11 .. 17: timing builds of form 3 with one ingredient removed (no LDS-DMA in the loop / no MFMAs / no fragment reads / no GELU / no
- * epilogue / reads never used / reads waited for but not used): the RESULTS ARE GARBAGE, scripts/mlp_speed.py only.
- * 21 .. 26: timing builds of the decoder's attention kernel with in_proj inside (csrc/dec_qkv_attn.hip: no LDS-DMA waits / no score,
- * softmax, output core / no projection MFMAs / no projection / no x row loads / x row loads only), GARBAGE results as well,
- * scripts/attn_speed.py only; the feed-forward kernel keeps its default form under these values. */
+ * Every accepted value gives the same result; anything else returns LADIFF_ERR_ARG.  (The timing builds of rounds 3 - values 11 .. 17 and
+ * 21 .. 26, kernels with one ingredient removed whose results are garbage - are not in this library: they are instantiated in the
+ * diagnostic twin libladiff_hip_stamps.so only, `python -m ladiff_amd.build --stamps`, for scripts/mlp_speed.py and attn_speed.py.) */
 int ladiff_debug_set_mlp_variant(int v);
 /* The block plan ladiff_diffusion_reverse would use for a batch (host arithmetic only, no GPU call): rows per block (16 = the
  * length-aware packing, 32 = padded blocks) and the number of blocks.  h_counts = latent counts on the host or NULL, masked = the
- * call passes device counts, loop_mode 1 / 2 / 3 as ladiff_sampler_set_loop, bf16x3 = the call passes w_split. */
-int ladiff_reverse_plan(int B, int T, const int32_t* h_counts, int masked, int loop_mode, int bf16x3, int* rows_per_block,
+ * call passes device counts, loop_mode 1 / 2 / 3 as ladiff_sampler_set_loop, bf16x3 = the call passes w_split, cfg = the call's
+ * guidance flag (without guidance: one-branch 16-row blocks; LADIFF_ERR_UNSUPPORTED when such a call has device-only counts - it runs
+ * launch-per-stage and has no block plan). */
+int ladiff_reverse_plan(int B, int T, const int32_t* h_counts, int masked, int loop_mode, int bf16x3, int cfg, int* rows_per_block,
                         int* n_blocks);
 /* Device time of the N-step loop of the sampler's last call (HIP events recorded on the call's stream right around the
  * pipeline kernel, or around the graph replays); blocks until it has finished.  Measurement aid (bench.py). */
@@ -300,9 +300,10 @@ int ladiff_reverse_status(void* ws, int B, int T, int n_steps, int n_text, int* 
  * not block copies the 8 bytes to pinned host memory with an async copy on the call's stream and reads them once an event
  * recorded behind the copy has completed (ladiff_amd/pipeline.py does, and raises / re-runs the call launch-per-stage). */
 size_t ladiff_reverse_status_offset_bytes(int B, int T, int n_steps, int n_text);
-/* Test aid (process-wide): workgroup >= 0 makes that pipeline workgroup leave right after the start-up handshake of every
- * launch, so that its consumers time out (-1: off); timeout_ms > 0 replaces the 1.5 s bound of every wait (0: default). */
-int ladiff_debug_set_pipeline_fault(int workgroup, int timeout_ms);
+/* Fault injection for the abort-path tests, a property of ONE sampler handle: workgroup >= 0 makes that pipeline workgroup leave right
+ * after the start-up handshake of every launch of this sampler, so that its consumers time out (-1: off); timeout_ms > 0 replaces the
+ * 1.5 s bound of every wait (0: default).  Other samplers of the process are not affected. */
+int ladiff_sampler_set_fault(void* sampler, int workgroup, int timeout_ms);
 size_t ladiff_reverse_workspace_bytes(int B, int T, int n_steps, int n_text);
 int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* const* w_split /*or NULL*/,
                              uint64_t weights_generation, const float* text_emb /*[2B or B,n_text,768]*/,

@@ -72,7 +72,7 @@ _SIGNATURES = {
     "ladiff_sampler_last_loop": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "ladiff_reverse_status": (c_int, [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "ladiff_reverse_status_offset_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "ladiff_debug_set_pipeline_fault": (c_int, [c_int, c_int]),
+    "ladiff_sampler_set_fault": (c_int, [c_void_p, c_int, c_int]),
     "ladiff_reverse_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ladiff_diffusion_reverse": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_int, c_int,
@@ -110,7 +110,7 @@ _SIGNATURES = {
     "ladiff_debug_set_xcd_local": (c_int, [c_int]),
     "ladiff_debug_set_decoder_fusion": (c_int, [c_int]),
     "ladiff_debug_set_mlp_variant": (c_int, [c_int]),
-    "ladiff_reverse_plan": (c_int, [c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ladiff_reverse_plan": (c_int, [c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ladiff_decoder_graph_create": (c_int, [ctypes.POINTER(c_void_p)]),
     "ladiff_decoder_graph_destroy": (c_int, [c_void_p]),
     "ladiff_vae_decode_graphed": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

@@ -83,6 +83,10 @@ struct Sampler {
     std::vector<hipEvent_t> wev;          // [2 i], [2 i + 1]: around the loop launches of window i of the last call
     int n_windows = 0;
     int last_pipeline = 0;                // the last call ran the persistent pipeline kernel (1) or launch-per-stage graphs (0)
+    // fault injection for the abort-path tests (ladiff_sampler_set_fault): THIS sampler's pipeline launches lose one workgroup right after
+    // the start-up handshake and bound their waits; -1 / 0 = none / the default bound.  A field of the handle, not of the process.
+    int fault_wg = -1;
+    unsigned long long timeout_ticks = 0;
     // capture key: a graph bakes pointers, shapes and scalars into its kernel nodes.  The weight tables are identified by
     // a hash over EVERY pointer of both tables plus the caller's generation id (bumped whenever a table is rebuilt), not
     // by the address of the host array (which a rebuilt table can land on again).
@@ -346,11 +350,12 @@ static void choose_plan(int B, int T, const int32_t* h_counts, bool masked, int 
 
 extern "C" {
 
-int ladiff_reverse_plan(int B, int T, const int32_t* h_counts, int masked, int loop_mode, int bf16x3, int* rows_per_block, int* n_blocks) {
+int ladiff_reverse_plan(int B, int T, const int32_t* h_counts, int masked, int loop_mode, int bf16x3, int cfg, int* rows_per_block, int* n_blocks) {
     LADIFF_CHECK_ARG(B >= 1 && T >= 1 && T <= LADIFF_MAX_LATENTS && loop_mode >= 1 && loop_mode <= 3 && rows_per_block && n_blocks);
+    if (!cfg && masked && h_counts == nullptr) return LADIFF_ERR_UNSUPPORTED;      // such a call runs launch-per-stage (no block plan)
     std::vector<unsigned char> plan;
     int mr = 2, nb = 0;
-    choose_plan(B, T, h_counts, masked != 0, loop_mode, bf16x3 != 0, plan, &mr, &nb);
+    choose_plan(B, T, h_counts, masked != 0, loop_mode, bf16x3 != 0, plan, &mr, &nb, cfg != 0);
     *rows_per_block = 16 * mr; *n_blocks = nb;
     return 0;
 }
@@ -368,7 +373,11 @@ int ladiff_debug_set_handoff(int tagged) {
 }
 
 int ladiff_debug_set_mlp_variant(int v) {
-    LADIFF_CHECK_ARG((v >= 0 && v <= 3) || (v >= 11 && v <= 17) || (v >= 21 && v <= 26));
+#ifdef LADIFF_STAMPS
+    LADIFF_CHECK_ARG((v >= 0 && v <= 3) || (v >= 11 && v <= 17) || (v >= 21 && v <= 26));    // the diagnostic twin also carries the timing builds
+#else
+    LADIFF_CHECK_ARG(v >= 0 && v <= 3);          // workgroup forms of the fused feed-forward kernel; every one gives the same result
+#endif
     g_mlp_variant = v;
     return 0;
 }
@@ -434,10 +443,11 @@ int ladiff_sampler_last_loop(void* sampler, int* pipeline, int* rows_per_block, 
     return 0;
 }
 
-int ladiff_debug_set_pipeline_fault(int workgroup, int timeout_ms) {
-    LADIFF_CHECK_ARG(workgroup >= -1 && workgroup < 256 && timeout_ms >= 0);
-    g_fault_wg = workgroup;
-    g_timeout_ticks = (unsigned long long)timeout_ms * 100000ull;      // s_memrealtime: 100 MHz
+int ladiff_sampler_set_fault(void* sampler, int workgroup, int timeout_ms) {
+    Sampler* sp = reinterpret_cast<Sampler*>(sampler);
+    LADIFF_CHECK_ARG(sp != nullptr && workgroup >= -1 && workgroup < 256 && timeout_ms >= 0);
+    sp->fault_wg = workgroup;
+    sp->timeout_ticks = (unsigned long long)timeout_ms * 100000ull;    // s_memrealtime: 100 MHz
     return 0;
 }
 
@@ -629,7 +639,8 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
             }
             if (pipeline) {
                 LADIFF_TRY(launch_systolic_loop(W, r.sys, r.tables, den_cache_tkv(r.cache, B2, 1), den_cache_ctab(r.cache, B2, 1), r.window,
-                                                coef, step_noise, r.latents, counts, guidance_scale, B, T, lo, r.window, WSp ? 0 : 1, plan_mr, plan_nb, s, cfg));
+                                                coef, step_noise, r.latents, counts, guidance_scale, B, T, lo, r.window, WSp ? 0 : 1, plan_mr, plan_nb, s, cfg,
+                                                sp->fault_wg, sp->timeout_ticks));
             } else {
                 for (int i = 0; i < r.window / sp->unroll; ++i) LADIFF_HIP(hipGraphLaunch(sp->exec, s));
             }
@@ -788,6 +799,8 @@ int ladiff_vae_decode_graphed(void* graph, const float* const* w, const float* c
                       h == dg->key_hash && weights_generation == dg->key_gen && dg->epoch == g_graph_epoch.load();
     if (!same) {
         if (dg->exec) { LADIFF_HIP(hipStreamSynchronize(s)); (void)hipGraphExecDestroy(dg->exec); dg->exec = nullptr; }
+        LADIFF_TRY(dec_mlp_prepare());            // kernel attributes are set outside the capture
+        LADIFF_TRY(dec_qkv_attn_prepare());
         hipGraph_t gr = nullptr;
         LADIFF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         int rc = 0;

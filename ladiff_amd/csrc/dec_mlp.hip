@@ -32,6 +32,7 @@
 // they do not show that the reads cost 20 us - constant operands let the chip clock the matrix pipe ~25 % higher than random
 // weights do (MI355X_MICROARCH.md: 1.5 - 1.7 GHz in MFMA-dense loops on random data, 2.39 GHz on zeros).  Deeper fragment prefetch
 // (10 -> 17 MFMAs) moved the kernel by 2 us: the waits are not what binds.
+#include <mutex>
 #include "model.h"
 #include "tile_mma.h"
 
@@ -364,7 +365,32 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void dec_mlp_kernel(const MlpArgs 
     }
 }
 
-int g_mlp_variant = 0;            // measurement switch (ladiff_debug_set_mlp_variant)
+std::atomic<int> g_mlp_variant{0};   // measurement switch (ladiff_debug_set_mlp_variant)
+
+// hipFuncSetAttribute is per DEVICE and must not land inside a stream capture: once per device, under a mutex; the graphed decode
+// calls it before it begins its capture
+int dec_mlp_prepare() {
+    static std::mutex mu;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    LADIFF_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return LADIFF_ERR_ARG;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!attr_set[dev]) {
+        const void* k[3] = {reinterpret_cast<const void*>(dec_mlp_kernel<4, 2>), reinterpret_cast<const void*>(dec_mlp_kernel<8, 1>),
+                            reinterpret_cast<const void*>(dec_mlp_kernel<4, 1>)};
+        for (int i = 0; i < 3; ++i) LADIFF_HIP(hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
+#ifdef LADIFF_STAMPS
+        const void* d[7] = {reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 1>), reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 2>),
+                            reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 3>), reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 4>),
+                            reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 5>), reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 6>),
+                            reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 7>)};
+        for (int i = 0; i < 7; ++i) LADIFF_HIP(hipFuncSetAttribute(d[i], hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
+#endif
+        attr_set[dev] = true;
+    }
+    return 0;
+}
 // Rows from which the fused kernel beats linear1 + linear2 + LayerNorm as three launches: a workgroup streams all 2 MB of weights
 // whatever its share of the rows, ~60 us even alone on the chip, while the three launches scale down with the rows (6272 rows: 56 us
 // against 64, 12544 rows: 78 against 71, profiles/r3)
@@ -374,16 +400,7 @@ int dec_mlp_min_rows() { return 10000; }
 int launch_dec_mlp(const float* xs, const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* g3,
                    const float* be3, const float* g4, const float* be4, float* y, float* ys, int M, hipStream_t s) {
     if (M <= 0) return 0;
-    static bool attr_set[64] = {};
-    int dev = 0;
-    LADIFF_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) return LADIFF_ERR_ARG;
-    if (!attr_set[dev]) {
-        const void* k[3] = {reinterpret_cast<const void*>(dec_mlp_kernel<4, 2>), reinterpret_cast<const void*>(dec_mlp_kernel<8, 1>),
-                            reinterpret_cast<const void*>(dec_mlp_kernel<4, 1>)};
-        for (int i = 0; i < 3; ++i) LADIFF_HIP(hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
-        attr_set[dev] = true;
-    }
+    LADIFF_TRY(dec_mlp_prepare());
     MlpArgs a{xs, x, w1, b1, w2, b2, g3, be3, g4, be4, y, ys, M};
     // every workgroup streams all 2 MB of weights: 128-row workgroups when they fill the chip, 64-row ones (twice as many) otherwise
     // (measured, profiles/r3: 25088 rows 111 us <4,2> / 116 <8,1> / 137 <4,1>; 12544 rows 106 / 108 / 71; the caller keeps the
@@ -391,19 +408,18 @@ int launch_dec_mlp(const float* xs, const float* x, const float* w1, const float
     int form = g_mlp_variant;                      // 0: by size, 1: <8, 1>, 2: <4, 1>, 3: <4, 2>
     if (form >= 21) form = 0;                      // 21 .. 23: timing builds of the attention kernel (dec_qkv_attn.hip)
     if (form == 0) form = (M + 127) / 128 < 160 ? 2 : 3;
-    if (form >= 11 && form <= 17) {                // timing experiments (garbage results): <4, 2> without DMA / MFMAs / fragment reads / GELU / epilogue
-        static bool dset = false;
+#ifdef LADIFF_STAMPS
+    // diagnostic twin only (the product library has no such instantiation and rejects the values): timing builds with garbage
+    // results - <4, 2> without DMA / MFMAs / fragment reads / GELU / epilogue
+    if (form >= 11 && form <= 17) {
         const void* k[7] = {reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 1>), reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 2>),
                             reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 3>), reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 4>),
                             reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 5>), reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 6>),
                             reinterpret_cast<const void*>(dec_mlp_kernel<4, 2, 7>)};
-        if (!dset) {
-            for (int i = 0; i < 7; ++i) LADIFF_HIP(hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS));
-            dset = true;
-        }
         void* args[] = {&a};
         LADIFF_HIP(hipLaunchKernel(k[form - 11], dim3((M + 127) / 128), dim3(256), args, MLP_LDS, s));
     } else
+#endif
     if (form == 3) hipLaunchKernelGGL((dec_mlp_kernel<4, 2>), dim3((M + 127) / 128), dim3(256), MLP_LDS, s, a);
     else if (form == 1) hipLaunchKernelGGL((dec_mlp_kernel<8, 1>), dim3((M + 127) / 128), dim3(512), MLP_LDS, s, a);
     else hipLaunchKernelGGL((dec_mlp_kernel<4, 1>), dim3((M + 63) / 64), dim3(256), MLP_LDS, s, a);

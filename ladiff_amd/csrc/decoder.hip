@@ -6,10 +6,10 @@
 namespace ladiff {
 
 constexpr int DEC_SMALL_ROWS = 4096;
-int g_dec_fused_attn = 1;         // measurement switch (+ 16): in_proj GEMM + attention kernel as two launches (the path before)
-int g_dec_final_split = 1;        // measurement switch (ladiff_debug_set_decoder_fusion + 8): final_layer on the fp32 kernel as in round 2
-int g_dec_small_rows_path = 1;    // measurement switch (ladiff_debug_set_decoder_fusion bit 2 clear / set): the small-M GEMM routing
-int g_dec_fused_mlp = 1;          // measurement switch (ladiff_debug_set_decoder_fusion): 0 = linear1 / linear2 / LayerNorm as three launches, 1 = fused from dec_mlp_min_rows() rows, 2 = fused always
+std::atomic<int> g_dec_fused_attn{1};         // measurement switch (+ 16): in_proj GEMM + attention kernel as two launches (the path before)
+std::atomic<int> g_dec_final_split{1};        // measurement switch (ladiff_debug_set_decoder_fusion + 8): final_layer on the fp32 kernel as in round 2
+std::atomic<int> g_dec_small_rows_path{1};    // measurement switch (ladiff_debug_set_decoder_fusion bit 2 clear / set): the small-M GEMM routing
+std::atomic<int> g_dec_fused_mlp{1};          // measurement switch (ladiff_debug_set_decoder_fusion): 0 = linear1 / linear2 / LayerNorm as three launches, 1 = fused from dec_mlp_min_rows() rows, 2 = fused always
 
 static GemmArgs lin(const float* A, int lda, const float* W, const float* bias, float* Y, int ldy, int M, int N, int K,
                     int act = ACT_NONE) {

@@ -1,5 +1,6 @@
 // Host-side sequencing entry points shared by denoiser.hip / decoder.hip / api.hip.
 #pragma once
+#include <atomic>
 #include "gemm.h"
 #include "gemm_kr.h"
 #include "kernels.h"
@@ -36,11 +37,16 @@ int linear_cross_attention(const DenoiserW& w, int layer, const float* x, const 
 size_t linear_cross_attention_ws_floats(int B, int T, int N);
 void den_loop_io(float* ws, int rows, float** x, float** xs);
 
-extern int g_dec_fused_mlp;
-extern int g_dec_small_rows_path;
-extern int g_dec_final_split;
-extern int g_dec_fused_attn;
-extern int g_mlp_variant;
+// Measurement switches (include/ladiff_hip.h, ladiff_debug_set_*): process-wide atomics.  Every value they accept selects a launch
+// form that the tests hold to the same tolerances; the timing builds that produce garbage exist in the diagnostic twin only
+// (-DLADIFF_STAMPS).
+extern std::atomic<int> g_dec_fused_mlp;
+extern std::atomic<int> g_dec_small_rows_path;
+extern std::atomic<int> g_dec_final_split;
+extern std::atomic<int> g_dec_fused_attn;
+extern std::atomic<int> g_mlp_variant;
+int dec_mlp_prepare();           // per-device kernel attributes (dynamic LDS): outside any stream capture, under a mutex
+int dec_qkv_attn_prepare();
 int dec_mlp_min_rows();
 size_t dec_ws_floats(int B, size_t rows, int T);
 int vae_decode(const DecoderW& w, const DecoderW* w_split, const float* z, const int32_t* lengths, const int32_t* counts,
@@ -61,19 +67,18 @@ extern unsigned long long* g_sys_stamps;
 #endif
 size_t sys_ws_floats(int B, int T);
 bool sys_supported(int B, int T, int cfg, bool split);
-extern int g_waves16;
-extern int g_handoff;
-extern int g_fault_wg;
-extern unsigned long long g_timeout_ticks;
+extern std::atomic<int> g_waves16;
+extern std::atomic<int> g_handoff;
 int sys_reset_status(float* ws, hipStream_t s);
-extern int g_xcd_local;
+extern std::atomic<int> g_xcd_local;
 void sys_pack_blocks(int B, int T, int want_mr, const int32_t* h_counts, bool masked, bool cfg, std::vector<unsigned char>& out, int* mr, int* nb);
 int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR, int NB, std::vector<unsigned char>& host);
 size_t sys_blocks_offset_floats(int MR, int NB);
 size_t sys_status_offset_floats(int B, int T);
 int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, const float* tkv, const float* ctab, int n_ctab,
                          const float* coef, const float* noise, float* lat, const int32_t* counts, float gscale, int B, int T,
-                         int step_lo, int n, int fp32, int MR, int NB, hipStream_t s, int cfg = 1);
+                         int step_lo, int n, int fp32, int MR, int NB, hipStream_t s, int cfg = 1, int fault_wg = -1,
+                         unsigned long long timeout_ticks = 0);
 
 // qkv_attn.hip: in_proj GEMM + self-attention of the denoiser's sa_block in one launch (bf16x3 mode, S-format in / out)
 int launch_qkv_attention(const float* x, const float* w, const float* bias, const float* text_kv, const float* tables,

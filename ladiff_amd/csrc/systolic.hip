@@ -2013,7 +2013,7 @@ void sys_pack_blocks(int B, int T, int want_mr, const int32_t* h_counts, bool ma
 // flows through the stages); the stages are dealt to the XCDs in that order, 32 (31) to each, so that a layer's hand-offs stay
 // inside one XCD's L2 and the chain crosses an XCD boundary only 7 times (+ the skip connections and the tail).  A stage whose
 // readers all sit on its own XCD stores plainly (Stage::out_local); everything else works as before (write-through).
-int g_xcd_local = 1;              // measurement switch: ladiff_debug_set_xcd_local
+std::atomic<int> g_xcd_local{1};  // measurement switch: ladiff_debug_set_xcd_local
 
 __global__ __launch_bounds__(512, 1) void xcd_probe_kernel(unsigned* xcc) {
     extern __shared__ char lds[];
@@ -2161,13 +2161,10 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR,
 // One launch = local steps [step_lo, step_lo + n) of the loop on the latents in `lat`.  The stage table must already be in
 // the workspace (sys_upload_stages); `ctab` holds the hoisted cross-attention rows of n_ctab >= n steps starting at step_lo.
 // waves per SIMD of the 16-row plan's stage workgroups (measurement switch: ladiff_debug_set_stage_waves)
-int g_waves16 = 2;
+std::atomic<int> g_waves16{2};
 // hand-off protocol of the 16-row plan's eight-wave stages: 1 = parity tags in the data (default), 0 = flags (ladiff_debug_set_handoff)
-int g_handoff = 1;
+std::atomic<int> g_handoff{1};
 constexpr int LOOK_AHEAD_BLOCKS = 72;      // see `settle`: 58 blocks (128 prompts of mixed lengths) lose with it, 86 win
-// test aids (ladiff_debug_set_pipeline_fault): a workgroup that never publishes, and the bound of a wait in s_memrealtime ticks (0: default)
-int g_fault_wg = -1;
-unsigned long long g_timeout_ticks = 0;
 
 int sys_reset_status(float* ws, hipStream_t s) {
     const SysLayout L = sys_layout(2, 1);            // the status words sit at a fixed offset (before everything sized by the plan)
@@ -2177,7 +2174,8 @@ int sys_reset_status(float* ws, hipStream_t s) {
 
 int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, const float* tkv, const float* ctab, int n_ctab,
                          const float* coef, const float* noise, float* lat, const int32_t* counts, float gscale, int B, int T,
-                         int step_lo, int n, int fp32, int MR, int NB, hipStream_t s, int cfg) {
+                         int step_lo, int n, int fp32, int MR, int NB, hipStream_t s, int cfg, int fault_wg, unsigned long long timeout_ticks) {
+    // fault_wg / timeout_ticks: the caller's SAMPLER's fault injection (ladiff_sampler_set_fault; -1 / 0 = none / default bound)
     const SysLayout L = sys_layout(MR, NB);
     SysArgs a;
     a.stages = reinterpret_cast<const Stage*>(ws + L.off_stages);
@@ -2189,8 +2187,8 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     a.n_ctab = n_ctab;
     a.split = cfg ? L.split : 0;       // no guidance: every block is a unit of its own (sys_pack_blocks)
     a.force_mismatch = g_xcd_local == 2 ? 1 : 0;
-    a.fault_wg = g_fault_wg;
-    a.timeout_ticks = g_timeout_ticks > 0 ? g_timeout_ticks : TIMEOUT_TICKS;
+    a.fault_wg = fault_wg;
+    a.timeout_ticks = timeout_ticks > 0 ? timeout_ticks : TIMEOUT_TICKS;
     a.look_ahead = NB >= LOOK_AHEAD_BLOCKS ? 1 : 0;
     a.stamps = nullptr;
 #ifdef LADIFF_STAMPS

@@ -120,6 +120,7 @@ class LADIFF(nn.Module):
         self.fallback = bool(fallback)
         self.fallback_count = 0
         self._pending = []            # (event, pinned status words, plan key) per launch of the last call, not yet looked at
+        self._fault = (-1, 0)         # fault injection of the abort-path tests: applied to every sampler of THIS object (set_pipeline_fault)
         self._stream = None
         self._plans = {}              # plan key -> persistent buffers + sampler (a few shapes stay cached: chunks, alternating batches)
         self._last = []               # the plans the last call ran on, in order
@@ -203,6 +204,8 @@ class LADIFF(nn.Module):
             h = c_void_p()
             _lib.check(L.ladiff_sampler_create(byref(h)))
             plan["sampler"] = h
+            if self._fault != (-1, 0):
+                _lib.check(L.ladiff_sampler_set_fault(h, *self._fault))
         # the pipeline kernel's {code, info} words inside the workspace, and where the host reads them
         off = L.ladiff_reverse_status_offset_bytes(B, T, n_steps, n_text)
         if off == 0 or off % 4:
@@ -218,6 +221,14 @@ class LADIFF(nn.Module):
                 _lib.check(L.ladiff_sampler_destroy(old["sampler"]))
         self._plans[key] = plan
         return plan
+
+    def set_pipeline_fault(self, workgroup=-1, timeout_ms=0):
+        """Test aid (tests/test_gpu_pipeline.py): the pipeline launches of THIS object's samplers lose workgroup `workgroup` right after the
+        start-up handshake and bound every wait to `timeout_ms` (-1, 0: off).  Other LADIFF objects of the process are not affected."""
+        self._fault = (int(workgroup), int(timeout_ms))
+        for plan in self._plans.values():
+            if plan.get("sampler") is not None:
+                _lib.check(_lib.lib().ladiff_sampler_set_fault(plan["sampler"], *self._fault))
 
     def check(self, wait=True):
         """Look at the status of the last `_diffusion_reverse` call: raises LadiffHipError when a pipeline loop of it was abandoned
@@ -242,11 +253,12 @@ class LADIFF(nn.Module):
 
     # ------------------------------------------------------------------ the hot loop
     def _chunks(self, B):
-        """[lo, hi) prompt ranges of the launches a batch of B prompts runs as (balanced chunks of <= 256 prompts)."""
+        """[lo, hi) prompt ranges of the launches a batch of B prompts runs as: balanced chunks of at most min(cap, 256) prompts (beyond
+        ~170 blocks the per-layer buffers of one launch fall out of the memory-side cache)."""
         cap = self.max_prompts_per_launch
         if cap is None or B <= cap or self.loop == "launches":
             return [(0, B)]
-        n = -(-B // 256)
+        n = -(-B // max(1, min(int(cap), 256)))
         base, extra = divmod(B, n)
         spans, lo = [], 0
         for i in range(n):

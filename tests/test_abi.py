@@ -87,11 +87,11 @@ def test_block_plan_of_the_pipeline_loop(lib):
     import ctypes
     import math
 
-    def plan(lengths, mode, masked=True, host=True, T=5):
+    def plan(lengths, mode, masked=True, host=True, T=5, cfg=1):
         B = len(lengths)
         counts = (ctypes.c_int32 * B)(*[math.ceil(l / 48) for l in lengths])
         rows, nb = ctypes.c_int(0), ctypes.c_int(0)
-        rc = lib.ladiff_reverse_plan(B, T, ctypes.cast(counts, ctypes.c_void_p) if host else None, int(masked), mode, 1,
+        rc = lib.ladiff_reverse_plan(B, T, ctypes.cast(counts, ctypes.c_void_p) if host else None, int(masked), mode, 1, cfg,
                                      ctypes.byref(rows), ctypes.byref(nb))
         assert rc == 0
         return rows.value, nb.value
@@ -108,7 +108,25 @@ def test_block_plan_of_the_pipeline_loop(lib):
     assert plan([196], 1) == (16, 2) and plan([196], 3) == (32, 1)    # one prompt: the 16-row plan's trip through the stages is shorter
     assert plan(mixed, 2, host=False) == (32, 43)              # counts on the device only: the packing needs them on the host
     assert plan([40] * 40, 2) == (16, 10)                      # one-row prompts: 8 per block (text K|V slots), 5 groups x 2 branches
-    assert lib.ladiff_reverse_plan(0, 5, None, 0, 1, 1, None, None) != 0
+    assert lib.ladiff_reverse_plan(0, 5, None, 0, 1, 1, 1, None, None) != 0
+    # without guidance (ladiff.py:472-490): one-branch 16-row blocks, half as many; with device-only counts there is no plan
+    assert plan(uniform, 1, cfg=0) == (16, 43) and plan(uniform, 3, cfg=0) == (16, 43)
+    rows, nb = ctypes.c_int(0), ctypes.c_int(0)
+    assert lib.ladiff_reverse_plan(4, 5, None, 1, 1, 1, 0, ctypes.byref(rows), ctypes.byref(nb)) == -4
+
+
+def test_product_library_has_no_garbage_result_kernels(lib):
+    """the timing builds of the decoder kernels (results are garbage) live in the diagnostic twin only.  The product
+    library rejects their selector values and exports no process-wide fault switch."""
+    import ctypes
+    for v in (0, 1, 2, 3):
+        assert lib.ladiff_debug_set_mlp_variant(v) == 0
+    for v in (-1, 4, 11, 17, 21, 26, 27):
+        assert lib.ladiff_debug_set_mlp_variant(v) == -1
+    assert lib.ladiff_debug_set_mlp_variant(0) == 0
+    raw = ctypes.CDLL(lib._name)
+    assert not hasattr(raw, "ladiff_debug_set_pipeline_fault") and not hasattr(raw, "ladiff_debug_set_stamps")
+    assert hasattr(raw, "ladiff_sampler_set_fault")
 
 
 def test_argument_errors_do_not_touch_the_gpu(lib):

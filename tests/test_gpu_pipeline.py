@@ -271,12 +271,17 @@ def test_aborted_pipeline_launch_raises_poisons_and_recovers(nets):
     lens = [196, 60, 120, 100, 48, 150, 196, 30, 77, 196, 13]
     B = len(lens)
     text, noise = syn.text_embeddings(B, seed=41), syn.init_noise(lens, seed=42)
-    good = _fault_pipe(nets)._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV))
+    clean = _fault_pipe(nets)
+    good = clean._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV))
     pipe = _fault_pipe(nets)
+    fb = wp = None
     try:
-        assert L.ladiff_debug_set_pipeline_fault(17, 20) == 0          # workgroup 17 of 255 leaves at once; waits time out after 20 ms
+        pipe.set_pipeline_fault(17, 20)                                # workgroup 17 of 255 leaves at once; waits time out after 20 ms
         z = pipe._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV))
         assert torch.isnan(z).all()                                    # poisoned, not "plausible garbage"
+        # the fault is a property of THAT object's samplers: another one in the same process runs clean meanwhile
+        assert torch.equal(clean._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV)), good)
+        clean.check()
         with pytest.raises(_lib.LadiffHipError, match="abandoned"):
             pipe.check()
         pipe.check()                                                   # reported once
@@ -285,6 +290,7 @@ def test_aborted_pipeline_launch_raises_poisons_and_recovers(nets):
             pipe._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV))
         # fallback=True: the same call is re-run launch-per-stage in this process and matches the oracle
         fb = _fault_pipe(nets, fallback=True)
+        fb.set_pipeline_fault(17, 20)
         zf = fb._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV))
         assert fb.fallback_count == 1 and torch.isfinite(zf).all()
         assert (zf - good).abs().max().item() < 2e-4 * max(1.0, good.abs().max().item())     # launches vs pipeline: summation order only
@@ -293,12 +299,15 @@ def test_aborted_pipeline_launch_raises_poisons_and_recovers(nets):
         den, vae = nets
         wp = LADIFF(denoiser=den, vae=vae, scheduler=DDPMScheduler(variance_type="fixed_small", **SCHED_KW), guidance_scale=7.5,
                     num_inference_timesteps=200, eta=0.0, max_it=5, precision="bf16x3", loop="pipeline")
+        wp.set_pipeline_fault(17, 20)
         zw = wp._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV), step_noise=sn)
         assert torch.isnan(zw).all() and wp.loop_status()[0] == 2
         with pytest.raises(_lib.LadiffHipError):
             wp.check()
     finally:
-        assert L.ladiff_debug_set_pipeline_fault(-1, 0) == 0
+        for o in (pipe, fb, wp):
+            if o is not None:
+                o.set_pipeline_fault(-1, 0)
     # fault removed: clean, and the same bits as the run that never failed
     z2 = pipe._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV))
     pipe.check()
@@ -317,10 +326,10 @@ def test_fallback_result_matches_oracle(nets):
     text, noise = syn.text_embeddings(3, seed=43), syn.init_noise(lens, seed=44)
     fb = _fault_pipe(nets, fallback=True)
     try:
-        assert L.ladiff_debug_set_pipeline_fault(100, 20) == 0
+        fb.set_pipeline_fault(100, 20)
         z, feats = fb.sample(text.to(DEV), lens, init_noise=noise.to(DEV))
     finally:
-        L.ladiff_debug_set_pipeline_fault(-1, 0)
+        fb.set_pipeline_fault(-1, 0)
     assert fb.fallback_count == 1
     z_o, f_o = orc.sample_motions(syn.denoiser_weights(), syn.vae_weights(263), text, lens, noise, 8, "ddim")
     assert (feats.cpu() - f_o).abs().max().item() < 1e-3
