@@ -1083,6 +1083,7 @@ struct OutRole {
                             for (int k = 0; k < 4; ++k) res[k] = ld_sc1(rx, base + erow * 1024 + (64 * k + ec) * 4);
                         }
                     }
+                    SYS_STAMP(6);
                     f32x4 v[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -1093,6 +1094,7 @@ struct OutRole {
                     }
                     float mean, rstd;
                     row_stats16(v, mean, rstd);
+                    SYS_STAMP(7);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
 #pragma unroll
@@ -1434,14 +1436,17 @@ struct StylRole {
             }
             tile_put4<AR, 4>(atile, lr, c, v);                           // u row -> operand tile (unused rows: zero)
         }
+        SYS_STAMP(3);
         mid.before_barrier();
         __syncthreads();
         mid.after_barrier();
+        SYS_STAMP(6);
         f32x4 acc[1][NTW];
         zero_acc(acc);
         mma<AR, 4, NTW, 8, 1>(atile, wf, acc);
         stage_c(ct, acc, [&](int j) { return 16 * NTW * wave + 16 * j; });
         __syncthreads();
+        SYS_STAMP(7);
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
             const int lr = wave + NW * q, row = g.row[q];

@@ -67,7 +67,8 @@ for i, n in enumerate(names):
     if r[1] == 0: continue
     if any(k in n for k in ("QKV0", "OUT", "LIN0", "RED2.0", "FFN0", "STYL.0", "SKIP0", "TAIL0")) or (len(sys.argv) > 4 and n.startswith(sys.argv[4])):
         f = lambda v: f"{v - t0:10.2f}" if v > 0 else f"{'-':>10s}"
-        print(f"{n:12s} {f(r[1])} {f(r[2])} {f(r[3])} {f(r[4])} {f(r[5])}   {r[5] - r[1] if r[5] > 0 else r[4] - r[1]:6.2f}")
+        print(f"{n:12s} {f(r[1])} {f(r[2])} {f(r[3])} {f(r[4])} {f(r[5])}   {r[5] - r[1] if r[5] > 0 else r[4] - r[1]:6.2f}"
+              "   since rows valid: " + " ".join(f"{j}:{r[j] - r[1]:5.2f}" for j in (2, 3, 6, 7, 4, 5) if r[j] > 0))
 lap = t[tail, step, blk, 4] - t0
 print(f"one step of one block: {lap:.1f} us over {59} hops = {lap / 59:.2f} us per hop")
 

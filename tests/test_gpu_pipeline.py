@@ -350,3 +350,56 @@ def test_pipeline_without_guidance_matches_launches(nets, precision, tol, B, T):
         c = -(-l // 48)
         if c < T:
             assert zb[c:, i].abs().max().item() == 0
+
+
+# ---------------------------------------------------------------- round 4: the tagged hand-off against the flag protocol
+def _with_handoff(tagged, fn):
+    from ladiff_amd import _lib
+    L = _lib.lib()
+    assert L.ladiff_debug_set_handoff(1 if tagged else 0) == 0
+    try:
+        return fn()
+    finally:
+        L.ladiff_debug_set_handoff(1)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("B,T,steps,guidance", [
+    (1, 5, 3, 7.5), (3, 5, 2, 7.5), (7, 5, 5, 7.5), (43, 5, 6, 7.5),      # one unit, padding rows in every tile, an odd step count
+    (5, 1, 4, 7.5), (9, 2, 4, 7.5), (5, 8, 3, 7.5),                        # 1 ... 8 latent rows per prompt: blocks with idle waves and 16 live rows
+    (130, 5, 4, 7.5),                                                     # 88 blocks: ring back-pressure and look-ahead are on
+    (7, 5, 5, 1.0), (40, 5, 3, 1.0),                                      # no guidance: a block is a unit of its own
+])
+def test_tagged_handoff_gives_the_flag_protocol_s_bits(nets, precision, B, T, steps, guidance):
+    """The parity-tagged hand-off (rows carry the step's parity in the last mantissa bit of every word, consumers load until every word
+    shows it: no drain, no flag, no poll round trip) must give the SAME BITS as the flag protocol: both store the canonical value (bit
+    cleared) and sum in the same order.  A consumer that ever computed on a stale, torn or half-written word would differ."""
+    lens = [max(1, min(196, 48 * ((i % T) + 1) - 5 * (i % 3))) for i in range(B)]
+    zf = _with_handoff(False, lambda: run(nets, "pipeline16", precision, B, T, steps, lens, guidance=guidance))
+    zt = _with_handoff(True, lambda: run(nets, "pipeline16", precision, B, T, steps, lens, guidance=guidance))
+    assert torch.isfinite(zt).all() and torch.equal(zf, zt)
+
+
+def test_tagged_handoff_ddpm_windows_and_replays(nets):
+    """A 200-step DDPM schedule = four launches of 50 steps (the hand-off buffers start every launch at parity 1), then ten replays of a
+    50-step DDIM call: identical bits to the flag protocol, identical from call to call."""
+    B, T = 11, 5
+    lens = [196, 60, 120, 100, 48, 150, 196, 30, 77, 196, 13]
+    sn = syn.ddpm_noise(200, B, seed=5).to(DEV)
+    zf = _with_handoff(False, lambda: run(nets, "pipeline16", "bf16x3", B, T, 200, lens, sched="ddpm", step_noise=sn))
+    zt = _with_handoff(True, lambda: run(nets, "pipeline16", "bf16x3", B, T, 200, lens, sched="ddpm", step_noise=sn))
+    assert torch.equal(zf, zt)
+    first = run(nets, "pipeline16", "bf16x3", B, T, 50, lens)
+    for _ in range(10):
+        assert torch.equal(run(nets, "pipeline16", "bf16x3", B, T, 50, lens), first)
+
+
+def test_tagged_handoff_full_batch_soak(nets):
+    """128 prompts x 50 steps x 30 calls through the tagged hand-off (86 blocks x 59 hops x 50 steps x 30 = 7.6 million tile hand-offs, ~1.2e11
+    tagged words) while alternating with the flag protocol: every call bit-identical to the first."""
+    B, T = 128, 5
+    lens = [196] * B
+    ref = _with_handoff(False, lambda: run(nets, "pipeline16", "bf16x3", B, T, 50, lens))
+    for i in range(30):
+        z = _with_handoff(i % 5 != 4, lambda: run(nets, "pipeline16", "bf16x3", B, T, 50, lens))
+        assert torch.equal(z, ref), f"call {i} differs"
