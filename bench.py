@@ -117,6 +117,11 @@ CONFIGS = {
                metric="motions/sec (c5: mixed {60,120,196} frames, KIT 251-dim, 50-step DDIM, bs128 per GPU)", tag="ddim50_cfg7.5_mixed"),
 }
 CONFIGS["c4"] = dict(CONFIGS["headline"])          # B = 1024 over 8 GPUs = the default workload at --gpus 8
+# What the reference itself times (`self.times`, ladiff.py:253-306; demo.py:308-327): prompts -> joints.  Token ids (the tokenizer is
+# host string work) -> CLIP ViT-L/14 text tower on the B empty + B real prompts of the guidance batch (mld_clip.py:51-78) -> the loop ->
+# decode -> feats2joints on the device (HumanML3D.py:44-48).  Random-init CLIP weights of the full geometry (12 layers, 49408 tokens).
+CONFIGS["e2e"] = dict(batch=128, frames=196, nfeats=263, sched="ddim", steps=50, lens="uniform", decode_only=False, e2e=True,
+                      metric="motions/sec (e2e: token ids -> CLIP -> 50-step DDIM -> decode -> joints, 196 frames, bs128)", tag="e2e_ddim50_cfg7.5")
 
 
 def ref_flops_per_motion(F=FRAMES, C=NFEATS, n_steps=STEPS_DDIM):
@@ -179,6 +184,22 @@ class Workload:
         self.step_noise = None
         self.z_in = None
         self.gather_buf = None
+        self.e2e = bool(cfg.get("e2e"))
+        self.stage_ev = None           # e2e: events between the stages of the last pass (text | loop | decode | joints)
+        if self.e2e:
+            from ladiff_amd.text_encoder import MldTextEncoder
+            from ladiff_amd.feats2joints import Feats2Joints
+            # guidance batch of token ids: B empty prompts, then this rank's B prompts of <= 30 words (global draw, sliced)
+            gids = syn.clip_token_ids(2 * self.total, empty_first=self.total)
+            self.ids_cpu = torch.cat([gids[:self.total][self.lo:self.hi], gids[self.total:][self.lo:self.hi]])
+            self.ids = self.ids_cpu.to(dev)
+            self.clip_sd = syn.clip_weights()
+            enc = MldTextEncoder(precision="bf16x3")
+            enc.text_model.load_state_dict(self.clip_sd, strict=True)
+            self.text_encoder = enc.to(dev).eval()
+            rs = torch.Generator().manual_seed(77)
+            self.mean, self.std = torch.randn(cfg["nfeats"], generator=rs) * 0.5, torch.rand(cfg["nfeats"], generator=rs) + 0.5
+            self.f2j = Feats2Joints(self.mean, self.std, 22)
         if cfg["sched"] == "ddpm":
             # per-step noise of the GLOBAL batch, drawn on the device from one seed and sliced (655 MB per 128 prompts: resident)
             g = torch.Generator(device=dev) if torch.device(dev).type == "cuda" else torch.Generator()
@@ -196,6 +217,23 @@ class Workload:
             self.gather_buf = torch.empty(world * bmax, max(self.glens), cfg["nfeats"], device=dev)
 
     def one_pass(self, pipe):
+        if self.e2e:
+            st = torch.cuda.current_stream(self.dev)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            ev[0].record(st)
+            self.text_encoder.precision = pipe.precision
+            text = self.text_encoder.encode_ids(self.ids).unsqueeze(1)                     # [2B, 1, 768]
+            ev[1].record(st)
+            z = pipe._diffusion_reverse(text, self.lens, init_noise=self.noise)
+            ev[2].record(st)
+            feats = pipe.vae.decode(z, self.lens)
+            ev[3].record(st)
+            joints = self.f2j(feats)                                                       # [B, F, 22, 3]: what crosses PCIe in forward()
+            ev[4].record(st)
+            self.stage_ev, self.last_feats, self.last_joints = ev, feats, joints
+            if self.use_dist:
+                joints = D.gather_feats(joints.reshape(self.B, joints.shape[1], 66), self.total, self.world, lengths=self.glens)
+            return joints
         if self.cfg["decode_only"]:
             feats = pipe.vae.decode(self.z_in, self.lens)
         else:
@@ -214,6 +252,24 @@ class Workload:
         idx = sorted({0, B // 3, (2 * B) // 3, B - 1})[:n_prompts]
         sub_lens = [self.lens[i] for i in idx]
         vae_sd = syn.vae_weights(cfg["nfeats"])
+        if self.e2e:
+            # the whole chain on the CPU: CLIP tower -> loop -> decode -> recover_from_ric.  The GATE is north_star's: the decoded frames
+            # (this rank's, kept from the last pass).  The joints integrate root velocities over the frames (two cumulative sums), so their
+            # difference is reported relative to the joints' magnitude, for information (self.joints_rel_err).
+            with torch.no_grad():
+                ids = torch.cat([self.ids_cpu[:B][idx], self.ids_cpu[B:][idx]])
+                text_o = orc.clip_text_features(self.clip_sd, ids, 12).unsqueeze(1)
+                _, f_o = orc.sample_motions(syn.denoiser_weights(), vae_sd, text_o, sub_lens, self.noise_cpu[idx], cfg["steps"], cfg["sched"])
+                j_o = orc.feats2joints(f_o, self.mean, self.std, 22)
+            jm, fm = self.last_joints.cpu(), feats.cpu()                  # this rank's joints / frames of the pass `feats` came from
+            err, jerr, jmag = 0.0, 0.0, 1e-30
+            for j, i in enumerate(idx):
+                l = self.lens[i]
+                err = max(err, (fm[i, :l].double() - f_o[j, :l].double()).abs().max().item())
+                jerr = max(jerr, (jm[i, :l].double() - j_o[j, :l].double()).abs().max().item())
+                jmag = max(jmag, j_o[j, :l].abs().max().item())
+            self.joints_rel_err = jerr / jmag
+            return err, idx
         with torch.no_grad():
             if cfg["decode_only"]:
                 f_o = orc.vae_decode(vae_sd, self.z_cpu[:, idx], sub_lens)
@@ -330,10 +386,20 @@ def cpu_baseline(cfg, sample_b):
             sn = syn.ddpm_noise(cfg["steps"], sample_b) if cfg["sched"] == "ddpm" else None
             warm = torch.cat([text[:2], text[sample_b:sample_b + 2]])
             orc.sample_motions(den_sd, vae_sd, warm, lens[:2], noise[:2], 2, "ddim")   # warm-up (threads, allocator)
+            e2e = bool(cfg.get("e2e"))
+            if e2e:
+                ids, clip_sd = syn.clip_token_ids(2 * sample_b, empty_first=sample_b), syn.clip_weights()
+                g = torch.Generator().manual_seed(77)
+                mean, std = torch.randn(cfg["nfeats"], generator=g) * 0.5, torch.rand(cfg["nfeats"], generator=g) + 0.5
             t0 = time.perf_counter()
-            orc.sample_motions(den_sd, vae_sd, text, lens, noise, cfg["steps"], cfg["sched"], step_noise=sn)
+            if e2e:          # as the reference: every row of the guidance batch through the text tower (mld_clip.py:75), all 77 positions
+                text = orc.clip_text_features(clip_sd, ids, 12).unsqueeze(1)
+            _, f_o = orc.sample_motions(den_sd, vae_sd, text, lens, noise, cfg["steps"], cfg["sched"], step_noise=sn)
+            if e2e:
+                orc.feats2joints(f_o, mean, std, 22)
             dt = time.perf_counter() - t0
-            what = f"{sample_b} motions, lengths {sorted(set(lens))}, {cfg['steps']}-step {cfg['sched'].upper()} + decode"
+            what = (f"{sample_b} motions, lengths {sorted(set(lens))}, " + ("CLIP text tower + " if e2e else "") +
+                    f"{cfg['steps']}-step {cfg['sched'].upper()} + decode" + (" + feats2joints" if e2e else ""))
     return {"value": sample_b / dt, "unit": "motions/s", "cores": torch.get_num_threads(), "kind": "port",
             "host_cpus": os.cpu_count(), "measured_in_this_run": True,
             "sample": f"{what}, fp32 PyTorch CPU oracle, {dt:.1f} s"}
@@ -345,7 +411,8 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="timed passes (default 10; 3 for c3)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed passes (default 3; 1 for c3)")
     ap.add_argument("--config", default="headline", choices=sorted(CONFIGS),
-                    help="BASELINE.json configuration (default: the headline metric's workload = c4's per-rank slice)")
+                    help="BASELINE.json configuration (default: the headline metric's workload = c4's per-rank slice); e2e = what the "
+                         "reference itself times: token ids -> CLIP text tower -> loop -> decode -> joints, per-stage device times")
     ap.add_argument("--batch", type=int, default=None, help="prompts per GPU (default: the config's)")
     ap.add_argument("--cpu-sample", type=int, default=None, help="motions in the CPU-baseline sample (0 = skip; default per config)")
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"],
@@ -401,6 +468,8 @@ def main():
             warm = None
             for _ in range(w):
                 warm = wl.one_pass(pipe)
+            if wl.e2e and warm is not None:
+                warm = wl.last_feats
             warm = None if warm is None else warm.clone()
             fence()
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -414,9 +483,13 @@ def main():
         tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
         if use_dist:
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        if wl.e2e:          # parity is judged on this rank's decoded FRAMES (the joints integrate them); stage times of the last pass
+            feats = wl.last_feats
+            wl.stage_ms = [wl.stage_ev[i].elapsed_time(wl.stage_ev[i + 1]) for i in range(4)]
         return float(tmax.item()), ev0.elapsed_time(ev1), feats.clone(), warm
 
     wall, dev_ms, feats, warm = timed(args.precision, steps, warmup)
+    stage_ms = getattr(wl, "stage_ms", None)          # e2e: of the timed mode (the other mode runs later)
     # ---- checks, outside the timed region
     if not cfg["decode_only"]:
         pipe.check()                                   # raises when the pipeline loop of the last pass was abandoned
@@ -493,6 +566,16 @@ def main():
                        "scheduler": cfg["sched"], "denoising_steps": n_steps, "parallelism": f"dp{world}", "loop": loop_desc},
             "roofline": whole,
         }
+        if wl.e2e and stage_ms is not None:
+            names = ["clip_text_tower", "reverse_loop_with_prologue", "vae_decode", "feats2joints"]
+            ms = stage_ms
+            tot = sum(ms)
+            line["stages"] = {"device_ms_last_pass": {n: round(v, 3) for n, v in zip(names, ms)},
+                              "share_of_pass": {n: round(v / tot, 4) for n, v in zip(names, ms)},
+                              "note": "HIP events between the stages of the last timed pass; token ids in HBM -> joints [B,F,22,3] in HBM "
+                                      "(tokenising is host string work and not part of it; reference: ladiff.py:253-306 self.times). "
+                                      "CLIP: 12-layer ViT-L/14 text tower, random-init, B empty prompts encoded once + B prompts of <= 30 words, "
+                                      "positions behind the last EOS skipped (exact under the causal mask)"}
         if o is not None:
             o_steps, o_wall, o_dev_ms, mode_diff = o
             o_tf = B * ref_f / (o_dev_ms / 1e3 / o_steps) / 1e12
@@ -503,6 +586,9 @@ def main():
                                   "roofline_note": "reference-equivalent FLOPs (SURVEY.md §8d), not executed FLOPs"}
         line["parity"] = {"max_abs_diff_frames_vs_oracle": oracle_err, "oracle_prompts": oracle_idx, "tolerance": FRAME_TOL,
                           "timed_pass_equals_warmup_pass": identical,
+                          "oracle_compares": ("decoded frames [F,C] of the CPU chain CLIP -> loop -> decode (the gate); joints reported beside" if wl.e2e
+                                              else "decoded frames [F,C]"),
+                          "max_rel_diff_joints_vs_oracle": getattr(wl, "joints_rel_err", None),
                           "max_abs_diff_frames_between_modes": o[3] if o is not None else None,
                           "note": "prompts of the timed batch against the CPU oracle, computed after the timed region; "
                                   "fp32 mode is within 1e-4 of the reference goldens, bf16x3 within 5e-4 (tests/test_gpu_path.py)"}
@@ -532,7 +618,7 @@ def main():
             if sample is None:
                 # ~10 - 30 s of CPU work on the GPU box's host (16 threads there run ~19 motions/s of 50-step DDIM, 0.23 motions/s of
                 # 1000-step DDPM; the decode-only sample repeats for 10 s)
-                sample = {"c1": 8, "c3": 4}.get(args.config, 256)
+                sample = {"c1": 8, "c3": 4, "e2e": 64}.get(args.config, 256)
             if sample > 0:
                 line["cpu_baseline"] = cpu_baseline(cfg, sample)
                 line["cpu_baseline"]["gpu_over_cpu"] = round(motions_per_s / line["cpu_baseline"]["value"], 1)
