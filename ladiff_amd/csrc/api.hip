@@ -98,12 +98,19 @@ struct Sampler {
     std::vector<hipGraphExec_t> retired;  // replaced while a launch of them could still be queued: destroyed at the next drain
 };
 
-// A graph is only replayed while it is the NEWEST graph instantiation of the process.  Seen on ROCm 7.2 / MI355X
-// (scripts/repro_seq.py, tests/test_gpu_pipeline.py::test_old_step_graph_is_not_replayed_after_other_plans): the step graph of one
-// sampler (~150 kernel nodes), replayed after two OTHER samplers had instantiated their graphs and a blocking hipMemcpy had run in
-// between, dispatched kernels with garbage pointer arguments (memory access fault; every pointer the nodes were captured with was
-// still alive, and the same sequence without graphs is clean).  Whatever the runtime does to an older exec's argument storage,
-// re-instantiating costs a few hundred microseconds and only happens when samplers alternate.
+// Graph replay and the round-3 memory fault.  Seen on ROCm 7.2 / MI355X (scripts/repro_seq.py, scripts/repro_graph.py): the graphs of one
+// sampler, replayed after two OTHER samplers had instantiated theirs and a blocking hipMemcpy had run in between, faulted at a wild
+// address (MEMORY_APERTURE_VIOLATION / an address in the host heap's range), every captured pointer still alive.  Round 4 bisected it
+// (profiles/r4/06_*): with the rule below switched off the fault reproduces every time; it goes away when the prologue graph's ONE
+// memset node (hipMemsetAsync of the 16-byte step counter) is issued outside the graph, and stays away with every KERNEL node of both
+// graphs replayed from the old execs.  So: an older exec's MEMSET NODE is what the runtime replays wrongly after newer instantiations
+// - kernel nodes (by-value argument blocks up to 3.8 KB, 300 nodes) are fine, also in a library-free program
+// (scripts/repro_graph_args.hip: clean in every configuration, the memset-node case included - the trigger needs more than that
+// program has, and was not reduced further).  Fix: NOTHING captured by this library is a memset node any more (launch_zero_fill
+// kernels: the step counter in the prologue graph, the ragged decode's output clear); tests/test_gpu_pipeline.py replays old execs on
+// purpose (LADIFF_GRAPH_EPOCH_OFF) and gets identical bits.  The rule stays as a second line, cheap (a few hundred microseconds when
+// samplers alternate): a graph is replayed only while it is the newest instantiation of THIS library; instantiations by other
+// components of the process (torch CUDA graphs, RCCL) do not count - they were never implicated (scripts/repro_graph.py 'graphs').
 std::atomic<uint64_t> g_graph_epoch{0};
 
 void drain_retired(Sampler* sp) {            // call with the stream drained
@@ -518,7 +525,9 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
         if (n_text > 1) LADIFF_TRY(denoiser_text_cache(W, text_emb, B2, r.tables, n_steps, r.cache, r.fwd, r.fwd_floats, st, n_text));
         else LADIFF_TRY(denoiser_text_static(W, text_emb, B2, r.cache, r.fwd, r.fwd_floats, st));      // the c table: per window, below
         LADIFF_TRY(launch_init_latents(init_noise, counts, init_noise_sigma, r.latents, B, T, st));
-        LADIFF_HIP(hipMemsetAsync(r.d_step, 0, 4 * sizeof(int32_t), st));      // [0] step index, [1] tail-kernel ticket, [2] window base
+        // [0] step index, [1] tail-kernel ticket, [2] window base.  A KERNEL, not hipMemsetAsync: this runs inside the captured prologue
+        // graph, and a memset NODE is what an older exec replayed wrongly (see g_graph_epoch)
+        LADIFF_TRY(launch_zero_fill(reinterpret_cast<float*>(r.d_step), 4, st));
         // One step = the nine denoiser layers + ONE tail launch (final LayerNorm of the guidance branches, guidance,
         // scheduler step, next step's network input, step counter).  The network input / last-layer output buffer of the
         // forward workspace is primed here.
@@ -560,7 +569,9 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
         const bool same = sp->setup && std::memcmp(kp, sp->key_ptrs, sizeof(kp)) == 0 &&
                           std::memcmp(ki, sp->key_ints, sizeof(ki)) == 0 && std::memcmp(kf, sp->key_f, sizeof(kf)) == 0 &&
                           h == sp->key_hash && weights_generation == sp->key_gen;
-        const bool newest = sp->epoch == g_graph_epoch.load();      // nothing else has been instantiated since (g_graph_epoch)
+        // LADIFF_GRAPH_EPOCH_OFF (test aid): trust an older exec, as tests/test_gpu_pipeline.py does to show that the graphs - kernel
+        // nodes only since round 4 - replay correctly however old they are
+        const bool newest = sp->epoch == g_graph_epoch.load() || std::getenv("LADIFF_GRAPH_EPOCH_OFF") != nullptr;
         if (!same || !newest) {
             if (!same) {
                 // replays of the old graphs may still be queued (the host never paces the GPU): drain before destroying them
@@ -804,9 +815,8 @@ int ladiff_vae_decode_graphed(void* graph, const float* const* w, const float* c
         hipGraph_t gr = nullptr;
         LADIFF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         int rc = 0;
-        if (row_off != nullptr) {
-            const hipError_t em = hipMemsetAsync(feats, 0, (size_t)B * F * C * sizeof(float), s);
-            if (em != hipSuccess) rc = (int)em;
+        if (row_off != nullptr) {      // inside the capture: a zero-fill KERNEL, never a memset node (g_graph_epoch)
+            rc = launch_zero_fill(feats, (size_t)B * F * C, s);
         }
         if (rc == 0) rc = vae_decode(W, w_split ? &WS : nullptr, z, lengths, counts, row_off, total_rows, B, F, T, C, feats, (float*)ws,
                                      ws_bytes / sizeof(float), s);

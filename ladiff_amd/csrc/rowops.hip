@@ -376,6 +376,21 @@ int launch_relu(const float* x, float* y, size_t n, hipStream_t s) {
     return 0;
 }
 
+// x[0 .. n) = 0 (x 16-byte aligned).  For everything that runs INSIDE a captured graph: a hipMemsetAsync there becomes a memset
+// node, and the memset node of an older graph exec is what faulted in round 3 (api.hip, g_graph_epoch) - kernel nodes do not.
+__global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ x, size_t n4, int tail) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) st4(x + i * 4, f32x4{0.f, 0.f, 0.f, 0.f});
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) x[n4 * 4 + threadIdx.x] = 0.f;
+}
+int launch_zero_fill(float* x, size_t n, hipStream_t s) {
+    if (n == 0) return 0;
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n4 + 255) / 256 > 0 ? (n4 + 255) / 256 : 1)), dim3(256), 0, s, x, n4, (int)(n % 4));
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
 // y = silu(x), flat
 __global__ __launch_bounds__(256) void silu_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n4) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

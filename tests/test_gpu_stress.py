@@ -42,3 +42,16 @@ def test_random_sample_sequences_on_one_object():
     second object on the fp32 launch-per-stage path."""
     out = _run("stress_sample.py", 60, 29)
     assert "60 sample() cases done, 0 bad" in out
+
+
+def test_old_graph_execs_replay_correctly_without_the_epoch_rule():
+    """The round-3 fault, bisected in round 4 (api.hip, g_graph_epoch; profiles/r4/06_*): an OLDER exec's memset node was what the runtime
+    replayed wrongly.  No graph of this library holds a memset node any more, so the formerly failing sequence - plan A, two other plans
+    with blocking status reads in between, plan A again from its old execs - must be clean with the re-instantiation rule switched OFF."""
+    env = dict(os.environ, LADIFF_GRAPH_EPOCH_OFF="1", STATUS="1")
+    for _ in range(2):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "repro_graph.py"), "plans"], cwd=ROOT, capture_output=True, text=True,
+                           timeout=300, env=env)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("ok ")]
+        assert r.returncode == 0 and len(lines) == 4, (r.stdout + r.stderr)[-600:]
+        assert lines[0] == lines[3]                                   # plan A's result: the same before and after the other plans
