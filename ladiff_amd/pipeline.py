@@ -194,7 +194,9 @@ class LADIFF(nn.Module):
             "text": torch.empty(2 * B, n_text, 768, dtype=torch.float32, device=dev), "n_text": n_text,
             "noise": torch.empty(B, T, 256, dtype=torch.float32, device=dev),
             "counts": torch.empty(B, dtype=torch.int32, device=dev),
-            "step_noise": torch.empty(n_steps, B, T, 256, dtype=torch.float32, device=dev) if need_noise else None,
+            # per-step noise (DDPM / eta > 0): the CALLER's tensor is used in place when it is a contiguous fp32 tensor on this device
+            # (1000 steps x 128 prompts are 655 MB: not held twice, not copied per call); otherwise a plan-owned copy, made on first need
+            "step_noise": None,
             "z": torch.empty(T, B, 256, dtype=torch.float32, device=dev),
             "ws": _lib.workspace(wsb, dev), "ws_bytes": wsb,
             "tables_key": None,      # weights the time tables inside `ws` were built from
@@ -316,6 +318,17 @@ class LADIFF(nn.Module):
             init_noise = torch.randn(B, T, 256, device=dev, dtype=torch.float32)       # ladiff.py:380-385
         if need_noise and step_noise is None:
             step_noise = torch.randn(n, B, T, 256, device=dev, dtype=torch.float32)
+        noise_t = None
+        if need_noise:
+            if tuple(step_noise.shape) != (n, B, T, 256):
+                raise ValueError(f"step_noise {tuple(step_noise.shape)} for a schedule of {n} steps x {B} prompts x {T} latents")
+            big = step_noise.numel() * 4 >= (64 << 20)             # a new pointer re-captures the prologue graph (~1 ms): worth it for big tensors only
+            if big and step_noise.is_cuda and step_noise.device == dev and step_noise.dtype == torch.float32 and step_noise.is_contiguous():
+                noise_t = step_noise                                   # in place: the loop only reads it, on this call's stream
+            else:
+                if plan["step_noise"] is None:
+                    plan["step_noise"] = torch.empty(n, B, T, 256, dtype=torch.float32, device=dev)
+                noise_t = plan["step_noise"]
         wt = self.denoiser._weight_table()
         cur = torch.cuda.current_stream(dev)
         # hipStreamBeginCapture is illegal on the null stream: run on the caller's stream when it is a real
@@ -338,7 +351,7 @@ class LADIFF(nn.Module):
                 # ladiff_denoiser.py:254) - but the final zeroing of ladiff.py:559-566 has no such switch
                 None if self.test_efficiency else plan["counts"].data_ptr(), plan["counts"].data_ptr(),
                 None if self.test_efficiency else (ctypes.c_int32 * B)(*counts),       # host copy: length-aware block packing
-                _lib.ptr(plan["sinus"]), _lib.ptr(plan["coef"]), _lib.ptr(plan["step_noise"]) if need_noise else None,
+                _lib.ptr(plan["sinus"]), _lib.ptr(plan["coef"]), _lib.ptr(noise_t) if need_noise else None,
                 self.guidance_scale, float(sch.init_noise_sigma), 1 if cfg else 0, B, T, n_text, n, _lib.ptr(plan["z"]),
                 _lib.ptr(plan["ws"]), plan["ws_bytes"], 1 if plan["tables_key"] == wt.key else 0, run.cuda_stream))
             plan["tables_key"] = wt.key
@@ -356,8 +369,8 @@ class LADIFF(nn.Module):
             plan["text"][:dup * B].copy_(encoder_hidden_states.reshape(dup * B, n_text, 768))
             plan["noise"].copy_(init_noise)
             plan["counts"].copy_(_lib.device_ints(counts, dev))       # device-to-device: the graph bakes plan["counts"] in
-            if need_noise:
-                plan["step_noise"].copy_(step_noise)
+            if need_noise and noise_t is not step_noise:
+                noise_t.copy_(step_noise)
             enqueue(self.loop)
             if self.fallback and self.loop != "launches":
                 try:
