@@ -56,7 +56,7 @@ enum {
 enum { LADIFF_ACT_NONE = 0, LADIFF_ACT_RELU = 1, LADIFF_ACT_GELU = 2, LADIFF_ACT_SILU = 3, LADIFF_ACT_QGELU = 4 /* x*sigmoid(1.702x) */,
        LADIFF_ACT_LRELU = 5 /* LeakyReLU(0.2) */ };
 
-#define LADIFF_ABI_VERSION 3
+#define LADIFF_ABI_VERSION 4
 #define LADIFF_LATENT_DIM 256     /* model.latent_dim[-1], config_ladiff_humanml3d.yaml:132 */
 #define LADIFF_NUM_HEADS 4        /* configs/modules/denoiser.yaml:7 */
 #define LADIFF_NUM_LAYERS 9       /* configs/modules/denoiser.yaml:6, motion_vae.yaml:5 */
@@ -318,9 +318,10 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
 /* ------------------------------------------------------------------ LA-VAE decoder (LADiffVae.decode)
  * feats[B,F,C] from z[T,B,256]; frames >= lengths[b] come out zero.  ladiff_vae.py:288-362
  * (call site ladiff.py:283).  lengths/counts are int32 device arrays of B entries. */
-/* w_split (bf16x3 mode): the S-format copies of the weight matrices as for the denoiser, EXCEPT final_layer.weight and
- * final_layer.bias, which are padded with zero rows / zeros to ceil(C / 128) * 128 output features (384 for HumanML3D, 256 for KIT)
- * before the conversion: from 4,096 frame rows up the final projection runs on whole 128-column bf16x3 tiles. */
+/* w_split (bf16x3 mode): the S-format copies of the weight matrices as for the denoiser.  final_layer.weight needs its C rows only
+ * (ABI 4; ABI 3 asked for tables padded to ceil(C / 128) * 128 rows - such tables still work, the extra rows are not read): from 4,096
+ * frame rows up the final projection runs on whole 128-column bf16x3 tiles, and the library pads the rows it needs itself.  The bias is
+ * taken from the fp32 table `w`. */
 size_t ladiff_decoder_workspace_bytes(int B, int F, int T, int C);
 int ladiff_vae_decode(const float* const* w, const float* const* w_split /*or NULL: fp32 MFMA*/, const float* z,
                       const int32_t* lengths, const int32_t* counts, int B, int F, int T, int C, float* feats,

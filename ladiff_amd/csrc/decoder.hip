@@ -196,12 +196,15 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
     }
     // final_layer + zero padded frames, written as [B, F, C]   ladiff_vae.py:356-360
     if (sp && M >= DEC_SMALL_ROWS && g_dec_final_split) {
-        // bf16x3 mode: the projection runs on the large-M bf16x3 kernel over whole 128-column tiles - the S-format table carries
-        // final_layer.weight / .bias padded with zero rows to Np = ceil(C / 128) 128 features - into the (free) hidden buffer, and a row
-        // kernel moves the C real columns into [B, F, C] (zeroing padded frames / scattering ragged rows): 94 us -> ~40 us at 25088 rows
+        // bf16x3 mode: the projection runs on the large-M bf16x3 kernel over whole 128-column tiles, into the (free) hidden buffer, and a
+        // row kernel moves the C real columns into [B, F, C] (zeroing padded frames / scattering ragged rows): 94 us -> ~40 us at 25088
+        // rows.  The tiles need Np = ceil(C / 128) 128 weight rows: the library pads the caller's C rows ITSELF (a 1-KiB-per-row copy
+        // into the in_proj buffer, free by now) - a table of exactly C rows is never read past its end.
         const int Np = (C + 127) / 128 * 128;
-        if ((size_t)Np > (size_t)FF) return LADIFF_ERR_SHAPE;
-        GemmArgs g = lin(curs, D, wsp->final_layer.w, wsp->final_layer.b, hid, Np, M, Np, D);
+        if ((size_t)Np > (size_t)FF || (size_t)Np * (D + 1) > 3 * MD) return LADIFF_ERR_SHAPE;
+        float* wpad = qkv; float* bpad = qkv + (size_t)Np * D;
+        LADIFF_TRY(launch_pad_rows(wsp->final_layer.w, w.final_layer.b, wpad, bpad, C, Np, s));
+        GemmArgs g = lin(curs, D, wpad, bpad, hid, Np, M, Np, D);
         g.split = 1;
         LADIFF_TRY(launch_gemm(g, s));
         return launch_scatter_feats(hid, Np, C, M, F, ragged ? nullptr : lengths, ragged ? row_out : nullptr, feats, s);

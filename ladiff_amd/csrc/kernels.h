@@ -29,6 +29,7 @@ int launch_broadcast_pe(const float* pe, int B, int F, float* x, float* xs, hipS
 int launch_broadcast_pe_ragged(const float* pe, const int32_t* row_off, int B, int F, int F_out, float* x, float* xs, int32_t* row_out,
                                hipStream_t s);
 int launch_relu(const float* x, float* y, size_t n, hipStream_t s);
+int launch_pad_rows(const float* src, const float* srcb, float* dst, float* dstb, int C, int Np, hipStream_t s);
 int launch_zero_fill(float* x, size_t n, hipStream_t s);          // kernel, not a memset node (graphs: api.hip g_graph_epoch)
 int launch_silu(const float* x, float* y, size_t n, hipStream_t s);
 int launch_sinusoid(const int64_t* t, int n, float* out, hipStream_t s);

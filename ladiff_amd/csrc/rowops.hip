@@ -391,6 +391,22 @@ int launch_zero_fill(float* x, size_t n, hipStream_t s) {
     return 0;
 }
 
+// dst [Np][256] = src [C][256] followed by zero rows, dstb [Np] = srcb [C] followed by zeros: the decoder's final_layer brought to whole
+// 128-column GEMM tiles INSIDE the library (an S-format row is 1 KiB like an fp32 one, and zero rows are zero in both formats), so that a
+// caller's table of C rows is never read past its end
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, const float* __restrict__ srcb, float* __restrict__ dst,
+                                                       float* __restrict__ dstb, int C) {
+    const int r = blockIdx.x, t = threadIdx.x;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    if (t < 64) st4(dst + (size_t)r * D + 4 * t, r < C ? ld4(src + (size_t)r * D + 4 * t) : zero);
+    if (t == 64) dstb[r] = r < C ? srcb[r] : 0.f;
+}
+int launch_pad_rows(const float* src, const float* srcb, float* dst, float* dstb, int C, int Np, hipStream_t s) {
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(Np), dim3(256), 0, s, src, srcb, dst, dstb, C);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
 // y = silu(x), flat
 __global__ __launch_bounds__(256) void silu_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n4) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -54,8 +54,9 @@ def _get(ablation, name, default=None):
 class _HipModule(_ParamTree):
     _KIND = None
 
-    # S-format table only: tensors padded to whole 128-column GEMM tiles (include/ladiff_hip.h, ladiff_vae_decode)
-    _PAD_ROWS = {"decoder": {"final_layer.weight": 128, "final_layer.bias": 128}}
+    # S-format table only: tensors padded to a multiple of rows.  None since ABI 4: the decoder pads final_layer to whole 128-column GEMM
+    # tiles inside the library (include/ladiff_hip.h, ladiff_vae_decode), so the table carries exactly the module's rows
+    _PAD_ROWS = {}
 
     def _weight_table(self, kind=None):
         kind = kind or self._KIND
