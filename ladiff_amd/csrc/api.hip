@@ -812,6 +812,7 @@ int ladiff_vae_decode_graphed(void* graph, const float* const* w, const float* c
         if (dg->exec) { LADIFF_HIP(hipStreamSynchronize(s)); (void)hipGraphExecDestroy(dg->exec); dg->exec = nullptr; }
         LADIFF_TRY(dec_mlp_prepare());            // kernel attributes are set outside the capture
         LADIFF_TRY(dec_qkv_attn_prepare());
+        LADIFF_TRY(dec_cross_prepare());
         hipGraph_t gr = nullptr;
         LADIFF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         int rc = 0;

@@ -8,6 +8,7 @@
 // 4 T axpys of length 256 (20 kFLOP at T = 5) instead of two 256x256 projections (262 kFLOP), and the query / attention
 // output tensors ([B F, 256] each, written and re-read) never exist.  Before: q GEMM + cross-attention kernel + out GEMM +
 // LayerNorm kernel, 102 us per layer at B = 128, F = 196 (profiles/r2/03); now prep (per sample, 10 us) + apply.
+#include <mutex>
 #include "kernels.h"
 
 namespace ladiff {
@@ -181,6 +182,23 @@ __global__ __launch_bounds__(256) void dec_cross_apply_kernel(const float* __res
 
 size_t dec_cross_ws_floats(int B, int T) { return (size_t)B * H * T * (2 * D + 1); }
 
+// per-device kernel attribute (T = 8 needs 64.1 KiB of dynamic LDS): once per device, under a mutex, outside any stream capture
+// (the graphed decode calls it before it begins to capture)
+int dec_cross_prepare() {
+    static std::mutex mu;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    LADIFF_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return LADIFF_ERR_ARG;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!attr_set[dev]) {
+        LADIFF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cross_apply_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(((size_t)H * TM * 2 * D + H * TM) * sizeof(float))));
+        attr_set[dev] = true;
+    }
+    return 0;
+}
+
 // G | U | c of n layers at once (they depend on z and the weights only): pb.gu[l] holds dec_cross_ws_floats(B, T) floats
 int launch_decoder_cross_prep(const DecCrossPrepBatch& pb, int n, int B, int T, hipStream_t s) {
     if (B == 0 || n == 0) return 0;
@@ -205,12 +223,7 @@ int launch_decoder_cross_apply(const float* x, const float* bo, const float* g2,
     const int rows_per_wg = ((F + chunks - 1) / chunks + 15) / 16 * 16;
     chunks = (F + rows_per_wg - 1) / rows_per_wg;
     const size_t lds = ((size_t)H * T * 2 * D + H * T) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {           // T = 8 needs 64.1 KiB of dynamic LDS
-        LADIFF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cross_apply_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(((size_t)H * TM * 2 * D + H * TM) * sizeof(float))));
-        attr_set = true;
-    }
+    LADIFF_TRY(dec_cross_prepare());
 #define LADIFF_DC_CASE(TT)                                                                                                   \
     case TT:                                                                                                                 \
         hipLaunchKernelGGL(dec_cross_apply_kernel<TT>, dim3(B, chunks), dim3(256), lds, s, x, gu, cc, counts, bo, g2, b2, F, \

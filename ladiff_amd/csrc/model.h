@@ -47,6 +47,7 @@ extern std::atomic<int> g_dec_fused_attn;
 extern std::atomic<int> g_mlp_variant;
 int dec_mlp_prepare();           // per-device kernel attributes (dynamic LDS): outside any stream capture, under a mutex
 int dec_qkv_attn_prepare();
+int dec_cross_prepare();
 int dec_mlp_min_rows();
 size_t dec_ws_floats(int B, size_t rows, int T);
 int vae_decode(const DecoderW& w, const DecoderW* w_split, const float* z, const int32_t* lengths, const int32_t* counts,
