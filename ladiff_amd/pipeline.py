@@ -113,13 +113,16 @@ class LADIFF(nn.Module):
         self.precision = precision if precision is not None else getattr(self.denoiser, "precision", "fp32")
         # What happens when the persistent pipeline kernel abandons a call (a stage timed out on its producer: the GPU was shared with
         # another process, or a long kernel on another stream kept a CU busy).  The 8-byte status is copied to pinned host memory
-        # behind every call; it is read when the host next synchronises anyway (forward, t2m_eval, loop_ms, check()) and at the start
-        # of the NEXT call, and z is NaN in the meantime.  fallback=False: raise LadiffHipError.  fallback=True: the call waits for
+        # behind every call; it is read when the host next synchronises anyway (sample, forward, t2m_eval, loop_ms, check()), and a
+        # new call looks at its predecessor's words if they have arrived and waits only for the call before that (the host can queue
+        # one call ahead); z is NaN in the meantime.  fallback=False: raise LadiffHipError.  fallback=True: the call waits for
         # its own status and, when it aborted, runs again launch-per-stage in this process (same library, same arithmetic; counted
         # in `fallback_count`).
         self.fallback = bool(fallback)
         self.fallback_count = 0
-        self._pending = []            # (event, pinned status words, plan key) per launch of the last call, not yet looked at
+        self._pending = []            # (event, pinned status words, plan key, call number) per launch not yet looked at
+        self._call = 0                # number of the current `_diffusion_reverse` call
+        self._window_timing = False   # per-window events wanted (window_ms(enable=True)): applied to every sampler, also later ones
         self._fault = (-1, 0)         # fault injection of the abort-path tests: applied to every sampler of THIS object (set_pipeline_fault)
         self._stream = None
         self._plans = {}              # plan key -> persistent buffers + sampler (a few shapes stay cached: chunks, alternating batches)
@@ -158,7 +161,7 @@ class LADIFF(nn.Module):
 
     def __del__(self):
         try:
-            for ev, host, _ in self._pending:
+            for ev, host, _, _ in self._pending:
                 ev.synchronize()
                 if int(host[0]) != 0:
                     import warnings
@@ -208,6 +211,8 @@ class LADIFF(nn.Module):
             plan["sampler"] = h
             if self._fault != (-1, 0):
                 _lib.check(L.ladiff_sampler_set_fault(h, *self._fault))
+            if self._window_timing:
+                _lib.check(L.ladiff_sampler_set_window_timing(h, 1))
         # the pipeline kernel's {code, info} words inside the workspace, and where the host reads them
         off = L.ladiff_reverse_status_offset_bytes(B, T, n_steps, n_text)
         if off == 0 or off % 4:
@@ -232,15 +237,17 @@ class LADIFF(nn.Module):
             if plan.get("sampler") is not None:
                 _lib.check(_lib.lib().ladiff_sampler_set_fault(plan["sampler"], *self._fault))
 
-    def check(self, wait=True):
-        """Look at the status of the last `_diffusion_reverse` call: raises LadiffHipError when a pipeline loop of it was abandoned
-        (the returned z is NaN then).  wait=False only looks if the copies have already arrived.  Returns True when looked at."""
-        if not self._pending:
+    def check(self, wait=True, before=None):
+        """Look at the status of the `_diffusion_reverse` calls not looked at yet: raises LadiffHipError when a pipeline loop of one
+        was abandoned (the returned z is NaN then).  wait=False only looks if the copies have already arrived; `before` restricts
+        the look to calls numbered below it.  Returns True when everything asked for was looked at."""
+        mine = [e for e in self._pending if before is None or e[3] < before]
+        if not mine:
             return True
-        if not wait and not all(ev.query() for ev, _, _ in self._pending):
+        if not wait and not all(e[0].query() for e in mine):
             return False
-        pending, self._pending = self._pending, []
-        for ev, host, _ in pending:
+        self._pending = [e for e in self._pending if not (before is None or e[3] < before)]
+        for ev, host, _, _ in mine:
             ev.synchronize()
             code, info = int(host[0]), int(host[1])
             if code != 0:
@@ -274,7 +281,11 @@ class LADIFF(nn.Module):
         dev = encoder_hidden_states.device
         if not encoder_hidden_states.is_cuda:
             raise _lib.LadiffHipError("_diffusion_reverse needs GPU tensors; there is no CPU fallback")
-        self.check()          # the previous call's status (its loop has long finished: the copy sits right behind it on the stream)
+        # earlier calls' status: the last-but-one call's words are waited for (long there), the previous call's only if they have
+        # arrived - the host never blocks on a loop that is still running, and no status is dropped unread
+        self._call += 1
+        self.check(before=self._call - 1)
+        self.check(wait=False)
         n_text = int(encoder_hidden_states.shape[1])          # 1: CLIP pooled token; > 1: clip_hidden / bert (mld_clip.py:80-86)
         cfg = bool(self.do_classifier_free_guidance)        # ladiff.py:339-340, :472-490
         dup = 2 if cfg else 1
@@ -296,10 +307,10 @@ class LADIFF(nn.Module):
         zs = []
         for lo, hi in spans:
             zs.append(self._reverse_one(text[:, lo:hi].reshape(dup * (hi - lo), n_text, 768), lengths[lo:hi], counts[lo:hi], T,
-                                        init_noise[lo:hi], None if step_noise is None else step_noise[:, lo:hi], keep_pending=True))
+                                        init_noise[lo:hi], None if step_noise is None else step_noise[:, lo:hi]))
         return torch.cat(zs, dim=1)
 
-    def _reverse_one(self, encoder_hidden_states, lengths, counts, T, init_noise, step_noise, keep_pending=False):
+    def _reverse_one(self, encoder_hidden_states, lengths, counts, T, init_noise, step_noise):
         """One launch sequence of the loop on B prompts: prologue graph, N steps (pipeline kernel or step graphs), final masking."""
         L = _lib.lib()
         dev = encoder_hidden_states.device
@@ -337,8 +348,6 @@ class LADIFF(nn.Module):
         if run is not cur:
             run.wait_stream(cur)
         loop_codes = {"pipeline": 1, "pipeline16": 2, "pipeline32": 3, "launches": 0}
-        if not keep_pending:
-            self._pending = []
 
         def enqueue(loop):
             if sampler is not None:
@@ -363,7 +372,7 @@ class LADIFF(nn.Module):
             host, ev = plan["status_host"][slot], plan["status_event"][slot]
             host.copy_(plan["status_dev"], non_blocking=True)
             ev.record(run)
-            self._pending.append((ev, host, plan["key"]))
+            self._pending.append((ev, host, plan["key"], self._call))
 
         with torch.cuda.stream(run):
             plan["text"][:dup * B].copy_(encoder_hidden_states.reshape(dup * B, n_text, 768))
@@ -403,6 +412,7 @@ class LADIFF(nn.Module):
         from ctypes import c_float, c_int
         L = _lib.lib()
         if enable is not None:
+            self._window_timing = bool(enable)
             for plan in self._plans.values():
                 if plan["sampler"] is not None:
                     _lib.check(L.ladiff_sampler_set_window_timing(plan["sampler"], 1 if enable else 0))
@@ -433,10 +443,14 @@ class LADIFF(nn.Module):
         return code.value, info.value
 
     # ------------------------------------------------------------------ callers' surface
-    def sample(self, text_emb, lengths, init_noise=None, step_noise=None):
-        """text embeddings -> (z [max_it,B,256], feats [B,max(len),nfeats]): ladiff.py:266 + :283."""
+    def sample(self, text_emb, lengths, init_noise=None, step_noise=None, check=True):
+        """text embeddings -> (z [max_it,B,256], feats [B,max(len),nfeats]): ladiff.py:266 + :283.  Returns checked frames: the
+        decode is queued, then the host waits for the loop's status words (LadiffHipError if the loop was abandoned).
+        check=False skips the wait (the host may then queue a call ahead) - the caller owes a `check()` before using the frames."""
         z = self._diffusion_reverse(text_emb, lengths, init_noise=init_noise, step_noise=step_noise)
         feats = self.vae.decode(z, lengths)
+        if check:
+            self.check()
         return z, feats
 
     def forward(self, batch, latentwise_gen=None, plot_att_map=None):
