@@ -12,7 +12,7 @@ config c4's per-rank slice): 128 prompts per GPU, 196 frames, 50-step DDIM with 
 (random-init weights, random "CLIP" embeddings, seeded noise: ladiff_amd/synthetic.py) are resident in HBM before the timed
 region.  Metric: motions/s, whole job.  `--config` runs the other BASELINE.json configurations in the same JSON shape
 (SURVEY.md §8a/§8d): c1 decode only (8 motions of 60 frames), c2 64 prompts, c3 1000-step DDPM on 128 prompts (per-step
-noise streamed from a resident [1000,128,5,256] tensor; 20 windows of 50 steps), c5 128 prompts of {60,120,196} frames with
+noise drawn inside the loop by a counter-based generator keyed by seed / step / global prompt; 20 windows of 50 steps), c5 128 prompts of {60,120,196} frames with
 the KIT 251-dim decoder (the slice one of 8 ranks runs); c4 = the default workload (meant for --gpus 8).
 
 After the timed region (never inside it) the run is CHECKED: the last timed pass must equal the warm-up pass bit for bit,
@@ -200,12 +200,9 @@ class Workload:
             rs = torch.Generator().manual_seed(77)
             self.mean, self.std = torch.randn(cfg["nfeats"], generator=rs) * 0.5, torch.rand(cfg["nfeats"], generator=rs) + 0.5
             self.f2j = Feats2Joints(self.mean, self.std, 22)
-        if cfg["sched"] == "ddpm":
-            # per-step noise of the GLOBAL batch, drawn on the device from one seed and sliced (655 MB per 128 prompts: resident)
-            g = torch.Generator(device=dev) if torch.device(dev).type == "cuda" else torch.Generator()
-            g.manual_seed(syn.DDPM_NOISE_SEED)
-            sn = torch.randn(cfg["steps"], self.total, 5, 256, generator=g, device=dev)
-            self.step_noise = sn[:, self.lo:self.hi].contiguous()
+        # stochastic schedules: the per-step noise is drawn inside the loop, keyed by (seed, step, GLOBAL prompt index) - no
+        # [steps, B, 5, 256] tensor (655 MB per 128 prompts at 1000 steps) exists; a rank draws exactly its slice of the global batch
+        self.noise_seed = syn.DDPM_NOISE_SEED if cfg["sched"] == "ddpm" else None
         if cfg["decode_only"]:
             z = torch.randn(5, self.total, 256, generator=torch.Generator().manual_seed(syn.NOISE_SEED))
             for i, m in enumerate(syn.max_iter_elements(self.glens)):
@@ -237,7 +234,8 @@ class Workload:
         if self.cfg["decode_only"]:
             feats = pipe.vae.decode(self.z_in, self.lens)
         else:
-            _, feats = pipe.sample(self.text, self.lens, init_noise=self.noise, step_noise=self.step_noise)
+            pipe.noise_first_prompt = self.lo
+            _, feats = pipe.sample(self.text, self.lens, init_noise=self.noise, noise_seed=self.noise_seed)
         if self.use_dist:      # final gather of the decoded frames (RCCL over xGMI); also exercised at world size 1 under torchrun
             feats = D.gather_feats(feats, self.total, self.world, out=self.gather_buf, lengths=self.glens)
         return feats
@@ -275,7 +273,9 @@ class Workload:
                 f_o = orc.vae_decode(vae_sd, self.z_cpu[:, idx], sub_lens)
             else:
                 sub_text = torch.cat([self.text_cpu[:B][idx], self.text_cpu[B:][idx]])
-                sn = None if self.step_noise is None else self.step_noise[:, idx].cpu().contiguous()
+                # the oracle consumes the NUMPY restatement of the generator, for the global indices of the checked prompts
+                sn = None if self.noise_seed is None else torch.cat(
+                    [torch.from_numpy(orc.device_noise(self.noise_seed, self.lo + i, 0, cfg["steps"], 1, 5)) for i in idx], dim=1)
                 _, f_o = orc.sample_motions(syn.denoiser_weights(), vae_sd, sub_text, sub_lens, self.noise_cpu[idx], cfg["steps"],
                                             cfg["sched"], step_noise=sn)
         mine = self.local_rows(feats).cpu()
@@ -604,12 +604,12 @@ def main():
             dk = pipeline_kernel_roofline(B, steps_per_launch, ms, launches, args.precision, summary, {"profiled_workload": is_default})
             if win is not None and win[1] > 1:
                 ksum, nwin, tot = win
-                noise_bytes = n_steps * B * 5 * 256 * 4
+                noise_bytes = n_steps * B * 5 * 256 * 4           # what a [steps,B,5,256] tensor would be: drawn in the TAIL stage instead
                 dk["windows"] = {"n": nwin, "steps_per_window": n_steps // nwin, "loop_kernel_ms_per_window": round(ksum / nwin, 3),
                                  "table_rebuild_ms_between_windows": round((tot - ksum) / (nwin - 1), 4),
                                  "loop_ms_total": round(tot, 3),
-                                 "noise_stream_GBps": round(noise_bytes / (tot / 1e3) / 1e9, 2),
-                                 "noise_bytes_per_pass": noise_bytes}
+                                 "noise": "drawn on the device where consumed (Philox4x32-10 + Box-Muller, csrc/noise_gen.h)",
+                                 "noise_tensor_bytes_not_held": noise_bytes}
             dk["peak_note"] = whole["peak_note"]
             dk["whole_pass"] = whole
             line["roofline"] = dk

@@ -56,7 +56,7 @@ enum {
 enum { LADIFF_ACT_NONE = 0, LADIFF_ACT_RELU = 1, LADIFF_ACT_GELU = 2, LADIFF_ACT_SILU = 3, LADIFF_ACT_QGELU = 4 /* x*sigmoid(1.702x) */,
        LADIFF_ACT_LRELU = 5 /* LeakyReLU(0.2) */ };
 
-#define LADIFF_ABI_VERSION 4
+#define LADIFF_ABI_VERSION 5
 #define LADIFF_LATENT_DIM 256     /* model.latent_dim[-1], config_ladiff_humanml3d.yaml:132 */
 #define LADIFF_NUM_HEADS 4        /* configs/modules/denoiser.yaml:7 */
 #define LADIFF_NUM_LAYERS 9       /* configs/modules/denoiser.yaml:6, motion_vae.yaml:5 */
@@ -304,6 +304,19 @@ size_t ladiff_reverse_status_offset_bytes(int B, int T, int n_steps, int n_text)
  * after the start-up handshake of every launch of this sampler, so that its consumers time out (-1: off); timeout_ms > 0 replaces the
  * 1.5 s bound of every wait (0: default).  Other samplers of the process are not affected. */
 int ladiff_sampler_set_fault(void* sampler, int workgroup, int timeout_ms);
+/* Per-step noise of the stochastic schedulers (DDPM, DDIM with eta > 0) drawn ON THE DEVICE, where it is consumed, instead of read
+ * from a [n_steps,B,T,256] tensor (655 MB for 1000 steps x 128 prompts).  Replaces diffusers' `randn_tensor` inside
+ * `scheduler.step` (reference call site: ladiff.py:492; configs/modules_novae/scheduler.yaml:16-29).  A value is a pure function of
+ * (seed, schedule position, global prompt index = first_prompt + b, latent, column): Philox4x32-10 bits, Box-Muller normals
+ * (csrc/noise_gen.h; oracle/ladiff_oracle.py:device_noise is the numpy restatement) - so a batch sharded over ranks or cut into
+ * chunks draws what the whole batch would, and a call is reproducible from its seed.
+ *   ladiff_sampler_set_noise_generator: with enable != 0, calls of ladiff_diffusion_reverse on this sampler that pass
+ *     step_noise = NULL draw from the generator (a non-NULL step_noise still wins); enable = 0: such calls add no noise (as before).
+ *   ladiff_noise_fill: the same values as a tensor, out[i][b][t][:] for schedule positions first_step + i (tests, oracle checks,
+ *     callers that want to keep the noise). */
+int ladiff_sampler_set_noise_generator(void* sampler, uint64_t seed, uint32_t first_prompt, int enable);
+int ladiff_noise_fill(uint64_t seed, uint32_t first_prompt, int first_step, int n_steps, int B, int T, float* out /*[n_steps,B,T,256]*/,
+                      ladiff_stream_t stream);
 size_t ladiff_reverse_workspace_bytes(int B, int T, int n_steps, int n_text);
 int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* const* w_split /*or NULL*/,
                              uint64_t weights_generation, const float* text_emb /*[2B or B,n_text,768]*/,

@@ -73,6 +73,8 @@ _SIGNATURES = {
     "ladiff_reverse_status": (c_int, [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "ladiff_reverse_status_offset_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ladiff_sampler_set_fault": (c_int, [c_void_p, c_int, c_int]),
+    "ladiff_sampler_set_noise_generator": (c_int, [c_void_p, c_uint64, ctypes.c_uint32, c_int]),
+    "ladiff_noise_fill": (c_int, [c_uint64, ctypes.c_uint32, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ladiff_reverse_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ladiff_diffusion_reverse": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_int, c_int,

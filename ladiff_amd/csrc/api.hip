@@ -87,11 +87,14 @@ struct Sampler {
     // the start-up handshake and bound their waits; -1 / 0 = none / the default bound.  A field of the handle, not of the process.
     int fault_wg = -1;
     unsigned long long timeout_ticks = 0;
+    // per-step noise drawn on the device (ladiff_sampler_set_noise_generator): used by the calls that pass step_noise = NULL
+    NoiseGen gen = NoiseGen{0u, 0u, 0u, 0};
     // capture key: a graph bakes pointers, shapes and scalars into its kernel nodes.  The weight tables are identified by
     // a hash over EVERY pointer of both tables plus the caller's generation id (bumped whenever a table is rebuilt), not
     // by the address of the host array (which a rebuilt table can land on again).
     const void* key_ptrs[9] = {nullptr};
     int key_ints[4] = {0};
+    unsigned key_gen_noise[4] = {0u, 0u, 0u, 0u};
     float key_f[2] = {0.f, 0.f};
     uint64_t key_hash = 0, key_gen = 0;
     uint64_t epoch = 0;                   // g_graph_epoch when these graphs were instantiated (see there)
@@ -450,6 +453,20 @@ int ladiff_sampler_last_loop(void* sampler, int* pipeline, int* rows_per_block, 
     return 0;
 }
 
+int ladiff_sampler_set_noise_generator(void* sampler, uint64_t seed, uint32_t first_prompt, int enable) {
+    Sampler* sp = reinterpret_cast<Sampler*>(sampler);
+    LADIFF_CHECK_ARG(sp != nullptr);
+    sp->gen = NoiseGen{(unsigned)(seed & 0xffffffffull), (unsigned)(seed >> 32), first_prompt, enable ? 1 : 0};
+    return 0;
+}
+
+int ladiff_noise_fill(uint64_t seed, uint32_t first_prompt, int first_step, int n_steps, int B, int T, float* out, ladiff_stream_t stream) {
+    LADIFF_CHECK_ARG(out != nullptr && first_step >= 0 && n_steps >= 0 && B >= 0);
+    if (T < 1 || T > LADIFF_MAX_LATENTS) return LADIFF_ERR_SHAPE;
+    return launch_noise_fill(NoiseGen{(unsigned)(seed & 0xffffffffull), (unsigned)(seed >> 32), first_prompt, 1}, first_step, n_steps, B, T, out,
+                             S(stream));
+}
+
 int ladiff_sampler_set_fault(void* sampler, int workgroup, int timeout_ms) {
     Sampler* sp = reinterpret_cast<Sampler*>(sampler);
     LADIFF_CHECK_ARG(sp != nullptr && workgroup >= -1 && workgroup < 256 && timeout_ms >= 0);
@@ -509,6 +526,8 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
     const int B2 = dup * B;
 
     Sampler* sp = reinterpret_cast<Sampler*>(sampler);
+    // the sampler's generator stands in for a step-noise tensor the caller did not pass (schedules without noise never look at either)
+    const NoiseGen gen = (sp != nullptr && step_noise == nullptr) ? sp->gen : NoiseGen{0u, 0u, 0u, 0};
     float *xio = nullptr, *xios = nullptr;
     den_loop_io(r.fwd, B2 * T, &xio, &xios);
     if (WSp == nullptr) xios = nullptr;
@@ -537,7 +556,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
         LADIFF_TRY(denoiser_forward(W, WSp, r.tables, r.d_step, r.cache, r.window, r.latents, B, dup, T, counts, r.eps, r.fwd,
                                     r.fwd_floats, st, 0, B2, 1, n_text, r.d_step + 2));
         return launch_step_tail(xio, xios, W.norm.g, W.norm.b, r.latents, coef, r.d_step, step_noise, W.query_pe,
-                                guidance_scale, cfg, B, T, st);
+                                guidance_scale, cfg, B, T, st, gen);
     };
     // without guidance the pipeline runs one-branch 16-row blocks, which need the latent counts on the host (or no masking at all)
     const bool pipeline = sp != nullptr && sp->loop == 1 && n_text == 1 && sys_supported(B, T, cfg, WSp != nullptr) &&
@@ -564,10 +583,12 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
         const void* kp[9] = {ws, counts, final_counts, coef, step_noise, stream, text_emb, init_noise, z};
         const int ki[4] = {B, T, n_steps + 65536 * plan_nb, cfg + 2 * (pipeline ? plan_mr : 0) + 16 * n_text + 4096 * (WSp ? 1 : 0)};
         const float kf[2] = {guidance_scale, init_noise_sigma};
+        const unsigned kn[4] = {gen.seed_lo, gen.seed_hi, gen.prompt0, (unsigned)gen.on};      // baked into the step graphs' tail nodes
         uint64_t h = hash_ptrs(w, DEN_NPARAMS, 1469598103934665603ull);
         if (w_split) h = hash_ptrs(w_split, DEN_NPARAMS, h ^ 0x9e3779b97f4a7c15ull);
         const bool same = sp->setup && std::memcmp(kp, sp->key_ptrs, sizeof(kp)) == 0 &&
                           std::memcmp(ki, sp->key_ints, sizeof(ki)) == 0 && std::memcmp(kf, sp->key_f, sizeof(kf)) == 0 &&
+                          (pipeline || std::memcmp(kn, sp->key_gen_noise, sizeof(kn)) == 0) &&
                           h == sp->key_hash && weights_generation == sp->key_gen;
         // LADIFF_GRAPH_EPOCH_OFF (test aid): trust an older exec, as tests/test_gpu_pipeline.py does to show that the graphs - kernel
         // nodes only since round 4 - replay correctly however old they are
@@ -625,6 +646,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
             std::memcpy(sp->key_ptrs, kp, sizeof(kp));
             std::memcpy(sp->key_ints, ki, sizeof(ki));
             std::memcpy(sp->key_f, kf, sizeof(kf));
+            std::memcpy(sp->key_gen_noise, kn, sizeof(kn));
             sp->key_hash = h;
             sp->key_gen = weights_generation;
             sp->epoch = ++g_graph_epoch;
@@ -651,7 +673,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
             if (pipeline) {
                 LADIFF_TRY(launch_systolic_loop(W, r.sys, r.tables, den_cache_tkv(r.cache, B2, 1), den_cache_ctab(r.cache, B2, 1), r.window,
                                                 coef, step_noise, r.latents, counts, guidance_scale, B, T, lo, r.window, WSp ? 0 : 1, plan_mr, plan_nb, s, cfg,
-                                                sp->fault_wg, sp->timeout_ticks));
+                                                sp->fault_wg, sp->timeout_ticks, gen));
             } else {
                 for (int i = 0; i < r.window / sp->unroll; ++i) LADIFF_HIP(hipGraphLaunch(sp->exec, s));
             }

@@ -1,6 +1,7 @@
 // Launchers of the non-GEMM kernels (rowops.hip, attention.hip).
 #pragma once
 #include "common.h"
+#include "noise_gen.h"
 
 namespace ladiff {
 
@@ -37,7 +38,8 @@ int launch_cfg_step(const float* eps, float* lat, const float* coef, const int32
                     float g, int cfg, int B, int T, hipStream_t s);
 int launch_advance(int32_t* d_step, hipStream_t s);
 int launch_step_tail(float* x, float* xs, const float* ng, const float* nb, float* lat, const float* coef, int32_t* d_step,
-                     const float* noise, const float* pe, float g, int cfg, int B, int T, hipStream_t s);
+                     const float* noise, const float* pe, float g, int cfg, int B, int T, hipStream_t s, const NoiseGen& gen = NoiseGen{0u, 0u, 0u, 0});
+int launch_noise_fill(const NoiseGen& gen, int step0, int n, int B, int T, float* out, hipStream_t s);
 int launch_init_latents(const float* noise, const int32_t* counts, float sigma, float* lat, int B, int T, hipStream_t s);
 int launch_finalize_latents(const float* lat, const int32_t* counts, float* z, int B, int T, hipStream_t s, const unsigned* status = nullptr);
 

@@ -79,7 +79,7 @@ size_t sys_status_offset_floats(int B, int T);
 int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, const float* tkv, const float* ctab, int n_ctab,
                          const float* coef, const float* noise, float* lat, const int32_t* counts, float gscale, int B, int T,
                          int step_lo, int n, int fp32, int MR, int NB, hipStream_t s, int cfg = 1, int fault_wg = -1,
-                         unsigned long long timeout_ticks = 0);
+                         unsigned long long timeout_ticks = 0, const NoiseGen& gen = NoiseGen{0u, 0u, 0u, 0});
 
 // qkv_attn.hip: in_proj GEMM + self-attention of the denoiser's sa_block in one launch (bf16x3 mode, S-format in / out)
 int launch_qkv_attention(const float* x, const float* w, const float* bias, const float* text_kv, const float* tables,

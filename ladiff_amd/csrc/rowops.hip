@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void step_tail_kernel(float* __restrict__ x, f
                                                         const float* __restrict__ nb, float* __restrict__ lat,
                                                         const float* __restrict__ coef, int32_t* __restrict__ d_step,
                                                         const float* __restrict__ noise, const float* __restrict__ pe, float g,
-                                                        int cfg, int B, int T) {
+                                                        int cfg, int B, int T, const NoiseGen gen) {
     const int step = d_step[0];
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);      // row = b * T + t of the B prompts
     const int c = (threadIdx.x & 63) * 4;
@@ -506,7 +506,11 @@ __global__ __launch_bounds__(256) void step_tail_kernel(float* __restrict__ x, f
         }
         f32x4 l = ld4(lat + (size_t)row * D + c);
         f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        if (noise != nullptr && kn != 0.f) z = ld4(noise + ((size_t)step * M + row) * D + c);
+        if (gen.on && kn != 0.f) {       // drawn here (noise_gen.h): the same function of (seed, step, global prompt, latent, column) as everywhere
+            float zz[4];
+            noise_normal4(gen, step, gen.prompt0 + (unsigned)(row / T), row % T, c / 4, zz);
+            z = f32x4{zz[0], zz[1], zz[2], zz[3]};
+        } else if (noise != nullptr && kn != 0.f) z = ld4(noise + ((size_t)step * M + row) * D + c);
         const f32x4 p = ld4(pe + (size_t)(row % T) * D + c);
         f32x4 xn;
 #pragma unroll
@@ -531,10 +535,30 @@ __global__ __launch_bounds__(256) void step_tail_kernel(float* __restrict__ x, f
     }
 }
 int launch_step_tail(float* x, float* xs, const float* ng, const float* nb, float* lat, const float* coef, int32_t* d_step,
-                     const float* noise, const float* pe, float g, int cfg, int B, int T, hipStream_t s) {
+                     const float* noise, const float* pe, float g, int cfg, int B, int T, hipStream_t s, const NoiseGen& gen) {
     const int M = B * T;
     hipLaunchKernelGGL(step_tail_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, x, xs, ng, nb, lat, coef,
-                       d_step, noise, pe, g, cfg, B, T);
+                       d_step, noise, pe, g, cfg, B, T, gen);
+    LADIFF_LAUNCH_CHECK();
+    return 0;
+}
+
+// the generator's values as a tensor: out[i][b][t][:] = the noise of schedule position step0 + i, global prompt prompt0 + b, latent t
+__global__ __launch_bounds__(256) void noise_fill_kernel(const NoiseGen gen, int step0, int n, int B, int T, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // one 16-byte chunk per thread
+    const size_t per_step = (size_t)B * T * (D / 4);
+    if (i >= per_step * n) return;
+    const int st = (int)(i / per_step);
+    const size_t r = i % per_step;
+    const int chunk = (int)(r % (D / 4)), row = (int)(r / (D / 4));
+    float z[4];
+    noise_normal4(gen, step0 + st, gen.prompt0 + (unsigned)(row / T), row % T, chunk, z);
+    st4(out + i * 4, f32x4{z[0], z[1], z[2], z[3]});
+}
+int launch_noise_fill(const NoiseGen& gen, int step0, int n, int B, int T, float* out, hipStream_t s) {
+    const size_t n4 = (size_t)n * B * T * (D / 4);
+    if (n4 == 0) return 0;
+    hipLaunchKernelGGL(noise_fill_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, gen, step0, n, B, T, out);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }

@@ -134,6 +134,7 @@ struct SysArgs {
     int fault_wg;                         // test aid: this workgroup leaves right after the start-up handshake and never publishes (-1: none)
     unsigned long long timeout_ticks;     // bound of every spin, in s_memrealtime ticks (100 MHz)
     int look_ahead;                       // tagged hand-off: stages may request the next block's rows early (see `settle`)
+    NoiseGen gen;                         // on: the TAIL stage draws the per-step noise itself (noise_gen.h) instead of reading `noise`
     unsigned long long* stamps;           // diagnostic twin build only (-DLADIFF_STAMPS): [workgroup][step][block][8] realtime ticks
 };
 
@@ -1607,7 +1608,11 @@ struct TailRole {
                 y.ec[i] = ld_sc1(rin, bc + g.rc[i] * 1024 + c * 4);
                 y.lt[i] = ld4(p.lat + (size_t)g.lat[i] * D + c);
                 y.pe[i] = ld4(p.pe + (size_t)g.t[i] * D + c);
-                if (p.noise != nullptr && kn != 0.f) y.zz[i] = ld4(p.noise + ((size_t)step * p.B * T + g.lat[i]) * D + c);
+                if (p.gen.on && kn != 0.f) {
+                    float zz[4];
+                    noise_normal4(p.gen, step, p.gen.prompt0 + (unsigned)(g.lat[i] / T), g.t[i], lane, zz);
+                    y.zz[i] = f32x4{zz[0], zz[1], zz[2], zz[3]};
+                } else if (p.noise != nullptr && kn != 0.f) y.zz[i] = ld4(p.noise + ((size_t)step * p.B * T + g.lat[i]) * D + c);
             } else if (HO) {                                             // the tickets of a slot that only pads (Red2Role::issue)
                 if (g.pad[i] >= 0) y.eu[i] = ld_sc1(rin, bu + g.pad[i] * 1024 + c * 4);
                 if (g.rc[i] >= 0) y.ec[i] = ld_sc1(rin, bc + g.rc[i] * 1024 + c * 4);
@@ -2179,7 +2184,8 @@ int sys_reset_status(float* ws, hipStream_t s) {
 
 int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, const float* tkv, const float* ctab, int n_ctab,
                          const float* coef, const float* noise, float* lat, const int32_t* counts, float gscale, int B, int T,
-                         int step_lo, int n, int fp32, int MR, int NB, hipStream_t s, int cfg, int fault_wg, unsigned long long timeout_ticks) {
+                         int step_lo, int n, int fp32, int MR, int NB, hipStream_t s, int cfg, int fault_wg, unsigned long long timeout_ticks,
+                         const NoiseGen& gen) {
     // fault_wg / timeout_ticks: the caller's SAMPLER's fault injection (ladiff_sampler_set_fault; -1 / 0 = none / default bound)
     const SysLayout L = sys_layout(MR, NB);
     SysArgs a;
@@ -2195,6 +2201,7 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     a.fault_wg = fault_wg;
     a.timeout_ticks = timeout_ticks > 0 ? timeout_ticks : TIMEOUT_TICKS;
     a.look_ahead = NB >= LOOK_AHEAD_BLOCKS ? 1 : 0;
+    a.gen = gen;
     a.stamps = nullptr;
 #ifdef LADIFF_STAMPS
     a.stamps = g_sys_stamps;

@@ -123,6 +123,8 @@ class LADIFF(nn.Module):
         self._pending = []            # (event, pinned status words, plan key, call number) per launch not yet looked at
         self._call = 0                # number of the current `_diffusion_reverse` call
         self._window_timing = False   # per-window events wanted (window_ms(enable=True)): applied to every sampler, also later ones
+        self.noise_first_prompt = 0   # global index of this object's prompt 0 (a rank of a sharded batch sets its offset): keys the device noise
+        self.last_noise_seed = None
         self._fault = (-1, 0)         # fault injection of the abort-path tests: applied to every sampler of THIS object (set_pipeline_fault)
         self._stream = None
         self._plans = {}              # plan key -> persistent buffers + sampler (a few shapes stay cached: chunks, alternating batches)
@@ -276,8 +278,11 @@ class LADIFF(nn.Module):
             lo = hi
         return spans
 
-    def _diffusion_reverse(self, encoder_hidden_states, lengths=None, init_noise=None, step_noise=None):
-        """text_emb [2B,1,768] (unconditional half first), lengths list[int] -> z [max_it, B, 256]  (ladiff.py:333-571)."""
+    def _diffusion_reverse(self, encoder_hidden_states, lengths=None, init_noise=None, step_noise=None, noise_seed=None):
+        """text_emb [2B,1,768] (unconditional half first), lengths list[int] -> z [max_it, B, 256]  (ladiff.py:333-571).
+        Stochastic schedules (DDPM, eta > 0): `step_noise` [n,B,T,256] if given; otherwise the noise is drawn on the device where it
+        is consumed (csrc/noise_gen.h) from `noise_seed` (default: a seed taken from torch's CPU generator, so torch.manual_seed makes
+        a run reproducible) - the reference draws it inside scheduler.step, ladiff.py:492.  `last_noise_seed` holds the seed used."""
         dev = encoder_hidden_states.device
         if not encoder_hidden_states.is_cuda:
             raise _lib.LadiffHipError("_diffusion_reverse needs GPU tensors; there is no CPU fallback")
@@ -297,8 +302,12 @@ class LADIFF(nn.Module):
         T = counts[0] if self.test_efficiency else self.max_it     # ladiff.py:381
         self._last = []
         spans = self._chunks(B)
+        if step_noise is None and noise_seed is None:
+            noise_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self.last_noise_seed = None if step_noise is not None else int(noise_seed)
+        first = int(self.noise_first_prompt)
         if len(spans) == 1:
-            return self._reverse_one(encoder_hidden_states, lengths, counts, T, init_noise, step_noise)
+            return self._reverse_one(encoder_hidden_states, lengths, counts, T, init_noise, step_noise, noise_seed, first)
         # prompts are independent (attention is per sample, guidance pairs the two branches of one prompt): a large batch is
         # several launches of the loop on contiguous prompt ranges, the noise drawn for the whole batch and sliced
         if init_noise is None:
@@ -307,10 +316,10 @@ class LADIFF(nn.Module):
         zs = []
         for lo, hi in spans:
             zs.append(self._reverse_one(text[:, lo:hi].reshape(dup * (hi - lo), n_text, 768), lengths[lo:hi], counts[lo:hi], T,
-                                        init_noise[lo:hi], None if step_noise is None else step_noise[:, lo:hi]))
+                                        init_noise[lo:hi], None if step_noise is None else step_noise[:, lo:hi], noise_seed, first + lo))
         return torch.cat(zs, dim=1)
 
-    def _reverse_one(self, encoder_hidden_states, lengths, counts, T, init_noise, step_noise):
+    def _reverse_one(self, encoder_hidden_states, lengths, counts, T, init_noise, step_noise, noise_seed=None, first_prompt=0):
         """One launch sequence of the loop on B prompts: prologue graph, N steps (pipeline kernel or step graphs), final masking."""
         L = _lib.lib()
         dev = encoder_hidden_states.device
@@ -327,10 +336,15 @@ class LADIFF(nn.Module):
             self._stream = torch.cuda.Stream(device=dev)
         if init_noise is None:
             init_noise = torch.randn(B, T, 256, device=dev, dtype=torch.float32)       # ladiff.py:380-385
-        if need_noise and step_noise is None:
-            step_noise = torch.randn(n, B, T, 256, device=dev, dtype=torch.float32)
+        generated = need_noise and step_noise is None      # drawn inside the loop, keyed by (seed, step, global prompt, latent, column)
+        if generated and sampler is None:
+            # no sampler handle to carry the seed (use_graph=False): the same values as a tensor (n x B x T x 256 floats)
+            step_noise = self.noise_tensor(noise_seed, n, B, T, first_prompt=first_prompt, device=dev)
+            generated = False
+        if sampler is not None:
+            _lib.check(L.ladiff_sampler_set_noise_generator(sampler, int(noise_seed or 0), int(first_prompt), 1 if generated else 0))
         noise_t = None
-        if need_noise:
+        if need_noise and not generated:
             if tuple(step_noise.shape) != (n, B, T, 256):
                 raise ValueError(f"step_noise {tuple(step_noise.shape)} for a schedule of {n} steps x {B} prompts x {T} latents")
             big = step_noise.numel() * 4 >= (64 << 20)             # a new pointer re-captures the prologue graph (~1 ms): worth it for big tensors only
@@ -360,7 +374,7 @@ class LADIFF(nn.Module):
                 # ladiff_denoiser.py:254) - but the final zeroing of ladiff.py:559-566 has no such switch
                 None if self.test_efficiency else plan["counts"].data_ptr(), plan["counts"].data_ptr(),
                 None if self.test_efficiency else (ctypes.c_int32 * B)(*counts),       # host copy: length-aware block packing
-                _lib.ptr(plan["sinus"]), _lib.ptr(plan["coef"]), _lib.ptr(noise_t) if need_noise else None,
+                _lib.ptr(plan["sinus"]), _lib.ptr(plan["coef"]), _lib.ptr(noise_t) if noise_t is not None else None,
                 self.guidance_scale, float(sch.init_noise_sigma), 1 if cfg else 0, B, T, n_text, n, _lib.ptr(plan["z"]),
                 _lib.ptr(plan["ws"]), plan["ws_bytes"], 1 if plan["tables_key"] == wt.key else 0, run.cuda_stream))
             plan["tables_key"] = wt.key
@@ -378,7 +392,7 @@ class LADIFF(nn.Module):
             plan["text"][:dup * B].copy_(encoder_hidden_states.reshape(dup * B, n_text, 768))
             plan["noise"].copy_(init_noise)
             plan["counts"].copy_(_lib.device_ints(counts, dev))       # device-to-device: the graph bakes plan["counts"] in
-            if need_noise and noise_t is not step_noise:
+            if noise_t is not None and noise_t is not step_noise:
                 noise_t.copy_(step_noise)
             enqueue(self.loop)
             if self.fallback and self.loop != "launches":
@@ -391,6 +405,16 @@ class LADIFF(nn.Module):
         if run is not cur:
             cur.wait_stream(run)
         return plan["z"].clone()
+
+    @staticmethod
+    def noise_tensor(seed, n_steps, B, T, first_prompt=0, first_step=0, device="cuda:0"):
+        """The device generator's values as a tensor [n_steps,B,T,256] (what a call with noise_seed=seed consumes at schedule
+        positions first_step .. for global prompts first_prompt ..): for tests and for callers that want to keep the noise."""
+        out = torch.empty(n_steps, B, T, 256, dtype=torch.float32, device=device)
+        with torch.cuda.device(out.device):
+            _lib.check(_lib.lib().ladiff_noise_fill(int(seed), int(first_prompt), int(first_step), int(n_steps), int(B), int(T),
+                                                    _lib.ptr(out), torch.cuda.current_stream(out.device).cuda_stream))
+        return out
 
     def loop_ms(self):
         """Device milliseconds of the N-step loop(s) of the last `_diffusion_reverse` call (HIP events on its stream; summed over the
@@ -443,11 +467,11 @@ class LADIFF(nn.Module):
         return code.value, info.value
 
     # ------------------------------------------------------------------ callers' surface
-    def sample(self, text_emb, lengths, init_noise=None, step_noise=None, check=True):
+    def sample(self, text_emb, lengths, init_noise=None, step_noise=None, check=True, noise_seed=None):
         """text embeddings -> (z [max_it,B,256], feats [B,max(len),nfeats]): ladiff.py:266 + :283.  Returns checked frames: the
         decode is queued, then the host waits for the loop's status words (LadiffHipError if the loop was abandoned).
         check=False skips the wait (the host may then queue a call ahead) - the caller owes a `check()` before using the frames."""
-        z = self._diffusion_reverse(text_emb, lengths, init_noise=init_noise, step_noise=step_noise)
+        z = self._diffusion_reverse(text_emb, lengths, init_noise=init_noise, step_noise=step_noise, noise_seed=noise_seed)
         feats = self.vae.decode(z, lengths)
         if check:
             self.check()

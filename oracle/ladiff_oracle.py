@@ -339,6 +339,45 @@ class DDPM(_SchedulerBase):
         return out
 
 
+# --------------------------------------------------------------------------- per-step noise drawn on the device
+# The product draws the stochastic schedulers' noise where it is consumed (csrc/noise_gen.h) instead of reading a tensor that
+# `scheduler.step` would have drawn with randn_tensor (ladiff.py:492; diffusers' DDPMScheduler.step / DDIMScheduler.step with eta > 0).
+# This is the numpy restatement of that generator: the same integers (Philox4x32-10, pinned to the Random123 known-answer vectors in
+# tests/test_noise.py), the same fp32 Box-Muller; ln / cos / sin come from numpy instead of the device library (last-bit differences).
+def philox4x32_10(counter, key):
+    """counter [..., 4] uint32, key [..., 2] uint32 (broadcastable) -> [..., 4] uint32 (Salmon et al., SC'11)."""
+    import numpy as np
+    c = [np.asarray(counter[..., i], dtype=np.uint64) for i in range(4)]
+    k = [np.asarray(key[..., i], dtype=np.uint64) for i in range(2)]
+    m32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]
+        p1 = np.uint64(0xCD9E8D57) * c[2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & m32, p1 >> np.uint64(32), p1 & m32
+        c = [hi1 ^ c[1] ^ k[0], lo1, hi0 ^ c[3] ^ k[1], lo0]
+        k = [(k[0] + np.uint64(0x9E3779B9)) & m32, (k[1] + np.uint64(0xBB67AE85)) & m32]
+    return np.stack(c, axis=-1).astype(np.uint32)
+
+
+def device_noise(seed, first_prompt, first_step, n_steps, B, T, dim=256):
+    """[n_steps, B, T, dim] float32: what csrc/noise_gen.h draws for schedule positions first_step .., global prompts first_prompt .."""
+    import numpy as np
+    st, b, t, ch = np.meshgrid(np.arange(n_steps, dtype=np.uint64) + np.uint64(first_step),
+                               np.arange(B, dtype=np.uint64) + np.uint64(first_prompt),
+                               np.arange(T, dtype=np.uint64), np.arange(dim // 4, dtype=np.uint64), indexing="ij")
+    counter = np.stack([t * np.uint64(64) + ch, b & np.uint64(0xFFFFFFFF), st, np.zeros_like(st)], axis=-1)
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint64)
+    x = philox4x32_10(counter, key)
+    u = ((x >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23)
+    out = np.empty(x.shape, dtype=np.float32)
+    for h in range(2):
+        r = np.sqrt(np.float32(-2.0) * np.log(u[..., 2 * h]), dtype=np.float32)
+        th = np.float32(6.2831854820251465) * u[..., 2 * h + 1]
+        out[..., 2 * h] = r * np.cos(th, dtype=np.float32)
+        out[..., 2 * h + 1] = r * np.sin(th, dtype=np.float32)
+    return out.reshape(n_steps, B, T, dim)
+
+
 # --------------------------------------------------------------------------- sampling loop (A2, A4)
 def diffusion_reverse(denoise_fn, scheduler, text_emb, lengths, init_noise, n_steps,
                       guidance_scale=7.5, eta=0.0, step_noise=None, frame_per_latent=48, test_efficiency=False):

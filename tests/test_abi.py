@@ -32,7 +32,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_errors(lib):
-    assert lib.ladiff_version() == 4
+    assert lib.ladiff_version() == 5
     assert lib.ladiff_error_string(0) == b"ok"
     assert b"workspace" in lib.ladiff_error_string(-3)
 

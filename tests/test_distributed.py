@@ -91,9 +91,12 @@ class _MockPipe:
 
     def __init__(self):
         self.calls = 0
+        self.noise_first_prompt = -1
+        self.first_prompt_seen = None
 
-    def sample(self, text, lens, init_noise=None, step_noise=None):
+    def sample(self, text, lens, init_noise=None, step_noise=None, noise_seed=None):
         self.calls += 1
+        self.first_prompt_seen = self.noise_first_prompt          # bench sets the rank's global prompt offset: keys the device noise
         B = len(lens)
         assert text.shape == (2 * B, 1, 768) and init_noise.shape == (B, 5, 256)
         F = max(lens)
@@ -128,6 +131,7 @@ def _bench_worker(rank, world, port, total, ret):
     gtext, gnoise = syn.text_embeddings(total), syn.init_noise(lens)
     ok = out.shape == (total, max(lens), 251) and calls == {"into": 2, "other": 0} and pipe.calls == 2 and torch.equal(out, out2)
     ok = ok and wl.glens == lens and (wl.lo, wl.hi) == D.shard_range(total, r, w) and wl.B == wl.hi - wl.lo
+    ok = ok and pipe.first_prompt_seen == wl.lo
     for i, l in enumerate(lens):
         want = torch.tensor([gtext[i, 0, 0], gtext[total + i, 0, 0], gnoise[i, 0, 0], float(l)])
         ok = ok and bool((out[i, :l, :4] == want).all()) and bool((out[i, l:] == 0).all())

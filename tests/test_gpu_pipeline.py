@@ -258,16 +258,16 @@ def test_pipeline_ddpm_windows(nets):
 def test_window_timing_switch_reaches_plans_made_later(nets):
     """`window_ms(enable=True)` before any plan exists: the sampler of the plan the next call creates still times its windows."""
     den, vae = nets
-    B, T, n = 3, 5, 150
+    B, T, n = 3, 5, 200                                             # four windows of 50 steps
     lens = [196, 60, 120]
     pipe = LADIFF(denoiser=den, vae=vae, scheduler=DDPMScheduler(variance_type="fixed_small", **SCHED_KW), guidance_scale=7.5,
                   num_inference_timesteps=n, eta=0.0, max_it=T, precision="bf16x3", loop="pipeline")
     pipe.window_ms(enable=True)
     text, noise = syn.text_embeddings(B, seed=3), syn.init_noise(lens, seed=4)
-    pipe._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV), step_noise=syn.ddpm_noise(n, B, seed=5).to(DEV))
+    pipe._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV), noise_seed=5)
     total = pipe.loop_ms()
     ms, windows = pipe.window_ms()
-    assert windows == 3 and 0.0 < ms <= total * 1.05
+    assert windows == 4 and 0.0 < ms <= total * 1.05
 
 
 # ---------------------------------------------------------------- an abandoned pipeline launch (VERDICT r2 #2, ADVICE r2)
@@ -301,13 +301,18 @@ def test_aborted_pipeline_launch_raises_poisons_and_recovers(nets):
             pipe.check()
         pipe.check()                                                   # reported once
         # later calls notice by themselves, without the host ever blocking on a loop that is still running: the next call looks only
-        # if the status words have arrived (here they have not: the loop takes its 20 ms timeout), the one after it waits for them
-        z = pipe._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV))
+        # if the status words have arrived already (the aborting loop takes its 20 ms timeout), the one after it waits for them
+        td, nd = text.to(DEV), noise.to(DEV)
+        z = pipe._diffusion_reverse(td, lens, init_noise=nd)
         pipe.set_pipeline_fault(-1, 0)
-        z = pipe._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV))     # queued behind the aborting call
-        with pytest.raises(_lib.LadiffHipError):
-            pipe._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV))
-        pipe.check()                                                   # the clean call in between: nothing to report
+        raised = 0
+        for _ in range(2):
+            try:
+                pipe._diffusion_reverse(td, lens, init_noise=nd)
+            except _lib.LadiffHipError:
+                raised += 1
+        assert raised == 1                                             # reported by the next call or the one after it, once
+        pipe.check()                                                   # the clean call(s) in between: nothing to report
         pipe.set_pipeline_fault(17, 20)
         z = pipe._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV))
         torch.cuda.synchronize()                                       # status arrived: the very next call reports it
