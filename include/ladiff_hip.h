@@ -263,7 +263,9 @@ int ladiff_debug_set_xcd_local(int on);
  * path; same arithmetic per product).  + 4: decodes of fewer than 4,096 frame rows keep the large-M GEMM kernels instead of the
  * small-M ones (the round-2 routing).  + 8: final_layer on the fp32-input kernel in bf16x3 mode too (the round-2 path).  + 16: the
  * decoder's self-attention as in_proj GEMM + attention kernel (two launches, q | k | v rows through memory) instead of the kernel
- * that computes its head's q | k | v itself (csrc/dec_qkv_attn.hip; default from 4,096 frame rows up); + 32: that kernel at every size. */
+ * that computes its head's q | k | v itself (csrc/dec_qkv_attn.hip; default from 4,096 frame rows up); + 32: that kernel at every size.
+ * + 64: the self-attention out_proj GEMM and the cross-attention row kernel as two launches (x + out_proj(att) through memory) instead
+ * of the one kernel that keeps out_proj's weight in registers (csrc/dec_cross.hip; default from 4,096 frame rows up in bf16x3 mode). */
 int ladiff_debug_set_decoder_fusion(int on);
 /* Measurement switch (process-wide) of the fused feed-forward kernel's form: 0 (default) = chosen by the row count, 1 = 128-row
  * workgroups of eight waves x 16 rows, 2 = 64-row workgroups of four waves x 16 rows, 3 = 128-row workgroups of four waves x 32 rows.

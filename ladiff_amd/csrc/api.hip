@@ -393,7 +393,8 @@ int ladiff_debug_set_mlp_variant(int v) {
 }
 
 int ladiff_debug_set_decoder_fusion(int on) {
-    LADIFF_CHECK_ARG(on >= 0 && on <= 62 && (on & 3) != 3 && (on & 48) != 48);
+    LADIFF_CHECK_ARG(on >= 0 && on <= 126 && (on & 3) != 3 && (on & 48) != 48);
+    g_dec_out_cross = (on & 64) ? 0 : 1;
     g_dec_fused_mlp = on & 3;
     g_dec_small_rows_path = (on & 4) ? 0 : 1;
     g_dec_final_split = (on & 8) ? 0 : 1;

@@ -6,6 +6,7 @@
 namespace ladiff {
 
 constexpr int DEC_SMALL_ROWS = 4096;
+std::atomic<int> g_dec_out_cross{1};          // measurement switch (+ 64): self-attention out_proj GEMM + cross-attention row kernel as two launches (the path before)
 std::atomic<int> g_dec_fused_attn{1};         // measurement switch (+ 16): in_proj GEMM + attention kernel as two launches (the path before)
 std::atomic<int> g_dec_final_split{1};        // measurement switch (ladiff_debug_set_decoder_fusion + 8): final_layer on the fp32 kernel as in round 2
 std::atomic<int> g_dec_small_rows_path{1};    // measurement switch (ladiff_debug_set_decoder_fusion bit 2 clear / set): the small-M GEMM routing
@@ -159,6 +160,12 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
         // norm1: fused in the GEMM epilogue in fp32 mode; in bf16x3 mode the GEMM writes x + out_proj(att) and the only reader of
         // norm1's output, the cross-attention kernel below, normalises its rows as it loads them (one row kernel pass less)
         const NormW* n1_late = nullptr;
+        if (sp && !small && g_dec_out_cross) {
+            // bf16x3 mode, many rows: out_proj + residual + norm1 + cross-attention + residual + norm2 in ONE kernel that keeps Wo in
+            // its registers (dec_cross.hip): x + out_proj(att) is never written
+            LADIFF_TRY(launch_decoder_out_cross(att, cur, Ls.self_attn.out_w, L.self_attn.out_b, L.norm1.g, L.norm1.b, L.cross_attn.out_b,
+                                                L.norm2.g, L.norm2.b, counts, B, F, T, guws + l * gu_l, P[2], Ps[2], s, row_off));
+        } else {
         if (sp) {
             if (small) LADIFF_TRY(krs(att, D, Ls.self_attn.out_w, L.self_attn.out_b, P[1], nullptr, D, D, ACT_NONE, cur, M));
             else {
@@ -174,6 +181,7 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
         // (the q / out projections are folded into the <= 8 keys / values per sample: dec_cross.hip; fp32 in both modes)
         LADIFF_TRY(launch_decoder_cross_apply(P[1], L.cross_attn.out_b, L.norm2.g, L.norm2.b, counts, B, F, T, guws + l * gu_l, P[2],
                                               Ps[2], s, row_off, n1_late ? n1_late->g : nullptr, n1_late ? n1_late->b : nullptr));
+        }
         // ---- feed-forward, GELU(erf), + residual + norm3 (+ decoder.norm on the last layer, cross_attention.py:150-151)   :410-412
         float* dst = is_in ? SK[l] : P[0];
         float* dsts = is_in ? SKs[l] : Ps[0];

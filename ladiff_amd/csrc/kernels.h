@@ -67,6 +67,9 @@ int launch_denoiser_self_attention_general(const float* qkv, const float* text_k
 size_t dec_cross_ws_floats(int B, int T);
 int launch_decoder_cross_prep(const DecCrossPrepBatch& pb, int n, int B, int T, hipStream_t s);
 // g1 / b1 (optional): x holds pre-norm1 rows and the kernel applies LayerNorm(g1, b1) to each row as it loads it
+int launch_decoder_out_cross(const float* att_s, const float* x0, const float* wo_s, const float* bo, const float* g1, const float* b1,
+                             const float* bo_c, const float* g2, const float* b2, const int32_t* counts, int B, int F, int T,
+                             const float* gu_ws, float* y, float* ys, hipStream_t s, const int32_t* row_off);
 int launch_decoder_cross_apply(const float* x, const float* bo, const float* g2, const float* b2, const int32_t* counts, int B, int F,
                                int T, const float* gu_ws, float* y, float* ys, hipStream_t s, const int32_t* row_off = nullptr,
                                const float* g1 = nullptr, const float* b1 = nullptr);

@@ -43,6 +43,7 @@ void den_loop_io(float* ws, int rows, float** x, float** xs);
 extern std::atomic<int> g_dec_fused_mlp;
 extern std::atomic<int> g_dec_small_rows_path;
 extern std::atomic<int> g_dec_final_split;
+extern std::atomic<int> g_dec_out_cross;
 extern std::atomic<int> g_dec_fused_attn;
 extern std::atomic<int> g_mlp_variant;
 int dec_mlp_prepare();           // per-device kernel attributes (dynamic LDS): outside any stream capture, under a mutex

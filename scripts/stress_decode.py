@@ -30,7 +30,7 @@ for case in range(cases):
     out = {}
     with torch.no_grad():
         vae.precision = "bf16x3"
-        for sw in (1, 1, 1 + 16, 0, 1 + 8, 1 + 4, 2 + 32):
+        for sw in (1, 1, 1 + 16, 0, 1 + 8, 1 + 4, 2 + 32, 1 + 64):
             L.ladiff_debug_set_decoder_fusion(sw)
             out.setdefault(sw, []).append(vae.decode(z, lens))
         L.ladiff_debug_set_decoder_fusion(1)
@@ -42,7 +42,7 @@ for case in range(cases):
     msgs = []
     if not torch.isfinite(a).all(): msgs.append("non-finite")
     if not torch.equal(a, out[1][1]): msgs.append("repeat differs")
-    for sw in (17, 0, 9, 5, 34):
+    for sw in (17, 0, 9, 5, 34, 65):
         d = (out[sw][0] - a).abs().max().item()
         if d > 1e-4 * scale: msgs.append(f"switch {sw}: {d:.2e}")
     d = (ref - a).abs().max().item()
