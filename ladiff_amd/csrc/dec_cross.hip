@@ -20,48 +20,48 @@ namespace {
 constexpr int TM = LADIFF_MAX_LATENTS;
 }
 
-// one workgroup per (sample, head): G | U rows [T][2][256] of that head and the score offsets c [T] from the sample's K|V rows.
-// Wq rows h*64 .. are read coalesced over the output column; the Wo tile [256][64] goes through LDS (row stride 65: the
-// per-thread row walk is conflict-free).
+// One workgroup per (group of PREP_SPW samples, head, layer): G | U rows [T][2][256] of that head and the score offsets c [T] from each
+// sample's K|V rows.  Thread n = output column n keeps its 64 Wq values and its 64 Wo values of the head in REGISTERS for all the
+// group's samples; a sample's K | V values are the same for every thread, so they are read with uniform addresses (scalar loads
+// into SGPRs, an FMA takes one as an operand) - no LDS, no barrier.  Before: one workgroup per sample re-read the head's 128 KB of
+// weights for five rows of output (590 MB per decode) and broadcast every K | V value to its 256 threads through the LDS, which
+// was the bound (137 us per decode; profiles/r4).
+constexpr int PREP_SPW = 8;
 __global__ __launch_bounds__(256) void dec_cross_prep_kernel(const DecCrossPrepBatch pb, int B, int T) {
-    __shared__ float wos[D * 65];
-    __shared__ float ks[TM * DH], vs[TM * DH];
-    const int b = blockIdx.x, h = blockIdx.y, n = threadIdx.x, layer = blockIdx.z;
+    const int b0 = blockIdx.x * PREP_SPW, h = blockIdx.y, n = threadIdx.x, layer = blockIdx.z;
     const float* __restrict__ kv = pb.kv[layer]; const float* __restrict__ wq = pb.wq[layer]; const float* __restrict__ bq = pb.bq[layer];
     const float* __restrict__ wo = pb.wo[layer]; float* __restrict__ gu = pb.gu[layer];
     float* __restrict__ cc = gu + (size_t)B * H * T * 2 * D;
-    float qv[DH];                                                                  // Wq[h*64 + d][n]: all 64 loads in flight at once
+    float qv[DH], wv[DH];                                                          // Wq[h*64 + d][n] (coalesced over n), Wo[n][h*64 + d]
 #pragma unroll
     for (int d = 0; d < DH; ++d) qv[d] = wq[(size_t)(h * DH + d) * D + n];
-    for (int u = n; u < D * DH; u += 256) wos[(u >> 6) * 65 + (u & 63)] = wo[(size_t)(u >> 6) * D + h * DH + (u & 63)];
-    for (int u = n; u < T * DH; u += 256) {
-        const int j = u >> 6, d = u & 63;
-        ks[u] = kv[((size_t)j * B + b) * 2 * D + h * DH + d];
-        vs[u] = kv[((size_t)j * B + b) * 2 * D + D + h * DH + d];
+#pragma unroll
+    for (int d4 = 0; d4 < DH; d4 += 4) {
+        const f32x4 w4 = ld4(wo + (size_t)n * D + h * DH + d4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wv[d4 + e] = w4[e];
     }
-    __syncthreads();
-    float g[TM], u_[TM];
+    const int nb = B - b0 < PREP_SPW ? B - b0 : PREP_SPW;
+    const int wvi = __builtin_amdgcn_readfirstlane(n >> 6), ln = n & 63;
+    for (int s = 0; s < nb; ++s) {
+        const int b = b0 + s;
+        for (int j = 0; j < T; ++j) {
+            // uniform addresses in the constant address space: scalar loads (the rows were written by an earlier launch)
+            typedef __attribute__((address_space(4))) const float cfloat;
+            cfloat* kr = (cfloat*)(kv + ((size_t)j * B + b) * 2 * D + h * DH);
+            cfloat* vr = kr + D;
+            float g = 0.f, u = 0.f;
 #pragma unroll
-    for (int j = 0; j < TM; ++j) { g[j] = 0.f; u_[j] = 0.f; }
-#pragma unroll
-    for (int d = 0; d < DH; ++d) {
-        const float q = qv[d];
-        const float w = wos[n * 65 + d];                                           // Wo[n][h*64 + d]
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-            if (j < T) { g[j] = fmaf(q, ks[j * DH + d], g[j]); u_[j] = fmaf(w, vs[j * DH + d], u_[j]); }
-    }
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-        if (j < T) {
+            for (int d = 0; d < DH; ++d) { g = fmaf(qv[d], kr[d], g); u = fmaf(wv[d], vr[d], u); }
             float* o = gu + ((((size_t)b * H + h) * T + j) * 2) * D;
-            o[n] = g[j] * 0.125f;                                                  // 1 / sqrt(64), exact
-            o[D + n] = u_[j];
+            o[n] = g * 0.125f;                                                     // 1 / sqrt(64), exact
+            o[D + n] = u;
+            // c[h][j] = bq_h . k[b,j,h] / 8: one wave sums its 64 products
+            if (wvi == (j & 3)) {
+                const float c = wave_sum(bq[h * DH + ln] * kv[((size_t)j * B + b) * 2 * D + h * DH + ln]);
+                if (ln == 0) cc[((size_t)b * H + h) * T + j] = c * 0.125f;
+            }
         }
-    if (n < T) {                                                                   // c[h][j] = bq_h . k[b,j,h] / 8
-        float c = 0.f;
-        for (int d = 0; d < DH; ++d) c = fmaf(bq[h * DH + d], ks[n * DH + d], c);
-        cc[((size_t)b * H + h) * T + n] = c * 0.125f;
     }
 }
 
@@ -553,7 +553,7 @@ int dec_cross_prepare() {
 int launch_decoder_cross_prep(const DecCrossPrepBatch& pb, int n, int B, int T, hipStream_t s) {
     if (B == 0 || n == 0) return 0;
     if (T < 1 || T > TM || n > DEC_PREP_MAX) return LADIFF_ERR_SHAPE;
-    hipLaunchKernelGGL(dec_cross_prep_kernel, dim3(B, H, n), dim3(256), 0, s, pb, B, T);
+    hipLaunchKernelGGL(dec_cross_prep_kernel, dim3((B + PREP_SPW - 1) / PREP_SPW, H, n), dim3(256), 0, s, pb, B, T);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
