@@ -257,6 +257,13 @@ int ladiff_debug_set_handoff(int tagged);
  * 0 = every hand-off writes through to the memory side, stages in table order; 2 = as 1, but one workgroup of every launch
  * reports a placement that disagrees with the others (test aid: the launch must then agree to write through everywhere and still
  * give the same bits; ladiff_reverse_status reports code 0, info -1 for such a launch). */
+/* Measurement switch (process-wide; takes effect for stage tables built afterwards, i.e. for new samplers): how a layer's workgroups of
+ * the 16-row pipeline plan that hold no MLP slice are dealt.  0 (default) = one OUT workgroup, STYL as two groups on alternating blocks x
+ * two row parts (255 workgroups); 1 = OUT as two groups on alternating blocks, STYL as one group x two row parts (246).  Same results. */
+int ladiff_debug_set_stage_plan(int v);
+/* Measurement switch (process-wide): stage types of the tagged pipeline whose waves rest `len` x ~60 ns between two polls of rows that
+ * are not there yet (mask bits: 1 LIN, 2 RED2, 4 STYL, 8 FFN, 64 SKIP).  Same results. */
+int ladiff_debug_set_poll_pause(int mask, int len);
 int ladiff_debug_set_xcd_local(int on);
 /* Measurement switch (process-wide): 1 (default) = the decoder's feed-forward block runs as the fused kernel of csrc/dec_mlp.hip in
  * bf16x3 mode from 10,000 frame rows up, 2 = at every size, 0 = as linear1 GEMM + linear2 GEMM + LayerNorm row kernel (the round-2

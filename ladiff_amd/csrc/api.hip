@@ -202,6 +202,7 @@ int ladiff_gemm_split(const float* A, int lda, const float* A2, int lda2, int K1
 #ifdef LADIFF_STAMPS
 void ladiff_debug_set_stamps(unsigned long long* p) { g_stamps = p; }   // diagnostic builds only
 void ladiff_debug_set_sys_stamps(unsigned long long* p) { ladiff::g_sys_stamps = p; }
+void ladiff_debug_set_probe(int v) { ladiff::g_sys_probe = v; }        // timing probes of the pipeline kernel: garbage results
 #endif
 
 int ladiff_combine_rows(const float* partials, int n_planes, int M, const float* bias, const float* res, int mode,
@@ -399,6 +400,18 @@ int ladiff_debug_set_decoder_fusion(int on) {
     g_dec_small_rows_path = (on & 4) ? 0 : 1;
     g_dec_final_split = (on & 8) ? 0 : 1;
     g_dec_fused_attn = (on & 16) ? 0 : (on & 32) ? 2 : 1;
+    return 0;
+}
+
+int ladiff_debug_set_stage_plan(int v) {
+    LADIFF_CHECK_ARG(v >= 0 && v <= 1);
+    g_stage_plan = v;
+    return 0;
+}
+
+int ladiff_debug_set_poll_pause(int mask, int len) {
+    LADIFF_CHECK_ARG(mask >= 0 && mask <= 255 && len >= 0 && len <= 64);
+    g_poll_pause = mask | (len << 8);
     return 0;
 }
 

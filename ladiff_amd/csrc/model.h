@@ -44,6 +44,8 @@ extern std::atomic<int> g_dec_fused_mlp;
 extern std::atomic<int> g_dec_small_rows_path;
 extern std::atomic<int> g_dec_final_split;
 extern std::atomic<int> g_dec_out_cross;
+extern std::atomic<int> g_stage_plan;
+extern std::atomic<int> g_poll_pause;
 extern std::atomic<int> g_dec_fused_attn;
 extern std::atomic<int> g_mlp_variant;
 int dec_mlp_prepare();           // per-device kernel attributes (dynamic LDS): outside any stream capture, under a mutex
@@ -66,6 +68,7 @@ int vae_encode(const EncoderW& w, const EncoderW* w_split, const float* features
 // systolic.hip: the guided denoiser loop as one persistent weight-stationary pipeline (both arithmetic modes)
 #ifdef LADIFF_STAMPS
 extern unsigned long long* g_sys_stamps;
+extern int g_sys_probe;
 #endif
 size_t sys_ws_floats(int B, int T);
 bool sys_supported(int B, int T, int cfg, bool split);

@@ -42,6 +42,9 @@
 
 namespace ladiff {
 
+std::atomic<int> g_stage_plan{0};   // measurement switch: ladiff_debug_set_stage_plan (red_plan below)
+std::atomic<int> g_poll_pause{0};   // measurement switch: ladiff_debug_set_poll_pause (mask | len << 8)
+
 namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -113,8 +116,13 @@ static_assert(NRED == 3, "BlockDesc::part_pk");
 // How the reduce workgroups of a layer share a block's rows.  32-row blocks: NRED row parts each (<= 11 rows, 3 per wave).
 // 16-row blocks: a part can take 8 rows (2 per wave), so RED2 needs only two workgroups and the freed one goes to STYL, the
 // busiest stage of that plan: two GROUPS of two parts, group g visiting the blocks b = g (mod 2) - it sees every other block.
-struct RedPlan { int red2_parts, styl_parts, styl_groups; };
-inline RedPlan red_plan(int MR) { return MR == 1 ? RedPlan{2, 2, 2} : RedPlan{NRED, NRED, 1}; }
+struct RedPlan { int red2_parts, styl_parts, styl_groups, out_groups; };
+// how a layer's workgroups that hold no MLP slice are dealt (16-row blocks): variant 0 = one OUT workgroup, STYL as two groups on
+// alternating blocks x two row parts; variant 1 = OUT as two groups on alternating blocks, STYL as one group x two row parts
+inline RedPlan red_plan(int MR) {
+    if (MR != 1) return RedPlan{NRED, NRED, 1, 1};
+    return g_stage_plan.load() == 1 ? RedPlan{2, 2, 1, 2} : RedPlan{2, 2, 2, 1};
+}
 
 struct SysArgs {
     const Stage* stages;
@@ -135,6 +143,8 @@ struct SysArgs {
     unsigned long long timeout_ticks;     // bound of every spin, in s_memrealtime ticks (100 MHz)
     int look_ahead;                       // tagged hand-off: stages may request the next block's rows early (see `settle`)
     NoiseGen gen;                         // on: the TAIL stage draws the per-step noise itself (noise_gen.h) instead of reading `noise`
+    int probe;                            // diagnostic twin build only: timing probes with garbage results (ladiff_debug_set_probe)
+    int pause_mask, pause_len;            // stage types (R::PAUSE_BIT) that rest pause_len x ~60 ns between two polls of rows that are not there yet
     unsigned long long* stamps;           // diagnostic twin build only (-DLADIFF_STAMPS): [workgroup][step][block][8] realtime ticks
 };
 
@@ -556,6 +566,8 @@ __device__ __forceinline__ bool settle(const SysArgs& p, R& r, int s, int b, con
         if (__all((r.bad(s, b, g, y) & 1u) == 0u)) { first_look = spins == 0u; return true; }
         if (spins == 0u) t0 = __builtin_amdgcn_s_memrealtime();
         else if (spin_give_up(p, spins, t0)) return false;
+        if ((p.pause_mask & R::PAUSE_BIT) != 0)
+            for (int i = 0; i < p.pause_len; ++i) __builtin_amdgcn_s_sleep(2);
     }
 }
 template <class R>
@@ -634,6 +646,7 @@ struct QkvRole {
     static constexpr bool PREFETCH = true;
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = false;
+    static constexpr int PAUSE_BIT = 16;
     static constexpr bool TILE = true;
     struct Geo { int gw, rb2, b2[NX]; };                                 // descriptor word `tid` (+ its row's sample-branch); sample-branch of this thread's text slots
     struct Pay { Rows256<MR, WS> x; f32x4 xk[NX]; };
@@ -708,6 +721,21 @@ struct QkvRole {
         const int lane = threadIdx.x & 63, frow = lane & 15;
         f32x4 acc[MR][NTW];
         zero_acc(acc);
+#ifdef LADIFF_STAMPS
+        bool probe = false;                       // timing probe (garbage results), bit 4: the projection at a quarter of its MFMAs
+        if constexpr (AR == 0) {
+            probe = (p.probe & 16) != 0;
+            if (probe) {
+                WFrag<0, NTW, 2> hw;
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { hw.hi[j][q] = wf.hi[j][q]; hw.lo[j][q] = wf.lo[j][q]; }
+                mma<0, 4, NTW, 2, MR>(atile, hw, acc);
+            }
+        }
+        if (probe) {} else
+#endif
         if (nvt == NTW) {
             mma<AR, 4, NTW, 8, MR>(atile, wf, acc);
         } else {                                                         // the SIMD's second wave: one tile (the fragment set's first)
@@ -927,6 +955,7 @@ struct OutRole {
     static constexpr bool PREFETCH = true;
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = false;
+    static constexpr int PAUSE_BIT = 32;
     static constexpr bool TILE = true;
     struct Geo {};
     struct Pay { Rows256<MR, WS> att; f32x4 res[RPW]; };
@@ -1064,6 +1093,21 @@ struct OutRole {
                 }
                 f32x4 acc[MR][NTW];
                 zero_acc(acc);
+#ifdef LADIFF_STAMPS
+                bool probe = false;               // timing probe (garbage results), bit 2: the out-projection at a quarter of its MFMAs
+                if constexpr (AR == 0) {
+                    probe = (p.probe & 4) != 0;
+                    if (probe) {
+                        WFrag<0, NTW, 2> hw;
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) { hw.hi[j][q] = wf.hi[j][q]; hw.lo[j][q] = wf.lo[j][q]; }
+                        mma<0, 4, NTW, 2, MR>(atile, hw, acc);
+                    }
+                }
+                if (!probe)
+#endif
                 mma<AR, 4, NTW, 8, MR>(atile, wf, acc);
                 stage_c(ct, acc, [&](int j) { return 16 * NTW * wave + 16 * j; });
                 lds_barrier();
@@ -1123,6 +1167,7 @@ struct MlpRole {
     static constexpr bool PREFETCH = true;
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = true;
+    static constexpr int PAUSE_BIT = ACT == ACT_GELU ? 8 : 1;          // FFN : LIN
     static constexpr bool TILE = true;
     struct Geo {};
     struct Pay { Rows256<MR, WS> x; };
@@ -1201,6 +1246,22 @@ struct MlpRole {
         const unsigned par = HO ? ring_use_par(p, s, b) : 0u;
         f32x4 acc1[MR][NT1];
         zero_acc(acc1);
+#ifdef LADIFF_STAMPS
+        // timing probe (garbage results): what would the loop do if this stage type were faster?  bit 0: FFN, bit 1: LIN - half of
+        // the first product's k-steps, no activation, half of the second product's k-steps
+        const bool probe = AR == 0 && (p.probe & (ACT == ACT_GELU ? 1 : 2)) != 0;
+        if constexpr (AR == 0) {
+            if (probe) {
+                WFrag<0, NT1, 4> h1;
+#pragma unroll
+                for (int j = 0; j < NT1; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { h1.hi[j][q] = w1.hi[j][q]; h1.lo[j][q] = w1.lo[j][q]; }
+                mma<0, 4, NT1, 4, MR>(atile, h1, acc1);
+            }
+        }
+        if (!probe)
+#endif
         mma<AR, 4, NT1, 8, MR>(atile, w1, acc1);
         SYS_STAMP(3);
         // hidden slice -> S-format operand tile (k = hidden column within the slice)
@@ -1212,6 +1273,10 @@ struct MlpRole {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * i + 4 * fk + r;
+#ifdef LADIFF_STAMPS
+                    if (probe) tile_put1<AR, 2>(htile, row, k, acc1[i][j][r] + b1[j]);
+                    else
+#endif
                     tile_put1<AR, 2>(htile, row, k, act_c<ACT>(acc1[i][j][r] + b1[j]));
                 }
             }
@@ -1222,6 +1287,19 @@ struct MlpRole {
         SYS_STAMP(7);
         f32x4 acc2[MR][NT2];
         zero_acc(acc2);
+#ifdef LADIFF_STAMPS
+        if constexpr (AR == 0) {
+            if (probe) {
+                WFrag<0, NT2, 2> h2;
+#pragma unroll
+                for (int j = 0; j < NT2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { h2.hi[j][q] = w2.hi[j][q]; h2.lo[j][q] = w2.lo[j][q]; }
+                mma<0, 2, NT2, 2, MR>(htile, h2, acc2);
+            }
+        }
+        if (!probe)
+#endif
         mma<AR, 2, NT2, 4, MR>(htile, w2, acc2);
         stage_c(ct, acc2, [&](int j) { return 16 * NT2 * wave + 16 * j; });
         mid.before_stores();
@@ -1246,6 +1324,7 @@ struct Red2Role {
     static constexpr bool PREFETCH = HO == 0;
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = false;
+    static constexpr int PAUSE_BIT = 2;
     static constexpr bool TILE = false;
     struct Geo { int pk[PQ], b2[PQ], row[PQ], t[PQ], cnt[PQ]; };          // slot wave + NW q of this part: raw words, then decoded
     struct Pay { f32x4 pl[PQ][NSLICE], rs[PQ], tv[PQ], tp[PQ]; };
@@ -1354,6 +1433,7 @@ struct StylRole {
     static constexpr bool PREFETCH = MR == 1 && WS == 1;
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = false;
+    static constexpr int PAUSE_BIT = 4;
     struct Geo { int pk[PQ], row[PQ]; };                                 // tile row of slot wave + NW q of this part (-1: none)
     struct Pay { f32x4 pl[PQ][NSLICE], rs[PQ], scl, shf; };
     const SysArgs& p; const Stage& st;
@@ -1444,6 +1524,21 @@ struct StylRole {
         SYS_STAMP(6);
         f32x4 acc[1][NTW];
         zero_acc(acc);
+#ifdef LADIFF_STAMPS
+        bool probe = false;                       // timing probe (garbage results), bit 3: the out product at a quarter of its MFMAs
+        if constexpr (AR == 0) {
+            probe = (p.probe & 8) != 0;
+            if (probe) {
+                WFrag<0, NTW, 2> hw;
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { hw.hi[j][q] = wf.hi[j][q]; hw.lo[j][q] = wf.lo[j][q]; }
+                mma<0, 4, NTW, 2, 1>(atile, hw, acc);
+            }
+        }
+        if (!probe)
+#endif
         mma<AR, 4, NTW, 8, 1>(atile, wf, acc);
         stage_c(ct, acc, [&](int j) { return 16 * NTW * wave + 16 * j; });
         __syncthreads();
@@ -1471,6 +1566,7 @@ struct SkipRole {
     static constexpr bool PREFETCH = true;
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = false;
+    static constexpr int PAUSE_BIT = 64;
     static constexpr bool TILE = true;
     struct Geo {};
     struct Pay { Rows256<MR, WS> x, k; };
@@ -1858,6 +1954,7 @@ __global__ __launch_bounds__(256 * WS, 1) void systolic_loop_kernel(const SysArg
 // ================================================================== host side
 #ifdef LADIFF_STAMPS
 unsigned long long* g_sys_stamps = nullptr;
+int g_sys_probe = 0;                                                   // diagnostic twin build: SysArgs::probe
 #endif
 namespace {
 struct SysLayout {
@@ -1865,7 +1962,11 @@ struct SysLayout {
     size_t off_stages, off_blocks, off_flags, off_status, off_xin0, off_xs, off_xo, off_att, off_x1, off_x2, off_pc, off_pe, total;
     int nwg, NB, split;
 };
-constexpr int NWG = NL * (4 + 1 + NSLICE + NRED + NSLICE + NRED) + 2 * NSKIP + NTAIL;
+constexpr int NWG = NL * (4 + 1 + NSLICE + NRED + NSLICE + NRED) + 2 * NSKIP + NTAIL;     // the largest plan
+int plan_nwg(int MR) {
+    const RedPlan rp = red_plan(MR);
+    return NL * (4 + rp.out_groups + NSLICE + rp.red2_parts + NSLICE + rp.styl_parts * rp.styl_groups) + 2 * NSKIP + NTAIL;
+}
 // 32-row tiles: P prompts per block, both guidance branches, T rows each
 int prompts_per_block32(int T) { int P = 32 / (2 * T); return P > 7 ? 7 : (P < 1 ? 1 : P); }   // QKV parks <= 14 text K|V slots
 int nb32(int B, int T) { const int P = prompts_per_block32(T); return (B + P - 1) / P; }
@@ -1877,7 +1978,7 @@ SysLayout sys_layout(int MR, int NB) {
     const int RT = 16 * MR;
     L.split = MR == 1 ? 1 : 0;
     L.NB = NB;
-    L.nwg = NWG;
+    L.nwg = plan_nwg(MR);
     L.blk = (size_t)NB * RT * D;
     size_t off = 0;
     auto take = [&](size_t floats) { const size_t o = off; off += (floats + 63) / 64 * 64; return o; };
@@ -2110,10 +2211,11 @@ int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR,
             s.w0 = ws_.sa_attn.in_w; s.b0 = w.sa_attn.in_b; s.in0 = xin; s.out = att;
             st.push_back(s);
         }
-        {
+        for (int g = 0; g < rp.out_groups; ++g) {                         // groups: workgroups of their own on alternating blocks
             Stage s{};
             s.role = R_OUT; s.layer = l; s.wait_group = G(l, G_ATT); s.wait_n = H; s.out_group = G(l, G_X1); s.out_slot = 0;
             s.out_rep = NSLICE; s.out_rep_stride = 1;                     // one flag line per LIN workgroup
+            s.blk0 = g; s.blkstride = rp.out_groups;
             s.w0 = ws_.sa_attn.out_w; s.b0 = w.sa_attn.out_b; s.g = w.sa_norm1.g; s.be = w.sa_norm1.b; s.in0 = att; s.in1 = xin; s.out = x1;
             st.push_back(s);
         }
@@ -2202,9 +2304,12 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     a.timeout_ticks = timeout_ticks > 0 ? timeout_ticks : TIMEOUT_TICKS;
     a.look_ahead = NB >= LOOK_AHEAD_BLOCKS ? 1 : 0;
     a.gen = gen;
+    a.pause_mask = g_poll_pause.load() & 0xff; a.pause_len = g_poll_pause.load() >> 8;
+    a.probe = 0;
     a.stamps = nullptr;
 #ifdef LADIFF_STAMPS
     a.stamps = g_sys_stamps;
+    a.probe = g_sys_probe;
 #endif
     // A pipeline kernel needs its 255 workgroups resident at once: two of them launched on different streams of one process
     // could each hold part of the chip and wait for the rest (they would time out, not hang, but the results are lost).  Launches are

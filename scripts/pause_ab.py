@@ -1,0 +1,38 @@
+"""Targeted poll pauses of the tagged pipeline (ladiff_debug_set_poll_pause): loop kernel ms per batch shape, calls queued back to back;
+results compared bit for bit with no pause.  python scripts/pause_ab.py mask:len [mask:len ...]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import bench
+from ladiff_amd import _lib, synthetic as syn
+
+dev = torch.device("cuda", 0)
+L = _lib.lib()
+cfgs = [(0, 0)] + [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] + [(0, 0)]
+shapes = [(64, "u"), (128, "u"), (128, "m"), (256, "u")]
+stream = torch.cuda.Stream(device=dev)
+pipe = bench.build_pipe(dev, 128)
+pipe.precision = "bf16x3"; pipe.loop = "pipeline16"; pipe.num_inference_timesteps = 50
+ref = {}
+data = {}
+for B, kind in shapes:
+    lens = [196] * B if kind == "u" else ([196, 60, 120] * 200)[:B]
+    data[(B, kind)] = (lens, syn.text_embeddings(B).to(dev), syn.init_noise(lens).to(dev))
+for mask, ln in cfgs:
+    _lib.check(L.ladiff_debug_set_poll_pause(mask, ln))
+    row = []
+    for B, kind in shapes:
+        lens, text, noise = data[(B, kind)]
+        with torch.cuda.stream(stream), torch.no_grad():
+            for _ in range(8):
+                z = pipe._diffusion_reverse(text, lens, init_noise=noise)
+            ms = pipe.loop_ms()
+        assert pipe.loop_status()[0] == 0, pipe.loop_status()
+        if (B, kind) in ref:
+            assert torch.equal(ref[(B, kind)], z), "different bits"
+        else:
+            ref[(B, kind)] = z.clone()
+        row.append(f"{B}{kind} {ms:7.3f}")
+    print(f"pause mask {mask:3d} len {ln:2d}: " + " | ".join(row), flush=True)
+_lib.check(L.ladiff_debug_set_poll_pause(0, 0))

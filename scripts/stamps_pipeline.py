@@ -17,6 +17,7 @@ mode = sys.argv[3] if len(sys.argv) > 3 else "pipeline"
 dev = torch.device("cuda", 0)
 L = _lib.lib()
 L.ladiff_debug_set_sys_stamps.argtypes = [ctypes.c_void_p]
+L.ladiff_debug_set_probe(int(os.environ.get("PROBE", "0")))        # timing probes of the twin build (garbage results): scripts/ffn_probe.py
 pipe = bench.build_pipe(dev, B)
 pipe.precision = "bf16x3"; pipe.num_inference_timesteps = steps; pipe.loop = mode
 lens = [196] * B

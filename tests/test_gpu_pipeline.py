@@ -435,3 +435,27 @@ def test_tagged_handoff_full_batch_soak(nets):
     for i in range(30):
         z = _with_handoff(i % 5 != 4, lambda: run(nets, "pipeline16", "bf16x3", B, T, 50, lens))
         assert torch.equal(z, ref), f"call {i} differs"
+
+
+# ---------------------------------------------------------------- round 4: measurement switches of the pipeline that must not change a bit
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+def test_stage_plan_and_poll_pause_switches_keep_the_bits(nets, precision):
+    """`ladiff_debug_set_stage_plan(1)` (OUT as two workgroups on alternating blocks, STYL as one group: 246 workgroups instead of 255)
+    and `ladiff_debug_set_poll_pause` (waves of chosen stage types rest between polls) re-deal work and change timing only: the
+    latents are the same bits - in both hand-off protocols, on a batch with ring back-pressure (88 blocks)."""
+    from ladiff_amd import _lib
+    L = _lib.lib()
+    B, T, steps = 130, 5, 3
+    lens = [max(1, min(196, 48 * ((i % T) + 1) - 5 * (i % 3))) for i in range(B)]
+    ref = run(nets, "pipeline16", precision, B, T, steps, lens)
+    try:
+        assert L.ladiff_debug_set_stage_plan(2) != 0 and L.ladiff_debug_set_poll_pause(256, 1) != 0      # rejected
+        assert L.ladiff_debug_set_stage_plan(1) == 0
+        assert torch.equal(run(nets, "pipeline16", precision, B, T, steps, lens), ref)                    # a new LADIFF object: new stage table
+        assert torch.equal(_with_handoff(False, lambda: run(nets, "pipeline16", precision, B, T, steps, lens)), ref)
+        assert L.ladiff_debug_set_stage_plan(0) == 0
+        assert L.ladiff_debug_set_poll_pause(1 | 2 | 4 | 8 | 64, 3) == 0
+        assert torch.equal(run(nets, "pipeline16", precision, B, T, steps, lens), ref)
+    finally:
+        L.ladiff_debug_set_stage_plan(0)
+        L.ladiff_debug_set_poll_pause(0, 0)
