@@ -20,15 +20,14 @@ namespace {
 constexpr int TM = LADIFF_MAX_LATENTS;
 }
 
-// One workgroup per (group of PREP_SPW samples, head, layer): G | U rows [T][2][256] of that head and the score offsets c [T] from each
+// One workgroup per (group of `spw` samples, head, layer): G | U rows [T][2][256] of that head and the score offsets c [T] from each
 // sample's K|V rows.  Thread n = output column n keeps its 64 Wq values and its 64 Wo values of the head in REGISTERS for all the
 // group's samples; a sample's K | V values are the same for every thread, so they are read with uniform addresses (scalar loads
 // into SGPRs, an FMA takes one as an operand) - no LDS, no barrier.  Before: one workgroup per sample re-read the head's 128 KB of
 // weights for five rows of output (590 MB per decode) and broadcast every K | V value to its 256 threads through the LDS, which
 // was the bound (137 us per decode; profiles/r4).
-constexpr int PREP_SPW = 8;
-__global__ __launch_bounds__(256) void dec_cross_prep_kernel(const DecCrossPrepBatch pb, int B, int T) {
-    const int b0 = blockIdx.x * PREP_SPW, h = blockIdx.y, n = threadIdx.x, layer = blockIdx.z;
+__global__ __launch_bounds__(256) void dec_cross_prep_kernel(const DecCrossPrepBatch pb, int B, int T, int spw) {
+    const int b0 = blockIdx.x * spw, h = blockIdx.y, n = threadIdx.x, layer = blockIdx.z;
     const float* __restrict__ kv = pb.kv[layer]; const float* __restrict__ wq = pb.wq[layer]; const float* __restrict__ bq = pb.bq[layer];
     const float* __restrict__ wo = pb.wo[layer]; float* __restrict__ gu = pb.gu[layer];
     float* __restrict__ cc = gu + (size_t)B * H * T * 2 * D;
@@ -41,7 +40,7 @@ __global__ __launch_bounds__(256) void dec_cross_prep_kernel(const DecCrossPrepB
 #pragma unroll
         for (int e = 0; e < 4; ++e) wv[d4 + e] = w4[e];
     }
-    const int nb = B - b0 < PREP_SPW ? B - b0 : PREP_SPW;
+    const int nb = B - b0 < spw ? B - b0 : spw;
     const int wvi = __builtin_amdgcn_readfirstlane(n >> 6), ln = n & 63;
     for (int s = 0; s < nb; ++s) {
         const int b = b0 + s;
@@ -553,7 +552,10 @@ int dec_cross_prepare() {
 int launch_decoder_cross_prep(const DecCrossPrepBatch& pb, int n, int B, int T, hipStream_t s) {
     if (B == 0 || n == 0) return 0;
     if (T < 1 || T > TM || n > DEC_PREP_MAX) return LADIFF_ERR_SHAPE;
-    hipLaunchKernelGGL(dec_cross_prep_kernel, dim3((B + PREP_SPW - 1) / PREP_SPW, H, n), dim3(256), 0, s, pb, B, T);
+    // samples per workgroup: enough workgroups to fill the chip first (each walks its samples' T rows one scalar-load latency at a time),
+    // then as many samples as possible behind one read of the head's 128 KB of weights
+    const int spw = B * H * n >= 8 * 512 ? 8 : (B * H * n >= 2 * 512 ? 2 : 1);
+    hipLaunchKernelGGL(dec_cross_prep_kernel, dim3((B + spw - 1) / spw, H, n), dim3(256), 0, s, pb, B, T, spw);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
