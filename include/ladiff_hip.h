@@ -262,7 +262,8 @@ int ladiff_debug_set_handoff(int tagged);
  * two row parts (255 workgroups); 1 = OUT as two groups on alternating blocks, STYL as one group x two row parts (246).  Same results. */
 int ladiff_debug_set_stage_plan(int v);
 /* Measurement switch (process-wide): stage types of the tagged pipeline whose waves rest `len` x ~60 ns between two polls of rows that
- * are not there yet (mask bits: 1 LIN, 2 RED2, 4 STYL, 8 FFN, 64 SKIP).  Same results. */
+ * are not there yet (mask bits: 1 LIN, 2 RED2, 4 STYL, 8 FFN, 16 / 32 the loader waves of QKV / OUT, 64 SKIP).  Same results; measured: no shape moves by
+ * more than 1 % (scripts/pause_ab.py) - the loop is not bound by poll traffic. */
 int ladiff_debug_set_poll_pause(int mask, int len);
 int ladiff_debug_set_xcd_local(int on);
 /* Measurement switch (process-wide): 1 (default) = the decoder's feed-forward block runs as the fused kernel of csrc/dec_mlp.hip in

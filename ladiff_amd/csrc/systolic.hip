@@ -833,6 +833,7 @@ struct QkvRole {
                             if (__all((t & 1u) == 0u)) break;
                             if (spin_give_up(p, spins, t0)) return;
                             __builtin_amdgcn_s_sleep(1);
+                            if ((p.pause_mask & 16) != 0) for (int i_ = 0; i_ < p.pause_len; ++i_) __builtin_amdgcn_s_sleep(2);
                             load_x();
                         }
                     }
@@ -1058,6 +1059,7 @@ struct OutRole {
                             if (__all((t & 1u) == 0u)) break;
                             if (spin_give_up(p, spins, t0)) return;
                             __builtin_amdgcn_s_sleep(1);
+                            if ((p.pause_mask & 32) != 0) for (int i_ = 0; i_ < p.pause_len; ++i_) __builtin_amdgcn_s_sleep(2);
                             load_x();
                         }
                     }
