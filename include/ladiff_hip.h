@@ -265,6 +265,9 @@ int ladiff_debug_set_stage_plan(int v);
  * are not there yet (mask bits: 1 LIN, 2 RED2, 4 STYL, 8 FFN, 16 / 32 the loader waves of QKV / OUT, 64 SKIP).  Same results; measured: no shape moves by
  * more than 1 % (scripts/pause_ab.py) - the loop is not bound by poll traffic. */
 int ladiff_debug_set_poll_pause(int mask, int len);
+/* Measurement switch (process-wide): stage types (bits 1 LIN, 2 RED2, 4 STYL, 8 FFN, 64 SKIP) whose workgroups idle `len` x ~60 ns after
+ * every block - a pacing experiment (does a stage that runs ahead of its neighbours cost the loop?).  Same results. */
+int ladiff_debug_set_stage_delay(int mask, int len);
 int ladiff_debug_set_xcd_local(int on);
 /* Measurement switch (process-wide): 1 (default) = the decoder's feed-forward block runs as the fused kernel of csrc/dec_mlp.hip in
  * bf16x3 mode from 10,000 frame rows up, 2 = at every size, 0 = as linear1 GEMM + linear2 GEMM + LayerNorm row kernel (the round-2

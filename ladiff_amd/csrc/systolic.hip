@@ -144,6 +144,7 @@ struct SysArgs {
     int look_ahead;                       // tagged hand-off: stages may request the next block's rows early (see `settle`)
     NoiseGen gen;                         // on: the TAIL stage draws the per-step noise itself (noise_gen.h) instead of reading `noise`
     int probe;                            // diagnostic twin build only: timing probes with garbage results (ladiff_debug_set_probe)
+    int delay_mask, delay_len;            // measurement: stage types (R::PAUSE_BIT) that idle delay_len x ~60 ns after every block (pacing experiment)
     int pause_mask, pause_len;            // stage types (R::PAUSE_BIT) that rest pause_len x ~60 ns between two polls of rows that are not there yet
     unsigned long long* stamps;           // diagnostic twin build only (-DLADIFF_STAMPS): [workgroup][step][block][8] realtime ticks
 };
@@ -626,6 +627,8 @@ __device__ __forceinline__ void tag_loop(const SysArgs& p, const Stage& st, R& r
             r.compute(s, b, gcur, cur, mid);
             settled = mid.settled; issued = mid.ahead;
             gcur = gnxt; gnxt = gnn;
+            if ((p.delay_mask & R::PAUSE_BIT) != 0)
+                for (int i = 0; i < p.delay_len; ++i) __builtin_amdgcn_s_sleep(2);
             SYS_STAMP(4);
             if constexpr (R::PREFETCH) { if (issued) cur = nxt; }
             SYS_STAMP(5);
@@ -2306,7 +2309,8 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     a.timeout_ticks = timeout_ticks > 0 ? timeout_ticks : TIMEOUT_TICKS;
     a.look_ahead = NB >= LOOK_AHEAD_BLOCKS ? 1 : 0;
     a.gen = gen;
-    a.pause_mask = g_poll_pause.load() & 0xff; a.pause_len = g_poll_pause.load() >> 8;
+    a.pause_mask = g_poll_pause.load() & 0xff; a.pause_len = (g_poll_pause.load() >> 8) & 0xff;
+    a.delay_mask = (g_poll_pause.load() >> 16) & 0xff; a.delay_len = (g_poll_pause.load() >> 24) & 0x7f;
     a.probe = 0;
     a.stamps = nullptr;
 #ifdef LADIFF_STAMPS

@@ -454,8 +454,10 @@ def test_stage_plan_and_poll_pause_switches_keep_the_bits(nets, precision):
         assert torch.equal(run(nets, "pipeline16", precision, B, T, steps, lens), ref)                    # a new LADIFF object: new stage table
         assert torch.equal(_with_handoff(False, lambda: run(nets, "pipeline16", precision, B, T, steps, lens)), ref)
         assert L.ladiff_debug_set_stage_plan(0) == 0
-        assert L.ladiff_debug_set_poll_pause(1 | 2 | 4 | 8 | 64, 3) == 0
+        assert L.ladiff_debug_set_poll_pause(1 | 2 | 4 | 8 | 16 | 32 | 64, 3) == 0
+        assert L.ladiff_debug_set_stage_delay(1 | 2 | 4 | 8 | 64, 2) == 0
         assert torch.equal(run(nets, "pipeline16", precision, B, T, steps, lens), ref)
     finally:
         L.ladiff_debug_set_stage_plan(0)
         L.ladiff_debug_set_poll_pause(0, 0)
+        L.ladiff_debug_set_stage_delay(0, 0)
