@@ -268,6 +268,12 @@ int ladiff_debug_set_poll_pause(int mask, int len);
 /* Measurement switch (process-wide): stage types (bits 1 LIN, 2 RED2, 4 STYL, 8 FFN, 64 SKIP) whose workgroups idle `len` x ~60 ns after
  * every block - a pacing experiment (does a stage that runs ahead of its neighbours cost the loop?).  Same results. */
 int ladiff_debug_set_stage_delay(int mask, int len);
+/* Pacing of the tagged pipeline's polling (process-wide): a stage that waited W for a block's rows sleeps eighths / 8 x W before it
+ * starts to poll for the next block's; mask: the stage types that do (only STYL, bit 4, has the code compiled in).  Default: 4, 4 - the
+ * STYL workgroups (4 per layer, each poll = 72 KB of the FFN stages' partial rows) stop loading the lines the busiest stage type is
+ * storing to for half of their wait: loop kernel -3 % at 128 and 256 prompts, unchanged at 64 / mixed lengths (scripts/pause_ab.py,
+ * profiles/r4/12_*).  0, 0 switches it off.  Same results. */
+int ladiff_debug_set_pacing(int eighths, int mask);
 int ladiff_debug_set_xcd_local(int on);
 /* Measurement switch (process-wide): 1 (default) = the decoder's feed-forward block runs as the fused kernel of csrc/dec_mlp.hip in
  * bf16x3 mode from 10,000 frame rows up, 2 = at every size, 0 = as linear1 GEMM + linear2 GEMM + LayerNorm row kernel (the round-2

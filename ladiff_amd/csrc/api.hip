@@ -415,6 +415,12 @@ int ladiff_debug_set_poll_pause(int mask, int len) {
     return 0;
 }
 
+int ladiff_debug_set_pacing(int eighths, int mask) {
+    LADIFF_CHECK_ARG(eighths >= 0 && eighths <= 8 && mask >= 0 && mask <= 255);
+    g_pace = eighths | (mask << 8);
+    return 0;
+}
+
 int ladiff_debug_set_stage_delay(int mask, int len) {
     LADIFF_CHECK_ARG(mask >= 0 && mask <= 255 && len >= 0 && len <= 64);
     g_poll_pause = (g_poll_pause.load() & 0xffff) | (mask << 16) | (len << 24);

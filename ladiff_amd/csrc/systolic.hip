@@ -43,7 +43,8 @@
 namespace ladiff {
 
 std::atomic<int> g_stage_plan{0};   // measurement switch: ladiff_debug_set_stage_plan (red_plan below)
-std::atomic<int> g_poll_pause{0};   // measurement switch: ladiff_debug_set_poll_pause (mask | len << 8)
+std::atomic<int> g_poll_pause{0};   // measurement switches: ladiff_debug_set_poll_pause (mask | len << 8), _stage_delay (<< 16)
+std::atomic<int> g_pace{4 | (4 << 8)};   // ladiff_debug_set_pacing: STYL sleeps half of its last observed wait before polling (measured: -3 % at 128 / 256 prompts)
 
 namespace {
 
@@ -61,6 +62,7 @@ constexpr int FLAG_SLOTS = 16;
 // block b of local step s is (s NB + b) % PRING: blocks are counted THROUGH the steps, so that the reuse distance is PRING
 // blocks at the wrap from one step to the next as well.
 constexpr int PRING = 16;
+constexpr int PACED_ROLES = 4;              // stage types (R::PAUSE_BIT) whose polling is paced (tag_loop): STYL
 constexpr int FLAG_STRIDE = 32;             // words between the flags of two producers: every flag on a 128-byte line of its own
 constexpr int SYS_LDS_BYTES = 100 * 1024;   // > 80 KiB: one workgroup per CU, so the <= 256 workgroups sit on distinct CUs
 constexpr int GROUPS_PER_LAYER = 7;
@@ -144,6 +146,7 @@ struct SysArgs {
     int look_ahead;                       // tagged hand-off: stages may request the next block's rows early (see `settle`)
     NoiseGen gen;                         // on: the TAIL stage draws the per-step noise itself (noise_gen.h) instead of reading `noise`
     int probe;                            // diagnostic twin build only: timing probes with garbage results (ladiff_debug_set_probe)
+    int pace;                             // low byte: eighths of its last observed wait a tag_loop stage sleeps before the first poll of a block; bits 8 ..: the stage types (R::PAUSE_BIT) that do
     int delay_mask, delay_len;            // measurement: stage types (R::PAUSE_BIT) that idle delay_len x ~60 ns after every block (pacing experiment)
     int pause_mask, pause_len;            // stage types (R::PAUSE_BIT) that rest pause_len x ~60 ns between two polls of rows that are not there yet
     unsigned long long* stamps;           // diagnostic twin build only (-DLADIFF_STAMPS): [workgroup][step][block][8] realtime ticks
@@ -600,6 +603,7 @@ __device__ __forceinline__ void tag_loop(const SysArgs& p, const Stage& st, R& r
     r.geo_fix(gcur);
     gnn = gnxt;
     bool settled = false, issued = false, ahead = false;
+    unsigned est = 0u;                    // the wait this wave saw for its last block's rows (10-ns ticks): pacing, see below
     SYS_STAT_DECL;
     for (int s = 0; s < p.n_steps; ++s)
         for (int b = b0; b < p.NB; b += bstride) {
@@ -608,10 +612,27 @@ __device__ __forceinline__ void tag_loop(const SysArgs& p, const Stage& st, R& r
             if constexpr (R::BACKP) { if (!r.backpressure_tag(s, b)) return; }
             SYS_STAT_T0;
             if (!settled) {
+                // Pacing (stage types with R::PAUSE_BIT in PACED_ROLES): a stage that waited W for its previous block's rows will most
+                // likely wait about as long again (the pipeline is periodic) - it sleeps a fraction of W before it starts to poll
+                // instead of polling through the whole wait.  A first look that hits means the rows may have been there for a while: the
+                // estimate decays.  Compiled into the paced stage types only: the others keep their registers.
+                constexpr bool PACED = (R::PAUSE_BIT & PACED_ROLES) != 0;
+                unsigned long long te = 0ull;
+                if constexpr (PACED) {
+                    te = __builtin_amdgcn_s_memrealtime();
+                    if ((p.pace >> 8 & R::PAUSE_BIT) != 0 && !issued && est > 8u) {
+                        const unsigned long long until = te + (unsigned long long)((est * (unsigned)(p.pace & 0xff)) >> 3);
+                        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(1);
+                    }
+                }
                 bool first = false;
                 if (!settle(p, r, s, b, gcur, cur, issued, first)) return;
+                if constexpr (PACED) {
+                    const unsigned obs = (unsigned)(__builtin_amdgcn_s_memrealtime() - te);
+                    est = first ? (est * 3u) >> 2 : (obs < 400u ? obs : 400u);  // ticks of 10 ns; never more than 4 us
+                }
                 ahead = first && p.look_ahead != 0;                      // rows were waiting: the stage is behind - look ahead
-            }
+            } else est >>= 1;
             SYS_STAT_WAIT;
             SYS_STAMP(1);
             int s2 = s, b2 = b + bstride;
@@ -2310,6 +2331,7 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     a.look_ahead = NB >= LOOK_AHEAD_BLOCKS ? 1 : 0;
     a.gen = gen;
     a.pause_mask = g_poll_pause.load() & 0xff; a.pause_len = (g_poll_pause.load() >> 8) & 0xff;
+    a.pace = g_pace.load();
     a.delay_mask = (g_poll_pause.load() >> 16) & 0xff; a.delay_len = (g_poll_pause.load() >> 24) & 0x7f;
     a.probe = 0;
     a.stamps = nullptr;

@@ -9,8 +9,10 @@ from ladiff_amd import _lib, synthetic as syn
 
 dev = torch.device("cuda", 0)
 L = _lib.lib()
-delay = os.environ.get("KNOB") == "delay"       # KNOB=delay: mask:len are ladiff_debug_set_stage_delay arguments (idle after every block)
+knob = os.environ.get("KNOB", "pause")          # pause | delay | pace (pace: "eighths:0")
+delay = knob == "delay"       # KNOB=delay: mask:len are ladiff_debug_set_stage_delay arguments (idle after every block)
 cfgs = [(0, 0)] + [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] + [(0, 0)]
+if knob != "pace": _lib.check(L.ladiff_debug_set_pacing(0, 0))        # the other knobs are measured against the unpaced loop
 shapes = [(64, "u"), (128, "u"), (128, "m"), (256, "u")]
 stream = torch.cuda.Stream(device=dev)
 pipe = bench.build_pipe(dev, 128)
@@ -21,7 +23,8 @@ for B, kind in shapes:
     lens = [196] * B if kind == "u" else ([196, 60, 120] * 200)[:B]
     data[(B, kind)] = (lens, syn.text_embeddings(B).to(dev), syn.init_noise(lens).to(dev))
 for mask, ln in cfgs:
-    _lib.check((L.ladiff_debug_set_stage_delay if delay else L.ladiff_debug_set_poll_pause)(mask, ln))
+    if knob == "pace": _lib.check(L.ladiff_debug_set_pacing(ln, mask))          # mask:eighths
+    else: _lib.check((L.ladiff_debug_set_stage_delay if delay else L.ladiff_debug_set_poll_pause)(mask, ln))
     row = []
     for B, kind in shapes:
         lens, text, noise = data[(B, kind)]
@@ -35,5 +38,5 @@ for mask, ln in cfgs:
         else:
             ref[(B, kind)] = z.clone()
         row.append(f"{B}{kind} {ms:7.3f}")
-    print(f"{'delay' if delay else 'pause'} mask {mask:3d} len {ln:2d}: " + " | ".join(row), flush=True)
-_lib.check(L.ladiff_debug_set_poll_pause(0, 0)); _lib.check(L.ladiff_debug_set_stage_delay(0, 0))
+    print(f"{knob} mask {mask:3d} len {ln:2d}: " + " | ".join(row), flush=True)
+_lib.check(L.ladiff_debug_set_poll_pause(0, 0)); _lib.check(L.ladiff_debug_set_stage_delay(0, 0)); _lib.check(L.ladiff_debug_set_pacing(4, 4))          # the default

@@ -457,7 +457,12 @@ def test_stage_plan_and_poll_pause_switches_keep_the_bits(nets, precision):
         assert L.ladiff_debug_set_poll_pause(1 | 2 | 4 | 8 | 16 | 32 | 64, 3) == 0
         assert L.ladiff_debug_set_stage_delay(1 | 2 | 4 | 8 | 64, 2) == 0
         assert torch.equal(run(nets, "pipeline16", precision, B, T, steps, lens), ref)
+        for eighths, mask in ((0, 0), (8, 4), (6, 255)):                 # the pacing of STYL's polling off, at its longest, for every type asked
+            assert L.ladiff_debug_set_pacing(eighths, mask) == 0
+            assert torch.equal(run(nets, "pipeline16", precision, B, T, steps, lens), ref)
+        assert L.ladiff_debug_set_pacing(9, 4) != 0
     finally:
         L.ladiff_debug_set_stage_plan(0)
         L.ladiff_debug_set_poll_pause(0, 0)
         L.ladiff_debug_set_stage_delay(0, 0)
+        L.ladiff_debug_set_pacing(4, 4)
