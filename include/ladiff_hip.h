@@ -265,8 +265,11 @@ int ladiff_debug_set_stage_plan(int v);
  * are not there yet (mask bits: 1 LIN, 2 RED2, 4 STYL, 8 FFN, 16 / 32 the loader waves of QKV / OUT, 64 SKIP).  Same results; measured: no shape moves by
  * more than 1 % (scripts/pause_ab.py) - the loop is not bound by poll traffic. */
 int ladiff_debug_set_poll_pause(int mask, int len);
-/* Measurement switch (process-wide): stage types (bits 1 LIN, 2 RED2, 4 STYL, 8 FFN, 64 SKIP) whose workgroups idle `len` x ~60 ns after
- * every block - a pacing experiment (does a stage that runs ahead of its neighbours cost the loop?).  Same results. */
+/* Stage types (bits 1 LIN, 2 RED2, 4 STYL, 8 FFN, 64 SKIP) whose workgroups idle `len` x ~60 ns after every block before they look for the
+ * next one's rows (process-wide).  mask = -1 (default): chosen per launch - LIN and FFN, len 4, in launches of <= 60 blocks (a block's
+ * trip through the stages bounds the step there, and eight workgroups polling the lines a critical-path stage is still storing to do not
+ * make it faster: loop -2.2 % at 32 ... 64 prompts and at mixed-length batches of 100 / 128, profiles/r4/14_*), nobody in larger ones.
+ * mask = 0: nobody, whatever the size.  Same results. */
 int ladiff_debug_set_stage_delay(int mask, int len);
 /* Pacing of the tagged pipeline's polling (process-wide): a stage that waited W for a block's rows sleeps eighths / 8 x W before it
  * starts to poll for the next block's; mask: the stage types that do (only STYL, bit 4, has the code compiled in).  Default: 4, 4 - the

@@ -411,7 +411,7 @@ int ladiff_debug_set_stage_plan(int v) {
 
 int ladiff_debug_set_poll_pause(int mask, int len) {
     LADIFF_CHECK_ARG(mask >= 0 && mask <= 255 && len >= 0 && len <= 64);
-    g_poll_pause = (g_poll_pause.load() & ~0xffff) | mask | (len << 8);
+    g_poll_pause = mask | (len << 8);
     return 0;
 }
 
@@ -422,8 +422,8 @@ int ladiff_debug_set_pacing(int eighths, int mask) {
 }
 
 int ladiff_debug_set_stage_delay(int mask, int len) {
-    LADIFF_CHECK_ARG(mask >= 0 && mask <= 255 && len >= 0 && len <= 64);
-    g_poll_pause = (g_poll_pause.load() & 0xffff) | (mask << 16) | (len << 24);
+    LADIFF_CHECK_ARG(mask >= -1 && mask <= 255 && len >= 0 && len <= 64);
+    g_stage_delay = mask < 0 ? -1 : (mask | (len << 8));
     return 0;
 }
 

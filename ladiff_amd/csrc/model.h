@@ -46,6 +46,7 @@ extern std::atomic<int> g_dec_final_split;
 extern std::atomic<int> g_dec_out_cross;
 extern std::atomic<int> g_stage_plan;
 extern std::atomic<int> g_poll_pause;
+extern std::atomic<int> g_stage_delay;
 extern std::atomic<int> g_pace;
 extern std::atomic<int> g_dec_fused_attn;
 extern std::atomic<int> g_mlp_variant;

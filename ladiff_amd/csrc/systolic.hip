@@ -43,7 +43,8 @@
 namespace ladiff {
 
 std::atomic<int> g_stage_plan{0};   // measurement switch: ladiff_debug_set_stage_plan (red_plan below)
-std::atomic<int> g_poll_pause{0};   // measurement switches: ladiff_debug_set_poll_pause (mask | len << 8), _stage_delay (<< 16)
+std::atomic<int> g_poll_pause{0};   // measurement switch: ladiff_debug_set_poll_pause (mask | len << 8)
+std::atomic<int> g_stage_delay{-1}; // ladiff_debug_set_stage_delay (mask | len << 8); -1: by block count (launch_systolic_loop)
 std::atomic<int> g_pace{4 | (4 << 8)};   // ladiff_debug_set_pacing: STYL sleeps half of its last observed wait before polling (measured: -3 % at 128 / 256 prompts)
 
 namespace {
@@ -62,6 +63,7 @@ constexpr int FLAG_SLOTS = 16;
 // block b of local step s is (s NB + b) % PRING: blocks are counted THROUGH the steps, so that the reuse distance is PRING
 // blocks at the wrap from one step to the next as well.
 constexpr int PRING = 16;
+constexpr int SMALL_LAUNCH_BLOCKS = 60;     // launches up to this many blocks: LIN / FFN rest after every block (launch_systolic_loop)
 constexpr int PACED_ROLES = 4;              // stage types (R::PAUSE_BIT) whose polling is paced (tag_loop): STYL
 constexpr int FLAG_STRIDE = 32;             // words between the flags of two producers: every flag on a 128-byte line of its own
 constexpr int SYS_LDS_BYTES = 100 * 1024;   // > 80 KiB: one workgroup per CU, so the <= 256 workgroups sit on distinct CUs
@@ -2332,7 +2334,13 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     a.gen = gen;
     a.pause_mask = g_poll_pause.load() & 0xff; a.pause_len = (g_poll_pause.load() >> 8) & 0xff;
     a.pace = g_pace.load();
-    a.delay_mask = (g_poll_pause.load() >> 16) & 0xff; a.delay_len = (g_poll_pause.load() >> 24) & 0x7f;
+    // Small launches (a block's trip through the stages bounds the step, the stages wait for rows most of the time): the LIN and FFN
+    // workgroups idle ~0.25 us after every block before they start to poll for the next one's rows - those are being produced just then by
+    // a stage on the critical path (OUT / RED2), and eight workgroups loading its lines do not make it faster.  Measured (profiles/r4/14_*):
+    // loop -2.2 % at 32 ... 64 prompts and at 100 / 128 prompts of mixed lengths (<= 58 blocks), nothing from 65 blocks, a loss beyond.
+    const int sd = g_stage_delay.load();
+    if (sd < 0) { a.delay_mask = NB <= SMALL_LAUNCH_BLOCKS ? 1 | 8 : 0; a.delay_len = 4; }
+    else { a.delay_mask = sd & 0xff; a.delay_len = (sd >> 8) & 0x7f; }
     a.probe = 0;
     a.stamps = nullptr;
 #ifdef LADIFF_STAMPS

@@ -12,8 +12,11 @@ L = _lib.lib()
 knob = os.environ.get("KNOB", "pause")          # pause | delay | pace (pace: "eighths:0")
 delay = knob == "delay"       # KNOB=delay: mask:len are ladiff_debug_set_stage_delay arguments (idle after every block)
 cfgs = [(0, 0)] + [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] + [(0, 0)]
-if knob != "pace": _lib.check(L.ladiff_debug_set_pacing(0, 0))        # the other knobs are measured against the unpaced loop
+if knob != "delay": _lib.check(L.ladiff_debug_set_stage_delay(0, 0))       # the other knobs: against a loop without the small-launch rest
+
 shapes = [(64, "u"), (128, "u"), (128, "m"), (256, "u")]
+if os.environ.get("SHAPES"):
+    shapes = [(int(t[:-1]), t[-1]) for t in os.environ["SHAPES"].split(",")]
 stream = torch.cuda.Stream(device=dev)
 pipe = bench.build_pipe(dev, 128)
 pipe.precision = "bf16x3"; pipe.loop = "pipeline16"; pipe.num_inference_timesteps = 50
@@ -39,4 +42,4 @@ for mask, ln in cfgs:
             ref[(B, kind)] = z.clone()
         row.append(f"{B}{kind} {ms:7.3f}")
     print(f"{knob} mask {mask:3d} len {ln:2d}: " + " | ".join(row), flush=True)
-_lib.check(L.ladiff_debug_set_poll_pause(0, 0)); _lib.check(L.ladiff_debug_set_stage_delay(0, 0)); _lib.check(L.ladiff_debug_set_pacing(4, 4))          # the default
+_lib.check(L.ladiff_debug_set_poll_pause(0, 0)); _lib.check(L.ladiff_debug_set_stage_delay(-1, 0)); _lib.check(L.ladiff_debug_set_pacing(4, 4))          # the defaults

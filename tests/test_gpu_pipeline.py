@@ -461,8 +461,15 @@ def test_stage_plan_and_poll_pause_switches_keep_the_bits(nets, precision):
             assert L.ladiff_debug_set_pacing(eighths, mask) == 0
             assert torch.equal(run(nets, "pipeline16", precision, B, T, steps, lens), ref)
         assert L.ladiff_debug_set_pacing(9, 4) != 0
+        # a small launch (44 blocks): by default its LIN / FFN workgroups rest after every block - the same bits as without
+        Bs = 64
+        lens_s = [196] * Bs
+        assert L.ladiff_debug_set_stage_delay(0, 0) == 0
+        small = run(nets, "pipeline16", precision, Bs, T, steps, lens_s)
+        assert L.ladiff_debug_set_stage_delay(-1, 0) == 0
+        assert torch.equal(run(nets, "pipeline16", precision, Bs, T, steps, lens_s), small)
     finally:
         L.ladiff_debug_set_stage_plan(0)
         L.ladiff_debug_set_poll_pause(0, 0)
-        L.ladiff_debug_set_stage_delay(0, 0)
+        L.ladiff_debug_set_stage_delay(-1, 0)
         L.ladiff_debug_set_pacing(4, 4)
