@@ -33,6 +33,7 @@
 // v_mfma_f32_16x16x32_bf16, fp32 accumulation and fp32 everything else); only the summation order of the split products
 // differs (8 hidden slices instead of 4 K-slices).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -2330,7 +2331,9 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     a.force_mismatch = g_xcd_local == 2 ? 1 : 0;
     a.fault_wg = fault_wg;
     a.timeout_ticks = timeout_ticks > 0 ? timeout_ticks : TIMEOUT_TICKS;
-    a.look_ahead = NB >= LOOK_AHEAD_BLOCKS ? 1 : 0;
+    static const int la_from = std::getenv("LADIFF_LOOK_AHEAD_FROM") ? std::atoi(std::getenv("LADIFF_LOOK_AHEAD_FROM")) : LOOK_AHEAD_BLOCKS;      // experiment hook
+    static const int small_upto = std::getenv("LADIFF_SMALL_UPTO") ? std::atoi(std::getenv("LADIFF_SMALL_UPTO")) : SMALL_LAUNCH_BLOCKS;
+    a.look_ahead = NB >= la_from ? 1 : 0;
     a.gen = gen;
     a.pause_mask = g_poll_pause.load() & 0xff; a.pause_len = (g_poll_pause.load() >> 8) & 0xff;
     a.pace = g_pace.load();
@@ -2339,7 +2342,7 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     // a stage on the critical path (OUT / RED2), and eight workgroups loading its lines do not make it faster.  Measured (profiles/r4/14_*):
     // loop -2.2 % at 32 ... 64 prompts and at 100 / 128 prompts of mixed lengths (<= 58 blocks), nothing from 65 blocks, a loss beyond.
     const int sd = g_stage_delay.load();
-    if (sd < 0) { a.delay_mask = NB <= SMALL_LAUNCH_BLOCKS ? 1 | 8 : 0; a.delay_len = 4; }
+    if (sd < 0) { a.delay_mask = NB <= small_upto ? 1 | 8 : 0; a.delay_len = 4; }
     else { a.delay_mask = sd & 0xff; a.delay_len = (sd >> 8) & 0x7f; }
     a.probe = 0;
     a.stamps = nullptr;

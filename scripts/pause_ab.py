@@ -12,7 +12,7 @@ L = _lib.lib()
 knob = os.environ.get("KNOB", "pause")          # pause | delay | pace (pace: "eighths:0")
 delay = knob == "delay"       # KNOB=delay: mask:len are ladiff_debug_set_stage_delay arguments (idle after every block)
 cfgs = [(0, 0)] + [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] + [(0, 0)]
-if knob != "delay": _lib.check(L.ladiff_debug_set_stage_delay(0, 0))       # the other knobs: against a loop without the small-launch rest
+if knob not in ("delay", "none"): _lib.check(L.ladiff_debug_set_stage_delay(0, 0))       # the other knobs: against a loop without the small-launch rest
 
 shapes = [(64, "u"), (128, "u"), (128, "m"), (256, "u")]
 if os.environ.get("SHAPES"):
@@ -26,7 +26,8 @@ for B, kind in shapes:
     lens = [196] * B if kind == "u" else ([196, 60, 120] * 200)[:B]
     data[(B, kind)] = (lens, syn.text_embeddings(B).to(dev), syn.init_noise(lens).to(dev))
 for mask, ln in cfgs:
-    if knob == "pace": _lib.check(L.ladiff_debug_set_pacing(ln, mask))          # mask:eighths
+    if knob == "none": pass                                                      # the library's defaults (thresholds by environment: scripts/thresholds_ab.sh)
+    elif knob == "pace": _lib.check(L.ladiff_debug_set_pacing(ln, mask))          # mask:eighths
     else: _lib.check((L.ladiff_debug_set_stage_delay if delay else L.ladiff_debug_set_poll_pause)(mask, ln))
     row = []
     for B, kind in shapes:
