@@ -38,6 +38,12 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: only the entries declared here (and, for measurement, in
+ * ladiff_hip_debug.h) are exported. */
+#ifndef LADIFF_API
+#define LADIFF_API __attribute__((visibility("default")))
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -68,20 +74,20 @@ enum { LADIFF_ACT_NONE = 0, LADIFF_ACT_RELU = 1, LADIFF_ACT_GELU = 2, LADIFF_ACT
 #define LADIFF_CLIP_MAX_LAYERS 12  /* CLIP ViT-L/14 text tower: 12 layers, width 768 (= LADIFF_TEXT_DIM), 12 heads, MLP 3072 */
 #define LADIFF_CLIP_MAX_POSITIONS 77
 
-int ladiff_version(void);
-const char* ladiff_error_string(int code);
+LADIFF_API int ladiff_version(void);
+LADIFF_API const char* ladiff_error_string(int code);
 
 /* ------------------------------------------------------------------ weight tables */
-int ladiff_denoiser_num_params(void);
-const char* ladiff_denoiser_param_name(int i); /* state-dict key of LADiffDenoiser, ladiff_denoiser.py:62-123 */
-int ladiff_decoder_num_params(void);
-const char* ladiff_decoder_param_name(int i);  /* keys LADiffVae.decode reads, ladiff_vae.py:334-356 */
+LADIFF_API int ladiff_denoiser_num_params(void);
+LADIFF_API const char* ladiff_denoiser_param_name(int i); /* state-dict key of LADiffDenoiser, ladiff_denoiser.py:62-123 */
+LADIFF_API int ladiff_decoder_num_params(void);
+LADIFF_API const char* ladiff_decoder_param_name(int i);  /* keys LADiffVae.decode reads, ladiff_vae.py:334-356 */
 
 /* ------------------------------------------------------------------ unit kernels (parity tests)
  * Y[M,N] = LN?( act(A[M,K] . W[N,K]^T + bias) + res ), A optionally the concat [A | A2] along K.
  * Replaces nn.Linear (+ F.relu / F.gelu / residual / nn.LayerNorm) call sites such as
  * mdiff_transformer.py:62-66, cross_attention.py:79-82 and :408-412.  ln_gamma != NULL needs N == 256. */
-int ladiff_gemm(const float* A, int lda, const float* A2, int lda2, int K1, const float* W, int ldw,
+LADIFF_API int ladiff_gemm(const float* A, int lda, const float* A2, int lda2, int K1, const float* W, int ldw,
                 const float* bias, const float* res, int ldres, const float* ln_gamma,
                 const float* ln_beta, float* Y, int ldy, int M, int N, int K, int act,
                 ladiff_stream_t stream);
@@ -90,14 +96,14 @@ int ladiff_gemm(const float* A, int lda, const float* A2, int lda2, int K1, cons
  *   K == 256:        Y = act( A . W^T + bias ) + res
  *   K == 512 / 1024: split-K - Y receives K/256 raw partial planes [K/256][M][ldy]; bias/act/res are NOT applied,
  *                    combine them with ladiff_combine_rows. */
-int ladiff_gemm_resident(const float* A, int lda, const float* A2, int lda2, int K1, const float* W, int ldw,
+LADIFF_API int ladiff_gemm_resident(const float* A, int lda, const float* A2, int lda2, int K1, const float* W, int ldw,
                          const float* bias, const float* res, int ldres, float* Y, int ldy, int M, int N, int K,
                          int act, int split, float* Ys, ladiff_stream_t stream);
 
 /* Large-M bf16x3 GEMM of the decoder / encoder / CLIP (128x128 tiles, persistent producer/consumer workgroups):
  *   Y and/or Ys = act( [A | A2] . W^T + bias ) (+ res);  A, A2, W are S-format rows (ladiff_split_rows), K and K1
  *   multiples of 64, N multiple of 128, ldy multiple of 64; Y fp32 and Ys its S-format twin, either may be NULL. */
-int ladiff_gemm_split(const float* A, int lda, const float* A2, int lda2, int K1, const float* W, int ldw,
+LADIFF_API int ladiff_gemm_split(const float* A, int lda, const float* A2, int lda2, int K1, const float* W, int ldw,
                       const float* bias, const float* res, int ldres, float* Y, float* Ys, int ldy, int M, int N, int K,
                       int act, ladiff_stream_t stream);
 
@@ -106,14 +112,14 @@ int ladiff_gemm_split(const float* A, int lda, const float* A2, int lda2, int K1
  * this format and evaluates every product as hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation
  * (~2^-16 relative error per product, fp32 exponent range); Ys (may be NULL) receives the K == 256 result in
  * S-format, Y (may then be NULL) in fp32.  ladiff_split_rows converts fp32 [R,K] -> S-format [R,K]. */
-int ladiff_split_rows(const float* x, float* y, int R, int K, ladiff_stream_t stream);
+LADIFF_API int ladiff_split_rows(const float* x, float* y, int R, int K, ladiff_stream_t stream);
 
 /* The decoder layer's feed-forward block as ONE kernel, bf16x3 arithmetic (csrc/dec_mlp.hip):
  *   y / ys [M,256] = LN( x + W2 gelu(W1 x + b1) + b2 ), then a second LayerNorm when ln2_gamma != NULL
  * TransformerDecoderLayer.forward_post, cross_attention.py:410-412 (tgt = norm3(tgt + linear2(gelu(linear1(tgt))))) and, on the
  * last layer, decoder.norm (:150-151).  xs = S-format twin of x (the operand; x is the fp32 residual), w1s [1024,256] and
  * w2s [256,1024] S-format (ladiff_split_rows), b1 [1024], b2 [256]; y fp32 and / or ys S-format (either may be NULL). */
-int ladiff_mlp_ln_fused(const float* xs, const float* x, const float* w1s, const float* b1, const float* w2s, const float* b2,
+LADIFF_API int ladiff_mlp_ln_fused(const float* xs, const float* x, const float* w1s, const float* b1, const float* w2s, const float* b2,
                         const float* ln_gamma, const float* ln_beta, const float* ln2_gamma, const float* ln2_beta, float* y,
                         float* ys, int M, ladiff_stream_t stream);
 
@@ -121,30 +127,30 @@ int ladiff_mlp_ln_fused(const float* xs, const float* x, const float* w1s, const
  *   mode 0: x;   mode 1: LN(x);   mode 2: LN(x) + table[sample row | pad_row] (rows grouped T per sample, sample = row / T, padded when
  *   row % T >= counts[sample % Bs]);   mode 3: SiLU(LN(x) * (1 + table[0:256]) + table[256:512]).
  * Replaces the residual / LayerNorm / StylizationBlock element-wise tails at mdiff_transformer.py:65-66, :160-162. */
-int ladiff_combine_rows(const float* partials, int n_planes, int M, const float* bias, const float* res, int mode,
+LADIFF_API int ladiff_combine_rows(const float* partials, int n_planes, int M, const float* bias, const float* res, int mode,
                         const float* ln_gamma, const float* ln_beta, const float* table, const int32_t* counts,
                         int Bs, int T, int pad_row, float* out, ladiff_stream_t stream);
 
 /* y = LayerNorm(x) over rows of 256 (nn.LayerNorm, eps 1e-5), cross_attention.py:84-85, :150-151 */
-int ladiff_layernorm(const float* x, const float* gamma, const float* beta, float* y, int M,
+LADIFF_API int ladiff_layernorm(const float* x, const float* gamma, const float* beta, float* y, int M,
                      ladiff_stream_t stream);
 
 /* Self-attention core (softmax(QK^T/8 + key mask) V per sample and head) on packed qkv[B*F,768], F <= 224.
  * Key validity: keys < lengths[b], or - when keybits != NULL - bit k of the 256-bit map keybits[b][8] (uint32 words,
  * LSB first).  The nn.MultiheadAttention inside TransformerDecoderLayer.forward_post (cross_attention.py:367-369)
  * and TransformerEncoderLayer.forward_post (:298-300), without the in/out projections. */
-int ladiff_decoder_self_attention(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out,
+LADIFF_API int ladiff_decoder_self_attention(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out,
                                   int B, int F, ladiff_stream_t stream);
 
 /* The same core in bf16x3 arithmetic (q, k, v and the probabilities as bf16 hi + lo pairs, three bf16 MFMAs per product,
  * fp32 softmax and accumulation) for any number of 64-wide heads: qkv[B*F, 3*64*nheads] packed [q | k | v],
  * out[B*F, 64*nheads] fp32.  lengths and keybits may both be NULL (all keys valid); causal != 0 adds key <= query. */
-int ladiff_self_attention_bf16x3(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
+LADIFF_API int ladiff_self_attention_bf16x3(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
                                  int nheads, int causal, ladiff_stream_t stream);
 
 /* Decoder cross-attention core: q[B*F,256] against the T memory tokens kv[T*B,512] (row = t*B+b,
  * K | V), tokens >= counts[b] masked.  cross_attention.py:373-376. */
-int ladiff_decoder_cross_attention(const float* q, const float* kv, const int32_t* counts, float* out,
+LADIFF_API int ladiff_decoder_cross_attention(const float* q, const float* kv, const int32_t* counts, float* out,
                                    int B, int F, int T, ladiff_stream_t stream);
 
 /* ------------------------------------------------------------------ denoiser (LADiffDenoiser.forward)
@@ -155,22 +161,22 @@ int ladiff_decoder_cross_attention(const float* q, const float* kv, const int32_
  *                whole cross-attention block (mdiff_transformer.py:219-247), which with ONE text token adds a
  *                vector that depends on (step, layer, sample) only (ladiff_denoiser.py:193-198).  It is built
  *                from the time tables, so call ladiff_denoiser_time_tables first.                             */
-size_t ladiff_denoiser_tables_floats(int n_steps);
+LADIFF_API size_t ladiff_denoiser_tables_floats(int n_steps);
 /* n_text = text tokens per prompt.  1 (the CLIP pooled token, mld_clip.py:75-78) is the hoisted form above.  n_text > 1
  * (`clip_hidden` / `bert`, mld_clip.py:80-86) is the literal path in fp32 arithmetic (w_split must be NULL): the text
  * cache then holds emb_proj of every token, their per-layer K|V for the self-attention over [latents | text | time], and
  * per (layer, sample, head) the 64x64 matrix sum_n softmax_n(key) value^T of LinearTemporalCrossAttention
  * (mdiff_transformer.py:235-239), which depends on the text only. */
-size_t ladiff_denoiser_text_cache_floats(int B2, int n_steps, int n_text);
-size_t ladiff_denoiser_workspace_bytes(int B2, int T, int n_steps, int n_text);
+LADIFF_API size_t ladiff_denoiser_text_cache_floats(int B2, int n_steps, int n_text);
+LADIFF_API size_t ladiff_denoiser_workspace_bytes(int B2, int T, int n_steps, int n_text);
 
 /* sinusoid[n_steps,768] = Timesteps(768, flip_sin_to_cos, freq_shift 0)(t) for every step of the schedule
  * (tools/embeddings.py:245-285).  It is a t-only table like the scheduler coefficients; the host may fill it
  * itself (bit-identical to the reference's fp32 ops) or with ladiff_timestep_sinusoid. */
-int ladiff_timestep_sinusoid(const int64_t* timesteps, int n_steps, float* sinusoid, ladiff_stream_t stream);
-int ladiff_denoiser_time_tables(const float* const* w, const float* sinusoid, int n_steps,
+LADIFF_API int ladiff_timestep_sinusoid(const int64_t* timesteps, int n_steps, float* sinusoid, ladiff_stream_t stream);
+LADIFF_API int ladiff_denoiser_time_tables(const float* const* w, const float* sinusoid, int n_steps,
                                 float* tables, void* ws, size_t ws_bytes, ladiff_stream_t stream);
-int ladiff_denoiser_text_cache(const float* const* w, const float* text_emb /*[B2,n_text,768]*/, int B2, int n_text,
+LADIFF_API int ladiff_denoiser_text_cache(const float* const* w, const float* text_emb /*[B2,n_text,768]*/, int B2, int n_text,
                                const float* tables, int n_steps, float* cache, void* ws, size_t ws_bytes,
                                ladiff_stream_t stream);
 
@@ -180,7 +186,7 @@ int ladiff_denoiser_text_cache(const float* const* w, const float* text_emb /*[B
  * w_split = NULL: fp32-input MFMA everywhere (bit-for-bit fp32 fma chains).  w_split != NULL: the bf16x3 matrix path;
  * it is a second pointer table in the same order as w whose >= 2-D entries are the S-format copies of the weight
  * matrices (ladiff_split_rows), the other entries are ignored. */
-int ladiff_denoiser_forward(const float* const* w, const float* const* w_split, const float* tables,
+LADIFF_API int ladiff_denoiser_forward(const float* const* w, const float* const* w_split, const float* tables,
                             const int32_t* d_step, const float* text_cache, int n_text, int n_steps,
                             const float* sample /*[Bs,T,256]*/, int Bs, int dup, int T, const int32_t* counts, float* eps, void* ws,
                             size_t ws_bytes, ladiff_stream_t stream);
@@ -190,8 +196,8 @@ int ladiff_denoiser_forward(const float* const* w, const float* const* w_split, 
  * x [B,T,256], xf [B,n_text,256] (text tokens already in the latent width), emb [B,256] time embedding per sample,
  * counts [B] valid latent rows (rows >= counts[b] have their query zeroed; NULL = none), `layer` = block index 0..8 in
  * the order input_blocks, middle_block, output_blocks.  Unit entry point of the n_text > 1 path. */
-size_t ladiff_linear_cross_attention_workspace_bytes(int B, int T, int n_text);
-int ladiff_linear_cross_attention(const float* const* w, int layer, const float* x, const float* xf, const float* emb,
+LADIFF_API size_t ladiff_linear_cross_attention_workspace_bytes(int B, int T, int n_text);
+LADIFF_API int ladiff_linear_cross_attention(const float* const* w, int layer, const float* x, const float* xf, const float* emb,
                                   const int32_t* counts, int B, int T, int n_text, float* out, void* ws, size_t ws_bytes,
                                   ladiff_stream_t stream);
 
@@ -201,17 +207,17 @@ int ladiff_linear_cross_attention(const float* const* w, int layer, const float*
  *   x0 = (x - sqrt(1-a_t) e) / sqrt(a_t);  x' = k_x0 x0 + k_x x + k_eps e + k_noise z
  * (DDIM: k_x0 = sqrt(a_prev), k_eps = sqrt(1-a_prev-sigma^2), k_noise = sigma; DDPM: posterior mean
  * coefficients and sqrt(variance)).  Replaces ladiff.py:487-492 + diffusers *Scheduler.step. */
-int ladiff_cfg_scheduler_step(const float* eps, float* latents /*[B,T,256] in/out*/, const float* coef,
+LADIFF_API int ladiff_cfg_scheduler_step(const float* eps, float* latents /*[B,T,256] in/out*/, const float* coef,
                               const int32_t* d_step, const float* step_noise /*[n,B,T,256] or NULL*/,
                               float guidance_scale, int cfg, int B, int T, ladiff_stream_t stream);
-int ladiff_advance_step(int32_t* d_step, ladiff_stream_t stream);
+LADIFF_API int ladiff_advance_step(int32_t* d_step, ladiff_stream_t stream);
 
 /* latents[B,T,256] = noise * valid * sigma  (ladiff.py:380-390, :407) */
-int ladiff_init_latents(const float* noise, const int32_t* counts, float init_noise_sigma, float* latents,
+LADIFF_API int ladiff_init_latents(const float* noise, const int32_t* counts, float init_noise_sigma, float* latents,
                         int B, int T, ladiff_stream_t stream);
 /* z[T,B,256] = permute(latents) with rows >= counts[b] zeroed  (ladiff.py:500, :562-566).  (Inside
  * ladiff_diffusion_reverse the same kernel also reads the pipeline's abort word and writes NaN when the loop was abandoned.) */
-int ladiff_finalize_latents(const float* latents, const int32_t* counts, float* z, int B, int T,
+LADIFF_API int ladiff_finalize_latents(const float* latents, const int32_t* counts, float* z, int B, int T,
                             ladiff_stream_t stream);
 
 /* ------------------------------------------------------------------ whole reverse loop
@@ -235,97 +241,48 @@ int ladiff_finalize_latents(const float* latents, const int32_t* counts, float* 
  * events on first use, calls hipStreamSynchronize(stream) whenever its capture key changes (before the old graphs are destroyed,
  * after a new stage table is uploaded, before a changed block plan replaces the previous host copy), and a pipeline launch takes
  * a process-wide mutex and waits (on the stream, not the host) for the previous pipeline launch of the device. */
-int ladiff_sampler_create(void** sampler);
-int ladiff_sampler_destroy(void* sampler);
+LADIFF_API int ladiff_sampler_create(void** sampler);
+LADIFF_API int ladiff_sampler_destroy(void* sampler);
 /* How a sampler runs the N steps: 1 (default) = ONE persistent pipeline kernel for the whole loop when the call qualifies
  * (guidance on, one text token, a CU per pipeline stage; both arithmetic modes) - every CU keeps one stage's weights in
  * registers and blocks of prompts flow through the stages (csrc/systolic.hip).  The block geometry is planned per call: 32-row
  * blocks (both guidance branches of three prompts, padded to T latent rows) or LENGTH-AWARE 16-row blocks (one guidance branch of
  * as many prompts as fit with only their valid latent rows; needs h_counts) - whichever the stage-time model predicts faster;
  * 2 / 3 force the 16- / 32-row plan; 0 = one launch per stage, captured in a hipGraph of up to 10 steps. */
-int ladiff_sampler_set_loop(void* sampler, int mode);
-/* Measurement switch (process-wide): waves per SIMD of the stage workgroups of the 16-row plan, 2 (default: 512-thread workgroups,
- * each stage's weight slice split over the two waves of a SIMD) or 1 (256 threads). */
-int ladiff_debug_set_stage_waves(int waves_per_simd);
-/* Measurement switch (process-wide): how the eight-wave stages of the 16-row plan hand a block's rows to the next stage.
- * 1 (default) = the rows carry a parity tag in the last mantissa bit of every word and a consumer loads them until all its words
- * show the parity of the step (no drain, no flag, no separate poll; csrc/systolic.hip, tag4); 0 = the flag protocol (write-through
- * or XCD-local stores, drain, barrier, one epoch word per producer, polled by every consumer wave).  Both give the same bits. */
-int ladiff_debug_set_handoff(int tagged);
-/* Measurement switch (process-wide, read when a sampler builds its stage table): 1 (default) = the pipeline stages are dealt to
- * the XCDs in chain order and a stage whose readers share its XCD hands its rows over through that XCD's L2 (plain stores);
- * 0 = every hand-off writes through to the memory side, stages in table order; 2 = as 1, but one workgroup of every launch
- * reports a placement that disagrees with the others (test aid: the launch must then agree to write through everywhere and still
- * give the same bits; ladiff_reverse_status reports code 0, info -1 for such a launch). */
-/* Measurement switch (process-wide; takes effect for stage tables built afterwards, i.e. for new samplers): how a layer's workgroups of
- * the 16-row pipeline plan that hold no MLP slice are dealt.  0 (default) = one OUT workgroup, STYL as two groups on alternating blocks x
- * two row parts (255 workgroups); 1 = OUT as two groups on alternating blocks, STYL as one group x two row parts (246).  Same results. */
-int ladiff_debug_set_stage_plan(int v);
-/* Measurement switch (process-wide): stage types of the tagged pipeline whose waves rest `len` x ~60 ns between two polls of rows that
- * are not there yet (mask bits: 1 LIN, 2 RED2, 4 STYL, 8 FFN, 16 / 32 the loader waves of QKV / OUT, 64 SKIP).  Same results; measured: no shape moves by
- * more than 1 % (scripts/pause_ab.py) - the loop is not bound by poll traffic. */
-int ladiff_debug_set_poll_pause(int mask, int len);
-/* Stage types (bits 1 LIN, 2 RED2, 4 STYL, 8 FFN, 64 SKIP) whose workgroups idle `len` x ~60 ns after every block before they look for the
- * next one's rows (process-wide).  mask = -1 (default): chosen per launch - LIN and FFN, len 4, in launches of <= 60 blocks (a block's
- * trip through the stages bounds the step there, and eight workgroups polling the lines a critical-path stage is still storing to do not
- * make it faster: loop -2.2 % at 32 ... 64 prompts and at mixed-length batches of 100 / 128, profiles/r4/14_*), nobody in larger ones.
- * mask = 0: nobody, whatever the size.  Same results. */
-int ladiff_debug_set_stage_delay(int mask, int len);
-/* Pacing of the tagged pipeline's polling (process-wide): a stage that waited W for a block's rows sleeps eighths / 8 x W before it
- * starts to poll for the next block's; mask: the stage types that do (only STYL, bit 4, has the code compiled in).  Default: 4, 4 - the
- * STYL workgroups (4 per layer, each poll = 72 KB of the FFN stages' partial rows) stop loading the lines the busiest stage type is
- * storing to for half of their wait: loop kernel -3 % at 128 and 256 prompts, unchanged at 64 / mixed lengths (scripts/pause_ab.py,
- * profiles/r4/12_*).  0, 0 switches it off.  Same results. */
-int ladiff_debug_set_pacing(int eighths, int mask);
-int ladiff_debug_set_xcd_local(int on);
-/* Measurement switch (process-wide): 1 (default) = the decoder's feed-forward block runs as the fused kernel of csrc/dec_mlp.hip in
- * bf16x3 mode from 10,000 frame rows up, 2 = at every size, 0 = as linear1 GEMM + linear2 GEMM + LayerNorm row kernel (the round-2
- * path; same arithmetic per product).  + 4: decodes of fewer than 4,096 frame rows keep the large-M GEMM kernels instead of the
- * small-M ones (the round-2 routing).  + 8: final_layer on the fp32-input kernel in bf16x3 mode too (the round-2 path).  + 16: the
- * decoder's self-attention as in_proj GEMM + attention kernel (two launches, q | k | v rows through memory) instead of the kernel
- * that computes its head's q | k | v itself (csrc/dec_qkv_attn.hip; default from 4,096 frame rows up); + 32: that kernel at every size.
- * + 64: the self-attention out_proj GEMM and the cross-attention row kernel as two launches (x + out_proj(att) through memory) instead
- * of the one kernel that keeps out_proj's weight in registers (csrc/dec_cross.hip; default from 4,096 frame rows up in bf16x3 mode). */
-int ladiff_debug_set_decoder_fusion(int on);
-/* Measurement switch (process-wide) of the fused feed-forward kernel's form: 0 (default) = chosen by the row count, 1 = 128-row
- * workgroups of eight waves x 16 rows, 2 = 64-row workgroups of four waves x 16 rows, 3 = 128-row workgroups of four waves x 32 rows.
- * Every accepted value gives the same result; anything else returns LADIFF_ERR_ARG.  (The timing builds of rounds 3 - values 11 .. 17 and
- * 21 .. 26, kernels with one ingredient removed whose results are garbage - are not in this library: they are instantiated in the
- * diagnostic twin libladiff_hip_stamps.so only, `python -m ladiff_amd.build --stamps`, for scripts/mlp_speed.py and attn_speed.py.) */
-int ladiff_debug_set_mlp_variant(int v);
+LADIFF_API int ladiff_sampler_set_loop(void* sampler, int mode);
 /* The block plan ladiff_diffusion_reverse would use for a batch (host arithmetic only, no GPU call): rows per block (16 = the
  * length-aware packing, 32 = padded blocks) and the number of blocks.  h_counts = latent counts on the host or NULL, masked = the
  * call passes device counts, loop_mode 1 / 2 / 3 as ladiff_sampler_set_loop, bf16x3 = the call passes w_split, cfg = the call's
  * guidance flag (without guidance: one-branch 16-row blocks; LADIFF_ERR_UNSUPPORTED when such a call has device-only counts - it runs
  * launch-per-stage and has no block plan). */
-int ladiff_reverse_plan(int B, int T, const int32_t* h_counts, int masked, int loop_mode, int bf16x3, int cfg, int* rows_per_block,
+LADIFF_API int ladiff_reverse_plan(int B, int T, const int32_t* h_counts, int masked, int loop_mode, int bf16x3, int cfg, int* rows_per_block,
                         int* n_blocks);
 /* Device time of the N-step loop of the sampler's last call (HIP events recorded on the call's stream right around the
  * pipeline kernel, or around the graph replays); blocks until it has finished.  Measurement aid (bench.py). */
-int ladiff_sampler_loop_ms(void* sampler, float* ms);
+LADIFF_API int ladiff_sampler_loop_ms(void* sampler, float* ms);
 /* Measurement aids (bench.py --config c3).  A schedule longer than 64 steps runs as several windows (the hoisted cross-attention
  * table is rebuilt per window, the latents carry over): with window timing on, every window's loop launches are bracketed by
  * their own event pair, and ladiff_sampler_window_ms returns their sum and count for the last call (blocks until they have
  * completed) - ladiff_sampler_loop_ms minus that sum is what the table rebuilds between the windows cost.
  * ladiff_sampler_last_loop: whether the last call ran the persistent pipeline kernel (1) or launch-per-stage graphs (0), and
  * the pipeline's block plan (rows per block, blocks; 0 otherwise). */
-int ladiff_sampler_set_window_timing(void* sampler, int on);
-int ladiff_sampler_window_ms(void* sampler, float* loop_ms_sum, int* n_windows);
-int ladiff_sampler_last_loop(void* sampler, int* pipeline, int* rows_per_block, int* n_blocks);
+LADIFF_API int ladiff_sampler_set_window_timing(void* sampler, int on);
+LADIFF_API int ladiff_sampler_window_ms(void* sampler, float* loop_ms_sum, int* n_windows);
+LADIFF_API int ladiff_sampler_last_loop(void* sampler, int* pipeline, int* rows_per_block, int* n_blocks);
 /* Blocking read (hipMemcpy: synchronises the device) of the pipeline kernel's status words of the last call in this workspace:
  * code 0 = completed, 2 = a stage timed out waiting for its producer (info = workgroup) - the loop was abandoned, every later
  * window of the call ended at once and z was filled with NaN; code 0 with info -1 = completed, but the workgroups were not on
  * the XCDs the plan assumed and every hand-off was written through (slower, same results).  The words are cleared once per
  * ladiff_diffusion_reverse call and are sticky over its windows; loop forms other than the pipeline leave them at 0. */
-int ladiff_reverse_status(void* ws, int B, int T, int n_steps, int n_text, int* code, int* info);
+LADIFF_API int ladiff_reverse_status(void* ws, int B, int T, int n_steps, int n_text, int* code, int* info);
 /* Where those two uint32 words {code, info} live: byte offset from the workspace base (0 = bad arguments).  A caller that must
  * not block copies the 8 bytes to pinned host memory with an async copy on the call's stream and reads them once an event
  * recorded behind the copy has completed (ladiff_amd/pipeline.py does, and raises / re-runs the call launch-per-stage). */
-size_t ladiff_reverse_status_offset_bytes(int B, int T, int n_steps, int n_text);
+LADIFF_API size_t ladiff_reverse_status_offset_bytes(int B, int T, int n_steps, int n_text);
 /* Fault injection for the abort-path tests, a property of ONE sampler handle: workgroup >= 0 makes that pipeline workgroup leave right
  * after the start-up handshake of every launch of this sampler, so that its consumers time out (-1: off); timeout_ms > 0 replaces the
  * 1.5 s bound of every wait (0: default).  Other samplers of the process are not affected. */
-int ladiff_sampler_set_fault(void* sampler, int workgroup, int timeout_ms);
+LADIFF_API int ladiff_sampler_set_fault(void* sampler, int workgroup, int timeout_ms);
 /* Per-step noise of the stochastic schedulers (DDPM, DDIM with eta > 0) drawn ON THE DEVICE, where it is consumed, instead of read
  * from a [n_steps,B,T,256] tensor (655 MB for 1000 steps x 128 prompts).  Replaces diffusers' `randn_tensor` inside
  * `scheduler.step` (reference call site: ladiff.py:492; configs/modules_novae/scheduler.yaml:16-29).  A value is a pure function of
@@ -336,11 +293,11 @@ int ladiff_sampler_set_fault(void* sampler, int workgroup, int timeout_ms);
  *     step_noise = NULL draw from the generator (a non-NULL step_noise still wins); enable = 0: such calls add no noise (as before).
  *   ladiff_noise_fill: the same values as a tensor, out[i][b][t][:] for schedule positions first_step + i (tests, oracle checks,
  *     callers that want to keep the noise). */
-int ladiff_sampler_set_noise_generator(void* sampler, uint64_t seed, uint32_t first_prompt, int enable);
-int ladiff_noise_fill(uint64_t seed, uint32_t first_prompt, int first_step, int n_steps, int B, int T, float* out /*[n_steps,B,T,256]*/,
+LADIFF_API int ladiff_sampler_set_noise_generator(void* sampler, uint64_t seed, uint32_t first_prompt, int enable);
+LADIFF_API int ladiff_noise_fill(uint64_t seed, uint32_t first_prompt, int first_step, int n_steps, int B, int T, float* out /*[n_steps,B,T,256]*/,
                       ladiff_stream_t stream);
-size_t ladiff_reverse_workspace_bytes(int B, int T, int n_steps, int n_text);
-int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* const* w_split /*or NULL*/,
+LADIFF_API size_t ladiff_reverse_workspace_bytes(int B, int T, int n_steps, int n_text);
+LADIFF_API int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* const* w_split /*or NULL*/,
                              uint64_t weights_generation, const float* text_emb /*[2B or B,n_text,768]*/,
                              const float* init_noise /*[B,T,256]*/, const int32_t* counts /*[B] or NULL*/,
                              const int32_t* final_counts /*[B] or NULL*/,
@@ -357,8 +314,8 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
  * (ABI 4; ABI 3 asked for tables padded to ceil(C / 128) * 128 rows - such tables still work, the extra rows are not read): from 4,096
  * frame rows up the final projection runs on whole 128-column bf16x3 tiles, and the library pads the rows it needs itself.  The bias is
  * taken from the fp32 table `w`. */
-size_t ladiff_decoder_workspace_bytes(int B, int F, int T, int C);
-int ladiff_vae_decode(const float* const* w, const float* const* w_split /*or NULL: fp32 MFMA*/, const float* z,
+LADIFF_API size_t ladiff_decoder_workspace_bytes(int B, int F, int T, int C);
+LADIFF_API int ladiff_vae_decode(const float* const* w, const float* const* w_split /*or NULL: fp32 MFMA*/, const float* z,
                       const int32_t* lengths, const int32_t* counts, int B, int F, int T, int C, float* feats,
                       void* ws, size_t ws_bytes, ladiff_stream_t stream);
 /* The same decode computing ONLY the valid frames of a mixed-length batch (ragged rows): row_off[b] (device int32,
@@ -367,7 +324,7 @@ int ladiff_vae_decode(const float* const* w, const float* const* w_split /*or NU
  * frames do not depend on the other samples or on padding - padded frames are masked keys (cross_attention.py:367-371)
  * and zeroed at the end (ladiff_vae.py:356-360) - so the output equals ladiff_vae_decode's.  The workspace of
  * ladiff_decoder_workspace_bytes(B, F, T, C) is enough. */
-int ladiff_vae_decode_ragged(const float* const* w, const float* const* w_split /*or NULL*/, const float* z,
+LADIFF_API int ladiff_vae_decode_ragged(const float* const* w, const float* const* w_split /*or NULL*/, const float* z,
                              const int32_t* lengths, const int32_t* counts, const int32_t* row_off, int total_rows, int B,
                              int F, int T, int C, float* feats, void* ws, size_t ws_bytes, ladiff_stream_t stream);
 
@@ -378,9 +335,9 @@ int ladiff_vae_decode_ragged(const float* const* w, const float* const* w_split 
  * `weights_generation`, as ladiff_diffusion_reverse) and is re-captured - after a hipStreamSynchronize(stream) - when any of them
  * changes, so callers keep z / feats / ws in persistent buffers.  `stream` must not be the null stream (capture is illegal there).
  * ladiff_decoder_graph_destroy synchronises the device. */
-int ladiff_decoder_graph_create(void** graph);
-int ladiff_decoder_graph_destroy(void* graph);
-int ladiff_vae_decode_graphed(void* graph, const float* const* w, const float* const* w_split /*or NULL*/, uint64_t weights_generation,
+LADIFF_API int ladiff_decoder_graph_create(void** graph);
+LADIFF_API int ladiff_decoder_graph_destroy(void* graph);
+LADIFF_API int ladiff_vae_decode_graphed(void* graph, const float* const* w, const float* const* w_split /*or NULL*/, uint64_t weights_generation,
                               const float* z, const int32_t* lengths, const int32_t* counts, const int32_t* row_off /*or NULL*/,
                               int total_rows, int B, int F, int T, int C, float* feats, void* ws, size_t ws_bytes,
                               ladiff_stream_t stream);
@@ -390,10 +347,10 @@ int ladiff_vae_decode_graphed(void* graph, const float* const* w, const float* c
  * mu, std, latent, each [T,B,256] (sequence-first like the reference); latent = mu + std * eps with rows >= counts[b]
  * zeroed; eps[T,B,256] stands in for the draw inside Normal.rsample().  F + 2T <= 224.  Weight table as for the
  * decoder: ladiff_encoder_param_name(i) lists the state-dict keys. */
-int ladiff_encoder_num_params(void);
-const char* ladiff_encoder_param_name(int i);
-size_t ladiff_encoder_workspace_bytes(int B, int F, int T, int C);
-int ladiff_vae_encode(const float* const* w, const float* const* w_split /*or NULL*/, const float* features,
+LADIFF_API int ladiff_encoder_num_params(void);
+LADIFF_API const char* ladiff_encoder_param_name(int i);
+LADIFF_API size_t ladiff_encoder_workspace_bytes(int B, int F, int T, int C);
+LADIFF_API int ladiff_vae_encode(const float* const* w, const float* const* w_split /*or NULL*/, const float* features,
                       const int32_t* lengths, const int32_t* counts, const float* eps, int B, int F, int T, int C,
                       float* mu, float* std, float* latent, void* ws, size_t ws_bytes, ladiff_stream_t stream);
 
@@ -405,10 +362,10 @@ int ladiff_vae_encode(const float* const* w, const float* const* w_split /*or NU
  * the pooled EOS row (argmax of the ids) does not depend on later positions, so any L > max_b argmax(ids[b]) gives the
  * same result as L = S.  The pointer table lists LADIFF_CLIP_MAX_LAYERS layers; a model with n_layers < 12 fills the
  * first 5 + 16 * n_layers entries (rest may be NULL).  vocab = rows of the token-embedding table. */
-int ladiff_clip_num_params(void);
-const char* ladiff_clip_param_name(int i);     /* keys of transformers.CLIPModel.state_dict() (text side) */
-size_t ladiff_clip_workspace_bytes(int B, int L);
-int ladiff_clip_text_encode(const float* const* w, const float* const* w_split /*or NULL*/, int n_layers, int vocab,
+LADIFF_API int ladiff_clip_num_params(void);
+LADIFF_API const char* ladiff_clip_param_name(int i);     /* keys of transformers.CLIPModel.state_dict() (text side) */
+LADIFF_API size_t ladiff_clip_workspace_bytes(int B, int L);
+LADIFF_API int ladiff_clip_text_encode(const float* const* w, const float* const* w_split /*or NULL*/, int n_layers, int vocab,
                             const int64_t* ids, int B, int S, int L, float* out, void* ws, size_t ws_bytes,
                             ladiff_stream_t stream);
 
@@ -423,27 +380,27 @@ int ladiff_clip_text_encode(const float* const* w, const float* const* w_split /
  *             -> out[B,512].
  * Pointer tables: ladiff_t2m_*_param_name(i) are the keys of the `movement_encoder` / `motion_encoder` / `text_encoder`
  * state dicts of the evaluator checkpoint (ladiff.py:205-212). */
-int ladiff_t2m_movement_num_params(void);
-const char* ladiff_t2m_movement_param_name(int i);
-int ladiff_t2m_motion_num_params(void);
-const char* ladiff_t2m_motion_param_name(int i);
-int ladiff_t2m_text_num_params(void);
-const char* ladiff_t2m_text_param_name(int i);
-size_t ladiff_t2m_movement_workspace_bytes(int B, int F, int Cin);
-size_t ladiff_t2m_motion_workspace_bytes(int B, int T);
-size_t ladiff_t2m_text_workspace_bytes(int B, int L);
-int ladiff_t2m_movement_encode(const float* const* w, const float* feats, int ld, int B, int F, int Cin, float* out,
+LADIFF_API int ladiff_t2m_movement_num_params(void);
+LADIFF_API const char* ladiff_t2m_movement_param_name(int i);
+LADIFF_API int ladiff_t2m_motion_num_params(void);
+LADIFF_API const char* ladiff_t2m_motion_param_name(int i);
+LADIFF_API int ladiff_t2m_text_num_params(void);
+LADIFF_API const char* ladiff_t2m_text_param_name(int i);
+LADIFF_API size_t ladiff_t2m_movement_workspace_bytes(int B, int F, int Cin);
+LADIFF_API size_t ladiff_t2m_motion_workspace_bytes(int B, int T);
+LADIFF_API size_t ladiff_t2m_text_workspace_bytes(int B, int L);
+LADIFF_API int ladiff_t2m_movement_encode(const float* const* w, const float* feats, int ld, int B, int F, int Cin, float* out,
                                void* ws, size_t ws_bytes, ladiff_stream_t stream);
-int ladiff_t2m_motion_encode(const float* const* w, const float* movements, const int32_t* m_lens, int B, int T, float* out,
+LADIFF_API int ladiff_t2m_motion_encode(const float* const* w, const float* movements, const int32_t* m_lens, int B, int T, float* out,
                              void* ws, size_t ws_bytes, ladiff_stream_t stream);
-int ladiff_t2m_text_encode(const float* const* w, const float* word_embs, const float* pos_onehot, const int32_t* cap_lens,
+LADIFF_API int ladiff_t2m_text_encode(const float* const* w, const float* word_embs, const float* pos_onehot, const int32_t* cap_lens,
                            int B, int L, float* out, void* ws, size_t ws_bytes, ladiff_stream_t stream);
 
 /* ------------------------------------------------------------------ feats2joints (the step after the path)
  * joints[B,F,njoints,3] = recover_from_ric(feats * std + mean): HumanML3DDataModule.feats2joints
  * (data/HumanML3D.py:44-48, data/Kit.py:48-53; motion_process.py:362-381, :415-430).  feats [B,F,C] as produced by
  * ladiff_vae_decode, mean/std [C] (device), C = 263 with 22 joints or 251 with 21 joints, F <= 256. */
-int ladiff_feats2joints(const float* feats, const float* mean, const float* std, int B, int F, int C, int njoints,
+LADIFF_API int ladiff_feats2joints(const float* feats, const float* mean, const float* std, int B, int F, int C, int njoints,
                         float* joints, ladiff_stream_t stream);
 
 #ifdef __cplusplus

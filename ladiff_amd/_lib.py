@@ -76,6 +76,9 @@ _SIGNATURES = {
     "ladiff_debug_set_poll_pause": (c_int, [c_int, c_int]),
     "ladiff_debug_set_stage_delay": (c_int, [c_int, c_int]),
     "ladiff_debug_set_pacing": (c_int, [c_int, c_int]),
+    "ladiff_debug_set_loop_thresholds": (c_int, [c_int, c_int]),
+    "ladiff_debug_set_graph_epoch_rule": (c_int, [c_int]),
+    "ladiff_debug_graph_instantiations": (c_int, []),
     "ladiff_sampler_set_fault": (c_int, [c_void_p, c_int, c_int]),
     "ladiff_sampler_set_noise_generator": (c_int, [c_void_p, c_uint64, ctypes.c_uint32, c_int]),
     "ladiff_noise_fill": (c_int, [c_uint64, ctypes.c_uint32, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -9,7 +9,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libladiff_hip.so")
 SOURCES = ["gemm.hip", "gemm_big.hip", "gemm_kr.hip", "gemm_rowln.hip", "rowops.hip", "attention.hip", "qkv_attn.hip", "systolic.hip", "linear_ca.hip", "dec_cross.hip", "dec_mlp.hip", "dec_qkv_attn.hip", "feats2joints.hip", "denoiser.hip", "decoder.hip", "encoder.hip", "clip.hip", "evaluator.hip", "api.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -fvisibility=hidden: the library exports the C ABI of include/ladiff_hip.h (+ ladiff_hip_debug.h) and nothing else (LADIFF_API)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc():
@@ -26,25 +27,30 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def stamps_lib(level=1):
+    """Path of the diagnostic twin of a stamps level (1: per-workgroup totals only, 2: + per-block timeline)."""
+    return LIB.replace(".so", "_stamps.so" if int(level) == 1 else f"_stamps{int(level)}.so")
+
+
 def build(force=False, verbose=False, stamps=False):
-    """stamps=True builds the diagnostic twin libladiff_hip_stamps.so (in-kernel s_memtime stamps; never timed)."""
-    global OBJ, LIB
-    flags = list(FLAGS)
+    """stamps=True builds the diagnostic twin (in-kernel s_memrealtime stamps and timing probes; never timed, never shipped as the
+    product): level 1 -> libladiff_hip_stamps.so, LADIFF_STAMPS_LEVEL=2 in the environment -> libladiff_hip_stamps2.so (each level has
+    its own object directory AND its own library, so one never serves the other)."""
+    obj, lib, flags = OBJ, LIB, list(FLAGS)
     if stamps:
-        OBJ, LIB = OBJ + "_stamps", LIB.replace(".so", "_stamps.so")
-        # LADIFF_STAMPS=1: per-workgroup totals only (blocked / busy time: undistorted); LADIFF_STAMPS_LEVEL=2 in the environment adds
-        # the per-block timeline stamps (~0.1 us each: read intervals from it, not totals)
+        # level 1: per-workgroup totals only (blocked / busy time: undistorted); level 2 adds the per-block timeline stamps (~0.1 us
+        # each: read intervals from it, not totals)
         lvl = os.environ.get("LADIFF_STAMPS_LEVEL", "1")
-        OBJ += lvl if lvl != "1" else ""
+        obj, lib = OBJ + "_stamps" + (lvl if lvl != "1" else ""), stamps_lib(lvl)
         flags.append("-DLADIFF_STAMPS=" + lvl)
-    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(obj, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers.append(os.path.join(os.path.dirname(HERE), "include", "ladiff_hip.h"))
+    headers += [os.path.join(os.path.dirname(HERE), "include", h) for h in ("ladiff_hip.h", "ladiff_hip_debug.h")]
     hipcc = _hipcc()
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(obj, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
             jobs.append([hipcc, *flags, "-c", s, "-o", o])
 
@@ -60,10 +66,12 @@ def build(force=False, verbose=False, stamps=False):
         for err in ex.map(run, jobs):
             if verbose and err.strip():
                 print(err)
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
-    return LIB
+    objs = [os.path.join(obj, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _stale(lib, objs + [os.path.join(CSRC, "exports.map")]):
+        # the version script keeps what -fvisibility=hidden cannot reach (libstdc++ template instantiations, kernel handle objects) local
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"),
+             "-o", lib, *objs])
+    return lib
 
 
 if __name__ == "__main__":

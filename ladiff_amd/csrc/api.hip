@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "model.h"
+#include "../../include/ladiff_hip_debug.h"
 
 using namespace ladiff;
 
@@ -115,6 +116,8 @@ struct Sampler {
 // samplers alternate): a graph is replayed only while it is the newest instantiation of THIS library; instantiations by other
 // components of the process (torch CUDA graphs, RCCL) do not count - they were never implicated (scripts/repro_graph.py 'graphs').
 std::atomic<uint64_t> g_graph_epoch{0};
+std::atomic<int> g_graph_epoch_rule{1};       // ladiff_debug_set_graph_epoch_rule
+std::atomic<int> g_graph_instantiations{0};   // ladiff_debug_graph_instantiations
 
 void drain_retired(Sampler* sp) {            // call with the stream drained
     for (hipGraphExec_t g : sp->retired) (void)hipGraphExecDestroy(g);
@@ -427,6 +430,21 @@ int ladiff_debug_set_stage_delay(int mask, int len) {
     return 0;
 }
 
+int ladiff_debug_set_loop_thresholds(int look_ahead_from, int small_upto) {
+    LADIFF_CHECK_ARG(look_ahead_from >= -1 && small_upto >= -1);
+    g_look_ahead_from = look_ahead_from;
+    g_small_upto = small_upto;
+    return 0;
+}
+
+int ladiff_debug_set_graph_epoch_rule(int on) {
+    LADIFF_CHECK_ARG(on == 0 || on == 1);
+    g_graph_epoch_rule = on;
+    return 0;
+}
+
+int ladiff_debug_graph_instantiations(void) { return g_graph_instantiations.load(); }
+
 int ladiff_debug_set_xcd_local(int on) {
     LADIFF_CHECK_ARG(on >= 0 && on <= 2);
     g_xcd_local = on;
@@ -553,7 +571,9 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
 
     Sampler* sp = reinterpret_cast<Sampler*>(sampler);
     // the sampler's generator stands in for a step-noise tensor the caller did not pass (schedules without noise never look at either)
-    const NoiseGen gen = (sp != nullptr && step_noise == nullptr) ? sp->gen : NoiseGen{0u, 0u, 0u, 0};
+    // A generator that is off is all zeros: its seed must not be part of any graph key (the Python loop owner draws a fresh seed per call,
+    // also for deterministic schedules - a key that changed with it re-captured ~150-node graphs on every launch-per-stage call).
+    const NoiseGen gen = (sp != nullptr && step_noise == nullptr && sp->gen.on) ? sp->gen : NoiseGen{0u, 0u, 0u, 0};
     float *xio = nullptr, *xios = nullptr;
     den_loop_io(r.fwd, B2 * T, &xio, &xios);
     if (WSp == nullptr) xios = nullptr;
@@ -616,9 +636,9 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
                           std::memcmp(ki, sp->key_ints, sizeof(ki)) == 0 && std::memcmp(kf, sp->key_f, sizeof(kf)) == 0 &&
                           (pipeline || std::memcmp(kn, sp->key_gen_noise, sizeof(kn)) == 0) &&
                           h == sp->key_hash && weights_generation == sp->key_gen;
-        // LADIFF_GRAPH_EPOCH_OFF (test aid): trust an older exec, as tests/test_gpu_pipeline.py does to show that the graphs - kernel
-        // nodes only since round 4 - replay correctly however old they are
-        const bool newest = sp->epoch == g_graph_epoch.load() || std::getenv("LADIFF_GRAPH_EPOCH_OFF") != nullptr;
+        // ladiff_debug_set_graph_epoch_rule(0) (test aid): trust an older exec, as tests/test_gpu_stress.py does to show that the graphs -
+        // kernel nodes only since round 4 - replay correctly however old they are
+        const bool newest = sp->epoch == g_graph_epoch.load() || g_graph_epoch_rule.load() == 0;
         if (!same || !newest) {
             if (!same) {
                 // replays of the old graphs may still be queued (the host never paces the GPU): drain before destroying them
@@ -641,6 +661,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
                 if (rc0 != 0) { if (graph) (void)hipGraphDestroy(graph); return rc0; }
                 LADIFF_HIP(e0);
                 const hipError_t i0 = hipGraphInstantiate(&sp->setup, graph, nullptr, nullptr, 0);
+                ++g_graph_instantiations;
                 (void)hipGraphDestroy(graph);
                 graph = nullptr;
                 LADIFF_HIP(i0);
@@ -666,6 +687,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
                 if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
                 LADIFF_HIP(ec);
                 const hipError_t ei = hipGraphInstantiate(&sp->exec, graph, nullptr, nullptr, 0);
+                ++g_graph_instantiations;
                 (void)hipGraphDestroy(graph);
                 LADIFF_HIP(ei);
             }
@@ -873,6 +895,7 @@ int ladiff_vae_decode_graphed(void* graph, const float* const* w, const float* c
         if (rc != 0) { if (gr) (void)hipGraphDestroy(gr); return rc; }
         LADIFF_HIP(ec);
         const hipError_t ei = hipGraphInstantiate(&dg->exec, gr, nullptr, nullptr, 0);
+        ++g_graph_instantiations;
         (void)hipGraphDestroy(gr);
         LADIFF_HIP(ei);
         std::memcpy(dg->key_ptrs, kp, sizeof(kp));

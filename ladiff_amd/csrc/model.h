@@ -48,6 +48,7 @@ extern std::atomic<int> g_stage_plan;
 extern std::atomic<int> g_poll_pause;
 extern std::atomic<int> g_stage_delay;
 extern std::atomic<int> g_pace;
+extern std::atomic<int> g_look_ahead_from, g_small_upto;
 extern std::atomic<int> g_dec_fused_attn;
 extern std::atomic<int> g_mlp_variant;
 int dec_mlp_prepare();           // per-device kernel attributes (dynamic LDS): outside any stream capture, under a mutex

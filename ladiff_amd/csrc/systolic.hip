@@ -46,6 +46,7 @@ namespace ladiff {
 std::atomic<int> g_stage_plan{0};   // measurement switch: ladiff_debug_set_stage_plan (red_plan below)
 std::atomic<int> g_poll_pause{0};   // measurement switch: ladiff_debug_set_poll_pause (mask | len << 8)
 std::atomic<int> g_stage_delay{-1}; // ladiff_debug_set_stage_delay (mask | len << 8); -1: by block count (launch_systolic_loop)
+std::atomic<int> g_look_ahead_from{-1}, g_small_upto{-1};   // ladiff_debug_set_loop_thresholds (-1: the built-in block counts)
 std::atomic<int> g_pace{4 | (4 << 8)};   // ladiff_debug_set_pacing: STYL sleeps half of its last observed wait before polling (measured: -3 % at 128 / 256 prompts)
 
 namespace {
@@ -2331,8 +2332,8 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     a.force_mismatch = g_xcd_local == 2 ? 1 : 0;
     a.fault_wg = fault_wg;
     a.timeout_ticks = timeout_ticks > 0 ? timeout_ticks : TIMEOUT_TICKS;
-    static const int la_from = std::getenv("LADIFF_LOOK_AHEAD_FROM") ? std::atoi(std::getenv("LADIFF_LOOK_AHEAD_FROM")) : LOOK_AHEAD_BLOCKS;      // experiment hook
-    static const int small_upto = std::getenv("LADIFF_SMALL_UPTO") ? std::atoi(std::getenv("LADIFF_SMALL_UPTO")) : SMALL_LAUNCH_BLOCKS;
+    const int la_from = g_look_ahead_from.load() >= 0 ? g_look_ahead_from.load() : LOOK_AHEAD_BLOCKS;      // ladiff_debug_set_loop_thresholds
+    const int small_upto = g_small_upto.load() >= 0 ? g_small_upto.load() : SMALL_LAUNCH_BLOCKS;
     a.look_ahead = NB >= la_from ? 1 : 0;
     a.gen = gen;
     a.pause_mask = g_poll_pause.load() & 0xff; a.pause_len = (g_poll_pause.load() >> 8) & 0xff;

@@ -6,7 +6,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 subprocess.check_call([sys.executable, "-m", "ladiff_amd.build", "--stamps"], cwd=ROOT, stdout=subprocess.DEVNULL)
 import torch
 from ladiff_amd import _lib, synthetic as syn
-_lib.LIB_PATH = os.path.join(ROOT, "ladiff_amd", "libladiff_hip_stamps.so")
+from ladiff_amd import build as _build
+_lib.LIB_PATH = _build.stamps_lib(os.environ.get("LADIFF_STAMPS_LEVEL", "1"))
 import bench
 dev = torch.device("cuda", 0)
 L = _lib.lib()

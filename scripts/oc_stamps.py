@@ -6,7 +6,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ctypes
 import torch
 from ladiff_amd import LADiffVae, _lib, synthetic as syn
-_lib.LIB_PATH = os.path.join(ROOT, "ladiff_amd", "libladiff_hip_stamps.so")
+from ladiff_amd import build as _build
+_lib.LIB_PATH = _build.stamps_lib(os.environ.get("LADIFF_STAMPS_LEVEL", "1"))
 from test_abi import ABL, VAE_KW
 dev = "cuda:0"
 vae = LADiffVae(ABL, **VAE_KW); vae.load_state_dict(syn.vae_weights(263)); vae = vae.to(dev).eval()

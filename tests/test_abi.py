@@ -18,17 +18,29 @@ def lib():
     return _lib.lib()
 
 
-def header_functions():
-    src = open(os.path.join(ROOT, "include", "ladiff_hip.h")).read()
+def header_functions(name="ladiff_hip.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"#ifdef LADIFF_STAMPS.*?#endif", "", src, flags=re.S)      # the diagnostic twin's extra entries
     return sorted(set(re.findall(r"\b(ladiff_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_and_binding_agree(lib):
-    declared = header_functions()
+    product, debug = header_functions(), header_functions("ladiff_hip_debug.h")
+    assert not [n for n in product if n.startswith("ladiff_debug_")], "measurement switches belong in ladiff_hip_debug.h"
+    assert all(n.startswith("ladiff_debug_") for n in debug)
+    declared = sorted(product + debug)
     assert declared == sorted(_lib.EXPORTS)
     for name in declared:
-        assert hasattr(lib, name), f"{name} declared in include/ladiff_hip.h but not exported"
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+
+
+def test_library_exports_only_the_declared_entries(lib):
+    """-fvisibility=hidden: `nm -D` shows the C ABI and nothing of the C++ inside (no ladiff:: symbols, no launch_* helpers)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = sorted(ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-2] in "TW")
+    assert names == sorted(_lib.EXPORTS), sorted(set(names) ^ set(_lib.EXPORTS))[:10]
 
 
 def test_version_and_errors(lib):
