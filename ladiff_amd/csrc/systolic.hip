@@ -1467,17 +1467,23 @@ struct StylRole {
     struct Geo { int pk[PQ], row[PQ]; };                                 // tile row of slot wave + NW q of this part (-1: none)
     struct Pay { f32x4 pl[PQ][NSLICE], rs[PQ], scl, shf; };
     const SysArgs& p; const Stage& st;
-    char* atile; float* ct;
+    char* atile; float *ct, *cst;
     WFrag<AR, NTW, 8> wf;
-    f32x4 bias2, bias, gg, bb;
-    __amdgpu_buffer_rsrc_t rp, rx, rout;
+    // ffn.linear2 bias | out bias | norm beta: [3][256] in LDS, read where they are used (12 registers per lane otherwise: with the 128 weight registers
+    // and the nine-row image of a block that was 7 dwords of scratch per block in the eight-wave kernel, and a scratch load waits behind
+    // the stores in flight); the LayerNorm gamma stays in registers
+    f32x4 gg;
+    __amdgpu_buffer_rsrc_t rp, rx, rout, rtab;
     unsigned pstride;
     __device__ __forceinline__ StylRole(const SysArgs& p_, const Stage& st_, char* lds) : p(p_), st(st_) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         atile = lds; ct = reinterpret_cast<float*>(lds + tile_bytes<AR, 4>(16));
+        cst = ct + 16 * CLD;
         load_w(wf, st.w0, D, 0, [&](int j) { return 16 * NTW * wave + 16 * j; });
-        bias2 = ld4(st.b1 + 4 * lane); bias = ld4(st.b0 + 4 * lane); gg = ld4(st.g + 4 * lane); bb = ld4(st.be + 4 * lane);
-        rp = rsrc_of(st.in0); rx = rsrc_of(st.in1); rout = rsrc_of(st.out);
+        if (wave == 0) { st4(cst + 4 * lane, ld4(st.b1 + 4 * lane)); st4(cst + D + 4 * lane, ld4(st.b0 + 4 * lane)); st4(cst + 2 * D + 4 * lane, ld4(st.be + 4 * lane)); }
+        gg = ld4(st.g + 4 * lane);
+        __syncthreads();
+        rp = rsrc_of(st.in0); rx = rsrc_of(st.in1); rout = rsrc_of(st.out); rtab = rsrc_of(p.tables);
         pstride = (unsigned)PRING * RT * 1024;
     }
     __device__ __forceinline__ void geo(int b, Geo& g) {
@@ -1492,8 +1498,11 @@ struct StylRole {
     __device__ __forceinline__ void issue(int s, int b, const Geo& g, Pay& y) {
         const int lane = threadIdx.x & 63, c = 4 * lane;
         const unsigned base = (unsigned)b * RT * 1024, pbase = (unsigned)((s * p.NB + b) % PRING) * RT * 1024;
-        const float* mod = p.tables + (size_t)(p.step_lo + s) * DEN_STEP_STRIDE + st.layer * DEN_LAYER_STRIDE + DEN_OFF_FFN_MOD;
-        y.scl = ld4(mod + c); y.shf = ld4(mod + D + c);                  // AdaLN scale | shift of this step (time tables)
+        // AdaLN scale | shift of this step (time tables): buffer loads with a SCALAR table offset - a per-lane 64-bit pointer held over the
+        // loop was two dwords of scratch per block in the eight-wave kernel (reloaded behind the stores in flight)
+        const unsigned mod = (unsigned)(((p.step_lo + s) * DEN_STEP_STRIDE + st.layer * DEN_LAYER_STRIDE + DEN_OFF_FFN_MOD) * 4);
+        y.scl = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rtab, (unsigned)c * 4u, mod, 0));
+        y.shf = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rtab, (unsigned)(D + c) * 4u, mod, 0));
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
             const int row = g.row[q];
@@ -1538,6 +1547,7 @@ struct StylRole {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (q < PQ && g.row[q < PQ ? q : 0] >= 0) {
                 v = sum8(y.pl[q < PQ ? q : 0]);
+                const f32x4 bias2 = ld4(cst + c), bb = ld4(cst + 2 * D + c);      // both reads fly under the first pass of the statistics
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] += bias2[i];
                 float mean, rstd;
@@ -1578,7 +1588,7 @@ struct StylRole {
             const int lr = wave + NW * q, row = g.row[q];
             if (row >= 0) {
                 f32x4 v = ld4(ct + lr * CLD + c);
-                const f32x4 rs = untag4(y.rs[q]);
+                const f32x4 rs = untag4(y.rs[q]), bias = ld4(cst + D + c);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = v[i] + bias[i] + rs[i];
                 st_out<HO>(st, rout, base + row * 1024 + c * 4, v, par);
