@@ -24,8 +24,11 @@
  *       ladiff_sampler_loop_ms       hipEventSynchronize on the loop's end event
  *       ladiff_reverse_status        blocking hipMemcpy (use ladiff_reverse_status_offset_bytes + an async copy to poll)
  *       the first pipeline launch on a device  runs a probe kernel on a private stream (hipMalloc / hipFree / stream create)
- *   - tensors are dense row-major fp32.  Arithmetic: w_split == NULL -> fp32-input MFMA, fp32 accumulate (bit-exact fp32
- *     fma chains); w_split != NULL (and ladiff_gemm_split / ladiff_self_attention_bf16x3 / split = 1) -> "bf16x3": operands as
+ *   - tensors are dense row-major fp32.  Arithmetic: w_split == NULL -> fp32-input MFMA, fp32 accumulate (exact fp32
+ *     fma chains inside every product; the persistent pipeline kernel of ladiff_diffusion_reverse additionally clears the last
+ *     mantissa bit of every activation word it hands from one stage to the next - the bit carries the hand-off's parity tag,
+ *     csrc/systolic.hip tag4: a truncation of <= 1 ulp toward zero at each of the 59 hand-offs of a step, in both hand-off
+ *     protocols; 1e-5 ... 3e-5 on the decoded frames against the fp64-checked oracle); w_split != NULL (and ladiff_gemm_split / ladiff_self_attention_bf16x3 / split = 1) -> "bf16x3": operands as
  *     bf16 hi + lo pairs, three bf16 MFMAs per product, fp32 accumulate; softmax, LayerNorm statistics, guidance and the
  *     scheduler are fp32 in both.
  *   - weights are passed as an array of device pointers, one per state-dict tensor, in the order

@@ -98,3 +98,21 @@ for i, n in enumerate(names):
         for k in range(4):
             order = [0, 1, 2, 3, 6, 7, 4, 5]
             print(f"  {n:10s} block+{k}: " + " ".join(f"{j}:{m[k, j] - t00:7.2f}" if m[k, j] > 0 else f"{j}:      -" for j in order))
+
+# One block's way through three layers MID-RUN (step n/2, block NB/2), absolute times: how long it sat in front of each stage
+# (rows stored by the producer -> this stage has them = transit + queueing) and how long the stage took
+print("mid-run, ONE block through layers 3-5 (us since L3.QKV0 had its rows): rows valid | stored | in stage | since the producer stored")
+seq = []
+for l in (3, 4, 5):
+    seq += ([f"L{l} SKIP0"] if l > 4 else []) + [f"L{l} QKV0", f"L{l} OUT", f"L{l} LIN0", f"L{l} RED2.0", f"L{l} FFN0", f"L{l} STYL.0", f"L{l} STYLb.0"]
+idx = {n: i for i, n in enumerate(names)}
+T0, prev_done = None, None
+for n in seq:
+    if n not in idx: continue
+    m = mid[idx[n]][0]
+    if m[1] == 0: continue                                     # (a STYL group that does not visit this block)
+    valid = m[1]
+    done = max(m[4], m[5])
+    if T0 is None: T0 = valid
+    print(f"  {n:10s} {valid - T0:8.2f} | {done - T0:8.2f} | {done - valid:6.2f} | " + (f"{valid - prev_done:6.2f}" if prev_done is not None else "     -"))
+    prev_done = done

@@ -141,6 +141,18 @@ def _bench_worker(rank, world, port, total, ret):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("total", [16, 21, 1024])
+def test_bench_pass_plumbing_world8_config_c5(total):
+    """BASELINE config c5's 8-GPU form on 8 gloo ranks: `Workload.one_pass` with the config's cycling lengths {60,120,196}.  1,024 = the
+    config's stated batch (128 prompts per rank); 16 / 21 prompts give ranks whose own longest motion is SHORTER than the batch's (rank
+    slices of 2 - 3 prompts: the frames of such a rank go through gather_feats' staging buffer) and uneven shards (21 -> 3,3,3,3,3,2,2,2)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bench_worker, args=(8, port, total, ret), nprocs=8, join=True)
+    assert all(ret[r] for r in range(8)), dict(ret)
+
+
 @pytest.mark.parametrize("total", [10, 7])
 def test_bench_pass_plumbing_world4_uneven_shards(total):
     """bench.py's `Workload.one_pass` (what the timed loop calls) on 4 gloo ranks with a batch that does not divide evenly

@@ -129,3 +129,46 @@ def test_prompts_to_frames_against_oracle():
     z_o, feats_o = orc.sample_motions(den_sd, vae_sd, text_o, lens, noise, 5, "ddim")
     assert maxdiff(text, text_o) < TOL["fp32"]
     assert maxdiff(feats, feats_o) < 1e-3
+
+
+# the whole chain at the FULL geometry: what `bench.py --config e2e` times
+E2E_TOL = {"fp32": 1e-3, "bf16x3": 3e-3}
+
+
+def test_full_geometry_chain_against_oracle_both_modes():
+    """Token ids -> 12-layer CLIP ViT-L/14 text tower (49,408 tokens, random init) -> 50-step guided DDIM -> LA-VAE frames for 16 prompts of
+    mixed lengths, both arithmetic modes, against the CPU oracle chain.  The north-star gate (1e-3) is defined on IDENTICAL text embeddings;
+    here the embeddings come from the tower in the same arithmetic mode, and the 50-step loop amplifies their rounding (random-init
+    weights: |latent| ~ 280): the fp32 chain is held to the gate, the bf16x3 chain to a stated 3e-3 (measured ~1e-3 on the worst prompt
+    of the benchmark batch: bench.py `parity.worst_prompt`).  The loop + decode on the ORACLE's embeddings stays within the gate in bf16x3 too."""
+    from ladiff_amd import LADIFF, DDIMScheduler, LADiffDenoiser, LADiffVae
+    from test_abi import ABL, DEN_KW, VAE_KW
+    B = 16
+    lens = ([196, 60, 120, 196, 100, 196, 48, 150] * 2)[:B]
+    den_sd, vae_sd, clip_sd = syn.denoiser_weights(), syn.vae_weights(263), syn.clip_weights()
+    ids = syn.clip_token_ids(2 * B, empty_first=B, seed=97)
+    noise = syn.init_noise(lens, seed=98)
+    with torch.no_grad():
+        text_o = orc.clip_text_features(clip_sd, ids, 12).unsqueeze(1)
+        z_o, f_o = orc.sample_motions(den_sd, vae_sd, text_o, lens, noise, 50, "ddim")
+    den = LADiffDenoiser(ABL, **DEN_KW); den.load_state_dict(den_sd)
+    vae = LADiffVae(ABL, **VAE_KW); vae.load_state_dict(vae_sd)
+    sch = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+                        set_alpha_to_one=False, steps_offset=1)
+    pipe = LADIFF(denoiser=den.to(DEV), vae=vae.to(DEV), scheduler=sch, guidance_scale=7.5, num_inference_timesteps=50)
+    enc = MldTextEncoder(precision="fp32")
+    enc.text_model.load_state_dict(clip_sd, strict=True)
+    enc = enc.to(DEV).eval()
+    for precision in ("fp32", "bf16x3"):
+        pipe.precision = enc.precision = precision
+        text = enc.encode_ids(ids.to(DEV)).unsqueeze(1)
+        _, feats = pipe.sample(text, lens, init_noise=noise.to(DEV))
+        per_prompt = [maxdiff(feats[i, :l], f_o[i, :l]) for i, l in enumerate(lens)]
+        worst = max(range(B), key=lambda i: per_prompt[i])
+        emb = maxdiff(text, text_o)
+        _, feats_same = pipe.sample(text_o.to(DEV), lens, init_noise=noise.to(DEV))        # the gate's own condition: identical embeddings
+        same = maxdiff(feats_same, f_o)
+        print(f"full-geometry chain, {precision}: embeddings {emb:.2e}, frames worst prompt {worst}: {per_prompt[worst]:.2e}; "
+              f"loop + decode on the oracle's embeddings: {same:.2e}")
+        assert per_prompt[worst] < E2E_TOL[precision], (precision, per_prompt)
+        assert same < 1e-3, (precision, same)

@@ -330,6 +330,38 @@ def test_512_prompts_run_as_chunks_against_oracle(denoiser, vae, precision):
     assert torch.equal(z1, z[:, :256])
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("cfg_name", ["c4", "c5"])
+def test_configs_c4_c5_at_1024_prompts_on_one_gpu(denoiser, vae, precision, cfg_name):
+    """BASELINE configs c4 / c5 at their STATED batch (1,024 prompts; the 8-GPU form shards them 128 per rank) on ONE GPU: c4 = 196 frames
+    uniform, 263 features; c5 = lengths cycling {60,120,196}, KIT 251 features.  Four pipeline launches of 256 prompts (`_chunks`), one
+    decode of 1,024 motions.  Rows on both sides of EVERY chunk boundary, at the ends and mid-chunk against the CPU oracle; frames past
+    each length and latent rows past each count exactly zero over the whole batch."""
+    B = 1024
+    C = 263 if cfg_name == "c4" else 251
+    lens = [196] * B if cfg_name == "c4" else syn.mixed_lengths(B)
+    v = vae if C == 263 else make_vae(251)
+    text, noise = syn.text_embeddings(B, seed=81), syn.init_noise(lens, seed=82)
+    pipe = make_pipe(denoiser, v, "ddim", 50, precision=precision)
+    assert pipe._chunks(B) == [(0, 256), (256, 512), (512, 768), (768, 1024)]
+    z, feats = pipe.sample(text.to(DEV), lens, init_noise=noise.to(DEV))
+    pipe.check()
+    assert z.shape == (5, B, 256) and feats.shape == (B, 196, C) and torch.isfinite(feats).all()
+    counts = syn.max_iter_elements(lens)
+    lt = torch.tensor(lens, device=feats.device)
+    pad = torch.arange(196, device=feats.device)[None, :] >= lt[:, None]                     # [B, F]: frames past each length
+    assert feats.abs().amax(dim=2)[pad].sum().item() == 0
+    ct = torch.tensor(counts, device=z.device)
+    zpad = torch.arange(5, device=z.device)[:, None] >= ct[None, :]                           # [T, B]: latent rows past each count
+    assert z.abs().amax(dim=2)[zpad].sum().item() == 0
+    idx = [0, 1, 2, 255, 256, 257, 400, 511, 512, 513, 767, 768, 769, 900, 1022, 1023]
+    sub_text = torch.cat([text[:B][idx], text[B:][idx]])
+    z_o, f_o = _oracle((cfg_name, "b1024", tuple(idx)), lambda: orc.sample_motions(
+        syn.denoiser_weights(), syn.vae_weights(C), sub_text, [lens[i] for i in idx], noise[idx], 50, "ddim"))
+    err = _direct_oracle_check(z, feats, idx, lens, z_o, f_o)
+    print(f"{cfg_name} at 1024 prompts (4 x 256), {precision}: max |frames[idx] - oracle| = {err:.3e}")
+
+
 def test_drop_in_via_yaml_style_config(denoiser):
     """The reference's plugin API: {target, params} nodes with the reference's own dotted paths."""
     cfg = {"model": {"guidance_scale": 7.5,
