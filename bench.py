@@ -242,7 +242,9 @@ class Workload:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
             ev[0].record(st)
             self.text_encoder.precision = pipe.precision
-            text = self.text_encoder.encode_ids(self.ids).unsqueeze(1)                     # [2B, 1, 768]
+            # token ids as the tokenizer delivers them - on the HOST (mld_clip.py:54-76 tokenises on the CPU, then .to(device)): the text tower's
+            # host side scans them for the EOS positions; 158 KB cross PCIe inside the timed region, as in the reference
+            text = self.text_encoder.encode_ids(self.ids_cpu).unsqueeze(1)                 # [2B, 1, 768]
             ev[1].record(st)
             z = pipe._diffusion_reverse(text, self.lens, init_noise=self.noise)
             ev[2].record(st)

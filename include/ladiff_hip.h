@@ -371,6 +371,15 @@ LADIFF_API size_t ladiff_clip_workspace_bytes(int B, int L);
 LADIFF_API int ladiff_clip_text_encode(const float* const* w, const float* const* w_split /*or NULL*/, int n_layers, int vocab,
                             const int64_t* ids, int B, int S, int L, float* out, void* ws, size_t ws_bytes,
                             ladiff_stream_t stream);
+/* The same with RAGGED rows: prompt b is evaluated at its OWN positions 0 .. eos_b only (same argument as L above, per prompt: nothing
+ * behind a prompt's EOS reaches its pooled row), 2.3x fewer rows than the padded batch for prompts of 1 .. 30 words.  seq_len[B] =
+ * eos_b + 1 (the caller computes it from the ids as the reference's argmax does, mld_clip.py:75-78 -> CLIPTextTransformer), row_off[B+1]
+ * = exclusive prefix sums of seq_len (row_off[B] = total_rows), row_seq[total_rows] = the prompt of each row; all int32 on the device;
+ * L = max seq_len.  Same result as ladiff_clip_text_encode within the arithmetic mode's rounding (the row tiling of the GEMMs differs). */
+LADIFF_API size_t ladiff_clip_workspace_bytes_ragged(int B, int total_rows);
+LADIFF_API int ladiff_clip_text_encode_ragged(const float* const* w, const float* const* w_split /*or NULL*/, int n_layers, int vocab,
+                            const int64_t* ids, int B, int S, int L, const int32_t* seq_len, const int32_t* row_off,
+                            const int32_t* row_seq, int total_rows, float* out, void* ws, size_t ws_bytes, ladiff_stream_t stream);
 
 /* ------------------------------------------------------------------ T2M evaluator encoders (evaluation)
  * The three frozen networks `t2m_eval` runs to get the embeddings of the TM2T metrics (ladiff.py:1264-1271), fp32:

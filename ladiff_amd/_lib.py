@@ -96,6 +96,9 @@ _SIGNATURES = {
     "ladiff_clip_workspace_bytes": (c_size_t, [c_int, c_int]),
     "ladiff_clip_text_encode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                         c_size_t, c_void_p]),
+    "ladiff_clip_workspace_bytes_ragged": (c_size_t, [c_int, c_int]),
+    "ladiff_clip_text_encode_ragged": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                               c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ladiff_t2m_movement_num_params": (c_int, []),
     "ladiff_t2m_movement_param_name": (c_char_p, [c_int]),
     "ladiff_t2m_motion_num_params": (c_int, []),

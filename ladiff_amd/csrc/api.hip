@@ -780,6 +780,18 @@ int ladiff_clip_text_encode(const float* const* w, const float* const* w_split, 
                             ws_bytes / sizeof(float), S(stream));
 }
 
+size_t ladiff_clip_workspace_bytes_ragged(int B, int total_rows) { return clip_ws_floats_rows(B, total_rows) * sizeof(float); }
+
+int ladiff_clip_text_encode_ragged(const float* const* w, const float* const* w_split, int n_layers, int vocab, const int64_t* ids,
+                                   int B, int seq, int L, const int32_t* seq_len, const int32_t* row_off, const int32_t* row_seq,
+                                   int total_rows, float* out, void* ws, size_t ws_bytes, ladiff_stream_t stream) {
+    ClipW W, WS;
+    LADIFF_CHECK_ARG(load_clip(W, w, n_layers) && ids && out && ws && B >= 0 && seq_len && row_off && row_seq && total_rows >= 0);
+    if (w_split != nullptr) LADIFF_CHECK_ARG(load_clip(WS, w_split, n_layers));
+    return clip_text_encode(W, w_split ? &WS : nullptr, n_layers, vocab, ids, B, seq, L, out, (float*)ws,
+                            ws_bytes / sizeof(float), S(stream), seq_len, row_off, row_seq, total_rows);
+}
+
 // ------------------------------------------------------------------ T2M evaluator encoders
 static bool all_set(const float* const* w, size_t n) {
     if (w == nullptr) return false;

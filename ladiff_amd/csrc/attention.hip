@@ -391,14 +391,14 @@ int launch_self_attention_bf16x3(const float* qkv, const int32_t* lengths, const
 
 // generic entry: `nheads` heads of 64, packed rows [q | k | v] of width 3 * 64 * nheads, optional causal mask
 int launch_self_attention(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F, int nheads,
-                          int causal, int split_out, hipStream_t s) {
+                          int causal, int split_out, hipStream_t s, const int32_t* row_off) {
     if (F > SA_FMAX || F < 1 || nheads < 1) return LADIFF_ERR_SHAPE;
     if (B == 0) return 0;
     const int W = nheads * DH;
     const AttnGeom g{nheads, 3 * W, W, 2 * W, W, causal};
     const int nqt = (F + 31) / 32;
     hipLaunchKernelGGL(dec_self_attn_kernel, dim3((nqt + 3) / 4, B * nheads), dim3(256), 0, s, qkv, lengths, keybits, out, B, F,
-                       split_out, g, (const int32_t*)nullptr, 0);
+                       split_out, g, row_off, 0);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }

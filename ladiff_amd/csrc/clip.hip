@@ -6,7 +6,9 @@
 //
 // Exact shortcut: under a causal mask the EOS row depends only on rows <= EOS, so only the first `L` positions are
 // evaluated (L >= 1 + max EOS index over the batch, chosen by the host from the token ids); rows behind are never built.
-// Rows are batch-major (row = b * L + t).  Large GEMMs go through launch_gemm (fp32 MFMA, or bf16x3 with S-format
+// Rows are batch-major (row = b * L + t) - or RAGGED (round 5): prompt b owns rows [row_off[b], row_off[b + 1]) = its OWN positions
+// 0 .. eos_b (the same argument per prompt: nothing behind a prompt's EOS reaches its pooled row), 2.3x fewer rows than the padded
+// batch for prompts of 1 .. 30 words; q / k / v are one batched GEMM launch.  Large GEMMs go through launch_gemm (fp32 MFMA, or bf16x3 with S-format
 // operands when a split weight table is given); the attention core is the decoder's MFMA kernel with 12 heads + causal.
 #include "model.h"
 
@@ -52,11 +54,14 @@ __device__ __forceinline__ void wide_stats(const f32x4 (&v)[CNV], float& mean, f
 
 // x[b*L+t] = token_embedding[ids[b*S+t]] + position_embedding[t]          (CLIPTextEmbeddings.forward)
 __global__ __launch_bounds__(256) void clip_embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ tok,
-                                                         const float* __restrict__ pos, int vocab, int B, int S, int L,
+                                                         const float* __restrict__ pos, int vocab, int M, int S, int L,
+                                                         const int32_t* __restrict__ row_seq, const int32_t* __restrict__ row_off,
                                                          float* __restrict__ x) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= B * L) return;
-    const int b = row / L, t = row - b * L;
+    if (row >= M) return;
+    int b, t;
+    if (row_seq != nullptr) { b = row_seq[row]; t = row - row_off[b]; }      // ragged rows
+    else { b = row / L; t = row - b * L; }
     long long id = ids[(size_t)b * S + t];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);          // ids are validated on the host; clamp for memory safety only
     const int c = (threadIdx.x & 63) * 4;
@@ -83,13 +88,14 @@ __global__ __launch_bounds__(64) void clip_eos_kernel(const int64_t* __restrict_
     if (lane == 0) eos[b] = at;
 }
 
-// y[r] = LayerNorm(x[src(r)]) with src(r) = r, or r * L + eos[r] when `eos` is given (the pooled row);  fp32 and / or S-format
-__global__ __launch_bounds__(256) void clip_ln_kernel(const float* __restrict__ x, const int32_t* __restrict__ eos, int L,
+// y[r] = LayerNorm(x[src(r)]) with src(r) = r, or r * L + eos[r] + adj when `eos` is given (the pooled row; ragged rows: L = 0,
+// eos = row_off + 1, adj = -1: the prompt's last row);  fp32 and / or S-format
+__global__ __launch_bounds__(256) void clip_ln_kernel(const float* __restrict__ x, const int32_t* __restrict__ eos, int L, int adj,
                                                       const float* __restrict__ g, const float* __restrict__ bt, int M,
                                                       float* __restrict__ y, float* __restrict__ ys) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const size_t src = eos != nullptr ? (size_t)row * L + eos[row] : (size_t)row;
+    const size_t src = eos != nullptr ? (size_t)((long long)row * L + eos[row] + adj) : (size_t)row;
     const int c = (threadIdx.x & 63) * 4;
     f32x4 v[CNV];
 #pragma unroll
@@ -106,8 +112,8 @@ __global__ __launch_bounds__(256) void clip_ln_kernel(const float* __restrict__ 
     }
 }
 
-static int ln_rows(const float* x, const int32_t* eos, int L, const NormW& n, int M, float* y, float* ys, hipStream_t s) {
-    hipLaunchKernelGGL(clip_ln_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, eos, L, n.g, n.b, M, y, ys);
+static int ln_rows(const float* x, const int32_t* eos, int L, const NormW& n, int M, float* y, float* ys, hipStream_t s, int adj = 0) {
+    hipLaunchKernelGGL(clip_ln_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, eos, L, adj, n.g, n.b, M, y, ys);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
@@ -117,13 +123,22 @@ size_t clip_ws_floats(int B, int L) {
     return M * (2 * CW /*x ping-pong*/ + CW /*h*/ + 3 * CW /*qkv*/ + CW /*att*/ + CFF /*mlp*/) + (size_t)B * CW + (size_t)B + 64;
 }
 
+size_t clip_ws_floats_rows(int B, int M) {
+    return (size_t)M * (2 * CW + CW + 3 * CW + CW + CFF) + (size_t)B * CW + (size_t)B + 64;
+}
+
+// seq_len / row_off / row_seq (all or none): ragged rows - prompt b has seq_len[b] = 1 + (its EOS position) rows from row_off[b]
+// (row_off has B + 1 entries, row_off[B] = total_rows), row_seq[r] = the prompt of row r; L then only bounds the lengths.
 int clip_text_encode(const ClipW& w, const ClipW* wsp, int n_layers, int vocab, const int64_t* ids, int B, int S, int L,
-                     float* out, float* ws, size_t ws_floats, hipStream_t s) {
+                     float* out, float* ws, size_t ws_floats, hipStream_t s, const int32_t* seq_len, const int32_t* row_off,
+                     const int32_t* row_seq, int total_rows) {
     if (n_layers < 1 || n_layers > CLIP_MAX_LAYERS || S < 1 || S > CLIP_MAX_POSITIONS || L < 1 || L > S || vocab < 1)
         return LADIFF_ERR_SHAPE;
-    if (ws_floats < clip_ws_floats(B, L)) return LADIFF_ERR_WORKSPACE;
+    const bool ragged = row_off != nullptr;
+    if (ragged && (seq_len == nullptr || row_seq == nullptr || total_rows < B || (long long)total_rows > (long long)B * L)) return LADIFF_ERR_ARG;
+    if (ws_floats < (ragged ? clip_ws_floats_rows(B, total_rows) : clip_ws_floats(B, L))) return LADIFF_ERR_WORKSPACE;
     if (B == 0) return 0;
-    const int M = B * L;
+    const int M = ragged ? total_rows : B * L;
     const bool sp = wsp != nullptr;
     float* p = ws;
     float* x = p; p += (size_t)M * CW;          // residual stream, ping-pong with x2 across the two sub-blocks
@@ -144,28 +159,40 @@ int clip_text_encode(const ClipW& w, const ClipW* wsp, int n_layers, int vocab, 
         return launch_gemm(g, s);
     };
 
-    hipLaunchKernelGGL(clip_embed_kernel, dim3((M + 3) / 4), dim3(256), 0, s, ids, w.tok, w.pos, vocab, B, S, L, x);
+    hipLaunchKernelGGL(clip_embed_kernel, dim3((M + 3) / 4), dim3(256), 0, s, ids, w.tok, w.pos, vocab, M, S, L, row_seq, row_off, x);
     LADIFF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(clip_eos_kernel, dim3(B), dim3(64), 0, s, ids, S, L, eos);
-    LADIFF_LAUNCH_CHECK();
+    if (!ragged) {
+        hipLaunchKernelGGL(clip_eos_kernel, dim3(B), dim3(64), 0, s, ids, S, L, eos);
+        LADIFF_LAUNCH_CHECK();
+    }
 
     for (int l = 0; l < n_layers; ++l) {                       // CLIPEncoderLayer.forward (pre-LN residual blocks)
         const ClipLayerW& W = w.layer[l];
         const ClipLayerW& Ws = sp ? wsp->layer[l] : w.layer[l];
         LADIFF_TRY(ln_rows(x, nullptr, 0, W.ln1, M, sp ? nullptr : h, sp ? h : nullptr, s));
-        // q | k | v packed by columns; the 1/sqrt(64) query scale is applied (exactly) inside the attention kernel
-        LADIFF_TRY(gemm(h, CW, W.q, Ws.q, qkv, 3 * CW, CW, ACT_NONE, nullptr, false));
-        LADIFF_TRY(gemm(h, CW, W.k, Ws.k, qkv + CW, 3 * CW, CW, ACT_NONE, nullptr, false));
-        LADIFF_TRY(gemm(h, CW, W.v, Ws.v, qkv + 2 * CW, 3 * CW, CW, ACT_NONE, nullptr, false));
-        if (sp) LADIFF_TRY(launch_self_attention_bf16x3(qkv, nullptr, nullptr, att, B, L, CH, 1, 1, s));
-        else LADIFF_TRY(launch_self_attention(qkv, nullptr, nullptr, att, B, L, CH, 1, 0, s));
+        // q | k | v packed by columns; the 1/sqrt(64) query scale is applied (exactly) inside the attention kernel.  One batched
+        // launch of the three same-shape products (each alone leaves half of the chip idle at a few thousand rows)
+        {
+            GemmArgs g3[3];
+            const LinearW* lw[3] = {&W.q, &W.k, &W.v};
+            const LinearW* lws[3] = {&Ws.q, &Ws.k, &Ws.v};
+            for (int i = 0; i < 3; ++i) {
+                GemmArgs& g = g3[i];
+                g.A = h; g.lda = CW; g.W = sp ? lws[i]->w : lw[i]->w; g.ldw = CW; g.bias = lw[i]->b; g.M = M; g.N = CW; g.K = CW; g.ldy = 3 * CW;
+                g.Y = qkv + i * CW; g.split = sp ? 1 : 0;
+            }
+            LADIFF_TRY(launch_gemm_batch(g3, 3, s));
+        }
+        if (sp) LADIFF_TRY(launch_self_attention_bf16x3(qkv, seq_len, nullptr, att, B, L, CH, 1, 1, s, row_off, 0));
+        else LADIFF_TRY(launch_self_attention(qkv, seq_len, nullptr, att, B, L, CH, 1, 0, s, row_off));
         LADIFF_TRY(gemm(att, CW, W.o, Ws.o, x2, CW, CW, ACT_NONE, x, false));             // x2 = x + out_proj(attn)
         LADIFF_TRY(ln_rows(x2, nullptr, 0, W.ln2, M, sp ? nullptr : h, sp ? h : nullptr, s));
         LADIFF_TRY(gemm(h, CW, W.fc1, Ws.fc1, mlp, CFF, CFF, ACT_QGELU, nullptr, true));  // quick_gelu(fc1)
         LADIFF_TRY(gemm(mlp, CFF, W.fc2, Ws.fc2, x, CW, CW, ACT_NONE, x2, false));        // x = x2 + fc2(...)
     }
     // pooled = final_layer_norm(x)[b, eos[b]];  text_embeds = text_projection(pooled)   (fp32: B rows only)
-    LADIFF_TRY(ln_rows(x, eos, L, w.final_ln, B, pooled, nullptr, s));
+    if (ragged) LADIFF_TRY(ln_rows(x, row_off + 1, 0, w.final_ln, B, pooled, nullptr, s, -1));     // the prompt's last row = its EOS position
+    else LADIFF_TRY(ln_rows(x, eos, L, w.final_ln, B, pooled, nullptr, s));
     GemmArgs g;
     g.A = pooled; g.lda = CW; g.W = w.proj; g.ldw = CW; g.Y = out; g.ldy = CW; g.M = B; g.N = CW; g.K = CW;
     return launch_gemm(g, s);

@@ -377,7 +377,14 @@ bool gemm_big_supported(const GemmArgs& a) {
 int launch_gemm_big(const GemmArgs& a, hipStream_t s) {
     if (a.split) {
         const int nbm = (a.M + 127) / 128, nbn = a.N / 128;
-        hipLaunchKernelGGL((gemm_big_split_kernel<128, 128>), dim3(((nbm + 7) / 8) * 8 * nbn), dim3(256), 0, s, a);
+        // Few row tiles (the ragged CLIP tower: ~2,300 rows, N = 768): 128-row tiles leave the launch one partial round of workgroups whose
+        // length is ONE tile's k loop (K = 3072: 82 us for 108 workgroups); 64-row tiles double the workgroups and halve each one's work
+        if (nbm * nbn <= 256 && a.M > 64) {
+            const int nbm64 = (a.M + 63) / 64;
+            hipLaunchKernelGGL((gemm_big_split_kernel<64, 128>), dim3(((nbm64 + 7) / 8) * 8 * nbn), dim3(256), 0, s, a);
+        } else {
+            hipLaunchKernelGGL((gemm_big_split_kernel<128, 128>), dim3(((nbm + 7) / 8) * 8 * nbn), dim3(256), 0, s, a);
+        }
         LADIFF_LAUNCH_CHECK();
         return 0;
     }

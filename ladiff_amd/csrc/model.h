@@ -94,8 +94,10 @@ int launch_qkv_attention(const float* x, const float* w, const float* bias, cons
                          int b_n, int T, float* out, hipStream_t s);
 
 size_t clip_ws_floats(int B, int L);
+size_t clip_ws_floats_rows(int B, int total_rows);
 int clip_text_encode(const ClipW& w, const ClipW* w_split, int n_layers, int vocab, const int64_t* ids, int B, int S, int L,
-                     float* out, float* ws, size_t ws_floats, hipStream_t s);
+                     float* out, float* ws, size_t ws_floats, hipStream_t s, const int32_t* seq_len = nullptr,
+                     const int32_t* row_off = nullptr, const int32_t* row_seq = nullptr, int total_rows = 0);
 
 // evaluator.hip: T2M evaluator encoders; tables are pointer arrays in *_param_names() order
 const std::vector<std::string>& t2m_move_param_names();

@@ -53,6 +53,14 @@ namespace {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef LADIFF_PF1
+#define LADIFF_PF1 2
+#endif
+#ifndef LADIFF_PF2
+#define LADIFF_PF2 1
+#endif
+constexpr int PF1 = LADIFF_PF1;           // fragment fetch distance of the one-column-tile products (tile_mma.h, mma): LIN / FFN first product, QKV's third tile
+constexpr int PF2 = LADIFF_PF2;           // ... of the two-tile products of the eight-wave roles
 constexpr int NSLICE = 8;                 // hidden slices of the two MLPs (128 columns each)
 constexpr int HS = FF / NSLICE;           // 128
 constexpr int NRED = 3;                   // workgroups per layer of each of the two reduce stages (how they share the work: red_parts())
@@ -765,11 +773,11 @@ struct QkvRole {
         if (probe) {} else
 #endif
         if (nvt == NTW) {
-            mma<AR, 4, NTW, 8, MR>(atile, wf, acc);
+            mma<AR, 4, NTW, 8, MR, NTW, (MR == 1 && WS == 2 ? PF2 : 1)>(atile, wf, acc);
         } else {                                                         // the SIMD's second wave: one tile (the fragment set's first)
             f32x4 a1[MR][1];
             zero_acc(a1);
-            mma<AR, 4, 1, 8, MR, NTW>(atile, wf, a1);
+            mma<AR, 4, 1, 8, MR, NTW, (MR == 1 ? PF1 : 1)>(atile, wf, a1);
 #pragma unroll
             for (int i = 0; i < MR; ++i) acc[i][0] = a1[i][0];
         }
@@ -1024,7 +1032,7 @@ struct OutRole {
         const unsigned par = HO ? (unsigned)(s & 1) : 0u;
         f32x4 acc[MR][NTW];
         zero_acc(acc);
-        mma<AR, 4, NTW, 8, MR>(atile, wf, acc);
+        mma<AR, 4, NTW, 8, MR, NTW, (MR == 1 && WS == 2 ? PF2 : 1)>(atile, wf, acc);
         SYS_STAMP(3);
         stage_c(ct, acc, [&](int j) { return 16 * NTW * wave + 16 * j; });
         mid.before_barrier();
@@ -1138,7 +1146,7 @@ struct OutRole {
                 }
                 if (!probe)
 #endif
-                mma<AR, 4, NTW, 8, MR>(atile, wf, acc);
+                mma<AR, 4, NTW, 8, MR, NTW, PF2>(atile, wf, acc);
                 stage_c(ct, acc, [&](int j) { return 16 * NTW * wave + 16 * j; });
                 lds_barrier();
                 SYS_STAMP(3);
@@ -1292,7 +1300,7 @@ struct MlpRole {
         }
         if (!probe)
 #endif
-        mma<AR, 4, NT1, 8, MR>(atile, w1, acc1);
+        mma<AR, 4, NT1, 8, MR, NT1, (NT1 == 1 && MR == 1 ? PF1 : 1)>(atile, w1, acc1);
         SYS_STAMP(3);
         // hidden slice -> S-format operand tile (k = hidden column within the slice)
 #pragma unroll
@@ -1330,7 +1338,7 @@ struct MlpRole {
         }
         if (!probe)
 #endif
-        mma<AR, 2, NT2, 4, MR>(htile, w2, acc2);
+        mma<AR, 2, NT2, 4, MR, NT2, (MR == 1 && WS == 2 ? PF2 : 1)>(htile, w2, acc2);
         stage_c(ct, acc2, [&](int j) { return 16 * NT2 * wave + 16 * j; });
         mid.before_stores();
         // each wave stores the columns it staged itself (64 or 32 of them: 256 / 128 B per row, 4 / 8 rows per instruction): no
@@ -1579,7 +1587,7 @@ struct StylRole {
         }
         if (!probe)
 #endif
-        mma<AR, 4, NTW, 8, 1>(atile, wf, acc);
+        mma<AR, 4, NTW, 8, 1, NTW, (WS == 2 ? PF2 : 1)>(atile, wf, acc);
         stage_c(ct, acc, [&](int j) { return 16 * NTW * wave + 16 * j; });
         __syncthreads();
         SYS_STAMP(7);
@@ -1644,7 +1652,7 @@ struct SkipRole {
         const unsigned par = HO ? (unsigned)(s & 1) : 0u;
         f32x4 acc[MR][NTW];
         zero_acc(acc);
-        mma<AR, 8, NTW, 16, MR>(atile, wf, acc);
+        mma<AR, 8, NTW, 16, MR, NTW, (MR == 1 && WS == 2 ? PF2 : 1)>(atile, wf, acc);
         stage_c(ct, acc, [&](int j) { return n0 + 16 * NTW * wave + 16 * j; });
         mid.before_barrier();
         __syncthreads();
@@ -1943,6 +1951,20 @@ __global__ __launch_bounds__(256 * WS, 1) void systolic_loop_kernel(const SysArg
     __syncthreads();
     if (ctl->abort) return;
     if ((int)blockIdx.x == p.fault_wg) return;       // injected fault (ladiff_debug_set_pipeline_fault): its consumers time out
+#ifdef LADIFF_STAMPS
+    // the shader clock this launch really ran at: s_memtime counts core clocks, s_memrealtime 100 MHz ticks (totals slot of the unused
+    // workgroup index 255: [0] core clocks, [1] 100 MHz ticks, written when workgroup 0's first wave leaves)
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+    struct ClockProbe {
+        const SysArgs& p; unsigned long long c0, r0;
+        __device__ ~ClockProbe() {
+            if (p.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+                p.stamps[(size_t)256 * 4 * 4 * 8 + 255 * 4] = __builtin_amdgcn_s_memtime() - c0;
+                p.stamps[(size_t)256 * 4 * 4 * 8 + 255 * 4 + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+            }
+        }
+    } clock_probe{p, clk0, rt0};
+#endif
     if (!ctl->local_ok) st.out_local = 0;
 #ifdef LADIFF_STAMPS
     if (p.stamps != nullptr && threadIdx.x == 0)         // who runs here (the stage table is permuted by the XCD placement)

@@ -104,33 +104,39 @@ template <int N>
 __device__ __forceinline__ void lds_wait(u32x4_t& a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
 
 // acc[i][j] += A(tile rows 16 i ..) . W(tile j)^T over KS k-steps of 32; MR = row tiles.  The operand fragments of the next
-// step are requested before the MFMAs of the current one are issued, so their LDS latency hides under the MFMAs.
-// NTF >= NT: the fragment set may hold more column tiles than are multiplied (its first NT are used)
-template <int AR, int KB, int NT, int KS, int MR, int NTF = NT>
+// PF steps are requested before the MFMAs of the current one are issued, so their LDS latency hides under the MFMAs.
+// NTF >= NT: the fragment set may hold more column tiles than are multiplied (its first NT are used).
+// PF = how many k-steps the fragment fetches run ahead (bf16x3 tiles): a step of ONE column tile is 3 MFMAs = 48 cycles of the SIMD's
+// matrix pipe (96 with the SIMD's second wave in the same phase) - less than an LDS read takes when all eight waves fetch at once, so
+// with PF = 1 every step of such a product waits for its fragments; PF = 2 keeps two steps in flight (8 more registers per row tile).
+template <int AR, int KB, int NT, int KS, int MR, int NTF = NT, int PF = 1>
 __device__ __forceinline__ void mma(const char* tile, const WFrag<AR, NTF, KS>& f, f32x4 (&acc)[MR][NT]) {
     const int lane = threadIdx.x & 63, frow = lane & 15, fk = lane >> 4;
     if constexpr (AR == 0) {
+        static_assert(PF == 1 || PF == 2, "fetch distance");
+        constexpr int NB = PF + 1;                                       // fragment buffers
         // lane part of the four slot addresses a step can need: hi / lo plane x even / odd step of a 64-column block
         // (a_slot: slot ^ row, and row = 16 i + frow leaves the low four bits to frow); the rest is an immediate offset
         unsigned base[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) base[v] = lds_addr(tile) + frow * (KB * 256) + ((((v & 1) * 4 + (v >> 1) * 8 + fk) ^ frow) & 15) * 16;
-        u32x4_t ah[2][MR], al[2][MR];
-        auto fetch = [&](auto sc, auto bc) {                             // step sc.value into buffer bc.value
-            constexpr int s = decltype(sc)::value, bf = decltype(bc)::value;
+        u32x4_t ah[NB][MR], al[NB][MR];
+        auto fetch = [&](auto sc) {                                      // step sc.value into buffer sc.value % NB
+            constexpr int s = decltype(sc)::value, bf = s % NB;
             static_for<MR>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 lds_fetch16<16 * i * KB * 256 + (s >> 1) * 256>(ah[bf][i], base[s & 1]);
                 lds_fetch16<16 * i * KB * 256 + (s >> 1) * 256>(al[bf][i], base[2 + (s & 1)]);
             });
         };
-        fetch(IntC<0>{}, IntC<0>{});
+        static_for<(PF < KS ? PF : KS)>([&](auto sc) { fetch(sc); });
         static_for<KS>([&](auto sc) {
-            constexpr int s = decltype(sc)::value, cur = s & 1;
-            if constexpr (s + 1 < KS) fetch(IntC<s + 1>{}, IntC<cur ^ 1>{});
-            static_for<MR>([&](auto ic) {                                // the current step's fragments: all but the 2 MR just requested
+            constexpr int s = decltype(sc)::value, cur = s % NB;
+            if constexpr (s + PF < KS) fetch(IntC<s + PF>{});
+            constexpr int ahead = (KS - 1 - s) < PF ? (KS - 1 - s) : PF;   // steps whose fragments may still be in flight behind this one's
+            static_for<MR>([&](auto ic) {                                // the current step's fragments: all but the 2 MR x `ahead` requested after them
                 constexpr int i = decltype(ic)::value;
-                lds_wait<(s + 1 < KS ? 2 * MR : 0)>(ah[cur][i], al[cur][i]);
+                lds_wait<2 * MR * ahead>(ah[cur][i], al[cur][i]);
             });
             __builtin_amdgcn_sched_barrier(0);
             // the three products of a split operand pair go to the same accumulator: one product at a time over all MR x NT

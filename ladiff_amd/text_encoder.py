@@ -11,6 +11,7 @@ Two exact host-side savings, both consequences of the causal mask / row independ
 """
 import os
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -93,37 +94,91 @@ class MldTextEncoder(nn.Module):
         return self.encode_ids(ids[:, :self.max_length]).unsqueeze(1)
 
     @torch.no_grad()
-    def encode_ids(self, input_ids, full_length=False, dedup=True):
-        """Token ids [B, S<=77] (int64, any device) -> text features [B, 768] on the module's device."""
+    def encode_ids(self, input_ids, full_length=False, dedup=True, ragged=True):
+        """Token ids [B, S<=77] (int64; as the tokenizer delivers them: on the HOST - a device tensor works but costs a device -> host
+        copy, i.e. a stream synchronisation) -> text features [B, 768] on the module's device.  Host work (as the reference's tokenizer
+        side): identical prompts are evaluated once (`dedup`: the B empty prompts of the guidance batch), every prompt's EOS position
+        is found (the argmax the reference's CLIPTextTransformer takes) and the rows are laid out ragged - prompt b at its own positions
+        0 .. eos_b (`ragged`; False: every prompt padded to the batch's longest, `full_length`: to all S positions)."""
         tower = self.text_model
         dev = self.device
-        ids = torch.as_tensor(input_ids).to(torch.int64).cpu()
+        ids = torch.as_tensor(input_ids).to(torch.int64)
+        if ids.device.type != "cpu":
+            ids = ids.cpu()
         if ids.dim() != 2 or ids.shape[1] < 1 or ids.shape[1] > 77:
             raise ValueError(f"input_ids must be [B, 1..77], got {tuple(ids.shape)}")
-        if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= tower.vocab_size):
+        # the host side works on numpy arrays: torch's CPU ops wake the whole intra-op thread pool for every one of these tiny tensors
+        # (measured on the 128-thread GPU box: 4 ms for unique(dim=0) of [256,77], 5 ms for the row layout below; numpy: < 0.2 ms in all)
+        a = np.ascontiguousarray(ids.numpy())
+        if a.size and (int(a.min()) < 0 or int(a.max()) >= tower.vocab_size):
             raise IndexError("index out of range in self")          # what nn.Embedding raises inside the reference
-        B, S = ids.shape
+        B, S = a.shape
         out = torch.empty(B, 768, dtype=torch.float32, device=dev)
         if B == 0:
             return out
         inverse = None
         if dedup:
-            uniq, inverse = torch.unique(ids, dim=0, return_inverse=True)
-            if uniq.shape[0] == B:
-                inverse = None
-            else:
-                ids = uniq
-        n = ids.shape[0]
-        Lx = S if full_length else int(ids.argmax(dim=1).max()) + 1
+            uniq, inv = np.unique(a, axis=0, return_inverse=True)
+            if uniq.shape[0] != B:
+                a, inverse = np.ascontiguousarray(uniq), inv.reshape(-1).astype(np.int64)
+        n = a.shape[0]
+        eos = a.argmax(axis=1)                                          # first position of the largest id (EOS), per prompt
+        Lx = S if full_length else int(eos.max()) + 1
         L = _lib.lib()
         wt = tower._weight_table()
-        d_ids = ids.contiguous().to(dev)
+        split = wt.split_array() if self.precision == "bf16x3" else None
         res = out if inverse is None else torch.empty(n, 768, dtype=torch.float32, device=dev)
-        wsb = L.ladiff_clip_workspace_bytes(n, Lx)
-        ws = _lib.workspace(wsb, dev)
-        _lib.check(L.ladiff_clip_text_encode(wt.array, wt.split_array() if self.precision == "bf16x3" else None,
-                                             tower.num_layers, tower.vocab_size, _lib.ptr(d_ids, torch.int64), n, S, Lx,
-                                             _lib.ptr(res), _lib.ptr(ws), wsb, _lib.stream_ptr()))
+        if ragged and not full_length:
+            seq_len = (eos + 1).astype(np.int32)
+            row_off = np.zeros(n + 1, dtype=np.int32)
+            np.cumsum(seq_len, out=row_off[1:])
+            total = int(row_off[-1])
+            row_seq = np.repeat(np.arange(n, dtype=np.int32), seq_len)
+            # one pinned staging slot, one asynchronous copy: [ids (int64) | seq_len | row_off | row_seq (int32)]; nothing here waits for the GPU
+            meta = np.concatenate([seq_len, row_off, row_seq, np.zeros(1, dtype=np.int32)])
+            meta = meta[:meta.size // 2 * 2]
+            packed = np.concatenate([a.reshape(-1), meta.view(np.int64)])
+            d_packed = self._stage(packed, dev)
+            d_ids = d_packed[:n * S].view(n, S)
+            d_meta = d_packed[n * S:].view(torch.int32)
+            d_len, d_off, d_seq = d_meta[:n], d_meta[n:2 * n + 1], d_meta[2 * n + 1:2 * n + 1 + total]
+            wsb = L.ladiff_clip_workspace_bytes_ragged(n, total)
+            ws = _lib.workspace(wsb, dev)
+            _lib.check(L.ladiff_clip_text_encode_ragged(wt.array, split, tower.num_layers, tower.vocab_size, _lib.ptr(d_ids, torch.int64), n, S, Lx,
+                                                        _lib.ptr(d_len, torch.int32), _lib.ptr(d_off, torch.int32), _lib.ptr(d_seq, torch.int32),
+                                                        total, _lib.ptr(res), _lib.ptr(ws), wsb, _lib.stream_ptr()))
+            self._keep = d_packed                                       # alive until the next call (the stream may still read it)
+        else:
+            d_ids = self._stage(a.reshape(-1), dev).view(n, S)
+            wsb = L.ladiff_clip_workspace_bytes(n, Lx)
+            ws = _lib.workspace(wsb, dev)
+            _lib.check(L.ladiff_clip_text_encode(wt.array, split, tower.num_layers, tower.vocab_size, _lib.ptr(d_ids, torch.int64), n, S, Lx,
+                                                 _lib.ptr(res), _lib.ptr(ws), wsb, _lib.stream_ptr()))
+            self._keep = d_ids
         if inverse is not None:
-            out = res[inverse.to(dev)]
+            out = res[self._stage(inverse, dev)]
         return out
+
+    def _stage(self, host_tensor, dev, slots=16):
+        """Host int64 numpy vector -> device copy through a ring of pinned staging slots carved from ONE pinned arena (a hipHostMalloc costs tens
+        of milliseconds; a pageable source makes the copy wait for the stream): asynchronous, a slot is reused `slots` calls later, behind
+        its copy's event."""
+        n = int(host_tensor.size)
+        ring = self.__dict__.get("_ring")
+        if ring is None or ring["elems"] < n:
+            if ring is not None:
+                torch.cuda.synchronize(dev)                             # copies from the old arena may still be queued
+            elems = max(2 * n, 32768)
+            ring = {"i": 0, "elems": elems, "arena": torch.empty(slots * elems, dtype=torch.int64).pin_memory(), "events": [None] * slots}
+            self.__dict__["_ring"] = ring
+        k = ring["i"] % slots
+        ring["i"] += 1
+        if ring["events"][k] is not None:
+            ring["events"][k].synchronize()                             # the copy issued `slots` calls ago has long run
+        src = ring["arena"][k * ring["elems"]:k * ring["elems"] + n]
+        src.numpy()[:] = host_tensor                                    # (a numpy int64 vector)
+        d = src.to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        ring["events"][k] = ev
+        return d
