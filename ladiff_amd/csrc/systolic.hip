@@ -1345,6 +1345,12 @@ struct MlpRole {
         // barrier - LDS serves a wave's accesses in order, and the next block's hidden tile is only written behind the stage loop's
         // barrier
         constexpr int CW = 16 * NT2, LPR = CW / 4, RPI = 64 / LPR;
+#ifdef LADIFF_HALF_PLANES
+        // traffic probe (a build of its own, garbage results: scripts/build_variant.sh): the partial planes at half width - hidden slices
+        // 4 .. 7 store nothing, the reduce stages load planes 0 .. 3 only (57 % of the loop's hand-off bytes are these planes: is the
+        // traffic what bounds the step?)
+        if (st.slice >= NSLICE / 2) return;
+#endif
 #pragma unroll
         for (int q = 0; q < RT / RPI; ++q) {
             const int row = RPI * q + lane / LPR, cc = CW * wave + 4 * (lane % LPR);
@@ -1406,7 +1412,12 @@ struct Red2Role {
                 y.tv[q] = y.tp[q];
                 if (g.b2[q] >= 0 && g.t[q] < g.cnt[q]) y.tv[q] = ld4(ct + (size_t)g.b2[q] * D + c);
 #pragma unroll
-                for (int j = 0; j < NSLICE; ++j) y.pl[q][j] = ld_sc1(rp, j * pstride + pbase + row * 1024 + c * 4);
+                for (int j = 0; j < NSLICE; ++j) {
+#ifdef LADIFF_HALF_PLANES
+                    if (j >= NSLICE / 2) { y.pl[q][j] = y.pl[q][j - NSLICE / 2]; continue; }
+#endif
+                    y.pl[q][j] = ld_sc1(rp, j * pstride + pbase + row * 1024 + c * 4);
+                }
                 y.rs[q] = ld_sc1(rx, base + row * 1024 + c * 4);
             } else if (HO && row <= -2) {
                 // A padding row is stored as zeros, but not before this step's input of the block exists: the same row of the
@@ -1517,7 +1528,12 @@ struct StylRole {
             y.rs[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (row >= 0) {
 #pragma unroll
-                for (int j = 0; j < NSLICE; ++j) y.pl[q][j] = ld_sc1(rp, j * pstride + pbase + row * 1024 + c * 4);
+                for (int j = 0; j < NSLICE; ++j) {
+#ifdef LADIFF_HALF_PLANES
+                    if (j >= NSLICE / 2) { y.pl[q][j] = y.pl[q][j - NSLICE / 2]; continue; }
+#endif
+                    y.pl[q][j] = ld_sc1(rp, j * pstride + pbase + row * 1024 + c * 4);
+                }
                 y.rs[q] = ld_sc1(rx, base + row * 1024 + c * 4);
             } else if (HO && row <= -2) {
                 y.rs[q] = ld_sc1(rx, base + (-2 - row) * 1024 + c * 4);     // a padding row's ticket (Red2Role::issue)
@@ -1951,20 +1967,6 @@ __global__ __launch_bounds__(256 * WS, 1) void systolic_loop_kernel(const SysArg
     __syncthreads();
     if (ctl->abort) return;
     if ((int)blockIdx.x == p.fault_wg) return;       // injected fault (ladiff_debug_set_pipeline_fault): its consumers time out
-#ifdef LADIFF_STAMPS
-    // the shader clock this launch really ran at: s_memtime counts core clocks, s_memrealtime 100 MHz ticks (totals slot of the unused
-    // workgroup index 255: [0] core clocks, [1] 100 MHz ticks, written when workgroup 0's first wave leaves)
-    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
-    struct ClockProbe {
-        const SysArgs& p; unsigned long long c0, r0;
-        __device__ ~ClockProbe() {
-            if (p.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
-                p.stamps[(size_t)256 * 4 * 4 * 8 + 255 * 4] = __builtin_amdgcn_s_memtime() - c0;
-                p.stamps[(size_t)256 * 4 * 4 * 8 + 255 * 4 + 1] = __builtin_amdgcn_s_memrealtime() - r0;
-            }
-        }
-    } clock_probe{p, clk0, rt0};
-#endif
     if (!ctl->local_ok) st.out_local = 0;
 #ifdef LADIFF_STAMPS
     if (p.stamps != nullptr && threadIdx.x == 0)         // who runs here (the stage table is permuted by the XCD placement)

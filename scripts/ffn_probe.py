@@ -18,7 +18,7 @@ for B in (64, 128, 256):
     lens = [196] * B
     text, noise = syn.text_embeddings(B).to(dev), syn.init_noise(lens).to(dev)
     row = []
-    for probe in (0, 1, 4, 16, 5, 20, 21, 0):
+    for probe in ([int(v) for v in os.environ["PROBES"].split(",")] if os.environ.get("PROBES") else (0, 1, 4, 16, 5, 20, 21, 0)):
         L.ladiff_debug_set_probe(probe)
         with torch.cuda.stream(stream), torch.no_grad():
             for _ in range(6):

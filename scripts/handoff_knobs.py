@@ -8,6 +8,8 @@ import torch
 import bench
 from ladiff_amd import _lib, synthetic as syn
 
+if os.environ.get("LADIFF_LIB"):                      # an experiment build of the library (scripts/build_variant.sh; same ABI)
+    _lib.LIB_PATH = os.path.join(ROOT, os.environ["LADIFF_LIB"])
 dev = torch.device("cuda", 0)
 pipe = bench.build_pipe(dev, 128)
 pipe.precision = "fp32" if "fp32" in sys.argv[1:] else "bf16x3"

@@ -32,9 +32,6 @@ with torch.cuda.stream(s), torch.no_grad():
     pipe._diffusion_reverse(text, lens, init_noise=noise)
     torch.cuda.synchronize()
 print("status", pipe.loop_status())
-_ck = st[256 * 4 * 4 * 8 + 255 * 4:256 * 4 * 4 * 8 + 255 * 4 + 2].cpu().tolist()
-if _ck[1] > 0:
-    print(f"shader clock over the launch: {_ck[0]} core clocks in {_ck[1] * 0.01:.1f} us = {_ck[0] / (_ck[1] * 0.01):.0f} MHz")
 stats = st[256 * 4 * 4 * 8:256 * 4 * 4 * 8 + 256 * 4].cpu().reshape(256, 4)
 mid = st[256 * 4 * 4 * 8 + 256 * 4:256 * 4 * 4 * 8 + 256 * 4 + 256 * 4 * 8].cpu().reshape(256, 4, 8).double() * 0.01
 ident = st[-256:].cpu().tolist()
