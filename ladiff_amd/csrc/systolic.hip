@@ -690,7 +690,7 @@ struct QkvRole {
     char* atile; float *qt, *xt; int* gd;
     WFrag<AR, NTW, 8> wf;
     float bcol[NTW];
-    __amdgpu_buffer_rsrc_t rin, rout;
+    __amdgpu_buffer_rsrc_t rin, rout, rtab, rtkv;
     const float* tkv;
     int h, T, nkeys, nvt;                                                // nvt: column tiles this wave really has
     // tile column of this wave's tile j (j >= nvt: a duplicate of a valid one, loaded but never used)
@@ -714,6 +714,7 @@ struct QkvRole {
         for (int j = 0; j < NTW; ++j) { const int tc = tile_col(j) + frow; bcol[j] = st.b0[(tc >> 6) * 256 + h * 64 + (tc & 63)]; }
         rin = rsrc_of(st.in0); rout = rsrc_of(st.out);
         tkv = p.tkv + (size_t)st.layer * p.B2 * 512;
+        rtab = rsrc_of(p.tables); rtkv = rsrc_of(tkv);
     }
     __device__ __forceinline__ void geo(int b, Geo& g) {
         const int tid = threadIdx.x;
@@ -817,12 +818,21 @@ struct QkvRole {
     // operand tile is free once every wave is past the projection); all eight waves then do the projection; waves 0-3 do the
     // attention, drain their stores, count themselves in (LDS) and the last one publishes.  Per block the stage then costs
     // projection + max(attention + drain, wait + load + commit) instead of their sum.  A lone block's latency is unchanged.
+    // EARLY (tagged hand-off, launches in which rows queue up in front of the stage: SysArgs::look_ahead): the loader waves request the
+    // NEXT block's rows as soon as this block's tile is built - their row registers are free from then on and they never store to global
+    // memory, so the load round trip (0.5 us) runs under the projection instead of standing between two tiles; the attention waves had
+    // been waiting 0.6 us per block at the tile barrier.  Loop kernel 10.13 -> 9.80 ms at 128 prompts, 20.13 -> 19.25 at 256
+    // (profiles/r5/08_*).  A loop of its own: in the launches that gain nothing (a block's trip bounds them) the row registers must not
+    // stay live across the projection.
+    template <bool EARLY>
     __device__ __forceinline__ void split_loop(Ctl* ctl) {
         static_assert(WS == 2 && MR == 1, "wave groups: the eight-wave, 16-row form only");
         const int tid = threadIdx.x, lane = tid & 63, tl = tid - 256;
         const bool loader = tid >= 256;
         typedef __attribute__((address_space(3))) unsigned lu32;
         auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        f32x4 x[2][2];                                                   // loader waves: a block's rows between their loads and the tile
+        bool xissued = false, first = true;                              // ... already requested (behind the previous block's tile); complete at the first look
         SYS_SPLIT_DECL;
         for (int s = 0; s < p.n_steps; ++s)
             for (int b = st.blk0; b < p.NB; b += st.blkstride) {
@@ -839,26 +849,28 @@ struct QkvRole {
                     const int rb2 = d->row_b2[tl >= 1 && tl <= RT ? tl - 1 : 0];
                     // the text / time K|V rows do not depend on the block's flags (the per-call tables): they are requested BEFORE the
                     // wait - these are plain loads of rows nobody touched since the prologue, often a trip to the memory side
-                    const float* timekv = p.tables + (size_t)(p.step_lo + s) * DEN_STEP_STRIDE + st.layer * DEN_LAYER_STRIDE + DEN_OFF_TIME_KV;
+                    // (buffer loads with the table's base in scalar registers: as 64-bit per-lane pointers these addresses were spilled)
+                    const unsigned timeoff = (unsigned)(((p.step_lo + s) * DEN_STEP_STRIDE + st.layer * DEN_LAYER_STRIDE + DEN_OFF_TIME_KV + h * 64) * 4);
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {                        // text K|V slices of this head per sample-branch, slot 15: time
                         const int f4 = tl + 256 * u, sx = f4 >> 5, c4 = (f4 & 31) * 4;
-                        if (sx == 15) xk[u] = ld4(timekv + (c4 < 64 ? c4 : 192 + c4) + h * 64);
-                        else if (b2[u] >= 0) xk[u] = ld4(tkv + (size_t)b2[u] * 512 + (c4 < 64 ? c4 : 192 + c4) + h * 64);
+                        const unsigned col = (unsigned)(c4 < 64 ? c4 : 192 + c4) * 4u;
+                        if (sx == 15) xk[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rtab, col, timeoff, 0));
+                        else if (b2[u] >= 0) xk[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rtkv, (unsigned)b2[u] * 2048u + col, (unsigned)h * 256u, 0));
                     }
                     SYS_SPLIT_T0;
                     if constexpr (!HO) { if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, 0u, p.timeout_ticks)) return; }
-                    f32x4 x[2][2];
                     const unsigned base = (unsigned)b * RT * 1024;
-                    auto load_x = [&] {
+                    auto load_x = [&](unsigned bs) {
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             const int id = tl + 256 * u, row = id >> 5, c8 = id & 31;
-                            x[u][0] = ld_sc1(rin, base + row * 1024 + c8 * 32);
-                            x[u][1] = ld_sc1(rin, base + row * 1024 + c8 * 32 + 16);
+                            x[u][0] = ld_sc1(rin, bs + row * 1024 + c8 * 32);
+                            x[u][1] = ld_sc1(rin, bs + row * 1024 + c8 * 32 + 16);
                         }
                     };
-                    load_x();
+                    if (!xissued) load_x(base);
+                    first = true;
                     if constexpr (HO) {              // tagged hand-off: the rows are loaded until every word shows this step's parity
                         const unsigned par = (unsigned)(s & 1);
                         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -867,10 +879,11 @@ struct QkvRole {
 #pragma unroll
                             for (int u = 0; u < 2; ++u) { tag_acc(t, x[u][0], par); tag_acc(t, x[u][1], par); }
                             if (__all((t & 1u) == 0u)) break;
+                            first = false;
                             if (spin_give_up(p, spins, t0)) return;
                             __builtin_amdgcn_s_sleep(1);
                             if ((p.pause_mask & 16) != 0) for (int i_ = 0; i_ < p.pause_len; ++i_) __builtin_amdgcn_s_sleep(2);
-                            load_x();
+                            load_x(base);
                         }
                     }
                     SYS_SPLIT_WAIT;
@@ -892,6 +905,21 @@ struct QkvRole {
                         } else {
                             tile_put4<1, 4>(atile, row, c8 * 8, v0);
                             tile_put4<1, 4>(atile, row, c8 * 8 + 4, v1);
+                        }
+                    }
+                    // the next block's rows are requested now when this block's were complete at the first look (rows queue up in front of the stage)
+                    xissued = false;
+                    if constexpr (HO != 0 && EARLY) {
+                        int s2 = s, b2n = b + st.blkstride;
+                        if (b2n >= p.NB) { s2 = s + 1; b2n = st.blk0; }
+                        xissued = first && s2 < p.n_steps;
+                        if (xissued) {
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const int id = tl + 256 * u, row = id >> 5, c8 = id & 31;
+                                x[u][0] = ld_sc1(rin, (unsigned)b2n * RT * 1024 + row * 1024 + c8 * 32);
+                                x[u][1] = ld_sc1(rin, (unsigned)b2n * RT * 1024 + row * 1024 + c8 * 32 + 16);
+                            }
                         }
                     }
                 }
@@ -1920,7 +1948,9 @@ __device__ __forceinline__ void tail_loop_tag(const SysArgs& p, const Stage& st,
 // WS = waves per SIMD of a stage workgroup: 1 = 256 threads (32-row blocks: 256 weight registers + two row tiles of everything else
 // per wave), 2 = 512 threads with the stage's weight slice split over the two waves of a SIMD (16-row blocks)
 // HO = hand-off protocol: 0 = flags (drain, barrier, epoch word, poll), 1 = parity tags in the data (see tag4)
-template <int MR, int AR, int WS, int HO>
+// EQ = QKV's loader waves request the next block's rows early (QkvRole::split_loop<true>): the instantiation for launches in which rows
+// queue up (SysArgs::look_ahead); a kernel of its own, so that the other launches run exactly the code without it
+template <int MR, int AR, int WS, int HO, bool EQ = false>
 __global__ __launch_bounds__(256 * WS, 1) void systolic_loop_kernel(const SysArgs p) {
     static_assert(WS == 1 || MR == 1, "two waves per SIMD: 16-row blocks only (the reduce parts' slot tables hold 12 slots: wave + 8 q needs q < 1)");
     // all LDS is dynamic (a static variable would shift the dynamic base off its 16-byte alignment, cdna_hip_programming.md G17)
@@ -1988,7 +2018,7 @@ __global__ __launch_bounds__(256 * WS, 1) void systolic_loop_kernel(const SysArg
         case R_QKV:
             with_ho([&](auto hc) {
                 QkvRole<MR, AR, WS, decltype(hc)::value> r(p, st, lds);
-                if constexpr (WS == 2) r.split_loop(ctl);
+                if constexpr (WS == 2) r.template split_loop<EQ>(ctl);
                 else run(r);
             });
             break;
@@ -2396,11 +2426,12 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     if (dev < 0 || dev >= 64) return LADIFF_ERR_ARG;
     std::lock_guard<std::mutex> lock(mu);
     if (!attr_set[dev]) {
-        const void* k[8] = {reinterpret_cast<const void*>(systolic_loop_kernel<1, 0, 2, 0>), reinterpret_cast<const void*>(systolic_loop_kernel<2, 0, 1, 0>),
-                            reinterpret_cast<const void*>(systolic_loop_kernel<1, 1, 2, 0>), reinterpret_cast<const void*>(systolic_loop_kernel<2, 1, 1, 0>),
-                            reinterpret_cast<const void*>(systolic_loop_kernel<1, 0, 1, 0>), reinterpret_cast<const void*>(systolic_loop_kernel<1, 1, 1, 0>),
-                            reinterpret_cast<const void*>(systolic_loop_kernel<1, 0, 2, 1>), reinterpret_cast<const void*>(systolic_loop_kernel<1, 1, 2, 1>)};
-        for (int i = 0; i < 8; ++i) LADIFF_HIP(hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, SYS_LDS_BYTES));
+        const void* k[10] = {reinterpret_cast<const void*>(systolic_loop_kernel<1, 0, 2, 0>), reinterpret_cast<const void*>(systolic_loop_kernel<2, 0, 1, 0>),
+                             reinterpret_cast<const void*>(systolic_loop_kernel<1, 1, 2, 0>), reinterpret_cast<const void*>(systolic_loop_kernel<2, 1, 1, 0>),
+                             reinterpret_cast<const void*>(systolic_loop_kernel<1, 0, 1, 0>), reinterpret_cast<const void*>(systolic_loop_kernel<1, 1, 1, 0>),
+                             reinterpret_cast<const void*>(systolic_loop_kernel<1, 0, 2, 1>), reinterpret_cast<const void*>(systolic_loop_kernel<1, 1, 2, 1>),
+                             reinterpret_cast<const void*>(systolic_loop_kernel<1, 0, 2, 1, true>), reinterpret_cast<const void*>(systolic_loop_kernel<1, 1, 2, 1, true>)};
+        for (int i = 0; i < 10; ++i) LADIFF_HIP(hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, SYS_LDS_BYTES));
         attr_set[dev] = true;
     }
     if (done[dev] == nullptr) LADIFF_HIP(hipEventCreateWithFlags(&done[dev], hipEventDisableTiming));
@@ -2417,12 +2448,14 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
         LADIFF_HIP(hipMemsetAsync(a.flags, 0, (L.off_xin0 - L.off_flags) * sizeof(float), s));
     }
     if (fp32) {
-        if (tagged) hipLaunchKernelGGL((systolic_loop_kernel<1, 1, 2, 1>), dim3(L.nwg), dim3(512), SYS_LDS_BYTES, s, a);
+        if (tagged && a.look_ahead) hipLaunchKernelGGL((systolic_loop_kernel<1, 1, 2, 1, true>), dim3(L.nwg), dim3(512), SYS_LDS_BYTES, s, a);
+        else if (tagged) hipLaunchKernelGGL((systolic_loop_kernel<1, 1, 2, 1>), dim3(L.nwg), dim3(512), SYS_LDS_BYTES, s, a);
         else if (MR == 1 && g_waves16 == 2) hipLaunchKernelGGL((systolic_loop_kernel<1, 1, 2, 0>), dim3(L.nwg), dim3(512), SYS_LDS_BYTES, s, a);
         else if (MR == 1) hipLaunchKernelGGL((systolic_loop_kernel<1, 1, 1, 0>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
         else hipLaunchKernelGGL((systolic_loop_kernel<2, 1, 1, 0>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
     } else {
-        if (tagged) hipLaunchKernelGGL((systolic_loop_kernel<1, 0, 2, 1>), dim3(L.nwg), dim3(512), SYS_LDS_BYTES, s, a);
+        if (tagged && a.look_ahead) hipLaunchKernelGGL((systolic_loop_kernel<1, 0, 2, 1, true>), dim3(L.nwg), dim3(512), SYS_LDS_BYTES, s, a);
+        else if (tagged) hipLaunchKernelGGL((systolic_loop_kernel<1, 0, 2, 1>), dim3(L.nwg), dim3(512), SYS_LDS_BYTES, s, a);
         else if (MR == 1 && g_waves16 == 2) hipLaunchKernelGGL((systolic_loop_kernel<1, 0, 2, 0>), dim3(L.nwg), dim3(512), SYS_LDS_BYTES, s, a);
         else if (MR == 1) hipLaunchKernelGGL((systolic_loop_kernel<1, 0, 1, 0>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
         else hipLaunchKernelGGL((systolic_loop_kernel<2, 0, 1, 0>), dim3(L.nwg), dim3(256), SYS_LDS_BYTES, s, a);
