@@ -41,6 +41,25 @@ __device__ __forceinline__ float erf_as(float x) {
     return copysignf(fmaf(-q * t, e, 1.f), x);
 }
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erf_as(v * 0.70710678118654752440f)); }
+// two values at once with the packed fp32 instructions of gfx950 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: one issue slot for two
+// IEEE operations): the same operations in the same order as gelu_erf on each component, hence the same bits; where a role's GELU is
+// bound by vector issue (the pipeline's FFN stage: 4 values per lane, two waves per SIMD) the polynomial and the affine steps cost half
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
+    const f32x2 x = v * 0.70710678118654752440f;
+    const f32x2 ax = f32x2{fabsf(x[0]), fabsf(x[1])};
+    const f32x2 d = __builtin_elementwise_fma(f32x2{0.3275911f, 0.3275911f}, ax, f32x2{1.f, 1.f});
+    const f32x2 t = f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2 q = __builtin_elementwise_fma(t, f32x2{1.061405429f, 1.061405429f}, f32x2{-1.453152027f, -1.453152027f});
+    q = __builtin_elementwise_fma(t, q, f32x2{1.421413741f, 1.421413741f});
+    q = __builtin_elementwise_fma(t, q, f32x2{-0.284496736f, -0.284496736f});
+    q = __builtin_elementwise_fma(t, q, f32x2{0.254829592f, 0.254829592f});
+    const f32x2 a2 = (-1.4426950408889634f * ax) * ax;
+    const f32x2 e = f32x2{__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+    const f32x2 r = __builtin_elementwise_fma(-q * t, e, f32x2{1.f, 1.f});
+    const f32x2 er = f32x2{copysignf(r[0], x[0]), copysignf(r[1], x[1])};
+    return (0.5f * v) * (1.f + er);
+}
 
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_SILU = 3, ACT_QGELU = 4, ACT_LRELU = 5 };
 

@@ -1336,14 +1336,30 @@ struct MlpRole {
 #pragma unroll
             for (int j = 0; j < NT1; ++j) {
                 const int k = 16 * NT1 * wave + 16 * j + frow;           // 0..127
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * i + 4 * fk + r;
+                if constexpr (ACT == ACT_GELU) {
+                    // GELU of the lane's four values as two packed pairs (gelu_erf2: the bits of gelu_erf)
 #ifdef LADIFF_STAMPS
-                    if (probe) tile_put1<AR, 2>(htile, row, k, acc1[i][j][r] + b1[j]);
-                    else
+                    if (probe) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) tile_put1<AR, 2>(htile, 16 * i + 4 * fk + r, k, acc1[i][j][r] + b1[j]);
+                    } else
 #endif
-                    tile_put1<AR, 2>(htile, row, k, act_c<ACT>(acc1[i][j][r] + b1[j]));
+                    {
+                        const f32x2 g01 = gelu_erf2(f32x2{acc1[i][j][0] + b1[j], acc1[i][j][1] + b1[j]});
+                        const f32x2 g23 = gelu_erf2(f32x2{acc1[i][j][2] + b1[j], acc1[i][j][3] + b1[j]});
+                        tile_put1<AR, 2>(htile, 16 * i + 4 * fk + 0, k, g01[0]); tile_put1<AR, 2>(htile, 16 * i + 4 * fk + 1, k, g01[1]);
+                        tile_put1<AR, 2>(htile, 16 * i + 4 * fk + 2, k, g23[0]); tile_put1<AR, 2>(htile, 16 * i + 4 * fk + 3, k, g23[1]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * i + 4 * fk + r;
+#ifdef LADIFF_STAMPS
+                        if (probe) tile_put1<AR, 2>(htile, row, k, acc1[i][j][r] + b1[j]);
+                        else
+#endif
+                        tile_put1<AR, 2>(htile, row, k, act_c<ACT>(acc1[i][j][r] + b1[j]));
+                    }
                 }
             }
         SYS_STAMP(6);
