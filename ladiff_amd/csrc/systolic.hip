@@ -999,7 +999,11 @@ struct QkvRole {
             }
             float l = 0.f;
 #pragma unroll
+#ifdef LADIFF_PROBE_QKV_NOSOFTMAX      // variant build (garbage results): QKV's attention without the exponentials
+            for (int j = 0; j < NKEY; ++j) { e[j] = e[j] - m; l += e[j]; }
+#else
             for (int j = 0; j < NKEY; ++j) { e[j] = __builtin_amdgcn_exp2f((e[j] - m) * 1.4426950408889634f); l += e[j]; }   // masked: exp2(-inf) = 0
+#endif
             const float inv = 1.f / l;
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1204,7 +1208,11 @@ struct OutRole {
                         for (int i = 0; i < 4; ++i) v[k][i] = v[k][i] + ebias[k][i] + rk[i];
                     }
                     float mean, rstd;
+#ifdef LADIFF_PROBE_OUT_NOSTATS        // variant build (scripts/build_variant.sh, garbage results): OUT's epilogue without its LayerNorm statistics
+                    mean = v[0][0]; rstd = 1.f;
+#else
                     row_stats16(v, mean, rstd);
+#endif
                     SYS_STAMP(7);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -1345,8 +1353,13 @@ struct MlpRole {
                     } else
 #endif
                     {
+#ifdef LADIFF_PROBE_FFN_NOGELU         // variant build (garbage results): FFN without its activation
+                        const f32x2 g01 = f32x2{acc1[i][j][0] + b1[j], acc1[i][j][1] + b1[j]};
+                        const f32x2 g23 = f32x2{acc1[i][j][2] + b1[j], acc1[i][j][3] + b1[j]};
+#else
                         const f32x2 g01 = gelu_erf2(f32x2{acc1[i][j][0] + b1[j], acc1[i][j][1] + b1[j]});
                         const f32x2 g23 = gelu_erf2(f32x2{acc1[i][j][2] + b1[j], acc1[i][j][3] + b1[j]});
+#endif
                         tile_put1<AR, 2>(htile, 16 * i + 4 * fk + 0, k, g01[0]); tile_put1<AR, 2>(htile, 16 * i + 4 * fk + 1, k, g01[1]);
                         tile_put1<AR, 2>(htile, 16 * i + 4 * fk + 2, k, g23[0]); tile_put1<AR, 2>(htile, 16 * i + 4 * fk + 3, k, g23[1]);
                     }
