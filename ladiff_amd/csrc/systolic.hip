@@ -655,7 +655,12 @@ __device__ __forceinline__ void tag_loop(const SysArgs& p, const Stage& st, R& r
             r.commit(cur);
             if constexpr (R::TILE) __syncthreads();                     // the operand tile is complete (roles without one: no barrier)
             SYS_STAMP(2);
-            MidTag<R> mid{p, r, nxt, gnxt, gnn, has_next ? s2 : s, has_next ? b2 : b, s3, b3, R::PREFETCH && ahead, false};
+            // A role whose row image is dead once the tile is built (R::IMAGE_DEAD: LIN, FFN, SKIP) takes the early request INTO THE SAME
+            // registers.  With a second image the compiler copied the freshly requested rows into the first one at once - behind an
+            // `s_waitcnt vmcnt(0)` at the head of the first product: the whole load round trip (0.3 us per block in the busiest stage,
+            // FFN) stood exactly where the early request was meant to hide it (round 5, ISA of the loop body).
+            constexpr bool ALIAS = R::PREFETCH && R::IMAGE_DEAD;
+            MidTag<R> mid{p, r, ALIAS ? cur : nxt, gnxt, gnn, has_next ? s2 : s, has_next ? b2 : b, s3, b3, R::PREFETCH && ahead, false};
             mid.start();
             r.compute(s, b, gcur, cur, mid);
             settled = mid.settled; issued = mid.ahead;
@@ -663,7 +668,7 @@ __device__ __forceinline__ void tag_loop(const SysArgs& p, const Stage& st, R& r
             if ((p.delay_mask & R::PAUSE_BIT) != 0)
                 for (int i = 0; i < p.delay_len; ++i) __builtin_amdgcn_s_sleep(2);
             SYS_STAMP(4);
-            if constexpr (R::PREFETCH) { if (issued) cur = nxt; }
+            if constexpr (R::PREFETCH && !ALIAS) { if (issued) cur = nxt; }
             SYS_STAMP(5);
         }
     SYS_STAT_END;
@@ -680,6 +685,7 @@ struct QkvRole {
     static constexpr int RT = 16 * MR, QLD = 196, TK = LADIFF_MAX_LATENTS + 2;   // keys of a row: <= 8 latents, text, time
     static constexpr int NTH = 256 * WS, NTW = WS == 1 ? 3 : 2, NX = 2 / WS;      // threads; column tiles a wave can hold; 16-byte text K|V units per thread
     static constexpr bool PREFETCH = true;
+    static constexpr bool IMAGE_DEAD = false;                            // the row image is not read again once commit() has built the tile
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = false;
     static constexpr int PAUSE_BIT = 16;
@@ -712,6 +718,7 @@ struct QkvRole {
         load_w(wf, st.w0, D, 0, [&](int j) { const int tc = tile_col(j); return (tc >> 6) * 256 + h * 64 + (tc & 63); });
 #pragma unroll
         for (int j = 0; j < NTW; ++j) { const int tc = tile_col(j) + frow; bcol[j] = st.b0[(tc >> 6) * 256 + h * 64 + (tc & 63)]; }
+        landed();
         rin = rsrc_of(st.in0); rout = rsrc_of(st.out);
         tkv = p.tkv + (size_t)st.layer * p.B2 * 512;
         rtab = rsrc_of(p.tables); rtkv = rsrc_of(tkv);
@@ -1022,6 +1029,7 @@ template <int MR, int AR, int WS, int HO>
 struct OutRole {
     static constexpr int RT = 16 * MR, NW = 4 * WS, RPW = RT / NW, NTW = 16 / NW;     // rows / column tiles per wave
     static constexpr bool PREFETCH = true;
+    static constexpr bool IMAGE_DEAD = false;                            // the row image is not read again once commit() has built the tile
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = false;
     static constexpr int PAUSE_BIT = 32;
@@ -1038,6 +1046,7 @@ struct OutRole {
         atile = lds; ct = reinterpret_cast<float*>(lds + tile_bytes<AR, 4>(RT));
         load_w(wf, st.w0, D, 0, [&](int j) { return 16 * NTW * wave + 16 * j; });
         bias = ld4(st.b0 + 4 * lane); gg = ld4(st.g + 4 * lane); bb = ld4(st.be + 4 * lane);
+        landed();
         ratt = rsrc_of(st.in0); rx = rsrc_of(st.in1); rout = rsrc_of(st.out);
     }
     __device__ __forceinline__ void geo(int, Geo&) {}
@@ -1239,6 +1248,7 @@ template <int MR, int ACT, int AR, int WS, int HO>
 struct MlpRole {
     static constexpr int RT = 16 * MR, NW = 4 * WS, NT1 = 8 / NW, NT2 = 16 / NW;       // hidden / output column tiles per wave
     static constexpr bool PREFETCH = true;
+    static constexpr bool IMAGE_DEAD = true;                            // the row image is not read again once commit() has built the tile
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = true;
     static constexpr int PAUSE_BIT = ACT == ACT_GELU ? 8 : 1;          // FFN : LIN
@@ -1262,6 +1272,7 @@ struct MlpRole {
         load_w(w2, st.w1, FF, 2 * st.slice, [&](int j) { return 16 * NT2 * wave + 16 * j; });
 #pragma unroll
         for (int j = 0; j < NT1; ++j) b1[j] = st.b0[j0 + 16 * NT1 * wave + 16 * j + frow];
+        landed();
         rin = rsrc_of(st.in0); rout = rsrc_of(st.out);
         plane = (unsigned)st.slice * PRING * RT * 1024;
     }
@@ -1423,6 +1434,7 @@ struct Red2Role {
     // tagged hand-off: no operand tile, no barrier - every wave settles, reduces and stores its own rows; nothing to gain from
     // requesting the next block's partial rows early (they are produced just in time)
     static constexpr bool PREFETCH = HO == 0;
+    static constexpr bool IMAGE_DEAD = false;                            // the row image is not read again once commit() has built the tile
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = false;
     static constexpr int PAUSE_BIT = 2;
@@ -1537,6 +1549,7 @@ struct StylRole {
     // waves per SIMD (256 registers per wave: 128 of weights + two images of 11 x 16 bytes spilled; that plan runs STYL as two
     // groups on alternating blocks, which have the slack)
     static constexpr bool PREFETCH = MR == 1 && WS == 1;
+    static constexpr bool IMAGE_DEAD = false;                            // the row image is not read again once commit() has built the tile
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = false;
     static constexpr int PAUSE_BIT = 4;
@@ -1558,6 +1571,7 @@ struct StylRole {
         load_w(wf, st.w0, D, 0, [&](int j) { return 16 * NTW * wave + 16 * j; });
         if (wave == 0) { st4(cst + 4 * lane, ld4(st.b1 + 4 * lane)); st4(cst + D + 4 * lane, ld4(st.b0 + 4 * lane)); st4(cst + 2 * D + 4 * lane, ld4(st.be + 4 * lane)); }
         gg = ld4(st.g + 4 * lane);
+        landed();
         __syncthreads();
         rp = rsrc_of(st.in0); rx = rsrc_of(st.in1); rout = rsrc_of(st.out); rtab = rsrc_of(p.tables);
         pstride = (unsigned)PRING * RT * 1024;
@@ -1685,6 +1699,7 @@ template <int MR, int AR, int WS, int HO>
 struct SkipRole {
     static constexpr int RT = 16 * MR, NW = 4 * WS, NTH = 64 * NW, NTW = 8 / NW;      // column tiles per wave of this half's 128 columns
     static constexpr bool PREFETCH = true;
+    static constexpr bool IMAGE_DEAD = true;                            // the row image is not read again once commit() has built the tile
     static constexpr bool PREPOLL = WS == 2;
     static constexpr bool BACKP = false;
     static constexpr int PAUSE_BIT = 64;
@@ -1704,6 +1719,7 @@ struct SkipRole {
         load_w(wf, st.w0, 2 * D, 0, [&](int j) { return n0 + 16 * NTW * wave + 16 * j; });
         rx = rsrc_of(st.in0); rs = rsrc_of(st.in1); rout = rsrc_of(st.out);
         bias = ld4(st.b0 + n0 + (threadIdx.x & 31) * 4);
+        landed();
     }
     __device__ __forceinline__ void geo(int, Geo&) {}
     __device__ __forceinline__ void geo_fix(Geo&) {}

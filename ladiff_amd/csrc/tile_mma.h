@@ -80,6 +80,13 @@ __device__ __forceinline__ void load_w(WFrag<AR, NT, KS>& f, const float* w, int
     }
 }
 
+// The weight fragments are loaded once, in front of a role's block loop.  To the compiler's wait-count pass their loads are still
+// "possibly in flight" at the loop header (a merge point), so it guards their first use INSIDE the loop with `s_waitcnt vmcnt(0)` - on
+// every iteration, where it also waits for whatever the iteration has requested itself (the next block's rows: the whole load round
+// trip, 0.3 us per block, stood in front of the first product of the busiest stage).  landed(): wait for every load once, in front of
+// the loop, with the BUILTIN (an instruction the pass sees and accounts for - an asm statement it does not).
+__device__ __forceinline__ void landed() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0), nothing else (gfx9 encoding)
+
 // ---- LDS operand fetches the compiler does not reschedule.  Left to itself the compiler sinks every ds_read next to its use
 // and waits with lgkmcnt(0): the LDS latency is then paid in front of every 2 - 4 MFMAs.  These reads are issued as asm (the
 // compiler does not track their completion) and waited for with an explicit counted s_waitcnt that is tied to the registers
