@@ -8,6 +8,7 @@
 //     planes) by LDS-DMA; a stage's fragment = one conflict-free ds_read_b128 per lane, issued by asm one k-step ahead of its MFMAs.
 //     The stages land in the K / V image areas while those are not written yet (eight of the twelve are requested before the
 //     loop starts, see slab_off), so no stage is requested less than two stages ahead although the images leave only 32 KiB.
+//     Every wait for a stage is a `vmcnt(0)` of the waves that requested it (see `issue`).
 //   * q and k are computed TRANSPOSED (D^T = W x^T, v_mfma_f32_32x32x16_bf16: weight fragment first), v plainly (x first): the
 //     accumulator of a q^T / k^T tile then has the row's query / key on the lane and 16 of its d values in the registers, and since
 //     d is the contraction index of q.k ANY order of d is fine as long as q and k share it: registers 8 j .. 8 j + 7 of tile T ARE the
@@ -132,12 +133,19 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
     // buffers 6, 7), stage 8 goes to the V region again, 9 / 10 to the ring buffers, 11 to the rows of the V planes that only ITS
     // OWN epilogue writes (d 32 .. 63: a barrier stands between its products and that epilogue) - every stage is requested at
     // least two stages ahead.  With two buffers and one stage of look-ahead every stage stood ~1.5 us waiting for its 16 KiB.
+    // WHO requests a stage: stages 0 .. 7 (all requested before the loop and all landed before it starts: the wait for the x rows
+    // below is a `vmcnt(0)`) every wave its slabs 2 w, 2 w + 1; stages 8 .. 11 (requested inside the loop, one stage ahead) the EVEN ones
+    // waves 0 - 3 and the ODD ones waves 4 - 7, four slabs each - so a wave never has two stages in flight and its wait for one is
+    // `vmcnt(0)`: LDS-DMA requests of a wave do not complete in issue order when their latencies differ (gemm_big.hip, header), and
+    // the counted `vmcnt(2)` of rounds 3 - 4 could be satisfied by the younger stage's two requests.
     auto issue = [&](auto gc) __attribute__((always_inline)) {
         constexpr int g = decltype(gc)::value, T = g >> 1, part = T >> 1, hf = T & 1;
         const char* wrow = reinterpret_cast<const char*>(p.w) + (size_t)(part * D + h * DH + 32 * hf + (lane & 31)) * 1024 + (lane >> 5) * 16;
+        constexpr int NI = g < 8 ? 2 : 4;
+        if (g >= 8 && (wave >> 2) != (g & 1)) return;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int slab = 2 * wave + i, s = slab >> 1, pl = slab & 1, sa = 8 * (g & 1) + s;
+        for (int i = 0; i < NI; ++i) {
+            const int slab = g < 8 ? 2 * wave + i : 4 * (wave & 3) + i, s = slab >> 1, pl = slab & 1, sa = 8 * (g & 1) + s;
             const char* src = wrow + (sa >> 2) * 256 + pl * 128 + (sa & 3) * 32;
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), (__attribute__((address_space(3))) void*)(lds + slab_off<g>(slab)), 16, 0, 0);
         }
@@ -184,11 +192,13 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
     }
     if constexpr (DIAG != 4) static_for<QA_NSTAGE>([&](auto gc) {
         constexpr int g = decltype(gc)::value, T = g >> 1, khalf = g & 1;
-        // this wave's slabs of stage g have landed (and, the first time, its x rows): all but the younger requests - stages
-        // g + 1 .. 7 up to stage 6, one stage (two instructions) from stage 7 on, none at the end
-        constexpr int younger = g <= 6 ? 2 * (7 - g) : (g < QA_NSTAGE - 1 ? 2 : 0);
-        if constexpr (DIAG != 1 || g == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(younger) : "memory");   // lgkmcnt: this wave's LDS writes (bias table, image rows)
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // stage g has landed: stages 0 .. 7 before the loop (with the x rows), a later one when the four waves that requested it have
+        // waited for it - their ONLY requests in flight (see `issue`)
+        if constexpr (g == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if constexpr (g >= 8 && DIAG != 1) {
+            if ((wave >> 2) == (g & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // lgkmcnt: this wave's LDS writes (bias table, image rows)
+        } else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                   // every wave's have; and every wave is done with stage g - 1
         asm volatile("" ::: "memory");
         if constexpr (g >= 6 && g + 2 < QA_NSTAGE) issue(IntC<g + 2>{});

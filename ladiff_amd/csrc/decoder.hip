@@ -2,8 +2,19 @@
 // Activations are kept batch-major [B*F, 256] (the reference is [F, B, 256]); all ops are per-row or per-sample,
 // so this only changes strides and lets the final write land directly in [B, F, C].
 #include "model.h"
+#ifdef LADIFF_STAMPS
+#include <cstdlib>
+#endif
 
 namespace ladiff {
+
+// Diagnostic twin only: LADIFF_DEC_CUT=n in the environment (read per call) ends a decode after its first n launches (garbage output) -
+// scripts/two_streams_aggressor_bisect.py bisects with it which launch of a co-running decode disturbs another one.  Nothing of it is in the product.
+#ifdef LADIFF_STAMPS
+#define DEC_CUT() do { if (dec_cut >= 0 && ++dec_launched >= dec_cut) return 0; } while (0)
+#else
+#define DEC_CUT() do { } while (0)
+#endif
 
 constexpr int DEC_SMALL_ROWS = 4096;
 std::atomic<int> g_dec_out_cross{1};          // measurement switch (+ 64): self-attention out_proj GEMM + cross-attention row kernel as two launches (the path before)
@@ -39,6 +50,12 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
     const int M = ragged ? R : B * F;
     if (ws_floats < dec_ws_floats(B, (size_t)M, T)) return LADIFF_ERR_WORKSPACE;
     if (M == 0) return 0;
+#ifdef LADIFF_STAMPS
+    const char* dec_cut_env = getenv("LADIFF_DEC_CUT");
+    const int dec_cut = dec_cut_env ? atoi(dec_cut_env) : -1;
+    int dec_launched = 0;
+    if (dec_cut == 0) return 0;
+#endif
     const bool sp = wsp != nullptr;
     const size_t MD = (size_t)M * D;
     float* P[4]; float* SK[NSKIP]; float* Ps[4]; float* SKs[NSKIP];
@@ -69,8 +86,8 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
             pb.kv[l] = kv + l * kv_l; pb.wq[l] = L.cross_attn.in_w; pb.bq[l] = L.cross_attn.in_b; pb.wo[l] = L.cross_attn.out_w;
             pb.gu[l] = guws + l * gu_l;
         }
-        LADIFF_TRY(launch_gemm_batch(g, NL, s));
-        LADIFF_TRY(launch_decoder_cross_prep(pb, NL, B, T, s));
+        LADIFF_TRY(launch_gemm_batch(g, NL, s)); DEC_CUT();
+        LADIFF_TRY(launch_decoder_cross_prep(pb, NL, B, T, s)); DEC_CUT();
     }
 
     // Few frame rows (config c1: 8 x 60 = 480): a 128x128-tile launch is then 8 - 32 workgroups that each walk the whole K, ~16 us per
@@ -110,8 +127,8 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
     };
 
     // queries = zeros + query_pos_decoder.pe[:F]     ladiff_vae.py:299, :334
-    if (ragged) LADIFF_TRY(launch_broadcast_pe_ragged(w.query_pe, row_off, B, F, F, P[0], Ps[0], row_out, s));
-    else LADIFF_TRY(launch_broadcast_pe(w.query_pe, B, F, P[0], Ps[0], s));
+    if (ragged) { LADIFF_TRY(launch_broadcast_pe_ragged(w.query_pe, row_off, B, F, F, P[0], Ps[0], row_out, s)); DEC_CUT(); }
+    else { LADIFF_TRY(launch_broadcast_pe(w.query_pe, B, F, P[0], Ps[0], s)); DEC_CUT(); }
     const float* cur = P[0]; const float* curs = Ps[0];
     for (int l = 0; l < NL; ++l) {
         const DecLayerW& L = w.layer[l];
@@ -123,12 +140,12 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
                 RowLnArgs g;
                 g.A = curs; g.lda = D; g.A2 = SKs[NL - 1 - l]; g.lda2 = D; g.K1 = D; g.W = wsp->skip[l - NSKIP - 1].w; g.ldw = 2 * D; g.bias = sk.b;
                 g.Y = P[3]; g.Ys = Ps[3]; g.ldy = D; g.M = M; g.K = 2 * D;
-                LADIFF_TRY(launch_gemm_rowln(g, s));
+                LADIFF_TRY(launch_gemm_rowln(g, s)); DEC_CUT();
             } else {
             GemmArgs g = lin(sp ? curs : cur, D, sp ? wsp->skip[l - NSKIP - 1].w : sk.w, sk.b, P[3], D, M, D, 2 * D);
             g.A2 = sp ? SKs[NL - 1 - l] : SK[NL - 1 - l]; g.lda2 = D; g.K1 = D;
             g.split = sp ? 1 : 0; g.Ys = Ps[3];
-            LADIFF_TRY(launch_gemm(g, s));
+            LADIFF_TRY(launch_gemm(g, s)); DEC_CUT();
             }
             cur = P[3]; curs = Ps[3];
         }
@@ -137,26 +154,26 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
         // the F table rows once and every sample's attention reads those q | k | v (its own length still masks the keys).
         const bool shared = l == 0;
         if (shared) {
-            LADIFF_TRY(launch_broadcast_pe(w.query_pe, 1, F, pex, sp ? pexs : nullptr, s));
-            if (small) LADIFF_TRY(krs(pexs, D, Ls.self_attn.in_w, L.self_attn.in_b, qkv0, nullptr, 3 * D, 3 * D, ACT_NONE, nullptr, F));
+            LADIFF_TRY(launch_broadcast_pe(w.query_pe, 1, F, pex, sp ? pexs : nullptr, s)); DEC_CUT();
+            if (small) { LADIFF_TRY(krs(pexs, D, Ls.self_attn.in_w, L.self_attn.in_b, qkv0, nullptr, 3 * D, 3 * D, ACT_NONE, nullptr, F)); DEC_CUT(); }
             else {
             GemmArgs g = lin(sp ? pexs : pex, D, Ls.self_attn.in_w, L.self_attn.in_b, qkv0, 3 * D, F, 3 * D, D);
             g.split = sp ? 1 : 0;
-            LADIFF_TRY(launch_gemm(g, s));
+            LADIFF_TRY(launch_gemm(g, s)); DEC_CUT();
             }
         } else if (fused_attn) {
             // bf16x3 mode: in_proj inside the attention kernel (dec_qkv_attn.hip) - the [M, 768] q | k | v rows are never written
         } else if (small) {
-            LADIFF_TRY(krs(curs, D, Ls.self_attn.in_w, L.self_attn.in_b, qkv, nullptr, 3 * D, 3 * D, ACT_NONE, nullptr, M));
+            LADIFF_TRY(krs(curs, D, Ls.self_attn.in_w, L.self_attn.in_b, qkv, nullptr, 3 * D, 3 * D, ACT_NONE, nullptr, M)); DEC_CUT();
         } else {
             GemmArgs g = lin(sp ? curs : cur, D, Ls.self_attn.in_w, L.self_attn.in_b, qkv, 3 * D, M, 3 * D, D);
             g.split = sp ? 1 : 0;
-            LADIFF_TRY(launch_gemm(g, s));
+            LADIFF_TRY(launch_gemm(g, s)); DEC_CUT();
         }
         const float* qkv_l = shared ? qkv0 : qkv;
-        if (fused_attn && !shared) LADIFF_TRY(launch_dec_qkv_attn(curs, Ls.self_attn.in_w, L.self_attn.in_b, lengths, row_off, att, B, F, 1, s));
-        else if (sp) LADIFF_TRY(launch_self_attention_bf16x3(qkv_l, lengths, nullptr, att, B, F, H, 0, 1, s, row_off, shared));
-        else LADIFF_TRY(launch_decoder_self_attention(qkv_l, lengths, nullptr, att, B, F, 0, s, row_off, shared));
+        if (fused_attn && !shared) { LADIFF_TRY(launch_dec_qkv_attn(curs, Ls.self_attn.in_w, L.self_attn.in_b, lengths, row_off, att, B, F, 1, s)); DEC_CUT(); }
+        else if (sp) { LADIFF_TRY(launch_self_attention_bf16x3(qkv_l, lengths, nullptr, att, B, F, H, 0, 1, s, row_off, shared)); DEC_CUT(); }
+        else { LADIFF_TRY(launch_decoder_self_attention(qkv_l, lengths, nullptr, att, B, F, 0, s, row_off, shared)); DEC_CUT(); }
         // norm1: fused in the GEMM epilogue in fp32 mode; in bf16x3 mode the GEMM writes x + out_proj(att) and the only reader of
         // norm1's output, the cross-attention kernel below, normalises its rows as it loads them (one row kernel pass less)
         const NormW* n1_late = nullptr;
@@ -164,41 +181,41 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
             // bf16x3 mode, many rows: out_proj + residual + norm1 + cross-attention + residual + norm2 in ONE kernel that keeps Wo in
             // its registers (dec_cross.hip): x + out_proj(att) is never written
             LADIFF_TRY(launch_decoder_out_cross(att, cur, Ls.self_attn.out_w, L.self_attn.out_b, L.norm1.g, L.norm1.b, L.cross_attn.out_b,
-                                                L.norm2.g, L.norm2.b, counts, B, F, T, guws + l * gu_l, P[2], Ps[2], s, row_off));
+                                                L.norm2.g, L.norm2.b, counts, B, F, T, guws + l * gu_l, P[2], Ps[2], s, row_off)); DEC_CUT();
         } else {
         if (sp) {
-            if (small) LADIFF_TRY(krs(att, D, Ls.self_attn.out_w, L.self_attn.out_b, P[1], nullptr, D, D, ACT_NONE, cur, M));
+            if (small) { LADIFF_TRY(krs(att, D, Ls.self_attn.out_w, L.self_attn.out_b, P[1], nullptr, D, D, ACT_NONE, cur, M)); DEC_CUT(); }
             else {
             GemmArgs g = lin(att, D, Ls.self_attn.out_w, L.self_attn.out_b, P[1], D, M, D, D);
             g.res = cur; g.ldres = D; g.split = 1;
-            LADIFF_TRY(launch_gemm(g, s));
+            LADIFF_TRY(launch_gemm(g, s)); DEC_CUT();
             }
             n1_late = &L.norm1;
         } else {
-            LADIFF_TRY(gemm_ln(att, D, L.self_attn.out_w, Ls.self_attn.out_w, L.self_attn.out_b, cur, L.norm1, nullptr, P[1], nullptr));
+            LADIFF_TRY(gemm_ln(att, D, L.self_attn.out_w, Ls.self_attn.out_w, L.self_attn.out_b, cur, L.norm1, nullptr, P[1], nullptr)); DEC_CUT();
         }
         // ---- cross-attention to the latent tokens, tokens >= ceil(len/48) masked, + residual + norm2   :373-376, :408-409
         // (the q / out projections are folded into the <= 8 keys / values per sample: dec_cross.hip; fp32 in both modes)
         LADIFF_TRY(launch_decoder_cross_apply(P[1], L.cross_attn.out_b, L.norm2.g, L.norm2.b, counts, B, F, T, guws + l * gu_l, P[2],
-                                              Ps[2], s, row_off, n1_late ? n1_late->g : nullptr, n1_late ? n1_late->b : nullptr));
+                                              Ps[2], s, row_off, n1_late ? n1_late->g : nullptr, n1_late ? n1_late->b : nullptr)); DEC_CUT();
         }
         // ---- feed-forward, GELU(erf), + residual + norm3 (+ decoder.norm on the last layer, cross_attention.py:150-151)   :410-412
         float* dst = is_in ? SK[l] : P[0];
         float* dsts = is_in ? SKs[l] : Ps[0];
         if (sp && g_dec_fused_mlp && (M >= dec_mlp_min_rows() || g_dec_fused_mlp == 2)) {     // one kernel: the hidden rows never leave the registers (dec_mlp.hip)
             LADIFF_TRY(launch_dec_mlp(Ps[2], P[2], Ls.lin1.w, L.lin1.b, Ls.lin2.w, L.lin2.b, L.norm3.g, L.norm3.b,
-                                      last ? w.norm.g : nullptr, last ? w.norm.b : nullptr, dst, dsts, M, s));
+                                      last ? w.norm.g : nullptr, last ? w.norm.b : nullptr, dst, dsts, M, s)); DEC_CUT();
         } else if (small) {
-            LADIFF_TRY(krs(Ps[2], D, Ls.lin1.w, L.lin1.b, nullptr, hid, FF, FF, ACT_GELU, nullptr, M));
+            LADIFF_TRY(krs(Ps[2], D, Ls.lin1.w, L.lin1.b, nullptr, hid, FF, FF, ACT_GELU, nullptr, M)); DEC_CUT();
             // linear2: K = 1024 as four partial planes (the q|k|v + attention buffers are free by now), summed by the LayerNorm pass
-            LADIFF_TRY(krs(hid, FF, Ls.lin2.w, nullptr, qkv, nullptr, D, D, ACT_NONE, nullptr, M));
+            LADIFF_TRY(krs(hid, FF, Ls.lin2.w, nullptr, qkv, nullptr, D, D, ACT_NONE, nullptr, M)); DEC_CUT();
             LADIFF_TRY(launch_reduce_rows(qkv, 4, M, L.lin2.b, P[2], RED_LN, L.norm3.g, L.norm3.b, nullptr, 0, nullptr, nullptr, 1, 1, 0, 0,
                                           dst, dsts, s, nullptr, last ? w.norm.g : nullptr, last ? w.norm.b : nullptr));
         } else {
             GemmArgs g = lin(sp ? Ps[2] : P[2], D, Ls.lin1.w, L.lin1.b, sp ? nullptr : hid, FF, M, FF, D, ACT_GELU);
             g.split = sp ? 1 : 0; if (sp) g.Ys = hid;
-            LADIFF_TRY(launch_gemm(g, s));
-            LADIFF_TRY(gemm_ln(hid, FF, L.lin2.w, Ls.lin2.w, L.lin2.b, P[2], L.norm3, last ? &w.norm : nullptr, dst, dsts));
+            LADIFF_TRY(launch_gemm(g, s)); DEC_CUT();
+            LADIFF_TRY(gemm_ln(hid, FF, L.lin2.w, Ls.lin2.w, L.lin2.b, P[2], L.norm3, last ? &w.norm : nullptr, dst, dsts)); DEC_CUT();
         }
         cur = dst; curs = dsts;
     }
@@ -211,10 +228,10 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
         const int Np = (C + 127) / 128 * 128;
         if ((size_t)Np > (size_t)FF || (size_t)Np * (D + 1) > 3 * MD) return LADIFF_ERR_SHAPE;
         float* wpad = qkv; float* bpad = qkv + (size_t)Np * D;
-        LADIFF_TRY(launch_pad_rows(wsp->final_layer.w, w.final_layer.b, wpad, bpad, C, Np, s));
+        LADIFF_TRY(launch_pad_rows(wsp->final_layer.w, w.final_layer.b, wpad, bpad, C, Np, s)); DEC_CUT();
         GemmArgs g = lin(curs, D, wpad, bpad, hid, Np, M, Np, D);
         g.split = 1;
-        LADIFF_TRY(launch_gemm(g, s));
+        LADIFF_TRY(launch_gemm(g, s)); DEC_CUT();
         return launch_scatter_feats(hid, Np, C, M, F, ragged ? nullptr : lengths, ragged ? row_out : nullptr, feats, s);
     }
     GemmArgs g = lin(cur, D, w.final_layer.w, w.final_layer.b, feats, C, M, C, D);

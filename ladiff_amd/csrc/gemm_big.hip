@@ -2,8 +2,14 @@
 //
 //   * 128x128 tiles (4 waves, 64x64 each) or, when LayerNorm follows, 64x256 tiles that own whole rows (4 waves, 32x128);
 //   * K in stages of 32 floats, two stages in LDS, filled by LDS-DMA (`global_load_lds_dwordx4`, one 1-KiB piece = 8 rows
-//     x 128 B per wave-instruction, no staging VGPRs); stage kt+1 is in flight during the MFMAs of stage kt, stage kt+2 is
-//     issued as soon as every wave has left buffer kt; two workgroups per CU hide each other's barriers and epilogues;
+//     x 128 B per wave-instruction, no staging VGPRs); stage kt+1 is requested behind the barrier in front of stage kt's MFMAs
+//     and is the ONLY request in flight when a wave waits for it - every wait is `vmcnt(0)`; two workgroups per CU hide each
+//     other's barriers, epilogues and what is left of the load latency.
+//     Why not two stages in flight behind a counted `vmcnt(PPW)` (rounds 1 - 4): LDS-DMA requests of one wave do NOT complete in
+//     issue order when their latencies differ - an activation piece that misses the L2 is overtaken by the next stage's weight
+//     pieces that hit, `vmcnt(PPW)` is then satisfied by the wrong eight and the MFMAs read rows that have not landed.  Never
+//     seen with the GPU to itself; with a second stream's kernels loading the memory system 1 - 2 % of the decodes came out
+//     with a wrong tile (scripts/two_streams_*.py, profiles/r5/11_*: 60 of 3000 against 0 of 3000 in this form, same speed);
 //   * LDS rows are 128 B; the 16-byte chunk c of row r sits in slot c ^ ((r >> 1) & 7) (applied on the DMA source
 //     address and on the fragment reads) -> conflict-free ds_read_b128 for the 32x32x2 operand layout;
 //   * blockIdx is remapped so that the N/BN workgroups that share an A row tile run on the same XCD (they hit in its L2);
@@ -33,7 +39,6 @@ __device__ __forceinline__ void gemm_big_body(const GemmArgs& p) {
     constexpr int GRP = 8 * NW;                    // rows covered by one piece per wave
     constexpr int GA = BM / GRP, GT = ROWS / GRP;
     static_assert(BM % GRP == 0 && BN % GRP == 0, "tiles are multiples of 32 rows");
-    constexpr int PPW = GT;                        // pieces per wave per stage
     constexpr int CLD = BN + 4;                    // row stride of the staged C tile
     constexpr int LDSF = (2 * STAGE > BM * CLD) ? 2 * STAGE : BM * CLD;
     constexpr int LPR = BN / 4;                    // lanes per output row (16-byte units)
@@ -114,11 +119,11 @@ __device__ __forceinline__ void gemm_big_body(const GemmArgs& p) {
     for (int e = 0; e < EI; ++e) rv[e] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     issue(0, 0);
-    if (nk > 1) issue(1, 1);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) wait_vm<PPW>(); else wait_vm<0>();
-        __builtin_amdgcn_s_barrier();
+        wait_vm<0>();                                  // this wave's pieces of stage kt: nothing younger is in flight (header)
+        __builtin_amdgcn_s_barrier();                  // every wave's have landed; every wave has left the other buffer
+        if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
         if (kt == nk - 1 && p.res != nullptr) {        // residual rows: latency hides under the last stage's MFMAs
 #pragma unroll
             for (int e = 0; e < EI; ++e) {
@@ -127,9 +132,8 @@ __device__ __forceinline__ void gemm_big_body(const GemmArgs& p) {
             }
         }
         compute(buf);
-        __builtin_amdgcn_s_barrier();                  // every wave has left `buf`
-        if (kt + 2 < nk) issue(kt + 2, buf);
     }
+    __builtin_amdgcn_s_barrier();                      // every wave has left the last stage: the C tile takes its place
 
     // ---- accumulators -> LDS (C tile, row stride BN + 4)
     float* ct = lds;
@@ -197,7 +201,6 @@ __device__ __forceinline__ void gemm_big_split_body(const GemmArgs& p) {
     constexpr int STAGE = ROWS * 32;               // floats (128 B per row)
     constexpr int GRP = 8 * NW;                    // rows covered by one piece per wave (a piece = 8 rows x 128 B)
     constexpr int GA = BM / GRP, GT = ROWS / GRP;
-    constexpr int PPW = GT;
     constexpr int CLD = BN + 4;
     constexpr int LPR = BN / 4, RPI = 64 / LPR, EI = BM / NW / RPI;
     constexpr int LDSF = (2 * STAGE > BM * CLD) ? 2 * STAGE : BM * CLD;
@@ -283,12 +286,13 @@ __device__ __forceinline__ void gemm_big_split_body(const GemmArgs& p) {
     for (int e = 0; e < EI; ++e) rv[e] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
 
+    // one stage in flight, every wait `vmcnt(0)` (see the header: LDS-DMA requests do not complete in issue order)
     issue(0, 0);
-    if (nk > 1) issue(1, 1);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) wait_vm<PPW>(); else wait_vm<0>();
-        __builtin_amdgcn_s_barrier();
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();              // stage kt has landed for every wave; every wave has left the other buffer
+        if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
         if (kt == nk - 1) {                        // epilogue operands: their latency hides under the last stage's MFMAs
             if (p.bias != nullptr) bv = ld4(p.bias + col0 + ec);
             if (p.res != nullptr) {
@@ -300,9 +304,8 @@ __device__ __forceinline__ void gemm_big_split_body(const GemmArgs& p) {
             }
         }
         compute(buf);
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) issue(kt + 2, buf);
     }
+    __builtin_amdgcn_s_barrier();                  // every wave has left the last stage: the C tile takes its place
 
     float* ct = lds;
 #pragma unroll

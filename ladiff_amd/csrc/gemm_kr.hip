@@ -6,9 +6,9 @@
 // the MFMA.  This kernel therefore (1) moves the minimum bytes per workgroup - one 256-wide K slice of a tile that
 // gives ~256 workgroups (80x64 for N=1024, 64x64 for N=768, 32x32 for N=256), with split-K over blockIdx.y for the
 // K=1024/512 GEMMs (partials are combined by reduce_rows_kernel, which also applies the LayerNorm that follows them);
-// (2) issues ALL of its loads at kernel entry as LDS-DMA (`global_load_lds_dwordx4`: no VGPRs, ~36 KiB in flight per
-// wave); (3) starts the MFMAs after the first 64-wide K sub-slice has landed (counted `s_waitcnt vmcnt(N)` + raw
-// `s_barrier`), the other three sub-slices stream in underneath.
+// (2) brings its operands by LDS-DMA (`global_load_lds_dwordx4`: no VGPRs), two of the four 64-wide K sub-slices in flight
+// per workgroup, ONE per wave (each wait is `vmcnt(0)`: LDS-DMA requests do not complete in issue order, gemm_big.hip);
+// (3) starts the MFMAs after the first sub-slice has landed (raw `s_barrier`), the others stream in underneath.
 //
 // LDS image: [4 sub-slices][BM + BN rows][64 floats] (256-byte rows = one LDS bank row).  One LDS-DMA instruction
 // writes 1 KiB = 4 consecutive rows of one sub-slice, lane i -> row i/16, 16-byte slot i%16.  The slot is XOR-swizzled
@@ -77,9 +77,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
     constexpr int PCS = ROWS / 4;                  // 1-KiB pieces per sub-slice
     static_assert(NW == 4, "four waves per workgroup");
     static_assert(PCS % NW == 0, "pieces must split evenly over the waves");
-    constexpr int PW = 4 * PCS / NW;               // pieces per wave
-    constexpr int PW_SUB = PCS / NW;               // ... per sub-slice
-    static_assert(PW <= 63, "vmcnt is 6 bits");
+    static_assert(PCS / 2 <= 63, "vmcnt is 6 bits (a wave has one sub-slice = PCS / 2 pieces in flight)");
 
     __shared__ __attribute__((aligned(1024))) float lds[4 * SUB];
 
@@ -114,28 +112,43 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
         if (has_res && gr < p.M && gc < p.N) rv[u] = ld4(p.res + (size_t)gr * p.ldres + gc);
     }
 
-    // ---- LDS-DMA pieces.  A piece = 4 rows x 64 floats of one sub-slice; wave w takes rows 16 g + 4 w .. + 3 of every
-    // 16-row group g, so (sub-slice, group, A-or-W) are compile-time per issue slot and only a row clamp is left at run time.
+    // ---- LDS-DMA pieces.  A piece = 4 rows x 64 floats of one sub-slice: rows 16 g + 4 q .. + 3 of 16-row group g, q < 4.
+    // WHO requests WHAT (round 5): the waves form two pairs; pair 0 (waves 0, 1) brings sub-slices 0 and 2, pair 1 (waves 2, 3) brings
+    // 1 and 3, wave `half` of a pair the row quads q = 2 half, 2 half + 1 - and a wave never has more than ONE sub-slice in flight, so
+    // every wait is `vmcnt(0)`.  LDS-DMA requests of a wave do not complete in issue order when their latencies differ (gemm_big.hip,
+    // header): the counted waits of rounds 1 - 4 (all four sub-slices requested at entry, `vmcnt(PW - PW_SUB)` ...) could be
+    // satisfied by the pieces of a later sub-slice.
     constexpr int GA = BM / 16, GT = ROWS / 16;    // 16-row groups: A tile, total
     static_assert(BM % 16 == 0 && BN % 16 == 0, "tiles are multiples of 16 rows");
-    const int rl = 4 * wave + (lane >> 4);         // row within a 16-row group = LDS row & 15
-    const int kl = (((lane & 15) ^ rl) << 2) + (ks << 8);   // this lane's k: swizzled 16-byte slot + K slice
+    const int pair = wave >> 1, half = wave & 1;
+    int rlq[2], klq[2];
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+        rlq[qq] = 4 * (2 * half + qq) + (lane >> 4);                      // row within a 16-row group = LDS row & 15
+        klq[qq] = (((lane & 15) ^ rlq[qq]) << 2) + (ks << 8);            // this lane's k: swizzled 16-byte slot + K slice
+    }
     // Workgroups that share operand rows (same bm: A rows, same bn: W rows) start at the same time; rotating which
     // 64-wide k block lands in LDS sub-slice s keeps them from all missing on the same cache lines at once.
     const int rot = (bm + bn) & 3;
     const float* abase; int ald;
     if ((ks << 8) < p.K1) { abase = p.A; ald = p.lda; } else { abase = p.A2 - p.K1; ald = p.lda2; }
-    float* const lbase = lds + 4 * wave * 64;
-    auto issue = [&](int s, int g) __attribute__((always_inline)) {   // s, g are compile-time at every call site
+    float* const lbase = lds + 4 * (2 * half) * 64;
+    auto issue = [&](int s, int g, int qq) __attribute__((always_inline)) {   // g, qq are compile-time at every call site
         const float* src;
         if (g < GA) {
-            int gr = row0 + 16 * g + rl; gr = gr < p.M ? gr : p.M - 1;
-            src = abase + (size_t)gr * ald + kl + (((s + rot) & 3) << 6);
+            int gr = row0 + 16 * g + rlq[qq]; gr = gr < p.M ? gr : p.M - 1;
+            src = abase + (size_t)gr * ald + klq[qq] + (((s + rot) & 3) << 6);
         } else {
-            int gc = col0 + 16 * (g - GA) + rl; gc = gc < p.N ? gc : p.N - 1;
-            src = p.W + (size_t)gc * p.ldw + kl + (((s + rot) & 3) << 6);
+            int gc = col0 + 16 * (g - GA) + rlq[qq]; gc = gc < p.N ? gc : p.N - 1;
+            src = p.W + (size_t)gc * p.ldw + klq[qq] + (((s + rot) & 3) << 6);
         }
-        glds16(src, lbase + s * SUB + 16 * g * 64);
+        glds16(src, lbase + s * SUB + (16 * g + 4 * qq) * 64);
+    };
+    auto issue_sub = [&](int s) __attribute__((always_inline)) {          // this wave's 2 GT pieces of sub-slice s
+#pragma unroll
+        for (int g = 0; g < GT; ++g)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) issue(s, g, qq);
     };
 
     Acc acc[RM][RN];
@@ -169,16 +182,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
 
     {
         STAMP(0);
-#pragma unroll
-        for (int ss = 0; ss < 4; ++ss)
-#pragma unroll
-            for (int g = 0; g < GT; ++g) issue(ss, g);
+        issue_sub(pair);                            // pair 0: sub-slice 0, pair 1: sub-slice 1
         STAMP(1);
-        wait_vmcnt<PW - PW_SUB>(); __builtin_amdgcn_s_barrier(); STAMP(2); compute_sub(0);
+        if (pair == 0) wait_vmcnt<0>();             // (also retires this wave's residual / bias loads: they are older)
+        __builtin_amdgcn_s_barrier();               // sub-slice 0 landed
+        if (pair == 0) issue_sub(2);
+        STAMP(2); compute_sub(0);
         STAMP(3);
-        wait_vmcnt<PW - 2 * PW_SUB>(); __builtin_amdgcn_s_barrier(); compute_sub(1);
-        wait_vmcnt<PW - 3 * PW_SUB>(); __builtin_amdgcn_s_barrier(); compute_sub(2);
-        wait_vmcnt<0>(); __builtin_amdgcn_s_barrier();
+        if (pair == 1) wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();               // 1
+        if (pair == 1) issue_sub(3);
+        compute_sub(1);
+        if (pair == 0) wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();               // 2
+        compute_sub(2);
+        if (pair == 1) wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();               // 3
         reg_touch(bv);                              // everything has landed: keep compiler-made vmcnt(0) out of the store loop
 #pragma unroll
         for (int u = 0; u < UNITS; ++u) reg_touch(rv[u]);
@@ -231,8 +250,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
 // MFMAs in the meantime.  Waves 0-3 (one per SIMD) only compute, arranged WN x WK: each owns BM x (BN / WN) outputs over
 // 1 / WK of the K slice - with 16x16x32 MFMAs a wave tile of tm x tn reads (1/tm + 1/tn) * 4 bytes of LDS per MAC, and an
 // 80 x 16 wave tile (four waves side by side) ran at LDS-read speed, not at matrix-pipe speed.  The K parts are summed in
-// the staged epilogue.  The producers signal "phase landed" through the workgroup barrier: counted s_waitcnt vmcnt with
-// the next sub-slice already in flight; the consumers take the four 64-wide sub-slices one by one (wave wk its 32-k
+// the staged epilogue.  The producers signal "phase landed" through the workgroup barrier (`vmcnt(0)` by the pair of producers that
+// brought the sub-slice, the other pair's next one already in flight); the consumers take the four 64-wide sub-slices one by one (wave wk its 32-k
 // half), so they trail the fill by one sub-slice.  Stamps: stores issued 6.5 k cycles after workgroup start (11.7 k for
 // the previous all-waves-do-everything kernel, 6.9 k with two phases of two sub-slices); an empty kernel with this
 // launch geometry costs 1.7 us per launch, the real one 5.4 us (scripts/ubench_empty.py).
@@ -245,7 +264,7 @@ __global__ __launch_bounds__(512) void gemm_kp_kernel(const KrArgs p) {
     constexpr int ROWS = BM + BN;
     constexpr int SUB = ROWS * 64;
     constexpr int GA = BM / 16, GT = ROWS / 16;    // 16-row groups = DMA pieces per producer wave per sub-slice
-    static_assert(2 * GT <= 63, "vmcnt is 6 bits");
+    static_assert(2 * GT <= 63, "vmcnt is 6 bits (a producer has one sub-slice = 2 GT pieces in flight)");
     static_assert(BM % 16 == 0 && BN % (16 * WN) == 0, "tiles are multiples of 16 rows");
 
     __shared__ __attribute__((aligned(1024))) float lds[4 * SUB];
@@ -323,38 +342,50 @@ __global__ __launch_bounds__(512) void gemm_kp_kernel(const KrArgs p) {
 
     if (wave >= 4) {
         // ------------------------------------------------------------------ producers
-        const int pw = wave - 4;
-        const int rl = 4 * pw + (lane >> 4);
-        const int kl = (((lane & 15) ^ rl) << 2) + (ks << 8);
+        // Producer pair 0 (waves 4, 5) brings sub-slices 0 and 2, pair 1 (waves 6, 7) brings 1 and 3; wave `half` of a pair the row
+        // quads q = 2 half, 2 half + 1 of every 16-row group.  A producer never has more than ONE sub-slice in flight and every wait
+        // is `vmcnt(0)` (LDS-DMA requests of a wave do not complete in issue order: gemm_big.hip, header); the workgroup still has two
+        // sub-slices in flight, requested at the points the counted form of rounds 1 - 4 requested them.
+        const int pw = wave - 4, pair = pw >> 1, half = pw & 1;
+        int rlq[2], klq[2];
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            rlq[qq] = 4 * (2 * half + qq) + (lane >> 4);
+            klq[qq] = (((lane & 15) ^ rlq[qq]) << 2) + (ks << 8);
+        }
         const float* abase; int ald;
         if ((ks << 8) < p.K1) { abase = p.A; ald = p.lda; } else { abase = p.A2 - p.K1; ald = p.lda2; }
-        float* const lbase = lds + 4 * pw * 64;
-        auto issue = [&](int s, int g) __attribute__((always_inline)) {
+        float* const lbase = lds + 4 * (2 * half) * 64;
+        auto issue = [&](int s, int g, int qq) __attribute__((always_inline)) {
             const float* src;
             if (g < GA) {
-                int gr = row0 + 16 * g + rl; gr = gr < p.M ? gr : p.M - 1;
-                src = abase + (size_t)gr * ald + kl + (s << 6);
+                int gr = row0 + 16 * g + rlq[qq]; gr = gr < p.M ? gr : p.M - 1;
+                src = abase + (size_t)gr * ald + klq[qq] + (s << 6);
             } else {
-                int gc = col0 + 16 * (g - GA) + rl; gc = gc < p.N ? gc : p.N - 1;
-                src = p.W + (size_t)gc * p.ldw + kl + (s << 6);
+                int gc = col0 + 16 * (g - GA) + rlq[qq]; gc = gc < p.N ? gc : p.N - 1;
+                src = p.W + (size_t)gc * p.ldw + klq[qq] + (s << 6);
             }
-            glds16(src, lbase + s * SUB + 16 * g * 64);
+            glds16(src, lbase + s * SUB + (16 * g + 4 * qq) * 64);
         };
-        auto issue_subs = [&](int s0, int s1) __attribute__((always_inline)) {
+        auto issue_sub = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
-            for (int s = s0; s < s1; ++s)
+            for (int g = 0; g < GT; ++g)
 #pragma unroll
-                for (int g = 0; g < GT; ++g) issue(s, g);
+                for (int qq = 0; qq < 2; ++qq) issue(s, g, qq);
         };
-        // four phases = the four 64-wide sub-slices; a sub-slice is signalled when it has landed, with the next one already
-        // in flight (counted vmcnt): the consumers trail the fill by one sub-slice instead of half the K slice
-        issue_subs(0, 2);
-        wait_vmcnt<GT>(); __builtin_amdgcn_s_barrier();                // sub-slice 0 landed
-        issue_subs(2, 3);
-        wait_vmcnt<GT>(); __builtin_amdgcn_s_barrier();                // 1
-        issue_subs(3, 4);
-        wait_vmcnt<GT>(); __builtin_amdgcn_s_barrier();                // 2
-        wait_vmcnt<0>(); __builtin_amdgcn_s_barrier();                 // 3
+        // four phases = the four 64-wide sub-slices; a sub-slice is signalled when it has landed, with the next one already in flight
+        // (the other pair's): the consumers trail the fill by one sub-slice instead of half the K slice
+        issue_sub(pair);
+        if (pair == 0) wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                                  // sub-slice 0 landed
+        if (pair == 0) issue_sub(2);
+        if (pair == 1) wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                                  // 1
+        if (pair == 1) issue_sub(3);
+        if (pair == 0) wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                                  // 2
+        if (pair == 1) wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                                  // 3
         prefetch_epilogue();
         __builtin_amdgcn_s_barrier();                                  // C planes staged
         store_tile();

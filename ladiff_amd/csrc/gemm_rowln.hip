@@ -56,13 +56,15 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const RowLnArgs p) {
 #pragma unroll
             for (int i = 1; i < PPW; ++i) dma16(wrow + (size_t)(16 * (i - 1)) * ldw + k0, dst + 16 * i * 64);
         };
+        // ONE stage in flight and every wait `vmcnt(0)`: LDS-DMA requests of a wave do not complete in issue order when their latencies
+        // differ (an A piece that misses the L2 against W pieces that hit), so a counted wait with a younger stage in flight can be
+        // satisfied by the wrong pieces (gemm_big.hip, header)
         issue(0);
-        if (nk > 1) issue(1);
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) wait_vm<PPW>(); else wait_vm<0>();
-            __builtin_amdgcn_s_barrier();          // A(kt): stage landed
+            wait_vm<0>();
+            __builtin_amdgcn_s_barrier();          // A(kt): stage landed (and B(kt - 1) has passed: the other buffer is free)
+            if (kt + 1 < nk) issue(kt + 1);
             __builtin_amdgcn_s_barrier();          // B(kt): stage consumed
-            if (kt + 2 < nk) issue(kt + 2);
         }
         __builtin_amdgcn_s_barrier();              // C tile staged (the producers take no part in the epilogue)
         return;
@@ -208,13 +210,12 @@ __global__ __launch_bounds__(512) void combine_gemm_kernel(const CombineGemmArgs
 #pragma unroll
             for (int i = 0; i < PPW; ++i) dma16(wrow + (size_t)(16 * i) * ldw + (kt << 6), dst + 16 * i * 64);
         };
-        issue(0);
-        issue(1);
+        issue(0);                                  // one stage in flight, `vmcnt(0)` waits only (see gemm_rowln_kernel above)
         for (int kt = 0; kt < NK; ++kt) {
-            if (kt + 1 < NK) wait_vm<PPW>(); else wait_vm<0>();
+            wait_vm<0>();
             __builtin_amdgcn_s_barrier();          // A(kt): W stage landed (kt = 0: and the A rows are built)
+            if (kt + 1 < NK) issue(kt + 1);
             __builtin_amdgcn_s_barrier();          // B(kt)
-            if (kt + 2 < NK) issue(kt + 2);
         }
         __builtin_amdgcn_s_barrier();              // C tile staged
         return;

@@ -102,13 +102,13 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnArgs p) {
                 dma16(wbase + (size_t)((wr >> 6) * 256 + (wr & 63)) * D + k0, dst + 16 * i * 64);
             }
         };
+        // one stage in flight, every wait `vmcnt(0)`: LDS-DMA requests do not complete in issue order (gemm_big.hip, header)
         issue(0);
-        issue(1);
         for (int kt = 0; kt < NK; ++kt) {
-            if (kt + 1 < NK) wait_vm<PPW>(); else wait_vm<0>();
+            wait_vm<0>();
             __builtin_amdgcn_s_barrier();          // A(kt)
+            if (kt + 1 < NK) issue(kt + 1);
             __builtin_amdgcn_s_barrier();          // B(kt)
-            if (kt + 2 < NK) issue(kt + 2);
         }
         // park the extra K|V in LDS (stage 0 is idle: every consumer passed B(3) after its last LDS read)
 #pragma unroll

@@ -5,6 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from ladiff_amd import synthetic as syn
+from ladiff_amd import _lib
+if os.environ.get("LADIFF_LIB"):                      # an experiment build of the library (same ABI)
+    _lib.LIB_PATH = os.path.join(ROOT, os.environ["LADIFF_LIB"])
 from ladiff_amd.text_encoder import MldTextEncoder
 dev = "cuda:0"
 B = 128

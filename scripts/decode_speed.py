@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from ladiff_amd import LADiffVae, _lib, synthetic as syn
+if os.environ.get("LADIFF_LIB"):                      # an experiment build of the library (same ABI)
+    _lib.LIB_PATH = os.path.join(ROOT, os.environ["LADIFF_LIB"])
 from test_abi import ABL, VAE_KW
 dev = "cuda:0"
 vae = LADiffVae(ABL, **VAE_KW); vae.load_state_dict(syn.vae_weights(263)); vae = vae.to(dev).eval()

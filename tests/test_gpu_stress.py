@@ -58,3 +58,19 @@ def test_old_graph_execs_replay_correctly_without_the_epoch_rule():
         # ... and it really came from plan A's OLD execs: the last call instantiated nothing (the Python loop owner draws a fresh noise
         # seed per call; a generator that is off must not be part of the graph key - ADVICE r4)
         assert lines[3][-1] == lines[2][-1], lines
+
+
+def test_two_decodes_on_two_streams_are_the_decodes_alone():
+    """include/ladiff_hip.h: calls are re-entrant across distinct (workspace, stream) pairs.  Two decodes of 64 x 196 frames launched back
+    to back on two streams, 400 times, default fusion and every fusion off: each pair must give the bits the two calls give one after
+    another.  With the GEMM's counted `vmcnt` waits of rounds 1 - 4 (two LDS-DMA stages in flight) 1 - 2 % of such pairs had a wrong
+    128-row tile in the first-launched decode (csrc/gemm_big.hip header); the second kernel's traffic is what makes LDS-DMA requests
+    complete out of issue order."""
+    out = _run("decode_reentrancy.py", 400, 1, 80)
+    assert out.count("concurrent True: 0 of 400 runs differ") == 2, out
+
+
+def test_decode_writes_only_inside_its_workspace_and_output():
+    """Workspace and output inside larger canary-filled buffers (64 MB of guard words on each side), four batch shapes, both modes."""
+    out = _run("decode_guard.py")
+    assert "guard zones touched: 0" in out
