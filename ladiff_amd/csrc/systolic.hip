@@ -268,6 +268,25 @@ __device__ __forceinline__ unsigned ring_use_par(const SysArgs& p, int s, int b)
 // hand-off with write-through / plain stores - there the form is a compile-time property of the role's loop, so that the loop
 // body is straight-line code and the compiler can COUNT the stores behind the next block's loads (`s_waitcnt vmcnt(n)`) instead of
 // draining them (`vmcnt(0)`) where those loads are first used.
+// Which roles run their products transposed (tile_mma.h, mma<..., TR>): compile-time switches so that a variant build can measure each
+// (scripts/build_variant.sh <name> -DLADIFF_TR_OUT=0 ...); same bits either way
+#ifndef LADIFF_TR_OUT
+#define LADIFF_TR_OUT 1
+#endif
+#ifndef LADIFF_TR_STYL
+#define LADIFF_TR_STYL 1
+#endif
+#ifndef LADIFF_TR_SKIP
+#define LADIFF_TR_SKIP 1
+#endif
+#ifndef LADIFF_TR_QKV
+#define LADIFF_TR_QKV 1
+#endif
+template <bool TR, int MR, int NT, class ColOf>
+__device__ __forceinline__ void stage_c_sel(float* ct, const f32x4 (&acc)[MR][NT], ColOf col_of) {
+    if constexpr (TR) stage_c_t(ct, acc, col_of); else stage_c(ct, acc, col_of);
+}
+
 template <int HO>
 __device__ __forceinline__ void st_out(const Stage& st, __amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v, unsigned par) {
     v = tag4(v, par);
@@ -695,7 +714,7 @@ struct QkvRole {
     const SysArgs& p; const Stage& st;
     char* atile; float *qt, *xt; int* gd;
     WFrag<AR, NTW, 8> wf;
-    float bcol[NTW];
+    f32x4 bcol[NTW];                                                     // in_proj bias at this lane's four columns of tile j (the projection runs transposed)
     __amdgpu_buffer_rsrc_t rin, rout, rtab, rtkv;
     const float* tkv;
     int h, T, nkeys, nvt;                                                // nvt: column tiles this wave really has
@@ -717,7 +736,10 @@ struct QkvRole {
         // tile column tc (+ frow): part tc / 64 (q, k, v), matrix row part * 256 + h * 64 + tc % 64
         load_w(wf, st.w0, D, 0, [&](int j) { const int tc = tile_col(j); return (tc >> 6) * 256 + h * 64 + (tc & 63); });
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) { const int tc = tile_col(j) + frow; bcol[j] = st.b0[(tc >> 6) * 256 + h * 64 + (tc & 63)]; }
+        for (int j = 0; j < NTW; ++j) {
+            if constexpr (LADIFF_TR_QKV) { const int tc = tile_col(j) + 4 * (lane >> 4); bcol[j] = ld4(st.b0 + (tc >> 6) * 256 + h * 64 + (tc & 63)); }
+            else { const int tc = tile_col(j) + frow; const float bb = st.b0[(tc >> 6) * 256 + h * 64 + (tc & 63)]; bcol[j] = f32x4{bb, bb, bb, bb}; }
+        }
         landed();
         rin = rsrc_of(st.in0); rout = rsrc_of(st.out);
         tkv = p.tkv + (size_t)st.layer * p.B2 * 512;
@@ -775,29 +797,35 @@ struct QkvRole {
                 for (int j = 0; j < NTW; ++j)
 #pragma unroll
                     for (int q = 0; q < 2; ++q) { hw.hi[j][q] = wf.hi[j][q]; hw.lo[j][q] = wf.lo[j][q]; }
-                mma<0, 4, NTW, 2, MR>(atile, hw, acc);
+                mma<0, 4, NTW, 2, MR, NTW, 1, LADIFF_TR_QKV>(atile, hw, acc);
             }
         }
         if (probe) {} else
 #endif
         if (nvt == NTW) {
-            mma<AR, 4, NTW, 8, MR, NTW, (MR == 1 && WS == 2 ? PF2 : 1)>(atile, wf, acc);
+            mma<AR, 4, NTW, 8, MR, NTW, (MR == 1 && WS == 2 ? PF2 : 1), LADIFF_TR_QKV>(atile, wf, acc);
         } else {                                                         // the SIMD's second wave: one tile (the fragment set's first)
             f32x4 a1[MR][1];
             zero_acc(a1);
-            mma<AR, 4, 1, 8, MR, NTW, (MR == 1 ? PF1 : 1)>(atile, wf, a1);
+            mma<AR, 4, 1, 8, MR, NTW, (MR == 1 ? PF1 : 1), LADIFF_TR_QKV>(atile, wf, a1);
 #pragma unroll
             for (int i = 0; i < MR; ++i) acc[i][0] = a1[i][0];
         }
+        // (transposed products: a lane holds columns tile_col(j) + 4 (lane >> 4) .. + 3 of row frow - one 16-byte write per tile)
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 if (j < nvt) {
-                    const int tc = tile_col(j) + frow;
-                    const float scl = tc < 64 ? 0.125f : 1.f;           // q / sqrt(64), exact
+                    const float scl = tile_col(j) < 64 ? 0.125f : 1.f;  // q / sqrt(64), exact (a tile is all q or all k | v)
+                    f32x4 v;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) qt[(16 * i + 4 * (lane >> 4) + r) * QLD + tc] = (acc[i][j][r] + bcol[j]) * scl;
+                    for (int r = 0; r < 4; ++r) v[r] = (acc[i][j][r] + bcol[j][r]) * scl;
+                    if constexpr (LADIFF_TR_QKV) *reinterpret_cast<f32x4*>(qt + (16 * i + frow) * QLD + tile_col(j) + 4 * (lane >> 4)) = v;
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) qt[(16 * i + 4 * (lane >> 4) + r) * QLD + tile_col(j) + frow] = v[r];
+                    }
                 }
             }
     }
@@ -1073,9 +1101,9 @@ struct OutRole {
         const unsigned par = HO ? (unsigned)(s & 1) : 0u;
         f32x4 acc[MR][NTW];
         zero_acc(acc);
-        mma<AR, 4, NTW, 8, MR, NTW, (MR == 1 && WS == 2 ? PF2 : 1)>(atile, wf, acc);
+        mma<AR, 4, NTW, 8, MR, NTW, (MR == 1 && WS == 2 ? PF2 : 1), LADIFF_TR_OUT>(atile, wf, acc);
         SYS_STAMP(3);
-        stage_c(ct, acc, [&](int j) { return 16 * NTW * wave + 16 * j; });
+        stage_c_sel<LADIFF_TR_OUT>(ct, acc, [&](int j) { return 16 * NTW * wave + 16 * j; });
         mid.before_barrier();
         __syncthreads();
         mid.after_barrier();
@@ -1182,13 +1210,13 @@ struct OutRole {
                         for (int j = 0; j < NTW; ++j)
 #pragma unroll
                             for (int q = 0; q < 2; ++q) { hw.hi[j][q] = wf.hi[j][q]; hw.lo[j][q] = wf.lo[j][q]; }
-                        mma<0, 4, NTW, 2, MR>(atile, hw, acc);
+                        mma<0, 4, NTW, 2, MR, NTW, 1, LADIFF_TR_OUT>(atile, hw, acc);
                     }
                 }
                 if (!probe)
 #endif
-                mma<AR, 4, NTW, 8, MR, NTW, PF2>(atile, wf, acc);
-                stage_c(ct, acc, [&](int j) { return 16 * NTW * wave + 16 * j; });
+                mma<AR, 4, NTW, 8, MR, NTW, PF2, LADIFF_TR_OUT>(atile, wf, acc);
+                stage_c_sel<LADIFF_TR_OUT>(ct, acc, [&](int j) { return 16 * NTW * wave + 16 * j; });
                 lds_barrier();
                 SYS_STAMP(3);
                 if (!loader) {
@@ -1259,11 +1287,11 @@ struct MlpRole {
     char *atile, *htile; float* ct;
     WFrag<AR, NT1, 8> w1;
     WFrag<AR, NT2, 4> w2;
-    float b1[NT1];
+    f32x4 b1[NT1];                                                       // linear1's bias at this lane's four hidden columns of tile j (the products run transposed)
     __amdgpu_buffer_rsrc_t rin, rout;
     unsigned plane;
     __device__ __forceinline__ MlpRole(const SysArgs& p_, const Stage& st_, char* lds) : p(p_), st(st_) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, frow = lane & 15;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fk = lane >> 4;
         atile = lds;                                                     // [RT] x K=256
         htile = lds + tile_bytes<AR, 4>(RT);                             // [RT] x K=128 (hidden slice, operand format)
         ct = reinterpret_cast<float*>(lds + tile_bytes<AR, 4>(RT) + tile_bytes<AR, 2>(RT));
@@ -1271,7 +1299,7 @@ struct MlpRole {
         load_w(w1, st.w0, D, 0, [&](int j) { return j0 + 16 * NT1 * wave + 16 * j; });
         load_w(w2, st.w1, FF, 2 * st.slice, [&](int j) { return 16 * NT2 * wave + 16 * j; });
 #pragma unroll
-        for (int j = 0; j < NT1; ++j) b1[j] = st.b0[j0 + 16 * NT1 * wave + 16 * j + frow];
+        for (int j = 0; j < NT1; ++j) b1[j] = ld4(st.b0 + j0 + 16 * NT1 * wave + 16 * j + 4 * fk);
         landed();
         rin = rsrc_of(st.in0); rout = rsrc_of(st.out);
         plane = (unsigned)st.slice * PRING * RT * 1024;
@@ -1342,49 +1370,39 @@ struct MlpRole {
                 for (int j = 0; j < NT1; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { h1.hi[j][q] = w1.hi[j][q]; h1.lo[j][q] = w1.lo[j][q]; }
-                mma<0, 4, NT1, 4, MR>(atile, h1, acc1);
+                mma<0, 4, NT1, 4, MR, NT1, 1, true>(atile, h1, acc1);
             }
         }
         if (!probe)
 #endif
-        mma<AR, 4, NT1, 8, MR, NT1, (NT1 == 1 && MR == 1 ? PF1 : 1)>(atile, w1, acc1);
+        mma<AR, 4, NT1, 8, MR, NT1, (NT1 == 1 && MR == 1 ? PF1 : 1), true>(atile, w1, acc1);
         SYS_STAMP(3);
-        // hidden slice -> S-format operand tile (k = hidden column within the slice)
+        // hidden slice -> S-format operand tile (k = hidden column within the slice).  The product ran transposed: a lane holds the four
+        // consecutive hidden columns 4 fk .. + 3 of tile row frow - one 8-byte write per plane (round 4: eight 2-byte writes)
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
             for (int j = 0; j < NT1; ++j) {
-                const int k = 16 * NT1 * wave + 16 * j + frow;           // 0..127
-                if constexpr (ACT == ACT_GELU) {
-                    // GELU of the lane's four values as two packed pairs (gelu_erf2: the bits of gelu_erf)
-#ifdef LADIFF_STAMPS
-                    if (probe) {
+                const int k0 = 16 * NT1 * wave + 16 * j + 4 * fk;        // 0..124
+                f32x4 h;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) tile_put1<AR, 2>(htile, 16 * i + 4 * fk + r, k, acc1[i][j][r] + b1[j]);
-                    } else
-#endif
-                    {
-#ifdef LADIFF_PROBE_FFN_NOGELU         // variant build (garbage results): FFN without its activation
-                        const f32x2 g01 = f32x2{acc1[i][j][0] + b1[j], acc1[i][j][1] + b1[j]};
-                        const f32x2 g23 = f32x2{acc1[i][j][2] + b1[j], acc1[i][j][3] + b1[j]};
-#else
-                        const f32x2 g01 = gelu_erf2(f32x2{acc1[i][j][0] + b1[j], acc1[i][j][1] + b1[j]});
-                        const f32x2 g23 = gelu_erf2(f32x2{acc1[i][j][2] + b1[j], acc1[i][j][3] + b1[j]});
-#endif
-                        tile_put1<AR, 2>(htile, 16 * i + 4 * fk + 0, k, g01[0]); tile_put1<AR, 2>(htile, 16 * i + 4 * fk + 1, k, g01[1]);
-                        tile_put1<AR, 2>(htile, 16 * i + 4 * fk + 2, k, g23[0]); tile_put1<AR, 2>(htile, 16 * i + 4 * fk + 3, k, g23[1]);
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 16 * i + 4 * fk + r;
+                for (int r = 0; r < 4; ++r) h[r] = acc1[i][j][r] + b1[j][r];
 #ifdef LADIFF_STAMPS
-                        if (probe) tile_put1<AR, 2>(htile, row, k, acc1[i][j][r] + b1[j]);
-                        else
+                if (!probe)
 #endif
-                        tile_put1<AR, 2>(htile, row, k, act_c<ACT>(acc1[i][j][r] + b1[j]));
+                {
+                    if constexpr (ACT == ACT_GELU) {
+#ifndef LADIFF_PROBE_FFN_NOGELU             // (defined: variant build, garbage results - FFN without its activation)
+                        // GELU of the lane's four values as two packed pairs (gelu_erf2: the bits of gelu_erf)
+                        const f32x2 g01 = gelu_erf2(f32x2{h[0], h[1]}), g23 = gelu_erf2(f32x2{h[2], h[3]});
+                        h = f32x4{g01[0], g01[1], g23[0], g23[1]};
+#endif
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h[r] = act_c<ACT>(h[r]);
                     }
                 }
+                tile_put4<AR, 2>(htile, 16 * i + frow, k0, h);
             }
         SYS_STAMP(6);
         mid.before_barrier();
@@ -1401,13 +1419,13 @@ struct MlpRole {
                 for (int j = 0; j < NT2; ++j)
 #pragma unroll
                     for (int q = 0; q < 2; ++q) { h2.hi[j][q] = w2.hi[j][q]; h2.lo[j][q] = w2.lo[j][q]; }
-                mma<0, 2, NT2, 2, MR>(htile, h2, acc2);
+                mma<0, 2, NT2, 2, MR, NT2, 1, true>(htile, h2, acc2);
             }
         }
         if (!probe)
 #endif
-        mma<AR, 2, NT2, 4, MR, NT2, (MR == 1 && WS == 2 ? PF2 : 1)>(htile, w2, acc2);
-        stage_c(ct, acc2, [&](int j) { return 16 * NT2 * wave + 16 * j; });
+        mma<AR, 2, NT2, 4, MR, NT2, (MR == 1 && WS == 2 ? PF2 : 1), true>(htile, w2, acc2);
+        stage_c_t(ct, acc2, [&](int j) { return 16 * NT2 * wave + 16 * j; });
         mid.before_stores();
         // each wave stores the columns it staged itself (64 or 32 of them: 256 / 128 B per row, 4 / 8 rows per instruction): no
         // barrier - LDS serves a wave's accesses in order, and the next block's hidden tile is only written behind the stage loop's
@@ -1669,13 +1687,13 @@ struct StylRole {
                 for (int j = 0; j < NTW; ++j)
 #pragma unroll
                     for (int q = 0; q < 2; ++q) { hw.hi[j][q] = wf.hi[j][q]; hw.lo[j][q] = wf.lo[j][q]; }
-                mma<0, 4, NTW, 2, 1>(atile, hw, acc);
+                mma<0, 4, NTW, 2, 1, NTW, 1, LADIFF_TR_STYL>(atile, hw, acc);
             }
         }
         if (!probe)
 #endif
-        mma<AR, 4, NTW, 8, 1, NTW, (WS == 2 ? PF2 : 1)>(atile, wf, acc);
-        stage_c(ct, acc, [&](int j) { return 16 * NTW * wave + 16 * j; });
+        mma<AR, 4, NTW, 8, 1, NTW, (WS == 2 ? PF2 : 1), LADIFF_TR_STYL>(atile, wf, acc);
+        stage_c_sel<LADIFF_TR_STYL>(ct, acc, [&](int j) { return 16 * NTW * wave + 16 * j; });
         __syncthreads();
         SYS_STAMP(7);
 #pragma unroll
@@ -1741,8 +1759,8 @@ struct SkipRole {
         const unsigned par = HO ? (unsigned)(s & 1) : 0u;
         f32x4 acc[MR][NTW];
         zero_acc(acc);
-        mma<AR, 8, NTW, 16, MR, NTW, (MR == 1 && WS == 2 ? PF2 : 1)>(atile, wf, acc);
-        stage_c(ct, acc, [&](int j) { return n0 + 16 * NTW * wave + 16 * j; });
+        mma<AR, 8, NTW, 16, MR, NTW, (MR == 1 && WS == 2 ? PF2 : 1), LADIFF_TR_SKIP>(atile, wf, acc);
+        stage_c_sel<LADIFF_TR_SKIP>(ct, acc, [&](int j) { return n0 + 16 * NTW * wave + 16 * j; });
         mid.before_barrier();
         __syncthreads();
         mid.after_barrier();

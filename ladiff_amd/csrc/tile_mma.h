@@ -116,7 +116,11 @@ __device__ __forceinline__ void lds_wait(u32x4_t& a) { asm volatile("s_waitcnt l
 // PF = how many k-steps the fragment fetches run ahead (bf16x3 tiles): a step of ONE column tile is 3 MFMAs = 48 cycles of the SIMD's
 // matrix pipe (96 with the SIMD's second wave in the same phase) - less than an LDS read takes when all eight waves fetch at once, so
 // with PF = 1 every step of such a product waits for its fragments; PF = 2 keeps two steps in flight (8 more registers per row tile).
-template <int AR, int KB, int NT, int KS, int MR, int NTF = NT, int PF = 1>
+// TR: the product TRANSPOSED, D^T = W . A^T (the weight fragment as the MFMA's first operand): the same products summed in the same
+// order - the same bits - but the accumulator of lane (l & 15, l >> 4) then holds FOUR CONSECUTIVE COLUMNS 4 (l >> 4) .. + 3 of tile
+// row l & 15 instead of one column of four rows: what follows (an operand tile, the fp32 staging tile) is written 8 / 16 bytes at a
+// time instead of 2 / 4 (tile_put4 / stage_c_t against tile_put1 / stage_c).
+template <int AR, int KB, int NT, int KS, int MR, int NTF = NT, int PF = 1, bool TR = false>
 __device__ __forceinline__ void mma(const char* tile, const WFrag<AR, NTF, KS>& f, f32x4 (&acc)[MR][NT]) {
     const int lane = threadIdx.x & 63, frow = lane & 15, fk = lane >> 4;
     if constexpr (AR == 0) {
@@ -148,21 +152,22 @@ __device__ __forceinline__ void mma(const char* tile, const WFrag<AR, NTF, KS>& 
             __builtin_amdgcn_sched_barrier(0);
             // the three products of a split operand pair go to the same accumulator: one product at a time over all MR x NT
             // accumulators, so that consecutive MFMAs never depend on each other
+            auto mm = [&](const bf16x8 a, const bf16x8 w, const f32x4 c) __attribute__((always_inline)) {
+                if constexpr (TR) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, c, 0, 0, 0);
+                else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w, c, 0, 0, 0);
+            };
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[cur][i]), f.hi[j][s], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[i][j] = mm(__builtin_bit_cast(bf16x8, al[cur][i]), f.hi[j][s], acc[i][j]);
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[cur][i]), f.lo[j][s], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[i][j] = mm(__builtin_bit_cast(bf16x8, ah[cur][i]), f.lo[j][s], acc[i][j]);
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[cur][i]), f.hi[j][s], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[i][j] = mm(__builtin_bit_cast(bf16x8, ah[cur][i]), f.hi[j][s], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
         });
     } else {
@@ -184,8 +189,10 @@ __device__ __forceinline__ void mma(const char* tile, const WFrag<AR, NTF, KS>& 
 #pragma unroll
                 for (int i = 0; i < MR; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(f32x4, a[cur][i])[e], f.w[j][4 * g + e], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j) {
+                        if constexpr (TR) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[j][4 * g + e], __builtin_bit_cast(f32x4, a[cur][i])[e], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(f32x4, a[cur][i])[e], f.w[j][4 * g + e], acc[i][j], 0, 0, 0);
+                    }
             __builtin_amdgcn_sched_barrier(0);
         });
     }
@@ -209,6 +216,17 @@ __device__ __forceinline__ void stage_c(float* ct, const f32x4 (&acc)[MR][NT], C
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ct[(16 * i + 4 * fk + r) * CLD + col_of(j) + frow] = acc[i][j][r];
+}
+
+// the same for the accumulators of a TRANSPOSED product (mma<..., TR = true>): lane (frow, fk) holds columns col_of(j) + 4 fk .. + 3 of
+// row 16 i + frow - one 16-byte write per tile instead of four 4-byte ones
+template <int MR, int NT, class ColOf>
+__device__ __forceinline__ void stage_c_t(float* ct, const f32x4 (&acc)[MR][NT], ColOf col_of) {
+    const int lane = threadIdx.x & 63, frow = lane & 15, fk = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(ct + (16 * i + frow) * CLD + col_of(j) + 4 * fk) = acc[i][j];
 }
 
 }  // namespace
