@@ -74,3 +74,11 @@ def test_decode_writes_only_inside_its_workspace_and_output():
     """Workspace and output inside larger canary-filled buffers (64 MB of guard words on each side), four batch shapes, both modes."""
     out = _run("decode_guard.py")
     assert "guard zones touched: 0" in out
+
+
+def test_launch_path_and_small_decode_on_two_streams():
+    """The launch-per-stage loop (gemm_kr / gemm_kp / gemm_rowln / qkv_attn: LDS-DMA of activations and weights) on two streams at once,
+    beside a large decode, and the 8 x 60 decode on two streams: the bits of the same calls one after another, both arithmetic modes.
+    (These kernels were never SEEN wrong with their counted waits - profiles/r5/19_* - they got the exact ones on principle)"""
+    out = _run("launch_path_reentrancy.py", 40, 3)
+    assert out.count("concurrent True: 0 of 40 runs differ") == 6, out
