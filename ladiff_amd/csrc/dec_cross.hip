@@ -20,46 +20,81 @@ namespace {
 constexpr int TM = LADIFF_MAX_LATENTS;
 }
 
-// One workgroup per (group of `spw` samples, head, layer): G | U rows [T][2][256] of that head and the score offsets c [T] from each
-// sample's K|V rows.  Thread n = output column n keeps its 64 Wq values and its 64 Wo values of the head in REGISTERS for all the
-// group's samples; a sample's K | V values are the same for every thread, so they are read with uniform addresses (scalar loads
-// into SGPRs, an FMA takes one as an operand) - no LDS, no barrier.  Before: one workgroup per sample re-read the head's 128 KB of
-// weights for five rows of output (590 MB per decode) and broadcast every K | V value to its 256 threads through the LDS, which
-// was the bound (137 us per decode; profiles/r4).
-__global__ __launch_bounds__(256) void dec_cross_prep_kernel(const DecCrossPrepBatch pb, int B, int T, int spw) {
-    const int b0 = blockIdx.x * spw, h = blockIdx.y, n = threadIdx.x, layer = blockIdx.z;
+// G | U | c of a (layer, head) are three small matrix products over the memory rows (bt = j B + b: kv is [T][B][512]) with K = 64:
+//   G^T [bt, n] = K_h [bt, d] Wq_h [d, n] / 8,     U^T [bt, n] = V_h [bt, d] Wo_h [n, d],     c [bt] = K_h [bt, d] bq_h [d] / 8
+// on the fp32 MFMA (`v_mfma_f32_16x16x4_f32`: exact fp32 products, fp32 accumulate).  One workgroup per (group of 16-row tiles of bt,
+// head, layer); wave w owns output columns 64 w .. 64 w + 63 and keeps its slice of Wq_h and Wo_h (64 + 64 values per lane) as B
+// fragments in REGISTERS for all its tiles; a tile's K_h / V_h rows are A fragments loaded straight from memory.  The contraction
+// index d is dealt to the MFMA's (k-step s, k-phase kq) as d = 16 kq + s - any bijection does, A and B share it - so a lane's 16
+// values per row are 64 contiguous bytes.  Before (rounds 3 - 4): one thread per output column with the K | V values as scalar
+// loads into SGPRs, bound by their latency: 68 us per decode at 128 x 5 memory rows; this form 33 - 40 us (rocprofv3), 8 x 2 rows: the
+// decode of config c1 0.556 -> 0.50 ms.
+__global__ __launch_bounds__(256) void dec_cross_prep_kernel(const DecCrossPrepBatch pb, int B, int T, int tiles_per_wg) {
+    const int h = blockIdx.y, layer = blockIdx.z, tid = threadIdx.x, lane = tid & 63, c16 = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* __restrict__ kv = pb.kv[layer]; const float* __restrict__ wq = pb.wq[layer]; const float* __restrict__ bq = pb.bq[layer];
     const float* __restrict__ wo = pb.wo[layer]; float* __restrict__ gu = pb.gu[layer];
     float* __restrict__ cc = gu + (size_t)B * H * T * 2 * D;
-    float qv[DH], wv[DH];                                                          // Wq[h*64 + d][n] (coalesced over n), Wo[n][h*64 + d]
+    const int M = T * B, ntiles = (M + 15) / 16;
+    float gq[4][16], uo[4][16], bqv[16];                                           // [column tile][k-step]: Wq[h 64 + 16 kq + s][n], Wo[n][h 64 + 16 kq + s]
 #pragma unroll
-    for (int d = 0; d < DH; ++d) qv[d] = wq[(size_t)(h * DH + d) * D + n];
+    for (int t = 0; t < 4; ++t) {
+        const int n = 64 * wave + 16 * t + c16;
 #pragma unroll
-    for (int d4 = 0; d4 < DH; d4 += 4) {
-        const f32x4 w4 = ld4(wo + (size_t)n * D + h * DH + d4);
+        for (int s = 0; s < 16; ++s) gq[t][s] = wq[(size_t)(h * DH + 16 * kq + s) * D + n];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) wv[d4 + e] = w4[e];
+        for (int s4 = 0; s4 < 16; s4 += 4) {
+            const f32x4 w4 = ld4(wo + (size_t)n * D + h * DH + 16 * kq + s4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) uo[t][s4 + e] = w4[e];
+        }
     }
-    const int nb = B - b0 < spw ? B - b0 : spw;
-    const int wvi = __builtin_amdgcn_readfirstlane(n >> 6), ln = n & 63;
-    for (int s = 0; s < nb; ++s) {
-        const int b = b0 + s;
-        for (int j = 0; j < T; ++j) {
-            // uniform addresses in the constant address space: scalar loads (the rows were written by an earlier launch)
-            typedef __attribute__((address_space(4))) const float cfloat;
-            cfloat* kr = (cfloat*)(kv + ((size_t)j * B + b) * 2 * D + h * DH);
-            cfloat* vr = kr + D;
-            float g = 0.f, u = 0.f;
 #pragma unroll
-            for (int d = 0; d < DH; ++d) { g = fmaf(qv[d], kr[d], g); u = fmaf(wv[d], vr[d], u); }
-            float* o = gu + ((((size_t)b * H + h) * T + j) * 2) * D;
-            o[n] = g * 0.125f;                                                     // 1 / sqrt(64), exact
-            o[D + n] = u;
-            // c[h][j] = bq_h . k[b,j,h] / 8: one wave sums its 64 products
-            if (wvi == (j & 3)) {
-                const float c = wave_sum(bq[h * DH + ln] * kv[((size_t)j * B + b) * 2 * D + h * DH + ln]);
-                if (ln == 0) cc[((size_t)b * H + h) * T + j] = c * 0.125f;
+    for (int s4 = 0; s4 < 16; s4 += 4) {
+        const f32x4 b4 = ld4(bq + h * DH + 16 * kq + s4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bqv[s4 + e] = b4[e];
+    }
+    const int tile1 = (blockIdx.x + 1) * tiles_per_wg < ntiles ? (blockIdx.x + 1) * tiles_per_wg : ntiles;
+    for (int tile = blockIdx.x * tiles_per_wg; tile < tile1; ++tile) {
+        const int arow = 16 * tile + c16 < M ? 16 * tile + c16 : M - 1;            // this lane's A row (clamped: rows >= M are not stored)
+        const float* kr = kv + (size_t)arow * 2 * D + h * DH + 16 * kq;
+        float ak[16], av[16];
+#pragma unroll
+        for (int s4 = 0; s4 < 16; s4 += 4) {
+            const f32x4 k4 = ld4(kr + s4), v4 = ld4(kr + D + s4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ak[s4 + e] = k4[e]; av[s4 + e] = v4[e]; }
+        }
+        f32x4 ag[4], au[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { ag[t] = f32x4{0.f, 0.f, 0.f, 0.f}; au[t] = ag[t]; }
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                ag[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ak[s], gq[t][s], ag[t], 0, 0, 0);
+                au[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], uo[t][s], au[t], 0, 0, 0);
             }
+        // accumulator of lane (c16, kq): column 64 wave + 16 t + c16 of rows 16 tile + 4 kq + i
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int bt = 16 * tile + 4 * kq + i;
+            if (bt < M) {
+                const int j = bt / B, b = bt - j * B;
+                float* o = gu + ((((size_t)b * H + h) * T + j) * 2) * D + 64 * wave + c16;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { o[16 * t] = ag[t][i] * 0.125f; o[D + 16 * t] = au[t][i]; }      // 1 / sqrt(64), exact
+            }
+        }
+        // c[h][j] = bq_h . k[b,j,h] / 8 (wave 0: every wave holds the same K fragments)
+        if (wave == 0) {
+            float c = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) c = fmaf(bqv[s], ak[s], c);
+            c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);                 // the row's four k-phases
+            const int bt = 16 * tile + c16;
+            if (kq == 0 && bt < M) { const int j = bt / B, b = bt - j * B; cc[((size_t)b * H + h) * T + j] = c * 0.125f; }
         }
     }
 }
@@ -552,10 +587,12 @@ int dec_cross_prepare() {
 int launch_decoder_cross_prep(const DecCrossPrepBatch& pb, int n, int B, int T, hipStream_t s) {
     if (B == 0 || n == 0) return 0;
     if (T < 1 || T > TM || n > DEC_PREP_MAX) return LADIFF_ERR_SHAPE;
-    // samples per workgroup: enough workgroups to fill the chip first (each walks its samples' T rows one scalar-load latency at a time),
-    // then as many samples as possible behind one read of the head's 128 KB of weights
-    const int spw = B * H * n >= 8 * 512 ? 8 : (B * H * n >= 2 * 512 ? 2 : 1);
-    hipLaunchKernelGGL(dec_cross_prep_kernel, dim3((B + spw - 1) / spw, H, n), dim3(256), 0, s, pb, B, T, spw);
+    // 16-row tiles of the T B memory rows per workgroup: enough workgroups to cover the chip, then as many tiles as possible behind one
+    // read of the head's 128 KB of weights
+    const int ntiles = (T * B + 15) / 16;
+    int tpw = 1;
+    while (tpw < 8 && (ntiles + 2 * tpw - 1) / (2 * tpw) * H * n >= 160) tpw *= 2;      // (1, 2, 4, 8 tiles: 33 - 40 us at 128 x 5 rows, no trend)
+    hipLaunchKernelGGL(dec_cross_prep_kernel, dim3((ntiles + tpw - 1) / tpw, H, n), dim3(256), 0, s, pb, B, T, tpw);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }

@@ -5,6 +5,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from ladiff_amd import LADiffVae, _lib, synthetic as syn
 from test_abi import ABL, VAE_KW
+if os.environ.get("LADIFF_LIB"):                      # an experiment build of the library (same ABI)
+    _lib.LIB_PATH = os.path.join(ROOT, os.environ["LADIFF_LIB"])
 dev = "cuda:0"
 vae = LADiffVae(ABL, **VAE_KW); vae.load_state_dict(syn.vae_weights(263)); vae = vae.to(dev).eval()
 vae.precision = "bf16x3"
