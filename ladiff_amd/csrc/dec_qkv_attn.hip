@@ -42,7 +42,9 @@ constexpr int QA_STAGE = 16384;                    // 8 k-steps x (hi, lo) x 32 
 constexpr int QA_NSTAGE = 12;                      // (q0 q1 k0 k1 v0 v1) x two k halves
 constexpr int QA_K_BYTES = 2 * QA_FMAX * DH * 2;
 constexpr int QA_V_BYTES = 2 * DH * QA_VLD * 2;
-constexpr int QA_LDS = QA_K_BYTES + QA_V_BYTES + 2 * QA_STAGE + 3 * DH * 4;
+constexpr int QA_LDS_BASE = QA_K_BYTES + QA_V_BYTES + 2 * QA_STAGE + 3 * DH * 4;      // images, ring, bias table
+constexpr int QA_LDS = QA_LDS_BASE + 3 * 4096;                                     // + the x-row scratch of waves 4 - 6 (see the kernel)
+static_assert(QA_LDS <= 160 * 1024 && QA_K_BYTES - 3 * QA_STAGE >= 8192 && QA_V_BYTES - 3 * QA_STAGE >= 8192, "scratch areas");
 
 struct QkvAttnArgs {
     const float* xs;           // [M, 256] S-format rows
@@ -74,6 +76,13 @@ __device__ __forceinline__ void frag_read(u32x4_q& v, unsigned addr) {
     if constexpr (OFF < 65536) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
     else if constexpr (OFF < 2 * 65536) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr + 65536u), "n"(OFF - 65536) : "memory");
     else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr + 131072u), "n"(OFF - 131072) : "memory");
+}
+
+__device__ __forceinline__ void lds_put16(unsigned addr, const u32x4_q& v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void wait_vm4(u32x4_q& a, u32x4_q& b, u32x4_q& c, u32x4_q& d) { asm volatile("s_waitcnt vmcnt(4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+__device__ __forceinline__ void wait_vm0(u32x4_q& a, u32x4_q& b, u32x4_q& c, u32x4_q& d) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+__device__ __forceinline__ void wait_lgkm0(u32x4_q& a, u32x4_q& b, u32x4_q& c, u32x4_q& d, u32x4_q& e, u32x4_q& f, u32x4_q& g, u32x4_q& h) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
 }
 
 // two 8-byte reads (offsets OFF8 and OFF8 + 2, in units of 8 bytes) into one register quad
@@ -156,21 +165,68 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
     const unsigned lds_lane = lds_addr(lds) + lane * 16;
     if constexpr (DIAG != 4) static_for<8>([&](auto gc) { issue(gc); });
 
-    // ---- x rows as operand fragments: k-step s (16 columns) -> lane (row q, half h2) holds columns 16 s + 8 h2 .. + 7, hi and lo
+    // ---- x rows as operand fragments: k-step s (16 columns) -> lane (row q, half h2) holds columns 16 s + 8 h2 .. + 7, hi and lo.
+    // Round 5: loaded a 128-byte LINE of every row at a time and turned into the fragment layout through a 4-KiB LDS scratch per wave.
+    // A fragment load straight from memory takes 16 bytes per lane from 32 different rows - 32 bytes of a row per instruction, a
+    // quarter of every line it touches (20 of the kernel's 66 us, timing builds of round 3); here one instruction fetches whole lines
+    // (8 rows x 128 B: lane l -> row 8 i + (l >> 3), piece l & 7), writes them to the scratch (row r at 128 r, piece p at slot
+    // p ^ ((r >> 1) & 7)) and four reads per line give lane (q, h2) its pieces 2 e + h2 = k-steps 4 blk + e of that line (hi / lo plane).
+    // The scratch areas are LDS nobody else uses before the stage loop: the 8-KiB tail of the K image (waves 0, 1), 8 KiB of the V
+    // image's tail (2, 3), 12 KiB behind the bias table (4 - 6; wave 7 never has rows: QA_FMAX = 7 x 32).  All LDS traffic is asm
+    // (the compiler would put a `vmcnt(0)` - the weight stages in flight - in front of every plain access), same wave writes and reads.
     bf16x8 xh[16], xl[16];
     {
         const bool live = qrow < F;
-        const char* xr = reinterpret_cast<const char*>(p.xs) + (row0 + (live ? qrow : 0)) * 1024 + h2 * 16;
+        unsigned scr = lds_addr(lds) + (wave < 2 ? 3 * QA_STAGE + wave * 4096
+                                        : wave < 4 ? QA_K_BYTES + 3 * QA_STAGE + (wave - 2) * 4096
+                                                   : QA_LDS_BASE + ((wave - 4) % 3) * 4096);
+        const unsigned wr = scr + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 4) & 3)) << 4);      // + 1024 i: row r = 8 i + (l >> 3), (r >> 1) & 7 = 4 (i & 1) + (l >> 4) - see below
+        const unsigned rd = scr + q * 128;
+        const int sw = (q >> 1) & 7;
+        u32x4_q t[2][4], xq[2][16];                                          // lines in flight; the fragments as the asm reads deliver them (hi, lo)
+        if (!(active && DIAG != 5)) {                                        // (defined registers on the path that skips the loads)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) { xq[0][s] = u32x4_q{0u, 0u, 0u, 0u}; xq[1][s] = xq[0][s]; }
+        }
+        auto fetch_line = [&](int j, int bf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int r = qt * 32 + 8 * i + (lane >> 3);
+                r = r < F ? r : 0;                                           // rows past the sample's frames: any valid row (their fragments are zeroed)
+                t[bf][i] = *reinterpret_cast<const u32x4_q*>(reinterpret_cast<const char*>(p.xs) + (row0 + r) * 1024 + (j >> 1) * 256 + (j & 1) * 128 + (lane & 7) * 16);
+            }
+        };
+        if (active && DIAG != 5) {
+            fetch_line(0, 0);
+            static_for<8>([&](auto jc) {
+                constexpr int j = decltype(jc)::value, bf = j & 1;
+                if constexpr (j + 1 < 8) fetch_line(j + 1, bf ^ 1);
+                // line j has landed: everything but the four loads just issued (the first time: the weight stages requested above as well)
+                if constexpr (j + 1 < 8) wait_vm4(t[bf][0], t[bf][1], t[bf][2], t[bf][3]);
+                else wait_vm0(t[bf][0], t[bf][1], t[bf][2], t[bf][3]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // row r = 8 i + (l >> 3): (r >> 1) & 7 = (4 i + (l >> 4)) & 7 - the lane part is in `wr`, the i part flips slot bit 2
+                    lds_put16((wr + 1024 * i) ^ ((i & 1) ? 64u : 0u), t[bf][i]);
+                }
+                static_for<4>([&](auto ec) {
+                    constexpr int e = decltype(ec)::value, ks = 4 * (j >> 1) + e;
+                    frag_read<0>(xq[j & 1][ks], rd + ((((2 * e) | h2) ^ sw) << 4));
+                });
+            });
+            // the reads have returned (asm reads: the compiler does not know they are in flight - the registers are tied to the wait)
+            static_for<4>([&](auto gc) {
+                constexpr int g4 = 4 * decltype(gc)::value;
+                wait_lgkm0(xq[0][g4], xq[0][g4 + 1], xq[0][g4 + 2], xq[0][g4 + 3], xq[1][g4], xq[1][g4 + 1], xq[1][g4 + 2], xq[1][g4 + 3]);
+            });
+        }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            bf16x8 a, c;
+            if (live && active && DIAG != 5) { xh[s] = __builtin_bit_cast(bf16x8, xq[0][s]); xl[s] = __builtin_bit_cast(bf16x8, xq[1][s]); }
+            else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { a[e] = (__bf16)0.f; c[e] = (__bf16)0.f; }
-            if (live && active && DIAG != 5) {
-                a = *reinterpret_cast<const bf16x8*>(xr + (s >> 2) * 256 + (s & 3) * 32);
-                c = *reinterpret_cast<const bf16x8*>(xr + (s >> 2) * 256 + (s & 3) * 32 + 128);
+                for (int e = 0; e < 8; ++e) { xh[s][e] = (__bf16)0.f; xl[s][e] = (__bf16)0.f; }
             }
-            xh[s] = a; xl[s] = c;
         }
     }
 
