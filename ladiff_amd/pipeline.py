@@ -366,6 +366,18 @@ class LADIFF(nn.Module):
         def enqueue(loop):
             if sampler is not None:
                 _lib.check(L.ladiff_sampler_set_loop(sampler, loop_codes[loop]))
+                # A call whose capture key is new makes the library capture its graphs (hipStreamBeginCapture, thread-local mode).  Under
+                # torch.distributed the process group's watchdog THREAD polls the events of collectives it has not yet seen complete
+                # (hipEventQuery, every ~100 ms); when such a poll fell into a capture the runtime invalidated the capture (error 901)
+                # and failed the poll, which takes the process down (seen once in ~15 bench runs under torchrun: profiles/r5/26_*).
+                # So before a capturing call: let the stream drain and give the watchdog two of its periods to retire finished work.
+                sig = (loop, self.precision, wt.generation, cfg, n_text, n, noise_t is not None and noise_t.data_ptr(), run.cuda_stream,
+                       bool(self.test_efficiency), float(self.guidance_scale), bool(self._window_timing), self._fault)
+                if plan.get("capture_sig") != sig:
+                    plan["capture_sig"] = sig
+                    if torch.distributed.is_available() and torch.distributed.is_initialized():
+                        torch.cuda.synchronize(dev)
+                        time.sleep(0.25)
             _lib.check(L.ladiff_diffusion_reverse(
                 sampler, wt.array,
                 wt.split_array() if self.precision == "bf16x3" else None, wt.generation, _lib.ptr(plan["text"]),
