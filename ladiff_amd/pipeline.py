@@ -125,6 +125,7 @@ class LADIFF(nn.Module):
         self._window_timing = False   # per-window events wanted (window_ms(enable=True)): applied to every sampler, also later ones
         self.noise_first_prompt = 0   # global index of this object's prompt 0 (a rank of a sharded batch sets its offset): keys the device noise
         self.last_noise_seed = None
+        self.capture_guard = True     # pause before a capturing call when a process group is up (see _reverse_one; scripts/capture_vs_watchdog.py switches it off)
         self._fault = (-1, 0)         # fault injection of the abort-path tests: applied to every sampler of THIS object (set_pipeline_fault)
         self._stream = None
         self._plans = {}              # plan key -> persistent buffers + sampler (a few shapes stay cached: chunks, alternating batches)
@@ -375,7 +376,7 @@ class LADIFF(nn.Module):
                        bool(self.test_efficiency), float(self.guidance_scale), bool(self._window_timing), self._fault)
                 if plan.get("capture_sig") != sig:
                     plan["capture_sig"] = sig
-                    if torch.distributed.is_available() and torch.distributed.is_initialized():
+                    if self.capture_guard and torch.distributed.is_available() and torch.distributed.is_initialized():
                         torch.cuda.synchronize(dev)
                         time.sleep(0.25)
             _lib.check(L.ladiff_diffusion_reverse(

@@ -82,3 +82,13 @@ def test_launch_path_and_small_decode_on_two_streams():
     (These kernels were never SEEN wrong with their counted waits - profiles/r5/19_* - they got the exact ones on principle)"""
     out = _run("launch_path_reentrancy.py", 40, 3)
     assert out.count("concurrent True: 0 of 40 runs differ") == 6, out
+
+
+def test_captures_beside_the_process_group_watchdog():
+    """With a process group up (RCCL, world size 1) a collective on the stream and at once a call that captures graphs, 30 times: the loop
+    owner's pause (LADIFF.capture_guard) keeps the watchdog thread's event polls out of the captures.  Without it this dies with
+    probability ~1 within 150 pairs (the watchdog's hipEventQuery of the collective's end event is refused while its stream captures, the
+    capture is invalidated: profiles/r5/26_*)."""
+    script = os.path.join(ROOT, "scripts", "capture_vs_watchdog.py")
+    r = subprocess.run([sys.executable, script, "child", "1", "30"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "child done" in r.stdout, (r.stdout + r.stderr)[-800:]
