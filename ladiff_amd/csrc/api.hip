@@ -100,7 +100,16 @@ struct Sampler {
     uint64_t key_hash = 0, key_gen = 0;
     uint64_t epoch = 0;                   // g_graph_epoch when these graphs were instantiated (see there)
     std::vector<hipGraphExec_t> retired;  // replaced while a launch of them could still be queued: destroyed at the next drain
+    // Graphs are CAPTURED on a stream of the handle's own and replayed on the caller's (round 5).  While a stream captures, a
+    // hipEventQuery of any event that belongs to it is refused and invalidates the capture - and torch.distributed's watchdog thread
+    // polls the end events of synchronous collectives, which run on the caller's CURRENT stream: a capture on that stream died about
+    // once in fifteen bench runs under torchrun (profiles/r5/26_*).  Nobody else holds events of this stream.
+    hipStream_t cap = nullptr;
 };
+static int capture_stream(hipStream_t* cap) {
+    if (*cap == nullptr) LADIFF_HIP(hipStreamCreateWithFlags(cap, hipStreamNonBlocking));
+    return 0;
+}
 
 // Graph replay and the round-3 memory fault.  Seen on ROCm 7.2 / MI355X (scripts/repro_seq.py, scripts/repro_graph.py): the graphs of one
 // sampler, replayed after two OTHER samplers had instantiated theirs and a blocking hipMemcpy had run in between, faulted at a wild
@@ -333,6 +342,7 @@ int ladiff_sampler_destroy(void* sampler) {
     if (sp->ev0) (void)hipEventDestroy(sp->ev0);
     if (sp->ev1) (void)hipEventDestroy(sp->ev1);
     for (hipEvent_t e : sp->wev) (void)hipEventDestroy(e);
+    if (sp->cap) (void)hipStreamDestroy(sp->cap);
     delete sp;
     return 0;
 }
@@ -654,10 +664,12 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
                 if (sp->setup) { sp->retired.push_back(sp->setup); sp->setup = nullptr; }
             }
             hipGraph_t graph = nullptr;
+            LADIFF_TRY(capture_stream(&sp->cap));
+            const hipStream_t cs = sp->cap;      // captured here, replayed on `s` (see Sampler::cap)
             {   // prologue graph
-                LADIFF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-                const int rc0 = prologue(s);
-                const hipError_t e0 = hipStreamEndCapture(s, &graph);
+                LADIFF_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+                const int rc0 = prologue(cs);
+                const hipError_t e0 = hipStreamEndCapture(cs, &graph);
                 if (rc0 != 0) { if (graph) (void)hipGraphDestroy(graph); return rc0; }
                 LADIFF_HIP(e0);
                 const hipError_t i0 = hipGraphInstantiate(&sp->setup, graph, nullptr, nullptr, 0);
@@ -676,14 +688,14 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
                 LADIFF_HIP(hipMemcpyAsync(r.sys, sp->stages.data(), sp->stages.size(), hipMemcpyHostToDevice, s));
                 LADIFF_HIP(hipStreamSynchronize(s));
             } else {
-                LADIFF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                LADIFF_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
                 // several steps per graph launch (the step index lives in device memory): fewer ~9 us replay gaps
                 int unroll = 1;
                 for (int u = 2; u <= 10; ++u) if (r.window % u == 0) unroll = u;
                 sp->unroll = unroll;
                 int rc = 0;
-                for (int u = 0; u < unroll && rc == 0; ++u) rc = one_step(s);
-                const hipError_t ec = hipStreamEndCapture(s, &graph);
+                for (int u = 0; u < unroll && rc == 0; ++u) rc = one_step(cs);
+                const hipError_t ec = hipStreamEndCapture(cs, &graph);
                 if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
                 LADIFF_HIP(ec);
                 const hipError_t ei = hipGraphInstantiate(&sp->exec, graph, nullptr, nullptr, 0);
@@ -853,6 +865,7 @@ int ladiff_vae_decode(const float* const* w, const float* const* w_split, const 
 namespace {
 struct DecodeGraph {
     hipGraphExec_t exec = nullptr;
+    hipStream_t cap = nullptr;            // captured on a stream of its own, replayed on the caller's (Sampler::cap)
     const void* key_ptrs[7] = {nullptr};
     uint64_t epoch = 0;                   // g_graph_epoch at instantiation: replayed only while it is the newest graph of the process
     int key_ints[6] = {0};
@@ -870,6 +883,7 @@ int ladiff_decoder_graph_destroy(void* graph) {
     if (g == nullptr) return 0;
     (void)hipDeviceSynchronize();         // a replay may still be queued
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->cap) (void)hipStreamDestroy(g->cap);
     delete g;
     return 0;
 }
@@ -896,14 +910,16 @@ int ladiff_vae_decode_graphed(void* graph, const float* const* w, const float* c
         LADIFF_TRY(dec_qkv_attn_prepare());
         LADIFF_TRY(dec_cross_prepare());
         hipGraph_t gr = nullptr;
-        LADIFF_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        LADIFF_TRY(capture_stream(&dg->cap));
+        const hipStream_t cs = dg->cap;
+        LADIFF_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
         int rc = 0;
         if (row_off != nullptr) {      // inside the capture: a zero-fill KERNEL, never a memset node (g_graph_epoch)
-            rc = launch_zero_fill(feats, (size_t)B * F * C, s);
+            rc = launch_zero_fill(feats, (size_t)B * F * C, cs);
         }
         if (rc == 0) rc = vae_decode(W, w_split ? &WS : nullptr, z, lengths, counts, row_off, total_rows, B, F, T, C, feats, (float*)ws,
-                                     ws_bytes / sizeof(float), s);
-        const hipError_t ec = hipStreamEndCapture(s, &gr);
+                                     ws_bytes / sizeof(float), cs);
+        const hipError_t ec = hipStreamEndCapture(cs, &gr);
         if (rc != 0) { if (gr) (void)hipGraphDestroy(gr); return rc; }
         LADIFF_HIP(ec);
         const hipError_t ei = hipGraphInstantiate(&dg->exec, gr, nullptr, nullptr, 0);

@@ -285,12 +285,6 @@ class LADiffVae(_HipModule):
         key = (B, F, T, tuple(lengths), tuple(counts), ragged_rows, str(dev), self.precision, bool(self.test_efficiency), run.cuda_stream)
         plan = self._dec_plans.get(key)
         if plan is None:
-            # a capture follows: under torch.distributed let the process group's watchdog thread retire finished work first (its event
-            # polls must not fall into the capture: pipeline.py, _reverse_one)
-            if torch.distributed.is_available() and torch.distributed.is_initialized():
-                import time
-                torch.cuda.synchronize(dev)
-                time.sleep(0.25)
             while len(self._dec_plans) >= 4:
                 old = self._dec_plans.pop(next(iter(self._dec_plans)))
                 _lib.check(L.ladiff_decoder_graph_destroy(old["graph"]))

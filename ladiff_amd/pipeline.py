@@ -125,7 +125,6 @@ class LADIFF(nn.Module):
         self._window_timing = False   # per-window events wanted (window_ms(enable=True)): applied to every sampler, also later ones
         self.noise_first_prompt = 0   # global index of this object's prompt 0 (a rank of a sharded batch sets its offset): keys the device noise
         self.last_noise_seed = None
-        self.capture_guard = True     # pause before a capturing call when a process group is up (see _reverse_one; scripts/capture_vs_watchdog.py switches it off)
         self._fault = (-1, 0)         # fault injection of the abort-path tests: applied to every sampler of THIS object (set_pipeline_fault)
         self._stream = None
         self._plans = {}              # plan key -> persistent buffers + sampler (a few shapes stay cached: chunks, alternating batches)
@@ -367,18 +366,6 @@ class LADIFF(nn.Module):
         def enqueue(loop):
             if sampler is not None:
                 _lib.check(L.ladiff_sampler_set_loop(sampler, loop_codes[loop]))
-                # A call whose capture key is new makes the library capture its graphs (hipStreamBeginCapture, thread-local mode).  Under
-                # torch.distributed the process group's watchdog THREAD polls the events of collectives it has not yet seen complete
-                # (hipEventQuery, every ~100 ms); when such a poll fell into a capture the runtime invalidated the capture (error 901)
-                # and failed the poll, which takes the process down (seen once in ~15 bench runs under torchrun: profiles/r5/26_*).
-                # So before a capturing call: let the stream drain and give the watchdog two of its periods to retire finished work.
-                sig = (loop, self.precision, wt.generation, cfg, n_text, n, noise_t is not None and noise_t.data_ptr(), run.cuda_stream,
-                       bool(self.test_efficiency), float(self.guidance_scale), bool(self._window_timing), self._fault)
-                if plan.get("capture_sig") != sig:
-                    plan["capture_sig"] = sig
-                    if self.capture_guard and torch.distributed.is_available() and torch.distributed.is_initialized():
-                        torch.cuda.synchronize(dev)
-                        time.sleep(0.25)
             _lib.check(L.ladiff_diffusion_reverse(
                 sampler, wt.array,
                 wt.split_array() if self.precision == "bf16x3" else None, wt.generation, _lib.ptr(plan["text"]),
