@@ -15,7 +15,10 @@
  *     *_workspace_bytes query).  The unit kernels, the denoiser / decoder / encoder / CLIP / evaluator entries and
  *     ladiff_diffusion_reverse with sampler == NULL neither allocate, free nor synchronise and are hipGraph-capturable;
  *     calls are re-entrant across distinct (workspace, stream) pairs.  EXCEPTIONS, each stated again at the entry:
- *       ladiff_diffusion_reverse with a sampler  instantiates hipGraphs and creates two events on first use; when its capture
+ *       ladiff_diffusion_reverse with a sampler  instantiates hipGraphs (captured on a stream the handle creates for itself, replayed
+ *                                    on `stream`: a capture on the caller's stream would be invalidated by any other thread's
+ *                                    hipEventQuery of an event of that stream - torch.distributed's watchdog does that) and creates
+ *                                    two events on first use; when its capture
  *                                    key changes it calls hipStreamSynchronize(stream) before destroying the old graphs and after
  *                                    uploading a new stage table; it is NOT capturable itself (it captures); a pipeline launch
  *                                    takes a process-wide mutex and chains through one event per device, so that two pipeline
