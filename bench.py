@@ -115,7 +115,6 @@ import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from ladiff_amd import LADIFF, DDIMScheduler, DDPMScheduler, LADiffDenoiser, LADiffVae, distributed as D, synthetic as syn  # noqa: E402
 
@@ -165,7 +164,7 @@ def executed_flops_per_motion(F=FRAMES, C=NFEATS, n_steps=STEPS_DDIM, T=5):
 
 
 def build_pipe(dev, batch=BATCH, cfg=None):
-    from test_abi import ABL, DEN_KW, VAE_KW
+    from ladiff_amd.schema import ABL, DEN_KW, VAE_KW
     cfg = cfg or CONFIGS["headline"]
     den = LADiffDenoiser(ABL, **DEN_KW)
     den.load_state_dict(syn.denoiser_weights())

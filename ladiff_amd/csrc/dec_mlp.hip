@@ -14,13 +14,15 @@
 //     addresses - free - so that the tile pair (2c, 2c+1) leaves lane group g with columns 32c + 8g .. + 7: exactly the eight k
 //     values that lane group needs as an operand of the next product's k-step c.
 //   * the weights (2 MB in S-format) stream through a ring of eight 16-KiB LDS stages filled by LDS-DMA
-//     (`global_load_lds_dwordx4`), six stages ahead of the MFMAs; a stage = 128 weight rows x 32 k (64 B hi + 64 B lo per row),
+//     (`global_load_lds_dwordx4`) in GROUPS of four stages, each wave with ONE group's pieces in flight and every wait for them
+//     `vmcnt(0)` with nothing younger outstanding (round 6, below); a stage = 128 weight rows x 32 k (64 B hi + 64 B lo per row),
 //     the layout and slot swizzle of gemm_big_split_kernel (conflict-free ds_read_b128 for the 16x16x32 operand layout).  Per
 //     128 hidden columns: 8 stages of W1 (k = the 256 model columns) then 8 stages of W2 (its 256 rows in two halves x the 128
 //     hidden columns in four k-steps).  Per 128 rows that is 2 MB of ingest for 403 MFLOP (bf16): 200 FLOP per byte, against
 //     96 for a 128x128x256 GEMM tile - the MFMA pipe, not the LDS fill, is the bound.
-//   * workgroup forms (template): four waves x 32 rows (default from 160 row tiles up: a weight fragment read from LDS feeds two row
-//     tiles), eight waves x 16 rows, four waves x 16 rows (64-row workgroups, twice as many, when there are few rows).
+//   * workgroup forms (template): eight waves x 16 rows (default from 160 row tiles up since round 6), four waves x 32 rows (a weight
+//     fragment read from LDS feeds two row tiles; the default of rounds 3 - 5), four waves x 16 rows (64-row workgroups, twice as many,
+//     when there are few rows).
 //   * the weight fragments travel through a ring of four tile buffers in registers that runs ACROSS the stage boundaries (the
 //     barrier of stage u + 1 stands in front of tile 5 of stage u), each fragment requested 17 MFMAs ahead of its use, the two
 //     ds_read_b128 of a tile behind the previous tile's first MFMA.
@@ -40,9 +42,9 @@ namespace ladiff {
 
 namespace {
 
-constexpr int MLP_NS = 8;                      // ring stages
+constexpr int MLP_NS = 8;                      // ring stages: two groups of MLP_GRP
+constexpr int MLP_GRP = 4;                     // stages a wave requests as ONE batch and waits for with vmcnt(0)
 constexpr int MLP_STAGE = 16384;               // bytes: 128 weight rows x 128 B
-constexpr int MLP_AHEAD = 6;                   // stages in flight behind the one being multiplied
 constexpr int MLP_LDS = MLP_NS * MLP_STAGE + FF * 4 + 5 * D * 4;      // ring + linear1's bias + b2, gamma / beta of the LayerNorm(s)
 
 typedef unsigned u32x4_m __attribute__((ext_vector_type(4)));
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void dec_mlp_kernel(const MlpArgs 
         constexpr int slot = decltype(slotc)::value, J0 = decltype(j0c)::value;
         static_for<8>([&](auto jc) {
             constexpr int j = decltype(jc)::value, cur = j & 3;
-            if constexpr (j == 5) next();
+            next(jc);
             // outstanding behind tile j's two reads: tiles j + 1, j + 2 (tile j + 3 follows this tile's first MFMA)
             if constexpr (DIAG != 3 && DIAG != 6) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wt[cur][0]), "+v"(wt[cur][1]));
             __builtin_amdgcn_sched_barrier(0);
@@ -211,44 +213,58 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void dec_mlp_kernel(const MlpArgs 
         });
     };
 
-    // prologue: stages 0 .. AHEAD-1 of hidden slice 0
-    static_for<MLP_AHEAD>([&](auto uc) {
+    // ---- the weight stream (round 6: exact waits).  `s_waitcnt vmcnt(N)`, N > 0, does NOT retire the older of several LDS-DMA batches
+    // a wave has in flight (the requests complete out of issue order when their latencies differ: DESIGN 4b, profiles/r5/11_*), so a
+    // wave has ONE batch outstanding and waits for it with vmcnt(0).  A batch = the wave's PPW pieces of each of the four stages of a
+    // group; group G + 1 is requested while group G is multiplied, into the ring half group G - 1 has left:
+    //   B1 (in front of tile 5 of a group's last stage, the first tile that reads a fragment of the next group): every wave waits
+    //      vmcnt(0) - its whole batch of the next group, nothing younger in flight - then the workgroup barrier: the next group is in LDS.
+    //      Every wave has also finished READING stages 0 .. 2 of the finishing group (the lgkmcnt waits of their tiles 7 lie behind it),
+    //      so from here on the batch after next goes into those three slots;
+    //   B2 (a plain barrier in front of tile 5 of a group's first stage): every wave has finished reading the previous group's LAST
+    //      stage; its slot takes the fourth stage of the batch.
+    // Issue schedule (H = PPW / 2 pieces behind each of the MFMA groups named; an LDS-DMA piece costs its wave 60 - 180 cycles of issue,
+    // which should fall where the matrix pipe has queued work): stage 3 of a group, behind tiles 5, 7: stage 0 of the batch; stage 0,
+    // behind tiles 1, 3, 5, 7: stages 1, 2; stage 1, behind tiles 1, 3: stage 3.  The batch is complete 2.5 stages (~1.9 us) before B1.
+    // Two barriers per four stages instead of four.  Measured (profiles/r6/01_*, one box, decode of 128 x 196 frames): the rest of the
+    // batch squeezed into the group's first stage (B2 in front of its tile 1: longer landing time) is SLOWER (2.08 against 2.02 ms
+    // with <4, 2>) - what costs is issue time taken from the matrix pipe in one place, not landing time.
+    static_for<MLP_GRP>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
-        static_for<PPW>([&](auto ic) { issue(DIAG == 1 ? -1 : 0, IntC<u>{}, IntC<u % MLP_NS>{}, ic); });
+        static_for<PPW>([&](auto ic) { issue(DIAG == 1 ? -1 : 0, IntC<u>{}, IntC<u>{}, ic); });
     });
     __syncthreads();                                                     // linear1's bias is in LDS (plain stores: lgkmcnt, compiler-tracked)
-
-    // which MFMA group of a stage a wave's DMA piece i follows: the first half of the waves issues early in a stage, the second half
-    // late (with one wave per SIMD: one piece after each of the four groups)
-    const int g_first = (wave < NW / 2 || PPW == 4) ? 0 : 4 - PPW;
-    // A stage's DMA pieces have landed when this wave's have (all but the pieces of the younger stages: vmcnt counts in issue order)
-    // and every other wave says the same (barrier).  The check of stage u + 1 stands in front of tile 5 of stage u: by then the wave has
-    // issued its pieces of stage u + AHEAD that follow groups 0 and 1.
-    auto landed = [&](bool first) __attribute__((always_inline)) {
-        // younger than the pieces waited for: first stage - the AHEAD - 1 stages behind it; otherwise the AHEAD - 2 whole stages
-        // u + 2 .. u + AHEAD - 1 and what this wave has issued of stage u + AHEAD so far
-        if (first) wait_vm<PPW * (MLP_AHEAD - 1)>();
-        else if (PPW == 4) wait_vm<PPW * (MLP_AHEAD - 2) + 2>();          // one piece behind each of groups 0, 1
-        else if (wave < NW / 2) wait_vm<PPW * (MLP_AHEAD - 2) + PPW>();   // issued behind groups 0 .. PPW - 1: all of them
-        else wait_vm<PPW * (MLP_AHEAD - 2)>();                            // issued behind groups 4 - PPW .. 3: none yet
+    auto landed = [&]() __attribute__((always_inline)) {
+        wait_vm<0>();                                                    // this wave's batch (and, the first time, its x rows); nothing younger in flight
         __builtin_amdgcn_s_barrier();
     };
-    landed(true);
+    landed();
+    static_for<PPW>([&](auto ic) { issue(DIAG == 1 ? -1 : 0, IntC<MLP_GRP>{}, IntC<MLP_GRP>{}, ic); });   // stage 0 of group 1 (in the loop: behind tiles 5, 7 of the previous group's last stage)
     static_for<3>([&](auto jc) { fetch_tile(IntC<0>{}, jc); });
+    constexpr int H = PPW / 2;
 #pragma unroll 1
     for (int hs = 0; hs < 8; ++hs) {
         static_for<16>([&](auto uc) {
-            constexpr int u = decltype(uc)::value, slot = u % MLP_NS;
-            constexpr int ut = (u + MLP_AHEAD) % 16, slot_t = (u + MLP_AHEAD) % MLP_NS;
-            const int hs_t = (hs + (u + MLP_AHEAD >= 16 ? 1 : 0)) & 7;  // past the last slice: a harmless re-fetch keeps the counts uniform
-            // The stage AHEAD further goes into the slot consumed two stages ago (every wave left it before the barrier in front of
-            // the previous stage's last group), a piece at a time behind the MFMA groups: an LDS-DMA piece costs its wave 60 - 180
-            // cycles of issue, which should fall where the matrix pipe has queued work (or the SIMD partner's)
+            constexpr int u = decltype(uc)::value, slot = u % MLP_NS, r = u % MLP_GRP;
+            // pieces [H * half, H * half + H) of the stage `ahead` further; past the last slice a harmless re-fetch (slice 0) keeps the loop uniform
+            auto batch_pieces = [&](auto aheadc, auto halfc) __attribute__((always_inline)) {
+                constexpr int ahead = decltype(aheadc)::value, half = decltype(halfc)::value;
+                constexpr int ut = (u + ahead) % 16, slot_t = (u + ahead) % MLP_NS;
+                const int hs_t = (hs + (u + ahead >= 16 ? 1 : 0)) & 7;
+                static_for<H>([&](auto ic) { issue(hs_t, IntC<ut>{}, IntC<slot_t>{}, IntC<H * half + decltype(ic)::value>{}); });
+            };
             auto between = [&](auto gc) __attribute__((always_inline)) {
                 constexpr int g = decltype(gc)::value;
-                static_for<PPW>([&](auto ic) { constexpr int i = decltype(ic)::value; if (g == g_first + i) issue(hs_t, IntC<ut>{}, IntC<slot_t>{}, ic); });
+                if constexpr (r == 3 && g >= 2) batch_pieces(IntC<5>{}, IntC<g - 2>{});          // stage 0 of the batch: behind B1
+                else if constexpr (r == 0 && g < 2) batch_pieces(IntC<5>{}, IntC<g>{});          // stage 1
+                else if constexpr (r == 0 && g >= 2) batch_pieces(IntC<6>{}, IntC<g - 2>{});     // stage 2
+                else if constexpr (r == 1 && g < 2) batch_pieces(IntC<6>{}, IntC<g>{});          // stage 3: its slot is free behind B2
             };
-            auto next = [&]() __attribute__((always_inline)) { landed(false); };
+            auto next = [&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (r == 3 && j == 5) landed();                                                  // B1
+                else if constexpr (r == 0 && j == 5) __builtin_amdgcn_s_barrier();                         // B2
+            };
             if constexpr (u < 8) {
                 if constexpr (u == 0) {
 #pragma unroll
@@ -407,7 +423,9 @@ int launch_dec_mlp(const float* xs, const float* x, const float* w1, const float
     // three-launch form below dec_mlp_min_rows())
     int form = g_mlp_variant;                      // 0: by size, 1: <8, 1>, 2: <4, 1>, 3: <4, 2>
     if (form >= 21) form = 0;                      // 21 .. 23: timing builds of the attention kernel (dec_qkv_attn.hip)
-    if (form == 0) form = (M + 127) / 128 < 160 ? 2 : 3;
+    // round 6: with one batch per wave behind vmcnt(0) the two-waves-per-SIMD form is the fastest at 25088 rows (decode 1.92 ms against
+    // 2.02 with <4, 2>; round 5's counted-wait ring: 2.00 / 1.97) - a wave's LDS-DMA issue falls under its SIMD partner's MFMAs
+    if (form == 0) form = (M + 127) / 128 < 160 ? 2 : 1;
 #ifdef LADIFF_STAMPS
     // diagnostic twin only (the product library has no such instantiation and rejects the values): timing builds with garbage
     // results - <4, 2> without DMA / MFMAs / fragment reads / GELU / epilogue

@@ -14,6 +14,7 @@ The schemas are also what the C-ABI library consumes: `csrc/weights.h` lists the
 names in the same order (checked by tests/test_abi.py).
 """
 from collections import OrderedDict
+from types import SimpleNamespace
 
 PE_MAX_LEN = 500  # position_encoding.py:140
 
@@ -192,3 +193,16 @@ def t2m_text_schema(word_size=300, pos_size=15, hidden_size=512, output_size=512
     _coemb_head(s, hidden_size, output_size)
     s["hidden"] = (2, 1, hidden_size)
     return s
+
+
+# The shipped configuration (`configs/config_ladiff_humanml3d.yaml` model.ablation + `configs/modules/denoiser.yaml`,
+# `configs/modules/motion_vae.yaml` as `get_model` instantiates them): what bench.py, smoke() and the tests build the two networks with.
+ABL = SimpleNamespace(SKIP_CONNECT=True, VAE_TYPE="actor", DIFF_PE_TYPE="mld", PE_TYPE="mld", IDEA="ard",
+                      MD_TRANS=True, TEST_EFFICIENCY=False, MLP_DIST=False, DVAE=False, PERCENTAGE_NOISED=0.0,
+                      MAX_IT=5, FRAME_PER_LATENT=48, JOINT_DISTRO_FIX=False, LAD=True)
+DEN_KW = dict(nfeats=263, condition="text", latent_dim=[7, 256], ff_size=1024, num_layers=9, num_heads=4,
+              dropout=0.1, normalize_before=False, activation="gelu", flip_sin_to_cos=True,
+              return_intermediate_dec=False, position_embedding="learned", arch="trans_enc", freq_shift=0,
+              guidance_scale=7.5, guidance_uncondp=0.1, text_encoded_dim=768, nclasses=10)
+VAE_KW = dict(nfeats=263, latent_dim=[7, 256], ff_size=1024, num_layers=9, num_heads=4, dropout=0.1,
+              arch="encoder_decoder", normalize_before=False, activation="gelu", position_embedding="learned")

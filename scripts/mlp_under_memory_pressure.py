@@ -1,5 +1,5 @@
-"""The fused feed-forward kernel (csrc/dec_mlp.hip: a ring of eight LDS-DMA weight stages, six in flight behind COUNTED vmcnt waits -
-DESIGN.md 4b's residual risk) beside kernels that sweep the caches on another stream: large device-to-device copies (the weights then
+"""The fused feed-forward kernel (csrc/dec_mlp.hip: a ring of eight LDS-DMA weight stages; rounds 3 - 5 six in flight behind COUNTED vmcnt
+waits, since round 6 one batch per wave behind vmcnt(0)) beside kernels that sweep the caches on another stream: large device-to-device copies (the weights then
 miss the L2 again and again: their pieces' latencies spread) and the split GEMM.  Every launch's output against the first one's bits.
 usage: mlp_under_memory_pressure.py [launches]"""
 import os, sys
@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from ladiff_amd import _lib
+if os.environ.get("LADIFF_LIB"):                      # an experiment build of the library (same ABI)
+    _lib.LIB_PATH = os.path.join(ROOT, os.environ["LADIFF_LIB"])
 L = _lib.lib()
 dev = "cuda:0"
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000

@@ -70,6 +70,16 @@ def test_two_decodes_on_two_streams_are_the_decodes_alone():
     assert out.count("concurrent True: 0 of 400 runs differ") == 2, out
 
 
+def test_dec_mlp_beside_cache_sweeping_kernels():
+    """csrc/dec_mlp.hip streams its weights through LDS-DMA stages; since round 6 a wave has ONE batch of them in flight and waits with
+    vmcnt(0) (rounds 3 - 5: six stages in flight behind counted waits - the pattern that broke gemm_big beside a second stream).  The
+    aggressors here are chosen for THIS kernel: 384-MB copies sweep the L2 and the memory-side cache so that its weight pieces miss
+    again and again, split GEMMs stream the same weight rows from 196 other workgroups.  1600 launches per aggressor against the
+    first launch's bits."""
+    out = _run("mlp_under_memory_pressure.py", 1600)
+    assert out.count(": 0 of 1600 launches differ") == 3, out
+
+
 def test_decode_writes_only_inside_its_workspace_and_output():
     """Workspace and output inside larger canary-filled buffers (64 MB of guard words on each side), four batch shapes, both modes."""
     out = _run("decode_guard.py")
