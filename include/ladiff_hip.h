@@ -31,8 +31,9 @@
  *     fma chains inside every product; the persistent pipeline kernel of ladiff_diffusion_reverse additionally clears the last
  *     mantissa bit of every activation word it hands from one stage to the next - the bit carries the hand-off's parity tag,
  *     csrc/systolic.hip tag4: a truncation of <= 1 ulp toward zero at each of the 59 hand-offs of a step, in both hand-off
- *     protocols; 1e-5 ... 3e-5 on the decoded frames against the fp64-checked oracle); w_split != NULL (and ladiff_gemm_split / ladiff_self_attention_bf16x3 / split = 1) -> "bf16x3": operands as
- *     bf16 hi + lo pairs, three bf16 MFMAs per product, fp32 accumulate; softmax, LayerNorm statistics, guidance and the
+ *     protocols; 1e-5 ... 3e-5 on the decoded frames against the fp64-checked oracle); w_split != NULL (and ladiff_gemm_split / ladiff_self_attention_split / split = 1) -> "f16x3": operands as
+ *     fp16 hi + lo pairs (22 significant bits; each half saturates at +-65504 - round 6; rounds 1 - 5 and a -DLADIFF_SPLIT_BF16 build: bf16
+ *     pairs, 16 bits, "bf16x3"; ladiff_split_format() tells), three 16-bit MFMAs per product, fp32 accumulate; softmax, LayerNorm statistics, guidance and the
  *     scheduler are fp32 in both.
  *   - weights are passed as an array of device pointers, one per state-dict tensor, in the order
  *     given by ladiff_{denoiser,decoder}_param_name(i) (names = the reference's state-dict keys,
@@ -68,7 +69,7 @@ enum {
 enum { LADIFF_ACT_NONE = 0, LADIFF_ACT_RELU = 1, LADIFF_ACT_GELU = 2, LADIFF_ACT_SILU = 3, LADIFF_ACT_QGELU = 4 /* x*sigmoid(1.702x) */,
        LADIFF_ACT_LRELU = 5 /* LeakyReLU(0.2) */ };
 
-#define LADIFF_ABI_VERSION 5
+#define LADIFF_ABI_VERSION 6
 #define LADIFF_LATENT_DIM 256     /* model.latent_dim[-1], config_ladiff_humanml3d.yaml:132 */
 #define LADIFF_NUM_HEADS 4        /* configs/modules/denoiser.yaml:7 */
 #define LADIFF_NUM_LAYERS 9       /* configs/modules/denoiser.yaml:6, motion_vae.yaml:5 */
@@ -81,6 +82,10 @@ enum { LADIFF_ACT_NONE = 0, LADIFF_ACT_RELU = 1, LADIFF_ACT_GELU = 2, LADIFF_ACT
 #define LADIFF_CLIP_MAX_POSITIONS 77
 
 LADIFF_API int ladiff_version(void);
+/* Element type of the two halves of an S-format pair in THIS build of the library: 1 = IEEE fp16 (the product: x ~ hi + lo carries 22
+ * significant bits, saturating at +-65504 per half), 0 = bf16 (rounds 1 - 5 and `-DLADIFF_SPLIT_BF16`: 16 bits, fp32's exponent range).
+ * Callers that only pass S-format buffers between entries of this library never need it; tests that decode the format do. */
+LADIFF_API int ladiff_split_format(void);
 LADIFF_API const char* ladiff_error_string(int code);
 
 /* ------------------------------------------------------------------ weight tables */
@@ -106,21 +111,21 @@ LADIFF_API int ladiff_gemm_resident(const float* A, int lda, const float* A2, in
                          const float* bias, const float* res, int ldres, float* Y, int ldy, int M, int N, int K,
                          int act, int split, float* Ys, ladiff_stream_t stream);
 
-/* Large-M bf16x3 GEMM of the decoder / encoder / CLIP (128x128 tiles, persistent producer/consumer workgroups):
+/* Large-M f16x3 GEMM of the decoder / encoder / CLIP (128x128 tiles, persistent producer/consumer workgroups):
  *   Y and/or Ys = act( [A | A2] . W^T + bias ) (+ res);  A, A2, W are S-format rows (ladiff_split_rows), K and K1
  *   multiples of 64, N multiple of 128, ldy multiple of 64; Y fp32 and Ys its S-format twin, either may be NULL. */
 LADIFF_API int ladiff_gemm_split(const float* A, int lda, const float* A2, int lda2, int K1, const float* W, int ldw,
                       const float* bias, const float* res, int ldres, float* Y, float* Ys, int ldy, int M, int N, int K,
                       int act, ladiff_stream_t stream);
 
-/* bf16x3 operand format ("S-format"): a row of K fp32 values (K multiple of 64) is stored in the same K*4 bytes as
- * K/64 blocks of [64 bf16 hi | 64 bf16 lo], x ~ hi + lo.  With split = 1 ladiff_gemm_resident reads A, A2 and W in
- * this format and evaluates every product as hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation
+/* f16x3 operand format ("S-format"): a row of K fp32 values (K multiple of 64) is stored in the same K*4 bytes as
+ * K/64 blocks of [64 x 16-bit hi | 64 x 16-bit lo], x ~ hi + lo (fp16 halves, or bf16 in a -DLADIFF_SPLIT_BF16 build).  With split = 1 ladiff_gemm_resident reads A, A2 and W in
+ * this format and evaluates every product as hi*hi + hi*lo + lo*hi on the 16-bit MFMA with fp32 accumulation
  * (~2^-16 relative error per product, fp32 exponent range); Ys (may be NULL) receives the K == 256 result in
  * S-format, Y (may then be NULL) in fp32.  ladiff_split_rows converts fp32 [R,K] -> S-format [R,K]. */
 LADIFF_API int ladiff_split_rows(const float* x, float* y, int R, int K, ladiff_stream_t stream);
 
-/* The decoder layer's feed-forward block as ONE kernel, bf16x3 arithmetic (csrc/dec_mlp.hip):
+/* The decoder layer's feed-forward block as ONE kernel, f16x3 arithmetic (csrc/dec_mlp.hip):
  *   y / ys [M,256] = LN( x + W2 gelu(W1 x + b1) + b2 ), then a second LayerNorm when ln2_gamma != NULL
  * TransformerDecoderLayer.forward_post, cross_attention.py:410-412 (tgt = norm3(tgt + linear2(gelu(linear1(tgt))))) and, on the
  * last layer, decoder.norm (:150-151).  xs = S-format twin of x (the operand; x is the fp32 residual), w1s [1024,256] and
@@ -148,10 +153,10 @@ LADIFF_API int ladiff_layernorm(const float* x, const float* gamma, const float*
 LADIFF_API int ladiff_decoder_self_attention(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out,
                                   int B, int F, ladiff_stream_t stream);
 
-/* The same core in bf16x3 arithmetic (q, k, v and the probabilities as bf16 hi + lo pairs, three bf16 MFMAs per product,
+/* The same core in f16x3 arithmetic (q, k, v and the probabilities as hi + lo pairs, three 16-bit MFMAs per product,
  * fp32 softmax and accumulation) for any number of 64-wide heads: qkv[B*F, 3*64*nheads] packed [q | k | v],
  * out[B*F, 64*nheads] fp32.  lengths and keybits may both be NULL (all keys valid); causal != 0 adds key <= query. */
-LADIFF_API int ladiff_self_attention_bf16x3(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
+LADIFF_API int ladiff_self_attention_split(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
                                  int nheads, int causal, ladiff_stream_t stream);
 
 /* Decoder cross-attention core: q[B*F,256] against the T memory tokens kv[T*B,512] (row = t*B+b,
@@ -189,7 +194,7 @@ LADIFF_API int ladiff_denoiser_text_cache(const float* const* w, const float* te
 /* eps[Bs*dup,T,256] = denoiser(cat([sample]*dup), t = step *d_step of the time tables, text, counts).
  * ladiff_denoiser.py:153-295 (call site ladiff.py:472-485).  counts[Bs] (int32, valid latent rows per
  * prompt, ceil(len/48)) may be NULL = no masking (TEST_EFFICIENCY / max_iter_elements=None).
- * w_split = NULL: fp32-input MFMA everywhere (bit-for-bit fp32 fma chains).  w_split != NULL: the bf16x3 matrix path;
+ * w_split = NULL: fp32-input MFMA everywhere (bit-for-bit fp32 fma chains).  w_split != NULL: the f16x3 matrix path;
  * it is a second pointer table in the same order as w whose >= 2-D entries are the S-format copies of the weight
  * matrices (ladiff_split_rows), the other entries are ignored. */
 LADIFF_API int ladiff_denoiser_forward(const float* const* w, const float* const* w_split, const float* tables,
@@ -258,10 +263,10 @@ LADIFF_API int ladiff_sampler_destroy(void* sampler);
 LADIFF_API int ladiff_sampler_set_loop(void* sampler, int mode);
 /* The block plan ladiff_diffusion_reverse would use for a batch (host arithmetic only, no GPU call): rows per block (16 = the
  * length-aware packing, 32 = padded blocks) and the number of blocks.  h_counts = latent counts on the host or NULL, masked = the
- * call passes device counts, loop_mode 1 / 2 / 3 as ladiff_sampler_set_loop, bf16x3 = the call passes w_split, cfg = the call's
+ * call passes device counts, loop_mode 1 / 2 / 3 as ladiff_sampler_set_loop, f16x3 = the call passes w_split, cfg = the call's
  * guidance flag (without guidance: one-branch 16-row blocks; LADIFF_ERR_UNSUPPORTED when such a call has device-only counts - it runs
  * launch-per-stage and has no block plan). */
-LADIFF_API int ladiff_reverse_plan(int B, int T, const int32_t* h_counts, int masked, int loop_mode, int bf16x3, int cfg, int* rows_per_block,
+LADIFF_API int ladiff_reverse_plan(int B, int T, const int32_t* h_counts, int masked, int loop_mode, int f16x3, int cfg, int* rows_per_block,
                         int* n_blocks);
 /* Device time of the N-step loop of the sampler's last call (HIP events recorded on the call's stream right around the
  * pipeline kernel, or around the graph replays); blocks until it has finished.  Measurement aid (bench.py). */
@@ -316,9 +321,9 @@ LADIFF_API int ladiff_diffusion_reverse(void* sampler, const float* const* w, co
 /* ------------------------------------------------------------------ LA-VAE decoder (LADiffVae.decode)
  * feats[B,F,C] from z[T,B,256]; frames >= lengths[b] come out zero.  ladiff_vae.py:288-362
  * (call site ladiff.py:283).  lengths/counts are int32 device arrays of B entries. */
-/* w_split (bf16x3 mode): the S-format copies of the weight matrices as for the denoiser.  final_layer.weight needs its C rows only
+/* w_split (f16x3 mode): the S-format copies of the weight matrices as for the denoiser.  final_layer.weight needs its C rows only
  * (ABI 4; ABI 3 asked for tables padded to ceil(C / 128) * 128 rows - such tables still work, the extra rows are not read): from 4,096
- * frame rows up the final projection runs on whole 128-column bf16x3 tiles, and the library pads the rows it needs itself.  The bias is
+ * frame rows up the final projection runs on whole 128-column f16x3 tiles, and the library pads the rows it needs itself.  The bias is
  * taken from the fp32 table `w`. */
 LADIFF_API size_t ladiff_decoder_workspace_bytes(int B, int F, int T, int C);
 LADIFF_API int ladiff_vae_decode(const float* const* w, const float* const* w_split /*or NULL: fp32 MFMA*/, const float* z,
@@ -378,7 +383,9 @@ LADIFF_API int ladiff_clip_text_encode(const float* const* w, const float* const
  * behind a prompt's EOS reaches its pooled row), 2.3x fewer rows than the padded batch for prompts of 1 .. 30 words.  seq_len[B] =
  * eos_b + 1 (the caller computes it from the ids as the reference's argmax does, mld_clip.py:75-78 -> CLIPTextTransformer), row_off[B+1]
  * = exclusive prefix sums of seq_len (row_off[B] = total_rows), row_seq[total_rows] = the prompt of each row; all int32 on the device;
- * L = max seq_len.  Same result as ladiff_clip_text_encode within the arithmetic mode's rounding (the row tiling of the GEMMs differs). */
+ * L = max seq_len.  Same result as ladiff_clip_text_encode within the arithmetic mode's rounding (the row tiling of the GEMMs differs).
+ * The three arrays must be mutually consistent (only total_rows is range-checked on the host): inconsistent ones give wrong embeddings,
+ * never an access outside ids / the position table (the kernels clamp prompt and position indices). */
 LADIFF_API size_t ladiff_clip_workspace_bytes_ragged(int B, int total_rows);
 LADIFF_API int ladiff_clip_text_encode_ragged(const float* const* w, const float* const* w_split /*or NULL*/, int n_layers, int vocab,
                             const int64_t* ids, int B, int S, int L, const int32_t* seq_len, const int32_t* row_off,

@@ -48,13 +48,13 @@ LADIFF_API int ladiff_debug_set_pacing(int eighths, int mask);
  * give the same bits; ladiff_reverse_status reports code 0, info -1 for such a launch). */
 LADIFF_API int ladiff_debug_set_xcd_local(int on);
 /* Measurement switch (process-wide): 1 (default) = the decoder's feed-forward block runs as the fused kernel of csrc/dec_mlp.hip in
- * bf16x3 mode from 10,000 frame rows up, 2 = at every size, 0 = as linear1 GEMM + linear2 GEMM + LayerNorm row kernel (the round-2
+ * f16x3 mode from 10,000 frame rows up, 2 = at every size, 0 = as linear1 GEMM + linear2 GEMM + LayerNorm row kernel (the round-2
  * path; same arithmetic per product).  + 4: decodes of fewer than 4,096 frame rows keep the large-M GEMM kernels instead of the
- * small-M ones (the round-2 routing).  + 8: final_layer on the fp32-input kernel in bf16x3 mode too (the round-2 path).  + 16: the
+ * small-M ones (the round-2 routing).  + 8: final_layer on the fp32-input kernel in f16x3 mode too (the round-2 path).  + 16: the
  * decoder's self-attention as in_proj GEMM + attention kernel (two launches, q | k | v rows through memory) instead of the kernel
  * that computes its head's q | k | v itself (csrc/dec_qkv_attn.hip; default from 4,096 frame rows up); + 32: that kernel at every size.
  * + 64: the self-attention out_proj GEMM and the cross-attention row kernel as two launches (x + out_proj(att) through memory) instead
- * of the one kernel that keeps out_proj's weight in registers (csrc/dec_cross.hip; default from 4,096 frame rows up in bf16x3 mode). */
+ * of the one kernel that keeps out_proj's weight in registers (csrc/dec_cross.hip; default from 4,096 frame rows up in f16x3 mode). */
 LADIFF_API int ladiff_debug_set_decoder_fusion(int on);
 /* Measurement switch (process-wide) of the fused feed-forward kernel's form: 0 (default) = chosen by the row count, 1 = 128-row
  * workgroups of eight waves x 16 rows, 2 = 64-row workgroups of four waves x 16 rows, 3 = 128-row workgroups of four waves x 32 rows.
@@ -67,7 +67,7 @@ LADIFF_API int ladiff_debug_set_mlp_variant(int v);
  * request the next block's rows early in launches of >= look_ahead_from blocks; the LIN / FFN workgroups rest after every block in
  * launches of <= small_upto blocks.  -1 keeps the built-in value.  Same results. */
 LADIFF_API int ladiff_debug_set_loop_thresholds(int look_ahead_from, int small_upto);
-/* The graph re-instantiation rule of a sampler (csrc/api.hip: an older graph exec is never replayed after a newer instantiation):
+/* The graph re-instantiation rule, process-wide - samplers AND decode graphs (csrc/api.hip: an older graph exec is never replayed after a newer instantiation):
  * 1 (default) on, 0 off - tests/test_gpu_stress.py replays old execs on purpose. */
 LADIFF_API int ladiff_debug_set_graph_epoch_rule(int on);
 /* Number of hipGraph instantiations the process has made so far (prologue + step graphs of all samplers): tests assert that a repeated

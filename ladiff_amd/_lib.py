@@ -24,8 +24,26 @@ class LadiffHipError(RuntimeError):
     pass
 
 
+SPLIT_MODES = ("f16x3", "bf16x3", "split")     # names accepted for "matrix products as hi + lo pairs of 16-bit halves"
+
+
+def is_split(precision):
+    """True for the split arithmetic mode.  WHICH 16-bit type the halves are is a property of the loaded build (`split_mode_name()`:
+    fp16 pairs = "f16x3" in the product, bf16 pairs = "bf16x3" in a -DLADIFF_SPLIT_BF16 build); every name selects that one path."""
+    if precision == "fp32":
+        return False
+    if precision in SPLIT_MODES:
+        return True
+    raise ValueError(f'precision must be "fp32" or one of {SPLIT_MODES}, got {precision!r}')
+
+
+def split_mode_name():
+    return "f16x3" if lib().ladiff_split_format() == 1 else "bf16x3"
+
+
 _SIGNATURES = {
     "ladiff_version": (c_int, []),
+    "ladiff_split_format": (c_int, []),
     "ladiff_error_string": (c_char_p, [c_int]),
     "ladiff_denoiser_num_params": (c_int, []),
     "ladiff_denoiser_param_name": (c_char_p, [c_int]),
@@ -45,7 +63,7 @@ _SIGNATURES = {
     "ladiff_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ladiff_timestep_sinusoid": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "ladiff_decoder_self_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "ladiff_self_attention_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ladiff_self_attention_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ladiff_decoder_cross_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ladiff_denoiser_tables_floats": (c_size_t, [c_int]),
     "ladiff_denoiser_text_cache_floats": (c_size_t, [c_int, c_int, c_int]),
@@ -209,7 +227,7 @@ class WeightTable:
         self._split = None
 
     def split_array(self):
-        """Second pointer table for the bf16x3 path: S-format copies of the weight matrices (built once, on the GPU)."""
+        """Second pointer table for the f16x3 path: S-format copies of the weight matrices (built once, on the GPU)."""
         if self._split is None:
             L = lib()
             self.split_tensors = []

@@ -32,11 +32,14 @@ def stamps_lib(level=1):
     return LIB.replace(".so", "_stamps.so" if int(level) == 1 else f"_stamps{int(level)}.so")
 
 
-def build(force=False, verbose=False, stamps=False):
+def build(force=False, verbose=False, stamps=False, tag=None, defines=()):
     """stamps=True builds the diagnostic twin (in-kernel s_memrealtime stamps and timing probes; never timed, never shipped as the
     product): level 1 -> libladiff_hip_stamps.so, LADIFF_STAMPS_LEVEL=2 in the environment -> libladiff_hip_stamps2.so (each level has
     its own object directory AND its own library, so one never serves the other)."""
     obj, lib, flags = OBJ, LIB, list(FLAGS)
+    if tag:                                                  # a whole-library variant for a same-box A/B (never the product): own objects, own .so
+        obj, lib = OBJ + "_" + tag, LIB.replace(".so", f"_{tag}.so")
+        flags += ["-D" + d for d in defines]
     if stamps:
         # level 1: per-workgroup totals only (blocked / busy time: undistorted); level 2 adds the per-block timeline stamps (~0.1 us
         # each: read intervals from it, not totals)
@@ -75,4 +78,6 @@ def build(force=False, verbose=False, stamps=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, stamps="--stamps" in sys.argv))
+    _tag = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--tag=")), None)
+    _defs = [a[2:] for a in sys.argv if a.startswith("-D")]
+    print(build(force="--force" in sys.argv, verbose=True, stamps="--stamps" in sys.argv, tag=_tag, defines=_defs))

@@ -105,9 +105,15 @@ struct Sampler {
     // polls the end events of synchronous collectives, which run on the caller's CURRENT stream: a capture on that stream died about
     // once in fifteen bench runs under torchrun (profiles/r5/26_*).  Nobody else holds events of this stream.
     hipStream_t cap = nullptr;
+    int cap_dev = -1;                     // the device `cap` was created on
 };
-static int capture_stream(hipStream_t* cap) {
-    if (*cap == nullptr) LADIFF_HIP(hipStreamCreateWithFlags(cap, hipStreamNonBlocking));
+// The capture stream belongs to the device that was current when it was created; a handle that is later used with another device
+// current gets a new one (the old graphs hold that device's pointers and are rebuilt by their key anyway).
+static int capture_stream(hipStream_t* cap, int* cap_dev) {
+    int dev = 0;
+    LADIFF_HIP(hipGetDevice(&dev));
+    if (*cap != nullptr && *cap_dev != dev) { (void)hipStreamDestroy(*cap); *cap = nullptr; }
+    if (*cap == nullptr) { LADIFF_HIP(hipStreamCreateWithFlags(cap, hipStreamNonBlocking)); *cap_dev = dev; }
     return 0;
 }
 
@@ -150,6 +156,13 @@ static unsigned long long* g_stamps = nullptr;
 extern "C" {
 
 int ladiff_version(void) { return LADIFF_ABI_VERSION; }
+int ladiff_split_format(void) {
+#ifndef LADIFF_SPLIT_BF16
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 const char* ladiff_error_string(int code) {
     switch (code) {
@@ -246,10 +259,10 @@ int ladiff_decoder_self_attention(const float* qkv, const int32_t* lengths, cons
     return launch_decoder_self_attention(qkv, lengths, keybits, out, B, F, 0, S(stream));
 }
 
-int ladiff_self_attention_bf16x3(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
+int ladiff_self_attention_split(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
                                  int nheads, int causal, ladiff_stream_t stream) {
     LADIFF_CHECK_ARG(qkv && out && B >= 0);
-    return launch_self_attention_bf16x3(qkv, lengths, keybits, out, B, F, nheads, causal, 0, S(stream));
+    return launch_self_attention_split(qkv, lengths, keybits, out, B, F, nheads, causal, 0, S(stream));
 }
 
 int ladiff_decoder_cross_attention(const float* q, const float* kv, const int32_t* counts, float* out, int B, int F,
@@ -350,7 +363,7 @@ int ladiff_sampler_destroy(void* sampler) {
 }  // extern "C"
 
 // Block plan of the pipeline loop for one call (host only).  loop_mode: 1 = pick by the cost model, 2 / 3 = force 16- / 32-row blocks.
-static void choose_plan(int B, int T, const int32_t* h_counts, bool masked, int loop_mode, bool bf16x3, std::vector<unsigned char>& plan,
+static void choose_plan(int B, int T, const int32_t* h_counts, bool masked, int loop_mode, bool f16x3, std::vector<unsigned char>& plan,
                         int* plan_mr, int* plan_nb, bool cfg = true) {
     int mr16 = 1, nb16 = 0, mr32 = 2, nb32 = 0;
     std::vector<unsigned char> p16, p32;
@@ -364,7 +377,7 @@ static void choose_plan(int B, int T, const int32_t* h_counts, bool masked, int 
     if (want == 0) {
         // measured (scripts/try_pipeline.py uniform, 1 ... 128 prompts, final build of round 2): the busiest stage's time per block
         // and one block's unloaded trip through the 59 stages, in us, for 16- / 32-row blocks
-        const double c16 = bf16x3 ? 2.45 : 5.05, c32 = bf16x3 ? 5.3 : 12.1, lat16 = bf16x3 ? 172.0 : 310.0, lat32 = bf16x3 ? 282.0 : 525.0;
+        const double c16 = f16x3 ? 2.45 : 5.05, c32 = f16x3 ? 5.3 : 12.1, lat16 = f16x3 ? 172.0 : 310.0, lat32 = f16x3 ? 282.0 : 525.0;
         const double e16 = mr16 == 1 ? std::max(lat16, nb16 * c16) : 1e30, e32 = std::max(lat32, nb32 * c32);
         want = e16 < e32 ? 1 : 2;
     }
@@ -374,12 +387,12 @@ static void choose_plan(int B, int T, const int32_t* h_counts, bool masked, int 
 
 extern "C" {
 
-int ladiff_reverse_plan(int B, int T, const int32_t* h_counts, int masked, int loop_mode, int bf16x3, int cfg, int* rows_per_block, int* n_blocks) {
+int ladiff_reverse_plan(int B, int T, const int32_t* h_counts, int masked, int loop_mode, int f16x3, int cfg, int* rows_per_block, int* n_blocks) {
     LADIFF_CHECK_ARG(B >= 1 && T >= 1 && T <= LADIFF_MAX_LATENTS && loop_mode >= 1 && loop_mode <= 3 && rows_per_block && n_blocks);
     if (!cfg && masked && h_counts == nullptr) return LADIFF_ERR_UNSUPPORTED;      // such a call runs launch-per-stage (no block plan)
     std::vector<unsigned char> plan;
     int mr = 2, nb = 0;
-    choose_plan(B, T, h_counts, masked != 0, loop_mode, bf16x3 != 0, plan, &mr, &nb, cfg != 0);
+    choose_plan(B, T, h_counts, masked != 0, loop_mode, f16x3 != 0, plan, &mr, &nb, cfg != 0);
     *rows_per_block = 16 * mr; *n_blocks = nb;
     return 0;
 }
@@ -664,7 +677,7 @@ int ladiff_diffusion_reverse(void* sampler, const float* const* w, const float* 
                 if (sp->setup) { sp->retired.push_back(sp->setup); sp->setup = nullptr; }
             }
             hipGraph_t graph = nullptr;
-            LADIFF_TRY(capture_stream(&sp->cap));
+            LADIFF_TRY(capture_stream(&sp->cap, &sp->cap_dev));
             const hipStream_t cs = sp->cap;      // captured here, replayed on `s` (see Sampler::cap)
             {   // prologue graph
                 LADIFF_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
@@ -866,6 +879,7 @@ namespace {
 struct DecodeGraph {
     hipGraphExec_t exec = nullptr;
     hipStream_t cap = nullptr;            // captured on a stream of its own, replayed on the caller's (Sampler::cap)
+    int cap_dev = -1;
     const void* key_ptrs[7] = {nullptr};
     uint64_t epoch = 0;                   // g_graph_epoch at instantiation: replayed only while it is the newest graph of the process
     int key_ints[6] = {0};
@@ -903,14 +917,15 @@ int ladiff_vae_decode_graphed(void* graph, const float* const* w, const float* c
     // the measurement switches change the launch sequence: part of the key
     h ^= (uint64_t)(g_dec_fused_mlp + 4 * g_dec_small_rows_path + 8 * g_dec_final_split + 16 * g_mlp_variant + 4096 * g_dec_fused_attn) * 0x100000001b3ull;
     const bool same = dg->exec && std::memcmp(kp, dg->key_ptrs, sizeof(kp)) == 0 && std::memcmp(ki, dg->key_ints, sizeof(ki)) == 0 &&
-                      h == dg->key_hash && weights_generation == dg->key_gen && dg->epoch == g_graph_epoch.load();
+                      h == dg->key_hash && weights_generation == dg->key_gen &&
+                      (dg->epoch == g_graph_epoch.load() || g_graph_epoch_rule.load() == 0);     // the rule's switch is process-wide: samplers and decode graphs
     if (!same) {
         if (dg->exec) { LADIFF_HIP(hipStreamSynchronize(s)); (void)hipGraphExecDestroy(dg->exec); dg->exec = nullptr; }
         LADIFF_TRY(dec_mlp_prepare());            // kernel attributes are set outside the capture
         LADIFF_TRY(dec_qkv_attn_prepare());
         LADIFF_TRY(dec_cross_prepare());
         hipGraph_t gr = nullptr;
-        LADIFF_TRY(capture_stream(&dg->cap));
+        LADIFF_TRY(capture_stream(&dg->cap, &dg->cap_dev));
         const hipStream_t cs = dg->cap;
         LADIFF_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
         int rc = 0;

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const float* __restr
     }
 }
 
-// ---- bf16x3 version (precision mode "bf16x3"): the same S^T / O^T formulation on v_mfma_f32_32x32x16_bf16 with every
+// ---- f16x3 version (precision mode "f16x3"): the same S^T / O^T formulation on v_mfma_f32_32x32x16_bf16 with every
 // product evaluated as lo*hi + hi*lo + hi*hi of bf16 pairs (q, k, v and the probabilities are split; fp32 accumulate,
 // fp32 softmax).  The fp32 MFMA (32x32x2, 64 cycles) made the fp32 kernel matrix-pipe-bound at 28.7 k cycles per query
 // tile; here the two products take 5.4 k.  One workgroup per (sample, head), 8 waves = up to 7 query tiles, so K / V are
@@ -169,19 +169,18 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const float* __restr
 // unmoved, the B operand of MFMA m of a key tile (keys 16m + 4g + {0..3, 8..11}); V^T is read with the same key map.
 constexpr int SB_VLD = 232;                    // keys per row of the transposed V planes (464 B, multiple of 8)
 
-__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { hi[e] = (__bf16)v[e]; lo[e] = (__bf16)(v[e] - (float)hi[e]); }
+__device__ __forceinline__ void split8(const float (&v)[8], s16x8& hi, s16x8& lo) {
+    split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
 }
 
-__global__ __launch_bounds__(512) void self_attn_bf16x3_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ lengths,
+__global__ __launch_bounds__(512) void self_attn_split_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ lengths,
                                                                const uint32_t* __restrict__ keybits, float* __restrict__ out,
                                                                int B, int F, int split_out, const AttnGeom g,
                                                                const int32_t* __restrict__ row_off, int shared_qkv) {
-    __shared__ __attribute__((aligned(16))) __bf16 Kp[2 * SA_FMAX * DH];      // hi plane, lo plane; first the fp32 staging of V
-    __shared__ __attribute__((aligned(16))) __bf16 Vt[2 * DH * SB_VLD];       // hi plane, lo plane, [d][key]
-    __bf16* const Kh = Kp; __bf16* const Kl = Kp + SA_FMAX * DH;
-    __bf16* const Vth = Vt; __bf16* const Vtl = Vt + DH * SB_VLD;
+    __shared__ __attribute__((aligned(16))) s16 Kp[2 * SA_FMAX * DH];      // hi plane, lo plane; first the fp32 staging of V
+    __shared__ __attribute__((aligned(16))) s16 Vt[2 * DH * SB_VLD];       // hi plane, lo plane, [d][key]
+    s16* const Kh = Kp; s16* const Kl = Kp + SA_FMAX * DH;
+    s16* const Vth = Vt; s16* const Vtl = Vt + DH * SB_VLD;
     float* const Vtmp = reinterpret_cast<float*>(Kp);                         // [key][64] fp32 = exactly the two K planes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / g.nheads, h = blockIdx.x % g.nheads;
@@ -211,7 +210,7 @@ __global__ __launch_bounds__(512) void self_attn_bf16x3_kernel(const float* __re
     const int q = lane & 31, h2 = lane >> 5;
     const int qrow = qt * 32 + q;
 
-    bf16x8 qh[4], ql[4];
+    s16x8 qh[4], ql[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -249,14 +248,10 @@ __global__ __launch_bounds__(512) void self_attn_bf16x3_kernel(const float* __re
         for (int p = 0; p < 7; ++p) {
             const int k0 = (p * 8 + kg) * 4;
             if (k0 < nkt * 32) {
-                bf16x4 hi, lo;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = Vtmp[(k0 + e) * DH + d];
-                    hi[e] = (__bf16)v; lo[e] = (__bf16)(v - (float)hi[e]);
-                }
-                *reinterpret_cast<bf16x4*>(Vth + d * SB_VLD + k0) = hi;
-                *reinterpret_cast<bf16x4*>(Vtl + d * SB_VLD + k0) = lo;
+                s16x4 hi, lo;
+                split4(Vtmp[k0 * DH + d], Vtmp[(k0 + 1) * DH + d], Vtmp[(k0 + 2) * DH + d], Vtmp[(k0 + 3) * DH + d], hi, lo);
+                *reinterpret_cast<s16x4*>(Vth + d * SB_VLD + k0) = hi;
+                *reinterpret_cast<s16x4*>(Vtl + d * SB_VLD + k0) = lo;
             }
         }
     }
@@ -265,12 +260,11 @@ __global__ __launch_bounds__(512) void self_attn_bf16x3_kernel(const float* __re
     for (int it = 0; it < 7; ++it) {
         const int id = tid + it * 512, r = id >> 4, c = id & 15;
         if (r < nkt * 32) {
-            bf16x4 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { hi[e] = (__bf16)kk[it][e]; lo[e] = (__bf16)(kk[it][e] - (float)hi[e]); }
+            s16x4 hi, lo;
+            split4(kk[it], hi, lo);
             const int off = r * DH + ((((c >> 1) ^ ((r >> 1) & 7)) << 3) | ((c & 1) << 2));   // bf16 elements
-            *reinterpret_cast<bf16x4*>(Kh + off) = hi;
-            *reinterpret_cast<bf16x4*>(Kl + off) = lo;
+            *reinterpret_cast<s16x4*>(Kh + off) = hi;
+            *reinterpret_cast<s16x4*>(Kl + off) = lo;
         }
     }
     __syncthreads();
@@ -289,11 +283,11 @@ __global__ __launch_bounds__(512) void self_attn_bf16x3_kernel(const float* __re
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int off = r * DH + (((2 * ks + h2) ^ ((r >> 1) & 7)) << 3);
-                const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Kh + off);
-                const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + off);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[ks], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[ks], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], acc, 0, 0, 0);
+                const s16x8 kh = *reinterpret_cast<const s16x8*>(Kh + off);
+                const s16x8 kl = *reinterpret_cast<const s16x8*>(Kl + off);
+                acc = MFMA32_S16(kl, qh[ks], acc, 0, 0, 0);
+                acc = MFMA32_S16(kh, ql[ks], acc, 0, 0, 0);
+                acc = MFMA32_S16(kh, qh[ks], acc, 0, 0, 0);
             }
             if (kb[kt] == 0xFFFFFFFFu && !g.causal) {             // every key of the tile is valid (wave-uniform): no masking
 #pragma unroll
@@ -338,20 +332,20 @@ __global__ __launch_bounds__(512) void self_attn_bf16x3_kernel(const float* __re
                 float pv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pv[j] = sT[kt][8 * mm + j];
-                bf16x8 ph, pl;
+                s16x8 ph, pl;
                 split8(pv, ph, pl);
                 const int k1 = 32 * kt + 16 * mm + 4 * h2;            // keys k1 .. k1+3 and k1+8 .. k1+11
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int voff = (32 * t + q) * SB_VLD + k1;
-                    const bf16x4 h_a = *reinterpret_cast<const bf16x4*>(Vth + voff), h_b = *reinterpret_cast<const bf16x4*>(Vth + voff + 8);
-                    const bf16x4 l_a = *reinterpret_cast<const bf16x4*>(Vtl + voff), l_b = *reinterpret_cast<const bf16x4*>(Vtl + voff + 8);
-                    const bf16x8 vh = {h_a[0], h_a[1], h_a[2], h_a[3], h_b[0], h_b[1], h_b[2], h_b[3]};
-                    const bf16x8 vl = {l_a[0], l_a[1], l_a[2], l_a[3], l_b[0], l_b[1], l_b[2], l_b[3]};
+                    const s16x4 h_a = *reinterpret_cast<const s16x4*>(Vth + voff), h_b = *reinterpret_cast<const s16x4*>(Vth + voff + 8);
+                    const s16x4 l_a = *reinterpret_cast<const s16x4*>(Vtl + voff), l_b = *reinterpret_cast<const s16x4*>(Vtl + voff + 8);
+                    const s16x8 vh = {h_a[0], h_a[1], h_a[2], h_a[3], h_b[0], h_b[1], h_b[2], h_b[3]};
+                    const s16x8 vl = {l_a[0], l_a[1], l_a[2], l_a[3], l_b[0], l_b[1], l_b[2], l_b[3]};
                     f32x16& o = t == 0 ? o0 : o1;
-                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o, 0, 0, 0);
-                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o, 0, 0, 0);
-                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o, 0, 0, 0);
+                    o = MFMA32_S16(vl, ph, o, 0, 0, 0);
+                    o = MFMA32_S16(vh, pl, o, 0, 0, 0);
+                    o = MFMA32_S16(vh, ph, o, 0, 0, 0);
                 }
             }
         }
@@ -377,14 +371,14 @@ __global__ __launch_bounds__(512) void self_attn_bf16x3_kernel(const float* __re
     }
 }
 
-// bf16x3 entry (same arguments as launch_self_attention)
-int launch_self_attention_bf16x3(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
+// f16x3 entry (same arguments as launch_self_attention)
+int launch_self_attention_split(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
                                  int nheads, int causal, int split_out, hipStream_t s, const int32_t* row_off, int shared_qkv) {
     if (F > SA_FMAX || F < 1 || nheads < 1) return LADIFF_ERR_SHAPE;
     if (B == 0) return 0;
     const int W = nheads * DH;
     const AttnGeom g{nheads, 3 * W, W, 2 * W, W, causal};
-    hipLaunchKernelGGL(self_attn_bf16x3_kernel, dim3(B * nheads), dim3(512), 0, s, qkv, lengths, keybits, out, B, F, split_out, g, row_off, shared_qkv);
+    hipLaunchKernelGGL(self_attn_split_kernel, dim3(B * nheads), dim3(512), 0, s, qkv, lengths, keybits, out, B, F, split_out, g, row_off, shared_qkv);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }

@@ -8,7 +8,7 @@
 // evaluated (L >= 1 + max EOS index over the batch, chosen by the host from the token ids); rows behind are never built.
 // Rows are batch-major (row = b * L + t) - or RAGGED (round 5): prompt b owns rows [row_off[b], row_off[b + 1]) = its OWN positions
 // 0 .. eos_b (the same argument per prompt: nothing behind a prompt's EOS reaches its pooled row), 2.3x fewer rows than the padded
-// batch for prompts of 1 .. 30 words; q / k / v are one batched GEMM launch.  Large GEMMs go through launch_gemm (fp32 MFMA, or bf16x3 with S-format
+// batch for prompts of 1 .. 30 words; q / k / v are one batched GEMM launch.  Large GEMMs go through launch_gemm (fp32 MFMA, or f16x3 with S-format
 // operands when a split weight table is given); the attention core is the decoder's MFMA kernel with 12 heads + causal.
 #include "model.h"
 
@@ -54,14 +54,15 @@ __device__ __forceinline__ void wide_stats(const f32x4 (&v)[CNV], float& mean, f
 
 // x[b*L+t] = token_embedding[ids[b*S+t]] + position_embedding[t]          (CLIPTextEmbeddings.forward)
 __global__ __launch_bounds__(256) void clip_embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ tok,
-                                                         const float* __restrict__ pos, int vocab, int M, int S, int L,
+                                                         const float* __restrict__ pos, int vocab, int B, int M, int S, int L,
                                                          const int32_t* __restrict__ row_seq, const int32_t* __restrict__ row_off,
                                                          float* __restrict__ x) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     int b, t;
-    if (row_seq != nullptr) { b = row_seq[row]; t = row - row_off[b]; }      // ragged rows
+    if (row_seq != nullptr) { b = row_seq[row]; b = b < 0 ? 0 : (b >= B ? B - 1 : b); t = row - row_off[b]; }      // ragged rows
     else { b = row / L; t = row - b * L; }
+    t = t < 0 ? 0 : (t >= L ? L - 1 : t);      // the three ragged arrays come from the caller: inconsistent ones must not read outside ids / pos (L <= S <= 77)
     long long id = ids[(size_t)b * S + t];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);          // ids are validated on the host; clamp for memory safety only
     const int c = (threadIdx.x & 63) * 4;
@@ -159,7 +160,7 @@ int clip_text_encode(const ClipW& w, const ClipW* wsp, int n_layers, int vocab, 
         return launch_gemm(g, s);
     };
 
-    hipLaunchKernelGGL(clip_embed_kernel, dim3((M + 3) / 4), dim3(256), 0, s, ids, w.tok, w.pos, vocab, M, S, L, row_seq, row_off, x);
+    hipLaunchKernelGGL(clip_embed_kernel, dim3((M + 3) / 4), dim3(256), 0, s, ids, w.tok, w.pos, vocab, B, M, S, L, row_seq, row_off, x);
     LADIFF_LAUNCH_CHECK();
     if (!ragged) {
         hipLaunchKernelGGL(clip_eos_kernel, dim3(B), dim3(64), 0, s, ids, S, L, eos);
@@ -183,7 +184,7 @@ int clip_text_encode(const ClipW& w, const ClipW* wsp, int n_layers, int vocab, 
             }
             LADIFF_TRY(launch_gemm_batch(g3, 3, s));
         }
-        if (sp) LADIFF_TRY(launch_self_attention_bf16x3(qkv, seq_len, nullptr, att, B, L, CH, 1, 1, s, row_off, 0));
+        if (sp) LADIFF_TRY(launch_self_attention_split(qkv, seq_len, nullptr, att, B, L, CH, 1, 1, s, row_off, 0));
         else LADIFF_TRY(launch_self_attention(qkv, seq_len, nullptr, att, B, L, CH, 1, 0, s, row_off));
         LADIFF_TRY(gemm(att, CW, W.o, Ws.o, x2, CW, CW, ACT_NONE, x, false));             // x2 = x + out_proj(attn)
         LADIFF_TRY(ln_rows(x2, nullptr, 0, W.ln2, M, sp ? nullptr : h, sp ? h : nullptr, s));

@@ -135,27 +135,70 @@ __device__ __forceinline__ float wave_sum(float v) {    // sum over the 64 lanes
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-// ---- bf16x3 "split" format (S-format).  A row of K fp32 values occupies the same K*4 bytes as K/64 blocks of
-// [64 x bf16 hi | 64 x bf16 lo] with x ~ hi + lo (16 significant bits).  A product of two split operands is evaluated as
-// hi*hi + hi*lo + lo*hi on the bf16 MFMA (fp32 accumulate): relative error ~2^-16 per product, measured 9e-5 on the
-// decoded frames of the 50-step benchmark against 1e-3 allowed; exponent range = fp32's.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// ---- "split" format (S-format).  A row of K fp32 values occupies the same K*4 bytes as K/64 blocks of
+// [64 x s16 hi | 64 x s16 lo] with x ~ hi + lo.  A product of two split operands is evaluated as hi*hi + hi*lo + lo*hi on the 16-bit
+// MFMA (fp32 accumulate).  The half type s16 is a property of the BUILD (ladiff_split_format()):
+//   * fp16 (the product since round 6, "f16x3"): 11 + 11 = 22 significant bits - a K = 768 product of random operands has an rms error
+//     of 2.7e-7 of its rms value, LESS than a sequential fp32 fma chain's 5e-7, against 4.6e-6 for bf16 pairs
+//     (scripts/ubench_mfma_f16_denorm.hip, profiles/r6/02_*); the MFMA keeps subnormal fp16 inputs (same probe), which is what the lo
+//     halves of small values are.  The price is fp16's exponent range: each half SATURATES at +-65504 (v_cvt_pkrtz_f16_f32 rounds
+//     toward zero and therefore never produces an infinity), so |x| <= 65504 is exact to 22 bits, up to 131008 degrades gracefully,
+//     beyond is clipped.  The largest GEMM operand of the path on random-init weights (the hard case: latents reach |x| ~ 280) is
+//     stated in DESIGN.md 1; every product input of these networks is a LayerNorm output, an activation of one, a softmax
+//     probability or a latent.  Same rate, same instruction count as the bf16 form (one v_cvt_pkrtz per two values where the bf16
+//     form needs one v_cvt_pk_bf16 per value).
+//   * bf16 (-DLADIFF_SPLIT_BF16, rounds 1 - 5, "bf16x3"): 16 significant bits, fp32's exponent range; 2e-4 on the decoded frames of the
+//     50-step benchmark where fp16 pairs give 3e-5.
+#ifndef LADIFF_SPLIT_BF16
+typedef _Float16 s16;                          // one half of an S-format pair
+#define MFMA16_S16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define MFMA32_S16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+__device__ __forceinline__ s16 s16_of(float v) { return (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }   // saturating
+typedef s16 s16x2 __attribute__((ext_vector_type(2)));
+// two values -> (hi, hi), (lo, lo): v_cvt_pkrtz_f16_f32 converts a pair per instruction and, rounding toward zero, SATURATES at +-65504
+// instead of producing an infinity; x - hi is exact in fp32 (hi keeps x's leading 11 bits), its conversion keeps 11 more: 22 bits.
+__device__ __forceinline__ void split2(float a, float b, s16x2& hi, s16x2& lo) {
+    hi = __builtin_bit_cast(s16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
+    lo = __builtin_bit_cast(s16x2, __builtin_amdgcn_cvt_pkrtz(a - (float)hi[0], b - (float)hi[1]));
+}
+#else
+typedef __bf16 s16;
+#define MFMA16_S16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define MFMA32_S16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+__device__ __forceinline__ s16 s16_of(float v) { return (__bf16)v; }
+typedef s16 s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2(float a, float b, s16x2& hi, s16x2& lo) {
+    hi[0] = (__bf16)a; hi[1] = (__bf16)b;
+    lo[0] = (__bf16)(a - (float)hi[0]); lo[1] = (__bf16)(b - (float)hi[1]);
+}
+#endif
+typedef s16 s16x8 __attribute__((ext_vector_type(8)));
+typedef s16 s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split4(float a, float b, float c, float d, s16x4& hi, s16x4& lo) {
+    s16x2 h0, l0, h1, l1;
+    split2(a, b, h0, l0); split2(c, d, h1, l1);
+    hi = s16x4{h0[0], h0[1], h1[0], h1[1]}; lo = s16x4{l0[0], l0[1], l1[0], l1[1]};
+}
+__device__ __forceinline__ void split4(const f32x4 v, s16x4& hi, s16x4& lo) { split4(v[0], v[1], v[2], v[3], hi, lo); }
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, s16x8& hi, s16x8& lo) {
+    s16x4 ha, la, hb, lb;
+    split4(a, ha, la); split4(b, hb, lb);
+    hi = s16x8{ha[0], ha[1], ha[2], ha[3], hb[0], hb[1], hb[2], hb[3]}; lo = s16x8{la[0], la[1], la[2], la[3], lb[0], lb[1], lb[2], lb[3]};
+}
 __device__ __forceinline__ void store_split4(float* row, int k, const float (&v)[4]) {   // columns k..k+3 of an S-format row
-    bf16x4 hi, lo;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { hi[e] = (__bf16)v[e]; lo[e] = (__bf16)(v[e] - (float)hi[e]); }
+    s16x4 hi, lo;
+    split4(v[0], v[1], v[2], v[3], hi, lo);
     char* base = reinterpret_cast<char*>(row) + ((k >> 6) << 8) + ((k & 63) << 1);
-    *reinterpret_cast<bf16x4*>(base) = hi;
-    *reinterpret_cast<bf16x4*>(base + 128) = lo;
+    *reinterpret_cast<s16x4*>(base) = hi;
+    *reinterpret_cast<s16x4*>(base + 128) = lo;
 }
 __device__ __forceinline__ void store_split4(float* row, int k, f32x4 v) {
     const float t[4] = {v[0], v[1], v[2], v[3]};
     store_split4(row, k, t);
 }
 __device__ __forceinline__ void store_split1(float* row, int k, float v) {
-    const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
-    __bf16* base = reinterpret_cast<__bf16*>(reinterpret_cast<char*>(row) + ((k >> 6) << 8)) + (k & 63);
+    const s16 hi = s16_of(v), lo = s16_of(v - (float)hi);
+    s16* base = reinterpret_cast<s16*>(reinterpret_cast<char*>(row) + ((k >> 6) << 8)) + (k & 63);
     base[0] = hi;
     base[64] = lo;
 }
@@ -175,16 +218,15 @@ __device__ __forceinline__ void reg_touch(f32x4& v) { asm volatile("" : "+v"(v))
 // pin_s() launders a pointer, so the compiler no longer knows it points to global memory and would emit flat_* accesses;
 // these say so explicitly.
 typedef __attribute__((address_space(1))) f32x4 g_f32x4;
-typedef __attribute__((address_space(1))) bf16x4 g_bf16x4;
+typedef __attribute__((address_space(1))) s16x4 g_s16x4;
 __device__ __forceinline__ void st4g(float* p, f32x4 v) { *(g_f32x4*)p = v; }
 __device__ __forceinline__ f32x4 ld4g(const float* p) { return *(const g_f32x4*)p; }
 __device__ __forceinline__ void store_split4g(float* row, int k, f32x4 v) {      // store_split4 on a global row
-    bf16x4 hi, lo;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { hi[e] = (__bf16)v[e]; lo[e] = (__bf16)(v[e] - (float)hi[e]); }
+    s16x4 hi, lo;
+    split4(v, hi, lo);
     char* base = reinterpret_cast<char*>(row) + ((k >> 6) << 8) + ((k & 63) << 1);
-    *(g_bf16x4*)base = hi;
-    *(g_bf16x4*)(base + 128) = lo;
+    *(g_s16x4*)base = hi;
+    *(g_s16x4*)(base + 128) = lo;
 }
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }

@@ -225,13 +225,13 @@ __global__ __launch_bounds__(256) void dec_cross_apply_kernel(const float* __res
 }
 
 
-// ---------------------------------------------------------------- self-attention out_proj + norm1 + the block above, one kernel (bf16x3 mode)
+// ---------------------------------------------------------------- self-attention out_proj + norm1 + the block above, one kernel (f16x3 mode)
 //   y = LN2( x1n + cross(x1n) ),  x1n = LN1( x0 + att Wo^T + bo )        cross_attention.py:369-376, :407-409
 // Before: a 128x128-tile GEMM that writes x0 + out_proj(att) (23 us at 25088 rows, 20 % MFMA use, ~80 MB moved) and the row kernel
 // above that reads it back (29 us, no MFMA, bound by the LDS: every frame row reads all 8 T KiB of its sample's G | U): 52 us per layer.
 // Here a workgroup of eight waves keeps EVERY operand that does not change in its REGISTERS for all its rows, as the stages of the
 // pipeline kernel do (tile_mma.h): Wo (256 KB in S-format; wave w: output columns 32 w .. 32 w + 31) and the sample's folded keys /
-// values as bf16x3 fragments (G: k-step w of the 32 padded (head, token) columns; U: this wave's 32 columns).  It walks its sample's
+// values as f16x3 fragments (G: k-step w of the 32 padded (head, token) columns; U: this wave's 32 columns).  It walks its sample's
 // frame rows 32 at a time, three small matrix products per pass:
 //   1. att rows (S-format, copied 16 bytes at a time into the swizzled operand tile - the global row layout IS the tile's block
 //      layout) x Wo -> staging tile -> + bias + residual, norm1 on 16 lanes per row -> x1n kept (fp32, LDS) and written as operand tile
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void dec_cross_apply_kernel(const float* __res
 //      + c, mask, softmax per head -> P as operand tile (K = 32)
 //   3. P x U [32 x 256] (12 MFMAs per wave) -> staging tile -> + bias + residual, norm2 -> y, ys
 // So the cross-attention's 20 dot products and 20 axpys of length 256 per row run on the MFMA (as hi*hi + hi*lo + lo*hi, like every
-// other product of bf16x3 mode) instead of out of the LDS, and x0 + out_proj(att) never exists in memory.
+// other product of f16x3 mode) instead of out of the LDS, and x0 + out_proj(att) never exists in memory.
 constexpr int OC_ROWS = 32;
 constexpr int OC_TILE = OC_ROWS * 1024;                                  // operand tile: att rows, then x1n rows
 constexpr int OC_CT = OC_ROWS * CLD * 4;                                 // fp32 staging tile (products 1 and 3)
@@ -348,8 +348,8 @@ __global__ __launch_bounds__(512, 1) void dec_out_cross_kernel(const OutCrossArg
 #pragma unroll
                     for (int st = 0; st < 8; ++st) {
                         const int r = 16 * j + frow;
-                        wf.hi[j][st] = *reinterpret_cast<const bf16x8*>(a_slot<4>(const_cast<char*>(srcb), r, st >> 1, 4 * (st & 1) + fk));
-                        wf.lo[j][st] = *reinterpret_cast<const bf16x8*>(a_slot<4>(const_cast<char*>(srcb), r, st >> 1, 8 + 4 * (st & 1) + fk));
+                        wf.hi[j][st] = *reinterpret_cast<const s16x8*>(a_slot<4>(const_cast<char*>(srcb), r, st >> 1, 4 * (st & 1) + fk));
+                        wf.lo[j][st] = *reinterpret_cast<const s16x8*>(a_slot<4>(const_cast<char*>(srcb), r, st >> 1, 8 + 4 * (st & 1) + fk));
                     }
             }
         }
@@ -450,15 +450,15 @@ __global__ __launch_bounds__(512, 1) void dec_out_cross_kernel(const OutCrossArg
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) as[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[i]), gf.hi[j][0], as[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) as[i][j] = MFMA16_S16(__builtin_bit_cast(s16x8, al[i]), gf.hi[j][0], as[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) as[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[i]), gf.lo[j][0], as[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) as[i][j] = MFMA16_S16(__builtin_bit_cast(s16x8, ah[i]), gf.lo[j][0], as[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) as[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[i]), gf.hi[j][0], as[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) as[i][j] = MFMA16_S16(__builtin_bit_cast(s16x8, ah[i]), gf.hi[j][0], as[i][j], 0, 0, 0);
             float* pw = ps + wave * (OC_ROWS * OC_SLD);
 #pragma unroll
             for (int i = 0; i < 2; ++i)

@@ -1,4 +1,4 @@
-// The decoder layer's feed-forward block as ONE kernel (bf16x3 mode):  y = LN3( x + W2 gelu(W1 x + b1) + b2 )  [+ a second LayerNorm]
+// The decoder layer's feed-forward block as ONE kernel (f16x3 mode):  y = LN3( x + W2 gelu(W1 x + b1) + b2 )  [+ a second LayerNorm]
 // TransformerDecoderLayer.forward_post, cross_attention.py:410-412 (+ decoder.norm, :150-151, on the last layer).
 //
 // Before: linear1 GEMM (writes the [M,1024] hidden rows, 103 MB at M = 25088) + linear2 GEMM (reads them back) + a LayerNorm row
@@ -78,7 +78,7 @@ template <int N>
 __device__ __forceinline__ void wait_lgkm(u32x4_m& a, u32x4_m& b, u32x4_m& c, u32x4_m& d) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
 }
-__device__ __forceinline__ bf16x8 as_bf(const u32x4_m v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ s16x8 as_bf(const u32x4_m v) { return __builtin_bit_cast(s16x8, v); }
 
 }  // namespace
 
@@ -110,14 +110,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void dec_mlp_kernel(const MlpArgs 
     }
 
     // ---- this wave's x rows as operand fragments: k-step s (32 columns) -> hi / lo 16 bytes of lane (row frow, k 8 fk .. + 7)
-    bf16x8 xh[RT][8], xl[RT][8];
+    s16x8 xh[RT][8], xl[RT][8];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const char* xr = reinterpret_cast<const char*>(p.xs) + (size_t)myrow[rt] * 1024 + fk * 16;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            xh[rt][s] = *reinterpret_cast<const bf16x8*>(xr + (s >> 1) * 256 + (s & 1) * 64);
-            xl[rt][s] = *reinterpret_cast<const bf16x8*>(xr + (s >> 1) * 256 + (s & 1) * 64 + 128);
+            xh[rt][s] = *reinterpret_cast<const s16x8*>(xr + (s >> 1) * 256 + (s & 1) * 64);
+            xl[rt][s] = *reinterpret_cast<const s16x8*>(xr + (s >> 1) * 256 + (s & 1) * 64 + 128);
         }
     }
     for (int i = tid; i < FF / 4; i += NT) st4(b1s + 4 * i, ld4(p.b1 + 4 * i));
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void dec_mlp_kernel(const MlpArgs 
     const unsigned rd_hi2 = rd_hi + 4 * MLP_STAGE, rd_lo2 = rd_lo + 4 * MLP_STAGE;     // slots 4..7: the offset field holds 16 bits
 
     f32x4 hacc[RT][8], oacc[RT][16];
-    bf16x8 hh[RT][4], hl[RT][4];
+    s16x8 hh[RT][4], hl[RT][4];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void dec_mlp_kernel(const MlpArgs 
         if constexpr (DIAG == 6) { fetch16_keep<so + j * 2048>(dummy[j & 3][0], ah); fetch16_keep<so + j * 2048>(dummy[j & 3][1], al); return; }
         fetch16<so + j * 2048>(wt[j & 3][0], ah); fetch16<so + j * 2048>(wt[j & 3][1], al);
     };
-    auto stage_mma = [&](auto slotc, auto& acc, auto j0c, const bf16x8 (&bh)[RT], const bf16x8 (&bl)[RT], auto&& between, auto&& next) __attribute__((always_inline)) {
+    auto stage_mma = [&](auto slotc, auto& acc, auto j0c, const s16x8 (&bh)[RT], const s16x8 (&bl)[RT], auto&& between, auto&& next) __attribute__((always_inline)) {
         constexpr int slot = decltype(slotc)::value, J0 = decltype(j0c)::value;
         static_for<8>([&](auto jc) {
             constexpr int j = decltype(jc)::value, cur = j & 3;
@@ -194,11 +194,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void dec_mlp_kernel(const MlpArgs 
             static_for<3 * RT>([&](auto mc) {
                 constexpr int m = decltype(mc)::value, prod = m / RT, rt = m % RT;
                 if constexpr (DIAG == 7) {                               // waits as in the real kernel, operands that no read wrote
-                    acc[rt][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(dummy[cur][prod == 1]), prod == 0 ? bl[rt] : bh[rt], acc[rt][J0 + j], 0, 0, 0);
+                    acc[rt][J0 + j] = MFMA16_S16(as_bf(dummy[cur][prod == 1]), prod == 0 ? bl[rt] : bh[rt], acc[rt][J0 + j], 0, 0, 0);
                 } else if constexpr (DIAG != 2) {
-                    if constexpr (prod == 0) acc[rt][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wt[cur][0]), bl[rt], acc[rt][J0 + j], 0, 0, 0);
-                    else if constexpr (prod == 1) acc[rt][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wt[cur][1]), bh[rt], acc[rt][J0 + j], 0, 0, 0);
-                    else acc[rt][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf(wt[cur][0]), bh[rt], acc[rt][J0 + j], 0, 0, 0);
+                    if constexpr (prod == 0) acc[rt][J0 + j] = MFMA16_S16(as_bf(wt[cur][0]), bl[rt], acc[rt][J0 + j], 0, 0, 0);
+                    else if constexpr (prod == 1) acc[rt][J0 + j] = MFMA16_S16(as_bf(wt[cur][1]), bh[rt], acc[rt][J0 + j], 0, 0, 0);
+                    else acc[rt][J0 + j] = MFMA16_S16(as_bf(wt[cur][0]), bh[rt], acc[rt][J0 + j], 0, 0, 0);
                 }
                 if constexpr (m == 0) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void dec_mlp_kernel(const MlpArgs 
 #pragma unroll
                         for (int j = 0; j < 8; ++j) hacc[rt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                bf16x8 bh[RT], bl[RT];
+                s16x8 bh[RT], bl[RT];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) { bh[rt] = xh[rt][u]; bl[rt] = xl[rt][u]; }
                 stage_mma(IntC<slot>{}, hacc, IntC<0>{}, bh, bl, between, next);
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void dec_mlp_kernel(const MlpArgs 
                         split8(va, vb, hh[rt][c], hl[rt][c]);
                     }
                 }
-                bf16x8 bh[RT], bl[RT];
+                s16x8 bh[RT], bl[RT];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) { bh[rt] = hh[rt][c]; bl[rt] = hl[rt][c]; }
                 stage_mma(IntC<slot>{}, oacc, IntC<8 * nh>{}, bh, bl, between, next);

@@ -1,9 +1,9 @@
-// Decoder self-attention with its in_proj inside (bf16x3 mode): one workgroup per (sample, head) computes that head's q | k | v rows
+// Decoder self-attention with its in_proj inside (f16x3 mode): one workgroup per (sample, head) computes that head's q | k | v rows
 // from the S-format x rows and attends, instead of an in_proj GEMM that writes [M, 768] fp32 (77 MB at M = 25088) and an attention
 // kernel that reads it back and re-splits it (cross_attention.py:367-369; nn.MultiheadAttention's packed in_proj).
 //
 //   * wave w owns frame rows 32 w .. 32 w + 31 both as queries and as keys / values.  Its x rows are MFMA operand fragments in
-//     registers (16 k-steps x (hi, lo) bf16x8 per lane, loaded straight from the S-format rows).
+//     registers (16 k-steps x (hi, lo) s16x8 per lane, loaded straight from the S-format rows).
 //   * the head's 192 in_proj rows (64 q, 64 k, 64 v) stream through LDS as twelve 16-KiB stages (32 weight rows x 128 k, hi and lo
 //     planes) by LDS-DMA; a stage's fragment = one conflict-free ds_read_b128 per lane, issued by asm one k-step ahead of its MFMAs.
 //     The stages land in the K / V image areas while those are not written yet (eight of the twelve are requested before the
@@ -15,7 +15,7 @@
 //     q operand fragment of k-step 2 T + j of the score product (no cross-lane move), and the same registers of a k^T tile are one
 //     16-byte write into chunk 2 (2 T + j) + h2 of the K image.  A v tile has its d on the lane and four consecutive keys per
 //     register quad: an 8-byte write into the transposed V image the output product reads.
-//   * then the score / softmax / output core of self_attn_bf16x3_kernel (attention.hip), unchanged: S^T = K Q^T, fp32 softmax in
+//   * then the score / softmax / output core of self_attn_split_kernel (attention.hip), unchanged: S^T = K Q^T, fp32 softmax in
 //     base 2, O^T = V^T P^T, every product as lo*hi + hi*lo + hi*hi.
 //   * the four heads of a sample get block ids of one residue class mod 8 (one XCD, one L2: they read the same x rows); the S-format
 //     result leaves through the dead K image as whole 256-byte blocks.
@@ -92,9 +92,8 @@ __device__ __forceinline__ void v_read2(u32x4_q& v, unsigned addr) {
     asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(OFF8), "n"(OFF8 + 2) : "memory");
 }
 
-__device__ __forceinline__ void split8v(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { hi[e] = (__bf16)v[e]; lo[e] = (__bf16)(v[e] - (float)hi[e]); }
+__device__ __forceinline__ void split8v(const float (&v)[8], s16x8& hi, s16x8& lo) {
+    split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
 }
 
 }  // namespace
@@ -104,10 +103,10 @@ __device__ __forceinline__ void split8v(const float (&v)[8], bf16x8& hi, bf16x8&
 template <int DIAG = 0>
 __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
-    __bf16* const Kh = reinterpret_cast<__bf16*>(lds);
-    __bf16* const Kl = Kh + QA_FMAX * DH;
-    __bf16* const Vth = reinterpret_cast<__bf16*>(lds + QA_K_BYTES);
-    __bf16* const Vtl = Vth + DH * QA_VLD;
+    s16* const Kh = reinterpret_cast<s16*>(lds);
+    s16* const Kl = Kh + QA_FMAX * DH;
+    s16* const Vth = reinterpret_cast<s16*>(lds + QA_K_BYTES);
+    s16* const Vtl = Vth + DH * QA_VLD;
     char* const ring = lds + QA_K_BYTES + QA_V_BYTES;
     float* const bsm = reinterpret_cast<float*>(ring + 2 * QA_STAGE);          // [q 64 | k 64 | v 64] of this head
     const int tid = threadIdx.x, lane = tid & 63;
@@ -160,7 +159,7 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
         }
     };
 
-    bf16x8 qh[4], ql[4];
+    s16x8 qh[4], ql[4];
     f32x16 acc;
     const unsigned lds_lane = lds_addr(lds) + lane * 16;
     if constexpr (DIAG != 4) static_for<8>([&](auto gc) { issue(gc); });
@@ -174,7 +173,7 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
     // The scratch areas are LDS nobody else uses before the stage loop: the 8-KiB tail of the K image (waves 0, 1), 8 KiB of the V
     // image's tail (2, 3), 12 KiB behind the bias table (4 - 6; wave 7 never has rows: QA_FMAX = 7 x 32).  All LDS traffic is asm
     // (the compiler would put a `vmcnt(0)` - the weight stages in flight - in front of every plain access), same wave writes and reads.
-    bf16x8 xh[16], xl[16];
+    s16x8 xh[16], xl[16];
     {
         const bool live = qrow < F;
         unsigned scr = lds_addr(lds) + (wave < 2 ? 3 * QA_STAGE + wave * 4096
@@ -222,10 +221,10 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
         }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            if (live && active && DIAG != 5) { xh[s] = __builtin_bit_cast(bf16x8, xq[0][s]); xl[s] = __builtin_bit_cast(bf16x8, xq[1][s]); }
+            if (live && active && DIAG != 5) { xh[s] = __builtin_bit_cast(s16x8, xq[0][s]); xl[s] = __builtin_bit_cast(s16x8, xq[1][s]); }
             else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { xh[s][e] = (__bf16)0.f; xl[s][e] = (__bf16)0.f; }
+                for (int e = 0; e < 8; ++e) { xh[s][e] = s16_of(0.f); xl[s][e] = s16_of(0.f); }
             }
         }
     }
@@ -280,17 +279,17 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh[cur]), "+v"(fl[cur]));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 wh = __builtin_bit_cast(bf16x8, fh[cur]), wl = __builtin_bit_cast(bf16x8, fl[cur]);
-                const bf16x8 bh = xh[8 * khalf + s], bl = xl[8 * khalf + s];
+                const s16x8 wh = __builtin_bit_cast(s16x8, fh[cur]), wl = __builtin_bit_cast(s16x8, fl[cur]);
+                const s16x8 bh = xh[8 * khalf + s], bl = xl[8 * khalf + s];
                 if constexpr (DIAG == 3) { acc[s] += (float)wh[0] + (float)wl[1] + (float)bh[2] + (float)bl[3]; }
                 else if constexpr (T < 4) {        // q^T / k^T tile: [32 d x 32 rows] += W . x^T
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, bh, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bl, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, acc, 0, 0, 0);
+                    acc = MFMA32_S16(wl, bh, acc, 0, 0, 0);
+                    acc = MFMA32_S16(wh, bl, acc, 0, 0, 0);
+                    acc = MFMA32_S16(wh, bh, acc, 0, 0, 0);
                 } else {                           // v tile: [32 rows x 32 d] += x . W^T
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, wh, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, wl, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, wh, acc, 0, 0, 0);
+                    acc = MFMA32_S16(bl, wh, acc, 0, 0, 0);
+                    acc = MFMA32_S16(bh, wl, acc, 0, 0, 0);
+                    acc = MFMA32_S16(bh, wh, acc, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -323,12 +322,12 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
                             const int i = 8 * j + e, d = 32 * Tk + (i & 3) + 8 * (i >> 2) + 4 * h2;
                             v[e] = acc[i] + bsm[DH + d];
                         }
-                        bf16x8 hi, lo;
+                        s16x8 hi, lo;
                         split8v(v, hi, lo);
                         const int ks = 2 * Tk + j;
                         const int off = qrow * DH + (((2 * ks + h2) ^ ((qrow >> 1) & 7)) << 3);
-                        *reinterpret_cast<bf16x8*>(Kh + off) = hi;
-                        *reinterpret_cast<bf16x8*>(Kl + off) = lo;
+                        *reinterpret_cast<s16x8*>(Kh + off) = hi;
+                        *reinterpret_cast<s16x8*>(Kl + off) = lo;
                     }
                 } else {                           // v: lane = d, four consecutive keys per register quad
                     constexpr int Tv = T - 4;
@@ -336,15 +335,11 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
                     const float bv = bsm[2 * DH + d];
 #pragma unroll
                     for (int grp = 0; grp < 4; ++grp) {
-                        bf16x4 hi, lo;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float v = acc[4 * grp + e] + bv;
-                            hi[e] = (__bf16)v; lo[e] = (__bf16)(v - (float)hi[e]);
-                        }
+                        s16x4 hi, lo;
+                        split4(acc[4 * grp] + bv, acc[4 * grp + 1] + bv, acc[4 * grp + 2] + bv, acc[4 * grp + 3] + bv, hi, lo);
                         const int key0 = 32 * qt + 8 * grp + 4 * h2;
-                        *reinterpret_cast<bf16x4*>(Vth + d * QA_VLD + key0) = hi;
-                        *reinterpret_cast<bf16x4*>(Vtl + d * QA_VLD + key0) = lo;
+                        *reinterpret_cast<s16x4*>(Vth + d * QA_VLD + key0) = hi;
+                        *reinterpret_cast<s16x4*>(Vtl + d * QA_VLD + key0) = lo;
                     }
                 }
             }
@@ -361,7 +356,7 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
         return;
     }
 
-    // ---- scores, softmax, output: the arithmetic of self_attn_bf16x3_kernel (attention.hip).  The K / V fragments are read by asm
+    // ---- scores, softmax, output: the arithmetic of self_attn_split_kernel (attention.hip).  The K / V fragments are read by asm
     // one step ahead of the MFMAs that use them (the compiler read every fragment through one register quad and waited for it in
     // front of each MFMA group: ~280 exposed LDS round trips per wave, most of this phase).  A read past the last valid key tile
     // fetches LDS bytes nobody uses.
@@ -389,10 +384,10 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
                     frag_read<kt2 * 32 * DH * 2 + KLO>(fb[cur ^ 1], ka[ks2]);
                     asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[cur]), "+v"(fb[cur]));
                     __builtin_amdgcn_sched_barrier(0);
-                    const bf16x8 kh = __builtin_bit_cast(bf16x8, fa[cur]), kl = __builtin_bit_cast(bf16x8, fb[cur]);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[ks], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[ks], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], a, 0, 0, 0);
+                    const s16x8 kh = __builtin_bit_cast(s16x8, fa[cur]), kl = __builtin_bit_cast(s16x8, fb[cur]);
+                    a = MFMA32_S16(kl, qh[ks], a, 0, 0, 0);
+                    a = MFMA32_S16(kh, ql[ks], a, 0, 0, 0);
+                    a = MFMA32_S16(kh, qh[ks], a, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 if (kb[kt] == 0xFFFFFFFFu) {
@@ -450,7 +445,7 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
                     float pv[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pv[j] = sT[kt][8 * mm + j];
-                    bf16x8 ph, pl;
+                    s16x8 ph, pl;
                     split8v(pv, ph, pl);
                     static_for<2>([&](auto tc) {
                         constexpr int t = decltype(tc)::value, n = (2 * kt + mm) * 2 + t, cur = n & 1;
@@ -459,11 +454,11 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
                         v_read2<4 * km2>(fb[cur ^ 1], t2 == 0 ? vl0 : vl1);
                         asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[cur]), "+v"(fb[cur]));
                         __builtin_amdgcn_sched_barrier(0);
-                        const bf16x8 vh = __builtin_bit_cast(bf16x8, fa[cur]), vl = __builtin_bit_cast(bf16x8, fb[cur]);
+                        const s16x8 vh = __builtin_bit_cast(s16x8, fa[cur]), vl = __builtin_bit_cast(s16x8, fb[cur]);
                         f32x16& o = t == 0 ? o0 : o1;
-                        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o, 0, 0, 0);
-                        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o, 0, 0, 0);
-                        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o, 0, 0, 0);
+                        o = MFMA32_S16(vl, ph, o, 0, 0, 0);
+                        o = MFMA32_S16(vh, pl, o, 0, 0, 0);
+                        o = MFMA32_S16(vh, ph, o, 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     });
                 });
@@ -484,16 +479,15 @@ __global__ __launch_bounds__(512) void dec_qkv_attn_kernel(const QkvAttnArgs p) 
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                bf16x4 hi, lo;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = (t == 0 ? o0[4 * rg + e] : o1[4 * rg + e]) * inv;
-                    hi[e] = (__bf16)v; lo[e] = (__bf16)(v - (float)hi[e]);
+                s16x4 hi, lo;
+                {
+                    const f32x16& o = t == 0 ? o0 : o1;
+                    split4(o[4 * rg] * inv, o[4 * rg + 1] * inv, o[4 * rg + 2] * inv, o[4 * rg + 3] * inv, hi, lo);
                 }
                 const int d = 32 * t + 8 * rg + 4 * h2;                     // four consecutive columns d .. d + 3 of row q
                 char* at = stg + q * 256 + ((((d >> 3) ^ q) & 7) << 4) + (d & 4) * 2;
-                *reinterpret_cast<bf16x4*>(at) = hi;
-                *reinterpret_cast<bf16x4*>(at + 128) = lo;
+                *reinterpret_cast<s16x4*>(at) = hi;
+                *reinterpret_cast<s16x4*>(at + 128) = lo;
             }
         // (same wave writes and reads: program order; the compiler counts its own LDS operations)
 #pragma unroll

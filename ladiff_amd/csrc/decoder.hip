@@ -36,7 +36,7 @@ size_t dec_ws_floats(int B, size_t rows, int T) {
            (size_t)LADIFF_MAX_FRAMES * (2 * D + 3 * D);       // layer 0: the position table as a GEMM operand and its q|k|v
 }
 
-// wsp != nullptr selects the bf16x3 matrix path (S-format copies of the weight matrices in `wsp`, GEMM operands in
+// wsp != nullptr selects the f16x3 matrix path (S-format copies of the weight matrices in `wsp`, GEMM operands in
 // S-format, LayerNorm as a row kernel after each fused GEMM); see denoiser.hip and common.h.
 // row_off != nullptr (B + 1 entries, row_off[B] = R): RAGGED rows - sample b owns rows [row_off[b], row_off[b] + lengths[b]) and
 // only the R valid frames of a mixed-length batch are computed.  Every op of the decoder is per row or per sample (padded
@@ -91,7 +91,7 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
     }
 
     // Few frame rows (config c1: 8 x 60 = 480): a 128x128-tile launch is then 8 - 32 workgroups that each walk the whole K, ~16 us per
-    // GEMM whatever its size (profiles/r3: 40 of them were 0.63 of a 0.9 ms decode).  Below DEC_SMALL_ROWS the bf16x3 path runs its
+    // GEMM whatever its size (profiles/r3: 40 of them were 0.63 of a 0.9 ms decode).  Below DEC_SMALL_ROWS the f16x3 path runs its
     // GEMMs on the denoiser's small-M kernels instead (gemm_kr.hip: K-resident 32 / 64 / 80-row tiles, K = 1024 as four partial planes
     // that the LayerNorm row pass sums) - the same S-format operands and products, 3 - 4x the workgroups.
     const bool small = sp && M < DEC_SMALL_ROWS && g_dec_small_rows_path;
@@ -107,7 +107,7 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
     };
 
     // GEMM + (residual) + LayerNorm: fused epilogue in the fp32 path; GEMM(+residual) then a LayerNorm row kernel in the
-    // bf16x3 path.  `A`/`As`: operand in fp32 / S-format; result (fp32 + S-format twin) goes to dst / dsts.
+    // f16x3 path.  `A`/`As`: operand in fp32 / S-format; result (fp32 + S-format twin) goes to dst / dsts.
     auto gemm_ln = [&](const float* A, int K, const float* W, const float* Wsp, const float* bias, const float* res,
                        const NormW& n1, const NormW* n2, float* dst, float* dsts) -> int {
         GemmArgs g = lin(A, K, sp ? Wsp : W, bias, dst, D, M, D, K);
@@ -162,7 +162,7 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
             LADIFF_TRY(launch_gemm(g, s)); DEC_CUT();
             }
         } else if (fused_attn) {
-            // bf16x3 mode: in_proj inside the attention kernel (dec_qkv_attn.hip) - the [M, 768] q | k | v rows are never written
+            // f16x3 mode: in_proj inside the attention kernel (dec_qkv_attn.hip) - the [M, 768] q | k | v rows are never written
         } else if (small) {
             LADIFF_TRY(krs(curs, D, Ls.self_attn.in_w, L.self_attn.in_b, qkv, nullptr, 3 * D, 3 * D, ACT_NONE, nullptr, M)); DEC_CUT();
         } else {
@@ -172,13 +172,13 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
         }
         const float* qkv_l = shared ? qkv0 : qkv;
         if (fused_attn && !shared) { LADIFF_TRY(launch_dec_qkv_attn(curs, Ls.self_attn.in_w, L.self_attn.in_b, lengths, row_off, att, B, F, 1, s)); DEC_CUT(); }
-        else if (sp) { LADIFF_TRY(launch_self_attention_bf16x3(qkv_l, lengths, nullptr, att, B, F, H, 0, 1, s, row_off, shared)); DEC_CUT(); }
+        else if (sp) { LADIFF_TRY(launch_self_attention_split(qkv_l, lengths, nullptr, att, B, F, H, 0, 1, s, row_off, shared)); DEC_CUT(); }
         else { LADIFF_TRY(launch_decoder_self_attention(qkv_l, lengths, nullptr, att, B, F, 0, s, row_off, shared)); DEC_CUT(); }
-        // norm1: fused in the GEMM epilogue in fp32 mode; in bf16x3 mode the GEMM writes x + out_proj(att) and the only reader of
+        // norm1: fused in the GEMM epilogue in fp32 mode; in f16x3 mode the GEMM writes x + out_proj(att) and the only reader of
         // norm1's output, the cross-attention kernel below, normalises its rows as it loads them (one row kernel pass less)
         const NormW* n1_late = nullptr;
         if (sp && !small && g_dec_out_cross) {
-            // bf16x3 mode, many rows: out_proj + residual + norm1 + cross-attention + residual + norm2 in ONE kernel that keeps Wo in
+            // f16x3 mode, many rows: out_proj + residual + norm1 + cross-attention + residual + norm2 in ONE kernel that keeps Wo in
             // its registers (dec_cross.hip): x + out_proj(att) is never written
             LADIFF_TRY(launch_decoder_out_cross(att, cur, Ls.self_attn.out_w, L.self_attn.out_b, L.norm1.g, L.norm1.b, L.cross_attn.out_b,
                                                 L.norm2.g, L.norm2.b, counts, B, F, T, guws + l * gu_l, P[2], Ps[2], s, row_off)); DEC_CUT();
@@ -221,7 +221,7 @@ int vae_decode(const DecoderW& w, const DecoderW* wsp, const float* z, const int
     }
     // final_layer + zero padded frames, written as [B, F, C]   ladiff_vae.py:356-360
     if (sp && M >= DEC_SMALL_ROWS && g_dec_final_split) {
-        // bf16x3 mode: the projection runs on the large-M bf16x3 kernel over whole 128-column tiles, into the (free) hidden buffer, and a
+        // f16x3 mode: the projection runs on the large-M f16x3 kernel over whole 128-column tiles, into the (free) hidden buffer, and a
         // row kernel moves the C real columns into [B, F, C] (zeroing padded frames / scattering ragged rows): 94 us -> ~40 us at 25088
         // rows.  The tiles need Np = ceil(C / 128) 128 weight rows: the library pads the caller's C rows ITSELF (a 1-KiB-per-row copy
         // into the in_proj buffer, free by now) - a table of exactly C rows is never read past its end.

@@ -187,7 +187,7 @@ int denoiser_text_static(const DenoiserW& w, const float* text, int B2, float* c
 
 // c table rows of `n` consecutive steps; `tables_lo` = the time tables at the first of them.  Sampling loops with many steps
 // build it one window at a time (ladiff_diffusion_reverse), so the table is O(window x B), not O(steps x B).
-// wsp != NULL (bf16x3 mode): the nine out-projections run as ONE batched bf16x3 launch on S-format inputs (the table is 15 GFLOP per
+// wsp != NULL (f16x3 mode): the nine out-projections run as ONE batched f16x3 launch on S-format inputs (the table is 15 GFLOP per
 // 50-step window at B = 128: 157 us on the fp32-input MFMA, profiles/r3/01)
 int denoiser_ctab(const DenoiserW& w, const float* tables_lo, int n, float* cache, int B2, float* u, size_t u_floats, hipStream_t s,
                   const DenoiserW* wsp) {
@@ -270,7 +270,7 @@ int linear_cross_attention(const DenoiserW& w, int layer, const float* x, const 
 //   part        = ffn.linear2(hid)                    split-K 4
 //   u           = SiLU(LN(sum part + b) * (1 + scale_t) + shift_t)   combine kernel            :152-162
 //   x'          = X3 + out_layers(u)                  N=256                                     :162, :261
-// bf16x3 mode (8 launches, 9 on the output blocks): the same arithmetic with the steps grouped into fused kernels -
+// f16x3 mode (8 launches, 9 on the output blocks): the same arithmetic with the steps grouped into fused kernels -
 //   [skip] gemm_rowln (concat GEMM + bias) | qkv_attn (qkv + att) | gemm_rowln (R1, X1) | linear1 | linear2 split-K |
 //   reduce_rows (X3) | ffn.linear1 | ffn.linear2 split-K | combine_gemm (u, x').
 size_t den_forward_ws_floats(int B2, int T) { return (size_t)B2 * T * (16 * D + 3 * D + D + FF + 4 * D); }
@@ -290,7 +290,7 @@ static KrArgs kr(const float* A, int lda, const float* W, const float* b, float*
 // B2); independent sample ranges can run concurrently on different streams with disjoint workspaces.
 // den_loop_io() exposes the buffer that holds both the network input and the last layer's output (loop_mode).
 //
-// ws != nullptr selects the bf16x3 matrix path: `ws` holds the S-format copies of the weight matrices (same table order
+// ws != nullptr selects the f16x3 matrix path: `ws` holds the S-format copies of the weight matrices (same table order
 // as `w`), GEMM operands travel in S-format (every tensor that is both a GEMM operand and a residual is written twice:
 // fp32 for the residual / LayerNorm consumers, S-format for the MFMA), accumulation and everything else stay fp32.
 int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tables, const int32_t* d_step, const float* cache,
@@ -318,7 +318,7 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tabl
     const float* tkv = den_cache_tkv(cache, B2, ntxt);
     const float* ctab = den_cache_ctab(cache, B2, ntxt);               // ntxt > 1: the [9][B2][4][64][64] key^T value matrices
     const int R = B2 + 1;
-    // operand view of a tensor: its S-format twin in the bf16x3 path, the fp32 tensor otherwise
+    // operand view of a tensor: its S-format twin in the f16x3 path, the fp32 tensor otherwise
     auto gemm = [&](KrArgs g) { g.split = sp ? 1 : 0; return launch_gemm_kr(g, s); };
 
     // x = cat([sample]*dup) + query_pos.pe[:T]        ladiff.py:472-474, ladiff_denoiser.py:251
@@ -354,7 +354,7 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tabl
         } else {
             LADIFF_TRY(gemm(kr(sp ? curs : cur, D, Ls.sa_attn.in_w, L.sa_attn.in_b, qkv, 3 * D, M, 3 * D, D)));
             if (ntxt > 1) {
-                // N text tokens as N extra keys (fp32 softmax in both modes); bf16x3 mode: the S-format twin of the result goes to
+                // N text tokens as N extra keys (fp32 softmax in both modes); f16x3 mode: the S-format twin of the result goes to
                 // the (still unused) hidden buffer
                 LADIFF_TRY(launch_denoiser_self_attention_general(qkv, tkv + (size_t)l * B2 * ntxt * 2 * D, ntxt, tl, DEN_OFF_TIME_KV,
                                                                   DEN_STEP_STRIDE, d_step, counts, Bs, b_lo, b_n, T, att, s));
@@ -389,7 +389,7 @@ int denoiser_forward(const DenoiserW& w, const DenoiserW* wsp, const float* tabl
         if (ntxt > 1) {
             // literal LinearTemporalCrossAttention (mdiff_transformer.py:219-247): X2 = LN2(..) -> P[1]; q = query(LN(X2));
             // u = SiLU(AdaLN(LN(softmax_d(q) . att_b)));  X3 = X2 + out(u) -> first M x 256 of the qkv buffer
-            // bf16x3 mode: the two projections run on S-format operands (3 bf16 MFMAs per product), softmax / LayerNorm / AdaLN fp32
+            // f16x3 mode: the two projections run on S-format operands (3 bf16 MFMAs per product), softmax / LayerNorm / AdaLN fp32
             LADIFF_TRY(launch_reduce_rows(part, 4, M, L.sa_lin2.b, P[2], RED_LN, L.sa_norm2.g, L.sa_norm2.b, nullptr, 0, nullptr,
                                           nullptr, 1, 1, 0, 0, P[1], nullptr, s));
             if (sp) LADIFF_TRY(launch_reduce_rows(P[1], 1, M, nullptr, nullptr, RED_LN, L.ca_norm.g, L.ca_norm.b, nullptr, 0, nullptr,

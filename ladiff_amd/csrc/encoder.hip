@@ -92,7 +92,7 @@ int vae_encode(const EncoderW& w, const EncoderW* wsp, const float* features, co
             g.split = sp ? 1 : 0;
             LADIFF_TRY(launch_gemm(g, s));
         }
-        if (sp) LADIFF_TRY(launch_self_attention_bf16x3(qkv, nullptr, keybits, att, B, S, H, 0, 1, s));
+        if (sp) LADIFF_TRY(launch_self_attention_split(qkv, nullptr, keybits, att, B, S, H, 0, 1, s));
         else LADIFF_TRY(launch_decoder_self_attention(qkv, nullptr, keybits, att, B, S, 0, s));
         LADIFF_TRY(gemm_ln(att, D, L.self_attn.out_w, Ls.self_attn.out_w, L.self_attn.out_b, cur, L.norm1, nullptr, P[1], Ps[1]));
         {

@@ -13,7 +13,7 @@ struct GemmArgs {
     const float* bias = nullptr;                 // [N] or null
     float* Y = nullptr;        int ldy = 0;      // [M, N]; may be null when Ys is set (split path)
     float* Ys = nullptr;                         // optional S-format copy of the result (row stride ldy), split path only
-    int split = 0;                               // 1: A, A2, W are S-format rows (bf16x3 products, common.h); large-M kernel only
+    int split = 0;                               // 1: A, A2, W are S-format rows (f16x3 products, common.h); large-M kernel only
     int M = 0, N = 0, K = 0;
     // epilogue, applied in this order
     int act = ACT_NONE;                          // activation on (acc + bias)

@@ -344,7 +344,7 @@ int launch_gemm_batch(const GemmArgs* list, int n, hipStream_t stream) {
     }
     const GemmArgs& a = b.a[0];
     if (a.M == 0) return 0;
-    if (a.split) {                                     // bf16x3 operands: the large-M kernel only, every set must qualify
+    if (a.split) {                                     // f16x3 operands: the large-M kernel only, every set must qualify
         for (int i = 0; i < n; ++i)
             if (!gemm_big_supported(b.a[i])) return LADIFF_ERR_SHAPE;
         return launch_gemm_big_batch(b, n, stream);

@@ -183,7 +183,7 @@ __device__ __forceinline__ void gemm_big_body(const GemmArgs& p) {
     });
 }
 
-// ---------------------------------------------------------------------------------------------- bf16x3 variant
+// ---------------------------------------------------------------------------------------------- f16x3 variant
 // Operands in S-format (common.h), every product is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 (fp32 accumulate).
 // One 128x128 tile per workgroup, 4 waves of 64x64.  A K stage is HALF an S-format block (32 k: 64 B hi + 64 B lo per
 // row), so the two stages take 64 KiB and the staged C tile 66 KiB: TWO workgroups fit on a CU, and one's epilogue (stores
@@ -252,31 +252,31 @@ __device__ __forceinline__ void gemm_big_split_body(const GemmArgs& p) {
     auto compute = [&](int buf) __attribute__((always_inline)) {
         const float* sa = lds + buf * STAGE + (wm * TMW) * 32;
         const float* sb = lds + buf * STAGE + (BM + wn * TNW) * 32;
-        bf16x8 ah[RM], al[RM], bh[RN], bl[RN];
+        s16x8 ah[RM], al[RM], bh[RN], bl[RN];
 #pragma unroll
         for (int i = 0; i < RM; ++i) {
             const int r = i * 16 + frow;
-            ah[i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 32 + ((fk ^ sw) << 2)));
-            al[i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 32 + (((4 + fk) ^ sw) << 2)));
+            ah[i] = __builtin_bit_cast(s16x8, ld4(sa + r * 32 + ((fk ^ sw) << 2)));
+            al[i] = __builtin_bit_cast(s16x8, ld4(sa + r * 32 + (((4 + fk) ^ sw) << 2)));
         }
 #pragma unroll
         for (int j = 0; j < RN; ++j) {
             const int r = j * 16 + frow;
-            bh[j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 32 + ((fk ^ sw) << 2)));
-            bl[j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 32 + (((4 + fk) ^ sw) << 2)));
+            bh[j] = __builtin_bit_cast(s16x8, ld4(sb + r * 32 + ((fk ^ sw) << 2)));
+            bl[j] = __builtin_bit_cast(s16x8, ld4(sb + r * 32 + (((4 + fk) ^ sw) << 2)));
         }
 #pragma unroll
         for (int i = 0; i < RM; ++i)
 #pragma unroll
-            for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < RN; ++j) acc[i][j] = MFMA16_S16(al[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < RM; ++i)
 #pragma unroll
-            for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < RN; ++j) acc[i][j] = MFMA16_S16(ah[i], bl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < RM; ++i)
 #pragma unroll
-            for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < RN; ++j) acc[i][j] = MFMA16_S16(ah[i], bh[j], acc[i][j], 0, 0, 0);
     };
 
     const int er = wave * (BM / NW) + lane / LPR;
@@ -339,7 +339,7 @@ __device__ __forceinline__ void gemm_big_split_body(const GemmArgs& p) {
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void gemm_big_split_kernel(const GemmArgs p) { gemm_big_split_body<BM, BN>(p); }
-// up to GEMM_BATCH_MAX independent same-shape bf16x3 GEMMs as one launch (grid.y = argument set): the nine layers' c-table GEMMs
+// up to GEMM_BATCH_MAX independent same-shape f16x3 GEMMs as one launch (grid.y = argument set): the nine layers' c-table GEMMs
 template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void gemm_big_split_batch_kernel(const GemmBatch b) { gemm_big_split_body<BM, BN>(b.a[blockIdx.y]); }
 

@@ -12,7 +12,7 @@ struct KrArgs {
     const float* bias = nullptr;
     float* Y = nullptr;        int ldy = 0;       // K > 256: K/256 partial planes [K/256][M][ldy] (split-K); may be null when Ys is set
     float* Ys = nullptr;                          // optional S-format copy of the result (row stride ldy), K == 256 only
-    int split = 0;                                // 1: A, A2 and W are S-format (bf16x3 products), see common.h
+    int split = 0;                                // 1: A, A2 and W are S-format (f16x3 products), see common.h
     int M = 0, N = 0, K = 0;                      // K multiple of 256
     int act = ACT_NONE;
     const float* res = nullptr; int ldres = 0;    // + residual after the activation

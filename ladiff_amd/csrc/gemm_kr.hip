@@ -64,7 +64,7 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 
 }  // namespace
 
-// fp32 mode (fp32-input MFMA); the bf16x3 mode has its own kernel below.
+// fp32 mode (fp32-input MFMA); the f16x3 mode has its own kernel below.
 template <int BM, int BN, int WM, int WN, int MT>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
     typedef Mf<MT> MM;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kr_kernel(const KrArgs p) {
     STAMP(6);
 }
 
-// ---- bf16x3 kernel: producer / consumer, 8 waves.  Waves 4-7 only issue LDS-DMA: the texture path takes 64 B/clk per
+// ---- f16x3 kernel: producer / consumer, 8 waves.  Waves 4-7 only issue LDS-DMA: the texture path takes 64 B/clk per
 // CU, so the 144 KiB of an 80x64 workgroup need ~2.3 k cycles of issue slots, and a wave that is issuing DMA cannot run
 // MFMAs in the meantime.  Waves 0-3 (one per SIMD) only compute, arranged WN x WK: each owns BM x (BN / WN) outputs over
 // 1 / WK of the K slice - with 16x16x32 MFMAs a wave tile of tm x tn reads (1/tm + 1/tn) * 4 bytes of LDS per MAC, and an
@@ -408,31 +408,31 @@ __global__ __launch_bounds__(512) void gemm_kp_kernel(const KrArgs p) {
         const float* sa = lds + ph * SUB;
         const float* sb = lds + ph * SUB + (BM + wn * TNW) * 64;
         const int ch = 4 * wk + fk, cl = 8 + 4 * wk + fk;
-        bf16x8 ah[RM], al[RM], bh[RN], bl[RN];
+        s16x8 ah[RM], al[RM], bh[RN], bl[RN];
 #pragma unroll
         for (int i = 0; i < RM; ++i) {
             const int r = i * MT + frow, x = r & 15;
-            ah[i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((ch ^ x) << 2)));
-            al[i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((cl ^ x) << 2)));
+            ah[i] = __builtin_bit_cast(s16x8, ld4(sa + r * 64 + ((ch ^ x) << 2)));
+            al[i] = __builtin_bit_cast(s16x8, ld4(sa + r * 64 + ((cl ^ x) << 2)));
         }
 #pragma unroll
         for (int j = 0; j < RN; ++j) {
             const int r = j * MT + frow, x = (BM + wn * TNW + r) & 15;
-            bh[j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((ch ^ x) << 2)));
-            bl[j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((cl ^ x) << 2)));
+            bh[j] = __builtin_bit_cast(s16x8, ld4(sb + r * 64 + ((ch ^ x) << 2)));
+            bl[j] = __builtin_bit_cast(s16x8, ld4(sb + r * 64 + ((cl ^ x) << 2)));
         }
 #pragma unroll
         for (int i = 0; i < RM; ++i)
 #pragma unroll
-            for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < RN; ++j) acc[i][j] = MFMA16_S16(al[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < RM; ++i)
 #pragma unroll
-            for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < RN; ++j) acc[i][j] = MFMA16_S16(ah[i], bl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < RM; ++i)
 #pragma unroll
-            for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < RN; ++j) acc[i][j] = MFMA16_S16(ah[i], bh[j], acc[i][j], 0, 0, 0);
     };
 
     STAMP(0);

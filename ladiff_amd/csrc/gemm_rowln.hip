@@ -1,4 +1,4 @@
-// Y = [LayerNorm]( [A | A2] . W^T + bias + res ) for the 256-wide rows of the denoiser loop, bf16x3 products (S-format operands):
+// Y = [LayerNorm]( [A | A2] . W^T + bias + res ) for the 256-wide rows of the denoiser loop, f16x3 products (S-format operands):
 // the self-attention out-projection + residual + norm1 of `TransformerEncoderLayer.forward_post`
 // (mdiff_transformer.py:57-63) in ONE launch instead of GEMM + row kernel.
 //
@@ -94,27 +94,27 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const RowLnArgs p) {
         const float* sa = lds + (kt & 1) * STAGE;
         const float* sb = sa + (BM + 64 * wave) * 64;
         __builtin_amdgcn_s_barrier();              // A(kt)
-        bf16x8 ah[2], al[2], bh[2][RN], bl[2][RN];
+        s16x8 ah[2], al[2], bh[2][RN], bl[2][RN];
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const int ch = 4 * g + fk, cl = 8 + 4 * g + fk;
-            ah[g] = __builtin_bit_cast(bf16x8, ld4(sa + frow * 64 + ((ch ^ frow) << 2)));
-            al[g] = __builtin_bit_cast(bf16x8, ld4(sa + frow * 64 + ((cl ^ frow) << 2)));
+            ah[g] = __builtin_bit_cast(s16x8, ld4(sa + frow * 64 + ((ch ^ frow) << 2)));
+            al[g] = __builtin_bit_cast(s16x8, ld4(sa + frow * 64 + ((cl ^ frow) << 2)));
 #pragma unroll
             for (int j = 0; j < RN; ++j) {
                 const int r = j * 16 + frow;
-                bh[g][j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((ch ^ frow) << 2)));
-                bl[g][j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((cl ^ frow) << 2)));
+                bh[g][j] = __builtin_bit_cast(s16x8, ld4(sb + r * 64 + ((ch ^ frow) << 2)));
+                bl[g][j] = __builtin_bit_cast(s16x8, ld4(sb + r * 64 + ((cl ^ frow) << 2)));
             }
         }
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
 #pragma unroll
-            for (int j = 0; j < RN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[g], bh[g][j], acc[j], 0, 0, 0);
+            for (int j = 0; j < RN; ++j) acc[j] = MFMA16_S16(al[g], bh[g][j], acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < RN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g], bl[g][j], acc[j], 0, 0, 0);
+            for (int j = 0; j < RN; ++j) acc[j] = MFMA16_S16(ah[g], bl[g][j], acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < RN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g], bh[g][j], acc[j], 0, 0, 0);
+            for (int j = 0; j < RN; ++j) acc[j] = MFMA16_S16(ah[g], bh[g][j], acc[j], 0, 0, 0);
             if (g == 0) {                          // both fragment sets are in registers: release the stage
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();      // B(kt)
@@ -250,17 +250,18 @@ __global__ __launch_bounds__(512) void combine_gemm_kernel(const CombineGemmArgs
 #pragma unroll
             for (int i = 0; i < 4; ++i) { const float d = v[i] - mean; sq += d * d; }
             const float rstd = rsqrtf(wave_sum(sq) * (1.f / 256.f) + LN_EPS);
-            bf16x4 hi, lo;
+            s16x4 hi, lo;
+            {
+                f32x4 u;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float u = silu(((v[i] - mean) * rstd * gg[i] + bb[i]) * (1.f + sc[i]) + sh[i]);
-                hi[i] = (__bf16)u; lo[i] = (__bf16)(u - (float)hi[i]);
+                for (int i = 0; i < 4; ++i) u[i] = silu(((v[i] - mean) * rstd * gg[i] + bb[i]) * (1.f + sc[i]) + sh[i]);
+                split4(u, hi, lo);
             }
             // column c of row r lives in K stage c / 64, 16-byte slot (cc / 8) [hi] and 8 + cc / 8 [lo], slot ^ (r & 15)
             const int r = 4 * wave + e, kt = c >> 6, cc = c & 63;
             char* rowp = reinterpret_cast<char*>(As + (kt * BM + r) * 64);
-            *reinterpret_cast<bf16x4*>(rowp + ((((cc >> 3)) ^ r) << 4) + ((cc & 7) << 1)) = hi;
-            *reinterpret_cast<bf16x4*>(rowp + (((8 + (cc >> 3)) ^ r) << 4) + ((cc & 7) << 1)) = lo;
+            *reinterpret_cast<s16x4*>(rowp + ((((cc >> 3)) ^ r) << 4) + ((cc & 7) << 1)) = hi;
+            *reinterpret_cast<s16x4*>(rowp + (((8 + (cc >> 3)) ^ r) << 4) + ((cc & 7) << 1)) = lo;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -282,27 +283,27 @@ __global__ __launch_bounds__(512) void combine_gemm_kernel(const CombineGemmArgs
         const float* sa = As + kt * BM * 64;
         const float* sb = lds + (kt & 1) * STAGE + (64 * wave) * 64;
         __builtin_amdgcn_s_barrier();              // A(kt)
-        bf16x8 ah[2], al[2], bh[2][RN], bl[2][RN];
+        s16x8 ah[2], al[2], bh[2][RN], bl[2][RN];
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const int ch = 4 * g + fk, cl = 8 + 4 * g + fk;
-            ah[g] = __builtin_bit_cast(bf16x8, ld4(sa + frow * 64 + ((ch ^ frow) << 2)));
-            al[g] = __builtin_bit_cast(bf16x8, ld4(sa + frow * 64 + ((cl ^ frow) << 2)));
+            ah[g] = __builtin_bit_cast(s16x8, ld4(sa + frow * 64 + ((ch ^ frow) << 2)));
+            al[g] = __builtin_bit_cast(s16x8, ld4(sa + frow * 64 + ((cl ^ frow) << 2)));
 #pragma unroll
             for (int j = 0; j < RN; ++j) {
                 const int r = j * 16 + frow;
-                bh[g][j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((ch ^ frow) << 2)));
-                bl[g][j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((cl ^ frow) << 2)));
+                bh[g][j] = __builtin_bit_cast(s16x8, ld4(sb + r * 64 + ((ch ^ frow) << 2)));
+                bl[g][j] = __builtin_bit_cast(s16x8, ld4(sb + r * 64 + ((cl ^ frow) << 2)));
             }
         }
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
 #pragma unroll
-            for (int j = 0; j < RN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[g], bh[g][j], acc[j], 0, 0, 0);
+            for (int j = 0; j < RN; ++j) acc[j] = MFMA16_S16(al[g], bh[g][j], acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < RN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g], bl[g][j], acc[j], 0, 0, 0);
+            for (int j = 0; j < RN; ++j) acc[j] = MFMA16_S16(ah[g], bl[g][j], acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < RN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g], bh[g][j], acc[j], 0, 0, 0);
+            for (int j = 0; j < RN; ++j) acc[j] = MFMA16_S16(ah[g], bh[g][j], acc[j], 0, 0, 0);
             if (g == 0) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();      // B(kt)

@@ -87,7 +87,7 @@ int launch_decoder_self_attention(const float* qkv, const int32_t* lengths, cons
                                   int split_out, hipStream_t s, const int32_t* row_off = nullptr, int shared_qkv = 0);
 int launch_self_attention(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F, int nheads,
                           int causal, int split_out, hipStream_t s, const int32_t* row_off = nullptr);
-int launch_self_attention_bf16x3(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
+int launch_self_attention_split(const float* qkv, const int32_t* lengths, const uint32_t* keybits, float* out, int B, int F,
                                  int nheads, int causal, int split_out, hipStream_t s, const int32_t* row_off = nullptr, int shared_qkv = 0);
 int launch_decoder_cross_attention(const float* q, const float* kv, const int32_t* counts, float* out, int B, int F,
                                    int T, int split_out, hipStream_t s);

@@ -59,7 +59,7 @@ size_t dec_ws_floats(int B, size_t rows, int T);
 int vae_decode(const DecoderW& w, const DecoderW* w_split, const float* z, const int32_t* lengths, const int32_t* counts,
                const int32_t* row_off, int R, int B, int F, int T, int C, float* feats, float* ws, size_t ws_floats, hipStream_t s);
 
-// dec_mlp.hip: the decoder layer's feed-forward block (linear1, GELU, linear2, residual, LayerNorm[s]) as one kernel, bf16x3 mode
+// dec_mlp.hip: the decoder layer's feed-forward block (linear1, GELU, linear2, residual, LayerNorm[s]) as one kernel, f16x3 mode
 int launch_dec_mlp(const float* xs, const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* g3,
                    const float* be3, const float* g4, const float* be4, float* y, float* ys, int M, hipStream_t s);
 
@@ -88,7 +88,7 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
                          int step_lo, int n, int fp32, int MR, int NB, hipStream_t s, int cfg = 1, int fault_wg = -1,
                          unsigned long long timeout_ticks = 0, const NoiseGen& gen = NoiseGen{0u, 0u, 0u, 0});
 
-// qkv_attn.hip: in_proj GEMM + self-attention of the denoiser's sa_block in one launch (bf16x3 mode, S-format in / out)
+// qkv_attn.hip: in_proj GEMM + self-attention of the denoiser's sa_block in one launch (f16x3 mode, S-format in / out)
 int launch_qkv_attention(const float* x, const float* w, const float* bias, const float* text_kv, const float* tables,
                          int kv_off, int step_stride, const int32_t* d_step, const int32_t* counts, int Bs, int b_off,
                          int b_n, int T, float* out, hipStream_t s);

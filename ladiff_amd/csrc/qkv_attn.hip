@@ -1,4 +1,4 @@
-// Self-attention input projection + attention core of the denoiser's sa_block in ONE launch (bf16x3 mode):
+// Self-attention input projection + attention core of the denoiser's sa_block in ONE launch (f16x3 mode):
 //   qkv = x . in_proj_weight^T + in_proj_bias ; per head: softmax(q k^T / 8) v over [T latent rows | text token | time token]
 // (nn.MultiheadAttention inside TransformerEncoderLayer, mdiff_transformer.py:57-61 / :296-313; masks as in
 // den_self_attn_kernel, attention.hip).  Before: a GEMM launch (240 workgroups) + an attention launch (one workgroup per
@@ -136,21 +136,21 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnArgs p) {
             const float* sa = lds + (kt & 1) * STAGE;
             const float* sb = sa + (BM + 48 * wave) * 64;
             __builtin_amdgcn_s_barrier();          // A(kt)
-            bf16x8 ah[2][RM], al[2][RM], bh[2][RN], bl[2][RN];
+            s16x8 ah[2][RM], al[2][RM], bh[2][RN], bl[2][RN];
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const int ch = 4 * g + fk, cl = 8 + 4 * g + fk;
 #pragma unroll
                 for (int i = 0; i < RM; ++i) {
                     const int r = i * 16 + frow;
-                    ah[g][i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((ch ^ frow) << 2)));
-                    al[g][i] = __builtin_bit_cast(bf16x8, ld4(sa + r * 64 + ((cl ^ frow) << 2)));
+                    ah[g][i] = __builtin_bit_cast(s16x8, ld4(sa + r * 64 + ((ch ^ frow) << 2)));
+                    al[g][i] = __builtin_bit_cast(s16x8, ld4(sa + r * 64 + ((cl ^ frow) << 2)));
                 }
 #pragma unroll
                 for (int j = 0; j < RN; ++j) {
                     const int r = j * 16 + frow;   // (BM + 48 w + r) & 15 == frow: 48 and BM are multiples of 16
-                    bh[g][j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((ch ^ frow) << 2)));
-                    bl[g][j] = __builtin_bit_cast(bf16x8, ld4(sb + r * 64 + ((cl ^ frow) << 2)));
+                    bh[g][j] = __builtin_bit_cast(s16x8, ld4(sb + r * 64 + ((ch ^ frow) << 2)));
+                    bl[g][j] = __builtin_bit_cast(s16x8, ld4(sb + r * 64 + ((cl ^ frow) << 2)));
                 }
             }
 #pragma unroll
@@ -158,15 +158,15 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(const QkvAttnArgs p) {
 #pragma unroll
                 for (int i = 0; i < RM; ++i)
 #pragma unroll
-                    for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[g][i], bh[g][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < RN; ++j) acc[i][j] = MFMA16_S16(al[g][i], bh[g][j], acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < RM; ++i)
 #pragma unroll
-                    for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g][i], bl[g][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < RN; ++j) acc[i][j] = MFMA16_S16(ah[g][i], bl[g][j], acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < RM; ++i)
 #pragma unroll
-                    for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g][i], bh[g][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < RN; ++j) acc[i][j] = MFMA16_S16(ah[g][i], bh[g][j], acc[i][j], 0, 0, 0);
                 if (g == 0) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();  // B(kt)

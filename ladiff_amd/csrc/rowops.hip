@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void ca_table_input_batch_kernel(const RowBatc
     f32x4 v = b < B2 ? ld4(rb.a[k] + (size_t)b * D + c) : ld4(rb.g[k] + c);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = silu(v[i] * (1.f + sc[i]) + sh[i]);
-    if (split_out) store_split4(rb.y[k] + (size_t)row * D, c, v);       // the only reader is a bf16x3 GEMM: S-format operand rows
+    if (split_out) store_split4(rb.y[k] + (size_t)row * D, c, v);       // the only reader is a f16x3 GEMM: S-format operand rows
     else st4(rb.y[k] + (size_t)row * D + c, v);
 }
 int launch_ca_table_input_batch(const RowBatch& rb, int n_layers, int step_stride, int n, int B2, hipStream_t s, int split_out) {

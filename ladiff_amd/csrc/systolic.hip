@@ -1,4 +1,4 @@
-// The denoiser loop as ONE persistent, weight-stationary pipeline over the whole chip (bf16x3 mode, guidance on).
+// The denoiser loop as ONE persistent, weight-stationary pipeline over the whole chip (f16x3 mode, guidance on).
 //
 // Why: a guided DDIM step is 9 layers x ~8 dependent matrix stages on only M = 2*B*T = 1280 rows.  As separate launches
 // (denoiser.hip: 77 per step) every stage costs a kernel boundary, a ramp-up in which each of ~256 workgroups re-fetches
@@ -29,7 +29,7 @@
 // chain of flags), so there is no back-pressure channel.  Every spin is bounded (wall clock); a timeout raises an abort word
 // that all pollers watch, and the host reports it.
 //
-// Numerics: the same arithmetic as the launch-per-stage bf16x3 path (S-format operands, hi*hi + hi*lo + lo*hi on
+// Numerics: the same arithmetic as the launch-per-stage f16x3 path (S-format operands, hi*hi + hi*lo + lo*hi on
 // v_mfma_f32_16x16x32_bf16, fp32 accumulation and fp32 everything else); only the summation order of the split products
 // differs (8 hidden slices instead of 4 K-slices).
 #include <algorithm>
@@ -375,10 +375,10 @@ __device__ __forceinline__ void commit_rows(char* tile, int kb0, const Rows256<M
         const int id = threadIdx.x + 256 * WS * u, row = id >> 5, c8 = id & 31;
         const f32x4 v0 = untag4(x.v[u][0]), v1 = untag4(x.v[u][1]);
         if constexpr (AR == 0) {
-            bf16x8 hi, lo;
+            s16x8 hi, lo;
             split8(v0, v1, hi, lo);
-            *reinterpret_cast<bf16x8*>(a_slot<KB>(tile, row, kb0 + (c8 >> 3), c8 & 7)) = hi;
-            *reinterpret_cast<bf16x8*>(a_slot<KB>(tile, row, kb0 + (c8 >> 3), 8 + (c8 & 7))) = lo;
+            *reinterpret_cast<s16x8*>(a_slot<KB>(tile, row, kb0 + (c8 >> 3), c8 & 7)) = hi;
+            *reinterpret_cast<s16x8*>(a_slot<KB>(tile, row, kb0 + (c8 >> 3), 8 + (c8 & 7))) = lo;
         } else {
             tile_put4<1, KB>(tile, row, kb0 * 64 + c8 * 8, v0);
             tile_put4<1, KB>(tile, row, kb0 * 64 + c8 * 8 + 4, v1);
@@ -397,7 +397,7 @@ __device__ __forceinline__ void rows_bad(unsigned& bad, const Rows256<MR, WS>& x
 // 64-column quarters as (q3 + q2) + (q1 + q0) - what wave_sum does with its two row broadcasts.
 // Every multiply-add here is spelled out (__fmul_rn / __fsub_rn / __fmaf_rn): left to -ffp-contract the compiler fuses `mean = s / 256`
 // into the subtractions that use it in one inlining context and not in another, and the two layouts then differ in the last bit
-// of a few deviations - which the bf16x3 splits of nine layers turn into 1e-4 on the latents.
+// of a few deviations - which the f16x3 splits of nine layers turn into 1e-4 on the latents.
 __device__ __forceinline__ float part_sum4(const f32x4 v) { return v[0] + v[1] + v[2] + v[3]; }
 __device__ __forceinline__ float part_sq4(const f32x4 v, float mean) {
     float q = 0.f;
@@ -933,10 +933,10 @@ struct QkvRole {
                         const int id = tl + 256 * u, row = id >> 5, c8 = id & 31;
                         const f32x4 v0 = untag4(x[u][0]), v1 = untag4(x[u][1]);
                         if constexpr (AR == 0) {
-                            bf16x8 hi, lo;
+                            s16x8 hi, lo;
                             split8(v0, v1, hi, lo);
-                            *reinterpret_cast<bf16x8*>(a_slot<4>(atile, row, c8 >> 3, c8 & 7)) = hi;
-                            *reinterpret_cast<bf16x8*>(a_slot<4>(atile, row, c8 >> 3, 8 + (c8 & 7))) = lo;
+                            *reinterpret_cast<s16x8*>(a_slot<4>(atile, row, c8 >> 3, c8 & 7)) = hi;
+                            *reinterpret_cast<s16x8*>(a_slot<4>(atile, row, c8 >> 3, 8 + (c8 & 7))) = lo;
                         } else {
                             tile_put4<1, 4>(atile, row, c8 * 8, v0);
                             tile_put4<1, 4>(atile, row, c8 * 8 + 4, v1);
@@ -1175,10 +1175,10 @@ struct OutRole {
                         const int id = tl + 256 * u, row = id >> 5, c8 = id & 31;
                         const f32x4 v0 = untag4(x[u][0]), v1 = untag4(x[u][1]);
                         if constexpr (AR == 0) {
-                            bf16x8 hi, lo;
+                            s16x8 hi, lo;
                             split8(v0, v1, hi, lo);
-                            *reinterpret_cast<bf16x8*>(a_slot<4>(atile, row, c8 >> 3, c8 & 7)) = hi;
-                            *reinterpret_cast<bf16x8*>(a_slot<4>(atile, row, c8 >> 3, 8 + (c8 & 7))) = lo;
+                            *reinterpret_cast<s16x8*>(a_slot<4>(atile, row, c8 >> 3, c8 & 7)) = hi;
+                            *reinterpret_cast<s16x8*>(a_slot<4>(atile, row, c8 >> 3, 8 + (c8 & 7))) = lo;
                         } else {
                             tile_put4<1, 4>(atile, row, c8 * 8, v0);
                             tile_put4<1, 4>(atile, row, c8 * 8 + 4, v1);
@@ -2334,7 +2334,7 @@ static void sys_place_stages(std::vector<Stage>& st) {
 }
 
 int sys_build_stages(const DenoiserW& W, const DenoiserW& WS, float* ws, int MR, int NB, std::vector<unsigned char>& host) {
-    // WS = the S-format weight table in bf16x3 mode; in fp32 mode the caller passes the fp32 table twice
+    // WS = the S-format weight table in f16x3 mode; in fp32 mode the caller passes the fp32 table twice
     const SysLayout L = sys_layout(MR, NB);
     const RedPlan rp = red_plan(MR);
     std::vector<Stage> st;

@@ -14,14 +14,7 @@ template <int KB>
 __device__ __forceinline__ char* a_slot(char* tile, int row, int kb, int slot) {
     return tile + row * (KB * 256) + kb * 256 + (((slot ^ row) & 15) << 4);
 }
-__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        hi[e] = (__bf16)a[e]; lo[e] = (__bf16)(a[e] - (float)hi[e]);
-        hi[4 + e] = (__bf16)b[e]; lo[4 + e] = (__bf16)(b[e] - (float)hi[4 + e]);
-    }
-}
-// ---- arithmetic policy AR: 0 = bf16x3 (S-format operand tiles, 3 x v_mfma_f32_16x16x32_bf16 per product),
+// ---- arithmetic policy AR: 0 = f16x3 (S-format operand tiles, 3 x v_mfma_f32_16x16x32_bf16 per product),
 //                           1 = fp32 (fp32 operand tiles, v_mfma_f32_16x16x4_f32: exact fp32 fma chains, the strict-parity mode)
 // fp32 tile: row stride K + 4 floats, element k of a row at (k & 3) * (K / 4) + (k >> 2): the lane (row l & 15, k-phase l >> 4) of
 // the 16x16x4 MFMA reads its A values of four consecutive k-steps with ONE conflict-free ds_read_b128.
@@ -30,11 +23,10 @@ template <int AR, int KB> constexpr int tile_bytes(int rows) { return AR == 0 ? 
 template <int AR, int KB>
 __device__ __forceinline__ void tile_put4(char* tile, int row, int k0, const f32x4 v) {            // k0 % 4 == 0
     if constexpr (AR == 0) {
-        bf16x4 h4, l4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { h4[e] = (__bf16)v[e]; l4[e] = (__bf16)(v[e] - (float)h4[e]); }
-        *reinterpret_cast<bf16x4*>(a_slot<KB>(tile, row, k0 >> 6, (k0 & 63) >> 3) + (k0 & 7) * 2) = h4;
-        *reinterpret_cast<bf16x4*>(a_slot<KB>(tile, row, k0 >> 6, 8 + ((k0 & 63) >> 3)) + (k0 & 7) * 2) = l4;
+        s16x4 h4, l4;
+        split4(v, h4, l4);
+        *reinterpret_cast<s16x4*>(a_slot<KB>(tile, row, k0 >> 6, (k0 & 63) >> 3) + (k0 & 7) * 2) = h4;
+        *reinterpret_cast<s16x4*>(a_slot<KB>(tile, row, k0 >> 6, 8 + ((k0 & 63) >> 3)) + (k0 & 7) * 2) = l4;
     } else {
         float* r = reinterpret_cast<float*>(tile) + row * (KB * 64 + 4) + (k0 >> 2);
 #pragma unroll
@@ -44,9 +36,9 @@ __device__ __forceinline__ void tile_put4(char* tile, int row, int k0, const f32
 template <int AR, int KB>
 __device__ __forceinline__ void tile_put1(char* tile, int row, int k, float v) {
     if constexpr (AR == 0) {
-        const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
-        *(reinterpret_cast<__bf16*>(a_slot<KB>(tile, row, k >> 6, (k & 63) >> 3)) + (k & 7)) = hi;
-        *(reinterpret_cast<__bf16*>(a_slot<KB>(tile, row, k >> 6, 8 + ((k & 63) >> 3))) + (k & 7)) = lo;
+        const s16 hi = s16_of(v), lo = s16_of(v - (float)hi);
+        *(reinterpret_cast<s16*>(a_slot<KB>(tile, row, k >> 6, (k & 63) >> 3)) + (k & 7)) = hi;
+        *(reinterpret_cast<s16*>(a_slot<KB>(tile, row, k >> 6, 8 + ((k & 63) >> 3))) + (k & 7)) = lo;
     } else {
         reinterpret_cast<float*>(tile)[row * (KB * 64 + 4) + (k & 3) * (KB * 16) + (k >> 2)] = v;
     }
@@ -54,7 +46,7 @@ __device__ __forceinline__ void tile_put1(char* tile, int row, int k, float v) {
 
 // weights of NT column tiles x KS k-steps (of 32) for this wave, register resident: 8 VGPRs per (tile, step) in both modes
 template <int AR, int NT, int KS> struct WFrag;
-template <int NT, int KS> struct WFrag<0, NT, KS> { bf16x8 hi[NT][KS], lo[NT][KS]; };
+template <int NT, int KS> struct WFrag<0, NT, KS> { s16x8 hi[NT][KS], lo[NT][KS]; };
 template <int NT, int KS> struct WFrag<1, NT, KS> { float w[NT][KS * 8]; };
 
 // w: weight matrix (S-format for AR 0, fp32 for AR 1), row stride ldw floats; tile j covers matrix rows row_of(j) + (lane & 15);
@@ -69,8 +61,8 @@ __device__ __forceinline__ void load_w(WFrag<AR, NT, KS>& f, const float* w, int
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const char* bp = rp + (kb0 + (s >> 1)) * 256 + ((4 * (s & 1) + fk) << 4);
-                f.hi[j][s] = *reinterpret_cast<const bf16x8*>(bp);
-                f.lo[j][s] = *reinterpret_cast<const bf16x8*>(bp + 128);
+                f.hi[j][s] = *reinterpret_cast<const s16x8*>(bp);
+                f.lo[j][s] = *reinterpret_cast<const s16x8*>(bp + 128);
             }
         } else {
             const float* rp = w + (size_t)(row_of(j) + frow) * ldw + kb0 * 64 + fk;
@@ -113,7 +105,7 @@ __device__ __forceinline__ void lds_wait(u32x4_t& a) { asm volatile("s_waitcnt l
 // acc[i][j] += A(tile rows 16 i ..) . W(tile j)^T over KS k-steps of 32; MR = row tiles.  The operand fragments of the next
 // PF steps are requested before the MFMAs of the current one are issued, so their LDS latency hides under the MFMAs.
 // NTF >= NT: the fragment set may hold more column tiles than are multiplied (its first NT are used).
-// PF = how many k-steps the fragment fetches run ahead (bf16x3 tiles): a step of ONE column tile is 3 MFMAs = 48 cycles of the SIMD's
+// PF = how many k-steps the fragment fetches run ahead (f16x3 tiles): a step of ONE column tile is 3 MFMAs = 48 cycles of the SIMD's
 // matrix pipe (96 with the SIMD's second wave in the same phase) - less than an LDS read takes when all eight waves fetch at once, so
 // with PF = 1 every step of such a product waits for its fragments; PF = 2 keeps two steps in flight (8 more registers per row tile).
 // TR: the product TRANSPOSED, D^T = W . A^T (the weight fragment as the MFMA's first operand): the same products summed in the same
@@ -152,22 +144,22 @@ __device__ __forceinline__ void mma(const char* tile, const WFrag<AR, NTF, KS>& 
             __builtin_amdgcn_sched_barrier(0);
             // the three products of a split operand pair go to the same accumulator: one product at a time over all MR x NT
             // accumulators, so that consecutive MFMAs never depend on each other
-            auto mm = [&](const bf16x8 a, const bf16x8 w, const f32x4 c) __attribute__((always_inline)) {
-                if constexpr (TR) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, c, 0, 0, 0);
-                else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w, c, 0, 0, 0);
+            auto mm = [&](const s16x8 a, const s16x8 w, const f32x4 c) __attribute__((always_inline)) {
+                if constexpr (TR) return MFMA16_S16(w, a, c, 0, 0, 0);
+                else return MFMA16_S16(a, w, c, 0, 0, 0);
             };
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mm(__builtin_bit_cast(bf16x8, al[cur][i]), f.hi[j][s], acc[i][j]);
+                for (int j = 0; j < NT; ++j) acc[i][j] = mm(__builtin_bit_cast(s16x8, al[cur][i]), f.hi[j][s], acc[i][j]);
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mm(__builtin_bit_cast(bf16x8, ah[cur][i]), f.lo[j][s], acc[i][j]);
+                for (int j = 0; j < NT; ++j) acc[i][j] = mm(__builtin_bit_cast(s16x8, ah[cur][i]), f.lo[j][s], acc[i][j]);
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mm(__builtin_bit_cast(bf16x8, ah[cur][i]), f.hi[j][s], acc[i][j]);
+                for (int j = 0; j < NT; ++j) acc[i][j] = mm(__builtin_bit_cast(s16x8, ah[cur][i]), f.hi[j][s], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
         });
     } else {

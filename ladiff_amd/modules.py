@@ -108,7 +108,7 @@ class LADiffDenoiser(_HipModule):
                                       + ", ".join(unsupported))
         self._build(schema.denoiser_schema(self.latent_dim, ff_size, num_layers, text_encoded_dim))
         self.reset_parameters()
-        self.precision = kwargs.get("precision", "fp32")     # "fp32" | "bf16x3" (matrix products only)
+        self.precision = kwargs.get("precision", "fp32")     # "fp32" | "f16x3" (matrix products only)
 
     def reset_parameters(self):
         """Init as the reference's constructors leave it."""
@@ -161,7 +161,7 @@ class LADiffDenoiser(_HipModule):
         _lib.check(L.ladiff_denoiser_time_tables(wt.array, _lib.ptr(sinus), 1, _lib.ptr(tables), _lib.ptr(ws), wsb, st))
         _lib.check(L.ladiff_denoiser_text_cache(wt.array, _lib.ptr(text), B2, n_text, _lib.ptr(tables), 1, _lib.ptr(cache),
                                                 _lib.ptr(ws), wsb, st))
-        _lib.check(L.ladiff_denoiser_forward(wt.array, wt.split_array() if self.precision == "bf16x3" else None,
+        _lib.check(L.ladiff_denoiser_forward(wt.array, wt.split_array() if _lib.is_split(self.precision) else None,
                                              _lib.ptr(tables), step0.data_ptr(), _lib.ptr(cache), n_text, 1, _lib.ptr(x),
                                              B2, 1, T, None if counts is None else counts.data_ptr(), _lib.ptr(eps),
                                              _lib.ptr(ws), wsb, st))
@@ -208,7 +208,7 @@ class LADiffVae(_HipModule):
                                       + ", ".join(unsupported))
         self._build(schema.vae_schema(nfeats, self.latent_dim, ff_size, num_layers, self.max_it))
         self.reset_parameters()
-        self.precision = kwargs.get("precision", "fp32")     # "fp32" | "bf16x3"
+        self.precision = kwargs.get("precision", "fp32")     # "fp32" | "f16x3"
 
     def reset_parameters(self):
         with torch.no_grad():
@@ -257,7 +257,7 @@ class LADiffVae(_HipModule):
         mu, std, latent = (torch.empty(T, B, self.latent_dim, dtype=torch.float32, device=dev) for _ in range(3))
         wsb = L.ladiff_encoder_workspace_bytes(B, F, T, C)
         ws = _lib.workspace(wsb, dev)
-        _lib.check(L.ladiff_vae_encode(wt.array, wt.split_array() if self.precision == "bf16x3" else None, _lib.ptr(x),
+        _lib.check(L.ladiff_vae_encode(wt.array, wt.split_array() if _lib.is_split(self.precision) else None, _lib.ptr(x),
                                        lens_t.data_ptr(), counts_t.data_ptr(), _lib.ptr(eps), B, F, T, C, _lib.ptr(mu),
                                        _lib.ptr(std), _lib.ptr(latent), _lib.ptr(ws), wsb, _lib.stream_ptr()))
         dist = torch.distributions.Normal(mu, std)
@@ -341,7 +341,7 @@ class LADiffVae(_HipModule):
             counts_t = _lib.device_ints(counts, dev)
         lens_t = _lib.device_ints(lengths, dev)
         wt = self._weight_table()
-        wsplit = wt.split_array() if self.precision == "bf16x3" else None
+        wsplit = wt.split_array() if _lib.is_split(self.precision) else None
         zz = z.detach().to(torch.float32).contiguous()
         rows = sum(lengths)
         ragged = self.length_aware and rows < B * F

@@ -109,7 +109,7 @@ class LADIFF(nn.Module):
         if loop not in ("pipeline", "pipeline16", "pipeline32", "launches"):
             raise ValueError(f"loop {loop!r} not supported")
         self.loop = loop
-        # matrix-product arithmetic of the denoiser loop: "fp32" (fp32-input MFMA) or "bf16x3" (3-term bf16 split)
+        # matrix-product arithmetic of the denoiser loop: "fp32" (fp32-input MFMA) or "f16x3" (3-term split: operands as hi + lo pairs of fp16)
         self.precision = precision if precision is not None else getattr(self.denoiser, "precision", "fp32")
         # What happens when the persistent pipeline kernel abandons a call (a stage timed out on its producer: the GPU was shared with
         # another process, or a long kernel on another stream kept a CU busy).  The 8-byte status is copied to pinned host memory
@@ -141,8 +141,7 @@ class LADIFF(nn.Module):
 
     @precision.setter
     def precision(self, value):
-        if value not in ("fp32", "bf16x3"):
-            raise ValueError(f"precision {value!r} not supported")
+        _lib.is_split(value)                               # raises on an unknown name ("fp32" | "f16x3"; "bf16x3" / "split": the same path)
         self._precision = value
         self.denoiser.precision = value
         self.vae.precision = value
@@ -368,7 +367,7 @@ class LADIFF(nn.Module):
                 _lib.check(L.ladiff_sampler_set_loop(sampler, loop_codes[loop]))
             _lib.check(L.ladiff_diffusion_reverse(
                 sampler, wt.array,
-                wt.split_array() if self.precision == "bf16x3" else None, wt.generation, _lib.ptr(plan["text"]),
+                wt.split_array() if _lib.is_split(self.precision) else None, wt.generation, _lib.ptr(plan["text"]),
                 _lib.ptr(plan["noise"]),
                 # TEST_EFFICIENCY: no masks inside the denoiser and no zeroing of the initial noise (ladiff.py:381-390,
                 # ladiff_denoiser.py:254) - but the final zeroing of ladiff.py:559-566 has no such switch

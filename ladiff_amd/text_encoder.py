@@ -126,7 +126,7 @@ class MldTextEncoder(nn.Module):
         Lx = S if full_length else int(eos.max()) + 1
         L = _lib.lib()
         wt = tower._weight_table()
-        split = wt.split_array() if self.precision == "bf16x3" else None
+        split = wt.split_array() if _lib.is_split(self.precision) else None
         res = out if inverse is None else torch.empty(n, 768, dtype=torch.float32, device=dev)
         if ragged and not full_length:
             seq_len = (eos + 1).astype(np.int32)

@@ -12,7 +12,7 @@ dev = torch.device("cuda", 0)
 cfg = bench.CONFIGS["headline"]
 wl = bench.Workload(cfg, dev, 0, 1)
 pipe = bench.build_pipe(dev, wl.B, cfg)
-pipe.precision = "bf16x3"
+pipe.precision = "f16x3"
 stream = torch.cuda.Stream(device=dev)
 for chk in (True, False, True, False):
     with torch.cuda.stream(stream), torch.no_grad():
@@ -30,7 +30,7 @@ for chk in (True, False, True, False):
 cfg = dict(bench.CONFIGS["c3"]); cfg["steps"] = 200
 wl = bench.Workload(cfg, dev, 0, 1)
 pipe = bench.build_pipe(dev, wl.B, cfg)
-pipe.precision = "bf16x3"
+pipe.precision = "f16x3"
 tensor = LADIFF.noise_tensor(7, 200, wl.B, 5, device=dev)
 with torch.cuda.stream(stream), torch.no_grad():
     for mode in ("generator", "tensor", "generator", "tensor"):

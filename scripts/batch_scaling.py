@@ -10,7 +10,7 @@ from ladiff_amd import synthetic as syn
 
 dev = torch.device("cuda", 0)
 pipe = bench.build_pipe(dev, 128)
-pipe.precision = "fp32" if "fp32" in sys.argv[1:] else "bf16x3"
+pipe.precision = "fp32" if "fp32" in sys.argv[1:] else "f16x3"
 stream = torch.cuda.Stream(device=dev)
 for B in (128, 192, 256, 320, 384, 512, 768, 1024):
     lens = [196] * B

@@ -23,7 +23,7 @@ sch = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012
                     clip_sample=False, set_alpha_to_one=False, steps_offset=1)
 pipe = LADIFF(denoiser=den.to(dev).eval(), vae=vae.to(dev).eval(), scheduler=sch, guidance_scale=7.5,
               num_inference_timesteps=50, eta=0.0)
-pipe.precision = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
+pipe.precision = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 B = 128
 mixed = ([60, 120, 196] * 43)[:B]
 text = syn.text_embeddings(B).to(dev)

@@ -9,7 +9,7 @@ from ladiff_amd.text_encoder import MldTextEncoder
 dev = torch.device("cuda:0")
 B = 128
 ids_h = syn.clip_token_ids(2 * B, empty_first=B)
-enc = MldTextEncoder(precision=os.environ.get("PRECISION", "bf16x3"))
+enc = MldTextEncoder(precision=os.environ.get("PRECISION", "f16x3"))
 enc.text_model.load_state_dict(syn.clip_weights(), strict=True)
 enc = enc.to(dev).eval()
 s = torch.cuda.Stream()

@@ -1,4 +1,4 @@
-"""Same-box A/B of the decode at the benchmark size (128 x 196 frames, bf16x3, default fusion): HIP-event ms per decode for each library
+"""Same-box A/B of the decode at the benchmark size (128 x 196 frames, f16x3, default fusion): HIP-event ms per decode for each library
 named on the command line (paths relative to the repo; `product` = the shipped one), each with dec_mlp's workgroup forms (0 = by size,
 1 = <8,1>), three rounds interleaved so that a drift of the box shows.  Every library runs in a child process of its own.
 usage: decode_ab.py product ladiff_amd/libladiff_hip_x.so ..."""
@@ -21,7 +21,7 @@ if os.environ.get("LADIFF_LIB"):
     _lib.LIB_PATH = os.path.join(ROOT, os.environ["LADIFF_LIB"])
 dev = "cuda:0"
 vae = LADiffVae(ABL, **VAE_KW); vae.load_state_dict(syn.vae_weights(263)); vae = vae.to(dev).eval()
-vae.precision = "bf16x3"
+vae.precision = "f16x3"
 L = _lib.lib()
 B, F = 128, 196
 lens = [F] * B

@@ -17,9 +17,9 @@ for B, F in ((64, 196), (128, 196), (8, 60), (37, 100)):
     T = 5
     z = torch.randn(T, B, 256, generator=torch.Generator().manual_seed(1)).to(dev)
     counts = [-(-l // 48) for l in lens]
-    for prec in ("bf16x3", "fp32"):
+    for prec in ("f16x3", "fp32"):
         vae.precision = prec
-        wt = vae._weight_table(); wsplit = wt.split_array() if prec == "bf16x3" else None
+        wt = vae._weight_table(); wsplit = wt.split_array() if prec == "f16x3" else None
         wsb = L.ladiff_decoder_workspace_bytes(B, F, T, 263)
         nw = (wsb + 3) // 4
         big = torch.full((nw + 2 * G,), CAN, dtype=torch.int32, device=dev)

@@ -1,4 +1,4 @@
-"""Ten bf16x3 decodes at the benchmark size (128 x 196 frames) for `rocprofv3 --kernel-trace --stats -- python3 scripts/decode_prof.py [switch]`."""
+"""Ten f16x3 decodes at the benchmark size (128 x 196 frames) for `rocprofv3 --kernel-trace --stats -- python3 scripts/decode_prof.py [switch]`."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,7 +9,7 @@ if os.environ.get("LADIFF_LIB"):                      # an experiment build of t
     _lib.LIB_PATH = os.path.join(ROOT, os.environ["LADIFF_LIB"])
 dev = "cuda:0"
 vae = LADiffVae(ABL, **VAE_KW); vae.load_state_dict(syn.vae_weights(263)); vae = vae.to(dev).eval()
-vae.precision = "bf16x3"
+vae.precision = "f16x3"
 _lib.lib().ladiff_debug_set_decoder_fusion(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 B, F = 128, 196
 lens = [F] * B

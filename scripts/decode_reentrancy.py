@@ -13,7 +13,7 @@ if os.environ.get("LADIFF_LIB"):                      # an experiment build of t
 from test_abi import ABL, VAE_KW
 dev = "cuda:0"
 vae = LADiffVae(ABL, **VAE_KW); vae.load_state_dict(syn.vae_weights(263)); vae = vae.to(dev).eval()
-vae.precision = "bf16x3"
+vae.precision = "f16x3"
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 switches = [int(a) for a in sys.argv[2:]] or [1, 65, 17, 81, 2 + 64 + 16, 0, 64 + 16]
 B, F = 128, 196

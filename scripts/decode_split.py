@@ -9,7 +9,7 @@ from ladiff_amd import LADiffVae, synthetic as syn
 from test_abi import ABL, VAE_KW
 dev = "cuda:0"
 vae = LADiffVae(ABL, **VAE_KW); vae.load_state_dict(syn.vae_weights(263)); vae = vae.to(dev).eval()
-vae.precision = "bf16x3"
+vae.precision = "f16x3"
 B, F = 128, 196
 lens = [F] * B
 z = torch.randn(5, B, 256, generator=torch.Generator().manual_seed(1)).to(dev)

@@ -12,7 +12,7 @@ import bench
 dev = torch.device("cuda", 0)
 L = _lib.lib()
 pipe = bench.build_pipe(dev, 128)
-pipe.precision = "bf16x3"; pipe.loop = "pipeline16"; pipe.num_inference_timesteps = 50
+pipe.precision = "f16x3"; pipe.loop = "pipeline16"; pipe.num_inference_timesteps = 50
 stream = torch.cuda.Stream(device=dev)
 for B in (64, 128, 256):
     lens = [196] * B

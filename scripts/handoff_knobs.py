@@ -12,7 +12,7 @@ if os.environ.get("LADIFF_LIB"):                      # an experiment build of t
     _lib.LIB_PATH = os.path.join(ROOT, os.environ["LADIFF_LIB"])
 dev = torch.device("cuda", 0)
 pipe = bench.build_pipe(dev, 128)
-pipe.precision = "fp32" if "fp32" in sys.argv[1:] else "bf16x3"
+pipe.precision = "fp32" if "fp32" in sys.argv[1:] else "f16x3"
 pipe.loop = "pipeline16"
 pipe.num_inference_timesteps = 50
 cfgs = [a for a in sys.argv[1:] if "=" in a]

@@ -9,7 +9,7 @@ if os.environ.get("LADIFF_LIB"):
     _lib.LIB_PATH = os.path.join(ROOT, os.environ["LADIFF_LIB"])
 dev = torch.device("cuda", 0)
 pipe = bench.build_pipe(dev, 128)
-pipe.precision = "bf16x3"; pipe.loop = "pipeline16"; pipe.num_inference_timesteps = 50
+pipe.precision = "f16x3"; pipe.loop = "pipeline16"; pipe.num_inference_timesteps = 50
 B = int(sys.argv[1]); seq = sys.argv[2]
 lens = [196] * B
 text, noise = syn.text_embeddings(B).to(dev), syn.init_noise(lens).to(dev)

@@ -19,7 +19,7 @@ lens = [196] * B
 data = [(syn.text_embeddings(B, seed=11 + i).to(dev),
          syn.init_noise(lens).to(dev) * (1 + 0.02 * i)) for i in range(2)]
 total_bad = 0
-for prec in ("bf16x3", "fp32"):
+for prec in ("f16x3", "fp32"):
     for p in pipes:
         p.loop = "launches"; p.precision = prec; p.num_inference_timesteps = steps
     def both(concurrent):
@@ -40,8 +40,8 @@ for prec in ("bf16x3", "fp32"):
         print(f"launch-per-stage loop, 64 prompts x {steps} steps, {prec}, concurrent {concurrent}: {bad} of {runs} runs differ (worst {worst:.3e})", flush=True)
 # the launch path beside a LARGE decode on the other stream (the load that spread the GEMM's LDS-DMA latencies: DESIGN.md 4b)
 zbig = torch.randn(5, 128, 256, generator=torch.Generator().manual_seed(9)).to(dev)
-pipes[1].vae.precision = "bf16x3"
-for prec in ("bf16x3", "fp32"):
+pipes[1].vae.precision = "f16x3"
+for prec in ("f16x3", "fp32"):
     pipes[0].precision = prec
     def loop_beside_decode(concurrent):
         with torch.cuda.stream(streams[1]), torch.no_grad():
@@ -62,7 +62,7 @@ for prec in ("bf16x3", "fp32"):
 # the small decode
 vaes = [p.vae for p in pipes]
 zz = [torch.randn(5, 8, 256, generator=torch.Generator().manual_seed(3 + i)).to(dev) for i in range(2)]
-for prec in ("bf16x3", "fp32"):
+for prec in ("f16x3", "fp32"):
     for v in vaes: v.precision = prec
     def both_d(concurrent):
         outs = []

@@ -25,14 +25,14 @@ pipe.loop = "launches"
 for B in (128, 32):
     lens = [196] * B
     text, noise = syn.text_embeddings(B).to(dev), syn.init_noise(lens).to(dev)
-    for prec in ("bf16x3", "fp32"):
+    for prec in ("f16x3", "fp32"):
         pipe.precision = prec
         ms = timed(lambda: pipe._diffusion_reverse(text, lens, init_noise=noise), 3)
         print(f"{sys.argv[1] if len(sys.argv) > 1 else ''} launch-per-stage loop, {B} prompts x 50 steps, {prec}: {ms:8.2f} ms", flush=True)
 vae = LADiffVae(ABL, **VAE_KW); vae.load_state_dict(syn.vae_weights(263)); vae = vae.to(dev).eval()
 for B, F in ((8, 60), (16, 196)):
     z = torch.randn(5, B, 256, generator=torch.Generator().manual_seed(1)).to(dev)
-    for prec in ("bf16x3", "fp32"):
+    for prec in ("f16x3", "fp32"):
         vae.precision = prec
         ms = timed(lambda: vae.decode(z, [F] * B), 20)
         print(f"{sys.argv[1] if len(sys.argv) > 1 else ''} decode {B} x {F} frames (small-rows path), {prec}: {ms:8.3f} ms", flush=True)

@@ -11,7 +11,7 @@ _lib.LIB_PATH = _build.stamps_lib(os.environ.get("LADIFF_STAMPS_LEVEL", "1"))
 from test_abi import ABL, VAE_KW
 dev = "cuda:0"
 vae = LADiffVae(ABL, **VAE_KW); vae.load_state_dict(syn.vae_weights(263)); vae = vae.to(dev).eval()
-vae.precision = "bf16x3"
+vae.precision = "f16x3"
 L = _lib.lib()
 B, F = 128, 196
 lens = [F] * B

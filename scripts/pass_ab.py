@@ -13,7 +13,7 @@ for name in (sys.argv[1:] or ["headline", "c2", "c5"]):
     cfg = bench.CONFIGS[name]
     wl = bench.Workload(cfg, dev, 0, 1)
     pipe = bench.build_pipe(dev, wl.B, cfg)
-    pipe.precision = "fp32" if os.environ.get("PRECISION") == "fp32" else "bf16x3"
+    pipe.precision = "fp32" if os.environ.get("PRECISION") == "fp32" else "f16x3"
     stream = torch.cuda.Stream(device=dev)
     for ho in (0, 1, 0, 1):
         _lib.check(L.ladiff_debug_set_handoff(ho))

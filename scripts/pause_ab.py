@@ -19,7 +19,7 @@ if os.environ.get("SHAPES"):
     shapes = [(int(t[:-1]), t[-1]) for t in os.environ["SHAPES"].split(",")]
 stream = torch.cuda.Stream(device=dev)
 pipe = bench.build_pipe(dev, 128)
-pipe.precision = "bf16x3"; pipe.loop = "pipeline16"; pipe.num_inference_timesteps = 50
+pipe.precision = "f16x3"; pipe.loop = "pipeline16"; pipe.num_inference_timesteps = 50
 ref = {}
 data = {}
 for B, kind in shapes:

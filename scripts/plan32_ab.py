@@ -13,7 +13,7 @@ for B in (64, 128, 192, 256):
     row = []
     for loop in ("pipeline16", "pipeline32", "pipeline"):
         pipe = bench.build_pipe(dev, B)
-        pipe.precision = "bf16x3"; pipe.loop = loop; pipe.num_inference_timesteps = 50; pipe.max_prompts_per_launch = None
+        pipe.precision = "f16x3"; pipe.loop = loop; pipe.num_inference_timesteps = 50; pipe.max_prompts_per_launch = None
         with torch.cuda.stream(stream), torch.no_grad():
             for _ in range(5):
                 pipe._diffusion_reverse(text, lens, init_noise=noise)

@@ -16,7 +16,7 @@ ref = {}
 for plan in plans:
     _lib.check(L.ladiff_debug_set_stage_plan(plan))
     pipe = bench.build_pipe(dev, 128)
-    pipe.precision = "fp32" if os.environ.get("PRECISION") == "fp32" else "bf16x3"
+    pipe.precision = "fp32" if os.environ.get("PRECISION") == "fp32" else "f16x3"
     pipe.loop = "pipeline16"; pipe.num_inference_timesteps = 50
     row = []
     for B, kind in shapes:

@@ -104,7 +104,7 @@ def main():
     dominant = next(iter(kernels))
     sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
     import bench
-    summary = {"git_sha": sha, "csrc_hash": bench.csrc_hash(), "steady_state_passes": steady_passes, "command": "rocprofv3 ... -- python3 scripts/profile_pass.py bf16x3 %d" % passes,
+    summary = {"git_sha": sha, "csrc_hash": bench.csrc_hash(), "steady_state_passes": steady_passes, "command": "rocprofv3 ... -- python3 scripts/profile_pass.py f16x3 %d" % passes,
                "normalisation": "util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x 2.4 GHz); traffic = 2 x FETCH_SIZE + WRITE_SIZE",
                "dominant_kernel": dominant, "kernels": kernels, "whole_pass": whole}
     json.dump(summary, open(out_json, "w"), indent=1)
@@ -112,7 +112,7 @@ def main():
         f.write(f"# PMC + kernel-trace summary (commit {sha}, csrc hash {summary['csrc_hash']}; {passes} passes + 1 warm-up per run; "
                 f"counts and shares over the {steady_passes} steady-state passes between the second and the last prologue)\n\n")
         f.write("Separate rocprofv3 runs: `--kernel-trace --stats`, `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE`, `--pmc FETCH_SIZE`, "
-                "`--pmc WRITE_SIZE`, each `-- python3 scripts/profile_pass.py bf16x3 N`.\n")
+                "`--pmc WRITE_SIZE`, each `-- python3 scripts/profile_pass.py f16x3 N`.\n")
         f.write("MFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x 2.4 GHz) - calibrated in 02_mfma_calibration.md; "
                 "traffic = 2 x FETCH_SIZE + WRITE_SIZE at the L2 <-> fabric interface (Infinity-Cache hits included).\n\n")
         f.write("| kernel | launches/pass | us/launch (trace) | % of pass | us/launch (pmc run) | MFMA util (pmc run) | MFMA util (trace duration) | fetch MB/launch | write MB/launch |\n|---|---|---|---|---|---|---|---|---|\n")

@@ -12,7 +12,7 @@ from ladiff_amd import _lib, synthetic as syn
 mode = sys.argv[1] if len(sys.argv) > 1 else "pace"
 dev = torch.device("cuda", 0)
 pipe = bench.build_pipe(dev, 128)
-pipe.precision = "bf16x3"; pipe.loop = "pipeline16"; pipe.num_inference_timesteps = 50
+pipe.precision = "f16x3"; pipe.loop = "pipeline16"; pipe.num_inference_timesteps = 50
 L = _lib.lib()
 stream = torch.cuda.Stream(device=dev)
 shapes = [(64, "u"), (128, "u"), (128, "m"), (256, "u")] if mode == "pace" else [(32, "u"), (64, "u"), (100, "m"), (128, "m")]

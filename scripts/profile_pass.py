@@ -1,4 +1,4 @@
-"""Profiling target: `python scripts/profile_pass.py <fp32|bf16x3> [passes] [config]` runs 1 warm-up + N passes of a
+"""Profiling target: `python scripts/profile_pass.py <fp32|f16x3> [passes] [config]` runs 1 warm-up + N passes of a
 benchmark workload (default: 128 prompts, 196 frames, 50-step DDIM + decode) in ONE precision mode and nothing else (no CPU
 baseline, no second mode), so rocprofv3 --stats / --pmc summaries are per-mode.  It runs bench.py's own Workload."""
 import os, sys
@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import bench
-mode = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
+mode = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 cfg = bench.CONFIGS[sys.argv[3] if len(sys.argv) > 3 else "headline"]
 dev = torch.device("cuda", 0)

@@ -20,7 +20,7 @@ L = _lib.lib()
 L.ladiff_debug_set_sys_stamps.argtypes = [ctypes.c_void_p]
 L.ladiff_debug_set_probe(int(os.environ.get("PROBE", "0")))        # timing probes of the twin build (garbage results): scripts/ffn_probe.py
 pipe = bench.build_pipe(dev, B)
-pipe.precision = "bf16x3"; pipe.num_inference_timesteps = steps; pipe.loop = mode
+pipe.precision = "f16x3"; pipe.num_inference_timesteps = steps; pipe.loop = mode
 lens = [196] * B
 text, noise = syn.text_embeddings(B).to(dev), syn.init_noise(lens).to(dev)
 st = torch.zeros(256 * 4 * 4 * 8 + 256 * 4 + 256 * 4 * 8 + 256, dtype=torch.int64, device=dev)

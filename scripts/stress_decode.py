@@ -1,5 +1,5 @@
-"""Stress (GPU box): random batch shapes through LADiffVae.decode - bf16x3 default path against the same path with each fusion switched
-off (attention with in_proj inside, fused feed-forward kernel, final_layer on bf16x3 tiles, small-M routing), against fp32 mode
+"""Stress (GPU box): random batch shapes through LADiffVae.decode - f16x3 default path against the same path with each fusion switched
+off (attention with in_proj inside, fused feed-forward kernel, final_layer on f16x3 tiles, small-M routing), against fp32 mode
 (tolerance), every call twice (same bits), padded frames exactly zero.  python scripts/stress_decode.py [cases] [seed]"""
 import os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,7 +29,7 @@ for case in range(cases):
         z[-(-l // 48):, i] = 0
     out = {}
     with torch.no_grad():
-        vae.precision = "bf16x3"
+        vae.precision = "f16x3"
         for sw in (1, 1, 1 + 16, 0, 1 + 8, 1 + 4, 2 + 32, 1 + 64):
             L.ladiff_debug_set_decoder_fusion(sw)
             out.setdefault(sw, []).append(vae.decode(z, lens))

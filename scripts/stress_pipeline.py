@@ -12,7 +12,7 @@ from ladiff_amd import synthetic as syn
 iters = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 100
 dev = torch.device("cuda", 0)
 bad = 0
-for precision in (["fp32"] if "fp32" in sys.argv[1:] else ["bf16x3", "fp32"]):
+for precision in (["fp32"] if "fp32" in sys.argv[1:] else ["f16x3", "fp32"]):
     pipe = bench.build_pipe(dev, 128)
     pipe.precision = precision
     pipe.num_inference_timesteps = 50

@@ -17,7 +17,7 @@ ref_pipe = bench.build_pipe(dev, 128)
 ref_pipe.precision = "fp32"; ref_pipe.loop = "launches"
 bad = 0
 for case in range(cases):
-    precision = rng.choice(["bf16x3", "bf16x3", "fp32"])
+    precision = rng.choice(["f16x3", "f16x3", "fp32"])
     loop = rng.choice(["pipeline", "pipeline", "pipeline16", "pipeline32", "launches"])
     guided = rng.random() < 0.8
     if not guided and loop == "pipeline32":
@@ -45,7 +45,7 @@ for case in range(cases):
     msgs = []
     if st != (0, 0): msgs.append(f"status {st}")
     if not (torch.equal(z1, z2) and torch.equal(f1, f2)): msgs.append("repeat differs")
-    tol = 2e-3 if precision == "bf16x3" else 2e-4
+    tol = 2e-3 if precision == "f16x3" else 2e-4
     dz = (z1 - zr).abs().max().item() / max(1.0, zr.abs().max().item())
     df = (f1 - fr).abs().max().item() / max(1.0, fr.abs().max().item())
     if not (dz < tol and df < tol): msgs.append(f"vs fp32 launches: latents {dz:.2e} frames {df:.2e}")

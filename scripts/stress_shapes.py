@@ -12,7 +12,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 dev = torch.device("cuda", 0)
 bad = 0
-for precision, tol in (("bf16x3", 2e-4), ("fp32", 2e-5)):
+for precision, tol in (("f16x3", 2e-4), ("fp32", 2e-5)):
     pipe = bench.build_pipe(dev, 128)
     pipe.precision = precision
     for case in range(cases):

@@ -20,7 +20,7 @@ _lib.check(L.ladiff_debug_set_loop_thresholds(la, small))
 sizes = [int(v) for v in os.environ.get("SIZES", "8,16,32,48,64,80,96,100,112,128,160,192,256,320").split(",")]
 kinds = os.environ.get("KINDS", "u,m").split(",")
 pipe = bench.build_pipe(dev, 128)
-pipe.precision = "bf16x3"; pipe.loop = "pipeline16"; pipe.num_inference_timesteps = 50
+pipe.precision = "f16x3"; pipe.loop = "pipeline16"; pipe.num_inference_timesteps = 50
 stream = torch.cuda.Stream(device=dev)
 print(f"thresholds: look-ahead from {la if la >= 0 else 'built-in'} blocks, LIN / FFN rest up to {small if small >= 0 else 'built-in'} blocks")
 print(f"{'prompts':>8s} {'kind':>5s} {'blocks':>6s} | {'flags ms':>9s} {'tags ms':>9s} {'tags motions/s (loop only)':>27s} {'us per block and step':>22s}")

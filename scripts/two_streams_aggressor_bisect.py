@@ -1,4 +1,4 @@
-"""Bisect (diagnostic twin, LADIFF_LIB=ladiff_amd/libladiff_hip_stamps.so): victim = a whole decode 64 x 196 bf16x3 launched first on
+"""Bisect (diagnostic twin, LADIFF_LIB=ladiff_amd/libladiff_hip_stamps.so): victim = a whole decode 64 x 196 f16x3 launched first on
 stream A; aggressor = the FIRST n launches of a second decode (LADIFF_DEC_CUT=n, csrc/decoder.hip) launched right after on stream B.
 usage: decode_victim3.py [runs] [cut ...]"""
 import os, sys
@@ -11,7 +11,7 @@ if os.environ.get("LADIFF_LIB"):                      # the diagnostic twin (sam
     _lib.LIB_PATH = os.path.join(ROOT, os.environ["LADIFF_LIB"])
 dev = "cuda:0"
 vae = LADiffVae(ABL, **VAE_KW); vae.load_state_dict(syn.vae_weights(263)); vae = vae.to(dev).eval()
-vae.precision = "bf16x3"
+vae.precision = "f16x3"
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 cuts = [int(a) for a in sys.argv[2:]] or [1, 2, 3, 4, 5, 6, 7, 8, 11, 20, 100]
 g = torch.Generator().manual_seed(1)

@@ -11,7 +11,7 @@ if os.environ.get("LADIFF_LIB"):                      # the diagnostic twin (sam
     _lib.LIB_PATH = os.path.join(ROOT, os.environ["LADIFF_LIB"])
 dev = "cuda:0"
 vae = LADiffVae(ABL, **VAE_KW); vae.load_state_dict(syn.vae_weights(263)); vae = vae.to(dev).eval()
-vae.precision = "bf16x3"
+vae.precision = "f16x3"
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 g = torch.Generator().manual_seed(1)
 B, F, T, C = 64, 196, 5, 263

@@ -1,4 +1,4 @@
-"""Diagnostic (GPU box): large-M bf16x3 GEMM shapes of the decoder / CLIP (M = 25088 by default, env M overrides) through
+"""Diagnostic (GPU box): large-M f16x3 GEMM shapes of the decoder / CLIP (M = 25088 by default, env M overrides) through
 ladiff_gemm_split; checks against fp64 on a row sample."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

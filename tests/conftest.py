@@ -14,6 +14,12 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# test infrastructure only: run the suite against a VARIANT build of the library (same ABI; scripts/build_file_variant.sh,
+# `python -m ladiff_amd.build --tag=...`) for a same-box A/B.  The product never reads this variable.
+if os.environ.get("LADIFF_TEST_LIB"):
+    from ladiff_amd import _lib as _lib_for_variant
+    _lib_for_variant.LIB_PATH = os.path.join(ROOT, os.environ["LADIFF_TEST_LIB"])
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

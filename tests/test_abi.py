@@ -44,7 +44,7 @@ def test_library_exports_only_the_declared_entries(lib):
 
 
 def test_version_and_errors(lib):
-    assert lib.ladiff_version() == 5
+    assert lib.ladiff_version() == 6
     assert lib.ladiff_error_string(0) == b"ok"
     assert b"workspace" in lib.ladiff_error_string(-3)
 

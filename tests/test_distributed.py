@@ -228,3 +228,35 @@ def test_bench_self_launch_propagates_the_ranks_failure():
     assert "not enough devices" in r.stderr
     assert "WORLD_SIZE=1" not in r.stderr
     assert r.stdout.strip() == ""
+
+
+def _scale_worker(rank, world, port, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, w, _ = D.init_from_env("gloo")
+    bench.recorded_n1_value = lambda name: (11000.0, "profiles/rX/bench_headline_n1.json")
+    rep = bench.scale_report("cpu", r, w, True, loop_ms=9.0 + 0.1 * r, gather_ms=0.5 + 0.01 * r, pass_ms=11.0 + r,
+                             motions_per_s=8 * 11000.0 * 0.9, config_name="headline")
+    ret[rank] = rep
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scale_report_world8_validates_itself():
+    """The fields an N > 1 bench line carries so that the first multi-GPU run checks itself (bench.scale_report) on 8 gloo ranks:
+    `ranks_seen` from an all-reduce of ones, min / max / slowest rank of the per-rank loop, gather and pass times, efficiency against
+    the recorded N = 1 line; only rank 0 gets the report."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_scale_worker, args=(8, port, ret), nprocs=8, join=True)
+    assert all(ret[r] is None for r in range(1, 8))
+    rep = ret[0]
+    assert rep["ranks_seen"] == 8 and rep["ranks_expected"] == 8 and rep["ranks_ok"] is True
+    assert rep["loop_kernel_ms_over_ranks"] == {"min": 9.0, "max": 9.7, "slowest_rank": 7}
+    assert rep["final_gather_ms_over_ranks"] == {"min": 0.5, "max": 0.57, "slowest_rank": 7}
+    assert rep["pass_device_ms_over_ranks"]["max"] == 18.0
+    assert rep["scaling_efficiency_vs_recorded_n1"] == 0.9 and rep["n1_value"] == 11000.0

@@ -10,7 +10,7 @@ from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-TOL = {"fp32": 5e-5, "bf16x3": 5e-4}     # outputs are O(1..4); bf16x3 keeps 16 significant bits per operand
+TOL = {"fp32": 5e-5, "f16x3": 5e-4}     # outputs are O(1..4); f16x3 keeps 16 significant bits per operand
 
 
 def make_encoder(vocab, layers, precision="fp32", **kw):
@@ -23,7 +23,7 @@ def maxdiff(a, b):
     return (a.double().cpu() - b.double().cpu()).abs().max().item()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 @pytest.mark.parametrize("name", ["clip_small", "clip_small_eos", "clip_full"])
 def test_text_features_match_transformers_golden(name, precision):
     g = load_golden(name)
@@ -53,8 +53,8 @@ def test_guidance_batch_against_oracle():
     out = enc.encode_ids(ids)
     ref = orc.clip_text_features(sd, ids, layers)
     assert maxdiff(out, ref) < TOL["fp32"]
-    enc.precision = "bf16x3"
-    assert maxdiff(enc.encode_ids(ids), ref) < TOL["bf16x3"]
+    enc.precision = "f16x3"
+    assert maxdiff(enc.encode_ids(ids), ref) < TOL["f16x3"]
 
 
 def test_forward_with_a_tokenizer_callable():
@@ -132,15 +132,15 @@ def test_prompts_to_frames_against_oracle():
 
 
 # the whole chain at the FULL geometry: what `bench.py --config e2e` times
-E2E_TOL = {"fp32": 1e-3, "bf16x3": 3e-3}
+E2E_TOL = 1e-3          # the north-star gate, for the whole chain in BOTH modes (rounds 4 - 5 held the bf16-pair chain to a looser 3e-3)
 
 
 def test_full_geometry_chain_against_oracle_both_modes():
     """Token ids -> 12-layer CLIP ViT-L/14 text tower (49,408 tokens, random init) -> 50-step guided DDIM -> LA-VAE frames for 16 prompts of
     mixed lengths, both arithmetic modes, against the CPU oracle chain.  The north-star gate (1e-3) is defined on IDENTICAL text embeddings;
     here the embeddings come from the tower in the same arithmetic mode, and the 50-step loop amplifies their rounding (random-init
-    weights: |latent| ~ 280): the fp32 chain is held to the gate, the bf16x3 chain to a stated 3e-3 (measured ~1e-3 on the worst prompt
-    of the benchmark batch: bench.py `parity.worst_prompt`).  The loop + decode on the ORACLE's embeddings stays within the gate in bf16x3 too."""
+    weights: |latent| ~ 280): both chains are held to the gate (with bf16 pairs - rounds 4 - 5 - the split chain measured 1.07e-3 on the worst prompt of
+    the benchmark batch and had a looser stated 3e-3; with fp16 pairs 2.7e-4).  The loop + decode on the ORACLE's embeddings is held to it as well."""
     from ladiff_amd import LADIFF, DDIMScheduler, LADiffDenoiser, LADiffVae
     from test_abi import ABL, DEN_KW, VAE_KW
     B = 16
@@ -159,7 +159,7 @@ def test_full_geometry_chain_against_oracle_both_modes():
     enc = MldTextEncoder(precision="fp32")
     enc.text_model.load_state_dict(clip_sd, strict=True)
     enc = enc.to(DEV).eval()
-    for precision in ("fp32", "bf16x3"):
+    for precision in ("fp32", "f16x3"):
         pipe.precision = enc.precision = precision
         text = enc.encode_ids(ids.to(DEV)).unsqueeze(1)
         _, feats = pipe.sample(text, lens, init_noise=noise.to(DEV))
@@ -170,5 +170,5 @@ def test_full_geometry_chain_against_oracle_both_modes():
         same = maxdiff(feats_same, f_o)
         print(f"full-geometry chain, {precision}: embeddings {emb:.2e}, frames worst prompt {worst}: {per_prompt[worst]:.2e}; "
               f"loop + decode on the oracle's embeddings: {same:.2e}")
-        assert per_prompt[worst] < E2E_TOL[precision], (precision, per_prompt)
+        assert per_prompt[worst] < E2E_TOL, (precision, per_prompt)
         assert same < 1e-3, (precision, same)

@@ -1,5 +1,5 @@
 """The decoder layer's self-attention out_proj + norm1 + cross-attention + norm2 as ONE kernel (csrc/dec_cross.hip,
-dec_out_cross_kernel: Wo and the sample's folded keys / values as MFMA fragments in registers, bf16x3 mode, from 4,096 frame rows up)
+dec_out_cross_kernel: Wo and the sample's folded keys / values as MFMA fragments in registers, f16x3 mode, from 4,096 frame rows up)
 against the two launches it replaces and against the CPU oracle - for every latent-token count 1 .. 8, padded and ragged rows.
 Reference: TransformerDecoderLayer.forward_post, operator/cross_attention.py:367-376, :407-409."""
 import pytest
@@ -34,7 +34,7 @@ def test_fused_out_proj_cross_attention_kernel(vae, T, fpl, ragged):
         z[c:, i] = 0
     old = (vae.frame_per_latent, vae.length_aware, vae.precision, vae.max_it)
     try:
-        vae.frame_per_latent, vae.length_aware, vae.precision = fpl, ragged, "bf16x3"
+        vae.frame_per_latent, vae.length_aware, vae.precision = fpl, ragged, "f16x3"
         with torch.no_grad():
             assert L.ladiff_debug_set_decoder_fusion(1) == 0
             fused = vae.decode(z.to(DEV), lens)
@@ -50,7 +50,7 @@ def test_fused_out_proj_cross_attention_kernel(vae, T, fpl, ragged):
     d2 = (fused - two).abs().max().item()
     dr = (fused.cpu() - ref).abs().max().item()
     print(f"T={T} ragged={ragged}: fused vs two launches {d2:.2e}, fused vs oracle {dr:.2e}")
-    assert 0.0 < d2 < 2e-4 * scale           # the cross-attention products on the bf16x3 MFMA instead of fp32 FMAs: 2^-16 per product
+    assert 0.0 < d2 < 2e-4 * scale           # the cross-attention products on the f16x3 MFMA instead of fp32 FMAs: 2^-16 per product
     assert dr < 5e-4 * scale
     for i, l in enumerate(lens):
         if l < fused.shape[1]:

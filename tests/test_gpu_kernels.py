@@ -215,7 +215,8 @@ def to_split(t):
 
 def from_split(y):
     """S-format [R,K] (GPU) -> fp32 hi + lo on the CPU."""
-    b = y.cpu().contiguous().view(torch.bfloat16).view(y.shape[0], y.shape[1] // 64, 2, 64).float()
+    half = torch.float16 if lib().ladiff_split_format() == 1 else torch.bfloat16
+    b = y.cpu().contiguous().view(half).view(y.shape[0], y.shape[1] // 64, 2, 64).float()
     return (b[:, :, 0] + b[:, :, 1]).reshape(y.shape[0], y.shape[1])
 
 
@@ -242,12 +243,13 @@ def gemm_resident(A, W, bias=None, A2=None, res=None, act="none", split=False, w
 def test_split_format_round_trip():
     x = rnd(37, 256, scale=50.0)
     back = from_split(to_split(x))
-    assert (back - x).abs().max().item() <= 2.0 ** -16 * x.abs().max().item()
+    bits = 21 if lib().ladiff_split_format() == 1 else 16       # fp16 pairs (both halves rounded toward zero): 22 bits; bf16 pairs: 16
+    assert (back - x).abs().max().item() <= 2.0 ** -bits * x.abs().max().item()
 
 
 @pytest.mark.parametrize("M,N,K,act", [(1280, 1024, 256, "gelu"), (1280, 768, 256, "none"), (1280, 256, 256, "none"),
                                        (77, 1024, 256, "relu"), (1280, 256, 1024, "none"), (90, 256, 512, "none")])
-def test_gemm_resident_bf16x3(M, N, K, act):
+def test_gemm_resident_split(M, N, K, act):
     """3-term bf16 split products: ~2^-16 relative error per product (vs 2^-24 for the fp32 MFMA path)."""
     A, W, b = rnd(M, K, scale=3.0), rnd(N, K, scale=1 / math.sqrt(K)), rnd(N)
     if K == 256:
@@ -307,7 +309,7 @@ def test_gemm_resident_split_k_and_combine(M, K, concat):
         assert (out.cpu().double() - wants[mode]).abs().max().item() < 3e-5, mode
 
 
-# ---------------------------------------------------------------- large-M bf16x3 GEMM (decoder / encoder / CLIP)
+# ---------------------------------------------------------------- large-M f16x3 GEMM (decoder / encoder / CLIP)
 @pytest.mark.parametrize("M,N,K,act,concat,res", [(4100, 256, 256, "none", False, True), (5000, 768, 256, "none", False, False),
                                                   (4224, 1024, 256, "gelu", False, False), (4099, 256, 1024, "none", False, True),
                                                   (4160, 256, 512, "none", True, False), (300, 768, 768, "qgelu", False, True),
@@ -339,17 +341,17 @@ def test_gemm_split_large_m(M, N, K, act, concat, res):
                                    K, 0, _lib.stream_ptr()) == -2          # N must be a multiple of 128
 
 
-# ---------------------------------------------------------------- self-attention core, bf16x3 arithmetic
+# ---------------------------------------------------------------- self-attention core, f16x3 arithmetic
 @pytest.mark.parametrize("lengths,nheads,causal", [([196, 196, 60], 4, 0), ([1, 33, 32, 31, 101], 4, 0), ([224, 200], 4, 0),
                                                    ([5], 4, 0), ([77, 77, 77], 12, 1), ([20, 20], 12, 1), ([128, 129, 97], 4, 0)])
-def test_self_attention_bf16x3(lengths, nheads, causal):
+def test_self_attention_split(lengths, nheads, causal):
     """q, k, v and the probabilities as bf16 hi + lo pairs (3 MFMAs per product): ~2^-16 relative per product."""
     B, Fr, W = len(lengths), max(lengths), 64 * nheads
     qkv = rnd(B * Fr, 3 * W, scale=2.0)
     out = torch.full((B * Fr, W), float("nan"), device=DEV)
     qd = qkv.to(DEV)
     ld = None if causal else torch.tensor(lengths, dtype=torch.int32, device=DEV)
-    _lib.check(lib().ladiff_self_attention_bf16x3(_lib.ptr(qd), None if ld is None else ld.data_ptr(), None, _lib.ptr(out), B, Fr,
+    _lib.check(lib().ladiff_self_attention_split(_lib.ptr(qd), None if ld is None else ld.data_ptr(), None, _lib.ptr(out), B, Fr,
                                                   nheads, causal, _lib.stream_ptr()))
     sync()
     q, k, v = qkv.double().view(B, Fr, 3, nheads, 64).permute(2, 0, 3, 1, 4)
@@ -364,8 +366,8 @@ def test_self_attention_bf16x3(lengths, nheads, causal):
     assert (got.double() - want).abs().max().item() < 2e-4                 # scores up to ~|30|: 2^-16 of that moves a softmax weight by 5e-4 relative
 
 
-def test_self_attention_bf16x3_key_bitmap_matches_fp32_kernel():
-    """Arbitrary 256-bit key maps (LA-VAE encoder): same masks as the fp32 kernel, values within the bf16x3 budget."""
+def test_self_attention_split_key_bitmap_matches_fp32_kernel():
+    """Arbitrary 256-bit key maps (LA-VAE encoder): same masks as the fp32 kernel, values within the f16x3 budget."""
     B, Fr = 3, 206
     valid = torch.rand(B, Fr, generator=torch.Generator().manual_seed(4)) > 0.3
     valid[:, 0] = True
@@ -374,7 +376,7 @@ def test_self_attention_bf16x3_key_bitmap_matches_fp32_kernel():
     qd = qkv.to(DEV)
     a, b_ = torch.empty(B * Fr, 256, device=DEV), torch.empty(B * Fr, 256, device=DEV)
     _lib.check(lib().ladiff_decoder_self_attention(_lib.ptr(qd), None, bits.data_ptr(), _lib.ptr(a), B, Fr, _lib.stream_ptr()))
-    _lib.check(lib().ladiff_self_attention_bf16x3(_lib.ptr(qd), None, bits.data_ptr(), _lib.ptr(b_), B, Fr, 4, 0, _lib.stream_ptr()))
+    _lib.check(lib().ladiff_self_attention_split(_lib.ptr(qd), None, bits.data_ptr(), _lib.ptr(b_), B, Fr, 4, 0, _lib.stream_ptr()))
     sync()
     assert (a - b_).abs().max().item() < 2e-4 and (a - b_).abs().max().item() > 0
 
@@ -390,14 +392,15 @@ def split_rows(t):
 def unsplit_rows(s):
     """S-format [R,K] -> fp32 (hi + lo), on the CPU."""
     R, K = s.shape
-    b = s.cpu().contiguous().view(torch.bfloat16).view(R, K // 64, 2, 64).float()
+    half = torch.float16 if lib().ladiff_split_format() == 1 else torch.bfloat16
+    b = s.cpu().contiguous().view(half).view(R, K // 64, 2, 64).float()
     return (b[:, :, 0] + b[:, :, 1]).reshape(R, K)
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("M,second_ln", [(1, False), (17, True), (480, False), (1000, True), (4133, False)])
 def test_fused_mlp_layernorm(M, second_ln, variant):
-    """y = LN(x + W2 gelu(W1 x + b1) + b2) [then a second LN] in one kernel (bf16x3 products, everything else fp32) against
+    """y = LN(x + W2 gelu(W1 x + b1) + b2) [then a second LN] in one kernel (f16x3 products, everything else fp32) against
     fp64: row counts that leave waves / lanes of the last 128-row workgroup without rows; fp32 and S-format outputs agree.
     Asymmetric weights and inputs: a wrong row permutation of a weight panel or a wrong k order shows up as O(1) errors."""
     x = rnd(M, 256, scale=2.0, seed=1)
@@ -442,12 +445,12 @@ def _fused_mlp_case(M, second_ln, x, w1, b1, w2, b2, g3, be3, g4, be4, xd, xs, w
 
 
 def test_fused_mlp_matches_three_launch_path_on_a_decode():
-    """LADiffVae.decode in bf16x3 mode with the feed-forward block fused (default) and as linear1 / linear2 / LayerNorm launches
+    """LADiffVae.decode in f16x3 mode with the feed-forward block fused (default) and as linear1 / linear2 / LayerNorm launches
     (the round-2 path, same products): the frames agree to rounding."""
     from ladiff_amd import LADiffVae, synthetic as syn
     from test_abi import ABL, VAE_KW
     vae = LADiffVae(ABL, **VAE_KW); vae.load_state_dict(syn.vae_weights(263)); vae = vae.to(DEV).eval()
-    vae.precision = "bf16x3"
+    vae.precision = "f16x3"
     lens = [196, 60, 120, 1, 77, 196, 48, 150, 33]
     z = torch.randn(5, len(lens), 256, generator=torch.Generator().manual_seed(4)).to(DEV)
     for i, l in enumerate(lens):
@@ -472,15 +475,15 @@ def test_fused_mlp_matches_three_launch_path_on_a_decode():
 
 
 @pytest.mark.parametrize("nfeats", [263, 251])
-def test_final_layer_on_padded_bf16x3_tiles_matches_fp32_kernel(nfeats):
-    """From 4,096 frame rows up the bf16x3 decode runs final_layer on whole 128-column tiles of the zero-padded S-format weight and
-    scatters the real columns into [B, F, C]; + 8 keeps the round-2 fp32-input kernel.  Same frames to bf16x3 rounding, exact zeros on
+def test_final_layer_on_padded_split_tiles_matches_fp32_kernel(nfeats):
+    """From 4,096 frame rows up the f16x3 decode runs final_layer on whole 128-column tiles of the zero-padded S-format weight and
+    scatters the real columns into [B, F, C]; + 8 keeps the round-2 fp32-input kernel.  Same frames to f16x3 rounding, exact zeros on
     padded frames, for a padded batch and a ragged one (row scatter) and both feature counts."""
     from ladiff_amd import LADiffVae, synthetic as syn
     from test_abi import ABL, VAE_KW
     vae = LADiffVae(ABL, **{**VAE_KW, "nfeats": nfeats})
     vae.load_state_dict(syn.vae_weights(nfeats)); vae = vae.to(DEV).eval()
-    vae.precision = "bf16x3"
+    vae.precision = "f16x3"
     for lens in ([196] * 24, [196, 60, 120, 1, 77, 196, 48, 150, 33] * 5):
         z = torch.randn(5, len(lens), 256, generator=torch.Generator().manual_seed(len(lens))).to(DEV)
         for i, l in enumerate(lens):
@@ -499,13 +502,13 @@ def test_final_layer_on_padded_bf16x3_tiles_matches_fp32_kernel(nfeats):
 
 @pytest.mark.parametrize("lens", [[196] * 6, [196, 60, 120, 1, 77, 196, 48, 150, 33, 32, 64, 65], [1], [224, 200]])
 def test_attention_with_in_proj_inside_matches_two_launches(lens):
-    """bf16x3 decode with the self-attention kernel that computes its head's q | k | v itself (default) against in_proj GEMM +
-    attention kernel (+ 16): same frames to bf16x3 rounding - padded batches (keys >= length masked, all F query rows computed),
+    """f16x3 decode with the self-attention kernel that computes its head's q | k | v itself (default) against in_proj GEMM +
+    attention kernel (+ 16): same frames to f16x3 rounding - padded batches (keys >= length masked, all F query rows computed),
     ragged batches, one-frame and 224-frame samples, lengths on both sides of a 32-row tile edge."""
     from ladiff_amd import LADiffVae, synthetic as syn
     from test_abi import ABL, VAE_KW
     vae = LADiffVae(ABL, **VAE_KW); vae.load_state_dict(syn.vae_weights(263)); vae = vae.to(DEV).eval()
-    vae.precision = "bf16x3"
+    vae.precision = "f16x3"
     z = torch.randn(5, len(lens), 256, generator=torch.Generator().manual_seed(len(lens))).to(DEV)
     for i, l in enumerate(lens):
         z[-(-l // 48):, i] = 0
@@ -531,7 +534,7 @@ def test_graphed_decode_matches_direct_decode():
     from test_abi import ABL, VAE_KW
     vae = LADiffVae(ABL, **VAE_KW); vae.load_state_dict(syn.vae_weights(263)); vae = vae.to(DEV).eval()
     cases = [[60] * 8, [196, 60, 120, 1, 77], [48, 48]]
-    for precision in ("bf16x3", "fp32"):
+    for precision in ("f16x3", "fp32"):
         vae.precision = precision
         for rep in range(2):
             for lens in cases:

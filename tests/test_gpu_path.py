@@ -64,9 +64,9 @@ def test_denoiser_forward_golden(denoiser, t):
     assert maxdiff(eps[0], g["eps"]) < 5e-5       # every row, padded latent rows included
 
 
-def test_denoiser_forward_bf16x3(denoiser):
+def test_denoiser_forward_split(denoiser):
     g = load_golden("denoiser_forward_t981")
-    denoiser.precision = "bf16x3"
+    denoiser.precision = "f16x3"
     try:
         eps = denoiser(g["sample"].to(DEV), g["t"].to(DEV), g["text"].to(DEV), max_iter_elements=g["counts"].to(DEV))[0]
     finally:
@@ -93,8 +93,8 @@ def test_denoiser_short_latent_count(denoiser):
 
 
 @pytest.mark.parametrize("B,T", [(1, 1), (3, 2), (7, 3), (10, 4), (33, 5), (37, 5), (5, 7), (13, 8)])
-def test_denoiser_bf16x3_shapes_against_oracle(denoiser, B, T):
-    """The bf16x3 path runs on its own fused kernels (in_proj + attention per (samples, head) workgroup, row-complete
+def test_denoiser_split_shapes_against_oracle(denoiser, B, T):
+    """The f16x3 path runs on its own fused kernels (in_proj + attention per (samples, head) workgroup, row-complete
     GEMMs with LayerNorm / combine prologues): every latent count 1..8, batches that do not fill the last workgroup, masked
     latent rows - against the CPU oracle (and therefore against the fp32 kernels, which the goldens pin)."""
     sd = syn.denoiser_weights()
@@ -103,7 +103,7 @@ def test_denoiser_bf16x3_shapes_against_oracle(denoiser, B, T):
     txt = torch.randn(B, 1, 768, generator=gen)
     counts = torch.randint(1, T + 1, (B,), generator=gen)
     want = orc.denoiser_forward(sd, x, 301, txt, counts)
-    denoiser.precision = "bf16x3"
+    denoiser.precision = "f16x3"
     try:
         got = denoiser(x.to(DEV), torch.tensor(301), txt.to(DEV), max_iter_elements=counts.to(DEV))[0]
     finally:
@@ -128,10 +128,10 @@ def test_vae_decode_golden(name, nfeats):
 
 
 @pytest.mark.parametrize("name,nfeats", [("vae_decode_c1", 263), ("vae_decode_mixed_kit", 251)])
-def test_vae_decode_golden_bf16x3(name, nfeats):
+def test_vae_decode_golden_split(name, nfeats):
     g = load_golden(name)
     vae = make_vae(nfeats)
-    vae.precision = "bf16x3"
+    vae.precision = "f16x3"
     feats = vae.decode(g["z"].to(DEV), g["lengths"].tolist())
     err = maxdiff(feats, g["feats"])
     assert 0 < err < FRAME_TOL / 2
@@ -148,7 +148,7 @@ def test_vae_decode_single_frame_and_single_sample(vae):
 # ---------------------------------------------------------------- sampling loop (A1-A4)
 @pytest.mark.parametrize("tag,sched,use_graph,precision", [
     ("ddim5", "ddim", True, "fp32"), ("ddim50", "ddim", True, "fp32"), ("ddim50", "ddim", False, "fp32"),
-    ("ddpm10", "ddpm", True, "fp32"), ("ddim50", "ddim", True, "bf16x3"), ("ddpm10", "ddpm", True, "bf16x3")])
+    ("ddpm10", "ddpm", True, "fp32"), ("ddim50", "ddim", True, "f16x3"), ("ddpm10", "ddpm", True, "f16x3")])
 def test_sampling_loop_golden(denoiser, vae, tag, sched, use_graph, precision):
     g = load_golden(f"loop_{tag}")
     pipe = make_pipe(denoiser, vae, sched, int(g["n_steps"]), use_graph=use_graph, precision=precision)
@@ -157,7 +157,7 @@ def test_sampling_loop_golden(denoiser, vae, tag, sched, use_graph, precision):
                            step_noise=None if sn is None else sn.to(DEV))
     assert torch.equal(pipe.scheduler.timesteps, g["timesteps"])
     scale = max(1.0, g["latents"].abs().max().item())
-    # fp32 MFMA path: rounding only; bf16x3 path: ~2^-16 per product, still >5x inside the frame tolerance
+    # fp32 MFMA path: rounding only; f16x3 path: ~2^-16 per product, still >5x inside the frame tolerance
     assert maxdiff(z, g["latents"]) < (2e-5 if precision == "fp32" else 2e-4) * scale
     assert maxdiff(feats, g["feats"]) < (FRAME_TOL if precision == "fp32" else FRAME_TOL / 2)
     # second call through the cached hipGraph gives the same bits
@@ -212,11 +212,11 @@ def _oracle(key, fn):
     return _ORACLE_CACHE[key]
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 def test_full_size_batch_properties(denoiser, vae, precision):
     """B=128, F=196, 50-step DDIM (the benchmark's workload): samples are independent of batch composition, so a
     sub-batch run alone must reproduce its rows of the full batch; padded frames are exactly zero; and the CPU oracle
-    on the sub-batch.  Both precision modes (the bf16x3 mode runs on its own fused kernels)."""
+    on the sub-batch.  Both precision modes (the f16x3 mode runs on its own fused kernels)."""
     B = 128
     lens = [196] * 120 + [60, 120, 49, 1, 100, 150, 196, 48]
     text = syn.text_embeddings(B)
@@ -247,7 +247,7 @@ def test_full_size_batch_properties(denoiser, vae, precision):
     print(f"B=128 pipeline run, {precision}: max |frames[idx] - oracle| = {err:.3e}")
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 def test_ddpm_1000_steps_full_batch_properties(denoiser, vae, precision):
     """BASELINE config c2 at full size (1000-step DDPM, B=128, F=196; a 10-step hipGraph replayed 100 times, the per-step
     noise streamed from a [1000, B, 5, 256] tensor): finite, bit-identical when repeated, padded rows / frames exactly
@@ -285,7 +285,7 @@ def test_ddpm_1000_steps_full_batch_properties(denoiser, vae, precision):
     assert err < FRAME_TOL, err
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 def test_256_prompts_172_blocks_against_oracle(denoiser, vae, precision):
     """Twice the benchmark batch in one call (172 length-aware blocks: more than the rings hold, every stage backlogged): rows of
     the full run against the CPU oracle directly."""
@@ -304,7 +304,7 @@ def test_256_prompts_172_blocks_against_oracle(denoiser, vae, precision):
     print(f"256 prompts, {precision}: max |frames[idx] - oracle| = {err:.3e}")
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 def test_512_prompts_run_as_chunks_against_oracle(denoiser, vae, precision):
     """A batch beyond `max_prompts_per_launch` runs as balanced chunks of <= 256 prompts (two pipeline launches here, the same plan
     twice): rows on both sides of the chunk boundary and at the ends against the CPU oracle, the same bits as the unchunked call on
@@ -330,7 +330,7 @@ def test_512_prompts_run_as_chunks_against_oracle(denoiser, vae, precision):
     assert torch.equal(z1, z[:, :256])
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 @pytest.mark.parametrize("cfg_name", ["c4", "c5"])
 def test_configs_c4_c5_at_1024_prompts_on_one_gpu(denoiser, vae, precision, cfg_name):
     """BASELINE configs c4 / c5 at their STATED batch (1,024 prompts; the 8-GPU form shards them 128 per rank) on ONE GPU: c4 = 196 frames
@@ -439,7 +439,7 @@ def test_forward_uses_device_feats2joints(denoiser, vae):
 
 # ---------------------------------------------------------------- LA-VAE encode (next row)
 @pytest.mark.parametrize("name,nfeats,precision", [("vae_encode_humanml", 263, "fp32"), ("vae_encode_kit", 251, "fp32"),
-                                                   ("vae_encode_humanml", 263, "bf16x3")])
+                                                   ("vae_encode_humanml", 263, "f16x3")])
 def test_vae_encode_golden(name, nfeats, precision):
     g = load_golden(name)
     v = make_vae(nfeats)
@@ -447,7 +447,7 @@ def test_vae_encode_golden(name, nfeats, precision):
     lens = g["lengths"].tolist()
     latent, dist, counts = v.encode(g["features"].to(DEV), lens, eps=g["eps"].to(DEV))
     assert counts.tolist() == g["counts"].tolist() and latent.shape == g["latent"].shape
-    tol = 1e-4 if precision == "fp32" else 2e-3     # std = exp(logvar / 2) amplifies the bf16x3 product error
+    tol = 1e-4 if precision == "fp32" else 2e-3     # std = exp(logvar / 2) amplifies the f16x3 product error
     assert maxdiff(dist.loc, g["mu"]) < tol and maxdiff(dist.scale, g["std"]) < tol * max(1.0, g["std"].max().item())
     assert maxdiff(latent, g["latent"]) < tol * max(1.0, g["latent"].abs().max().item())
     for i, c in enumerate(g["counts"].tolist()):
@@ -492,11 +492,11 @@ def _subbatch_check(pipe_factory, text, lens, noise, idx, nfeats, z, feats, prec
     return max(err, _direct_oracle_check(z, feats, idx, lens, z_o, f_o))
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 def test_config_c5_mixed_lengths_kit_per_rank_slice(denoiser, precision):
     """BASELINE config c5, the slice one of 8 ranks runs: 128 prompts with lengths {60,120,196} (latent counts {2,3,5}),
     KIT-ML 251-dim decoder, 50-step DDIM - the whole loop + decode, both arithmetic modes (the config's "fp16" label is
-    served by the bf16x3 mode: plain fp16 operands miss the 1e-3 gate).  Full size: shape, exact zeros past
+    served by the f16x3 mode: plain fp16 operands miss the 1e-3 gate).  Full size: shape, exact zeros past
     each length / latent count, bit-identical replay; 6-prompt sub-batch (two of each length) against the CPU oracle."""
     B = 128
     lens = syn.mixed_lengths(B)
@@ -519,10 +519,10 @@ def test_config_c5_mixed_lengths_kit_per_rank_slice(denoiser, precision):
     print(f"c5 slice, {precision}: max |frames - oracle| on the sub-batch = {err:.3e}")
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 def test_config_c2_exact_batch_64(denoiser, vae, precision):
     """BASELINE config c2 at its exact size: 64 prompts x 196 frames, 50-step DDIM (the "bf16" label is served by the
-    bf16x3 mode)."""
+    f16x3 mode)."""
     B = 64
     lens = [196] * B
     text, noise = syn.text_embeddings(B, seed=61), syn.init_noise(lens, seed=62)
@@ -533,27 +533,27 @@ def test_config_c2_exact_batch_64(denoiser, vae, precision):
     print(f"c2 (B=64), {precision}: max |frames - oracle| on the sub-batch = {err:.3e}")
 
 
-# ---------------------------------------------------------------- DDPM-1000 in bf16x3 against the oracle (VERDICT r1 #1d)
-def test_ddpm_1000_steps_bf16x3_vs_oracle(denoiser, vae):
-    """BASELINE config c3's schedule (1000-step DDPM, explicit per-step noise) in the bf16x3 mode against the CPU oracle
+# ---------------------------------------------------------------- DDPM-1000 in f16x3 against the oracle (VERDICT r1 #1d)
+def test_ddpm_1000_steps_split_vs_oracle(denoiser, vae):
+    """BASELINE config c3's schedule (1000-step DDPM, explicit per-step noise) in the f16x3 mode against the CPU oracle
     on 3 prompts; the measured frame error is printed and held to the north-star gate."""
     lens = [196, 100, 150]
     text, noise = syn.text_embeddings(3, seed=31), syn.init_noise(lens, seed=32)
     sn = syn.ddpm_noise(1000, 3, seed=33)
     z_o, f_o = orc.sample_motions(syn.denoiser_weights(), syn.vae_weights(263), text, lens, noise, 1000, "ddpm", step_noise=sn)
     errs = {}
-    for precision in ("fp32", "bf16x3"):
+    for precision in ("fp32", "f16x3"):
         pipe = make_pipe(denoiser, vae, "ddpm", 1000, precision=precision)
         z, feats = pipe.sample(text.to(DEV), lens, init_noise=noise.to(DEV), step_noise=sn.to(DEV))
         errs[precision] = (maxdiff(feats, f_o), maxdiff(z, z_o) / max(1.0, z_o.abs().max().item()))
     print("DDPM-1000 vs oracle (max |frames| diff, relative latent diff): " +
           ", ".join(f"{k}: {v[0]:.3e} / {v[1]:.3e}" for k, v in errs.items()))
     assert errs["fp32"][0] < FRAME_TOL, errs
-    assert errs["bf16x3"][0] < FRAME_TOL, errs
+    assert errs["f16x3"][0] < FRAME_TOL, errs
 
 
 # ---------------------------------------------------------------- DDIM with eta > 0 (variance noise path)
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 def test_ddim_eta_half_with_step_noise(denoiser, vae, precision):
     """DDIM eta = 0.5: sigma_t > 0, so every step adds sigma_t * z_t (the `step_noise` stream of the fused loop)."""
     lens = [196, 60, 130, 48]
@@ -572,7 +572,7 @@ def test_ddim_eta_half_with_step_noise(denoiser, vae, precision):
 
 
 # ---------------------------------------------------------------- no classifier-free guidance (ladiff.py:472-490)
-@pytest.mark.parametrize("precision,use_graph", [("fp32", True), ("bf16x3", True), ("fp32", False)])
+@pytest.mark.parametrize("precision,use_graph", [("fp32", True), ("f16x3", True), ("fp32", False)])
 def test_no_guidance_branch(denoiser, vae, precision, use_graph):
     """guidance_scale <= 1: `do_classifier_free_guidance` is False, the text batch has no unconditional half and the
     network runs on the B latents only."""
@@ -683,20 +683,20 @@ def test_denoiser_forward_many_text_tokens(denoiser, N):
     want = orc.denoiser_forward(sd, x, 481, txt, counts)
     got = denoiser(x.to(DEV), torch.tensor(481), txt.to(DEV), max_iter_elements=counts.to(DEV))[0]
     assert maxdiff(got, want) < 5e-5
-    denoiser.precision = "bf16x3"                    # the same branch with bf16x3 projections (softmax / LayerNorm / AdaLN stay fp32)
+    denoiser.precision = "f16x3"                    # the same branch with f16x3 projections (softmax / LayerNorm / AdaLN stay fp32)
     try:
         got3 = denoiser(x.to(DEV), torch.tensor(481), txt.to(DEV), max_iter_elements=counts.to(DEV))[0]
     finally:
         denoiser.precision = "fp32"
     err = maxdiff(got3, want)
-    print(f"N = {N} text tokens, bf16x3 forward: max |eps - oracle| = {err:.3e}")
+    print(f"N = {N} text tokens, f16x3 forward: max |eps - oracle| = {err:.3e}")
     assert 0 < err < 1e-3
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 def test_sampling_loop_many_text_tokens(denoiser, vae, precision):
     """The fused loop with 4 text tokens per prompt (hipGraph steps, both arithmetic modes) against the CPU oracle; the measured
-    frame error of the bf16x3 mode is printed and held to the north-star gate."""
+    frame error of the f16x3 mode is printed and held to the north-star gate."""
     lens = [196, 60, 130]
     gen = torch.Generator().manual_seed(77)
     text = torch.randn(6, 4, 768, generator=gen)

@@ -38,7 +38,7 @@ def run(nets, loop, precision, B, T, steps, lens, sched="ddim", step_noise=None,
 
 
 @pytest.mark.parametrize("loop", ["pipeline32", "pipeline16", "pipeline"])
-@pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-4), ("fp32", 1e-5)])
+@pytest.mark.parametrize("precision,tol", [("f16x3", 2e-4), ("fp32", 1e-5)])
 @pytest.mark.parametrize("B,T", [(1, 5), (2, 5), (3, 5), (4, 5), (7, 5), (43, 5), (5, 1), (9, 2), (6, 3), (5, 8)])
 def test_pipeline_matches_launches(nets, loop, precision, tol, B, T):
     """32-row blocks of P = 32 / (2 T) prompts (one block, several, a partial last block), the length-aware 16-row packing,
@@ -59,13 +59,13 @@ def test_pipeline16_variant_and_replay(nets):
     """The 16-row-block variant (one guidance branch of three prompts per block, the tails join the branches) gives the same
     rows as the 32-row blocks - the arithmetic per row is identical - and a replay is bit-identical."""
     lens = [196, 60, 120, 100, 48, 150, 196, 30, 77, 196, 13]
-    z32 = run(nets, "pipeline", "bf16x3", 11, 5, 8, lens)
-    z16 = run(nets, "pipeline16", "bf16x3", 11, 5, 8, lens)
+    z32 = run(nets, "pipeline", "f16x3", 11, 5, 8, lens)
+    z16 = run(nets, "pipeline16", "f16x3", 11, 5, 8, lens)
     assert torch.equal(z32, z16)
-    assert torch.equal(z32, run(nets, "pipeline", "bf16x3", 11, 5, 8, lens))
+    assert torch.equal(z32, run(nets, "pipeline", "f16x3", 11, 5, 8, lens))
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
 @pytest.mark.parametrize("name,lens", [
     ("eight one-row prompts per block", [40] * 40),
     ("ten-row last block", [196] * 128),
@@ -83,7 +83,7 @@ def test_packed_blocks_many(nets, precision, name, lens):
     z32 = run(nets, "pipeline32", precision, B, 5, 4, lens)
     z16 = run(nets, "pipeline16", precision, B, 5, 4, lens)
     assert torch.equal(z32, z16), name
-    assert (za - z16).abs().max().item() < (2e-4 if precision == "bf16x3" else 1e-5) * max(1.0, za.abs().max().item())
+    assert (za - z16).abs().max().item() < (2e-4 if precision == "f16x3" else 1e-5) * max(1.0, za.abs().max().item())
 
 
 def test_ragged_decode_matches_padded_pass(nets):
@@ -96,7 +96,7 @@ def test_ragged_decode_matches_padded_pass(nets):
         z = torch.randn(5, B, 256, generator=torch.Generator().manual_seed(3)).to(DEV)
         for i, l in enumerate(lens):
             z[-(-l // 48):, i] = 0
-        for precision, tol in (("fp32", 1e-5), ("bf16x3", 2e-5)):
+        for precision, tol in (("fp32", 1e-5), ("f16x3", 2e-5)):
             vae.precision = precision
             vae.length_aware = False
             one = vae.decode(z, lens)
@@ -117,7 +117,7 @@ def test_stage_workgroups_of_four_and_eight_waves_agree(nets):
     lens = [196, 60, 120, 100, 48, 150, 196, 30, 77, 196, 13]
     L = _lib.lib()
     try:
-        for precision in ("bf16x3", "fp32"):
+        for precision in ("f16x3", "fp32"):
             assert L.ladiff_debug_set_stage_waves(2) == 0
             z8 = run(nets, "pipeline16", precision, 11, 5, 6, lens)
             assert L.ladiff_debug_set_stage_waves(1) == 0
@@ -137,7 +137,7 @@ def test_xcd_placement_on_and_off_agree(nets):
     L = _lib.lib()
     lens = [196] * 70 + [60, 120, 49, 1, 100, 150, 196, 48, 30, 77]
     try:
-        for precision in ("bf16x3", "fp32"):
+        for precision in ("f16x3", "fp32"):
             for loop in ("pipeline16", "pipeline32"):
                 assert L.ladiff_debug_set_xcd_local(1) == 0
                 za = run(nets, loop, precision, len(lens), 5, 7, lens)
@@ -148,7 +148,7 @@ def test_xcd_placement_on_and_off_agree(nets):
         assert L.ladiff_debug_set_xcd_local(3) != 0
         # one workgroup somewhere else than planned: the launch agrees to write through everywhere (status info -1), same bits
         den, vae = nets
-        for precision in ("bf16x3", "fp32"):
+        for precision in ("f16x3", "fp32"):
             outs = []
             for mode in (1, 2):
                 assert L.ladiff_debug_set_xcd_local(mode) == 0
@@ -164,7 +164,7 @@ def test_xcd_placement_on_and_off_agree(nets):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
 def test_repeated_full_size_calls_are_identical(nets, precision):
     """The loop is deterministic: the benchmark-size call (84 length-aware blocks, 50 steps - the partial planes' 16-slot rings
     wrap off a slot boundary at every step) gives the same bits every time, alternating with a small batch on the same
@@ -188,7 +188,7 @@ def test_repeated_full_size_calls_are_identical(nets, precision):
         assert torch.equal(z, ref) and torch.equal(zs, ref_s), (precision, it)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
 def test_old_step_graph_is_not_replayed_after_other_plans(nets, precision):
     """A hipGraph is replayed only while it is the newest graph instantiation of the process (api.hip, g_graph_epoch).  The sequence
     that failed before: launch-per-stage loop at 200 prompts (its ~150-node step graph instantiated), a blocking status read, two
@@ -227,9 +227,9 @@ def test_two_samplers_on_two_streams(nets):
     noise = torch.randn(B, 5, 256, generator=torch.Generator().manual_seed(5)).to(DEV)
     sched = lambda: DDIMScheduler(set_alpha_to_one=False, steps_offset=1, **SCHED_KW)
     ref = LADIFF(denoiser=den, vae=vae, scheduler=sched(), guidance_scale=7.5, num_inference_timesteps=20, eta=0.0, max_it=5,
-                 precision="bf16x3", loop="launches")._diffusion_reverse(text, lens, init_noise=noise)
+                 precision="f16x3", loop="launches")._diffusion_reverse(text, lens, init_noise=noise)
     pipes = [LADIFF(denoiser=den, vae=vae, scheduler=sched(), guidance_scale=7.5, num_inference_timesteps=20, eta=0.0, max_it=5,
-                    precision="bf16x3", loop="pipeline") for _ in range(2)]
+                    precision="f16x3", loop="pipeline") for _ in range(2)]
     streams = [torch.cuda.Stream(device=DEV) for _ in range(2)]
     torch.cuda.synchronize()
     outs = []
@@ -250,8 +250,8 @@ def test_pipeline_ddpm_windows(nets):
     B, T, n = 5, 5, 200
     lens = [196, 60, 120, 100, 48]
     sn = syn.ddpm_noise(n, B, seed=5).to(DEV)
-    za = run(nets, "launches", "bf16x3", B, T, n, lens, sched="ddpm", step_noise=sn)
-    zb = run(nets, "pipeline", "bf16x3", B, T, n, lens, sched="ddpm", step_noise=sn)
+    za = run(nets, "launches", "f16x3", B, T, n, lens, sched="ddpm", step_noise=sn)
+    zb = run(nets, "pipeline", "f16x3", B, T, n, lens, sched="ddpm", step_noise=sn)
     assert (za - zb).abs().max().item() < 5e-4 * max(1.0, za.abs().max().item())
 
 
@@ -261,7 +261,7 @@ def test_window_timing_switch_reaches_plans_made_later(nets):
     B, T, n = 3, 5, 200                                             # four windows of 50 steps
     lens = [196, 60, 120]
     pipe = LADIFF(denoiser=den, vae=vae, scheduler=DDPMScheduler(variance_type="fixed_small", **SCHED_KW), guidance_scale=7.5,
-                  num_inference_timesteps=n, eta=0.0, max_it=T, precision="bf16x3", loop="pipeline")
+                  num_inference_timesteps=n, eta=0.0, max_it=T, precision="f16x3", loop="pipeline")
     pipe.window_ms(enable=True)
     text, noise = syn.text_embeddings(B, seed=3), syn.init_noise(lens, seed=4)
     pipe._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV), noise_seed=5)
@@ -274,7 +274,7 @@ def test_window_timing_switch_reaches_plans_made_later(nets):
 def _fault_pipe(nets, **kw):
     den, vae = nets
     return LADIFF(denoiser=den, vae=vae, scheduler=DDIMScheduler(set_alpha_to_one=False, steps_offset=1, **SCHED_KW),
-                  guidance_scale=7.5, num_inference_timesteps=8, eta=0.0, max_it=5, precision="bf16x3", loop="pipeline", **kw)
+                  guidance_scale=7.5, num_inference_timesteps=8, eta=0.0, max_it=5, precision="f16x3", loop="pipeline", **kw)
 
 
 def test_aborted_pipeline_launch_raises_poisons_and_recovers(nets):
@@ -330,7 +330,7 @@ def test_aborted_pipeline_launch_raises_poisons_and_recovers(nets):
         sn = syn.ddpm_noise(200, B, seed=5).to(DEV)
         den, vae = nets
         wp = LADIFF(denoiser=den, vae=vae, scheduler=DDPMScheduler(variance_type="fixed_small", **SCHED_KW), guidance_scale=7.5,
-                    num_inference_timesteps=200, eta=0.0, max_it=5, precision="bf16x3", loop="pipeline")
+                    num_inference_timesteps=200, eta=0.0, max_it=5, precision="f16x3", loop="pipeline")
         wp.set_pipeline_fault(17, 20)
         zw = wp._diffusion_reverse(text.to(DEV), lens, init_noise=noise.to(DEV), step_noise=sn)
         assert torch.isnan(zw).all() and wp.loop_status()[0] == 2
@@ -367,7 +367,7 @@ def test_fallback_result_matches_oracle(nets):
     assert (feats.cpu() - f_o).abs().max().item() < 1e-3
 
 
-@pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-4), ("fp32", 1e-5)])
+@pytest.mark.parametrize("precision,tol", [("f16x3", 2e-4), ("fp32", 1e-5)])
 @pytest.mark.parametrize("B,T", [(1, 5), (3, 5), (7, 5), (40, 5), (130, 5), (9, 2), (5, 8)])
 def test_pipeline_without_guidance_matches_launches(nets, precision, tol, B, T):
     """guidance_scale <= 1 (ladiff.py:472-490): the network sees the B latents once.  The pipeline runs it as one-branch 16-row
@@ -395,7 +395,7 @@ def _with_handoff(tagged, fn):
         L.ladiff_debug_set_handoff(1)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
 @pytest.mark.parametrize("B,T,steps,guidance", [
     (1, 5, 3, 7.5), (3, 5, 2, 7.5), (7, 5, 5, 7.5), (43, 5, 6, 7.5),      # one unit, padding rows in every tile, an odd step count
     (5, 1, 4, 7.5), (9, 2, 4, 7.5), (5, 8, 3, 7.5),                        # 1 ... 8 latent rows per prompt: blocks with idle waves and 16 live rows
@@ -418,12 +418,12 @@ def test_tagged_handoff_ddpm_windows_and_replays(nets):
     B, T = 11, 5
     lens = [196, 60, 120, 100, 48, 150, 196, 30, 77, 196, 13]
     sn = syn.ddpm_noise(200, B, seed=5).to(DEV)
-    zf = _with_handoff(False, lambda: run(nets, "pipeline16", "bf16x3", B, T, 200, lens, sched="ddpm", step_noise=sn))
-    zt = _with_handoff(True, lambda: run(nets, "pipeline16", "bf16x3", B, T, 200, lens, sched="ddpm", step_noise=sn))
+    zf = _with_handoff(False, lambda: run(nets, "pipeline16", "f16x3", B, T, 200, lens, sched="ddpm", step_noise=sn))
+    zt = _with_handoff(True, lambda: run(nets, "pipeline16", "f16x3", B, T, 200, lens, sched="ddpm", step_noise=sn))
     assert torch.equal(zf, zt)
-    first = run(nets, "pipeline16", "bf16x3", B, T, 50, lens)
+    first = run(nets, "pipeline16", "f16x3", B, T, 50, lens)
     for _ in range(10):
-        assert torch.equal(run(nets, "pipeline16", "bf16x3", B, T, 50, lens), first)
+        assert torch.equal(run(nets, "pipeline16", "f16x3", B, T, 50, lens), first)
 
 
 def test_tagged_handoff_full_batch_soak(nets):
@@ -431,14 +431,14 @@ def test_tagged_handoff_full_batch_soak(nets):
     tagged words) while alternating with the flag protocol: every call bit-identical to the first."""
     B, T = 128, 5
     lens = [196] * B
-    ref = _with_handoff(False, lambda: run(nets, "pipeline16", "bf16x3", B, T, 50, lens))
+    ref = _with_handoff(False, lambda: run(nets, "pipeline16", "f16x3", B, T, 50, lens))
     for i in range(30):
-        z = _with_handoff(i % 5 != 4, lambda: run(nets, "pipeline16", "bf16x3", B, T, 50, lens))
+        z = _with_handoff(i % 5 != 4, lambda: run(nets, "pipeline16", "f16x3", B, T, 50, lens))
         assert torch.equal(z, ref), f"call {i} differs"
 
 
 # ---------------------------------------------------------------- round 4: measurement switches of the pipeline that must not change a bit
-@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
 def test_stage_plan_and_poll_pause_switches_keep_the_bits(nets, precision):
     """`ladiff_debug_set_stage_plan(1)` (OUT as two workgroups on alternating blocks, STYL as one group: 246 workgroups instead of 255)
     and `ladiff_debug_set_poll_pause` (waves of chosen stage types rest between polls) re-deal work and change timing only: the

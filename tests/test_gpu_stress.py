@@ -22,7 +22,7 @@ def _run(script, *args, timeout=900):
 @pytest.mark.slow
 def test_random_decode_shapes():
     """LADiffVae.decode on 80 random batches (1 ... 257 samples, five length patterns, both feature counts, ragged and padded): the default
-    bf16x3 path against each fusion switched off, against fp32 mode, twice (same bits), frames past each length exactly zero."""
+    f16x3 path against each fusion switched off, against fp32 mode, twice (same bits), frames past each length exactly zero."""
     out = _run("stress_decode.py", 80, 17)
     assert "80 decode shapes done, 0 bad" in out
 
