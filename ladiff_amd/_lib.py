@@ -151,6 +151,22 @@ _SIGNATURES = {
 
 EXPORTS = tuple(_SIGNATURES)
 _lib = None
+LIB_PATH_BF16 = os.path.join(_HERE, "libladiff_hip_bf16.so")      # the same library built with -DLADIFF_SPLIT_BF16 (build.build_all)
+
+
+def select_split_format(fmt):
+    """Process-wide choice of the split arithmetic's operand pairs, BEFORE the library is first used: "fp16" (the default build: 22
+    significant bits, each half saturates at +-65504 - every GEMM operand of the shipped networks is a LayerNorm output, an activation
+    of one, a softmax probability or a latent; 241 at most on the random-init weights, tests/test_operand_range.py) or "bf16" (16
+    bits, fp32's exponent range: for weights whose activations leave fp16's range).  One format per process: the S-format weight
+    copies and every kernel agree on it by construction."""
+    global LIB_PATH, _lib
+    if fmt not in ("fp16", "bf16"):
+        raise ValueError(f'split format must be "fp16" or "bf16", got {fmt!r}')
+    path = LIB_PATH_BF16 if fmt == "bf16" else os.path.join(_HERE, "libladiff_hip.so")
+    if _lib is not None and path != LIB_PATH:
+        raise LadiffHipError("select_split_format() after the library has been used: weight tables of the other format exist")
+    LIB_PATH = path
 
 
 def lib():

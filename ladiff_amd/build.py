@@ -77,7 +77,18 @@ def build(force=False, verbose=False, stamps=False, tag=None, defines=()):
     return lib
 
 
+def build_all(force=False, verbose=False):
+    """Both flavours of the product: libladiff_hip.so (split operands as fp16 pairs) and libladiff_hip_bf16.so (bf16 pairs,
+    _lib.select_split_format("bf16"))."""
+    lib = build(force=force, verbose=verbose)
+    build(force=force, verbose=verbose, tag="bf16", defines=["LADIFF_SPLIT_BF16"])
+    return lib
+
+
 if __name__ == "__main__":
     _tag = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--tag=")), None)
     _defs = [a[2:] for a in sys.argv if a.startswith("-D")]
-    print(build(force="--force" in sys.argv, verbose=True, stamps="--stamps" in sys.argv, tag=_tag, defines=_defs))
+    if "--all" in sys.argv:
+        print(build_all(force="--force" in sys.argv, verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True, stamps="--stamps" in sys.argv, tag=_tag, defines=_defs))

@@ -868,20 +868,44 @@ struct QkvRole {
         auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
         f32x4 x[2][2];                                                   // loader waves: a block's rows between their loads and the tile
         bool xissued = false, first = true;                              // ... already requested (behind the previous block's tile); complete at the first look
+        // The loader threads' geometry words of a block (one load per value, QkvRole::geo) are fetched ONE BLOCK AHEAD (round 6): read at the
+        // top of the block's own iteration they stood in front of the text / time K|V loads, whose addresses they are - the loader
+        // waves' chain per block was three dependent round trips (geometry, K|V slot 0, K|V slot 1: the compiler waits vmcnt(0) at the
+        // head of every divergent region) before the rows were even looked at.  They wait in LDS, not in registers (the role sits at
+        // 256 VGPRs: four loop-carried words per loader thread spilled a weight fragment, reloaded inside the block loop): a thread
+        // requests the NEXT block's words beside this block's K|V and row loads, writes them to its own 16-byte slot once the rows'
+        // tags are right (the same vmcnt(0) covers them), and reads the slot back at the top of the next iteration.
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        i32x4* const gslot = reinterpret_cast<i32x4*>(gd + 64) + (loader ? tl : 0);
+        auto load_geo = [&](int bb, int (&b2o)[2], int& gwo, int& rb2o) __attribute__((always_inline)) {
+            const BlockDesc* d = p.blocks + bb;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int sx = (tl + 256 * u) >> 5; b2o[u] = sx < 15 ? d->b2[sx] : -1; }
+            const int* src = tl == 0 ? &d->nrows : &d->row_pk[tl <= RT ? tl - 1 : 0];
+            gwo = *src;
+            rb2o = d->row_b2[tl >= 1 && tl <= RT ? tl - 1 : 0];
+        };
+        if (loader && st.blk0 < p.NB) {
+            int b2f[2], gwf, rb2f;
+            load_geo(st.blk0, b2f, gwf, rb2f);
+            *gslot = i32x4{b2f[0], b2f[1], gwf, rb2f};
+        }
         SYS_SPLIT_DECL;
         for (int s = 0; s < p.n_steps; ++s)
             for (int b = st.blk0; b < p.NB; b += st.blkstride) {
                 f32x4 xk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
                 int gw = 0;
                 if (loader) {
-                    const BlockDesc* d = p.blocks + b;
-                    // geometry words first: they arrive while the flags are polled (one load per value, QkvRole::geo)
-                    int b2[2];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) { const int sx = (tl + 256 * u) >> 5; b2[u] = sx < 15 ? d->b2[sx] : -1; }
-                    const int* src = tl == 0 ? &d->nrows : &d->row_pk[tl <= RT ? tl - 1 : 0];
-                    gw = *src;
-                    const int rb2 = d->row_b2[tl >= 1 && tl <= RT ? tl - 1 : 0];
+                    const i32x4 g4 = *gslot;                             // this thread's own slot: no barrier
+                    int b2[2] = {g4[0], g4[1]};
+                    gw = g4[2];
+                    const int rb2 = g4[3];
+                    int nb2[2], ngw, nrb2;
+                    {
+                        int bn = b + st.blkstride;
+                        if (bn >= p.NB) bn = st.blk0;
+                        load_geo(bn, nb2, ngw, nrb2);
+                    }
                     // the text / time K|V rows do not depend on the block's flags (the per-call tables): they are requested BEFORE the
                     // wait - these are plain loads of rows nobody touched since the prologue, often a trip to the memory side
                     // (buffer loads with the table's base in scalar registers: as 64-bit per-lane pointers these addresses were spilled)
@@ -923,6 +947,7 @@ struct QkvRole {
                     }
                     SYS_SPLIT_WAIT;
                     SYS_STAMP_L(1);
+                    *gslot = i32x4{nb2[0], nb2[1], ngw, nrb2};           // the next block's words (requested above, landed with the rows)
                     if (tl >= 1 && tl <= RT && ((gw >> 16) & 0xff) == 0xff) {        // a latent count that lives on the device only
                         int c = T;
                         if (rb2 >= 0 && p.counts != nullptr) { c = p.counts[rb2 % p.B]; c = c > T ? T : c; }

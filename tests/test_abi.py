@@ -259,3 +259,22 @@ def test_host_sinusoid_matches_oracle():
     from oracle import ladiff_oracle as orc
     t = torch.tensor([981, 481, 1])
     assert torch.equal(timestep_sinusoid(t), orc.timestep_sinusoid(t))
+
+
+def test_both_split_flavours_are_built_and_say_what_they_are(lib):
+    """build_all(): libladiff_hip.so carries split operands as fp16 pairs, libladiff_hip_bf16.so as bf16 pairs; same exports."""
+    import ctypes
+    import subprocess
+    from ladiff_amd import build
+    build.build_all()
+    assert lib.ladiff_split_format() == 1
+    other = ctypes.CDLL(_lib.LIB_PATH_BF16)
+    other.ladiff_split_format.restype = ctypes.c_int
+    assert other.ladiff_split_format() == 0 and other.ladiff_version() == lib.ladiff_version()
+    syms = lambda p: sorted(l.split()[-1] for l in subprocess.run(["nm", "-D", "--defined-only", p], capture_output=True, text=True).stdout.splitlines()
+                            if " T " in l)
+    assert syms(_lib.LIB_PATH) == syms(_lib.LIB_PATH_BF16)
+    with pytest.raises(ValueError):
+        _lib.select_split_format("fp8")
+    with pytest.raises(_lib.LadiffHipError):            # this process has loaded the fp16 library already
+        _lib.select_split_format("bf16")

@@ -1,5 +1,6 @@
 """GPU parity of the whole hot path (drop-in modules + loop owner) against golden vectors captured from the
 reference and against the CPU oracle; plus size-independent properties at the benchmark's full size."""
+import os
 from types import SimpleNamespace
 
 import pytest
@@ -7,7 +8,7 @@ import torch
 
 from ladiff_amd import LADIFF, DDIMScheduler, DDPMScheduler, LADiffDenoiser, LADiffVae, _lib, synthetic as syn
 from oracle import ladiff_oracle as orc
-from conftest import load_golden
+from conftest import ROOT, load_golden
 from test_abi import ABL, DEN_KW, VAE_KW
 
 pytestmark = pytest.mark.gpu
@@ -754,3 +755,11 @@ def test_test_diffusion_forward_rs_set(denoiser, vae):
     # finetune_decoder=True / no ground truth: the three generation entries only (:1092)
     rs2 = model.test_diffusion_forward({"text": ["a", "b", "c"], "length": lens})
     assert set(rs2) == {"m_rst", "lat_t", "joints_rst"}
+
+
+def test_bf16_pair_flavour_of_the_library():
+    """libladiff_hip_bf16.so (fp32's exponent range, 16-bit operands: `_lib.select_split_format("bf16")`, one format per process) samples
+    within the gate as well; run in a child process of its own."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bf16_flavour_check.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "split format 0 (bf16x3)" in r.stdout, (r.stdout + r.stderr)[-800:]
