@@ -877,6 +877,7 @@ struct QkvRole {
         // tags are right (the same vmcnt(0) covers them), and reads the slot back at the top of the next iteration.
         typedef int i32x4 __attribute__((ext_vector_type(4)));
         i32x4* const gslot = reinterpret_cast<i32x4*>(gd + 64) + (loader ? tl : 0);
+        f32x4* const xstage = reinterpret_cast<f32x4*>(gd + 64 + 256 * 4) + (loader ? tl : 0);      // [2][256]
         auto load_geo = [&](int bb, int (&b2o)[2], int& gwo, int& rb2o) __attribute__((always_inline)) {
             const BlockDesc* d = p.blocks + bb;
 #pragma unroll
@@ -948,6 +949,10 @@ struct QkvRole {
                     SYS_SPLIT_WAIT;
                     SYS_STAMP_L(1);
                     *gslot = i32x4{nb2[0], nb2[1], ngw, nrb2};           // the next block's words (requested above, landed with the rows)
+                    // EARLY (rows queue up: the row registers stay in flight across the projection): the text / time K|V units wait in LDS
+                    // too - eight registers less across the tile build and the projection, where this instantiation reloaded a spilled
+                    // weight fragment in every block (loop -0.65 % at 128 prompts; the other instantiation loses 0.3 % with it: not there)
+                    if constexpr (EARLY) { xstage[0] = xk[0]; xstage[256] = xk[1]; }
                     if (tl >= 1 && tl <= RT && ((gw >> 16) & 0xff) == 0xff) {        // a latent count that lives on the device only
                         int c = T;
                         if (rb2 >= 0 && p.counts != nullptr) { c = p.counts[rb2 % p.B]; c = c > T ? T : c; }
@@ -989,7 +994,7 @@ struct QkvRole {
                 SYS_STAMP(2);
                 if (loader) {                                            // text / time K|V and the geometry words of THIS block
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) st4(xt + (tl + 256 * u) * 4, xk[u]);
+                    for (int u = 0; u < 2; ++u) st4(xt + (tl + 256 * u) * 4, EARLY ? xstage[256 * u] : xk[u]);
                     if (tl <= RT) gd[tl] = gw;
                 }
                 project();
