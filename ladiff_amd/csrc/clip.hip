@@ -11,6 +11,7 @@
 // batch for prompts of 1 .. 30 words; q / k / v are one batched GEMM launch.  Large GEMMs go through launch_gemm (fp32 MFMA, or f16x3 with S-format
 // operands when a split weight table is given); the attention core is the decoder's MFMA kernel with 12 heads + causal.
 #include "model.h"
+#include "gemm_kr.h"
 
 namespace ladiff {
 
@@ -119,13 +120,41 @@ static int ln_rows(const float* x, const int32_t* eos, int L, const NormW& n, in
     return 0;
 }
 
-size_t clip_ws_floats(int B, int L) {
-    const size_t M = (size_t)B * L;
-    return M * (2 * CW /*x ping-pong*/ + CW /*h*/ + 3 * CW /*qkv*/ + CW /*att*/ + CFF /*mlp*/) + (size_t)B * CW + (size_t)B + 64;
-}
+// Few rows (a demo.py call: the empty prompt + one prompt = ~40 rows; round 6): the 128-row tiles of the large-M GEMM leave N / 128 =
+// 6 .. 24 workgroups, each walking the whole K - 45 us per GEMM whatever its size, 1.9 of a single prompt's 10 ms (profiles/r6/11_*).
+// Up to CLIP_SMALL_ROWS rows the split mode's GEMMs run on the denoiser's K-resident 64x64 tiles instead (gemm_kr.hip: one 256-wide
+// K slice per workgroup, K / 256 = 3 or 12 partial planes, 36 .. 144 workgroups that each move 64 KB) and a row pass sums the
+// planes and applies bias / quick_gelu / residual: the same S-format operands and split products, summed per K slice.
+constexpr int CLIP_SMALL_ROWS = 256;
+constexpr int CLIP_PLANE_COLS = 12 * CW;       // floats per row of the partial planes: max over the GEMMs of (K / 256) * N = 3 * 3072 = 12 * 768 = 9216
 
 size_t clip_ws_floats_rows(int B, int M) {
-    return (size_t)M * (2 * CW + CW + 3 * CW + CW + CFF) + (size_t)B * CW + (size_t)B + 64;
+    return (size_t)M * (2 * CW /*x ping-pong*/ + CW /*h*/ + 3 * CW /*qkv*/ + CW /*att*/ + CFF /*mlp*/) + (size_t)B * CW + (size_t)B + 64 +
+           (size_t)(M <= CLIP_SMALL_ROWS ? M : 0) * CLIP_PLANE_COLS;
+}
+size_t clip_ws_floats(int B, int L) { return clip_ws_floats_rows(B, B * L); }
+
+// y = act(sum_k planes[k] + bias) + res over [M, N] (N % 4 == 0): fp32 and / or S-format; planes [np][M][ld]
+__global__ __launch_bounds__(256) void clip_reduce_kernel(const float* __restrict__ planes, int np, size_t plane, int ld, int M, int N,
+                                                          const float* __restrict__ bias, int act, const float* __restrict__ res, int ldres,
+                                                          float* __restrict__ y, float* __restrict__ ys, int ldy) {
+    const int n4 = N / 4;
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (size_t)M * n4) return;
+    const int row = (int)(id / n4), c = 4 * (int)(id % n4);
+    f32x4 v = ld4(planes + (size_t)row * ld + c);
+    for (int k = 1; k < np; ++k) {
+        const f32x4 t = ld4(planes + k * plane + (size_t)row * ld + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += t[i];
+    }
+    const f32x4 b = ld4(bias + c);
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    if (res != nullptr) r = ld4(res + (size_t)row * ldres + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = act_apply(v[i] + b[i], act) + r[i];
+    if (y != nullptr) st4(y + (size_t)row * ldy + c, v);
+    if (ys != nullptr) store_split4(ys + (size_t)row * ldy, c, v);
 }
 
 // seq_len / row_off / row_seq (all or none): ragged rows - prompt b has seq_len[b] = 1 + (its EOS position) rows from row_off[b]
@@ -148,11 +177,32 @@ int clip_text_encode(const ClipW& w, const ClipW* wsp, int n_layers, int vocab, 
     float* qkv = p; p += (size_t)M * 3 * CW;
     float* att = p; p += (size_t)M * CW;
     float* mlp = p; p += (size_t)M * CFF;
+    const bool small = sp && M <= CLIP_SMALL_ROWS;
+    float* planes = p; p += (size_t)(M <= CLIP_SMALL_ROWS ? M : 0) * CLIP_PLANE_COLS;   // [K / 256][M][ld] partial planes of the small-row path (16-byte aligned: every size so far is a multiple of 768 floats)
     float* pooled = p; p += (size_t)B * CW;
     int32_t* eos = reinterpret_cast<int32_t*>(p);
 
+    // small-row path: S-format A [M, K] x S-format W [N, K] -> K / 256 planes (row stride ld, written at column col0) ...
+    auto kr_planes = [&](const float* A, int K, const float* Wsp, int N, int ld, int col0) -> int {
+        KrArgs g;
+        g.A = A; g.lda = K; g.W = Wsp; g.ldw = K; g.Y = planes + col0; g.ldy = ld; g.M = M; g.N = N; g.K = K; g.split = 1;
+        if (K == 256) return LADIFF_ERR_SHAPE;   // (a single slice would apply the epilogue itself: not a shape of this tower)
+        return launch_gemm_kr(g, s);
+    };
+    // ... and their sum + bias, activation, residual
+    auto reduce = [&](int K, int N, int ld, const float* bias, int act, const float* res, int ldres, float* Y, float* Ys, int ldy) -> int {
+        const size_t n = (size_t)M * (N / 4);
+        hipLaunchKernelGGL(clip_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, planes, K / 256, (size_t)M * ld, ld, M, N, bias, act,
+                           res, ldres, Y, Ys, ldy);
+        LADIFF_LAUNCH_CHECK();
+        return 0;
+    };
     auto gemm = [&](const float* A, int K, const LinearW& l, const LinearW& ls, float* Y, int ldy, int N, int act,
                     const float* res, bool split_out) -> int {
+        if (small) {
+            LADIFF_TRY(kr_planes(A, K, ls.w, N, N, 0));
+            return reduce(K, N, N, l.b, act, res, ldy, split_out ? nullptr : Y, split_out ? Y : nullptr, ldy);
+        }
         GemmArgs g;
         g.A = A; g.lda = K; g.W = sp ? ls.w : l.w; g.ldw = K; g.bias = l.b; g.M = M; g.N = N; g.K = K; g.act = act; g.ldy = ldy;
         g.res = res; g.ldres = ldy; g.split = sp ? 1 : 0;
@@ -173,7 +223,17 @@ int clip_text_encode(const ClipW& w, const ClipW* wsp, int n_layers, int vocab, 
         LADIFF_TRY(ln_rows(x, nullptr, 0, W.ln1, M, sp ? nullptr : h, sp ? h : nullptr, s));
         // q | k | v packed by columns; the 1/sqrt(64) query scale is applied (exactly) inside the attention kernel.  One batched
         // launch of the three same-shape products (each alone leaves half of the chip idle at a few thousand rows)
-        {
+        if (small) {                             // q | k | v: three launches into one set of planes [3][M][2304], one row pass (the biases differ per part)
+            const LinearW* lw[3] = {&W.q, &W.k, &W.v};
+            const LinearW* lws[3] = {&Ws.q, &Ws.k, &Ws.v};
+            for (int i = 0; i < 3; ++i) LADIFF_TRY(kr_planes(h, CW, lws[i]->w, CW, 3 * CW, i * CW));
+            for (int i = 0; i < 3; ++i) {
+                const size_t n = (size_t)M * (CW / 4);
+                hipLaunchKernelGGL(clip_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, planes + i * CW, CW / 256, (size_t)M * 3 * CW,
+                                   3 * CW, M, CW, lw[i]->b, (int)ACT_NONE, (const float*)nullptr, 0, qkv + i * CW, (float*)nullptr, 3 * CW);
+                LADIFF_LAUNCH_CHECK();
+            }
+        } else {
             GemmArgs g3[3];
             const LinearW* lw[3] = {&W.q, &W.k, &W.v};
             const LinearW* lws[3] = {&Ws.q, &Ws.k, &Ws.v};

@@ -44,6 +44,21 @@ def test_truncation_and_dedup_are_exact():
     assert torch.equal(a[0], a[6]) and torch.equal(a[0], a[8]) and torch.equal(a[1], a[7])
 
 
+def test_few_rows_path_of_the_split_mode_against_the_many_rows_path_and_the_oracle():
+    """csrc/clip.hip: up to 256 rows (a demo.py call: "" + one prompt) the split mode's GEMMs run on the K-resident 64x64 tiles with K / 256
+    partial planes + a row pass; above, on the large-M tiles.  The same prompts through both (ragged rows: few; every prompt padded to 77
+    positions: many) and against the CPU oracle, full 12-layer geometry."""
+    vocab, layers = 49408, 12
+    sd = syn.clip_weights(vocab, layers)
+    ids = syn.clip_token_ids(2, vocab, empty_first=1, seed=5)                # the guidance batch of ONE prompt
+    enc = make_encoder(vocab, layers, "f16x3")
+    few = enc.encode_ids(ids)                                                # ~3 + n rows
+    many = enc.encode_ids(torch.cat([ids] * 3), full_length=True, dedup=False)[:2]   # 6 x 77 = 462 rows
+    ref = orc.clip_text_features(sd, ids, layers)
+    assert maxdiff(few, ref) < TOL["f16x3"] and maxdiff(many, ref) < TOL["f16x3"]
+    assert maxdiff(few, many) < 1e-5
+
+
 def test_guidance_batch_against_oracle():
     """[""] * B + prompts (ladiff.py:258-262) at a batch the oracle finishes in seconds; 4-layer tower, full vocabulary."""
     vocab, layers, B = 49408, 4, 24
