@@ -53,10 +53,11 @@ def stats(lo, hi):
                 memtime=c(r"s_memrealtime|s_memtime"), wait=vm)
 def guess(s):
     if s["mfma"] == 0: return "poll / row loop" if s["sleep"] else "-"
-    if s["exp"] and s["dpp"] > 40 and s["rsq"] == 0: return "QKV (projection + 7-key attention)"
-    if s["rsq"] and s["exp"] == 0 and s["mfma"] <= 200: return "OUT / SKIP / RED-like (product + LayerNorm)"
-    if s["exp"] and s["rcp"] and s["rsq"] == 0: return "FFN (two products, GELU)"
-    if s["exp"] and s["rsq"]: return "STYL (LayerNorm, AdaLN, SiLU, product)"
+    if s["mfma"] == 72 or (s["exp"] and s["dpp"] > 40 and s["rsq"] == 0): return "QKV (wave-group loop: loader chain, projection, 7-key attention)"
+    if s["rsq"] and s["exp"] == 0 and s["dpp"] >= 32: return "OUT (wave-group loop: loader chain, out-projection, residual + LayerNorm epilogue)"
+    if s["exp"] and s["rsq"]: return "STYL (eight partial planes, LayerNorm, AdaLN, SiLU, 256x256 product)"
+    if s["exp"] and s["rcp"]: return "FFN (two products, GELU)"
+    if s["buf_ld"] >= 8 and s["buf_st"] <= 1: return "SKIP (K = 512 product of two row images)"
     return "LIN (two products, ReLU)"
 outer = [(lo, hi) for lo, hi in loops if stats(lo, hi)["mfma"] > 0]
 # keep the innermost MFMA-bearing loops that are not contained in a smaller MFMA loop (block loops); print nested poll loops beneath
