@@ -247,10 +247,31 @@ def test_split_format_round_trip():
     assert (back - x).abs().max().item() <= 2.0 ** -bits * x.abs().max().item()
 
 
+def test_split_operands_saturate_instead_of_overflowing():
+    """The fp16 halves of a split operand (csrc/common.h: v_cvt_pkrtz_f16_f32 rounds toward zero and never produces an infinity): an
+    operand is exact to 22 bits up to 65504, degrades gracefully up to 131008 (both halves saturated) and is CLIPPED beyond - never an
+    infinity or a NaN.  The bf16 flavour of the library keeps fp32's range: there the round trip is exact to 16 bits everywhere."""
+    x = torch.tensor([[1.0, -3.5, 60000.0, 65504.0, -100000.0, 131008.0, 1.0e6, -3.0e38] + [0.0] * 56] * 2)
+    back = from_split(to_split(x))
+    assert torch.isfinite(back).all()
+    if lib().ladiff_split_format() == 1:
+        assert torch.equal(back[0, :4], x[0, :4]) and back[0, 4].item() == -100000.0 and back[0, 5].item() == 131008.0
+        assert back[0, 6].item() == 131008.0 and back[0, 7].item() == -131008.0          # clipped at hi + lo = 2 x 65504
+    else:
+        assert ((back - x).abs() <= 2.0 ** -16 * x.abs()).all()
+    # a product whose operands sit just inside fp16's range: finite, and as accurate as any other
+    A, W = rnd(64, 256, scale=15000.0), rnd(256, 256, scale=1 / 16)
+    got = gemm_resident(A, W, split=True)
+    want = ref_gemm(A, W)
+    assert torch.isfinite(got).all()
+    bits = 20 if lib().ladiff_split_format() == 1 else 14
+    assert (got.double() - want).abs().max().item() < 2.0 ** -bits * (A.abs().double() @ W.abs().double().t()).max().item()
+
+
 @pytest.mark.parametrize("M,N,K,act", [(1280, 1024, 256, "gelu"), (1280, 768, 256, "none"), (1280, 256, 256, "none"),
                                        (77, 1024, 256, "relu"), (1280, 256, 1024, "none"), (90, 256, 512, "none")])
 def test_gemm_resident_split(M, N, K, act):
-    """3-term bf16 split products: ~2^-16 relative error per product (vs 2^-24 for the fp32 MFMA path)."""
+    """3-term split products: ~2^-21 relative error per product with fp16 pairs, ~2^-16 with bf16 pairs (2^-24: the fp32 MFMA path); the bound below holds for both."""
     A, W, b = rnd(M, K, scale=3.0), rnd(N, K, scale=1 / math.sqrt(K)), rnd(N)
     if K == 256:
         res = rnd(M, N, seed=7)
