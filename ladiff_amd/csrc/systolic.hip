@@ -392,6 +392,12 @@ __device__ __forceinline__ void rows_bad(unsigned& bad, const Rows256<MR, WS>& x
     for (int u = 0; u < 2 * MR / WS; ++u) { tag_acc(bad, x.v[u][0], par); tag_acc(bad, x.v[u][1], par); }
 }
 
+template <int MR, int WS>
+__device__ __forceinline__ void rows_touch(Rows256<MR, WS>& x) {          // reg_touch on a row image: no instruction
+#pragma unroll
+    for (int u = 0; u < 2 * MR / WS; ++u) { reg_touch(x.v[u][0]); reg_touch(x.v[u][1]); }
+}
+
 // LayerNorm statistics of a 256-column row, two-pass, fp32 (as rowops.hip).  The per-lane parts are shared by the two layouts
 // below so that both sum in the same order: a lane's four consecutive columns first, then 16 lanes (row16_sum), then the four
 // 64-column quarters as (q3 + q2) + (q1 + q0) - what wave_sum does with its two row broadcasts.
@@ -621,7 +627,16 @@ struct MidTag {
         if (s3 < p.n_steps) r.geo(b3, gnn);
     }
     __device__ __forceinline__ void before_stores() {
-        if constexpr (R::PREFETCH) { if (ahead) settled = __all((r.bad(s2, b2, gnxt, nxt) & 1u) == 0u); }
+        if constexpr (R::PREFETCH) {
+            if (ahead) settled = __all((r.bad(s2, b2, gnxt, nxt) & 1u) == 0u);
+            // The look has waited for the early request (no store of this wave is in flight here: the wait is exact).  From here on the rows
+            // are plain register values to the compiler (round 6) - on EVERY path, also the one on which nothing was requested (the request and
+            // the look hang on the same condition in two places; the compiler does not know that, and a path "requested but not looked at"
+            // kept its bookkeeping of a load in flight alive).  Without this it guarded the rows' next use - the tile build at the top of
+            // the next iteration - with `s_waitcnt vmcnt(0)`, and there the only thing in flight is THIS block's stores: the drain the
+            // tagged hand-off exists to avoid stood at the top of every block of LIN / FFN / SKIP.
+            r.touch(nxt);
+        }
     }
 };
 template <class R>
@@ -711,6 +726,11 @@ struct QkvRole {
     static constexpr bool TILE = true;
     struct Geo { int gw, rb2, b2[NX]; };                                 // descriptor word `tid` (+ its row's sample-branch); sample-branch of this thread's text slots
     struct Pay { Rows256<MR, WS> x; f32x4 xk[NX]; };
+    __device__ __forceinline__ void touch(Pay& y) const {
+        rows_touch<MR, WS>(y.x);
+#pragma unroll
+        for (int u = 0; u < NX; ++u) reg_touch(y.xk[u]);
+    }
     const SysArgs& p; const Stage& st;
     char* atile; float *qt, *xt; int* gd;
     WFrag<AR, NTW, 8> wf;
@@ -1094,6 +1114,11 @@ struct OutRole {
     static constexpr bool TILE = true;
     struct Geo {};
     struct Pay { Rows256<MR, WS> att; f32x4 res[RPW]; };
+    __device__ __forceinline__ void touch(Pay& y) const {
+        rows_touch<MR, WS>(y.att);
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) reg_touch(y.res[q]);
+    }
     const SysArgs& p; const Stage& st;
     char* atile; float* ct;
     WFrag<AR, NTW, 8> wf;
@@ -1313,6 +1338,7 @@ struct MlpRole {
     static constexpr bool TILE = true;
     struct Geo {};
     struct Pay { Rows256<MR, WS> x; };
+    __device__ __forceinline__ void touch(Pay& y) const { rows_touch<MR, WS>(y.x); }
     const SysArgs& p; const Stage& st;
     char *atile, *htile; float* ct;
     WFrag<AR, NT1, 8> w1;
@@ -1754,6 +1780,7 @@ struct SkipRole {
     static constexpr bool TILE = true;
     struct Geo {};
     struct Pay { Rows256<MR, WS> x, k; };
+    __device__ __forceinline__ void touch(Pay& y) const { rows_touch<MR, WS>(y.x); rows_touch<MR, WS>(y.k); }
     const SysArgs& p; const Stage& st;
     char* atile; float* ct;
     WFrag<AR, NTW, 16> wf;
