@@ -167,29 +167,35 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const float* __restr
 // to [d][key] hi / lo planes (row stride 232 keys) so that the k = key operand of O^T += V^T . P^T is two 8-byte reads:
 // the accumulator tile of S^T has its query on the lane and its keys in the 16 registers, so registers 8m .. 8m+7 are,
 // unmoved, the B operand of MFMA m of a key tile (keys 16m + 4g + {0..3, 8..11}); V^T is read with the same key map.
-constexpr int SB_VLD = 232;                    // keys per row of the transposed V planes (464 B, multiple of 8)
 
 __device__ __forceinline__ void split8(const float (&v)[8], s16x8& hi, s16x8& lo) {
     split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
 }
 
-__global__ __launch_bounds__(512) void self_attn_split_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ lengths,
+// FM = the most keys a sample can have (a multiple of 32), NT = threads: <224, 512> is the decoder / encoder form (a wave per query tile of 32,
+// 116 KB of LDS: one workgroup per CU); <32, 64> serves sequences of up to 32 rows with ONE wave and 18 KB (round 6: the CLIP tower's ragged
+// rows are <= 31 per prompt - 1,548 (prompt, head) workgroups of the big form ran six deep on 256 CUs with seven of eight waves idle:
+// 36 us per layer, profiles/r6/13_*).
+template <int FM, int NT>
+__global__ __launch_bounds__(NT, NT == 64 ? 2 : 1) void self_attn_split_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ lengths,
                                                                const uint32_t* __restrict__ keybits, float* __restrict__ out,
                                                                int B, int F, int split_out, const AttnGeom g,
                                                                const int32_t* __restrict__ row_off, int shared_qkv) {
-    __shared__ __attribute__((aligned(16))) s16 Kp[2 * SA_FMAX * DH];      // hi plane, lo plane; first the fp32 staging of V
-    __shared__ __attribute__((aligned(16))) s16 Vt[2 * DH * SB_VLD];       // hi plane, lo plane, [d][key]
-    s16* const Kh = Kp; s16* const Kl = Kp + SA_FMAX * DH;
-    s16* const Vth = Vt; s16* const Vtl = Vt + DH * SB_VLD;
+    constexpr int NKT = FM / 32, IT = FM * 16 / NT, VLD = FM + 8;        // key tiles; 16-byte staging units per thread; keys per row of the transposed V planes (a multiple of 8)
+    static_assert(FM % 32 == 0 && (FM * 16) % NT == 0 && NT % 64 == 0 && (FM / 4) % (NT / 64) == 0 && NT / 64 >= FM / 32, "a wave per query tile");
+    __shared__ __attribute__((aligned(16))) s16 Kp[2 * FM * DH];      // hi plane, lo plane; first the fp32 staging of V
+    __shared__ __attribute__((aligned(16))) s16 Vt[2 * DH * VLD];       // hi plane, lo plane, [d][key]
+    s16* const Kh = Kp; s16* const Kl = Kp + FM * DH;
+    s16* const Vth = Vt; s16* const Vtl = Vt + DH * VLD;
     float* const Vtmp = reinterpret_cast<float*>(Kp);                         // [key][64] fp32 = exactly the two K planes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / g.nheads, h = blockIdx.x % g.nheads;
     int len = F;
-    uint32_t kb[SA_NKT + 1];
+    uint32_t kb[NKT + 1];
     if (keybits != nullptr) {
         len = 1;
 #pragma unroll
-        for (int i = 0; i < SA_NKT; ++i) {
+        for (int i = 0; i < NKT; ++i) {
             kb[i] = keybits[(size_t)b * 8 + i];
             if (kb[i]) len = 32 * i + 32 - __builtin_clz(kb[i]);
         }
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(512) void self_attn_split_kernel(const float* __res
         len = lengths != nullptr ? lengths[b] : F;
         len = len < 1 ? 1 : (len > F ? F : len);
 #pragma unroll
-        for (int i = 0; i < SA_NKT; ++i) kb[i] = len >= 32 * i + 32 ? 0xFFFFFFFFu : (len > 32 * i ? (1u << (len - 32 * i)) - 1u : 0u);
+        for (int i = 0; i < NKT; ++i) kb[i] = len >= 32 * i + 32 ? 0xFFFFFFFFu : (len > 32 * i ? (1u << (len - 32 * i)) - 1u : 0u);
     }
     const int nkt = (len + 31) >> 5;
     size_t row0 = (size_t)b * F;
@@ -226,10 +232,10 @@ __global__ __launch_bounds__(512) void self_attn_split_kernel(const float* __res
 
 
     // ---- staging.  All global loads first (7 x (k, v) float4 per thread), V through an fp32 image for the transpose.
-    f32x4 kk[7], vv[7];
+    f32x4 kk[IT], vv[IT];
 #pragma unroll
-    for (int it = 0; it < 7; ++it) {
-        const int id = tid + it * 512, r = id >> 4, c = id & 15;
+    for (int it = 0; it < IT; ++it) {
+        const int id = tid + it * NT, r = id >> 4, c = id & 15;
         kk[it] = f32x4{0.f, 0.f, 0.f, 0.f}; vv[it] = kk[it];
         if (r < nkt * 32 && r < F) {
             const float* src = qkv + base + (size_t)r * g.ld + c * 4;
@@ -238,27 +244,27 @@ __global__ __launch_bounds__(512) void self_attn_split_kernel(const float* __res
         }
     }
 #pragma unroll
-    for (int it = 0; it < 7; ++it) {
-        const int id = tid + it * 512, r = id >> 4, c = id & 15;
+    for (int it = 0; it < IT; ++it) {
+        const int id = tid + it * NT, r = id >> 4, c = id & 15;
         if (r < nkt * 32) st4(Vtmp + r * DH + c * 4, vv[it]);
     }
     __syncthreads();
     {   // transpose + split: thread (d, key group) turns 4 keys of column d into 8 bytes of each plane
         const int d = tid & 63, kg = tid >> 6;
-        for (int p = 0; p < 7; ++p) {
-            const int k0 = (p * 8 + kg) * 4;
+        for (int p = 0; p < FM / 4 / (NT / 64); ++p) {
+            const int k0 = (p * (NT / 64) + kg) * 4;
             if (k0 < nkt * 32) {
                 s16x4 hi, lo;
                 split4(Vtmp[k0 * DH + d], Vtmp[(k0 + 1) * DH + d], Vtmp[(k0 + 2) * DH + d], Vtmp[(k0 + 3) * DH + d], hi, lo);
-                *reinterpret_cast<s16x4*>(Vth + d * SB_VLD + k0) = hi;
-                *reinterpret_cast<s16x4*>(Vtl + d * SB_VLD + k0) = lo;
+                *reinterpret_cast<s16x4*>(Vth + d * VLD + k0) = hi;
+                *reinterpret_cast<s16x4*>(Vtl + d * VLD + k0) = lo;
             }
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 7; ++it) {
-        const int id = tid + it * 512, r = id >> 4, c = id & 15;
+    for (int it = 0; it < IT; ++it) {
+        const int id = tid + it * NT, r = id >> 4, c = id & 15;
         if (r < nkt * 32) {
             s16x4 hi, lo;
             split4(kk[it], hi, lo);
@@ -271,10 +277,10 @@ __global__ __launch_bounds__(512) void self_attn_split_kernel(const float* __res
 
     if (qt * 32 >= F) return;
 
-    f32x16 sT[SA_NKT];
+    f32x16 sT[NKT];
     float m = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < SA_NKT; ++kt) {
+    for (int kt = 0; kt < NKT; ++kt) {
         if (kt < nkt) {
             f32x16 acc;
 #pragma unroll
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(512) void self_attn_split_kernel(const float* __res
 
     float l = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < SA_NKT; ++kt) {
+    for (int kt = 0; kt < NKT; ++kt) {
         if (kt < nkt) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(512) void self_attn_split_kernel(const float* __res
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
 #pragma unroll
-    for (int kt = 0; kt < SA_NKT; ++kt) {
+    for (int kt = 0; kt < NKT; ++kt) {
         if (kt < nkt) {
 #pragma unroll
             for (int mm = 0; mm < 2; ++mm) {
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(512) void self_attn_split_kernel(const float* __res
                 const int k1 = 32 * kt + 16 * mm + 4 * h2;            // keys k1 .. k1+3 and k1+8 .. k1+11
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const int voff = (32 * t + q) * SB_VLD + k1;
+                    const int voff = (32 * t + q) * VLD + k1;
                     const s16x4 h_a = *reinterpret_cast<const s16x4*>(Vth + voff), h_b = *reinterpret_cast<const s16x4*>(Vth + voff + 8);
                     const s16x4 l_a = *reinterpret_cast<const s16x4*>(Vtl + voff), l_b = *reinterpret_cast<const s16x4*>(Vtl + voff + 8);
                     const s16x8 vh = {h_a[0], h_a[1], h_a[2], h_a[3], h_b[0], h_b[1], h_b[2], h_b[3]};
@@ -378,7 +384,8 @@ int launch_self_attention_split(const float* qkv, const int32_t* lengths, const 
     if (B == 0) return 0;
     const int W = nheads * DH;
     const AttnGeom g{nheads, 3 * W, W, 2 * W, W, causal};
-    hipLaunchKernelGGL(self_attn_split_kernel, dim3(B * nheads), dim3(512), 0, s, qkv, lengths, keybits, out, B, F, split_out, g, row_off, shared_qkv);
+    if (F <= 32) hipLaunchKernelGGL((self_attn_split_kernel<32, 64>), dim3(B * nheads), dim3(64), 0, s, qkv, lengths, keybits, out, B, F, split_out, g, row_off, shared_qkv);
+    else hipLaunchKernelGGL((self_attn_split_kernel<SA_FMAX, 512>), dim3(B * nheads), dim3(512), 0, s, qkv, lengths, keybits, out, B, F, split_out, g, row_off, shared_qkv);
     LADIFF_LAUNCH_CHECK();
     return 0;
 }
