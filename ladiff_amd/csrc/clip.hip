@@ -128,9 +128,18 @@ static int ln_rows(const float* x, const int32_t* eos, int L, const NormW& n, in
 constexpr int CLIP_SMALL_ROWS = 256;
 constexpr int CLIP_PLANE_COLS = 12 * CW;       // floats per row of the partial planes: max over the GEMMs of (K / 256) * N = 3 * 3072 = 12 * 768 = 9216
 
+// Many rows: fc2 (K = 3072, N = 768) is 6 column tiles x a few dozen row tiles - about one workgroup per CU, each walking 96 K stages with
+// ONE stage in flight (70 us at 2,260 rows, most of it load latency nobody hides).  Its K range is cut in CLIP_FC2_KPARTS parts over
+// blockIdx.y (GemmArgs::ksplit: four times the workgroups, two per CU hiding each other's stages) and the row pass sums the planes.
+constexpr int CLIP_FC2_KPARTS = 4;
+constexpr int CLIP_FC2_KPARTS_MAX_ROWS = 8192;  // beyond, the tiles alone fill the chip
+static size_t clip_plane_floats(int M) {
+    if (M <= CLIP_SMALL_ROWS) return (size_t)M * CLIP_PLANE_COLS;
+    return M <= CLIP_FC2_KPARTS_MAX_ROWS ? (size_t)M * CLIP_FC2_KPARTS * CW : 0;
+}
 size_t clip_ws_floats_rows(int B, int M) {
     return (size_t)M * (2 * CW /*x ping-pong*/ + CW /*h*/ + 3 * CW /*qkv*/ + CW /*att*/ + CFF /*mlp*/) + (size_t)B * CW + (size_t)B + 64 +
-           (size_t)(M <= CLIP_SMALL_ROWS ? M : 0) * CLIP_PLANE_COLS;
+           clip_plane_floats(M);
 }
 size_t clip_ws_floats(int B, int L) { return clip_ws_floats_rows(B, B * L); }
 
@@ -178,7 +187,7 @@ int clip_text_encode(const ClipW& w, const ClipW* wsp, int n_layers, int vocab, 
     float* att = p; p += (size_t)M * CW;
     float* mlp = p; p += (size_t)M * CFF;
     const bool small = sp && M <= CLIP_SMALL_ROWS;
-    float* planes = p; p += (size_t)(M <= CLIP_SMALL_ROWS ? M : 0) * CLIP_PLANE_COLS;   // [K / 256][M][ld] partial planes of the small-row path (16-byte aligned: every size so far is a multiple of 768 floats)
+    float* planes = p; p += clip_plane_floats(M);   // partial planes: [K / 256][M][ld] of the small-row path, [CLIP_FC2_KPARTS][M][768] of fc2 otherwise (16-byte aligned: every size so far is a multiple of 768 floats)
     float* pooled = p; p += (size_t)B * CW;
     int32_t* eos = reinterpret_cast<int32_t*>(p);
 
@@ -249,6 +258,16 @@ int clip_text_encode(const ClipW& w, const ClipW* wsp, int n_layers, int vocab, 
         LADIFF_TRY(gemm(att, CW, W.o, Ws.o, x2, CW, CW, ACT_NONE, x, false));             // x2 = x + out_proj(attn)
         LADIFF_TRY(ln_rows(x2, nullptr, 0, W.ln2, M, sp ? nullptr : h, sp ? h : nullptr, s));
         LADIFF_TRY(gemm(h, CW, W.fc1, Ws.fc1, mlp, CFF, CFF, ACT_QGELU, nullptr, true));  // quick_gelu(fc1)
+        if (sp && !small && M <= CLIP_FC2_KPARTS_MAX_ROWS) {                             // x = x2 + fc2(...), fc2 in K parts
+            GemmArgs g;
+            g.A = mlp; g.lda = CFF; g.W = Ws.fc2.w; g.ldw = CFF; g.M = M; g.N = CW; g.K = CFF; g.ldy = CW; g.split = 1;
+            g.Y = planes; g.ksplit = CLIP_FC2_KPARTS; g.plane = (size_t)M * CW;
+            LADIFF_TRY(launch_gemm(g, s));
+            const size_t n = (size_t)M * (CW / 4);
+            hipLaunchKernelGGL(clip_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, planes, CLIP_FC2_KPARTS, (size_t)M * CW, CW, M, CW,
+                               W.fc2.b, (int)ACT_NONE, (const float*)x2, CW, x, (float*)nullptr, CW);
+            LADIFF_LAUNCH_CHECK();
+        } else
         LADIFF_TRY(gemm(mlp, CFF, W.fc2, Ws.fc2, x, CW, CW, ACT_NONE, x2, false));        // x = x2 + fc2(...)
     }
     // pooled = final_layer_norm(x)[b, eos[b]];  text_embeds = text_projection(pooled)   (fp32: B rows only)

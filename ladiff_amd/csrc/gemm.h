@@ -25,6 +25,10 @@ struct GemmArgs {
     int post_act = ACT_NONE;                     // activation after LN / modulation
     const int32_t* row_len = nullptr; int rows_per_item = 0;     // zero rows with (row % rows_per_item) >= row_len[row / rows_per_item]
     const int32_t* row_map = nullptr;            // row r is written to Y row row_map[r] (ragged rows scattered into a padded tensor)
+    // split mode, large-M kernel only: the K range in `ksplit` equal parts over blockIdx.y, part z's RAW sums (no bias / activation /
+    // residual) to Y + z * plane; the caller sums the planes.  For launches whose tiles alone leave the chip one workgroup per CU or
+    // less: a workgroup keeps ONE K stage in flight (gemm_big.hip), so a lone workgroup on a CU pays every stage's load latency.
+    int ksplit = 1; size_t plane = 0;
 };
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream);

@@ -218,13 +218,15 @@ __device__ __forceinline__ void gemm_big_split_body(const GemmArgs& p) {
     const int bm = (local / nbn) * 8 + xcd, bn = local % nbn;
     if (bm >= nbm) return;
     const int row0 = bm * BM, col0 = bn * BN;
-    const int nk = p.K / 32;
+    const int ksplit = pin_s(p.ksplit), kz = ksplit > 1 ? (int)blockIdx.y : 0;       // (the batch kernel passes ksplit = 1: its blockIdx.y is the argument set)
+    const int nk_all = p.K / 32, nk = nk_all / ksplit, kt0 = kz * nk;
 
     const int rl = 8 * wave + (lane >> 3);                        // row within a 32-row group
     const int cs = (lane & 7) ^ ((rl >> 1) & 7);                  // source slot that lands in LDS slot (lane & 7)
     const int kl = (cs < 4 ? cs * 4 : 32 + (cs - 4) * 4);         // float offset inside the 64-float block: hi | lo halves
     float* const lbase = lds + 8 * wave * 32;
-    auto issue = [&](int kt, int buf) __attribute__((always_inline)) {
+    auto issue = [&](int ktl, int buf) __attribute__((always_inline)) {
+        const int kt = kt0 + ktl;
         const int k0 = (kt >> 1) * 64, hf = (kt & 1) * 16;       // block start (fp32 columns), half offset (floats)
         const float* abase; int ald;
         if (k0 < argK1) { abase = p.A + k0; ald = p.lda; } else { abase = p.A2 + (k0 - argK1); ald = p.lda2; }
@@ -293,7 +295,7 @@ __device__ __forceinline__ void gemm_big_split_body(const GemmArgs& p) {
         wait_vm<0>();
         __builtin_amdgcn_s_barrier();              // stage kt has landed for every wave; every wave has left the other buffer
         if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
-        if (kt == nk - 1) {                        // epilogue operands: their latency hides under the last stage's MFMAs
+        if (kt == nk - 1 && ksplit == 1) {         // epilogue operands: their latency hides under the last stage's MFMAs
             if (p.bias != nullptr) bv = ld4(p.bias + col0 + ec);
             if (p.res != nullptr) {
 #pragma unroll
@@ -321,6 +323,16 @@ __device__ __forceinline__ void gemm_big_split_body(const GemmArgs& p) {
 #pragma unroll
     for (int e = 0; e < EI; ++e) reg_touch(rv[e]);
 
+    if (ksplit > 1) {                              // a K part: raw sums to its plane
+        float* const Yz = argY + (size_t)kz * p.plane;
+#pragma unroll
+        for (int e = 0; e < EI; ++e) {
+            const int lr = er + e * RPI;
+            const int gr = row0 + lr;
+            if (gr < argM) st4g(Yz + (size_t)gr * ldy + col0 + ec, ld4(ct + lr * CLD + ec));
+        }
+        return;
+    }
     act_dispatch(act, [&](auto ACT) __attribute__((always_inline)) {
 #pragma unroll
         for (int e = 0; e < EI; ++e) {
@@ -341,7 +353,7 @@ template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void gemm_big_split_kernel(const GemmArgs p) { gemm_big_split_body<BM, BN>(p); }
 // up to GEMM_BATCH_MAX independent same-shape f16x3 GEMMs as one launch (grid.y = argument set): the nine layers' c-table GEMMs
 template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void gemm_big_split_batch_kernel(const GemmBatch b) { gemm_big_split_body<BM, BN>(b.a[blockIdx.y]); }
+__global__ __launch_bounds__(256, 2) void gemm_big_split_batch_kernel(const GemmBatch b) { gemm_big_split_body<BM, BN>(b.a[blockIdx.y]); }   // (launch_gemm_big_batch refuses ksplit > 1)
 
 template <int BM, int BN, int WM, int WN, bool LN>
 __global__ __launch_bounds__(256) void gemm_big_kernel(const GemmArgs p) { gemm_big_body<BM, BN, WM, WN, LN>(p); }
@@ -382,21 +394,27 @@ int launch_gemm_big(const GemmArgs& a, hipStream_t s) {
         const int nbm = (a.M + 127) / 128, nbn = a.N / 128;
         // Few row tiles (the ragged CLIP tower: ~2,300 rows, N = 768): 128-row tiles leave the launch one partial round of workgroups whose
         // length is ONE tile's k loop (K = 3072: 82 us for 108 workgroups); 64-row tiles double the workgroups and halve each one's work
+        const int ks = a.ksplit > 1 ? a.ksplit : 1;
+        if (ks > 1 && ((a.K / 32) % ks != 0 || a.Y == nullptr || a.Ys != nullptr || a.plane == 0)) return LADIFF_ERR_ARG;
+        // (measured, round 6: K parts on 256x128 tiles - half the LDS-DMA bytes per flop, one workgroup per CU - run CLIP's fc2 in 81 us
+        // against 54 us on the 64-row tiles below and 70 us without K parts: not instantiated)
         if (nbm * nbn <= 256 && a.M > 64) {
             const int nbm64 = (a.M + 63) / 64;
-            hipLaunchKernelGGL((gemm_big_split_kernel<64, 128>), dim3(((nbm64 + 7) / 8) * 8 * nbn), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((gemm_big_split_kernel<64, 128>), dim3(((nbm64 + 7) / 8) * 8 * nbn, ks), dim3(256), 0, s, a);
         } else {
-            hipLaunchKernelGGL((gemm_big_split_kernel<128, 128>), dim3(((nbm + 7) / 8) * 8 * nbn), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((gemm_big_split_kernel<128, 128>), dim3(((nbm + 7) / 8) * 8 * nbn, ks), dim3(256), 0, s, a);
         }
         LADIFF_LAUNCH_CHECK();
         return 0;
     }
+    if (a.ksplit > 1) return LADIFF_ERR_ARG;      // K parts: the split-mode kernel only
     if (a.ln_g != nullptr) return launch_big<64, 256, 2, 2, true>(a, s);
     return launch_big<128, 128, 2, 2, false>(a, s);
 }
 
 // (the caller checked gemm_big_supported on the common shape)
 int launch_gemm_big_batch(const GemmBatch& b, int n, hipStream_t s) {
+    for (int i = 0; i < n; ++i) if (b.a[i].ksplit > 1) return LADIFF_ERR_ARG;
     if (b.a[0].split) {
         const GemmArgs& a = b.a[0];
         const int nbm = (a.M + 127) / 128, nbn = a.N / 128;
