@@ -36,10 +36,11 @@ LADIFF_API int ladiff_debug_set_poll_pause(int mask, int len);
  * mask = 0: nobody, whatever the size.  Same results. */
 LADIFF_API int ladiff_debug_set_stage_delay(int mask, int len);
 /* Pacing of the tagged pipeline's polling (process-wide): a stage that waited W for a block's rows sleeps eighths / 8 x W before it
- * starts to poll for the next block's; mask: the stage types that do (only STYL, bit 4, has the code compiled in).  Default: 4, 4 - the
- * STYL workgroups (4 per layer, each poll = 72 KB of the FFN stages' partial rows) stop loading the lines the busiest stage type is
- * storing to for half of their wait: loop kernel -3 % at 128 and 256 prompts, unchanged at 64 / mixed lengths (scripts/pause_ab.py,
- * profiles/r4/12_*).  0, 0 switches it off.  Same results. */
+ * starts to poll for the next block's; mask: the stage types that do (only STYL, bit 4, has the code compiled in).  Built-in (until this is called): 4, 4 in
+ * launches above 60 blocks - the STYL workgroups (4 per layer, each poll = 72 KB of the FFN stages' partial rows) stop loading the lines
+ * the busiest stage type is storing to for half of their wait: loop kernel -3 % at 128 and 256 prompts (scripts/pause_ab.py,
+ * profiles/r4/12_*) - and nobody in smaller ones (pacing costs 0.4 % there, profiles/r6/12_*).  A call fixes the values for every
+ * launch size (eighths = -1: back to the built-in choice); 0, 0 switches pacing off.  Same results. */
 LADIFF_API int ladiff_debug_set_pacing(int eighths, int mask);
 /* Measurement switch (process-wide, read when a sampler builds its stage table): 1 (default) = the pipeline stages are dealt to
  * the XCDs in chain order and a stage whose readers share its XCD hands its rows over through that XCD's L2 (plain stores);

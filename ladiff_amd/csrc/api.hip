@@ -442,6 +442,7 @@ int ladiff_debug_set_poll_pause(int mask, int len) {
 }
 
 int ladiff_debug_set_pacing(int eighths, int mask) {
+    if (eighths == -1) { g_pace = -1; return 0; }       // back to the built-in choice by launch size
     LADIFF_CHECK_ARG(eighths >= 0 && eighths <= 8 && mask >= 0 && mask <= 255);
     g_pace = eighths | (mask << 8);
     return 0;

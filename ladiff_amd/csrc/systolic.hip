@@ -47,7 +47,7 @@ std::atomic<int> g_stage_plan{0};   // measurement switch: ladiff_debug_set_stag
 std::atomic<int> g_poll_pause{0};   // measurement switch: ladiff_debug_set_poll_pause (mask | len << 8)
 std::atomic<int> g_stage_delay{-1}; // ladiff_debug_set_stage_delay (mask | len << 8); -1: by block count (launch_systolic_loop)
 std::atomic<int> g_look_ahead_from{-1}, g_small_upto{-1};   // ladiff_debug_set_loop_thresholds (-1: the built-in block counts)
-std::atomic<int> g_pace{4 | (4 << 8)};   // ladiff_debug_set_pacing: STYL sleeps half of its last observed wait before polling (measured: -3 % at 128 / 256 prompts)
+std::atomic<int> g_pace{-1};   // ladiff_debug_set_pacing (eighths | mask << 8); -1: by block count - STYL sleeps half of its last observed wait before polling in launches above SMALL_LAUNCH_BLOCKS (measured: -3 % at 128 / 256 prompts, round 4; -1.8 / -2.9 % at the round-6 kernels), nobody below (there pacing costs 0.4 %: profiles/r6/12_*)
 
 namespace {
 
@@ -2521,7 +2521,7 @@ int launch_systolic_loop(const DenoiserW& W, float* ws, const float* tables, con
     a.look_ahead = NB >= la_from ? 1 : 0;
     a.gen = gen;
     a.pause_mask = g_poll_pause.load() & 0xff; a.pause_len = (g_poll_pause.load() >> 8) & 0xff;
-    a.pace = g_pace.load();
+    a.pace = g_pace.load() >= 0 ? g_pace.load() : (NB <= small_upto ? 0 : (4 | (4 << 8)));
     // Small launches (a block's trip through the stages bounds the step, the stages wait for rows most of the time): the LIN and FFN
     // workgroups idle ~0.25 us after every block before they start to poll for the next one's rows - those are being produced just then by
     // a stage on the critical path (OUT / RED2), and eight workgroups loading its lines do not make it faster.  Measured (profiles/r4/14_*):

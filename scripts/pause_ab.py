@@ -43,4 +43,4 @@ for mask, ln in cfgs:
             ref[(B, kind)] = z.clone()
         row.append(f"{B}{kind} {ms:7.3f}")
     print(f"{knob} mask {mask:3d} len {ln:2d}: " + " | ".join(row), flush=True)
-_lib.check(L.ladiff_debug_set_poll_pause(0, 0)); _lib.check(L.ladiff_debug_set_stage_delay(-1, 0)); _lib.check(L.ladiff_debug_set_pacing(4, 4))          # the defaults
+_lib.check(L.ladiff_debug_set_poll_pause(0, 0)); _lib.check(L.ladiff_debug_set_stage_delay(-1, 0)); _lib.check(L.ladiff_debug_set_pacing(-1, 0))          # the defaults

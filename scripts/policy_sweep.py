@@ -36,7 +36,7 @@ if mode == "pace":
             if sh not in ref: ref[sh] = z
             row.append(f"{sh[0]}{sh[1]} {ms:7.3f}{'' if torch.equal(z, ref[sh]) else ' BITS DIFFER'}")
         print(f"pace {eighths}/8 roles {mask:#x}: " + " | ".join(row), flush=True)
-    _lib.check(L.ladiff_debug_set_pacing(4, 4))
+    _lib.check(L.ladiff_debug_set_pacing(-1, 0))
 else:
     for mask, ln in ((-1, 0), (0, 0), (9, 2), (9, 4), (9, 6), (9, 8), (1, 4), (8, 4), (9 | 64, 4), (-1, 0)):
         _lib.check(L.ladiff_debug_set_stage_delay(mask, ln))

@@ -472,4 +472,4 @@ def test_stage_plan_and_poll_pause_switches_keep_the_bits(nets, precision):
         L.ladiff_debug_set_stage_plan(0)
         L.ladiff_debug_set_poll_pause(0, 0)
         L.ladiff_debug_set_stage_delay(-1, 0)
-        L.ladiff_debug_set_pacing(4, 4)
+        L.ladiff_debug_set_pacing(-1, 0)              # the built-in choice by launch size
