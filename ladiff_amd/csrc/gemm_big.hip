@@ -398,7 +398,9 @@ int launch_gemm_big(const GemmArgs& a, hipStream_t s) {
         if (ks > 1 && ((a.K / 32) % ks != 0 || a.Y == nullptr || a.Ys != nullptr || a.plane == 0)) return LADIFF_ERR_ARG;
         // (measured, round 6: K parts on 256x128 tiles - half the LDS-DMA bytes per flop, one workgroup per CU - run CLIP's fc2 in 81 us
         // against 54 us on the 64-row tiles below and 70 us without K parts, and its fc1 - N = 3072, no K parts - in 103 us against 66 us on 128x128
-        // tiles, two workgroups per CU: one workgroup per CU has nobody to hide its stage's load latency behind.  Not instantiated)
+        // tiles, two workgroups per CU: one workgroup per CU has nobody to hide its stage's load latency behind.  Not instantiated.  Nor is load latency what
+        // bounds the 64-row tiles: with THREE LDS stages and two in flight (wave pairs own alternate stages, one per wave, every wait
+        // vmcnt(0)) they run 36.3 us on average against 37.3 - the ~25 GB/s a CU takes in through LDS-DMA is the bound either way)
         if (nbm * nbn <= 256 && a.M > 64) {
             const int nbm64 = (a.M + 63) / 64;
             hipLaunchKernelGGL((gemm_big_split_kernel<64, 128>), dim3(((nbm64 + 7) / 8) * 8 * nbn, ks), dim3(256), 0, s, a);
