@@ -252,16 +252,20 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 // rings); the hand-off buffers are set to parity 1 before every launch (bytes 0x01) and the first use expects parity 0.
 // The value a consumer computes with has the bit CLEARED, whatever the parity was: results do not depend on the block plan, and
 // the flag protocol stores and clears the same way (parity 0), so the two protocols give the same bits.
+#ifndef LADIFF_TAG_BITS
+#define LADIFF_TAG_BITS 1                   // diagnostic builds: a wider tag (step / ring use modulo 2^bits) tells an A-B-A apart from a lost write
+#endif
+constexpr unsigned TAG_MASK = (1u << LADIFF_TAG_BITS) - 1u;
 __device__ __forceinline__ f32x4 tag4(const f32x4 v, unsigned par) {
-    return __builtin_bit_cast(f32x4, (__builtin_bit_cast(u32x4, v) & 0xfffffffeu) | par);
+    return __builtin_bit_cast(f32x4, (__builtin_bit_cast(u32x4, v) & ~TAG_MASK) | par);
 }
-__device__ __forceinline__ f32x4 untag4(const f32x4 v) { return __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, v) & 0xfffffffeu); }
+__device__ __forceinline__ f32x4 untag4(const f32x4 v) { return __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, v) & ~TAG_MASK); }
 // bad |= (parity bit of any of the four words) != par   (only bit 0 of `bad` means anything)
 __device__ __forceinline__ void tag_acc(unsigned& bad, const f32x4 v, unsigned par) {
     const u32x4 w = __builtin_bit_cast(u32x4, v) ^ par;
     bad |= (w[0] | w[1]) | (w[2] | w[3]);
 }
-__device__ __forceinline__ unsigned ring_use_par(const SysArgs& p, int s, int b) { return (unsigned)(((s * p.NB + b) / PRING) & 1); }
+__device__ __forceinline__ unsigned ring_use_par(const SysArgs& p, int s, int b) { return (unsigned)(((s * p.NB + b) / PRING) & TAG_MASK); }
 
 // a stage's output rows: plain when every reader shares this XCD's L2, write-through otherwise; par = the parity tag (0 under
 // the flag protocol).  HO as the roles' template argument: 0 = flag protocol (the store form is picked at run time), 1 / 2 = tagged
@@ -390,12 +394,6 @@ template <int MR, int WS>
 __device__ __forceinline__ void rows_bad(unsigned& bad, const Rows256<MR, WS>& x, unsigned par) {
 #pragma unroll
     for (int u = 0; u < 2 * MR / WS; ++u) { tag_acc(bad, x.v[u][0], par); tag_acc(bad, x.v[u][1], par); }
-}
-
-template <int MR, int WS>
-__device__ __forceinline__ void rows_touch(Rows256<MR, WS>& x) {          // reg_touch on a row image: no instruction
-#pragma unroll
-    for (int u = 0; u < 2 * MR / WS; ++u) { reg_touch(x.v[u][0]); reg_touch(x.v[u][1]); }
 }
 
 // LayerNorm statistics of a 256-column row, two-pass, fp32 (as rowops.hip).  The per-lane parts are shared by the two layouts
@@ -575,6 +573,54 @@ __device__ __forceinline__ bool spin_give_up(const SysArgs& p, unsigned spins, u
     }
     return false;
 }
+#ifdef LADIFF_SELFCHECK
+// Diagnostic build (scripts/race_hunt.py, never shipped): a stage that has accepted a block's rows loads them AGAIN and compares - the
+// buffer of (step, block) must not change before the next step's write, which this block's own result gates.  The first mismatch of a
+// launch is recorded in status[16 ..]: [17] role bit | layer << 8 | slice << 16 | where << 24, [18] step, [19] block, [20] wave | lane << 8,
+// [21] mask of the 16-byte units that differ, [22] / [23] first differing unit's word 0 (used / reloaded); [24] counts all of them.
+// The same build with -DLADIFF_TAG_BITS=4: a word whose low tag bit is right while the wider tag is not is a word a one-bit parity would have
+// ACCEPTED from another generation (A-B-A).  status[32 ..]: [32] count, first: [33] role | layer << 8 | slice << 16 | where << 24, [34] step,
+// [35] block, [36] wave | lane << 8, [37] the xor of expected and seen tag bits.
+__device__ __forceinline__ void aba_note(const SysArgs& p, const Stage& st, int role, int where, int s, int b, unsigned t) {
+    if (TAG_MASK > 1u && (t & 1u) == 0u && (t & TAG_MASK) != 0u) {
+        const int ri = 31 - __builtin_clz((unsigned)role);                // per role: [40 + ri] count, [48 + 2 ri] / [49 + 2 ri] its first event
+        atomicAdd(p.status + 32, 1u);
+        if (atomicAdd(p.status + 40 + ri, 1u) == 0u) {
+            p.status[48 + 2 * ri] = (unsigned)(t & TAG_MASK) | (unsigned)st.layer << 8 | (unsigned)st.slice << 16 | (unsigned)where << 24;
+            p.status[49 + 2 * ri] = (unsigned)s << 24 | (unsigned)b << 8 | (threadIdx.x >> 6);
+        }
+    }
+}
+template <int N>
+__device__ __forceinline__ void selfcheck_record(const SysArgs& p, const Stage& st, int role, int where, int s, int b, const f32x4 (&a)[N], const f32x4 (&c)[N]) {
+    unsigned m = 0u, wa = 0u, wc = 0u;
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        const u32x4 d = __builtin_bit_cast(u32x4, a[i]) ^ __builtin_bit_cast(u32x4, c[i]);
+        if ((d[0] | d[1] | d[2] | d[3]) != 0u) { m |= 1u << (i & 31); wa = __builtin_bit_cast(u32x4, a[i])[0]; wc = __builtin_bit_cast(u32x4, c[i])[0]; }
+    }
+    if (m != 0u) {
+        atomicAdd(p.status + 24, 1u);
+        if (atomicCAS(p.status + 16, 0u, 1u) == 0u) {
+            p.status[17] = (unsigned)role | (unsigned)st.layer << 8 | (unsigned)st.slice << 16 | (unsigned)where << 24;
+            p.status[18] = (unsigned)s; p.status[19] = (unsigned)b; p.status[20] = (threadIdx.x >> 6) | (threadIdx.x & 63) << 8;
+            p.status[21] = m; p.status[22] = wa; p.status[23] = wc;
+        }
+    }
+}
+template <class R>
+__device__ __forceinline__ void selfcheck_pay(const SysArgs& p, const Stage& st, R& r, int s, int b, const typename R::Geo& g, const typename R::Pay& used) {
+    typedef typename R::Pay Pay;
+    constexpr int N = sizeof(Pay) / 16;
+    static_assert(sizeof(Pay) % 16 == 0, "row images are 16-byte units");
+    Pay again = used;
+    r.issue(s, b, g, again);
+    f32x4 a[N], c[N];
+    __builtin_memcpy(a, &used, sizeof(Pay));
+    __builtin_memcpy(c, &again, sizeof(Pay));
+    selfcheck_record<N>(p, st, R::PAUSE_BIT, 0, s, b, a, c);
+}
+#endif
 // Roles that request a block's rows ahead (R::PREFETCH): the rows of the NEXT block are requested at the start of this block's
 // compute phase (the operand tile is committed, the row registers are free) and their tags are looked at for the first time just
 // BEFORE this block's output stores (MidTag::before_stores): at that point the wave has no store in flight, so the wait for the
@@ -604,7 +650,17 @@ __device__ __forceinline__ bool settle(const SysArgs& p, R& r, int s, int b, con
     unsigned long long t0 = 0ull;
     for (unsigned spins = 0;; ++spins) {
         if (spins != 0u || !issued) r.issue(s, b, g, y);
-        if (__all((r.bad(s, b, g, y) & 1u) == 0u)) { first_look = spins == 0u; return true; }
+#ifdef LADIFF_SELFCHECK
+        aba_note(p, r.st, R::PAUSE_BIT, 2, s, b, r.bad(s, b, g, y));
+        if constexpr (R::PAUSE_BIT == 2) {                                // RED2: the residual / ticket row's words as seen
+            const unsigned t_ = r.bad(s, b, g, y);
+            if (TAG_MASK > 1u && (t_ & 1u) == 0u && (t_ & TAG_MASK) != 0u && (threadIdx.x & 63) == 5 && p.status[60] == 0u) {
+                const u32x4 w_ = __builtin_bit_cast(u32x4, y.rs[0]);
+                p.status[60] = w_[0]; p.status[61] = w_[1]; p.status[62] = w_[2]; p.status[63] = (unsigned)g.row[0];
+            }
+        }
+#endif
+        if (__all((r.bad(s, b, g, y) & TAG_MASK) == 0u)) { first_look = spins == 0u; return true; }
         if (spins == 0u) t0 = __builtin_amdgcn_s_memrealtime();
         else if (spin_give_up(p, spins, t0)) return false;
         if ((p.pause_mask & R::PAUSE_BIT) != 0)
@@ -628,20 +684,20 @@ struct MidTag {
     }
     __device__ __forceinline__ void before_stores() {
         if constexpr (R::PREFETCH) {
-            if (ahead) settled = __all((r.bad(s2, b2, gnxt, nxt) & 1u) == 0u);
-            // The look has waited for the early request (no store of this wave is in flight here: the wait is exact).  From here on the rows
-            // are plain register values to the compiler (round 6) - on EVERY path, also the one on which nothing was requested (the request and
-            // the look hang on the same condition in two places; the compiler does not know that, and a path "requested but not looked at"
-            // kept its bookkeeping of a load in flight alive).  Without this it guarded the rows' next use - the tile build at the top of
-            // the next iteration - with `s_waitcnt vmcnt(0)`, and there the only thing in flight is THIS block's stores: the drain the
-            // tagged hand-off exists to avoid stood at the top of every block of LIN / FFN / SKIP.
-            r.touch(nxt);
+#ifdef LADIFF_SELFCHECK
+            if (ahead) aba_note(p, r.st, R::PAUSE_BIT, 3, s2, b2, r.bad(s2, b2, gnxt, nxt));
+#endif
+            if (ahead) settled = __all((r.bad(s2, b2, gnxt, nxt) & TAG_MASK) == 0u);
         }
     }
 };
 template <class R>
 __device__ __forceinline__ void tag_loop(const SysArgs& p, const Stage& st, R& r, int b0, int bstride) {
+#ifdef LADIFF_SELFCHECK
+    typename R::Pay cur{}, nxt{};         // (the diagnostics look at row images of padding slots too)
+#else
     typename R::Pay cur, nxt;
+#endif
     typename R::Geo gcur, gnxt, gnn;
     if (b0 >= p.NB || p.n_steps < 1) return;
     r.geo(b0, gcur);
@@ -686,6 +742,9 @@ __device__ __forceinline__ void tag_loop(const SysArgs& p, const Stage& st, R& r
             int s3 = s2, b3 = b2 + bstride;
             if (b3 >= p.NB) { s3 = s2 + 1; b3 = b0; }
             const bool has_next = s2 < p.n_steps;                       // behind the last block: that block again (never used)
+#ifdef LADIFF_SELFCHECK
+            selfcheck_pay(p, st, r, s, b, gcur, cur);
+#endif
             r.commit(cur);
             if constexpr (R::TILE) __syncthreads();                     // the operand tile is complete (roles without one: no barrier)
             SYS_STAMP(2);
@@ -726,11 +785,6 @@ struct QkvRole {
     static constexpr bool TILE = true;
     struct Geo { int gw, rb2, b2[NX]; };                                 // descriptor word `tid` (+ its row's sample-branch); sample-branch of this thread's text slots
     struct Pay { Rows256<MR, WS> x; f32x4 xk[NX]; };
-    __device__ __forceinline__ void touch(Pay& y) const {
-        rows_touch<MR, WS>(y.x);
-#pragma unroll
-        for (int u = 0; u < NX; ++u) reg_touch(y.xk[u]);
-    }
     const SysArgs& p; const Stage& st;
     char* atile; float *qt, *xt; int* gd;
     WFrag<AR, NTW, 8> wf;
@@ -778,7 +832,7 @@ struct QkvRole {
     }
     __device__ __forceinline__ unsigned bad(int s, int, const Geo&, const Pay& y) const {
         unsigned t = 0u;
-        rows_bad<MR, WS>(t, y.x, (unsigned)(s & 1));
+        rows_bad<MR, WS>(t, y.x, (unsigned)(s & TAG_MASK));
         return t;
     }
     __device__ __forceinline__ void geo_fix(Geo& g) {                    // a latent count that lives on the device only (0xff)
@@ -864,7 +918,7 @@ struct QkvRole {
         mid.after_barrier();
         SYS_STAMP(6);
         // the shipped models have T = 5 latent tokens (7 keys): the loops are unrolled over the keys, so the bound is compile time
-        const unsigned par = HO ? (unsigned)(s & 1) : 0u;
+        const unsigned par = HO ? (unsigned)(s & TAG_MASK) : 0u;
         mid.before_stores();
         if (T <= 5) attention<7>(b, par); else attention<TK>(b, par);
     }
@@ -952,13 +1006,16 @@ struct QkvRole {
                     if (!xissued) load_x(base);
                     first = true;
                     if constexpr (HO) {              // tagged hand-off: the rows are loaded until every word shows this step's parity
-                        const unsigned par = (unsigned)(s & 1);
+                        const unsigned par = (unsigned)(s & TAG_MASK);
                         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                         for (unsigned spins = 1;; ++spins) {
                             unsigned t = 0u;
 #pragma unroll
                             for (int u = 0; u < 2; ++u) { tag_acc(t, x[u][0], par); tag_acc(t, x[u][1], par); }
-                            if (__all((t & 1u) == 0u)) break;
+#ifdef LADIFF_SELFCHECK
+                            aba_note(p, st, 16, 4, s, b, t);
+#endif
+                            if (__all((t & TAG_MASK) == 0u)) break;
                             first = false;
                             if (spin_give_up(p, spins, t0)) return;
                             __builtin_amdgcn_s_sleep(1);
@@ -992,6 +1049,32 @@ struct QkvRole {
                             tile_put4<1, 4>(atile, row, c8 * 8 + 4, v1);
                         }
                     }
+#ifdef LADIFF_SELFCHECK
+                    {
+                        f32x4 a[8], c[8];
+                        a[0] = x[0][0]; a[1] = x[0][1]; a[2] = x[1][0]; a[3] = x[1][1];
+                        a[4] = EARLY ? xstage[0] : xk[0]; a[5] = EARLY ? xstage[256] : xk[1];
+                        a[6] = __builtin_bit_cast(f32x4, g4); a[7] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int id = tl + 256 * u, row = id >> 5, c8 = id & 31;
+                            c[2 * u] = ld_sc1(rin, base + row * 1024 + c8 * 32);
+                            c[2 * u + 1] = ld_sc1(rin, base + row * 1024 + c8 * 32 + 16);
+                        }
+                        int cb2[2], cgw, crb2;
+                        load_geo(b, cb2, cgw, crb2);
+                        c[6] = __builtin_bit_cast(f32x4, i32x4{cb2[0], cb2[1], cgw, crb2}); c[7] = a[7];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int f4 = tl + 256 * u, sx = f4 >> 5, c4 = (f4 & 31) * 4;
+                            const unsigned col = (unsigned)(c4 < 64 ? c4 : 192 + c4) * 4u;
+                            c[4 + u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (sx == 15) c[4 + u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rtab, col, timeoff, 0));
+                            else if (cb2[u] >= 0) c[4 + u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rtkv, (unsigned)cb2[u] * 2048u + col, (unsigned)h * 256u, 0));
+                        }
+                        selfcheck_record<8>(p, st, 16, 1, s, b, a, c);
+                    }
+#endif
                     // the next block's rows are requested now when this block's were complete at the first look (rows queue up in front of the stage)
                     xissued = false;
                     if constexpr (HO != 0 && EARLY) {
@@ -1021,7 +1104,7 @@ struct QkvRole {
                 lds_barrier();
                 SYS_STAMP(3);
                 if (!loader) {
-                    const unsigned par = HO ? (unsigned)(s & 1) : 0u;
+                    const unsigned par = HO ? (unsigned)(s & TAG_MASK) : 0u;
                     if (T <= 5) attention<7>(b, par); else attention<TK>(b, par);
                     SYS_STAMP(4);
                     if constexpr (!HO) {
@@ -1114,11 +1197,6 @@ struct OutRole {
     static constexpr bool TILE = true;
     struct Geo {};
     struct Pay { Rows256<MR, WS> att; f32x4 res[RPW]; };
-    __device__ __forceinline__ void touch(Pay& y) const {
-        rows_touch<MR, WS>(y.att);
-#pragma unroll
-        for (int q = 0; q < RPW; ++q) reg_touch(y.res[q]);
-    }
     const SysArgs& p; const Stage& st;
     char* atile; float* ct;
     WFrag<AR, NTW, 8> wf;
@@ -1136,9 +1214,9 @@ struct OutRole {
     __device__ __forceinline__ void geo_fix(Geo&) {}
     __device__ __forceinline__ unsigned bad(int s, int, const Geo&, const Pay& y) const {
         unsigned t = 0u;
-        rows_bad<MR, WS>(t, y.att, (unsigned)(s & 1));
+        rows_bad<MR, WS>(t, y.att, (unsigned)(s & TAG_MASK));
 #pragma unroll
-        for (int q = 0; q < RPW; ++q) tag_acc(t, y.res[q], (unsigned)(s & 1));
+        for (int q = 0; q < RPW; ++q) tag_acc(t, y.res[q], (unsigned)(s & TAG_MASK));
         return t;
     }
     __device__ __forceinline__ void issue(int, int b, const Geo&, Pay& y) {
@@ -1153,7 +1231,7 @@ struct OutRole {
     __device__ __forceinline__ void compute(int s, int b, const Geo&, const Pay& y, M& mid) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
         const unsigned base = (unsigned)b * RT * 1024;
-        const unsigned par = HO ? (unsigned)(s & 1) : 0u;
+        const unsigned par = HO ? (unsigned)(s & TAG_MASK) : 0u;
         f32x4 acc[MR][NTW];
         zero_acc(acc);
         mma<AR, 4, NTW, 8, MR, NTW, (MR == 1 && WS == 2 ? PF2 : 1), LADIFF_TR_OUT>(atile, wf, acc);
@@ -1196,7 +1274,7 @@ struct OutRole {
         for (int s = 0; s < p.n_steps; ++s)
             for (int b = st.blk0; b < p.NB; b += st.blkstride) {
                 const unsigned base = (unsigned)b * RT * 1024;
-                const unsigned par = HO ? (unsigned)(s & 1) : 0u;
+                const unsigned par = HO ? (unsigned)(s & TAG_MASK) : 0u;
                 if (loader) {
                     SYS_SPLIT_T0;
                     if constexpr (!HO) { if (!wait_epoch(flag_of(p, st.wait_group, b, st.wait_slot0), st.wait_n, s + 1, p.status, ctl, 0u, p.timeout_ticks)) return; }
@@ -1216,7 +1294,10 @@ struct OutRole {
                             unsigned t = 0u;
 #pragma unroll
                             for (int u = 0; u < 2; ++u) { tag_acc(t, x[u][0], par); tag_acc(t, x[u][1], par); }
-                            if (__all((t & 1u) == 0u)) break;
+#ifdef LADIFF_SELFCHECK
+                            aba_note(p, st, 32, 4, s, b, t);
+#endif
+                            if (__all((t & TAG_MASK) == 0u)) break;
                             if (spin_give_up(p, spins, t0)) return;
                             __builtin_amdgcn_s_sleep(1);
                             if ((p.pause_mask & 32) != 0) for (int i_ = 0; i_ < p.pause_len; ++i_) __builtin_amdgcn_s_sleep(2);
@@ -1239,6 +1320,18 @@ struct OutRole {
                             tile_put4<1, 4>(atile, row, c8 * 8 + 4, v1);
                         }
                     }
+#ifdef LADIFF_SELFCHECK
+                    {
+                        f32x4 a[4] = {x[0][0], x[0][1], x[1][0], x[1][1]}, c[4];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int id = tl + 256 * u, row = id >> 5, c8 = id & 31;
+                            c[2 * u] = ld_sc1(ratt, base + row * 1024 + c8 * 32);
+                            c[2 * u + 1] = ld_sc1(ratt, base + row * 1024 + c8 * 32 + 16);
+                        }
+                        selfcheck_record<4>(p, st, 32, 1, s, b, a, c);
+                    }
+#endif
                 }
                 if (!loader) SYS_SPLIT_T0;
                 lds_barrier();                                           // the operand tile is there (the loaders saw the block's flags); the previous epilogue is over
@@ -1283,7 +1376,7 @@ struct OutRole {
                             unsigned t = 0u;
 #pragma unroll
                             for (int k = 0; k < 4; ++k) tag_acc(t, res[k], par);
-                            if (__all((t & 1u) == 0u)) break;
+                            if (__all((t & TAG_MASK) == 0u)) break;
                             if (spin_give_up(p, spins, t0)) return;
                             __builtin_amdgcn_s_sleep(1);
 #pragma unroll
@@ -1338,7 +1431,6 @@ struct MlpRole {
     static constexpr bool TILE = true;
     struct Geo {};
     struct Pay { Rows256<MR, WS> x; };
-    __device__ __forceinline__ void touch(Pay& y) const { rows_touch<MR, WS>(y.x); }
     const SysArgs& p; const Stage& st;
     char *atile, *htile; float* ct;
     WFrag<AR, NT1, 8> w1;
@@ -1364,7 +1456,7 @@ struct MlpRole {
     __device__ __forceinline__ void geo_fix(Geo&) {}
     __device__ __forceinline__ unsigned bad(int s, int, const Geo&, const Pay& y) const {
         unsigned t = 0u;
-        rows_bad<MR, WS>(t, y.x, (unsigned)(s & 1));
+        rows_bad<MR, WS>(t, y.x, (unsigned)(s & TAG_MASK));
         return t;
     }
     __device__ __forceinline__ void issue(int, int b, const Geo&, Pay& y) { issue_rows<MR, WS>(y.x, rin, (unsigned)b * RT * 1024); }
@@ -1382,12 +1474,15 @@ struct MlpRole {
             const int gx = g - PRING / 2 - i;
             if (gx < 0) continue;
             const int sx = gx / p.NB, x = gx - sx * p.NB;
-            const unsigned par = (unsigned)(sx & 1);
+            const unsigned par = (unsigned)(sx & TAG_MASK);
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             for (unsigned spins = 1;; ++spins) {
                 unsigned w = par;
                 if (lane < RT) w = __builtin_amdgcn_raw_buffer_load_b32(rb, ((unsigned)x * RT + lane) * 1024, 0, 16);
-                if (__all(((w ^ par) & 1u) == 0u)) break;
+#ifdef LADIFF_SELFCHECK
+                aba_note(p, st, PAUSE_BIT, 5, sx, x, w ^ par);
+#endif
+                if (__all(((w ^ par) & TAG_MASK) == 0u)) break;
                 if (spin_give_up(p, spins, t0)) return false;
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -1567,12 +1662,26 @@ struct Red2Role {
                 // residual buffer (every producer writes all rows of its tiles) is the wave's ticket.  Without it a wave that owns
                 // nothing but padding would run through the steps by itself and rewrite rows whose readers are a step behind.
                 y.rs[q] = ld_sc1(rx, base + (-2 - row) * 1024 + c * 4);
+                // ... and not before the partial planes of the block exist (round 6): this stage has no barrier, every wave runs by
+                // itself, and a wave whose row is padding block after block (row 15 of every 15-row block) was held back by the
+                // ticket only - i.e. by OUT, not by LIN.  With OUT more than a ring (PRING blocks) ahead of LIN, the wave's next LIVE
+                // row found its ring slot still holding the block two uses back - whose one-bit tag is the one it expects - and
+                // summed that block's partials (seen as run-to-run differences of single prompts once QKV / OUT got ahead of the
+                // MLP stages; found with -DLADIFF_TAG_BITS=4 -DLADIFF_SELFCHECK, profiles/r6/22_*).  The padding rows of the planes are
+                // written like every other row, so a padding row waits for them as a live one does: no wave of this stage is ever ahead
+                // of the producer of its ring.
+                // One word of the row per plane is enough to know that the plane's producer has reached this block: lane l looks at
+                // plane l % 8 (one load instruction, eight lines - not the row's 8 KB).
+                static_assert(NSLICE == 8, "a padding row's look at the planes: lane % 8 = plane");
+                const f32x4 w = ld_sc1(rp, (unsigned)(lane & 7) * pstride + pbase + (unsigned)(-2 - row) * 1024 + (unsigned)(lane >> 3) * 16);
+#pragma unroll
+                for (int j = 0; j < NSLICE; ++j) y.pl[q][j] = w;
             }
         }
     }
     __device__ __forceinline__ void commit(const Pay&) {}
     __device__ __forceinline__ unsigned bad(int s, int b, const Geo& g, const Pay& y) const {
-        const unsigned rpar = ring_use_par(p, s, b), spar = (unsigned)(s & 1);
+        const unsigned rpar = ring_use_par(p, s, b), spar = (unsigned)(s & TAG_MASK);
         unsigned t = 0u;
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
@@ -1580,7 +1689,7 @@ struct Red2Role {
 #pragma unroll
             for (int j = 0; j < NSLICE; ++j) tag_acc(tq, y.pl[q][j], rpar);
             tag_acc(tr, y.rs[q], spar);
-            t |= g.row[q] >= 0 ? (tq | tr) : (g.row[q] <= -2 ? tr : 0u);
+            t |= g.row[q] != -1 ? (tq | tr) : 0u;                        // live and padding rows alike (issue)
         }
         return t;
     }
@@ -1588,7 +1697,7 @@ struct Red2Role {
     __device__ __forceinline__ void compute(int s, int b, const Geo& g, Pay& y, M& mid) {
         const int lane = threadIdx.x & 63, c = 4 * lane;
         const unsigned base = (unsigned)b * RT * 1024;
-        const unsigned par = HO ? (unsigned)(s & 1) : 0u;
+        const unsigned par = HO ? (unsigned)(s & TAG_MASK) : 0u;
         mid.before_barrier();
         if constexpr (!HO) __syncthreads();   // the stage's only barrier: the workgroup agrees on whether the next block is prefetched
         mid.after_barrier();
@@ -1681,13 +1790,17 @@ struct StylRole {
                 }
                 y.rs[q] = ld_sc1(rx, base + row * 1024 + c * 4);
             } else if (HO && row <= -2) {
-                y.rs[q] = ld_sc1(rx, base + (-2 - row) * 1024 + c * 4);     // a padding row's ticket (Red2Role::issue)
+                y.rs[q] = ld_sc1(rx, base + (-2 - row) * 1024 + c * 4);     // a padding row's ticket (Red2Role::issue) ...
+                // ... and one word of the row in each plane (never ahead of FFN, as there)
+                const f32x4 w = ld_sc1(rp, (unsigned)(lane & 7) * pstride + pbase + (unsigned)(-2 - row) * 1024 + (unsigned)(lane >> 3) * 16);
+#pragma unroll
+                for (int j = 0; j < NSLICE; ++j) y.pl[q][j] = w;
             }
         }
     }
     __device__ __forceinline__ void commit(const Pay&) {}
     __device__ __forceinline__ unsigned bad(int s, int b, const Geo& g, const Pay& y) const {
-        const unsigned rpar = ring_use_par(p, s, b), spar = (unsigned)(s & 1);
+        const unsigned rpar = ring_use_par(p, s, b), spar = (unsigned)(s & TAG_MASK);
         unsigned t = 0u;
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
@@ -1695,7 +1808,7 @@ struct StylRole {
 #pragma unroll
             for (int j = 0; j < NSLICE; ++j) tag_acc(tq, y.pl[q][j], rpar);
             tag_acc(tr, y.rs[q], spar);
-            t |= g.row[q] >= 0 ? (tq | tr) : (g.row[q] <= -2 ? tr : 0u);
+            t |= g.row[q] != -1 ? (tq | tr) : 0u;                        // live and padding rows alike (issue)
         }
         return t;
     }
@@ -1703,7 +1816,7 @@ struct StylRole {
     __device__ __forceinline__ void compute(int s, int b, const Geo& g, Pay& y, M& mid) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = 4 * lane;
         const unsigned base = (unsigned)b * RT * 1024;
-        const unsigned par = HO ? (unsigned)(s & 1) : 0u;
+        const unsigned par = HO ? (unsigned)(s & TAG_MASK) : 0u;
         const f32x4 scl = y.scl, shf = y.shf;
 #pragma unroll
         for (int q = 0; q < PQ; ++q) {
@@ -1780,7 +1893,6 @@ struct SkipRole {
     static constexpr bool TILE = true;
     struct Geo {};
     struct Pay { Rows256<MR, WS> x, k; };
-    __device__ __forceinline__ void touch(Pay& y) const { rows_touch<MR, WS>(y.x); rows_touch<MR, WS>(y.k); }
     const SysArgs& p; const Stage& st;
     char* atile; float* ct;
     WFrag<AR, NTW, 16> wf;
@@ -1800,8 +1912,8 @@ struct SkipRole {
     __device__ __forceinline__ void geo_fix(Geo&) {}
     __device__ __forceinline__ unsigned bad(int s, int, const Geo&, const Pay& y) const {
         unsigned t = 0u;
-        rows_bad<MR, WS>(t, y.x, (unsigned)(s & 1));
-        rows_bad<MR, WS>(t, y.k, (unsigned)(s & 1));
+        rows_bad<MR, WS>(t, y.x, (unsigned)(s & TAG_MASK));
+        rows_bad<MR, WS>(t, y.k, (unsigned)(s & TAG_MASK));
         return t;
     }
     __device__ __forceinline__ void issue(int, int b, const Geo&, Pay& y) {
@@ -1813,7 +1925,7 @@ struct SkipRole {
     __device__ __forceinline__ void compute(int s, int b, const Geo&, const Pay&, M& mid) {
         const int tid = threadIdx.x, wave = tid >> 6;
         const unsigned base = (unsigned)b * RT * 1024;
-        const unsigned par = HO ? (unsigned)(s & 1) : 0u;
+        const unsigned par = HO ? (unsigned)(s & TAG_MASK) : 0u;
         f32x4 acc[MR][NTW];
         zero_acc(acc);
         mma<AR, 8, NTW, 16, MR, NTW, (MR == 1 && WS == 2 ? PF2 : 1), LADIFF_TR_SKIP>(atile, wf, acc);
@@ -1891,7 +2003,7 @@ struct TailRole {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             unsigned tu = 0u, tc = 0u;
-            tag_acc(tu, y.eu[i], (unsigned)(s & 1)); tag_acc(tc, y.ec[i], (unsigned)(s & 1));
+            tag_acc(tu, y.eu[i], (unsigned)(s & TAG_MASK)); tag_acc(tc, y.ec[i], (unsigned)(s & TAG_MASK));
             t |= (g.lat[i] >= 0 || g.pad[i] >= 0 ? tu : 0u) | (g.lat[i] >= 0 || g.rc[i] >= 0 ? tc : 0u);
         }
         return t;
@@ -1952,11 +2064,11 @@ struct TailRole {
                     xn[k] = l[k] + y.pe[i][k];
                 }
                 st4(p.lat + (size_t)g.lat[i] * D + c, l);
-                const unsigned par = HO ? (unsigned)((s + 1) & 1) : 0u;     // the input of the NEXT local step
+                const unsigned par = HO ? (unsigned)((s + 1) & TAG_MASK) : 0u;     // the input of the NEXT local step
                 st_out<HO>(st, rout, bu + q * 1024 + c * 4, xn, par);          // after the last step nobody reads it
                 st_out<HO>(st, rout, bc + g.rc[i] * 1024 + c * 4, xn, par);
             } else {                                                       // padding rows of the unit's tiles: zeros, next step's parity
-                const unsigned par = HO ? (unsigned)((s + 1) & 1) : 0u;
+                const unsigned par = HO ? (unsigned)((s + 1) & TAG_MASK) : 0u;
                 if (g.pad[i] >= 0) st_out<HO>(st, rout, bu + g.pad[i] * 1024 + c * 4, f32x4{0.f, 0.f, 0.f, 0.f}, par);
                 if (g.rc[i] >= 0) st_out<HO>(st, rout, bc + g.rc[i] * 1024 + c * 4, f32x4{0.f, 0.f, 0.f, 0.f}, par);
             }
@@ -2049,12 +2161,18 @@ __device__ __forceinline__ void tail_loop_tag(const SysArgs& p, const Stage& st,
             int s3 = s2, u3 = u2 + NTAIL;
             if (u3 >= nu) { s3 = s2 + 1; u3 = u0; }
             if (s3 < p.n_steps) r.geo(u3, gnn);                          // geometry two units ahead
-            if (!__all((r.bad(s, gcur, cur) & 1u) == 0u)) {
+#ifdef LADIFF_SELFCHECK
+            aba_note(p, st, 128, 6, s, u, r.bad(s, gcur, cur));
+#endif
+            if (!__all((r.bad(s, gcur, cur) & TAG_MASK) == 0u)) {
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 for (unsigned spins = 1;; ++spins) {
                     __builtin_amdgcn_s_sleep(1);
                     r.issue(s, u, gcur, cur);
-                    if (__all((r.bad(s, gcur, cur) & 1u) == 0u)) break;
+#ifdef LADIFF_SELFCHECK
+                    aba_note(p, st, 128, 7, s, u, r.bad(s, gcur, cur));
+#endif
+                    if (__all((r.bad(s, gcur, cur) & TAG_MASK) == 0u)) break;
                     if (spin_give_up(p, spins, t0)) return;
                 }
             }

@@ -437,6 +437,22 @@ def test_tagged_handoff_full_batch_soak(nets):
         assert torch.equal(z, ref), f"call {i} differs"
 
 
+@pytest.mark.parametrize("B,calls", [(256, 20), (1024, 12)])
+def test_tagged_handoff_many_blocks_of_mixed_lengths(nets, B, calls):
+    """Round 6: 256 / 1,024 prompts of 2, 3 and 5 latents (114 / 452 blocks: config c5's shape) - launches in which the attention
+    stages run dozens of blocks ahead of the MLP stages.  RED2 has no barrier, and a wave whose row is padding in block after block (row 15
+    of every 15-row block) used to be held back by its ticket row only, i.e. by OUT, not by LIN: more than a ring (16 blocks) ahead of LIN,
+    its next live row - the first blocks of the next step, which have 16 live rows - found a ring slot two uses old, whose one-bit tag is
+    the one expected, and summed another block's partial products.  Seen as single prompts differing from call to call once QKV / OUT had
+    become faster than the MLP stages (every call at 1,024 prompts).  Every call must give the flag protocol's bits."""
+    lens = syn.mixed_lengths(B)
+    ref = _with_handoff(False, lambda: run(nets, "pipeline16", "f16x3", B, 5, 50, lens))
+    for i in range(calls):
+        z = _with_handoff(True, lambda: run(nets, "pipeline16", "f16x3", B, 5, 50, lens))
+        bad = torch.nonzero((z - ref).abs().amax(dim=(0, 2))).flatten().tolist()                 # latents are [T, B, 256]
+        assert not bad, f"call {i}: prompts {bad[:12]} differ from the flag protocol's result"
+
+
 # ---------------------------------------------------------------- round 4: measurement switches of the pipeline that must not change a bit
 @pytest.mark.parametrize("precision", ["f16x3", "fp32"])
 def test_stage_plan_and_poll_pause_switches_keep_the_bits(nets, precision):
