@@ -32,7 +32,13 @@ def stamps_lib(level=1):
     return LIB.replace(".so", "_stamps.so" if int(level) == 1 else f"_stamps{int(level)}.so")
 
 
-def build(force=False, verbose=False, stamps=False, tag=None, defines=()):
+def diag_lib():
+    """Path of the hand-off diagnostic build of the loop kernel (build_all): tags count 16 generations instead of 2 and every look a
+    one-bit tag would have accepted from another generation is recorded (csrc/systolic.hip, LADIFF_SELFCHECK); never the product."""
+    return LIB.replace(".so", "_diag.so")
+
+
+def build(force=False, verbose=False, stamps=False, tag=None, defines=(), only=None):
     """stamps=True builds the diagnostic twin (in-kernel s_memrealtime stamps and timing probes; never timed, never shipped as the
     product): level 1 -> libladiff_hip_stamps.so, LADIFF_STAMPS_LEVEL=2 in the environment -> libladiff_hip_stamps2.so (each level has
     its own object directory AND its own library, so one never serves the other)."""
@@ -51,10 +57,12 @@ def build(force=False, verbose=False, stamps=False, tag=None, defines=()):
     headers += [os.path.join(os.path.dirname(HERE), "include", h) for h in ("ladiff_hip.h", "ladiff_hip_debug.h")]
     hipcc = _hipcc()
     jobs = []
+    # only = the sources the variant's defines reach: every other object is the product's (built first by the caller)
+    objdir = {src: (obj if only is None or src in only else OBJ) for src in SOURCES}
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(obj, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + headers):
+        o = os.path.join(objdir[src], src.replace(".hip", ".o"))
+        if objdir[src] == obj and (force or _stale(o, [s] + headers)):
             jobs.append([hipcc, *flags, "-c", s, "-o", o])
 
     def run(cmd):
@@ -69,7 +77,7 @@ def build(force=False, verbose=False, stamps=False, tag=None, defines=()):
         for err in ex.map(run, jobs):
             if verbose and err.strip():
                 print(err)
-    objs = [os.path.join(obj, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [os.path.join(objdir[s], s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(lib, objs + [os.path.join(CSRC, "exports.map")]):
         # the version script keeps what -fvisibility=hidden cannot reach (libstdc++ template instantiations, kernel handle objects) local
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"),
@@ -79,9 +87,11 @@ def build(force=False, verbose=False, stamps=False, tag=None, defines=()):
 
 def build_all(force=False, verbose=False):
     """Both flavours of the product: libladiff_hip.so (split operands as fp16 pairs) and libladiff_hip_bf16.so (bf16 pairs,
-    _lib.select_split_format("bf16"))."""
+    _lib.select_split_format("bf16")) - and the loop kernel's hand-off diagnostic build (diag_lib(): test infrastructure)."""
     lib = build(force=force, verbose=verbose)
     build(force=force, verbose=verbose, tag="bf16", defines=["LADIFF_SPLIT_BF16"])
+    # the hand-off diagnostic build of the loop kernel (tests/test_gpu_pipeline.py runs it over the block geometries; diag_lib())
+    build(force=force, verbose=verbose, tag="diag", defines=["LADIFF_TAG_BITS=4", "LADIFF_SELFCHECK"], only=("systolic.hip",))
     return lib
 
 

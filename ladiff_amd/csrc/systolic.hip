@@ -249,7 +249,10 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 // What it rests on: an aligned 4-byte word is written whole (each word carries its own bit, so nothing is assumed about the
 // 16-byte store being seen as one unit); a slot is written exactly once per use and not again before every reader of that use
 // has loaded it (the dependency chain through the tail stage for the per-step buffers, MlpRole::backpressure_tag for the
-// rings); the hand-off buffers are set to parity 1 before every launch (bytes 0x01) and the first use expects parity 0.
+// rings); AND, on the reader's side, nobody ever looks at a slot that is more than ONE use old - one bit cannot tell the use before
+// last from the one awaited.  Every stage with a barrier and every live row has that by construction (it needed the previous use
+// to get here); a wave of a barrier-free stage whose row is padding did not until round 6 (Red2Role::issue: it now waits for its
+// ring's producers as a live row does); the hand-off buffers are set to parity 1 before every launch (bytes 0x01) and the first use expects parity 0.
 // The value a consumer computes with has the bit CLEARED, whatever the parity was: results do not depend on the block plan, and
 // the flag protocol stores and clears the same way (parity 0), so the two protocols give the same bits.
 #ifndef LADIFF_TAG_BITS

@@ -273,7 +273,7 @@ def test_both_split_flavours_are_built_and_say_what_they_are(lib):
     assert other.ladiff_split_format() == 0 and other.ladiff_version() == lib.ladiff_version()
     syms = lambda p: sorted(l.split()[-1] for l in subprocess.run(["nm", "-D", "--defined-only", p], capture_output=True, text=True).stdout.splitlines()
                             if " T " in l)
-    assert syms(_lib.LIB_PATH) == syms(_lib.LIB_PATH_BF16)
+    assert syms(_lib.LIB_PATH) == syms(_lib.LIB_PATH_BF16) == syms(build.diag_lib())   # + the loop kernel's hand-off diagnostic build
     with pytest.raises(ValueError):
         _lib.select_split_format("fp8")
     with pytest.raises(_lib.LadiffHipError):            # this process has loaded the fp16 library already

@@ -56,7 +56,10 @@ def test_few_rows_path_of_the_split_mode_against_the_many_rows_path_and_the_orac
     many = enc.encode_ids(torch.cat([ids] * 3), full_length=True, dedup=False)[:2]   # 6 x 77 = 462 rows
     ref = orc.clip_text_features(sd, ids, layers)
     assert maxdiff(few, ref) < TOL["f16x3"] and maxdiff(many, ref) < TOL["f16x3"]
-    assert maxdiff(few, many) < 1e-5
+    from ladiff_amd import _lib
+    # the two tilings sum the K parts in different orders: the difference is the split products' own rounding (fp16 pairs 3e-7 per K = 768
+    # product, bf16 pairs - LADIFF_TEST_LIB=ladiff_amd/libladiff_hip_bf16.so - 5e-6)
+    assert maxdiff(few, many) < (1e-5 if _lib.split_mode_name() == "f16x3" else 1e-4)
 
 
 def test_guidance_batch_against_oracle():

@@ -453,6 +453,17 @@ def test_tagged_handoff_many_blocks_of_mixed_lengths(nets, B, calls):
         assert not bad, f"call {i}: prompts {bad[:12]} differ from the flag protocol's result"
 
 
+def test_no_stage_ever_looks_at_a_slot_more_than_one_use_old():
+    """The reader's side of the tagged hand-off, checked by the kernel itself: the diagnostic build of the loop kernel (libladiff_hip_diag.so:
+    4-bit generation tags, every look that a one-bit tag would have accepted from another generation counted per stage type, accepted rows
+    reloaded and compared) over many mixed-length blocks, padding in every tile, one prompt, no guidance - zero events.  With round 5's
+    RED2 this records hundreds of looks per call at 1,024 prompts (profiles/r6/22g_*).  Child process: one library per process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "handoff_diag_check.py"), "quick"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "hand-off diagnostics: clean" in r.stdout, (r.stdout + r.stderr)[-1500:]
+
+
 # ---------------------------------------------------------------- round 4: measurement switches of the pipeline that must not change a bit
 @pytest.mark.parametrize("precision", ["f16x3", "fp32"])
 def test_stage_plan_and_poll_pause_switches_keep_the_bits(nets, precision):
