@@ -692,7 +692,7 @@ def main():
                  "traffic_source_stale": summary.get("_stale") if whole_traffic is not None else None,
                  "mfma_util_pmc": summary.get("whole_pass", {}).get("mfma_util_pmc") if (summary and is_default) else None,
                  "peak_note": "fp32-input MFMA 157.3 TF/s" if args.precision == "fp32" else
-                 "bf16 MFMA 2500 TF/s dense; every fp32-equivalent product costs 3 bf16 MFMAs (833 TF/s fp32-equivalent)"}
+                 "16-bit MFMA (f16 = bf16) 2500 TF/s dense; every fp32-equivalent product costs 3 16-bit MFMAs (833 TF/s fp32-equivalent)"}
         line = {
             "metric": cfg["metric"], "value": round(motions_per_s, 2),
             "unit": "motions/s", "n_gpus": world, "steps": steps, "warmup": warmup,
