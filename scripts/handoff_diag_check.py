@@ -4,7 +4,7 @@ generations instead of 2; every look at handed-off rows whose LOW tag bit is rig
 tag would have accepted from another generation - is counted per stage type, and every stage reloads the rows it accepted and compares.
 Both counters must stay 0 over the block geometries below (many blocks of mixed lengths: the attention stages dozens of blocks ahead
 of the MLP stages; padding rows in every tile; one prompt; no guidance).
-usage: handoff_diag_check.py [quick]"""
+usage: handoff_diag_check.py [quick]      (environment: PACING, THRESH, XCD_LOCAL, STAGE_PLAN = the library's measurement switches)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -18,6 +18,12 @@ den = LADiffDenoiser(ABL, **DEN_KW); den.load_state_dict(syn.denoiser_weights())
 vae = LADiffVae(ABL, **VAE_KW); vae.load_state_dict(syn.vae_weights(263))
 den, vae = den.to(dev).eval(), vae.to(dev).eval()
 NAMES = {0: "LIN", 1: "RED2", 2: "STYL", 3: "FFN", 4: "QKV", 5: "OUT", 6: "SKIP", 7: "TAIL"}
+# the library's measurement switches, from the environment (PACING=eighths,mask  THRESH=look_ahead_from,small_upto  XCD_LOCAL  STAGE_PLAN)
+L = _lib.lib()
+for env, fn in (("PACING", "ladiff_debug_set_pacing"), ("THRESH", "ladiff_debug_set_loop_thresholds")):
+    if env in os.environ: _lib.check(getattr(L, fn)(*[int(v) for v in os.environ[env].split(",")]))
+for env, fn in (("XCD_LOCAL", "ladiff_debug_set_xcd_local"), ("STAGE_PLAN", "ladiff_debug_set_stage_plan")):
+    if env in os.environ: _lib.check(getattr(L, fn)(int(os.environ[env])))
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 cases = [("mixed 256", syn.mixed_lengths(256), 7.5, 50, 6), ("mixed 1024", syn.mixed_lengths(1024), 7.5, 50, 3 if quick else 6),
          ("uniform 128", [196] * 128, 7.5, 50, 3), ("15-row tiles, 43 prompts", [196] * 43, 7.5, 20, 3),
@@ -39,7 +45,7 @@ for name, lens, guidance, steps, calls in cases:
         for _ in range(calls):
             z = pipe._diffusion_reverse(text, lens, init_noise=noise)
             torch.cuda.synchronize()
-            assert pipe.loop_status() == (0, 0) and pipe.last_loop()[0], (name, pipe.loop_status(), pipe.last_loop())
+            assert pipe.loop_status()[0] == 0 and pipe.last_loop()[0], (name, pipe.loop_status(), pipe.last_loop())
             first = z.clone() if first is None else first
             assert torch.equal(z, first), f"{name}: a call differs from the first"
             for plan in pipe._plans.values():
